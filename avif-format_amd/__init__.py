@@ -1,0 +1,197 @@
+"""ctypes binding of libavifgpu.so (C-ABI in include/avifgpu.h) for tests, smoke and bench.
+
+This package is plumbing: the product is the C-ABI shared library built from csrc/ (hand-written
+gfx950 HIP kernels + the C++ host shim).  Python never computes pixels here and there is no CPU
+fallback: `load()` raises if the library is missing, and `AvifGpu()` raises if no HIP device binds.
+
+The directory name contains a hyphen (it mirrors the reference repository's name), so import it
+through `importlib` -- see `__graft_entry__.load_package()`.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_void_p
+
+from . import sharding  # noqa: E402,F401  (row-tile partition used by bench.py / host shim tests)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libavifgpu.so")
+
+# ---- enums (include/avifgpu.h) ----------------------------------------------------------------
+TRANSFER_PQ, TRANSFER_HLG, TRANSFER_SMPTE428, TRANSFER_CLIP = 0, 1, 2, 3
+ALPHA_NONE, ALPHA_STRAIGHT, ALPHA_PREMULTIPLIED = 0, 1, 2
+COLORSPACE_YCBCR, COLORSPACE_RGB, COLORSPACE_MONOCHROME = 0, 1, 2
+CHROMA_MONOCHROME, CHROMA_420, CHROMA_422, CHROMA_444 = 0, 1, 2, 3
+MATRIX_RGB_GBR, MATRIX_BT709, MATRIX_UNSPECIFIED, MATRIX_FCC, MATRIX_BT470BG, MATRIX_BT601 = 0, 1, 2, 4, 5, 6
+MATRIX_SMPTE240M, MATRIX_YCGCO, MATRIX_BT2020_NCL, MATRIX_BT2020_CL, MATRIX_CHROMA_DERIVED_NCL = 7, 8, 9, 10, 12
+PRIMARIES_BT709, PRIMARIES_BT470M, PRIMARIES_BT470BG, PRIMARIES_BT601, PRIMARIES_BT2020 = 1, 4, 5, 6, 9
+PRIMARIES_SMPTE432 = 12
+TC_SRGB, TC_PQ, TC_SMPTE428, TC_HLG = 13, 16, 17, 18
+OUT_REFERENCE, OUT_YCBCR = 0, 1
+DOWNSAMPLE_AVERAGE, DOWNSAMPLE_NEAREST = 0, 1
+CHROMA_ZERO_LIBHEIF, CHROMA_ZERO_DECODER = 0, 1
+MEM_HOST, MEM_DEVICE = 0, 1
+
+noErr, userCanceledErr, readErr, writErr, memFullErr = 0, -128, -19, -20, -108
+formatBadParameters, formatCannotRead = -30500, -30501
+
+
+class WriteDesc(ctypes.Structure):
+    _fields_ = [(n, c_int32) for n in (
+        "width", "height", "depth", "planes", "bit_depth", "transfer", "peak_nits", "alpha_state",
+        "output", "chroma", "matrix_coefficients", "color_primaries", "full_range", "chroma_downsampling",
+        "chroma_zero_point", "reserved")]
+
+    def __init__(self, **kw):
+        super().__init__()
+        self.peak_nits = 80          # pqDefaultBrightness, reference AvifFormat.h:59
+        self.transfer = TRANSFER_CLIP
+        self.full_range = 1
+        self.chroma = CHROMA_444
+        self.matrix_coefficients = MATRIX_BT601
+        self.color_primaries = PRIMARIES_BT709
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise AttributeError(k)
+            setattr(self, k, v)
+
+
+class ReadDesc(ctypes.Structure):
+    _fields_ = [(n, c_int32) for n in (
+        "width", "height", "colorspace", "chroma", "bit_depth", "depth", "alpha_state", "has_nclx",
+        "color_primaries", "transfer_characteristics", "matrix_coefficients", "full_range_flag",
+        "pq_peak_nits", "hlg_apply_ootf")]
+    _fields_ += [("hlg_display_gamma", c_float), ("hlg_peak_nits", c_int32), ("reserved", c_int32 * 2)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        self.has_nclx = 1
+        self.color_primaries = PRIMARIES_BT709
+        self.transfer_characteristics = TC_SRGB
+        self.matrix_coefficients = MATRIX_BT601
+        self.full_range_flag = 1
+        self.pq_peak_nits = 80
+        self.hlg_apply_ootf = 0
+        self.hlg_display_gamma = 1.2   # reference AvifFormat.cpp:96-98 defaults
+        self.hlg_peak_nits = 1000
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise AttributeError(k)
+            setattr(self, k, v)
+
+
+_PLANES4 = c_void_p * 4
+_STRIDES4 = c_int64 * 4
+
+# every symbol include/avifgpu.h declares: (name, restype, argtypes)
+ABI = [
+    ("avifgpu_abi_version", c_int32, []),
+    ("avifgpu_init", c_int32, [c_int32]),
+    ("avifgpu_shutdown", None, []),
+    ("avifgpu_last_error", c_char_p, []),
+    ("avifgpu_write_rows", c_int32, [POINTER(WriteDesc), c_int32, c_int32, c_void_p, c_int64,
+                                     POINTER(_PLANES4), POINTER(_STRIDES4), c_int32, c_void_p]),
+    ("avifgpu_read_rows", c_int32, [POINTER(ReadDesc), c_int32, c_int32, POINTER(_PLANES4), POINTER(_STRIDES4),
+                                    c_void_p, c_int64, c_int32, c_void_p]),
+    ("avifgpu_get_yuv_coefficients", c_int32, [c_int32, c_int32, c_int32, POINTER(c_float * 3)]),
+    ("avifgpu_read_max_value", c_int32, [POINTER(ReadDesc)]),
+    ("avifgpu_write_plane_count", c_int32, [POINTER(WriteDesc)]),
+    ("avifgpu_write_plane_geometry", c_int32, [POINTER(WriteDesc), c_int32, POINTER(c_int32), POINTER(c_int32),
+                                               POINTER(c_int32), POINTER(c_int32)]),
+    ("avifgpu_write_algorithmic_bytes", c_int64, [POINTER(WriteDesc), c_int32]),
+    ("avifgpu_read_algorithmic_bytes", c_int64, [POINTER(ReadDesc), c_int32]),
+    ("avifgpu_last_kernel_name", c_char_p, []),
+]
+
+
+def bind(lib: ctypes.CDLL, table=ABI) -> ctypes.CDLL:
+    for name, res, args in table:
+        fn = getattr(lib, name)        # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libavifgpu.so (built in-tree by `make -C avif-format_amd`).  Fails loudly if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C avif-format_amd`.  There is no CPU fallback.")
+        _lib = bind(ctypes.CDLL(LIB_PATH))
+    return _lib
+
+
+class AvifGpuError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"OSErr {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+def planes4(ptrs):
+    arr = _PLANES4()
+    for i in range(4):
+        arr[i] = ptrs[i] if i < len(ptrs) and ptrs[i] else None
+    return arr
+
+
+def strides4(vals):
+    arr = _STRIDES4()
+    for i in range(4):
+        arr[i] = int(vals[i]) if i < len(vals) and vals[i] else 0
+    return arr
+
+
+class AvifGpu:
+    """One bound device.  Thin wrapper: raises AvifGpuError on any non-zero OSErr."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        code = self.lib.avifgpu_init(device)
+        if code != 0:
+            raise AvifGpuError(code, self.lib.avifgpu_last_error().decode())
+        self.device = device
+
+    def _check(self, code):
+        if code != 0:
+            raise AvifGpuError(code, self.lib.avifgpu_last_error().decode())
+
+    def write_rows(self, desc: WriteDesc, row0, nrows, src_ptr, src_row_bytes, dst_ptrs, dst_strides,
+                   mem=MEM_DEVICE, stream=0):
+        self._check(self.lib.avifgpu_write_rows(ctypes.byref(desc), row0, nrows, src_ptr, src_row_bytes,
+                                                ctypes.byref(planes4(dst_ptrs)), ctypes.byref(strides4(dst_strides)),
+                                                mem, stream or None))
+
+    def read_rows(self, desc: ReadDesc, row0, nrows, src_ptrs, src_strides, dst_ptr, dst_row_bytes,
+                  mem=MEM_DEVICE, stream=0):
+        self._check(self.lib.avifgpu_read_rows(ctypes.byref(desc), row0, nrows,
+                                               ctypes.byref(planes4(src_ptrs)), ctypes.byref(strides4(src_strides)),
+                                               dst_ptr, dst_row_bytes, mem, stream or None))
+
+    def last_kernel(self) -> str:
+        return self.lib.avifgpu_last_kernel_name().decode()
+
+    def write_plane_geometry(self, desc: WriteDesc, plane: int):
+        w, h, b, s = c_int32(), c_int32(), c_int32(), c_int32()
+        self._check(self.lib.avifgpu_write_plane_geometry(ctypes.byref(desc), plane, ctypes.byref(w), ctypes.byref(h),
+                                                          ctypes.byref(b), ctypes.byref(s)))
+        return w.value, h.value, b.value, s.value
+
+    def write_algorithmic_bytes(self, desc: WriteDesc, nrows: int) -> int:
+        return self.lib.avifgpu_write_algorithmic_bytes(ctypes.byref(desc), nrows)
+
+    def read_algorithmic_bytes(self, desc: ReadDesc, nrows: int) -> int:
+        return self.lib.avifgpu_read_algorithmic_bytes(ctypes.byref(desc), nrows)
+
+
+def yuv_coefficients(has_nclx: int, matrix: int, primaries: int):
+    out = (c_float * 3)()
+    load().avifgpu_get_yuv_coefficients(has_nclx, matrix, primaries, ctypes.byref(out))
+    return tuple(out)

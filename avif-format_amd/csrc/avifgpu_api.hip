@@ -1,0 +1,536 @@
+// avifgpu_api.hip -- the C-ABI of include/avifgpu.h: validation, nclx -> coefficients, staging, launches.
+//
+// There is no CPU fallback anywhere in this file: without a HIP device avifgpu_init fails and every
+// *_rows call returns an error.
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "../../include/avifgpu.h"
+#include "kernel_params.h"
+
+namespace avifgpu {
+hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16, int output, int xs, int ys,
+                        int variant, hipStream_t st, const char** name);
+hipError_t launch_read(const ReadParams& p, int colorspace, int depth, bool alpha, int xs, int ys,
+                       hipStream_t st, const char** name);
+}
+
+using namespace avifgpu;
+
+namespace {
+
+thread_local char g_err[512] = "";
+thread_local const char* g_kernel = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+struct Context {
+    std::mutex mu;
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    // device staging for AVIFGPU_MEM_HOST calls (grown on demand, reused across tiles)
+    void* d_in = nullptr;  size_t d_in_cap = 0;
+    void* d_out = nullptr; size_t d_out_cap = 0;
+    int hot_variant = kHotLdsTranspose;
+} g_ctx;
+
+int hip_fail(hipError_t e, const char* what, int code)
+{
+    return fail(code, "%s: %s", what, hipGetErrorString(e));
+}
+
+int ensure(void** p, size_t* cap, size_t need)
+{
+    if (need <= *cap) return 0;
+    if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+    const hipError_t e = hipMalloc(p, need);
+    if (e != hipSuccess) { *p = nullptr; return hip_fail(e, "hipMalloc(staging)", AVIFGPU_memFullErr); }
+    *cap = need;
+    return 0;
+}
+
+// ---- nclx -> (kr, kg, kb), the same derivation the plug-in performs (YUVCoefficiants.cpp:110-188) ----
+struct PrimariesRow { int code; float rX, rY, gX, gY, bX, bY, wX, wY; };
+const PrimariesRow kPrimariesRows[] = {              // ITU-T H.273 table 2 chromaticities (YUVCoefficiants.cpp:58-70)
+    { AVIFGPU_PRIMARIES_BT709,        0.64f,  0.33f,  0.3f,   0.6f,   0.15f,  0.06f,  0.3127f, 0.329f  },
+    { AVIFGPU_PRIMARIES_BT470M,       0.67f,  0.33f,  0.21f,  0.71f,  0.14f,  0.08f,  0.310f,  0.316f  },
+    { AVIFGPU_PRIMARIES_BT470BG,      0.64f,  0.33f,  0.29f,  0.60f,  0.15f,  0.06f,  0.3127f, 0.3290f },
+    { AVIFGPU_PRIMARIES_BT601,        0.630f, 0.340f, 0.310f, 0.595f, 0.155f, 0.070f, 0.3127f, 0.3290f },
+    { AVIFGPU_PRIMARIES_SMPTE240M,    0.630f, 0.340f, 0.310f, 0.595f, 0.155f, 0.070f, 0.3127f, 0.3290f },
+    { AVIFGPU_PRIMARIES_GENERIC_FILM, 0.681f, 0.319f, 0.243f, 0.692f, 0.145f, 0.049f, 0.310f,  0.316f  },
+    { AVIFGPU_PRIMARIES_BT2020,       0.708f, 0.292f, 0.170f, 0.797f, 0.131f, 0.046f, 0.3127f, 0.3290f },
+    { AVIFGPU_PRIMARIES_SMPTE428,     1.0f,   0.0f,   0.0f,   1.0f,   0.0f,   0.0f,   0.3333f, 0.3333f },
+    { AVIFGPU_PRIMARIES_SMPTE431,     0.680f, 0.320f, 0.265f, 0.690f, 0.150f, 0.060f, 0.314f,  0.351f  },
+    { AVIFGPU_PRIMARIES_SMPTE432,     0.680f, 0.320f, 0.265f, 0.690f, 0.150f, 0.060f, 0.3127f, 0.3290f },
+    { AVIFGPU_PRIMARIES_EBU3213,      0.630f, 0.340f, 0.295f, 0.605f, 0.155f, 0.077f, 0.3127f, 0.3290f },
+};
+
+bool kr_kb_from_nclx(int matrix, int primaries, float& kr, float& kb)
+{
+    switch (matrix) {                                 // H.273 table 4 (YUVCoefficiants.cpp:94-106)
+    case AVIFGPU_MATRIX_BT709:      kr = 0.2126f; kb = 0.0722f; return true;
+    case AVIFGPU_MATRIX_FCC:        kr = 0.30f;   kb = 0.11f;   return true;
+    case AVIFGPU_MATRIX_BT470BG:
+    case AVIFGPU_MATRIX_BT601:      kr = 0.299f;  kb = 0.114f;  return true;
+    case AVIFGPU_MATRIX_SMPTE240M:  kr = 0.212f;  kb = 0.087f;  return true;
+    case AVIFGPU_MATRIX_BT2020_NCL: kr = 0.2627f; kb = 0.0593f; return true;
+    case AVIFGPU_MATRIX_CHROMA_DERIVED_NCL: {
+        const PrimariesRow* pr = &kPrimariesRows[0]; // unknown primaries fall back to BT.709 (:88-90)
+        for (const PrimariesRow& row : kPrimariesRows) if (row.code == primaries) { pr = &row; break; }
+        const float rX = pr->rX, rY = pr->rY, gX = pr->gX, gY = pr->gY, bX = pr->bX, bY = pr->bY, wX = pr->wX, wY = pr->wY;
+        const float rZ = 1.0f - (rX + rY), gZ = 1.0f - (gX + gY), bZ = 1.0f - (bX + bY), wZ = 1.0f - (wX + wY);
+        const float den = wY * (rX * (gY * bZ - bY * gZ) + gX * (bY * rZ - rY * bZ) + bX * (rY * gZ - gY * rZ));
+        kr = (rY * (wX * (gY * bZ - bY * gZ) + wY * (bX * gZ - gX * bZ) + wZ * (gX * bY - bX * gY))) / den;   // H.273 eq. 32
+        kb = (bY * (wX * (rY * gZ - gY * rZ) + wY * (gX * rZ - rX * gZ) + wZ * (rX * gY - gX * rY))) / den;   // H.273 eq. 33
+        return true;
+    }
+    default: return false;
+    }
+}
+
+void yuv_coefficients(int has_nclx, int matrix, int primaries, float out[3])
+{
+    float kr = 0.299f, kb = 0.114f;                   // MIAF default, matrix_coefficients 5/6 (:169-174)
+    float kg = 1.0f - kr - kb;
+    float a, b;
+    if (has_nclx && kr_kb_from_nclx(matrix, primaries, a, b)) { kr = a; kb = b; kg = 1.0f - kr - kb; }
+    out[0] = kr; out[1] = kg; out[2] = kb;
+}
+
+bool chroma_shift(int chroma, int& xs, int& ys)
+{
+    switch (chroma) {
+    case AVIFGPU_CHROMA_444: xs = 0; ys = 0; return true;
+    case AVIFGPU_CHROMA_422: xs = 1; ys = 0; return true;
+    case AVIFGPU_CHROMA_420: xs = 1; ys = 1; return true;
+    default: xs = 0; ys = 0; return false;
+    }
+}
+
+// ---- write-side validation (same rules as the plug-in's option fix-ups and default branches) --------
+struct WriteGeom { bool color, alpha, dst16; int xs, ys, nplanes; };
+
+int check_write(const avifgpu_write_desc* d, int row0, int nrows, WriteGeom& g)
+{
+    if (!d) return fail(AVIFGPU_formatBadParameters, "null descriptor");
+    if (d->width <= 0 || d->height <= 0) return fail(AVIFGPU_formatBadParameters, "bad image size %dx%d", d->width, d->height);
+    if (row0 < 0 || nrows < 0 || (int64_t)row0 + nrows > d->height) return fail(AVIFGPU_formatBadParameters, "rows [%d,%d) outside image", row0, row0 + nrows);
+    if (d->depth != 8 && d->depth != 16 && d->depth != 32) return fail(AVIFGPU_formatBadParameters, "unsupported depth %d", d->depth);   // Write.cpp:318
+    if (d->planes < 1 || d->planes > 4) return fail(AVIFGPU_formatBadParameters, "unsupported plane count %d", d->planes);
+    if (d->bit_depth != 8 && d->bit_depth != 10 && d->bit_depth != 12) return fail(AVIFGPU_formatCannotRead, "unsupported image bit depth %d", d->bit_depth); // WriteHeifImage.cpp:57
+    if (d->depth == 32 && d->bit_depth == 8) return fail(AVIFGPU_formatCannotRead, "32-bit documents save as 10 or 12 bit");
+    g.color = d->planes >= 3;
+    g.alpha = (d->planes == 2 || d->planes == 4);
+    if (g.alpha != (d->alpha_state != AVIFGPU_ALPHA_NONE)) return fail(AVIFGPU_formatBadParameters, "alpha_state does not match planes");
+    if (d->alpha_state < AVIFGPU_ALPHA_NONE || d->alpha_state > AVIFGPU_ALPHA_PREMULTIPLIED) return fail(AVIFGPU_formatBadParameters, "bad alpha_state");
+    g.dst16 = d->bit_depth > 8;
+    g.xs = g.ys = 0;
+    if (d->depth == 32) {
+        if (d->transfer < AVIFGPU_TRANSFER_PQ || d->transfer > AVIFGPU_TRANSFER_CLIP) return fail(AVIFGPU_writErr, "Unsupported color transfer function.");
+        if (!g.color && d->transfer != AVIFGPU_TRANSFER_PQ && d->transfer != AVIFGPU_TRANSFER_CLIP)
+            return fail(AVIFGPU_writErr, "Unsupported color transfer function.");                                  // WriteHeifImage.cpp:581-582
+        if (d->transfer == AVIFGPU_TRANSFER_PQ && (d->peak_nits < 1 || d->peak_nits > 10000))
+            return fail(AVIFGPU_formatBadParameters, "nominalPeakBrightness %d outside [1,10000]", d->peak_nits); // AvifFormat.h:52-53
+    }
+    if (d->output == AVIFGPU_OUT_REFERENCE) {
+        g.nplanes = g.color ? 1 : (g.alpha ? 2 : 1);
+        return 0;
+    }
+    if (d->output != AVIFGPU_OUT_YCBCR) return fail(AVIFGPU_formatBadParameters, "bad output kind %d", d->output);
+    if (!g.color) return fail(AVIFGPU_formatBadParameters, "YCbCr output needs an RGB source");
+    if (!chroma_shift(d->chroma, g.xs, g.ys)) return fail(AVIFGPU_formatBadParameters, "bad chroma %d", d->chroma);
+    if (!d->full_range) return fail(AVIFGPU_formatBadParameters, "limited-range output is not produced by the plug-in (full_range_flag is always set)");
+    if (d->chroma_downsampling != AVIFGPU_DOWNSAMPLE_AVERAGE && d->chroma_downsampling != AVIFGPU_DOWNSAMPLE_NEAREST)
+        return fail(AVIFGPU_formatBadParameters, "bad chroma_downsampling");
+    if (d->chroma_zero_point != AVIFGPU_CHROMA_ZERO_LIBHEIF && d->chroma_zero_point != AVIFGPU_CHROMA_ZERO_DECODER)
+        return fail(AVIFGPU_formatBadParameters, "bad chroma_zero_point");
+    if (g.ys && (row0 & 1)) return fail(AVIFGPU_formatBadParameters, "4:2:0 tiles must start on an even row");
+    if (g.ys && (nrows & 1) && row0 + nrows != d->height) return fail(AVIFGPU_formatBadParameters, "4:2:0 tiles must have even height unless they end the image");
+    g.nplanes = g.alpha ? 4 : 3;
+    return 0;
+}
+
+int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const WriteGeom& g, WriteParams& p)
+{
+    memset(&p, 0, sizeof(p));
+    p.width = d->width; p.nrows = nrows; p.rows_to_end = d->height - row0;
+    p.transfer = d->depth == 32 ? d->transfer : AVIFGPU_TRANSFER_CLIP;
+    p.premultiply = d->alpha_state == AVIFGPU_ALPHA_PREMULTIPLIED;
+    p.nearest = d->chroma_downsampling == AVIFGPU_DOWNSAMPLE_NEAREST;
+    p.maxv = (1 << d->bit_depth) - 1;
+    p.maxf = (float)p.maxv;
+    p.pq_mult = (float)d->peak_nits / 10000.0f;          // ColorTransfer.cpp:86
+    p.half = d->chroma_zero_point == AVIFGPU_CHROMA_ZERO_DECODER ? p.maxf * 0.5f : (float)(1 << (d->bit_depth - 1));
+    if (d->output == AVIFGPU_OUT_YCBCR) {
+        if (d->matrix_coefficients == AVIFGPU_MATRIX_RGB_GBR) {       // lossless, WriteMetadata.cpp:143-146
+            if (d->chroma != AVIFGPU_CHROMA_444) return fail(AVIFGPU_formatBadParameters, "identity (GBR) matrix requires 4:4:4");
+            p.identity = 1;
+        } else {
+            float kr, kb;
+            if (!kr_kb_from_nclx(d->matrix_coefficients, d->color_primaries, kr, kb))
+                return fail(AVIFGPU_formatBadParameters, "matrix_coefficients %d has no Kr/Kb form", d->matrix_coefficients);
+            const float kg = 1.0f - kr - kb;
+            p.my[0] = kr;                        p.my[1] = kg;                        p.my[2] = kb;
+            p.mcb[0] = -kr / (1.0f - kb) / 2.0f; p.mcb[1] = -kg / (1.0f - kb) / 2.0f; p.mcb[2] = 0.5f;
+            p.mcr[0] = 0.5f;                     p.mcr[1] = -kg / (1.0f - kr) / 2.0f; p.mcr[2] = -kb / (1.0f - kr) / 2.0f;
+        }
+    }
+    (void)g;
+    return 0;
+}
+
+// plane -> (rows in this tile, bytes per row actually written)
+void write_plane_extent(const avifgpu_write_desc* d, const WriteGeom& g, int plane, int nrows, int& rows, int64_t& row_bytes)
+{
+    const int ssz = g.dst16 ? 2 : 1;
+    if (d->output == AVIFGPU_OUT_REFERENCE && g.color) { rows = nrows; row_bytes = (int64_t)d->width * d->planes * ssz; return; }
+    if (d->output == AVIFGPU_OUT_YCBCR && (plane == 1 || plane == 2)) {
+        rows = (nrows + g.ys) >> g.ys; row_bytes = (int64_t)((d->width + g.xs) >> g.xs) * ssz; return;
+    }
+    rows = nrows; row_bytes = (int64_t)d->width * ssz;
+}
+
+bool write_plane_used(const avifgpu_write_desc* d, const WriteGeom& g, int plane)
+{
+    if (d->output == AVIFGPU_OUT_REFERENCE) return g.color ? plane == 0 : (plane == 0 || (plane == 3 && g.alpha));
+    return plane < 3 || g.alpha;
+}
+
+// ---- read-side validation (runtime_error / OSErr conditions of ReadHeifImage.cpp) --------------------
+struct ReadGeom { int xs, ys, nch, transfer; bool alpha; };
+
+int transfer_from_tc(int tc)
+{
+    switch (tc) {                                       // ColorTransfer.cpp:47-67
+    case AVIFGPU_TC_PQ: return AVIFGPU_TRANSFER_PQ;
+    case AVIFGPU_TC_HLG: return AVIFGPU_TRANSFER_HLG;
+    case AVIFGPU_TC_SMPTE428: return AVIFGPU_TRANSFER_SMPTE428;
+    default: return -1;
+    }
+}
+
+int check_read(const avifgpu_read_desc* d, int row0, int nrows, ReadGeom& g)
+{
+    if (!d) return fail(AVIFGPU_formatBadParameters, "null descriptor");
+    if (d->width <= 0 || d->height <= 0) return fail(AVIFGPU_formatBadParameters, "bad image size");
+    if (row0 < 0 || nrows < 0 || (int64_t)row0 + nrows > d->height) return fail(AVIFGPU_formatBadParameters, "rows outside image");
+    if (d->depth != 8 && d->depth != 16 && d->depth != 32) return fail(AVIFGPU_formatBadParameters, "unsupported host depth %d", d->depth);
+    if (d->bit_depth != 8 && d->bit_depth != 10 && d->bit_depth != 12 && d->bit_depth != 16)
+        return fail(AVIFGPU_readErr, "The image has an unsupported bit depth, must be 8, 10, 12 or 16.");           // YuvLookupTables.cpp:118-124
+    if ((d->depth == 8) != (d->bit_depth == 8)) return fail(AVIFGPU_readErr, "host depth %d cannot carry %d-bit planes", d->depth, d->bit_depth);
+    if (d->colorspace != AVIFGPU_COLORSPACE_YCBCR && d->colorspace != AVIFGPU_COLORSPACE_RGB && d->colorspace != AVIFGPU_COLORSPACE_MONOCHROME)
+        return fail(AVIFGPU_readErr, "Unsupported image color space, expected RGB.");                               // ReadHeifImage.cpp:575-578
+    if (d->alpha_state < AVIFGPU_ALPHA_NONE || d->alpha_state > AVIFGPU_ALPHA_PREMULTIPLIED) return fail(AVIFGPU_formatBadParameters, "bad alpha_state");
+    g.alpha = d->alpha_state != AVIFGPU_ALPHA_NONE;
+    g.xs = g.ys = 0; g.transfer = AVIFGPU_TRANSFER_PQ;
+    const bool mono = d->colorspace == AVIFGPU_COLORSPACE_MONOCHROME;
+    g.nch = (mono ? 1 : 3) + (g.alpha ? 1 : 0);
+    if (d->colorspace == AVIFGPU_COLORSPACE_YCBCR) {
+        chroma_shift(d->chroma, g.xs, g.ys);            // GetChromaShift: anything else -> (0,0), ReadHeifImage.cpp:52-81
+        if (g.ys && (row0 & 1)) return fail(AVIFGPU_formatBadParameters, "4:2:0 tiles must start on an even row");
+    }
+    if (d->depth == 32) {
+        if (!d->has_nclx) return fail(AVIFGPU_readErr, "The nclxProfile is null.");                                 // ReadHeifImage.cpp:870-873, :956-959
+        g.transfer = transfer_from_tc(d->transfer_characteristics);
+        if (g.transfer < 0) return fail(AVIFGPU_readErr, "Unsupported NCLX transfer characteristic.");             // ColorTransfer.cpp:63
+        if (mono && g.transfer != AVIFGPU_TRANSFER_PQ) return fail(AVIFGPU_readErr, "Unsupported color transfer function."); // YuvDecode.cpp:219-220
+        if (g.transfer == AVIFGPU_TRANSFER_PQ && d->pq_peak_nits < 1) return fail(AVIFGPU_formatBadParameters, "bad pq_peak_nits");
+    }
+    return 0;
+}
+
+int fill_read_params(const avifgpu_read_desc* d, int nrows, const ReadGeom& g, ReadParams& p)
+{
+    memset(&p, 0, sizeof(p));
+    p.width = d->width; p.nrows = nrows; p.bits = d->bit_depth; p.maxc = (1 << d->bit_depth) - 1;
+    p.full_range = d->has_nclx ? (d->full_range_flag != 0) : 1;                                                    // YuvLookupTables.cpp:140
+    const int matrix = d->has_nclx ? d->matrix_coefficients : AVIFGPU_MATRIX_BT601;                                // :141
+    p.identity_lut = (d->colorspace == AVIFGPU_COLORSPACE_YCBCR) && matrix == AVIFGPU_MATRIX_RGB_GBR;              // :145
+    p.premultiplied = d->alpha_state == AVIFGPU_ALPHA_PREMULTIPLIED;
+    p.transfer = g.transfer;
+    float k[3]; yuv_coefficients(d->has_nclx, d->matrix_coefficients, d->color_primaries, k);
+    p.kr = k[0]; p.kg = k[1]; p.kb = k[2];
+    if (d->depth == 32) {
+        p.pq_mult = 10000.0f / (float)(d->pq_peak_nits > 0 ? d->pq_peak_nits : 1);                                 // ColorTransfer.cpp:114
+        p.hlg_ootf = d->hlg_apply_ootf != 0;
+        p.hlg_gamma_m1 = d->hlg_display_gamma - 1.0f;
+        p.hlg_peak = (float)d->hlg_peak_nits;
+        if (g.transfer == AVIFGPU_TRANSFER_HLG && p.hlg_ootf && d->colorspace != AVIFGPU_COLORSPACE_MONOCHROME) {
+            switch (d->color_primaries) {               // GetHLGLumaCoefficients, ColorTransfer.cpp:31-45
+            case AVIFGPU_PRIMARIES_BT709:  p.hlg_luma[0] = 0.2126f; p.hlg_luma[1] = 0.7152f; p.hlg_luma[2] = 0.0722f; break;
+            case AVIFGPU_PRIMARIES_BT470BG:
+            case AVIFGPU_PRIMARIES_BT601:  p.hlg_luma[0] = 0.299f;  p.hlg_luma[1] = 0.587f;  p.hlg_luma[2] = 0.114f;  break;
+            case AVIFGPU_PRIMARIES_BT2020: p.hlg_luma[0] = 0.2627f; p.hlg_luma[1] = 0.6780f; p.hlg_luma[2] = 0.0593f; break;
+            default: return fail(AVIFGPU_readErr, "Unsupported color primaries for the HLG Luma Coefficients ");
+            }
+        }
+    }
+    return 0;
+}
+
+bool read_plane_used(const avifgpu_read_desc* d, const ReadGeom& g, int plane)
+{
+    if (plane == 3) return g.alpha;
+    if (d->colorspace == AVIFGPU_COLORSPACE_MONOCHROME) return plane == 0;
+    return true;
+}
+
+void read_plane_extent(const avifgpu_read_desc* d, const ReadGeom& g, int plane, int nrows, int& rows, int64_t& row_bytes)
+{
+    const int ssz = d->bit_depth > 8 ? 2 : 1;
+    if (d->colorspace == AVIFGPU_COLORSPACE_YCBCR && (plane == 1 || plane == 2)) {
+        rows = (nrows + g.ys) >> g.ys; row_bytes = (int64_t)((d->width + g.xs) >> g.xs) * ssz; return;
+    }
+    rows = nrows; row_bytes = (int64_t)d->width * ssz;
+}
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+} // namespace
+
+// ======================================================================================================
+extern "C" {
+
+int32_t avifgpu_abi_version(void) { return AVIFGPU_ABI_VERSION; }
+
+const char* avifgpu_last_error(void) { return g_err; }
+const char* avifgpu_last_kernel_name(void) { return g_kernel; }
+
+int32_t avifgpu_init(int32_t device_index)
+{
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(AVIFGPU_formatBadParameters, "no HIP device available (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device_index < 0 || device_index >= n) return fail(AVIFGPU_formatBadParameters, "device %d out of range [0,%d)", device_index, n);
+    if (g_ctx.ready && g_ctx.device == device_index) return 0;
+    if ((e = hipSetDevice(device_index)) != hipSuccess) return hip_fail(e, "hipSetDevice", AVIFGPU_formatBadParameters);
+    if (!g_ctx.stream && (e = hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking)) != hipSuccess)
+        return hip_fail(e, "hipStreamCreate", AVIFGPU_memFullErr);
+    g_ctx.device = device_index;
+    g_ctx.ready = true;
+    if (const char* v = getenv("AVIFGPU_HOT_VARIANT")) g_ctx.hot_variant = atoi(v);
+    return 0;
+}
+
+void avifgpu_shutdown(void)
+{
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    if (!g_ctx.ready) return;
+    (void)hipStreamSynchronize(g_ctx.stream);
+    if (g_ctx.d_in) (void)hipFree(g_ctx.d_in);
+    if (g_ctx.d_out) (void)hipFree(g_ctx.d_out);
+    (void)hipStreamDestroy(g_ctx.stream);
+    g_ctx.d_in = g_ctx.d_out = nullptr; g_ctx.d_in_cap = g_ctx.d_out_cap = 0;
+    g_ctx.stream = nullptr; g_ctx.ready = false; g_ctx.device = -1;
+}
+
+int32_t avifgpu_get_yuv_coefficients(int32_t has_nclx, int32_t matrix_coefficients, int32_t color_primaries, float out[3])
+{
+    if (!out) return fail(AVIFGPU_formatBadParameters, "null output");
+    yuv_coefficients(has_nclx, matrix_coefficients, color_primaries, out);
+    return 0;
+}
+
+int32_t avifgpu_read_max_value(const avifgpu_read_desc* d)
+{
+    if (!d) return 0;
+    if (d->colorspace == AVIFGPU_COLORSPACE_RGB) return (1 << d->bit_depth) - 1;        // ReadHeifImage.cpp:744-747
+    return 32768;                                                                     // :206, :499
+}
+
+int32_t avifgpu_write_plane_count(const avifgpu_write_desc* d)
+{
+    WriteGeom g;
+    if (check_write(d, 0, 0, g)) return 0;
+    return g.nplanes;
+}
+
+int32_t avifgpu_write_plane_geometry(const avifgpu_write_desc* d, int32_t plane, int32_t* width, int32_t* height,
+                                     int32_t* bytes_per_sample, int32_t* samples_per_pixel)
+{
+    WriteGeom g;
+    const int err = check_write(d, 0, 0, g);
+    if (err) return err;
+    if (plane < 0 || plane > 3 || !write_plane_used(d, g, plane)) return fail(AVIFGPU_formatBadParameters, "plane %d not produced", plane);
+    const bool chroma = d->output == AVIFGPU_OUT_YCBCR && (plane == 1 || plane == 2);
+    if (width) *width = chroma ? (d->width + g.xs) >> g.xs : d->width;
+    if (height) *height = chroma ? (d->height + g.ys) >> g.ys : d->height;
+    if (bytes_per_sample) *bytes_per_sample = g.dst16 ? 2 : 1;
+    if (samples_per_pixel) *samples_per_pixel = (d->output == AVIFGPU_OUT_REFERENCE && g.color) ? d->planes : 1;
+    return 0;
+}
+
+int64_t avifgpu_write_algorithmic_bytes(const avifgpu_write_desc* d, int32_t nrows)
+{
+    WriteGeom g;
+    if (check_write(d, 0, 0, g)) return 0;
+    int64_t total = (int64_t)nrows * d->width * d->planes * (d->depth / 8);
+    for (int pl = 0; pl < 4; ++pl) {
+        if (!write_plane_used(d, g, pl)) continue;
+        int rows; int64_t rb; write_plane_extent(d, g, pl, nrows, rows, rb);
+        total += rows * rb;
+    }
+    return total;
+}
+
+int64_t avifgpu_read_algorithmic_bytes(const avifgpu_read_desc* d, int32_t nrows)
+{
+    ReadGeom g;
+    if (check_read(d, 0, 0, g)) return 0;
+    int64_t total = (int64_t)nrows * d->width * g.nch * (d->depth / 8);
+    for (int pl = 0; pl < 4; ++pl) {
+        if (!read_plane_used(d, g, pl)) continue;
+        int rows; int64_t rb; read_plane_extent(d, g, pl, nrows, rows, rb);
+        total += rows * rb;
+    }
+    return total;
+}
+
+int32_t avifgpu_write_rows(const avifgpu_write_desc* d, int32_t row0, int32_t nrows,
+                           const void* src, int64_t src_row_bytes,
+                           void* const dst[4], const int64_t dst_stride[4],
+                           int32_t mem_kind, void* stream)
+{
+    g_err[0] = 0;
+    WriteGeom g;
+    int err = check_write(d, row0, nrows, g);
+    if (err) return err;
+    if (!src || !dst || !dst_stride) return fail(AVIFGPU_formatBadParameters, "null buffer");
+    const int64_t min_src_row = (int64_t)d->width * d->planes * (d->depth / 8);
+    if (src_row_bytes < min_src_row) return fail(AVIFGPU_formatBadParameters, "src_row_bytes %lld < %lld", (long long)src_row_bytes, (long long)min_src_row);
+    for (int pl = 0; pl < 4; ++pl) {
+        if (!write_plane_used(d, g, pl)) continue;
+        int rows; int64_t rb; write_plane_extent(d, g, pl, nrows, rows, rb);
+        if (!dst[pl]) return fail(AVIFGPU_formatBadParameters, "destination plane %d is null", pl);
+        if (dst_stride[pl] < rb) return fail(AVIFGPU_formatBadParameters, "dst_stride[%d] %lld < %lld", pl, (long long)dst_stride[pl], (long long)rb);
+    }
+    if (!g_ctx.ready) return fail(AVIFGPU_formatBadParameters, "avifgpu_init has not succeeded: no HIP device bound (no CPU fallback)");
+    if (nrows == 0) return 0;
+
+    WriteParams p;
+    if ((err = fill_write_params(d, row0, nrows, g, p))) return err;
+
+    if (mem_kind == AVIFGPU_MEM_DEVICE) {
+        hipStream_t st = stream ? (hipStream_t)stream : g_ctx.stream;
+        p.src = (const uint8_t*)src; p.src_row_bytes = src_row_bytes;
+        for (int pl = 0; pl < 4; ++pl) { p.dst[pl] = (uint8_t*)dst[pl]; p.dst_stride[pl] = dst_stride[pl]; }
+        const hipError_t e = launch_write(p, d->depth, d->planes, g.dst16, d->output, g.xs, g.ys, g_ctx.hot_variant, st, &g_kernel);
+        if (e != hipSuccess) return hip_fail(e, "kernel launch", AVIFGPU_writErr);
+        return 0;
+    }
+    if (mem_kind != AVIFGPU_MEM_HOST) return fail(AVIFGPU_formatBadParameters, "bad mem_kind %d", mem_kind);
+
+    // ---- host buffers: stage tile in, convert, stage planes out (synchronous, like the reference call) ----
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    hipStream_t st = g_ctx.stream;
+    const size_t in_pitch = align256((size_t)min_src_row);
+    if ((err = ensure(&g_ctx.d_in, &g_ctx.d_in_cap, in_pitch * (size_t)nrows))) return err;
+    size_t off[4] = {0, 0, 0, 0}, pitch[4] = {0, 0, 0, 0}, out_total = 0;
+    int prow[4] = {0, 0, 0, 0}; int64_t pbytes[4] = {0, 0, 0, 0};
+    for (int pl = 0; pl < 4; ++pl) {
+        if (!write_plane_used(d, g, pl)) continue;
+        write_plane_extent(d, g, pl, nrows, prow[pl], pbytes[pl]);
+        pitch[pl] = align256((size_t)pbytes[pl]);
+        off[pl] = out_total;
+        out_total += pitch[pl] * (size_t)prow[pl];
+    }
+    if ((err = ensure(&g_ctx.d_out, &g_ctx.d_out_cap, out_total))) return err;
+    hipError_t e = hipMemcpy2DAsync(g_ctx.d_in, in_pitch, src, (size_t)src_row_bytes, (size_t)min_src_row, (size_t)nrows, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return hip_fail(e, "H2D copy", AVIFGPU_writErr);
+    p.src = (const uint8_t*)g_ctx.d_in; p.src_row_bytes = (int64_t)in_pitch;
+    for (int pl = 0; pl < 4; ++pl) {
+        p.dst[pl] = write_plane_used(d, g, pl) ? (uint8_t*)g_ctx.d_out + off[pl] : nullptr;
+        p.dst_stride[pl] = (int64_t)pitch[pl];
+    }
+    e = launch_write(p, d->depth, d->planes, g.dst16, d->output, g.xs, g.ys, g_ctx.hot_variant, st, &g_kernel);
+    if (e != hipSuccess) return hip_fail(e, "kernel launch", AVIFGPU_writErr);
+    for (int pl = 0; pl < 4; ++pl) {
+        if (!write_plane_used(d, g, pl)) continue;
+        e = hipMemcpy2DAsync(dst[pl], (size_t)dst_stride[pl], (uint8_t*)g_ctx.d_out + off[pl], pitch[pl], (size_t)pbytes[pl], (size_t)prow[pl], hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) return hip_fail(e, "D2H copy", AVIFGPU_writErr);
+    }
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "stream synchronize", AVIFGPU_writErr);
+    return 0;
+}
+
+int32_t avifgpu_read_rows(const avifgpu_read_desc* d, int32_t row0, int32_t nrows,
+                          const void* const src[4], const int64_t src_stride[4],
+                          void* dst, int64_t dst_row_bytes,
+                          int32_t mem_kind, void* stream)
+{
+    g_err[0] = 0;
+    ReadGeom g;
+    int err = check_read(d, row0, nrows, g);
+    if (err) return err;
+    if (!src || !src_stride || !dst) return fail(AVIFGPU_formatBadParameters, "null buffer");
+    const int64_t min_dst_row = (int64_t)d->width * g.nch * (d->depth / 8);
+    if (min_dst_row > 0x7fffffffLL) return fail(AVIFGPU_memFullErr, "rowBytes exceeds int32");                      // SetupFormatRecord, ReadHeifImage.cpp:40-47
+    if (dst_row_bytes < min_dst_row) return fail(AVIFGPU_formatBadParameters, "dst_row_bytes too small");
+    for (int pl = 0; pl < 4; ++pl) {
+        if (!read_plane_used(d, g, pl)) continue;
+        int rows; int64_t rb; read_plane_extent(d, g, pl, nrows, rows, rb);
+        if (!src[pl]) return fail(AVIFGPU_formatBadParameters, "source plane %d is null", pl);
+        if (src_stride[pl] < rb) return fail(AVIFGPU_formatBadParameters, "src_stride[%d] too small", pl);
+    }
+    if (!g_ctx.ready) return fail(AVIFGPU_formatBadParameters, "avifgpu_init has not succeeded: no HIP device bound (no CPU fallback)");
+    if (nrows == 0) return 0;
+
+    ReadParams p;
+    if ((err = fill_read_params(d, nrows, g, p))) return err;
+
+    if (mem_kind == AVIFGPU_MEM_DEVICE) {
+        hipStream_t st = stream ? (hipStream_t)stream : g_ctx.stream;
+        for (int pl = 0; pl < 4; ++pl) { p.src[pl] = (const uint8_t*)src[pl]; p.src_stride[pl] = src_stride[pl]; }
+        p.dst = (uint8_t*)dst; p.dst_row_bytes = dst_row_bytes;
+        const hipError_t e = launch_read(p, d->colorspace, d->depth, g.alpha, g.xs, g.ys, st, &g_kernel);
+        if (e != hipSuccess) return hip_fail(e, "kernel launch", AVIFGPU_readErr);
+        return 0;
+    }
+    if (mem_kind != AVIFGPU_MEM_HOST) return fail(AVIFGPU_formatBadParameters, "bad mem_kind %d", mem_kind);
+
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    hipStream_t st = g_ctx.stream;
+    size_t off[4] = {0, 0, 0, 0}, pitch[4] = {0, 0, 0, 0}, in_total = 0;
+    int prow[4] = {0, 0, 0, 0}; int64_t pbytes[4] = {0, 0, 0, 0};
+    for (int pl = 0; pl < 4; ++pl) {
+        if (!read_plane_used(d, g, pl)) continue;
+        read_plane_extent(d, g, pl, nrows, prow[pl], pbytes[pl]);
+        pitch[pl] = align256((size_t)pbytes[pl]);
+        off[pl] = in_total;
+        in_total += pitch[pl] * (size_t)prow[pl];
+    }
+    if ((err = ensure(&g_ctx.d_in, &g_ctx.d_in_cap, in_total))) return err;
+    const size_t out_pitch = align256((size_t)min_dst_row);
+    if ((err = ensure(&g_ctx.d_out, &g_ctx.d_out_cap, out_pitch * (size_t)nrows))) return err;
+    hipError_t e;
+    for (int pl = 0; pl < 4; ++pl) {
+        if (!read_plane_used(d, g, pl)) continue;
+        e = hipMemcpy2DAsync((uint8_t*)g_ctx.d_in + off[pl], pitch[pl], src[pl], (size_t)src_stride[pl], (size_t)pbytes[pl], (size_t)prow[pl], hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return hip_fail(e, "H2D copy", AVIFGPU_readErr);
+        p.src[pl] = (const uint8_t*)g_ctx.d_in + off[pl]; p.src_stride[pl] = (int64_t)pitch[pl];
+    }
+    p.dst = (uint8_t*)g_ctx.d_out; p.dst_row_bytes = (int64_t)out_pitch;
+    e = launch_read(p, d->colorspace, d->depth, g.alpha, g.xs, g.ys, st, &g_kernel);
+    if (e != hipSuccess) return hip_fail(e, "kernel launch", AVIFGPU_readErr);
+    e = hipMemcpy2DAsync(dst, (size_t)dst_row_bytes, g_ctx.d_out, out_pitch, (size_t)min_dst_row, (size_t)nrows, hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return hip_fail(e, "D2H copy", AVIFGPU_readErr);
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "stream synchronize", AVIFGPU_readErr);
+    return 0;
+}
+
+} // extern "C"

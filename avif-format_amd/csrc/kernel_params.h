@@ -1,0 +1,54 @@
+// kernel_params.h -- POD argument blocks handed to the gfx950 kernels (by value, in SGPRs/kernarg).
+// Host-side validation and coefficient derivation live in avifgpu_api.hip; the kernels trust these.
+#pragma once
+#include <stdint.h>
+
+namespace avifgpu {
+
+// Tuning variant of the dominant kernel (RGB f32 -> PQ -> YCbCr 4:4:4 u16); see write_kernels.hip.
+enum HotVariant : int {
+    kHotGeneric      = 0,   // generic per-thread 48-B strided loads
+    kHotLdsTranspose = 1,   // coalesced dwordx4 loads, per-wave LDS transpose (conflict-free 12-dword stride)
+};
+
+struct WriteParams {
+    const uint8_t* src;          // row `row0`, interleaved
+    int64_t        src_row_bytes;
+    uint8_t*       dst[4];       // plane pointers at row row0 (chroma: row0 >> ys)
+    int64_t        dst_stride[4];
+    int32_t width;
+    int32_t nrows;               // rows in this tile
+    int32_t rows_to_end;         // height - row0 (bottom-edge replication uses the IMAGE edge)
+    int32_t transfer;            // AVIFGPU_TRANSFER_*
+    int32_t premultiply;         // alpha_state == Premultiplied
+    int32_t nearest;             // chroma_downsampling == NEAREST
+    int32_t identity;            // matrix == GBR
+    int32_t maxv;                // 2^bits - 1
+    float   maxf;
+    float   pq_mult;             // peak_nits / 10000 (ColorTransfer.cpp:86)
+    float   my[3], mcb[3], mcr[3];
+    float   half;                // 1 << (bits-1)
+};
+
+struct ReadParams {
+    const uint8_t* src[4];       // Y,Cb,Cr,A / R,G,B,A / Y,-,-,A at row row0 (chroma: row0 >> ys)
+    int64_t        src_stride[4];
+    uint8_t*       dst;
+    int64_t        dst_row_bytes;
+    int32_t width;
+    int32_t nrows;
+    int32_t bits;                // 8 | 10 | 12 | 16
+    int32_t maxc;                // 2^bits - 1
+    int32_t full_range;          // effective (nclx ? flag : 1)
+    int32_t identity_lut;        // colour image with GBR matrix: T_UV = T_Y (YuvLookupTables.cpp:177-180)
+    int32_t premultiplied;
+    int32_t transfer;            // AVIFGPU_TRANSFER_* (depth 32)
+    float   kr, kg, kb;
+    float   pq_mult;             // 10000 / peak (ColorTransfer.cpp:114)
+    int32_t hlg_ootf;
+    float   hlg_gamma_m1;        // displayGamma - 1
+    float   hlg_peak;
+    float   hlg_luma[3];
+};
+
+} // namespace avifgpu

@@ -1,0 +1,339 @@
+// read_kernels.hip -- heif_image planes -> FormatRecord rows, gfx950 (CDNA4) kernels.
+//
+// Replaces the row loops of ReadHeifImage{Gray,RGB}{Eight,Sixteen,ThirtyTwo}Bit
+// (reference src/common/ReadHeifImage.cpp:83-1178) together with the twelve Decode*Row* kernels
+// (reference src/common/YuvDecode.cpp:55-696) and the unorm->float tables they consume
+// (reference src/common/YuvLookupTables.cpp:115-192).
+//
+// Same work shape as the write kernels (streaming, HBM-bound): one thread owns 4 << XS adjacent pixels on
+// 1 << YS rows = the footprint of 4 chroma samples, so each chroma sample is fetched once, every plane load
+// is one aligned 4/8/16-byte vector and the interleaved host row is written as whole dwordx4/x2 vectors.
+// The reference's tables (<= 3 x 4096 floats up to 12 bit) are rebuilt per workgroup in LDS with the same
+// IEEE operations and gathered with ds_read_b32; 16-bit images evaluate the table formula per sample.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include "kernel_params.h"
+#include "device_math.h"
+#include "../../include/avifgpu.h"
+
+#pragma clang fp contract(off)
+
+namespace avifgpu {
+
+// avifLimitedToFullY / UV, reference YuvLookupTables.cpp:52-109.
+// Depth 16 overflows int32 in the reference for v > 33791 (UB; wraps in the shipped build): the wrap is made
+// explicit with unsigned arithmetic so CPU oracle and GPU agree.
+AG_DEV int lim2full(int v, int lo, int hi, int full)
+{
+    v = (int)(((unsigned)(v - lo) * (unsigned)full) + (unsigned)((hi - lo) / 2)) / (hi - lo);
+    return v > full ? full : (v < 0 ? 0 : v);
+}
+AG_DEV int lim2full_y(int bits, int v)
+{
+    switch (bits) {
+    case 8:  return lim2full(v, 16, 235, 255);
+    case 10: return lim2full(v, 64, 940, 1023);
+    case 12: return lim2full(v, 256, 3760, 4095);
+    default: return lim2full(v, 1024, 60160, 65535);
+    }
+}
+AG_DEV int lim2full_uv(int bits, int v)
+{
+    switch (bits) {
+    case 8:  return lim2full(v, 16, 240, 255);
+    case 10: return lim2full(v, 64, 960, 1023);
+    case 12: return lim2full(v, 256, 3840, 4095);
+    default: return lim2full(v, 1024, 61440, 65535);
+    }
+}
+
+// Table formulas, reference YuvLookupTables.cpp:157-190 (and ReadHeifImage.cpp:402-415 for the alpha form).
+AG_DEV float table_y(const ReadParams& p, int i)
+{
+    const int u = p.full_range ? i : lim2full_y(p.bits, i);
+    return (float)u / (float)p.maxc;
+}
+AG_DEV float table_uv(const ReadParams& p, int i)
+{
+    if (p.identity_lut) return table_y(p, i);
+    const int u = p.full_range ? i : lim2full_uv(p.bits, i);
+    return (float)u / (float)p.maxc - 0.5f;
+}
+AG_DEV float table_a(const ReadParams& p, int i) { return (float)i / (float)p.maxc; }
+
+struct Tables {
+    const float* ty; const float* tuv; const float* ta;   // LDS (bits <= 12) or nullptr
+};
+AG_DEV float look_y(const ReadParams& p, const Tables& t, uint32_t i)  { return t.ty ? t.ty[i] : table_y(p, (int)i); }
+AG_DEV float look_uv(const ReadParams& p, const Tables& t, uint32_t i) { return t.tuv ? t.tuv[i] : table_uv(p, (int)i); }
+AG_DEV float look_a(const ReadParams& p, const Tables& t, uint32_t i)  { return t.ta ? t.ta[i] : table_a(p, (int)i); }
+
+// EOTF of one RGB triple, reference YuvDecode.cpp:563-591 / ReadHeifImage.cpp:1067-1095.
+template <int TRANSFER>
+AG_DEV void eotf_rgb(const ReadParams& p, float (&c)[3])
+{
+    if constexpr (TRANSFER == AVIFGPU_TRANSFER_PQ) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) c[k] = fast_pq_to_linear(c[k], p.pq_mult);
+    } else if constexpr (TRANSFER == AVIFGPU_TRANSFER_HLG) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) c[k] = fast_hlg_to_linear(c[k]);
+        if (p.hlg_ootf) {                                   // ApplyHLGOOTF, ColorTransfer.cpp:192-205
+            const float luma = (c[0] * p.hlg_luma[0]) + (c[1] * p.hlg_luma[1]) + (c[2] * p.hlg_luma[2]);
+            const float factor = p.hlg_peak * fast_pow(luma, p.hlg_gamma_m1);
+            c[0] *= factor; c[1] *= factor; c[2] *= factor;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) c[k] = fast_smpte428_to_linear(c[k]);
+    }
+}
+
+enum { kCsYcc = 0, kCsRgb = 1, kCsMono = 2 };
+
+// One pixel.  u[] = raw samples (Y,Cb,Cr | R,G,B | Y), ua = alpha sample.  out[] = NCH host samples
+// (u8/u16 values or f32 bit patterns).
+template <int CS, int DEPTH, bool ALPHA, int TRANSFER>
+AG_DEV void decode_pixel(const ReadParams& p, const Tables& t, uint32_t u0, uint32_t u1, uint32_t u2, uint32_t ua,
+                         uint32_t* out)
+{
+    const uint32_t maxc = (uint32_t)p.maxc;
+    const float rgb_max = DEPTH == 8 ? 255.0f : 32768.0f;
+
+    if constexpr (CS == kCsRgb) {                                   // ReadHeifImage.cpp:627-711, :776-860, :1027-1176
+        uint32_t q[3] = { u0, u1, u2 };
+        if constexpr (DEPTH == 16) { q[0] &= maxc; q[1] &= maxc; q[2] &= maxc; ua &= maxc; }       // :787-790
+        if constexpr (DEPTH == 32) { q[0] = min(q[0], maxc); q[1] = min(q[1], maxc); q[2] = min(q[2], maxc); ua = min(ua, maxc); }
+        if constexpr (ALPHA) {
+            if (p.premultiplied && ua < maxc) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) q[k] = (ua == 0) ? 0u : exact_unpremultiply(q[k], ua, (float)p.maxc);
+            }
+        }
+        if constexpr (DEPTH == 32) {
+            float c[3] = { look_a(p, t, q[0]), look_a(p, t, q[1]), look_a(p, t, q[2]) };
+            eotf_rgb<TRANSFER>(p, c);
+            out[0] = __float_as_uint(c[0]); out[1] = __float_as_uint(c[1]); out[2] = __float_as_uint(c[2]);
+            if constexpr (ALPHA) out[3] = __float_as_uint(look_a(p, t, ua));
+        } else {
+            out[0] = q[0]; out[1] = q[1]; out[2] = q[2];
+            if constexpr (ALPHA) out[3] = ua;
+        }
+        return;
+    } else {
+        if constexpr (DEPTH != 8) {                                 // std::min(sample, yuvMaxChannel), YuvDecode.cpp:139,:424-427
+            u0 = min(u0, maxc); u1 = min(u1, maxc); u2 = min(u2, maxc); ua = min(ua, maxc);
+        }
+        if constexpr (CS == kCsMono) {                              // YuvDecode.cpp:55-279
+            if constexpr (DEPTH == 32) {
+                if constexpr (ALPHA) {
+                    if (p.premultiplied && ua < maxc)               // integer-domain unpremultiply, :247-260
+                        u0 = (ua == 0) ? 0u : exact_unpremultiply(u0, ua, (float)p.maxc);
+                }
+                out[0] = __float_as_uint(fast_pq_to_linear(look_y(p, t, u0), p.pq_mult));
+                if constexpr (ALPHA) out[1] = __float_as_uint(look_a(p, t, ua));
+            } else {
+                float Y = look_y(p, t, u0);
+                if constexpr (ALPHA) {
+                    if (p.premultiplied && ua < maxc)               // :97-112, :172-185
+                        Y = (ua == 0) ? 0.0f : exact_unpremultiply_f(Y, look_a(p, t, ua));
+                }
+                out[0] = (uint32_t)(0.5f + (Y * rgb_max));
+                if constexpr (ALPHA) out[1] = (DEPTH == 8) ? ua : (uint32_t)(0.5f + (look_a(p, t, ua) * rgb_max)); // :116, :188
+            }
+            return;
+        } else {                                                    // YCbCr, YuvDecode.cpp:281-696
+            const float Y = look_y(p, t, u0), Cb = look_uv(p, t, u1), Cr = look_uv(p, t, u2);
+            const float kr = p.kr, kg = p.kg, kb = p.kb;
+            float R = Y + (2 * (1 - kr)) * Cr;                                          // :312
+            float B = Y + (2 * (1 - kb)) * Cb;                                          // :313
+            float G = Y - ((2 * ((kr * (1 - kr) * Cr) + (kb * (1 - kb) * Cb))) / kg);   // :314
+            R = cxx_clamp(R, 0.0f, 1.0f); G = cxx_clamp(G, 0.0f, 1.0f); B = cxx_clamp(B, 0.0f, 1.0f);
+            if constexpr (ALPHA) {
+                if (p.premultiplied && ua < maxc) {                                     // :369-388
+                    if (ua == 0) { R = 0.0f; G = 0.0f; B = 0.0f; }
+                    else {
+                        const float A = look_a(p, t, ua);
+                        R = exact_unpremultiply_f(R, A); G = exact_unpremultiply_f(G, A); B = exact_unpremultiply_f(B, A);
+                    }
+                }
+            }
+            if constexpr (DEPTH == 32) {
+                float c[3] = { R, G, B };
+                eotf_rgb<TRANSFER>(p, c);
+                out[0] = __float_as_uint(c[0]); out[1] = __float_as_uint(c[1]); out[2] = __float_as_uint(c[2]);
+                if constexpr (ALPHA) out[3] = __float_as_uint(look_a(p, t, ua));       // :692
+            } else {
+                out[0] = (uint32_t)(0.5f + (R * rgb_max));
+                out[1] = (uint32_t)(0.5f + (G * rgb_max));
+                out[2] = (uint32_t)(0.5f + (B * rgb_max));
+                if constexpr (ALPHA) out[3] = (DEPTH == 8) ? ua : (uint32_t)(0.5f + (look_a(p, t, ua) * rgb_max)); // :395, :515
+            }
+        }
+    }
+}
+
+// Load N consecutive samples of a plane row starting at sample index i0 (right-edge replicated to `count`).
+template <bool SRC16, int N>
+AG_DEV void load_plane(const uint8_t* row, int i0, int count, uint32_t (&v)[N])
+{
+    constexpr int SSZ = SRC16 ? 2 : 1;
+    constexpr int BYTES = N * SSZ;
+    if constexpr (BYTES % 4 == 0) {
+        if (i0 + N <= count) {
+            uint32_t d[BYTES / 4];
+            load_dwords<BYTES / 4>(row + (long long)i0 * SSZ, d);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                if constexpr (SRC16) v[j] = (d[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                else v[j] = (d[j >> 2] >> (8 * (j & 3))) & 0xffu;
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int i = min(i0 + j, count - 1);
+        v[j] = SRC16 ? ld_u16(row + 2LL * i) : ld_u8(row + i);
+    }
+}
+
+template <int CS, int DEPTH, bool ALPHA, int XS, int YS, int TRANSFER>
+__global__ __launch_bounds__(256) void read_px(const ReadParams p)
+{
+    constexpr bool SRC16 = DEPTH != 8;
+    constexpr int PXT = 4 << XS;
+    constexpr int VR = 1 << YS;
+    constexpr int NC = 4;
+    constexpr int NCH = (CS == kCsMono ? 1 : 3) + (ALPHA ? 1 : 0);
+    constexpr int OSZ = DEPTH / 8;
+
+    extern __shared__ float lut[];
+    Tables t = { nullptr, nullptr, nullptr };
+    if (p.bits <= 12) {
+        const int count = 1 << p.bits;
+        for (int i = threadIdx.x; i < count; i += 256) {
+            lut[i] = table_y(p, i);
+            lut[count + i] = table_uv(p, i);
+            lut[2 * count + i] = table_a(p, i);
+        }
+        __syncthreads();
+        t.ty = lut; t.tuv = lut + count; t.ta = lut + 2 * count;
+    }
+
+    const int gxn = (p.width + PXT - 1) / PXT;
+    const int gyn = (p.nrows + VR - 1) >> YS;
+    const long long total = (long long)gxn * gyn;
+    const int cw = (p.width + (1 << XS) - 1) >> XS;
+
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+        const int gy = (int)(g / gxn);
+        const int gx = (int)(g - (long long)gy * gxn);
+        const int x0 = gx * PXT;
+        const int r0 = gy * VR;
+        const int nvalid = min(PXT, p.width - x0);
+
+        uint32_t c1[NC] = {0, 0, 0, 0}, c2[NC] = {0, 0, 0, 0};
+        if constexpr (CS == kCsYcc) {                       // uvJ = y >> yChromaShift, uvI = x >> xChromaShift
+            load_plane<SRC16, NC>(p.src[1] + (long long)gy * p.src_stride[1], x0 >> XS, cw, c1);
+            load_plane<SRC16, NC>(p.src[2] + (long long)gy * p.src_stride[2], x0 >> XS, cw, c2);
+        }
+
+#pragma unroll
+        for (int vr = 0; vr < VR; ++vr) {
+            const int r = r0 + vr;
+            if (r >= p.nrows) continue;
+            uint32_t y[PXT], a[PXT], g1[PXT], g2[PXT];
+            load_plane<SRC16, PXT>(p.src[0] + (long long)r * p.src_stride[0], x0, p.width, y);
+            if constexpr (ALPHA) load_plane<SRC16, PXT>(p.src[3] + (long long)r * p.src_stride[3], x0, p.width, a);
+            if constexpr (CS == kCsRgb) {
+                load_plane<SRC16, PXT>(p.src[1] + (long long)r * p.src_stride[1], x0, p.width, g1);
+                load_plane<SRC16, PXT>(p.src[2] + (long long)r * p.src_stride[2], x0, p.width, g2);
+            }
+            uint32_t o[PXT * NCH];
+#pragma unroll
+            for (int i = 0; i < PXT; ++i) {
+                uint32_t u1 = 0, u2 = 0;
+                if constexpr (CS == kCsYcc) { u1 = c1[i >> XS]; u2 = c2[i >> XS]; }
+                if constexpr (CS == kCsRgb) { u1 = g1[i]; u2 = g2[i]; }
+                decode_pixel<CS, DEPTH, ALPHA, TRANSFER>(p, t, y[i], u1, u2, ALPHA ? a[i] : (uint32_t)p.maxc, &o[i * NCH]);
+            }
+            uint8_t* drow = p.dst + (long long)r * p.dst_row_bytes + (long long)x0 * NCH * OSZ;
+            if constexpr (DEPTH == 32) {
+                if (nvalid == PXT) store_dwords<PXT * NCH>(drow, o);
+                else {
+#pragma unroll
+                    for (int j = 0; j < PXT * NCH; ++j)
+                        if (j < nvalid * NCH) reinterpret_cast<uint32_t*>(drow)[j] = o[j];
+                }
+            } else {
+                store_samples<DEPTH == 16, PXT * NCH>(drow, o, nvalid * NCH);
+            }
+        }
+    }
+}
+
+// ---- dispatch --------------------------------------------------------------------------------------
+template <int CS, int DEPTH, bool ALPHA, int XS, int YS, int TRANSFER>
+static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, const char** name)
+{
+    constexpr int PXT = 4 << XS;
+    const long long groups = (long long)((p.width + PXT - 1) / PXT) * ((p.nrows + (1 << YS) - 1) >> YS);
+    if (groups == 0) return hipSuccess;
+    long long blocks = (groups + 255) / 256;
+    if (blocks > 256LL * 8) blocks = 256LL * 8;          // tables are rebuilt per block: keep blocks persistent-ish
+    const size_t lds = p.bits <= 12 ? (size_t)3 * (1u << p.bits) * sizeof(float) : 0;
+    static thread_local char label[160];
+    snprintf(label, sizeof(label), "read_px<cs=%d,depth=%d,alpha=%d,xs=%d,ys=%d,transfer=%d>", CS, DEPTH, (int)ALPHA, XS, YS, TRANSFER);
+    *name = label;
+    hipLaunchKernelGGL((read_px<CS, DEPTH, ALPHA, XS, YS, TRANSFER>), dim3((int)blocks), dim3(256), lds, st, p);
+    return hipGetLastError();
+}
+
+template <int CS, int DEPTH, bool ALPHA, int XS, int YS>
+static hipError_t launch_read_tr(const ReadParams& p, hipStream_t st, const char** name)
+{
+    if constexpr (DEPTH == 32 && CS != kCsMono) {
+        switch (p.transfer) {
+        case AVIFGPU_TRANSFER_PQ:  return launch_read_one<CS, DEPTH, ALPHA, XS, YS, AVIFGPU_TRANSFER_PQ>(p, st, name);
+        case AVIFGPU_TRANSFER_HLG: return launch_read_one<CS, DEPTH, ALPHA, XS, YS, AVIFGPU_TRANSFER_HLG>(p, st, name);
+        default:                   return launch_read_one<CS, DEPTH, ALPHA, XS, YS, AVIFGPU_TRANSFER_SMPTE428>(p, st, name);
+        }
+    } else {
+        return launch_read_one<CS, DEPTH, ALPHA, XS, YS, AVIFGPU_TRANSFER_PQ>(p, st, name);
+    }
+}
+
+template <int CS, int DEPTH, bool ALPHA>
+static hipError_t launch_read_chroma(const ReadParams& p, int xs, int ys, hipStream_t st, const char** name)
+{
+    if constexpr (CS == kCsYcc) {
+        if (xs == 0) return launch_read_tr<CS, DEPTH, ALPHA, 0, 0>(p, st, name);
+        if (ys == 0) return launch_read_tr<CS, DEPTH, ALPHA, 1, 0>(p, st, name);
+        return launch_read_tr<CS, DEPTH, ALPHA, 1, 1>(p, st, name);
+    } else {
+        return launch_read_tr<CS, DEPTH, ALPHA, 0, 0>(p, st, name);
+    }
+}
+
+template <int CS>
+static hipError_t launch_read_cs(const ReadParams& p, int depth, bool alpha, int xs, int ys, hipStream_t st, const char** name)
+{
+    switch (depth) {
+    case 8:  return alpha ? launch_read_chroma<CS, 8, true>(p, xs, ys, st, name)  : launch_read_chroma<CS, 8, false>(p, xs, ys, st, name);
+    case 16: return alpha ? launch_read_chroma<CS, 16, true>(p, xs, ys, st, name) : launch_read_chroma<CS, 16, false>(p, xs, ys, st, name);
+    default: return alpha ? launch_read_chroma<CS, 32, true>(p, xs, ys, st, name) : launch_read_chroma<CS, 32, false>(p, xs, ys, st, name);
+    }
+}
+
+hipError_t launch_read(const ReadParams& p, int colorspace, int depth, bool alpha, int xs, int ys,
+                       hipStream_t st, const char** name)
+{
+    switch (colorspace) {
+    case AVIFGPU_COLORSPACE_YCBCR: return launch_read_cs<kCsYcc>(p, depth, alpha, xs, ys, st, name);
+    case AVIFGPU_COLORSPACE_RGB:   return launch_read_cs<kCsRgb>(p, depth, alpha, xs, ys, st, name);
+    default:                       return launch_read_cs<kCsMono>(p, depth, alpha, xs, ys, st, name);
+    }
+}
+
+} // namespace avifgpu

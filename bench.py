@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the pixel-conversion hot path on MI355X.
+
+Workload (BASELINE.json configs[3], the configuration `metric` is quoted on; it fits one GPU):
+    8192 x 8192 32-bpc float RGB  ->  Rec.2100 PQ (80 nits)  ->  10-bit full-range BT.2020-NCL YCbCr 4:4:4 planes
+    = CreateHeifImageRGBThirtyTwoBit (reference WriteHeifImage.cpp:990-1139) fused with libheif's RGB->YCbCr stage
+      (reference call site Write.cpp:44).
+A "step" is one pass of that path over one synthetic frame, input and output resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+For N > 1 the driver launches one rank per GPU through torch.distributed.run; ranks never exchange pixels
+(row tiles / frames are independent -- SURVEY.md 8e), torch.distributed (RCCL) only provides the barrier and the
+MAX-over-ranks of the timed region.  --scaling weak (default): every rank converts one full frame per step.
+--scaling strong: ONE frame is split into N even-row tiles.
+
+Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per launch (18 B/px: 12 in + 6 out,
+SURVEY.md 8d) / mean kernel time from HIP events recorded on the launch stream.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def make_frame(torch, dev, width, height, planes, seed):
+    """Synthetic linear-light frame, SURVEY.md 8(d) C4 distribution, generated on the device."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    n = height * width * planes
+    a = torch.rand(n, generator=g, device=dev, dtype=torch.float32)
+    m = torch.rand(n, generator=g, device=dev, dtype=torch.float32)
+    hi = 1.0 + 11.5 * torch.rand(n, generator=g, device=dev, dtype=torch.float32)
+    a = torch.where(m < 0.10, hi, a)                       # ~10 % highlights in (1, 12.5]
+    a = torch.where(m > 0.999, -0.01 * a, a)               # ~0.1 % small negatives
+    return a.view(height, width * planes).contiguous()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=8192)
+    ap.add_argument("--height", type=int, default=8192)
+    ap.add_argument("--bits", type=int, default=10)
+    ap.add_argument("--chroma", choices=["444", "422", "420"], default="444")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=8192, help="rows of the frame the CPU baseline converts")
+    ap.add_argument("--pcie", action="store_true", help="also time the host-buffer (PCIe-inclusive) entry point")
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as entry
+    pkg = entry.load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"WORLD_SIZE {world} != --gpus {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU; there is no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)   # RCCL: barrier + MAX only, no pixel traffic
+
+    gpu = pkg.AvifGpu(local_rank)
+    W, H = args.width, args.height
+    chroma = {"444": pkg.CHROMA_444, "422": pkg.CHROMA_422, "420": pkg.CHROMA_420}[args.chroma]
+    desc = pkg.WriteDesc(width=W, height=H, depth=32, planes=3, bit_depth=args.bits, transfer=pkg.TRANSFER_PQ,
+                         peak_nits=80, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR, chroma=chroma,
+                         matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020)
+
+    # row tile of this rank (even-row boundaries)
+    sharding = entry.load_package().sharding
+    if args.scaling == "strong":
+        row0, nrows = sharding.row_tile(H, world, rank, even=True)
+        frame_seed = 1234
+    else:
+        row0, nrows = 0, H
+        frame_seed = 1234 + rank
+    frame = make_frame(torch, dev, W, H, 3, frame_seed)
+    src = frame[row0:row0 + nrows]
+
+    xs, ys = {pkg.CHROMA_444: (0, 0), pkg.CHROMA_422: (1, 0), pkg.CHROMA_420: (1, 1)}[chroma]
+    ssz = 2
+    planes = []
+    for pl in range(3):
+        w = W if pl == 0 else (W + xs) >> xs
+        h = nrows if pl == 0 else (nrows + ys) >> ys
+        planes.append(torch.empty((h, w * ssz), dtype=torch.uint8, device=dev))
+    ptrs = [p.data_ptr() for p in planes] + [None]
+    strides = [p.stride(0) for p in planes] + [0]
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        gpu.write_rows(desc, row0, nrows, src.data_ptr(), src.stride(0) * 4, ptrs, strides,
+                       mem=pkg.MEM_DEVICE, stream=stream.cuda_stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+
+    # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides ----
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        starts[i].record(stream)          # same stream the kernel is launched on
+        step()
+        ends[i].record(stream)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = sorted(s.elapsed_time(e) for s, e in zip(starts, ends))
+    mean_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
+    kernel_name = gpu.last_kernel()
+
+    total_rows = H * world if args.scaling == "weak" else H
+    total_px = float(W) * total_rows * args.steps
+    value = total_px / elapsed / 1e6
+    algo_bytes = gpu.write_algorithmic_bytes(desc, nrows)
+    achieved = algo_bytes / mean_kernel_s / 1e9
+
+    out = {
+        "metric": "Mpixels/s + achieved HBM GB/s, 8K 32bpc->10-bit Rec.2100 PQ, 1 GPU",
+        "value": round(value, 2),
+        "unit": "Mpixels/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+        "higher_is_better": True,
+        "scaling": args.scaling,
+        "vs_baseline": None,                 # the reference publishes no number for this path
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{W}x{H} RGB f32 -> PQ(80 nits) -> {args.bits}-bit BT.2020-NCL YCbCr {args.chroma} planes "
+                        f"(BASELINE.json configs[3])",
+            "rows_per_gpu": nrows,
+            "frames_per_step": world if args.scaling == "weak" else 1,
+            "parallelism": f"row-tile x{world}, no collective",
+            "kernel": kernel_name,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "traffic": None,
+            "algorithmic_bytes_per_launch": algo_bytes,
+            "kernel_ms_mean": round(mean_kernel_s * 1e3, 5),
+            "kernel_ms_p10_p50_p90": [round(kernel_ms[int(len(kernel_ms) * q)], 5) for q in (0.1, 0.5, 0.9)],
+            "read_only_frac": round((12.0 * W * nrows) / mean_kernel_s / 1e9 / HBM_PEAK_GBPS, 4),
+        },
+    }
+    # PMC-derived HBM traffic per launch, if a profile of this round was parsed into profiles/traffic.json
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("workload") == f"{W}x{H}-{args.chroma}-{args.bits}":
+                out["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+
+    if rank == 0 and world == 1:
+        if args.pcie:
+            import numpy as np
+            rows = min(1024, nrows)
+            h_src = src[:rows].cpu().numpy()
+            h_out = [np.empty((rows if pl == 0 else (rows + ys) >> ys, planes[pl].shape[1]), dtype=np.uint8) for pl in range(3)]
+            sub = pkg.WriteDesc(**{n: getattr(desc, n) for n, _ in pkg.WriteDesc._fields_})
+            def host_step():
+                gpu.write_rows(sub, 0, rows, h_src.ctypes.data, h_src.strides[0], [a.ctypes.data for a in h_out] + [None],
+                               [a.strides[0] for a in h_out] + [0], mem=pkg.MEM_HOST)
+            host_step()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                host_step()
+            dt = (time.perf_counter() - t1) / 5
+            out["pcie_inclusive"] = {"value": round(W * rows / dt / 1e6, 1), "unit": "Mpixels/s", "rows": rows,
+                                     "note": "pageable host buffers in, planes out, synchronous (avifgpu_write_rows MEM_HOST)"}
+        if not args.no_cpu_baseline:
+            import harness
+            rows = min(args.cpu_rows, nrows)
+            h_src = src[:rows].cpu().numpy()
+            sub = pkg.WriteDesc(**{n: getattr(desc, n) for n, _ in pkg.WriteDesc._fields_})
+            sub.height = rows
+            harness.oracle_write(sub, h_src[:8], row0=0, nrows=8)        # page in the library
+            t1 = time.perf_counter()
+            harness.oracle_write(sub, h_src, return_raw=True)
+            dt = time.perf_counter() - t1
+            out["cpu_baseline"] = {
+                "value": round(W * rows / dt / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+                "sample": f"first {rows} rows of the same {W}x{H} frame ({W * rows / 1e6:.1f} Mpx, {dt:.1f} s), "
+                          f"scalar C restatement oracle/avif_oracle.c (gcc -O2, glibc powf), 1 thread like the reference",
+            }
+        else:
+            out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,267 @@
+/*
+ * avifgpu.h -- C-ABI of the MI355X-native pixel-conversion layer for the
+ * avif-format Photoshop plug-in (reference: 0xC0000054/avif-format @ 1.0.7.0).
+ *
+ * This is the drop-in boundary.  It replaces the per-pixel work of
+ *   - the six CreateHeifImage{Gray,RGB}{Eight,Sixteen,ThirtyTwo}Bit functions
+ *     (reference src/common/WriteHeifImage.h:29-63, bodies WriteHeifImage.cpp:169-1139),
+ *   - optionally libheif's RGB -> YCbCr + chroma-subsample stage that runs inside
+ *     heif_context_encode_image (reference call site src/common/Write.cpp:44, selected by
+ *     src/common/WriteMetadata.cpp:107-149 and src/common/Write.cpp:96-127),
+ *   - the six ReadHeifImage{Gray,RGB}{Eight,Sixteen,ThirtyTwo}Bit functions
+ *     (reference src/common/ReadHeifImage.h:27-63) together with the twelve Decode*Row* kernels
+ *     (reference src/common/YUVDecode.h:29-145, bodies YuvDecode.cpp:55-696).
+ *
+ * Everything crossing this boundary is plain C: PODs, raw pointers, sizes.  No C++ types, no
+ * torch types.  Pointers are either all host pointers (AVIFGPU_MEM_HOST: the library stages
+ * through pinned memory) or all device pointers (AVIFGPU_MEM_DEVICE: zero-copy, kernels are
+ * enqueued on `stream` and the call returns without synchronising).
+ *
+ * Return values are Photoshop OSErr codes (reference error convention: src/common/Write.cpp:345-364,
+ * src/common/Read.cpp:531-550): 0 = noErr.
+ */
+#ifndef AVIFGPU_H
+#define AVIFGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVIFGPU_ABI_VERSION 1
+
+/* ---- OSErr codes used by the hot path (Photoshop SDK values) ------------------------------- */
+#define AVIFGPU_noErr                0
+#define AVIFGPU_userCanceledErr   (-128)  /* abortProc() returned true: WriteHeifImage.cpp:1019-1022 */
+#define AVIFGPU_readErr            (-19)
+#define AVIFGPU_writErr            (-20)
+#define AVIFGPU_memFullErr        (-108)  /* std::bad_alloc mapping: Write.cpp:345-348 */
+#define AVIFGPU_formatBadParameters (-30500) /* Write.cpp:318,334 default branch */
+#define AVIFGPU_formatCannotRead    (-30501) /* WriteHeifImage.cpp:57,81 default branch */
+
+/* ---- enums (numeric values follow the reference / libheif / ITU-T H.273) -------------------- */
+
+/* ColorTransferFunction, reference src/common/ColorTransfer.h:28-34 (same order). */
+enum {
+    AVIFGPU_TRANSFER_PQ       = 0,
+    AVIFGPU_TRANSFER_HLG      = 1,
+    AVIFGPU_TRANSFER_SMPTE428 = 2,
+    AVIFGPU_TRANSFER_CLIP     = 3
+};
+
+/* AlphaState, reference src/common/AlphaState.h:24-29 (same order). */
+enum {
+    AVIFGPU_ALPHA_NONE          = 0,
+    AVIFGPU_ALPHA_STRAIGHT      = 1,
+    AVIFGPU_ALPHA_PREMULTIPLIED = 2
+};
+
+/* heif_colorspace / heif_chroma subset (libheif public header values). */
+enum {
+    AVIFGPU_COLORSPACE_YCBCR      = 0,
+    AVIFGPU_COLORSPACE_RGB        = 1,
+    AVIFGPU_COLORSPACE_MONOCHROME = 2
+};
+enum {
+    AVIFGPU_CHROMA_MONOCHROME = 0,
+    AVIFGPU_CHROMA_420        = 1,
+    AVIFGPU_CHROMA_422        = 2,
+    AVIFGPU_CHROMA_444        = 3
+};
+
+/* nclx matrix_coefficients (H.273 table 4 == heif_matrix_coefficients). */
+enum {
+    AVIFGPU_MATRIX_RGB_GBR        = 0,
+    AVIFGPU_MATRIX_BT709          = 1,
+    AVIFGPU_MATRIX_UNSPECIFIED    = 2,
+    AVIFGPU_MATRIX_FCC            = 4,
+    AVIFGPU_MATRIX_BT470BG        = 5,
+    AVIFGPU_MATRIX_BT601          = 6,
+    AVIFGPU_MATRIX_SMPTE240M      = 7,
+    AVIFGPU_MATRIX_YCGCO          = 8,
+    AVIFGPU_MATRIX_BT2020_NCL     = 9,
+    AVIFGPU_MATRIX_BT2020_CL      = 10,
+    AVIFGPU_MATRIX_SMPTE2085      = 11,
+    AVIFGPU_MATRIX_CHROMA_DERIVED_NCL = 12,
+    AVIFGPU_MATRIX_CHROMA_DERIVED_CL  = 13,
+    AVIFGPU_MATRIX_ICTCP          = 14
+};
+
+/* nclx colour_primaries (H.273 table 2 == heif_color_primaries). */
+enum {
+    AVIFGPU_PRIMARIES_BT709      = 1,
+    AVIFGPU_PRIMARIES_UNSPECIFIED = 2,
+    AVIFGPU_PRIMARIES_BT470M     = 4,
+    AVIFGPU_PRIMARIES_BT470BG    = 5,
+    AVIFGPU_PRIMARIES_BT601      = 6,
+    AVIFGPU_PRIMARIES_SMPTE240M  = 7,
+    AVIFGPU_PRIMARIES_GENERIC_FILM = 8,
+    AVIFGPU_PRIMARIES_BT2020     = 9,
+    AVIFGPU_PRIMARIES_SMPTE428   = 10,
+    AVIFGPU_PRIMARIES_SMPTE431   = 11,
+    AVIFGPU_PRIMARIES_SMPTE432   = 12,
+    AVIFGPU_PRIMARIES_EBU3213    = 22
+};
+
+/* nclx transfer_characteristics (only the three HDR curves the read path accepts,
+ * reference src/common/ColorTransfer.cpp:47-67). */
+enum {
+    AVIFGPU_TC_SRGB     = 13,
+    AVIFGPU_TC_PQ       = 16,
+    AVIFGPU_TC_SMPTE428 = 17,
+    AVIFGPU_TC_HLG      = 18
+};
+
+/* What the write path emits. */
+enum {
+    /* Exactly what CreateHeifImage* hands to libheif: interleaved RGB(A) at bit_depth for colour
+     * (heif_channel_interleaved, WriteHeifImage.cpp:643-646), planar Y(+Alpha) for gray
+     * (WriteHeifImage.cpp:181-194).  dst[0] = interleaved / Y, dst[3] = Alpha (gray only). */
+    AVIFGPU_OUT_REFERENCE = 0,
+    /* Fused: stage A above followed by libheif's RGB->YCbCr + chroma subsample (Write.cpp:44).
+     * dst[0..2] = Y, Cb, Cr planes, dst[3] = Alpha plane.  Colour sources only. */
+    AVIFGPU_OUT_YCBCR = 1
+};
+
+/* Chroma down-sampling filter of the fused path (libheif stage, un-vendored => spec'd here). */
+enum {
+    AVIFGPU_DOWNSAMPLE_AVERAGE = 0,  /* box average of the 2x1 / 2x2 footprint, edge-replicated */
+    AVIFGPU_DOWNSAMPLE_NEAREST = 1   /* top-left (co-sited) sample */
+};
+
+/* Zero point of the full-range chroma codes written by the fused path.
+ *   LIBHEIF : Cb' = round(Cb + 2^(bits-1))      -- what libheif's encoder-side conversion emits (drop-in default)
+ *   DECODER : Cb' = round(Cb + (2^bits-1)/2)    -- exact inverse of the plug-in's own decoder tables
+ *                                                  (T_UV[i] = i/max - 0.5, YuvLookupTables.cpp:182); round trip <= 1 code */
+enum {
+    AVIFGPU_CHROMA_ZERO_LIBHEIF = 0,
+    AVIFGPU_CHROMA_ZERO_DECODER = 1
+};
+
+enum {
+    AVIFGPU_MEM_HOST   = 0,
+    AVIFGPU_MEM_DEVICE = 1
+};
+
+/* ---- descriptors ---------------------------------------------------------------------------- */
+
+/*
+ * Write direction: FormatRecord rows -> heif_image planes.
+ * Mirrors the arguments of CreateHeifImage*(formatRecord, alphaState, imageSize, saveOptions)
+ * (reference WriteHeifImage.h:29-63) reduced to the fields the pixel loops read.
+ */
+typedef struct avifgpu_write_desc {
+    int32_t width;               /* imageSize.h */
+    int32_t height;              /* imageSize.v */
+    int32_t depth;               /* formatRecord->depth: 8, 16 (0..32768), 32 (float) */
+    int32_t planes;              /* formatRecord->planes: 1|2 gray(+A), 3|4 RGB(+A); alpha last */
+    int32_t bit_depth;           /* saveOptions.imageBitDepth as 8 | 10 | 12 */
+    int32_t transfer;            /* saveOptions.hdrTransferFunction (depth 32 only), AVIFGPU_TRANSFER_* */
+    int32_t peak_nits;           /* saveOptions.pq.nominalPeakBrightness (1..10000) */
+    int32_t alpha_state;         /* AVIFGPU_ALPHA_* ; must agree with planes */
+    int32_t output;              /* AVIFGPU_OUT_* */
+    /* ---- stage B (AVIFGPU_OUT_YCBCR only) ---- */
+    int32_t chroma;              /* AVIFGPU_CHROMA_420|422|444 ("chroma" encoder parameter, Write.cpp:100-120) */
+    int32_t matrix_coefficients; /* nclx matrix the plug-in selects, WriteMetadata.cpp:113-146 */
+    int32_t color_primaries;     /* only consulted for AVIFGPU_MATRIX_CHROMA_DERIVED_NCL */
+    int32_t full_range;          /* reference always writes 1 (WriteMetadata.cpp:46); 0 is rejected */
+    int32_t chroma_downsampling; /* AVIFGPU_DOWNSAMPLE_* */
+    int32_t chroma_zero_point;   /* AVIFGPU_CHROMA_ZERO_* */
+    int32_t reserved;
+} avifgpu_write_desc;
+
+/*
+ * Read direction: heif_image planes -> FormatRecord rows.
+ * Mirrors ReadHeifImage*(image, alphaState, nclxProfile, [loadOptions,] formatRecord)
+ * (reference ReadHeifImage.h:27-63).
+ */
+typedef struct avifgpu_read_desc {
+    int32_t width;
+    int32_t height;
+    int32_t colorspace;          /* heif_image_get_colorspace: AVIFGPU_COLORSPACE_* */
+    int32_t chroma;              /* heif_image_get_chroma_format: AVIFGPU_CHROMA_* (YCbCr only) */
+    int32_t bit_depth;           /* heif_image_get_bits_per_pixel_range(Y or R): 8 | 10 | 12 | 16 */
+    int32_t depth;               /* host depth the driver chose (Read.cpp:359-515): 8 | 16 | 32 */
+    int32_t alpha_state;         /* AVIFGPU_ALPHA_* (Read.cpp:155-172) */
+    int32_t has_nclx;            /* 0 => nclxProfile == nullptr (BT.601, full range defaults) */
+    int32_t color_primaries;
+    int32_t transfer_characteristics;
+    int32_t matrix_coefficients;
+    int32_t full_range_flag;
+    /* LoadUIOptions (reference AvifFormat.h:61-85) */
+    int32_t pq_peak_nits;        /* loadOptions.pq.nominalPeakBrightness */
+    int32_t hlg_apply_ootf;      /* loadOptions.hlg.applyOOTF */
+    float   hlg_display_gamma;   /* loadOptions.hlg.displayGamma */
+    int32_t hlg_peak_nits;       /* loadOptions.hlg.nominalPeakBrightness */
+    int32_t reserved[2];
+} avifgpu_read_desc;
+
+/* ---- entry points --------------------------------------------------------------------------- */
+
+/* ABI version of the loaded library (== AVIFGPU_ABI_VERSION of the header it was built from). */
+int32_t avifgpu_abi_version(void);
+
+/* Bind the calling process to one HIP device and create the library's stream + staging buffers.
+ * Fails with AVIFGPU_formatBadParameters if no HIP device is present: there is NO CPU fallback. */
+int32_t avifgpu_init(int32_t device_index);
+void    avifgpu_shutdown(void);
+
+/* Message for the last non-zero return on this thread (what LibHeifException / runtime_error carry
+ * in the reference, UIWin.cpp:1827-1843). */
+const char* avifgpu_last_error(void);
+
+/*
+ * Convert rows [row0, row0 + nrows) of the image described by `desc`.
+ *
+ *   src            first byte of source row `row0` (interleaved, planes * depth/8 bytes per pixel,
+ *                  exactly the layout advanceState() leaves in formatRecord->data, Write.cpp:279-299)
+ *   src_row_bytes  distance between source rows (formatRecord->rowBytes)
+ *   dst[i]         first byte of destination plane i at row `row0` (chroma planes: row row0 >> yShift)
+ *   dst_stride[i]  libheif's stride for that plane (heif_image_get_plane, WriteHeifImage.cpp:646)
+ *
+ * row0 must be even for 4:2:0; nrows may be odd only for the tile that ends at `height`.
+ * Replaces the row loops WriteHeifImage.cpp:208-263,...,1017-1135.
+ */
+int32_t avifgpu_write_rows(const avifgpu_write_desc* desc,
+                           int32_t row0, int32_t nrows,
+                           const void* src, int64_t src_row_bytes,
+                           void* const dst[4], const int64_t dst_stride[4],
+                           int32_t mem_kind, void* stream);
+
+/*
+ * Inverse direction.  src[i] / src_stride[i] are what heif_image_get_plane_readonly returns
+ * (ReadHeifImage.cpp:104-111) advanced to row `row0` (chroma: row0 >> yShift); plane order is
+ * Y,Cb,Cr,Alpha / R,G,B,Alpha / Y,-,-,Alpha.  dst receives interleaved host rows
+ * (formatRecord->data layout, ReadHeifImage.cpp:31-50).  Replaces ReadHeifImage.cpp:141-181 etc.
+ */
+int32_t avifgpu_read_rows(const avifgpu_read_desc* desc,
+                          int32_t row0, int32_t nrows,
+                          const void* const src[4], const int64_t src_stride[4],
+                          void* dst, int64_t dst_row_bytes,
+                          int32_t mem_kind, void* stream);
+
+/* (kr, kg, kb) exactly as GetYUVCoefficiants derives them (reference YUVCoefficiants.cpp:154-188).
+ * has_nclx == 0 => BT.601 default. */
+int32_t avifgpu_get_yuv_coefficients(int32_t has_nclx, int32_t matrix_coefficients,
+                                     int32_t color_primaries, float out_kr_kg_kb[3]);
+
+/* Value formatRecord->maxValue must be set to for a 16-bit read (ReadHeifImage.cpp:206,499,747):
+ * 32768 for YCbCr / gray, 2^bits-1 for planar RGB (host rescales). */
+int32_t avifgpu_read_max_value(const avifgpu_read_desc* desc);
+
+/* Geometry helpers shared by host shim, tests and bench. */
+int32_t avifgpu_write_plane_count(const avifgpu_write_desc* desc);              /* planes written   */
+int32_t avifgpu_write_plane_geometry(const avifgpu_write_desc* desc, int32_t plane,
+                                     int32_t* width, int32_t* height,
+                                     int32_t* bytes_per_sample, int32_t* samples_per_pixel);
+int64_t avifgpu_write_algorithmic_bytes(const avifgpu_write_desc* desc, int32_t nrows); /* in + out */
+int64_t avifgpu_read_algorithmic_bytes(const avifgpu_read_desc* desc, int32_t nrows);
+
+/* Name + last launch geometry of the kernel the previous *_rows call dispatched (for bench/profiles). */
+const char* avifgpu_last_kernel_name(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVIFGPU_H */

@@ -1,0 +1,123 @@
+"""BASELINE.json configurations at FULL size on one MI355X, checked through size-independent properties:
+ (a) an oracle-checked stripe of rows (top, an interior even offset, and the bottom edge),
+ (b) row-tile invariance: the frame converted as 8 even-row tiles (the 8-GPU sharding) is byte-identical to the
+     frame converted in one launch (checksum of checksums over planes)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import harness
+
+pkg = harness.pkg
+pytestmark = pytest.mark.gpu
+
+
+def _device_frame(torch, dev, d, seed=1234):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    n = d.height * d.width * d.planes
+    if d.depth == 8:
+        t = torch.randint(0, 256, (n,), generator=g, device=dev, dtype=torch.uint8)
+    elif d.depth == 16:
+        t = torch.randint(0, 32769, (n,), generator=g, device=dev, dtype=torch.int32).to(torch.int16)
+    else:
+        t = torch.rand(n, generator=g, device=dev, dtype=torch.float32)
+        m = torch.rand(n, generator=g, device=dev, dtype=torch.float32)
+        t = torch.where(m < 0.10, 1.0 + 11.5 * t, t)
+        t = torch.where(m > 0.999, -0.01 * t, t)
+        if d.planes == 4:
+            t.view(-1, 4)[:, 3].clamp_(0.0, 1.0)
+    return t.view(d.height, d.width * d.planes)
+
+
+def _run(gpu, torch, dev, d, frame, tiles):
+    bufs = {}
+    ssz = 2 if d.bit_depth > 8 else 1
+    for pl, (w, xs, ys) in harness.write_planes(d).items():
+        bufs[pl] = torch.zeros(((d.height + ys) >> ys, w * ssz), dtype=torch.uint8, device=dev)
+    esz = frame.element_size()
+    for r0, n in tiles:
+        if n == 0:
+            continue
+        ptrs, strides = [None] * 4, [0] * 4
+        for pl, (w, xs, ys) in harness.write_planes(d).items():
+            ptrs[pl] = bufs[pl][r0 >> ys].data_ptr()
+            strides[pl] = bufs[pl].stride(0)
+        gpu.write_rows(d, r0, n, frame[r0].data_ptr(), frame.stride(0) * esz, ptrs, strides, mem=pkg.MEM_DEVICE,
+                       stream=torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
+    return bufs
+
+
+def _digest(torch, bufs):
+    h = hashlib.sha256()
+    for pl in sorted(bufs):
+        # checksum of checksums: 64-bit wraparound sums per plane, computed on the device
+        t = bufs[pl].view(torch.int16).to(torch.int64) if bufs[pl].shape[1] % 2 == 0 else bufs[pl].to(torch.int64)
+        w = torch.arange(1, t.shape[1] + 1, device=t.device, dtype=torch.int64)
+        h.update(str(int((t * w).sum().item())).encode())
+        h.update(str(int(t.sum().item())).encode())
+    return h.hexdigest()
+
+
+CONFIGS = {
+    "C2-4096-rgb8-420-709": dict(width=4096, height=4096, depth=8, planes=3, bit_depth=8, alpha_state=0,
+                                 output=1, chroma=1, matrix_coefficients=1),
+    "C3-8192-rgb16-12bit-444-2020": dict(width=8192, height=8192, depth=16, planes=3, bit_depth=12, alpha_state=0,
+                                         output=1, chroma=3, matrix_coefficients=9, color_primaries=9),
+    "C4-8192-f32-pq-10bit-444": dict(width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80,
+                                     alpha_state=0, output=1, chroma=3, matrix_coefficients=9, color_primaries=9),
+    "C4-8192-f32-pq-10bit-420": dict(width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80,
+                                     alpha_state=0, output=1, chroma=1, matrix_coefficients=9, color_primaries=9),
+    "C5-16384-f32a-pq-12bit-444": dict(width=16384, height=16384, depth=32, planes=4, bit_depth=12, transfer=0,
+                                       peak_nits=80, alpha_state=1, output=1, chroma=3, matrix_coefficients=9,
+                                       color_primaries=9),
+}
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_fullsize(gpu, name):
+    import torch
+    dev = f"cuda:{gpu.device}"
+    d = pkg.WriteDesc(**CONFIGS[name])
+    frame = _device_frame(torch, dev, d)
+    whole = _run(gpu, torch, dev, d, frame, [(0, d.height)])
+    tiled = _run(gpu, torch, dev, d, frame, pkg.sharding.all_tiles(d.height, 8))
+    assert _digest(torch, whole) == _digest(torch, tiled), name
+    for pl in whole:
+        assert torch.equal(whole[pl], tiled[pl]), (name, pl)
+    # oracle-checked stripes
+    float_tier = d.depth == 32
+    for r0, n in ((0, 16), (d.height // 2 + 6, 16), (d.height - 10, 10)):
+        stripe = frame[r0:r0 + n].cpu().numpy()
+        if d.depth == 16:
+            stripe = stripe.view(np.uint16)
+        sub = pkg.WriteDesc(**CONFIGS[name])
+        src_full = np.zeros((0,), dtype=stripe.dtype)
+        # oracle on the stripe as a tile of the full image (row0 keeps the bottom-edge semantics)
+        want = _oracle_tile(sub, stripe, r0, n)
+        ssz = 2 if d.bit_depth > 8 else 1
+        for pl, (w, xs, ys) in harness.write_planes(d).items():
+            got = whole[pl][r0 >> ys:(r0 >> ys) + ((n + ys) >> ys)].cpu().numpy()
+            got = got.view(np.uint16) if ssz == 2 else got
+            diff = np.abs(got.astype(np.int64) - want[pl].astype(np.int64))
+            if float_tier:
+                assert diff.max() <= 1 and (diff == 0).mean() > 0.99, (name, pl, int(diff.max()), float((diff == 0).mean()))
+            else:
+                assert diff.max() == 0, (name, pl)
+        del src_full
+
+
+def _oracle_tile(d, stripe, row0, nrows):
+    import ctypes
+    import oracle_binding
+    L = oracle_binding.load()
+    bufs = harness._alloc_write_out(d, nrows)
+    ptrs = [bufs[i].ctypes.data if i in bufs else None for i in range(4)]
+    strides = [bufs[i].strides[0] if i in bufs else 0 for i in range(4)]
+    stripe = np.ascontiguousarray(stripe)
+    code = L.oracle_write_rows(ctypes.byref(d), row0, nrows, stripe.ctypes.data, stripe.strides[0],
+                               ctypes.byref(pkg.planes4(ptrs)), ctypes.byref(pkg.strides4(strides)))
+    assert code == 0
+    return harness._trim(d, bufs, nrows, harness.write_planes)

@@ -1,0 +1,90 @@
+"""GPU parity, read direction: heif_image planes -> FormatRecord rows through the C-ABI vs the CPU oracle.
+8/16-bit host rows are bit-exact (T1).  32-bit float rows go through PQ/HLG/SMPTE-428 EOTFs built on native
+v_log/v_exp: tolerance |gpu - oracle| <= 5e-5 * |oracle| + 1e-9 (T2; the reference's own float powf chain carries
+~3e-6 relative uncertainty at the dark end)."""
+import numpy as np
+import pytest
+
+import cases
+import harness
+
+pkg = harness.pkg
+pytestmark = pytest.mark.gpu
+
+T2_RTOL, T2_ATOL = 5e-5, 1e-9
+
+
+def _check(cid, kw, got, want):
+    if cases.is_float_tier_read(kw):
+        w64, g64 = want.astype(np.float64), got.astype(np.float64)
+        assert np.all(np.isfinite(g64)), cid
+        err = np.abs(g64 - w64)
+        bound = T2_RTOL * np.abs(w64) + T2_ATOL
+        assert np.all(err <= bound), (cid, float((err / np.maximum(np.abs(w64), 1e-30)).max()))
+    else:
+        assert np.array_equal(got, want), (cid, int(np.abs(got.astype(np.int64) - want.astype(np.int64)).max()))
+
+
+@pytest.mark.parametrize("cid,kw", cases.read_cases())
+def test_read_parity_device(gpu, cid, kw):
+    d = pkg.ReadDesc(**kw)
+    planes = harness.make_read_source(d)
+    want = harness.oracle_read(d, planes)
+    got = harness.gpu_read(gpu, d, planes, mem="device")
+    _check(cid, kw, got, want)
+    assert "read" in gpu.last_kernel()
+
+
+@pytest.mark.parametrize("cid,kw", cases.read_cases()[::6])
+def test_read_parity_host_buffers(gpu, cid, kw):
+    d = pkg.ReadDesc(**kw)
+    planes = harness.make_read_source(d, seed=99, stride_pad=40)
+    want = harness.oracle_read(d, planes)
+    got = harness.gpu_read(gpu, d, planes, mem="host")
+    _check(cid, kw, got, want)
+
+
+def test_read_exhaustive_8bit_yuv(gpu):
+    """A 64^3 lattice of (Y,U,V) plus all 256 luma codes, every matrix, both ranges -- bit-exact."""
+    v = np.linspace(0, 255, 64).round().astype(np.uint8)
+    Y, U, V = np.meshgrid(v, v, v, indexing="ij")
+    n = Y.size
+    W, H = 512, n // 512
+    planes = {0: Y.reshape(H, W).copy(), 1: U.reshape(H, W).copy(), 2: V.reshape(H, W).copy()}
+    for m in (pkg.MATRIX_BT709, pkg.MATRIX_BT601, pkg.MATRIX_BT2020_NCL, pkg.MATRIX_FCC, pkg.MATRIX_SMPTE240M):
+        for fr in (1, 0):
+            d = pkg.ReadDesc(width=W, height=H, colorspace=pkg.COLORSPACE_YCBCR, chroma=pkg.CHROMA_444, bit_depth=8,
+                             depth=8, alpha_state=pkg.ALPHA_NONE, matrix_coefficients=m, full_range_flag=fr)
+            assert np.array_equal(harness.gpu_read(gpu, d, planes), harness.oracle_read(d, planes)), (m, fr)
+
+
+def test_read_exhaustive_table_entries(gpu):
+    """Every code of the 8/10/12/16-bit unorm->float tables (mono path exposes T_Y directly), both ranges."""
+    for bits, depth in ((8, 8), (10, 16), (12, 16), (16, 16)):
+        n = 1 << bits
+        dt = np.uint16 if bits > 8 else np.uint8
+        W = 256
+        planes = {0: np.arange(n, dtype=dt).reshape(n // W, W)}
+        for fr in (1, 0):
+            d = pkg.ReadDesc(width=W, height=n // W, colorspace=pkg.COLORSPACE_MONOCHROME, chroma=pkg.CHROMA_MONOCHROME,
+                             bit_depth=bits, depth=depth, alpha_state=pkg.ALPHA_NONE, full_range_flag=fr)
+            assert np.array_equal(harness.gpu_read(gpu, d, planes), harness.oracle_read(d, planes)), (bits, fr)
+
+
+def test_read_float_error_report(gpu):
+    """All 10/12-bit codes through each EOTF (planar RGB path = curve only): print the measured max relative error."""
+    for bits in (10, 12):
+        n = 1 << bits
+        W = 256
+        codes = np.arange(n, dtype=np.uint16).reshape(n // W, W)
+        planes = {0: codes, 1: codes.copy(), 2: codes.copy()}
+        for tc in (pkg.TC_PQ, pkg.TC_HLG, pkg.TC_SMPTE428):
+            d = pkg.ReadDesc(width=W, height=n // W, colorspace=pkg.COLORSPACE_RGB, chroma=pkg.CHROMA_444, bit_depth=bits,
+                             depth=32, alpha_state=pkg.ALPHA_NONE, matrix_coefficients=pkg.MATRIX_RGB_GBR,
+                             color_primaries=pkg.PRIMARIES_BT2020, transfer_characteristics=tc, pq_peak_nits=80)
+            want = harness.oracle_read(d, planes).astype(np.float64)
+            got = harness.gpu_read(gpu, d, planes).astype(np.float64)
+            rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-30)
+            rel[want == 0] = np.abs(got[want == 0])
+            print(f"EOTF tc={tc} bits={bits}: max rel err {rel.max():.3e}")
+            assert np.all(np.abs(got - want) <= T2_RTOL * np.abs(want) + T2_ATOL)

@@ -1,0 +1,219 @@
+"""Oracle self-consistency (CPU only): LUT shape, limited->full endpoints, tile invariance, and the round trip that
+anchors the un-vendored libheif stage (forward RGB->YCbCr restatement -> the plug-in's own decoder equations)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import cases
+import harness
+
+pkg = harness.pkg
+
+
+def test_rescale_luts(oracle):
+    for bits in (10, 12):
+        lut = np.zeros(256, dtype=np.uint16)
+        oracle.oracle_build_lut_8_to_n(bits, lut.ctypes.data)
+        assert lut[0] == 0 and lut[255] == (1 << bits) - 1 and np.all(np.diff(lut.astype(int)) >= 0)
+        lut = np.zeros(32769, dtype=np.uint16)
+        oracle.oracle_build_lut_16_to_n(bits, lut.ctypes.data)
+        assert lut[0] == 0 and lut[32768] == (1 << bits) - 1 and np.all(np.diff(lut.astype(int)) >= 0)
+        # (int)(i/32768*max + 0.5): mid-point rounds up
+        assert lut[16384] == int(((1 << bits) - 1) / 2 + 0.5)
+    lut8 = np.zeros(32769, dtype=np.uint8)
+    oracle.oracle_build_lut_16_to_8(lut8.ctypes.data)
+    assert lut8[0] == 0 and lut8[32768] == 255 and lut8[16384] == 128
+
+
+def test_limited_to_full(oracle):
+    # reference YuvLookupTables.cpp:69-109 ranges
+    for depth, (ylo, yhi, clo, chi) in {8: (16, 235, 16, 240), 10: (64, 940, 64, 960), 12: (256, 3760, 256, 3840)}.items():
+        full = (1 << depth) - 1
+        assert oracle.oracle_limited_to_full_y(depth, ylo) == 0
+        assert oracle.oracle_limited_to_full_y(depth, yhi) == full
+        assert oracle.oracle_limited_to_full_y(depth, 0) == 0            # clamps below
+        assert oracle.oracle_limited_to_full_y(depth, full) == full      # clamps above
+        assert oracle.oracle_limited_to_full_uv(depth, clo) == 0
+        assert oracle.oracle_limited_to_full_uv(depth, chi) == full
+    # depth 16: exact below the reference's int32 overflow point, wrapped (mirrored quirk) above it
+    assert oracle.oracle_limited_to_full_y(16, 1024) == 0
+    assert oracle.oracle_limited_to_full_y(16, 30592) == (29568 * 65535 + 29568) // 59136
+    assert oracle.oracle_limited_to_full_y(16, 60160) == 0          # (59136*65535) wraps negative -> clamps to 0
+
+
+def test_yuv_tables(oracle):
+    n = 1 << 10
+    ty, tuv, ta = (np.zeros(n, np.float32) for _ in range(3))
+    assert oracle.oracle_build_yuv_tables(1, pkg.MATRIX_BT709, 1, 10, 0, ty.ctypes.data, tuv.ctypes.data, ta.ctypes.data) == 0
+    i = np.arange(n, dtype=np.float32)
+    assert np.array_equal(ty, i / np.float32(1023)) and np.array_equal(ta, ty)
+    assert np.array_equal(tuv, i / np.float32(1023) - np.float32(0.5))
+    # identity matrix: UV table equals Y table (reference quirk, YuvLookupTables.cpp:177-180)
+    assert oracle.oracle_build_yuv_tables(1, pkg.MATRIX_RGB_GBR, 1, 10, 0, ty.ctypes.data, tuv.ctypes.data, ta.ctypes.data) == 0
+    assert np.array_equal(tuv, ty)
+    assert oracle.oracle_build_yuv_tables(1, pkg.MATRIX_BT709, 1, 9, 0, ty.ctypes.data, tuv.ctypes.data, ta.ctypes.data) != 0
+
+
+def test_coefficient_table(oracle):
+    out = (ctypes.c_float * 3)()
+    want = {pkg.MATRIX_BT709: (0.2126, 0.0722), pkg.MATRIX_FCC: (0.30, 0.11), pkg.MATRIX_BT470BG: (0.299, 0.114),
+            pkg.MATRIX_BT601: (0.299, 0.114), pkg.MATRIX_SMPTE240M: (0.212, 0.087), pkg.MATRIX_BT2020_NCL: (0.2627, 0.0593)}
+    for m, (kr, kb) in want.items():
+        oracle.oracle_get_yuv_coefficients(1, m, pkg.PRIMARIES_BT709, ctypes.byref(out))
+        assert out[0] == np.float32(kr) and out[2] == np.float32(kb)
+        assert out[1] == np.float32(1.0) - np.float32(kr) - np.float32(kb)
+    # not representable as Kr/Kb (identity, YCgCo, CL, ICtCp) and "no nclx" silently fall back to BT.601
+    for m, has in ((pkg.MATRIX_RGB_GBR, 1), (pkg.MATRIX_YCGCO, 1), (pkg.MATRIX_BT2020_CL, 1), (14, 1), (pkg.MATRIX_BT709, 0)):
+        oracle.oracle_get_yuv_coefficients(has, m, pkg.PRIMARIES_BT709, ctypes.byref(out))
+        assert (out[0], out[2]) == (np.float32(0.299), np.float32(0.114))
+    # chromaticity-derived from BT.709 primaries ~ BT.709
+    oracle.oracle_get_yuv_coefficients(1, pkg.MATRIX_CHROMA_DERIVED_NCL, pkg.PRIMARIES_BT709, ctypes.byref(out))
+    assert abs(out[0] - 0.2126) < 2e-4 and abs(out[2] - 0.0722) < 2e-4
+
+
+def test_pq_curve_properties(oracle):
+    # negative -> 0, monotone, inverse pair
+    assert oracle.oracle_linear_to_pq(-1.0, 80.0) == 0.0 and oracle.oracle_pq_to_linear(-0.1, 80.0) == 0.0
+    xs = np.linspace(0, 12.5, 500, dtype=np.float32)
+    ys = np.array([oracle.oracle_linear_to_pq(float(x), 80.0) for x in xs])
+    assert np.all(np.diff(ys) >= 0)
+    back = np.array([oracle.oracle_pq_to_linear(float(y), 80.0) for y in ys])
+    assert np.allclose(back[1:], xs[1:], rtol=2e-3)
+    for v in (0.01, 0.3, 0.9):
+        assert abs(oracle.oracle_hlg_to_linear(oracle.oracle_linear_to_hlg(v)) - v) < 1e-5
+        assert abs(oracle.oracle_smpte428_to_linear(oracle.oracle_linear_to_smpte428(v)) - v) < 1e-5
+
+
+def test_hlg_ootf_inverse(oracle):
+    f3 = ctypes.c_float * 3
+    luma = f3()
+    assert oracle.oracle_hlg_luma_coefficients(pkg.PRIMARIES_BT2020, ctypes.byref(luma)) == 0
+    assert oracle.oracle_hlg_luma_coefficients(pkg.PRIMARIES_SMPTE432, ctypes.byref(luma)) != 0   # runtime_error
+    oracle.oracle_hlg_luma_coefficients(pkg.PRIMARIES_BT2020, ctypes.byref(luma))
+    base = np.array([0.2, 0.5, 0.1])
+    ys = float(base @ np.array([0.2627, 0.6780, 0.0593]))
+    rgb = f3(*base)
+    oracle.oracle_apply_hlg_ootf(ctypes.byref(rgb), ctypes.byref(luma), 1.2, 1000.0)
+    assert np.allclose(list(rgb), base * 1000.0 * ys ** 0.2, rtol=1e-5)           # ColorTransfer.cpp:198-204
+    # ApplyInverseHLGOOTF is defined but never called by the reference, and as written (:214) it is NOT the
+    # algebraic inverse of ApplyHLGOOTF (exponent sign); the oracle restates it literally.
+    rgb = f3(*base)
+    oracle.oracle_apply_inverse_hlg_ootf(ctypes.byref(rgb), ctypes.byref(luma), 1.2, 1000.0)
+    assert np.allclose(list(rgb), base * (ys / 1000.0) ** (0.2 / 1.2) / 1000.0, rtol=1e-5)
+
+
+@pytest.mark.parametrize("cid,kw", [c for c in cases.write_cases() if c[0].startswith(("ycc-d8-p3-b8-c1", "ycc-d32-p4-b10-c1", "ycc-d16-p3-b12-c2"))])
+def test_write_tile_invariance(cid, kw):
+    """Even-row tiles reproduce the whole-frame result byte for byte (the multi-GPU sharding contract)."""
+    d = pkg.WriteDesc(**kw)
+    src = harness.make_write_source(d)
+    whole = harness.oracle_write(d, src)
+    cuts = [0, 6, 14, d.height]
+    for pl, (w, xs, ys) in harness.write_planes(d).items():
+        parts = [harness.oracle_write(d, src, row0=a, nrows=b - a)[pl] for a, b in zip(cuts[:-1], cuts[1:])]
+        assert np.array_equal(np.concatenate(parts, axis=0), whole[pl]), (cid, pl)
+
+
+def test_write_rejects_bad_tiles():
+    d = pkg.WriteDesc(width=8, height=8, depth=8, planes=3, bit_depth=8, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420,
+                      matrix_coefficients=pkg.MATRIX_BT709)
+    src = harness.make_write_source(d)
+    for row0, nrows in ((1, 2), (0, 3)):
+        with pytest.raises(pkg.AvifGpuError) as e:
+            harness.oracle_write(d, src, row0=row0, nrows=nrows)
+        assert e.value.code == pkg.formatBadParameters
+
+
+@pytest.mark.parametrize("zero", [pkg.CHROMA_ZERO_LIBHEIF, pkg.CHROMA_ZERO_DECODER])
+@pytest.mark.parametrize("bits", [8, 10, 12])
+@pytest.mark.parametrize("matrix,prim", [(pkg.MATRIX_BT709, pkg.PRIMARIES_BT709), (pkg.MATRIX_BT601, pkg.PRIMARIES_BT709),
+                                         (pkg.MATRIX_BT2020_NCL, pkg.PRIMARIES_BT2020), (pkg.MATRIX_FCC, pkg.PRIMARIES_BT709),
+                                         (pkg.MATRIX_SMPTE240M, pkg.PRIMARIES_BT709)])
+def test_roundtrip_through_reference_decoder(bits, matrix, prim, zero):
+    """T3 anchor: forward stage B (libheif restatement) followed by the plug-in's own decoder equations
+    (YuvDecode.cpp:312-322 restated in oracle_read_rows) returns every 4:4:4 code within +-1 when the chroma zero
+    point matches the decoder's tables (SURVEY 8c definition) and within +-2.4 codes with libheif's 2^(bits-1)
+    zero point (the half-code chroma bias the real save->load pipeline of the plug-in has as well)."""
+    depth_src = 8 if bits == 8 else 16
+    W, H = 64, 32
+    wd = pkg.WriteDesc(width=W, height=H, depth=depth_src, planes=3, bit_depth=bits, alpha_state=pkg.ALPHA_NONE,
+                       output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444, matrix_coefficients=matrix, color_primaries=prim,
+                       chroma_zero_point=zero)
+    src = harness.make_write_source(wd)
+    ref = harness.oracle_write(pkg.WriteDesc(width=W, height=H, depth=depth_src, planes=3, bit_depth=bits,
+                                             alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_REFERENCE), src)[0]
+    ycc = harness.oracle_write(wd, src, return_raw=True)
+    rd = pkg.ReadDesc(width=W, height=H, colorspace=pkg.COLORSPACE_YCBCR, chroma=pkg.CHROMA_444, bit_depth=bits,
+                      depth=8 if bits == 8 else 16, alpha_state=pkg.ALPHA_NONE, matrix_coefficients=matrix,
+                      color_primaries=prim, full_range_flag=1)
+    back = harness.oracle_read(rd, ycc).astype(np.float64)
+    codes = ref.astype(np.float64)                         # stage-A codes at `bits`
+    scale = 255.0 if bits == 8 else 32768.0
+    err_codes = np.abs(back / scale * ((1 << bits) - 1) - codes)
+    # quantising Y/Cb/Cr costs 0.5 + |2(1-kb)| * 0.5 <= 1.45 codes on the worst channel (B); libheif's zero point
+    # adds another |2(1-kb)| * 0.5.  Host rows are on the 0..32768 scale for 10/12 bit, hence the 0.51 slack.
+    if zero == pkg.CHROMA_ZERO_DECODER:
+        assert err_codes.max() <= 1.51, err_codes.max()
+    else:
+        assert err_codes.max() <= 2.45, err_codes.max()
+
+
+def test_roundtrip_chroma_constant_blocks():
+    """4:2:0 / 4:2:2 box average is exact on chroma-constant 2x2 blocks."""
+    W, H = 32, 16
+    rng = np.random.default_rng(7)
+    blocks = rng.integers(0, 256, size=(H // 2, W // 2, 3), dtype=np.uint8)
+    src = np.repeat(np.repeat(blocks, 2, axis=0), 2, axis=1).reshape(H, W * 3)
+    for chroma in (pkg.CHROMA_420, pkg.CHROMA_422):
+        kw = dict(width=W, height=H, depth=8, planes=3, bit_depth=8, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR,
+                  matrix_coefficients=pkg.MATRIX_BT709)
+        sub = harness.oracle_write(pkg.WriteDesc(chroma=chroma, **kw), src)
+        full = harness.oracle_write(pkg.WriteDesc(chroma=pkg.CHROMA_444, **kw), src)
+        xs, ys = harness.chroma_shift(chroma)
+        assert np.array_equal(sub[0], full[0])
+        assert np.array_equal(sub[1], full[1][::1 << ys, ::1 << xs])
+        assert np.array_equal(sub[2], full[2][::1 << ys, ::1 << xs])
+        near = harness.oracle_write(pkg.WriteDesc(chroma=chroma, chroma_downsampling=pkg.DOWNSAMPLE_NEAREST, **kw), src)
+        assert np.array_equal(near[1], sub[1]) and np.array_equal(near[2], sub[2])
+
+
+def test_write_error_paths():
+    src = np.zeros((2, 8), dtype=np.float32)
+    def code(**kw):
+        base = dict(width=2, height=2, depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_PQ,
+                    alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_REFERENCE)
+        base.update(kw)
+        try:
+            harness.oracle_write(pkg.WriteDesc(**base), src)
+        except pkg.AvifGpuError as e:
+            return e.code
+        return 0
+    assert code() == 0
+    assert code(bit_depth=9) == pkg.formatCannotRead           # GetHeifImageBitDepth default, WriteHeifImage.cpp:57
+    assert code(depth=24) == pkg.formatBadParameters           # Write.cpp:318
+    assert code(planes=1, transfer=pkg.TRANSFER_SMPTE428) == pkg.writErr   # gray: runtime_error :581-582
+    assert code(planes=4) == pkg.formatBadParameters           # alpha_state disagrees with planes
+    assert code(output=pkg.OUT_YCBCR, matrix_coefficients=pkg.MATRIX_YCGCO) == pkg.formatBadParameters
+    assert code(output=pkg.OUT_YCBCR, matrix_coefficients=pkg.MATRIX_RGB_GBR, chroma=pkg.CHROMA_420) == pkg.formatBadParameters
+    assert code(output=pkg.OUT_YCBCR, full_range=0) == pkg.formatBadParameters
+
+
+def test_read_error_paths():
+    planes = {i: np.zeros((2, 8), np.uint16) for i in range(4)}
+    def code(**kw):
+        base = dict(width=2, height=2, colorspace=pkg.COLORSPACE_YCBCR, chroma=pkg.CHROMA_444, bit_depth=10, depth=32,
+                    alpha_state=pkg.ALPHA_NONE, transfer_characteristics=pkg.TC_PQ)
+        base.update(kw)
+        try:
+            harness.oracle_read(pkg.ReadDesc(**base), planes)
+        except pkg.AvifGpuError as e:
+            return e.code
+        return 0
+    assert code() == 0
+    assert code(has_nclx=0) == pkg.readErr                                   # "The nclxProfile is null."
+    assert code(transfer_characteristics=pkg.TC_SRGB) == pkg.readErr         # unsupported NCLX transfer
+    assert code(colorspace=pkg.COLORSPACE_MONOCHROME, transfer_characteristics=pkg.TC_HLG) == pkg.readErr
+    assert code(bit_depth=9) == pkg.readErr
+    assert code(transfer_characteristics=pkg.TC_HLG, hlg_apply_ootf=1, color_primaries=pkg.PRIMARIES_SMPTE432) == pkg.readErr
+    assert code(depth=8) == pkg.readErr
