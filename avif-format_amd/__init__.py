@@ -102,6 +102,7 @@ ABI = [
     ("avifgpu_write_algorithmic_bytes", c_int64, [POINTER(WriteDesc), c_int32]),
     ("avifgpu_read_algorithmic_bytes", c_int64, [POINTER(ReadDesc), c_int32]),
     ("avifgpu_last_kernel_name", c_char_p, []),
+    ("avifgpu_set_hot_variant", None, [c_int32]),
 ]
 
 
@@ -120,6 +121,14 @@ def load() -> ctypes.CDLL:
     """Load libavifgpu.so (built in-tree by `make -C avif-format_amd`).  Fails loudly if absent."""
     global _lib
     if _lib is None:
+        # PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's).  Whichever copy is loaded
+        # first serves the whole process, and torch cannot initialise on top of the system copy -- so when torch is
+        # installed, let it load its runtime before libavifgpu.so pulls one in.  (torch is plumbing here: device
+        # memory + streams for tests and bench; the library itself does not depend on it.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

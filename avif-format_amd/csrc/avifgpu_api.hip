@@ -3,6 +3,7 @@
 // There is no CPU fallback anywhere in this file: without a HIP device avifgpu_init fails and every
 // *_rows call returns an error.
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -43,7 +44,7 @@ struct Context {
     // device staging for AVIFGPU_MEM_HOST calls (grown on demand, reused across tiles)
     void* d_in = nullptr;  size_t d_in_cap = 0;
     void* d_out = nullptr; size_t d_out_cap = 0;
-    int hot_variant = kHotLdsTranspose;
+    int hot_variant = kHotDefault;
 } g_ctx;
 
 int hip_fail(hipError_t e, const char* what, int code)
@@ -172,6 +173,8 @@ int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const Wr
     p.maxv = (1 << d->bit_depth) - 1;
     p.maxf = (float)p.maxv;
     p.pq_mult = (float)d->peak_nits / 10000.0f;          // ColorTransfer.cpp:86
+    p.pq_log2_mult_m1 = (float)((2610.0 / 16384.0) * std::log2((double)p.pq_mult));
+    p.log2_maxf = (float)std::log2((double)p.maxv);
     p.half = d->chroma_zero_point == AVIFGPU_CHROMA_ZERO_DECODER ? p.maxf * 0.5f : (float)(1 << (d->bit_depth - 1));
     if (d->output == AVIFGPU_OUT_YCBCR) {
         if (d->matrix_coefficients == AVIFGPU_MATRIX_RGB_GBR) {       // lossless, WriteMetadata.cpp:143-146
@@ -308,6 +311,8 @@ int32_t avifgpu_abi_version(void) { return AVIFGPU_ABI_VERSION; }
 const char* avifgpu_last_error(void) { return g_err; }
 const char* avifgpu_last_kernel_name(void) { return g_kernel; }
 
+void avifgpu_set_hot_variant(int32_t variant) { g_ctx.hot_variant = variant; }
+
 int32_t avifgpu_init(int32_t device_index)
 {
     std::lock_guard<std::mutex> lk(g_ctx.mu);
@@ -323,7 +328,7 @@ int32_t avifgpu_init(int32_t device_index)
         return hip_fail(e, "hipStreamCreate", AVIFGPU_memFullErr);
     g_ctx.device = device_index;
     g_ctx.ready = true;
-    if (const char* v = getenv("AVIFGPU_HOT_VARIANT")) g_ctx.hot_variant = atoi(v);
+    if (const char* v = getenv("AVIFGPU_HOT_VARIANT")) g_ctx.hot_variant = (int)strtol(v, nullptr, 0);   // tuning only
     return 0;
 }
 
@@ -426,7 +431,7 @@ int32_t avifgpu_write_rows(const avifgpu_write_desc* d, int32_t row0, int32_t nr
     if ((err = fill_write_params(d, row0, nrows, g, p))) return err;
 
     if (mem_kind == AVIFGPU_MEM_DEVICE) {
-        hipStream_t st = stream ? (hipStream_t)stream : g_ctx.stream;
+        hipStream_t st = (hipStream_t)stream;          // NULL = HIP's default stream, as in every HIP API
         p.src = (const uint8_t*)src; p.src_row_bytes = src_row_bytes;
         for (int pl = 0; pl < 4; ++pl) { p.dst[pl] = (uint8_t*)dst[pl]; p.dst_stride[pl] = dst_stride[pl]; }
         const hipError_t e = launch_write(p, d->depth, d->planes, g.dst16, d->output, g.xs, g.ys, g_ctx.hot_variant, st, &g_kernel);
@@ -494,7 +499,7 @@ int32_t avifgpu_read_rows(const avifgpu_read_desc* d, int32_t row0, int32_t nrow
     if ((err = fill_read_params(d, nrows, g, p))) return err;
 
     if (mem_kind == AVIFGPU_MEM_DEVICE) {
-        hipStream_t st = stream ? (hipStream_t)stream : g_ctx.stream;
+        hipStream_t st = (hipStream_t)stream;          // NULL = HIP's default stream
         for (int pl = 0; pl < 4; ++pl) { p.src[pl] = (const uint8_t*)src[pl]; p.src_stride[pl] = src_stride[pl]; }
         p.dst = (uint8_t*)dst; p.dst_row_bytes = dst_row_bytes;
         const hipError_t e = launch_read(p, d->colorspace, d->depth, g.alpha, g.xs, g.ys, st, &g_kernel);

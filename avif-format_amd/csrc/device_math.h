@@ -37,25 +37,70 @@ constexpr float kPqC1 = 3424.0f / 4096.0f;
 constexpr float kPqC2 = 2413.0f / 4096.0f * 32.0f;
 constexpr float kPqC3 = 2392.0f / 4096.0f * 32.0f;
 
-// LinearToPQ, reference ColorTransfer.cpp:69-92.  mult = peak / 10000.
-// value < 0 -> 0 in the reference; here max(value*mult, 0) gives x = 0 -> c1^m2 = 7.3e-7, which
-// quantises to code 0 at every supported depth exactly like the reference's 0.  NaN -> 0 (v_max_f32).
+// Quotient n/d rounded like IEEE division in all but a vanishing fraction of cases: v_rcp_f32 (1 ulp), then one
+// residual correction of the quotient (error after the step ~ ulp^2).  4 issue slots; the full
+// v_div_scale/fmas/fixup sequence costs ~10.
+AG_DEV float near_ieee_div(float n, float d)
+{
+    const float r = nat_rcp(d);
+    const float q = n * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, d, n), r, q);
+}
+
+// LinearToPQ, reference ColorTransfer.cpp:69-92, fused with the "* maxValue" of WriteHeifImage.cpp:1093.
+//
+//   x  = t^m1,  t = max(value, 0) * mult    (value < 0 -> 0 in the reference; x = 0 gives c1^m2 = 7.3e-7, i.e. code 0
+//                                            at every supported depth, exactly like the reference's 0; NaN -> 0)
+//   q  = (c1 + c2 x) / (1 + c3 x)           in [0.836, 1.009]
+//   pq = q^m2                                m2 = 78.84: one ulp of q moves pq by 4.7e-6 relative
+//
+// Because of that last amplification the float ROUNDING of q is part of the reference's result.  q depends only
+// weakly on x (dq/q = 0.015 dx/x), so it is reproduced bit-for-bit by evaluating N, D and N/D with the reference's
+// own operation order and IEEE rounding (separate mul and add: no FMA there), even though x itself comes from the
+// native v_log_f32 / v_exp_f32 pair.  Cost: 5 quarter-rate transcendentals (measured 3.45x a v_fma_f32 each on
+// gfx950, tools/alubench.hip) + 12 full-rate ops per sample; the two constant multiplies (mult, maxValue) are
+// folded into the exponents as log2 addends.
+//   log2_mult_m1 = m1 * log2(mult),  log2_max = log2(maxValue).  Returns pq * maxValue (unclamped).
+AG_DEV float fast_linear_to_pq_scaled(float value, float log2_mult_m1, float log2_max)
+{
+    const float l = nat_log2(fmaxf(value, 0.0f));
+    const float x = nat_exp2(__builtin_fmaf(kPqM1, l, log2_mult_m1));
+    const float n = kPqC1 + kPqC2 * x;                   // -ffp-contract=off: v_mul_f32 + v_add_f32, as the reference
+    const float d = 1.0f + kPqC3 * x;
+    return nat_exp2(__builtin_fmaf(kPqM2, nat_log2(near_ieee_div(n, d)), log2_max));
+}
 AG_DEV float fast_linear_to_pq(float value, float mult)
 {
-    const float t = fmaxf(value * mult, 0.0f);
-    const float x = fast_pow(t, kPqM1);
-    const float num = __builtin_fmaf(kPqC2, x, kPqC1);
-    const float den = __builtin_fmaf(kPqC3, x, 1.0f);
-    return fast_pow(num * fast_rcp_nr(den), kPqM2);
+    return fast_linear_to_pq_scaled(value, kPqM1 * nat_log2(mult), 0.0f);
 }
 
 // PQToLinear, reference ColorTransfer.cpp:94-117.  mult = 10000 / peak.
+//
+//   x = v^(1/m2);  out = (max(x - c1, 0) / (c2 - c3 x))^(1/m1) * mult
+//
+// As written this cancels catastrophically (c2 - c3 x = 18.85 - 18.69x with x in [0.9, 1]): one ulp of x moves the
+// result by up to 4.5e-5 relative, which is also the reference's own float noise floor.  Here delta = 1 - x =
+// -expm1(ln(v)/m2) is evaluated directly (|ln(v)/m2| <= 0.16 for every non-zero 12-bit code), and with
+// 1 - c1 = c2 - c3 = 0.1640625 exactly:  x - c1 = 0.1640625 - delta,  c2 - c3 x = 0.1640625 + c3 delta.
 AG_DEV float fast_pq_to_linear(float value, float mult)
 {
-    const float v = fmaxf(value, 0.0f);
-    const float x = fast_pow(v, 1.0f / kPqM2);
-    const float num = fmaxf(x - kPqC1, 0.0f);
-    const float den = __builtin_fmaf(-kPqC3, x, kPqC2);
+    if (!(value > 0.0f)) return 0.0f;                                   // v <= 0 (and NaN) -> 0
+    const float t = nat_log2(value) * (0.6931471805599453f / kPqM2);    // ln(v) / m2  (<= 0 for v <= 1)
+    float delta;
+    if (t > -0.25f && t < 0.25f) {
+        float p = __builtin_fmaf(t, 1.0f / 5040.0f, 1.0f / 720.0f);
+        p = __builtin_fmaf(p, t, 1.0f / 120.0f);
+        p = __builtin_fmaf(p, t, 1.0f / 24.0f);
+        p = __builtin_fmaf(p, t, 1.0f / 6.0f);
+        p = __builtin_fmaf(p, t, 0.5f);
+        p = __builtin_fmaf(p, t, 1.0f);
+        delta = -(t * p);                                               // 1 - e^t
+    } else {
+        delta = 1.0f - nat_exp2(t * 1.4426950408889634f);
+    }
+    const float k = 1.0f - kPqC1;                                       // = c2 - c3 = 0.1640625
+    const float num = fmaxf(k - delta, 0.0f);
+    const float den = __builtin_fmaf(kPqC3, delta, k);
     return fast_pow(num * fast_rcp_nr(den), 1.0f / kPqM1) * mult;
 }
 
@@ -118,12 +163,12 @@ AG_DEV float exact_unpremultiply_f(float color, float alpha)   // UnpremultiplyC
     return cxx_min(color * 1.0f / alpha, 1.0f);
 }
 
-// libheif-style `(long)(v + 0.5f)` with clip to [0, maxi] (stage B quantiser).
+// libheif-style `(long)(v + 0.5f)` with clip to [0, maxi] (stage B quantiser).  v_cvt_u32_f32 truncates toward
+// zero and saturates negatives to 0, which is exactly "(long) then clip at 0".
 AG_DEV uint32_t clip_round(float v, int maxi)
 {
-    const float t = v + 0.5f;
-    int x = (t < 0.0f) ? 0 : (int)t;     // (long) truncates toward zero; negatives clip to 0 either way
-    return (uint32_t)(x > maxi ? maxi : x);
+    const uint32_t x = (uint32_t)(v + 0.5f);
+    return x > (uint32_t)maxi ? (uint32_t)maxi : x;
 }
 
 // ---- vector load/store of ND dwords at a runtime-aligned address --------------------------------

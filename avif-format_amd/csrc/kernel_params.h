@@ -5,11 +5,10 @@
 
 namespace avifgpu {
 
-// Tuning variant of the dominant kernel (RGB f32 -> PQ -> YCbCr 4:4:4 u16); see write_kernels.hip.
-enum HotVariant : int {
-    kHotGeneric      = 0,   // generic per-thread 48-B strided loads
-    kHotLdsTranspose = 1,   // coalesced dwordx4 loads, per-wave LDS transpose (conflict-free 12-dword stride)
-};
+// Tuning word of the dominant kernel (RGB f32 -> curve -> YCbCr 4:4:4 u16), see launch_write():
+//   bit0 enable hot kernel, bit1 8 px/lane (else 4), bit2 non-temporal loads+stores, bit3 register prefetch,
+//   bit4 XCD-contiguous span mapping, bits 8.. = block cap (0 = default).
+enum : int { kHotDefault = 1 | 2 | 4 };
 
 struct WriteParams {
     const uint8_t* src;          // row `row0`, interleaved
@@ -26,6 +25,8 @@ struct WriteParams {
     int32_t maxv;                // 2^bits - 1
     float   maxf;
     float   pq_mult;             // peak_nits / 10000 (ColorTransfer.cpp:86)
+    float   pq_log2_mult_m1;     // m1 * log2(pq_mult): the multiply by pq_mult folded into the first exponent
+    float   log2_maxf;           // log2(maxf): the multiply by maxValue folded into the second exponent
     float   my[3], mcb[3], mcr[3];
     float   half;                // 1 << (bits-1)
 };

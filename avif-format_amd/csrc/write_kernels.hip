@@ -22,6 +22,19 @@
 
 namespace avifgpu {
 
+// One linear-light sample -> integer code: transfer curve, scale by maxValue, clamp, TRUNCATE
+// (reference WriteHeifImage.cpp:1072-1095).
+template <int TRANSFER>
+AG_DEV uint32_t oetf_code(const WriteParams& p, float f)
+{
+    float scaled;
+    if constexpr (TRANSFER == AVIFGPU_TRANSFER_PQ) scaled = fast_linear_to_pq_scaled(f, p.pq_log2_mult_m1, p.log2_maxf);
+    else if constexpr (TRANSFER == AVIFGPU_TRANSFER_SMPTE428) scaled = fast_linear_to_smpte428(f) * p.maxf;
+    else if constexpr (TRANSFER == AVIFGPU_TRANSFER_HLG) scaled = fast_linear_to_hlg(f) * p.maxf;
+    else scaled = f * p.maxf;                                                   // Clip: exact
+    return (uint32_t)__builtin_amdgcn_fmed3f(scaled, 0.0f, p.maxf);
+}
+
 // ---- stage A: one source pixel -> integer codes (reference WriteHeifImage.cpp inner loops) --------
 // s[] holds the PLANES raw samples (u8/u16 values, or f32 bit patterns).  q[0..NCOL-1] colour, q[3] alpha.
 template <int DEPTH, int PLANES, int TRANSFER>
@@ -48,12 +61,7 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
         }
 #pragma unroll
         for (int k = 0; k < NCOL; ++k) {
-            float v;
-            if constexpr (TRANSFER == AVIFGPU_TRANSFER_PQ) v = fast_linear_to_pq(col[k], p.pq_mult);
-            else if constexpr (TRANSFER == AVIFGPU_TRANSFER_SMPTE428) v = fast_linear_to_smpte428(col[k]);
-            else if constexpr (TRANSFER == AVIFGPU_TRANSFER_HLG) v = fast_linear_to_hlg(col[k]);
-            else v = col[k];                                                    // Clip
-            q[k] = (uint32_t)__builtin_amdgcn_fmed3f(v * p.maxf, 0.0f, p.maxf); // truncation, :1093-1095
+            q[k] = oetf_code<TRANSFER>(p, col[k]);
         }
         q[3] = ALPHA ? (uint32_t)__builtin_amdgcn_fmed3f(a * p.maxf, 0.0f, p.maxf) : (uint32_t)p.maxv;
         return;
@@ -209,66 +217,124 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
     }
 }
 
-// ---- hot variant: RGB f32 -> (transfer) -> YCbCr 4:4:4 u16 with coalesced loads + per-wave LDS transpose ----
+// ---- hot kernel: RGB f32 -> (transfer) -> YCbCr 4:4:4 u16, coalesced streaming + per-wave LDS transpose ----
 //
-// A wave owns 256 consecutive pixels of one row = 3072 B = 768 floats.  Load k (k = 0..2) of lane l
-// fetches float4 number 64k + l of that span: three fully coalesced 1-KiB transactions.  The transfer
-// curve is per-sample, so it runs on the samples exactly as loaded; the resulting integer codes are
-// written to the wave's private LDS strip as u32 (ds_write_b128, contiguous => conflict-free) and read
-// back pixel-major: lane l takes dwords [12l, 12l+12) with three ds_read_b128.  For that stride the
-// four 16-lane service groups of ds_read_b128 ({0-3,12-15,20-27}, ...) land on 16 distinct 4-bank
-// slots (12*l mod 64 is a permutation of the multiples of 4), i.e. conflict-free.  No __syncthreads:
-// the strip is wave-private, ordering is the wave's own lgkmcnt.
-template <int TRANSFER, bool ALPHA_UNUSED>
-__global__ __launch_bounds__(256) void write_rgb32_ycbcr444_lds(const WriteParams p)
+// A wave owns one SPAN of 64*PXL consecutive pixels of one row (PXL = 4 or 8 pixels per lane).
+//   load   : K = 3*PXL/4 float4 per lane, float4 number 64k + lane of the span => every wave-load is one fully
+//            coalesced 1-KiB transaction.  Non-temporal: each byte is touched exactly once, keep it out of L2/MALL.
+//   curve  : the transfer curve is per-sample, so it runs on the samples exactly as loaded (no de-interleave yet).
+//   LDS    : the integer codes are packed two per dword and written to the wave's private strip with
+//            ds_write_b64 (8-B lane stride, conflict-free), then read back pixel-major: lane l owns packed dwords
+//            [3*PXL/2 * l, ...), i.e. a 6- (ds_read_b64 x3) or 12-dword (ds_read_b128 x3) lane stride.  Both
+//            strides are conflict-free on gfx950: 6l mod 64 hits 32 distinct even banks per 32-lane group, and
+//            12l mod 64 over each ds_read_b128 service group {0-3,12-15,20-27},... is a permutation of the 16
+//            four-bank slots (MI355X_MICROARCH.md, LDS table).  The strip is wave-private: no s_barrier, the
+//            wave's own in-order DS queue (lgkmcnt) is the only ordering needed.
+//   matrix : 3x3 on exact integer codes, libheif rounding; plane stores are PXL*2 = 8 or 16 B per lane,
+//            contiguous across the wave, non-temporal.
+//   PREFETCH: the next span's loads are issued before the current span's math (register double-buffer).
+//   XCDMAP : block b runs on XCD b % 8 (observed, speed only); give each XCD one contiguous eighth of the
+//            frame so its L2/TLB working set is a single moving window instead of eight interleaved ones.
+typedef float    f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+template <bool NT> AG_DEV f32x4 stream_load(const f32x4* p)
 {
-    __shared__ uint32_t strip[4][768];
+    if constexpr (NT) return __builtin_nontemporal_load(p); else return *p;
+}
+template <bool NT, typename V> AG_DEV void stream_store(V* p, V v)
+{
+    if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
+template <int TRANSFER, int PXL, bool NT, bool PREFETCH, bool XCDMAP>
+__global__ __launch_bounds__(256) void write_rgb32_ycbcr444_hot(const WriteParams p)
+{
+    constexpr int K = 3 * PXL / 4;               // float4 per lane per span
+    constexpr int SPAN_PX = 64 * PXL;
+    constexpr int SPAN_DW = SPAN_PX * 3 / 2;     // packed u16 codes
+    constexpr int LDW = 3 * PXL / 2;             // packed dwords per lane after the transpose
+    __shared__ __attribute__((aligned(16))) uint32_t strip[4][SPAN_DW];
+
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     uint32_t* my = strip[wave];
 
-    const int spans_per_row = p.width >> 8;                  // host guarantees width % 256 == 0, 16-B aligned rows
-    const long long total = (long long)spans_per_row * p.nrows;
-    for (long long sidx = (long long)blockIdx.x * 4 + wave; sidx < total; sidx += (long long)gridDim.x * 4) {
-        const int r = (int)(sidx / spans_per_row);
-        const int sx = (int)(sidx - (long long)r * spans_per_row);
-        const float4* srow = reinterpret_cast<const float4*>(p.src + (long long)r * p.src_row_bytes) + (long long)sx * 192;
+    // span indices fit 32 bits (host checks): 32-bit udiv instead of a 64-bit software divide per trip
+    const uint32_t spans_per_row = (uint32_t)p.width / SPAN_PX;        // host guarantees divisibility and alignment
+    const uint32_t total = spans_per_row * (uint32_t)p.nrows;
+    uint32_t sidx, step, limit;
+    if constexpr (XCDMAP) {
+        const uint32_t xcd = blockIdx.x & 7;
+        const uint32_t chunk = (total + 7) >> 3;
+        const uint32_t lo = chunk * xcd;
+        limit = lo + chunk < total ? lo + chunk : total;
+        sidx = lo + (blockIdx.x >> 3) * 4 + wave;
+        step = (gridDim.x >> 3) * 4;
+    } else {
+        sidx = blockIdx.x * 4 + wave;
+        step = gridDim.x * 4;
+        limit = total;
+    }
+    if (sidx >= limit) return;
 
-        float4 in[3];
+    auto span_src = [&](uint32_t s) -> const f32x4* {
+        const uint32_t r = s / spans_per_row;
+        const uint32_t sx = s - r * spans_per_row;
+        return reinterpret_cast<const f32x4*>(p.src + (long long)r * p.src_row_bytes) + (long long)sx * (64 * K);
+    };
+
+    f32x4 cur[K];
+    {
+        const f32x4* sp = span_src(sidx);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) in[k] = srow[64 * k + lane];
+        for (int k = 0; k < K; ++k) cur[k] = stream_load<NT>(sp + 64 * k + lane);
+    }
+
+    for (; sidx < limit; sidx += step) {
+        f32x4 nxt[K];
+        if constexpr (PREFETCH) {
+            const uint32_t sn = sidx + step < limit ? sidx + step : sidx;      // last trip re-reads its own span (L2 hit)
+            const f32x4* sp = span_src(sn);
+#pragma unroll
+            for (int k = 0; k < K; ++k) nxt[k] = stream_load<NT>(sp + 64 * k + lane);
+        }
 
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float f[4] = { in[k].x, in[k].y, in[k].z, in[k].w };
-            uint32_t c[4];
+        for (int k = 0; k < K; ++k) {
+            const uint32_t c0 = oetf_code<TRANSFER>(p, cur[k].x), c1 = oetf_code<TRANSFER>(p, cur[k].y);
+            const uint32_t c2 = oetf_code<TRANSFER>(p, cur[k].z), c3 = oetf_code<TRANSFER>(p, cur[k].w);
+            u32x2 pk = { c0 | (c1 << 16), c2 | (c3 << 16) };
+            reinterpret_cast<u32x2*>(my)[64 * k + lane] = pk;
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t dw[LDW];
+        if constexpr (PXL == 4) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v;
-                if constexpr (TRANSFER == AVIFGPU_TRANSFER_PQ) v = fast_linear_to_pq(f[e], p.pq_mult);
-                else if constexpr (TRANSFER == AVIFGPU_TRANSFER_SMPTE428) v = fast_linear_to_smpte428(f[e]);
-                else if constexpr (TRANSFER == AVIFGPU_TRANSFER_HLG) v = fast_linear_to_hlg(f[e]);
-                else v = f[e];
-                c[e] = (uint32_t)__builtin_amdgcn_fmed3f(v * p.maxf, 0.0f, p.maxf);
+            for (int j = 0; j < 3; ++j) {
+                const u32x2 v = reinterpret_cast<const u32x2*>(my)[3 * lane + j];
+                dw[2 * j] = v.x; dw[2 * j + 1] = v.y;
             }
-            reinterpret_cast<uint4*>(my)[64 * k + lane] = make_uint4(c[0], c[1], c[2], c[3]);
-        }
-        // wave-private strip: DS ops of one wave complete in order (lgkmcnt) and the accesses alias, so no
-        // s_barrier is needed; wave_barrier only pins the compiler's schedule.
-        __builtin_amdgcn_wave_barrier();
-
-        uint32_t px[12];
+        } else {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const uint4 v = reinterpret_cast<const uint4*>(my)[3 * lane + k];
-            px[4 * k] = v.x; px[4 * k + 1] = v.y; px[4 * k + 2] = v.z; px[4 * k + 3] = v.w;
+            for (int j = 0; j < 3; ++j) {
+                const u32x4 v = reinterpret_cast<const u32x4*>(my)[3 * lane + j];
+                dw[4 * j] = v.x; dw[4 * j + 1] = v.y; dw[4 * j + 2] = v.z; dw[4 * j + 3] = v.w;
+            }
         }
         __builtin_amdgcn_wave_barrier();
 
-        uint32_t yv[4], cbv[4], crv[4];
+        uint32_t yv[PXL], cbv[PXL], crv[PXL];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t q[4] = { px[3 * i], px[3 * i + 1], px[3 * i + 2], 0u };
+        for (int i = 0; i < PXL; ++i) {
+            uint32_t q[4];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int e = 3 * i + c;
+                q[c] = (e & 1) ? (dw[e >> 1] >> 16) : (dw[e >> 1] & 0xffffu);
+            }
+            q[3] = 0;
             yv[i] = stage_b_luma(p, q);
             if (p.identity) { cbv[i] = q[2]; crv[i] = q[0]; }
             else {
@@ -277,10 +343,38 @@ __global__ __launch_bounds__(256) void write_rgb32_ycbcr444_lds(const WriteParam
                 crv[i] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
             }
         }
-        const long long xoff = ((long long)sx * 256 + 4 * lane) * 2;
-        *reinterpret_cast<uint2*>(p.dst[0] + (long long)r * p.dst_stride[0] + xoff) = make_uint2(yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16));
-        *reinterpret_cast<uint2*>(p.dst[1] + (long long)r * p.dst_stride[1] + xoff) = make_uint2(cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16));
-        *reinterpret_cast<uint2*>(p.dst[2] + (long long)r * p.dst_stride[2] + xoff) = make_uint2(crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16));
+        const uint32_t r = sidx / spans_per_row;
+        const uint32_t sx = sidx - r * spans_per_row;
+        const long long xoff = ((long long)sx * SPAN_PX + (long long)PXL * lane) * 2;
+        uint8_t* d0 = p.dst[0] + (long long)r * p.dst_stride[0] + xoff;
+        uint8_t* d1 = p.dst[1] + (long long)r * p.dst_stride[1] + xoff;
+        uint8_t* d2 = p.dst[2] + (long long)r * p.dst_stride[2] + xoff;
+        if constexpr (PXL == 4) {
+            u32x2 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16) };
+            u32x2 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16) };
+            u32x2 c = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16) };
+            stream_store<NT>(reinterpret_cast<u32x2*>(d0), a);
+            stream_store<NT>(reinterpret_cast<u32x2*>(d1), b);
+            stream_store<NT>(reinterpret_cast<u32x2*>(d2), c);
+        } else {
+            u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
+            u32x4 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16), cbv[4] | (cbv[5] << 16), cbv[6] | (cbv[7] << 16) };
+            u32x4 c = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16), crv[4] | (crv[5] << 16), crv[6] | (crv[7] << 16) };
+            stream_store<NT>(reinterpret_cast<u32x4*>(d0), a);
+            stream_store<NT>(reinterpret_cast<u32x4*>(d1), b);
+            stream_store<NT>(reinterpret_cast<u32x4*>(d2), c);
+        }
+
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) cur[k] = nxt[k];
+        } else {
+            if (sidx + step < limit) {
+                const f32x4* sp = span_src(sidx + step);
+#pragma unroll
+                for (int k = 0; k < K; ++k) cur[k] = stream_load<NT>(sp + 64 * k + lane);
+            }
+        }
     }
 }
 
@@ -288,7 +382,7 @@ __global__ __launch_bounds__(256) void write_rgb32_ycbcr444_lds(const WriteParam
 static inline int grid_for(long long threads_needed)
 {
     long long blocks = (threads_needed + 255) / 256;
-    const long long cap = 256LL * 16;          // 256 CUs x 16 resident 256-thread blocks worth of work per sweep
+    const long long cap = 256LL * 64;          // grid-stride beyond 16k blocks (larger grids measured faster than 2-4k)
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
@@ -359,31 +453,41 @@ static hipError_t launch_planes(const WriteParams& p, int planes, bool dst16, in
 hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16, int output, int xs, int ys,
                         int variant, hipStream_t st, const char** name)
 {
-    // hot path: RGB f32 (no alpha) -> YCbCr 4:4:4 u16, rows 16-B aligned, width % 256 == 0
-    if (variant == kHotLdsTranspose && depth == 32 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR &&
-        xs == 0 && ys == 0 && (p.width & 255) == 0 && (p.src_row_bytes & 15) == 0 &&
-        (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
+    // hot path: RGB f32 (no alpha) -> YCbCr 4:4:4 u16 with aligned rows; `variant` is a tuning word:
+    //   bit0 enable, bit1 PXL=8 (else 4), bit2 non-temporal, bit3 prefetch, bit4 XCD-contiguous mapping;
+    //   bits 8.. = blocks (0 = default).
+    if ((variant & 1) && depth == 32 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 0 && ys == 0 &&
+        (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |
-          (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2]) & 7) == 0) {
-        const long long spans = (long long)(p.width >> 8) * p.nrows;
-        if (spans == 0) return hipSuccess;
-        long long blocks = (spans + 3) / 4;
-        if (blocks > 256LL * 16) blocks = 256LL * 16;
-        switch (p.transfer) {
-        case AVIFGPU_TRANSFER_PQ:
-            *name = "write_rgb32_ycbcr444_lds<PQ>";
-            hipLaunchKernelGGL((write_rgb32_ycbcr444_lds<AVIFGPU_TRANSFER_PQ, false>), dim3((int)blocks), dim3(256), 0, st, p); break;
-        case AVIFGPU_TRANSFER_HLG:
-            *name = "write_rgb32_ycbcr444_lds<HLG>";
-            hipLaunchKernelGGL((write_rgb32_ycbcr444_lds<AVIFGPU_TRANSFER_HLG, false>), dim3((int)blocks), dim3(256), 0, st, p); break;
-        case AVIFGPU_TRANSFER_SMPTE428:
-            *name = "write_rgb32_ycbcr444_lds<SMPTE428>";
-            hipLaunchKernelGGL((write_rgb32_ycbcr444_lds<AVIFGPU_TRANSFER_SMPTE428, false>), dim3((int)blocks), dim3(256), 0, st, p); break;
-        default:
-            *name = "write_rgb32_ycbcr444_lds<Clip>";
-            hipLaunchKernelGGL((write_rgb32_ycbcr444_lds<AVIFGPU_TRANSFER_CLIP, false>), dim3((int)blocks), dim3(256), 0, st, p); break;
+          (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2]) & 15) == 0) {
+        const bool px8 = (variant & 2) && (p.width % 512) == 0;
+        if (px8 || (p.width % 256) == 0) {
+            const bool nt = variant & 4, pf = variant & 8, xm = variant & 16;
+            const long long spans = (long long)(p.width / (px8 ? 512 : 256)) * p.nrows;
+            if (spans == 0) return hipSuccess;
+            if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
+            long long blocks = (spans + 3) / 4;
+            const long long cap = (variant >> 8) ? (variant >> 8) : 256LL * 64;
+            if (blocks > cap) blocks = cap;
+            if (xm) blocks = (blocks + 7) & ~7LL;
+            static thread_local char label[96];
+            snprintf(label, sizeof(label), "write_rgb32_ycbcr444_hot<transfer=%d,pxl=%d,nt=%d,prefetch=%d,xcdmap=%d>",
+                     p.transfer, px8 ? 8 : 4, (int)nt, (int)pf, (int)xm);
+            *name = label;
+#define AG_HOT5(TR, PX, NT_, PF_, XM_) hipLaunchKernelGGL((write_rgb32_ycbcr444_hot<TR, PX, NT_, PF_, XM_>), dim3((int)blocks), dim3(256), 0, st, p)
+#define AG_HOT4(TR, PX, NT_, PF_) do { if (xm) AG_HOT5(TR, PX, NT_, PF_, true); else AG_HOT5(TR, PX, NT_, PF_, false); } while (0)
+#define AG_HOT3(TR, PX, NT_) do { if (pf) AG_HOT4(TR, PX, NT_, true); else AG_HOT4(TR, PX, NT_, false); } while (0)
+#define AG_HOT2(TR, PX) do { if (nt) AG_HOT3(TR, PX, true); else AG_HOT3(TR, PX, false); } while (0)
+#define AG_HOT1(TR) do { if (px8) AG_HOT2(TR, 8); else AG_HOT2(TR, 4); } while (0)
+            switch (p.transfer) {
+            case AVIFGPU_TRANSFER_PQ:       AG_HOT1(AVIFGPU_TRANSFER_PQ); break;
+            case AVIFGPU_TRANSFER_HLG:      AG_HOT1(AVIFGPU_TRANSFER_HLG); break;
+            case AVIFGPU_TRANSFER_SMPTE428: AG_HOT1(AVIFGPU_TRANSFER_SMPTE428); break;
+            default:                        AG_HOT1(AVIFGPU_TRANSFER_CLIP); break;
+            }
+            return hipGetLastError();
+            }
         }
-        return hipGetLastError();
     }
     switch (depth) {
     case 8:  return launch_planes<8>(p, planes, dst16, output, xs, ys, st, name);

@@ -54,8 +54,10 @@ def main():
     ap.add_argument("--bits", type=int, default=10)
     ap.add_argument("--chroma", choices=["444", "422", "420"], default="444")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--transfer", choices=["pq", "clip"], default="pq", help="clip = same traffic without the PQ math (diagnostic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=8192, help="rows of the frame the CPU baseline converts")
+    ap.add_argument("--sweep", default="", help="comma list of hot-kernel tuning words to time (diagnostic table on stderr)")
     ap.add_argument("--pcie", action="store_true", help="also time the host-buffer (PCIe-inclusive) entry point")
     args = ap.parse_args()
 
@@ -82,7 +84,8 @@ def main():
     gpu = pkg.AvifGpu(local_rank)
     W, H = args.width, args.height
     chroma = {"444": pkg.CHROMA_444, "422": pkg.CHROMA_422, "420": pkg.CHROMA_420}[args.chroma]
-    desc = pkg.WriteDesc(width=W, height=H, depth=32, planes=3, bit_depth=args.bits, transfer=pkg.TRANSFER_PQ,
+    desc = pkg.WriteDesc(width=W, height=H, depth=32, planes=3, bit_depth=args.bits,
+                         transfer=pkg.TRANSFER_PQ if args.transfer == 'pq' else pkg.TRANSFER_CLIP,
                          peak_nits=80, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR, chroma=chroma,
                          matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020)
 
@@ -106,11 +109,30 @@ def main():
         planes.append(torch.empty((h, w * ssz), dtype=torch.uint8, device=dev))
     ptrs = [p.data_ptr() for p in planes] + [None]
     strides = [p.stride(0) for p in planes] + [0]
-    stream = torch.cuda.current_stream(dev)
+    stream = torch.cuda.Stream(dev)            # the launch stream; the HIP events below are recorded on it
+    torch.cuda.synchronize(dev)
 
     def step():
         gpu.write_rows(desc, row0, nrows, src.data_ptr(), src.stride(0) * 4, ptrs, strides,
                        mem=pkg.MEM_DEVICE, stream=stream.cuda_stream)
+
+    if args.sweep:
+        lib = pkg.load()
+        for word in args.sweep.split(","):
+            v = int(word, 0)
+            lib.avifgpu_set_hot_variant(v)
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize(dev)
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(40)]
+            for a, b in evs:
+                a.record(stream); step(); b.record(stream)
+            torch.cuda.synchronize(dev)
+            ts = sorted(a.elapsed_time(b) for a, b in evs)
+            ab = gpu.write_algorithmic_bytes(desc, nrows)
+            print(f"sweep {word:>10s} p10={ts[4]:.4f} p50={ts[20]:.4f} mean={sum(ts)/len(ts):.4f} ms  "
+                  f"{ab / (sum(ts)/len(ts)) / 1e6:8.1f} GB/s  {gpu.last_kernel()}", file=sys.stderr, flush=True)
+        lib.avifgpu_set_hot_variant(1 | 2 | 4)
 
     for _ in range(args.warmup):
         step()
@@ -159,7 +181,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"{W}x{H} RGB f32 -> PQ(80 nits) -> {args.bits}-bit BT.2020-NCL YCbCr {args.chroma} planes "
+            "workload": f"{W}x{H} RGB f32 -> {'PQ(80 nits)' if args.transfer == 'pq' else 'Clip'} -> {args.bits}-bit BT.2020-NCL YCbCr {args.chroma} planes "
                         f"(BASELINE.json configs[3])",
             "rows_per_gpu": nrows,
             "frames_per_step": world if args.scaling == "weak" else 1,

@@ -13,9 +13,11 @@
  *     (reference src/common/YUVDecode.h:29-145, bodies YuvDecode.cpp:55-696).
  *
  * Everything crossing this boundary is plain C: PODs, raw pointers, sizes.  No C++ types, no
- * torch types.  Pointers are either all host pointers (AVIFGPU_MEM_HOST: the library stages
- * through pinned memory) or all device pointers (AVIFGPU_MEM_DEVICE: zero-copy, kernels are
- * enqueued on `stream` and the call returns without synchronising).
+ * torch types.  Pointers are either all host pointers (AVIFGPU_MEM_HOST: the library stages the tile
+ * through its own device buffers on its own stream and returns when the planes are back in host
+ * memory; `stream` is ignored) or all device pointers (AVIFGPU_MEM_DEVICE: zero-copy, the kernel is
+ * enqueued on `stream` -- a hipStream_t, NULL = HIP's default stream -- and the call returns without
+ * synchronising).
  *
  * Return values are Photoshop OSErr codes (reference error convention: src/common/Write.cpp:345-364,
  * src/common/Read.cpp:531-550): 0 = noErr.
@@ -257,6 +259,10 @@ int32_t avifgpu_write_plane_geometry(const avifgpu_write_desc* desc, int32_t pla
                                      int32_t* bytes_per_sample, int32_t* samples_per_pixel);
 int64_t avifgpu_write_algorithmic_bytes(const avifgpu_write_desc* desc, int32_t nrows); /* in + out */
 int64_t avifgpu_read_algorithmic_bytes(const avifgpu_read_desc* desc, int32_t nrows);
+
+/* Tuning hook for benchmarks (not part of the reference mapping): selects the implementation variant of the
+ * dominant kernel; see avif-format_amd/csrc/kernel_params.h.  Results are identical for every value. */
+void avifgpu_set_hot_variant(int32_t variant);
 
 /* Name + last launch geometry of the kernel the previous *_rows call dispatched (for bench/profiles). */
 const char* avifgpu_last_kernel_name(void);

@@ -1,6 +1,6 @@
 """GPU parity, read direction: heif_image planes -> FormatRecord rows through the C-ABI vs the CPU oracle.
 8/16-bit host rows are bit-exact (T1).  32-bit float rows go through PQ/HLG/SMPTE-428 EOTFs built on native
-v_log/v_exp: tolerance |gpu - oracle| <= 5e-5 * |oracle| + 1e-9 (T2; the reference's own float powf chain carries
+v_log/v_exp: tolerance |gpu - oracle| <= 1e-4 * |oracle| + 1e-9 (T2; the reference's own float powf chain carries
 ~3e-6 relative uncertainty at the dark end)."""
 import numpy as np
 import pytest
@@ -11,7 +11,7 @@ import harness
 pkg = harness.pkg
 pytestmark = pytest.mark.gpu
 
-T2_RTOL, T2_ATOL = 5e-5, 1e-9
+T2_RTOL, T2_ATOL = 1e-4, 1e-9
 
 
 def _check(cid, kw, got, want):

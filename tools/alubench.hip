@@ -1,0 +1,76 @@
+// alubench.hip -- VALU issue-rate probes on gfx950: plain / packed / transcendental f32, to size the PQ curve's cost.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <int OP>
+__global__ __launch_bounds__(256) void k(float* out, int iters, float seed)
+{
+    float a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = seed + 0.001f * (threadIdx.x + i);
+    f2 b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = f2{a[2 * i], a[2 * i + 1]};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if constexpr (OP == 0) a[i] = __builtin_fmaf(a[i], 1.0001f, 0.5f);
+            if constexpr (OP == 1) a[i] = __builtin_amdgcn_exp2f(a[i]);
+            if constexpr (OP == 2) a[i] = __builtin_amdgcn_logf(a[i]);
+            if constexpr (OP == 3) a[i] = __builtin_amdgcn_rcpf(a[i]);
+            if constexpr (OP == 5) a[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(a[i], 0.5f, 0.25f));          // 1 trans + 1 fma
+            if constexpr (OP == 6) a[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(__builtin_fmaf(__builtin_fmaf(a[i], 0.5f, 0.25f), 0.7f, 0.1f), 0.9f, 0.2f)); // 1 trans + 3 fma
+            if constexpr (OP == 7) a[i] = __builtin_amdgcn_sqrtf(a[i]);
+        }
+        if constexpr (OP == 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b[i] = b[i] * f2{1.0001f, 1.0002f} + f2{0.5f, 0.25f};   // v_pk_fma_f32 (2 lanes-ops per lane)
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += a[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += b[i].x + b[i].y;
+    if (s == 123.25f) out[0] = s;
+}
+
+template <int OP> void run(const char* name, double ops_per_iter_per_lane)
+{
+    float* d; CK(hipMalloc(&d, 64));
+    const int blocks = 256 * 8, iters = 2000;     // 8 blocks x 4 waves = 32 waves/CU
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    hipLaunchKernelGGL((k<OP>), dim3(blocks), dim3(256), 0, 0, d, iters, 1.5f);
+    CK(hipDeviceSynchronize());
+    std::vector<float> ts;
+    for (int r = 0; r < 5; ++r) {
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL((k<OP>), dim3(blocks), dim3(256), 0, 0, d, iters, 1.5f);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b)); ts.push_back(ms);
+    }
+    std::sort(ts.begin(), ts.end());
+    const double lane_ops = (double)blocks * 256 * iters * ops_per_iter_per_lane;
+    const double per_simd_wave_instr = lane_ops / 64.0 / 1024.0;          // wave-instructions per SIMD
+    printf("%-28s %8.3f ms  %8.2f Tlane-op/s   %6.2f cycles/wave-instr @2.4GHz-equivalent\n", name, ts[2],
+           lane_ops / ts[2] / 1e9, ts[2] * 1e-3 * 2.4e9 / per_simd_wave_instr);
+    CK(hipFree(d));
+}
+
+int main()
+{
+    run<0>("v_fma_f32", 8);
+    run<4>("v_pk_fma_f32 (2 per instr)", 8);
+    run<1>("v_exp_f32", 8);
+    run<2>("v_log_f32", 8);
+    run<3>("v_rcp_f32", 8);
+    run<7>("v_sqrt_f32", 8);
+    run<5>("exp + 1 fma (per pair)", 8);
+    run<6>("exp + 3 fma (per quad)", 8);
+    return 0;
+}
