@@ -14,6 +14,8 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_void_p
 
 from . import sharding  # noqa: E402,F401  (row-tile partition used by bench.py / host shim tests)
+from . import host  # noqa: E402,F401      (ctypes mirror of include/avifgpu_host.h)
+from . import distrib  # noqa: E402,F401   (barrier + MAX-over-ranks for bench.py)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libavifgpu.so")
@@ -133,7 +135,7 @@ def load() -> ctypes.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C avif-format_amd`.  There is no CPU fallback.")
-        _lib = bind(ctypes.CDLL(LIB_PATH))
+        _lib = bind(bind(ctypes.CDLL(LIB_PATH)), host.HOST_ABI)
     return _lib
 
 

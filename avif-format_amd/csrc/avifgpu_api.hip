@@ -21,6 +21,15 @@ hipError_t launch_read(const ReadParams& p, int colorspace, int depth, bool alph
                        hipStream_t st, const char** name);
 }
 
+namespace avifgpu {
+int wait_slot(int slot);
+int write_rows_host_enqueue(const avifgpu_write_desc* d, int row0, int nrows, const void* src, int64_t src_row_bytes,
+                            void* const dst[4], const int64_t dst_stride[4], int slot);
+int read_rows_host_enqueue(const avifgpu_read_desc* d, int row0, int nrows, const void* const src[4], const int64_t src_stride[4],
+                           void* dst, int64_t dst_row_bytes, int slot);
+void set_error(const char* msg);
+}
+
 using namespace avifgpu;
 
 namespace {
@@ -41,9 +50,14 @@ struct Context {
     bool ready = false;
     int device = -1;
     hipStream_t stream = nullptr;
-    // device staging for AVIFGPU_MEM_HOST calls (grown on demand, reused across tiles)
-    void* d_in = nullptr;  size_t d_in_cap = 0;
-    void* d_out = nullptr; size_t d_out_cap = 0;
+    // device staging for host-pointer calls: two slots so the host shim can have one tile in flight while the
+    // host fills / drains the other (grown on demand, reused across tiles)
+    struct Slot {
+        void* d_in = nullptr;  size_t d_in_cap = 0;
+        void* d_out = nullptr; size_t d_out_cap = 0;
+        hipEvent_t done = nullptr;
+        bool pending = false;
+    } slot[2];
     int hot_variant = kHotDefault;
 } g_ctx;
 
@@ -326,6 +340,9 @@ int32_t avifgpu_init(int32_t device_index)
     if ((e = hipSetDevice(device_index)) != hipSuccess) return hip_fail(e, "hipSetDevice", AVIFGPU_formatBadParameters);
     if (!g_ctx.stream && (e = hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking)) != hipSuccess)
         return hip_fail(e, "hipStreamCreate", AVIFGPU_memFullErr);
+    for (auto& sl : g_ctx.slot)
+        if (!sl.done && (e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming)) != hipSuccess)
+            return hip_fail(e, "hipEventCreate", AVIFGPU_memFullErr);
     g_ctx.device = device_index;
     g_ctx.ready = true;
     if (const char* v = getenv("AVIFGPU_HOT_VARIANT")) g_ctx.hot_variant = (int)strtol(v, nullptr, 0);   // tuning only
@@ -337,10 +354,13 @@ void avifgpu_shutdown(void)
     std::lock_guard<std::mutex> lk(g_ctx.mu);
     if (!g_ctx.ready) return;
     (void)hipStreamSynchronize(g_ctx.stream);
-    if (g_ctx.d_in) (void)hipFree(g_ctx.d_in);
-    if (g_ctx.d_out) (void)hipFree(g_ctx.d_out);
+    for (auto& sl : g_ctx.slot) {
+        if (sl.d_in) (void)hipFree(sl.d_in);
+        if (sl.d_out) (void)hipFree(sl.d_out);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        sl = Context::Slot();
+    }
     (void)hipStreamDestroy(g_ctx.stream);
-    g_ctx.d_in = g_ctx.d_out = nullptr; g_ctx.d_in_cap = g_ctx.d_out_cap = 0;
     g_ctx.stream = nullptr; g_ctx.ready = false; g_ctx.device = -1;
 }
 
@@ -440,37 +460,9 @@ int32_t avifgpu_write_rows(const avifgpu_write_desc* d, int32_t row0, int32_t nr
     }
     if (mem_kind != AVIFGPU_MEM_HOST) return fail(AVIFGPU_formatBadParameters, "bad mem_kind %d", mem_kind);
 
-    // ---- host buffers: stage tile in, convert, stage planes out (synchronous, like the reference call) ----
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    hipStream_t st = g_ctx.stream;
-    const size_t in_pitch = align256((size_t)min_src_row);
-    if ((err = ensure(&g_ctx.d_in, &g_ctx.d_in_cap, in_pitch * (size_t)nrows))) return err;
-    size_t off[4] = {0, 0, 0, 0}, pitch[4] = {0, 0, 0, 0}, out_total = 0;
-    int prow[4] = {0, 0, 0, 0}; int64_t pbytes[4] = {0, 0, 0, 0};
-    for (int pl = 0; pl < 4; ++pl) {
-        if (!write_plane_used(d, g, pl)) continue;
-        write_plane_extent(d, g, pl, nrows, prow[pl], pbytes[pl]);
-        pitch[pl] = align256((size_t)pbytes[pl]);
-        off[pl] = out_total;
-        out_total += pitch[pl] * (size_t)prow[pl];
-    }
-    if ((err = ensure(&g_ctx.d_out, &g_ctx.d_out_cap, out_total))) return err;
-    hipError_t e = hipMemcpy2DAsync(g_ctx.d_in, in_pitch, src, (size_t)src_row_bytes, (size_t)min_src_row, (size_t)nrows, hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) return hip_fail(e, "H2D copy", AVIFGPU_writErr);
-    p.src = (const uint8_t*)g_ctx.d_in; p.src_row_bytes = (int64_t)in_pitch;
-    for (int pl = 0; pl < 4; ++pl) {
-        p.dst[pl] = write_plane_used(d, g, pl) ? (uint8_t*)g_ctx.d_out + off[pl] : nullptr;
-        p.dst_stride[pl] = (int64_t)pitch[pl];
-    }
-    e = launch_write(p, d->depth, d->planes, g.dst16, d->output, g.xs, g.ys, g_ctx.hot_variant, st, &g_kernel);
-    if (e != hipSuccess) return hip_fail(e, "kernel launch", AVIFGPU_writErr);
-    for (int pl = 0; pl < 4; ++pl) {
-        if (!write_plane_used(d, g, pl)) continue;
-        e = hipMemcpy2DAsync(dst[pl], (size_t)dst_stride[pl], (uint8_t*)g_ctx.d_out + off[pl], pitch[pl], (size_t)pbytes[pl], (size_t)prow[pl], hipMemcpyDeviceToHost, st);
-        if (e != hipSuccess) return hip_fail(e, "D2H copy", AVIFGPU_writErr);
-    }
-    if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "stream synchronize", AVIFGPU_writErr);
-    return 0;
+    err = avifgpu::write_rows_host_enqueue(d, row0, nrows, src, src_row_bytes, dst, dst_stride, 0);
+    if (err) return err;
+    return avifgpu::wait_slot(0);
 }
 
 int32_t avifgpu_read_rows(const avifgpu_read_desc* d, int32_t row0, int32_t nrows,
@@ -508,8 +500,93 @@ int32_t avifgpu_read_rows(const avifgpu_read_desc* d, int32_t row0, int32_t nrow
     }
     if (mem_kind != AVIFGPU_MEM_HOST) return fail(AVIFGPU_formatBadParameters, "bad mem_kind %d", mem_kind);
 
+    err = avifgpu::read_rows_host_enqueue(d, row0, nrows, src, src_stride, dst, dst_row_bytes, 0);
+    if (err) return err;
+    return avifgpu::wait_slot(0);
+}
+
+} // extern "C"
+
+
+// ======================================================================================================
+// Internal (C++) staging API, also used by host_shim.cpp to pipeline tiles: enqueue on the library stream,
+// return immediately, wait per slot.
+// ======================================================================================================
+namespace avifgpu {
+
+int wait_slot(int slot)
+{
+    Context::Slot& sl = g_ctx.slot[slot & 1];
+    if (!sl.pending) return 0;
+    const hipError_t e = hipEventSynchronize(sl.done);
+    sl.pending = false;
+    if (e != hipSuccess) return hip_fail(e, "event synchronize", AVIFGPU_writErr);
+    return 0;
+}
+
+int write_rows_host_enqueue(const avifgpu_write_desc* d, int row0, int nrows, const void* src, int64_t src_row_bytes,
+                            void* const dst[4], const int64_t dst_stride[4], int slot)
+{
+    WriteGeom g;
+    int err = check_write(d, row0, nrows, g);
+    if (err) return err;
+    if (!g_ctx.ready) return fail(AVIFGPU_formatBadParameters, "avifgpu_init has not succeeded: no HIP device bound (no CPU fallback)");
+    if (nrows == 0) return 0;
+    WriteParams p;
+    if ((err = fill_write_params(d, row0, nrows, g, p))) return err;
+    if ((err = wait_slot(slot))) return err;
+
     std::lock_guard<std::mutex> lk(g_ctx.mu);
+    Context::Slot& sl = g_ctx.slot[slot & 1];
     hipStream_t st = g_ctx.stream;
+    const int64_t min_src_row = (int64_t)d->width * d->planes * (d->depth / 8);
+    const size_t in_pitch = align256((size_t)min_src_row);
+    if ((err = ensure(&sl.d_in, &sl.d_in_cap, in_pitch * (size_t)nrows))) return err;
+    size_t off[4] = {0, 0, 0, 0}, pitch[4] = {0, 0, 0, 0}, out_total = 0;
+    int prow[4] = {0, 0, 0, 0}; int64_t pbytes[4] = {0, 0, 0, 0};
+    for (int pl = 0; pl < 4; ++pl) {
+        if (!write_plane_used(d, g, pl)) continue;
+        write_plane_extent(d, g, pl, nrows, prow[pl], pbytes[pl]);
+        pitch[pl] = align256((size_t)pbytes[pl]);
+        off[pl] = out_total;
+        out_total += pitch[pl] * (size_t)prow[pl];
+    }
+    if ((err = ensure(&sl.d_out, &sl.d_out_cap, out_total))) return err;
+    hipError_t e = hipMemcpy2DAsync(sl.d_in, in_pitch, src, (size_t)src_row_bytes, (size_t)min_src_row, (size_t)nrows, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return hip_fail(e, "H2D copy", AVIFGPU_writErr);
+    p.src = (const uint8_t*)sl.d_in; p.src_row_bytes = (int64_t)in_pitch;
+    for (int pl = 0; pl < 4; ++pl) {
+        p.dst[pl] = write_plane_used(d, g, pl) ? (uint8_t*)sl.d_out + off[pl] : nullptr;
+        p.dst_stride[pl] = (int64_t)pitch[pl];
+    }
+    e = launch_write(p, d->depth, d->planes, g.dst16, d->output, g.xs, g.ys, g_ctx.hot_variant, st, &g_kernel);
+    if (e != hipSuccess) return hip_fail(e, "kernel launch", AVIFGPU_writErr);
+    for (int pl = 0; pl < 4; ++pl) {
+        if (!write_plane_used(d, g, pl)) continue;
+        e = hipMemcpy2DAsync(dst[pl], (size_t)dst_stride[pl], (uint8_t*)sl.d_out + off[pl], pitch[pl], (size_t)pbytes[pl], (size_t)prow[pl], hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) return hip_fail(e, "D2H copy", AVIFGPU_writErr);
+    }
+    if ((e = hipEventRecord(sl.done, st)) != hipSuccess) return hip_fail(e, "event record", AVIFGPU_writErr);
+    sl.pending = true;
+    return 0;
+}
+
+int read_rows_host_enqueue(const avifgpu_read_desc* d, int row0, int nrows, const void* const src[4], const int64_t src_stride[4],
+                           void* dst, int64_t dst_row_bytes, int slot)
+{
+    ReadGeom g;
+    int err = check_read(d, row0, nrows, g);
+    if (err) return err;
+    if (!g_ctx.ready) return fail(AVIFGPU_formatBadParameters, "avifgpu_init has not succeeded: no HIP device bound (no CPU fallback)");
+    if (nrows == 0) return 0;
+    ReadParams p;
+    if ((err = fill_read_params(d, nrows, g, p))) return err;
+    if ((err = wait_slot(slot))) return err;
+
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    Context::Slot& sl = g_ctx.slot[slot & 1];
+    hipStream_t st = g_ctx.stream;
+    const int64_t min_dst_row = (int64_t)d->width * g.nch * (d->depth / 8);
     size_t off[4] = {0, 0, 0, 0}, pitch[4] = {0, 0, 0, 0}, in_total = 0;
     int prow[4] = {0, 0, 0, 0}; int64_t pbytes[4] = {0, 0, 0, 0};
     for (int pl = 0; pl < 4; ++pl) {
@@ -519,23 +596,26 @@ int32_t avifgpu_read_rows(const avifgpu_read_desc* d, int32_t row0, int32_t nrow
         off[pl] = in_total;
         in_total += pitch[pl] * (size_t)prow[pl];
     }
-    if ((err = ensure(&g_ctx.d_in, &g_ctx.d_in_cap, in_total))) return err;
+    if ((err = ensure(&sl.d_in, &sl.d_in_cap, in_total))) return err;
     const size_t out_pitch = align256((size_t)min_dst_row);
-    if ((err = ensure(&g_ctx.d_out, &g_ctx.d_out_cap, out_pitch * (size_t)nrows))) return err;
+    if ((err = ensure(&sl.d_out, &sl.d_out_cap, out_pitch * (size_t)nrows))) return err;
     hipError_t e;
     for (int pl = 0; pl < 4; ++pl) {
         if (!read_plane_used(d, g, pl)) continue;
-        e = hipMemcpy2DAsync((uint8_t*)g_ctx.d_in + off[pl], pitch[pl], src[pl], (size_t)src_stride[pl], (size_t)pbytes[pl], (size_t)prow[pl], hipMemcpyHostToDevice, st);
+        e = hipMemcpy2DAsync((uint8_t*)sl.d_in + off[pl], pitch[pl], src[pl], (size_t)src_stride[pl], (size_t)pbytes[pl], (size_t)prow[pl], hipMemcpyHostToDevice, st);
         if (e != hipSuccess) return hip_fail(e, "H2D copy", AVIFGPU_readErr);
-        p.src[pl] = (const uint8_t*)g_ctx.d_in + off[pl]; p.src_stride[pl] = (int64_t)pitch[pl];
+        p.src[pl] = (const uint8_t*)sl.d_in + off[pl]; p.src_stride[pl] = (int64_t)pitch[pl];
     }
-    p.dst = (uint8_t*)g_ctx.d_out; p.dst_row_bytes = (int64_t)out_pitch;
+    p.dst = (uint8_t*)sl.d_out; p.dst_row_bytes = (int64_t)out_pitch;
     e = launch_read(p, d->colorspace, d->depth, g.alpha, g.xs, g.ys, st, &g_kernel);
     if (e != hipSuccess) return hip_fail(e, "kernel launch", AVIFGPU_readErr);
-    e = hipMemcpy2DAsync(dst, (size_t)dst_row_bytes, g_ctx.d_out, out_pitch, (size_t)min_dst_row, (size_t)nrows, hipMemcpyDeviceToHost, st);
+    e = hipMemcpy2DAsync(dst, (size_t)dst_row_bytes, sl.d_out, out_pitch, (size_t)min_dst_row, (size_t)nrows, hipMemcpyDeviceToHost, st);
     if (e != hipSuccess) return hip_fail(e, "D2H copy", AVIFGPU_readErr);
-    if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(e, "stream synchronize", AVIFGPU_readErr);
+    if ((e = hipEventRecord(sl.done, st)) != hipSuccess) return hip_fail(e, "event record", AVIFGPU_readErr);
+    sl.pending = true;
     return 0;
 }
 
-} // extern "C"
+void set_error(const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
+
+} // namespace avifgpu

@@ -1,0 +1,379 @@
+// host_shim.cpp -- host-side mirror of the plug-in's conversion-layer entry points, above the C-ABI.
+//
+// Keeps the reference's operator interface for this path: the twelve free functions
+//   CreateHeifImage{Gray,RGB}{Eight,Sixteen,ThirtyTwo}Bit(formatRecord, alphaState, imageSize, saveOptions)
+//   ReadHeifImage{Gray,RGB}{Eight,Sixteen,ThirtyTwo}Bit(image, alphaState, nclxProfile, [loadOptions,] formatRecord)
+// (reference src/common/WriteHeifImage.h:29-63, ReadHeifImage.h:27-63) with the same argument meaning and the same
+// error behaviour (OSErrException / std::runtime_error / std::bad_alloc, mapped to OSErr at the C boundary the way
+// DoWriteStart / DoReadContinue map them, Write.cpp:345-364, Read.cpp:659-678).
+//
+// What is different by design (MI355X-first): the row loop asks the host for multi-row TILES sized from maxData
+// and keeps TWO tiles in flight -- while the GPU converts tile k (H2D -> kernel -> D2H on the library stream) the
+// host's advanceState() is already filling tile k+1 into the other pinned buffer.  abortProc is polled per tile.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <new>
+#include <stdexcept>
+
+#include "../../include/avifgpu_host.h"
+
+namespace avifgpu {
+int wait_slot(int slot);
+int write_rows_host_enqueue(const avifgpu_write_desc* d, int row0, int nrows, const void* src, int64_t src_row_bytes,
+                            void* const dst[4], const int64_t dst_stride[4], int slot);
+int read_rows_host_enqueue(const avifgpu_read_desc* d, int row0, int nrows, const void* const src[4], const int64_t src_stride[4],
+                           void* dst, int64_t dst_row_bytes, int slot);
+void set_error(const char* msg);
+}
+
+namespace avifgpu::host {
+
+using FormatRecordPtr = avifgpu_FormatRecord*;
+using VPoint = avifgpu_VPoint;
+using OSErr = avifgpu_OSErr;
+using SaveUIOptions = avifgpu_SaveUIOptions;
+using LoadUIOptions = avifgpu_LoadUIOptions;
+
+enum class AlphaState { None = AVIFGPU_ALPHA_NONE, Straight = AVIFGPU_ALPHA_STRAIGHT, Premultiplied = AVIFGPU_ALPHA_PREMULTIPLIED };
+
+// reference src/common/OSErrException.h:27
+struct OSErrException {
+    OSErr err;
+    explicit OSErrException(OSErr e) : err(e) {}
+    static void ThrowIfError(OSErr e) { if (e != AVIFGPU_noErr) throw OSErrException(e); }
+};
+
+// ---- the four Utilities.cpp helpers the path uses (reference Utilities.cpp:382-446) ----------------
+VPoint GetImageSize(const FormatRecordPtr formatRecord)
+{
+    VPoint size;
+    if (formatRecord->HostSupports32BitCoordinates && formatRecord->PluginUsing32BitCoordinates) {
+        size.h = formatRecord->imageSize32.h; size.v = formatRecord->imageSize32.v;
+    } else {
+        size.h = formatRecord->imageSize.h; size.v = formatRecord->imageSize.v;
+    }
+    return size;
+}
+
+void SetRect(FormatRecordPtr formatRecord, int32_t top, int32_t left, int32_t bottom, int32_t right)
+{
+    if (formatRecord->HostSupports32BitCoordinates && formatRecord->PluginUsing32BitCoordinates) {
+        formatRecord->theRect32 = { top, left, bottom, right };
+    } else {
+        formatRecord->theRect = { (int16_t)top, (int16_t)left, (int16_t)bottom, (int16_t)right };
+    }
+}
+
+bool IsMonochromeImage(const FormatRecordPtr formatRecord)
+{
+    switch (formatRecord->imageMode) {
+    case avifgpu_plugInModeGrayScale: case avifgpu_plugInModeGray16: case avifgpu_plugInModeGray32: return true;
+    default: return false;
+    }
+}
+
+bool HasAlphaChannel(const FormatRecordPtr formatRecord)
+{
+    switch (formatRecord->imageMode) {
+    case avifgpu_plugInModeGrayScale: case avifgpu_plugInModeGray16: case avifgpu_plugInModeGray32: return formatRecord->planes == 2;
+    case avifgpu_plugInModeRGBColor: case avifgpu_plugInModeRGB48: case avifgpu_plugInModeRGB96: return formatRecord->planes == 4;
+    default: return false;
+    }
+}
+
+// ---- pinned double buffer the host fills / drains (replaces ScopedBufferSuiteBuffer, Write.cpp:297-299) ----
+class TileBuffers {
+public:
+    TileBuffers(size_t bytes_each)
+    {
+        for (int i = 0; i < 2; ++i)
+            if (hipHostMalloc(&buf_[i], bytes_each, hipHostMallocDefault) != hipSuccess) { release(); throw std::bad_alloc(); }
+    }
+    ~TileBuffers() { release(); }
+    TileBuffers(const TileBuffers&) = delete;
+    TileBuffers& operator=(const TileBuffers&) = delete;
+    void* operator[](int i) const { return buf_[i & 1]; }
+private:
+    void release() { for (auto& b : buf_) { if (b) (void)hipHostFree(b); b = nullptr; } }
+    void* buf_[2] = { nullptr, nullptr };
+};
+
+struct ImageDeleter { void operator()(avifgpu_image* img) const { if (img) { avifgpu_image_free(img); delete img; } } };
+using ScopedHeifImage = std::unique_ptr<avifgpu_image, ImageDeleter>;      // reference ScopedHeif.h:37,50
+
+int rows_per_tile(int32_t max_data, int64_t row_bytes, int height, bool even)
+{
+    int64_t budget = max_data > 0 ? max_data : (64LL << 20);
+    budget = std::min<int64_t>(budget, std::numeric_limits<int32_t>::max());
+    int64_t rows = std::max<int64_t>(1, budget / std::max<int64_t>(row_bytes, 1));
+    rows = std::min<int64_t>(rows, height);
+    if (even && rows > 1) rows -= rows & 1;
+    if (even && rows < 2 && height > 1) rows = 2;           // a 4:2:0 block never straddles a tile
+    return (int)rows;
+}
+
+// ---- write ---------------------------------------------------------------------------------------------
+struct WritePlan { avifgpu_write_desc desc; int output; };
+
+// Shared body of the six CreateHeifImage* functions: FormatRecord set-up as DoWriteStart (Write.cpp:279-295), then
+// the tile loop that replaces WriteHeifImage.cpp:1017-1135 (and its five siblings).
+void CreateHeifImageInto(FormatRecordPtr formatRecord, AlphaState alphaState, const VPoint& imageSize,
+                         const SaveUIOptions& saveOptions, int output, int matrix, int primaries, avifgpu_image* img)
+{
+    const bool hasAlpha = alphaState != AlphaState::None;
+    const bool mono = IsMonochromeImage(formatRecord);
+    if (hasAlpha != HasAlphaChannel(formatRecord)) throw OSErrException(AVIFGPU_formatBadParameters);
+
+    formatRecord->planeBytes = (int16_t)((formatRecord->depth + 7) / 8);
+    formatRecord->loPlane = 0;
+    formatRecord->hiPlane = (int16_t)(formatRecord->planes - 1);
+    formatRecord->colBytes = (int16_t)(formatRecord->planes * formatRecord->planeBytes);
+    const uint64_t rowBytes = (uint64_t)imageSize.h * (uint64_t)formatRecord->colBytes;
+    if (rowBytes > (uint64_t)std::numeric_limits<int32_t>::max()) throw std::bad_alloc();   // Write.cpp:288-291
+    formatRecord->rowBytes = (int32_t)rowBytes;
+
+    avifgpu_write_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.width = imageSize.h; d.height = imageSize.v;
+    d.depth = formatRecord->depth; d.planes = formatRecord->planes;
+    d.bit_depth = saveOptions.imageBitDepth;
+    d.transfer = saveOptions.hdrTransferFunction;
+    d.peak_nits = saveOptions.pq.nominalPeakBrightness;
+    d.alpha_state = (int)alphaState;
+    d.output = output;
+    d.chroma = saveOptions.lossless ? AVIFGPU_CHROMA_444 : saveOptions.chromaSubsampling;   // Write.cpp:98-127
+    d.matrix_coefficients = matrix; d.color_primaries = primaries;
+    d.full_range = 1;                                                                        // WriteMetadata.cpp:46
+    d.chroma_downsampling = AVIFGPU_DOWNSAMPLE_AVERAGE;
+    d.chroma_zero_point = AVIFGPU_CHROMA_ZERO_LIBHEIF;
+
+    // describe the image the way CreateHeifImage / heif_image_add_plane do (WriteHeifImage.cpp:31-39,:63-85,:181-194)
+    img->width = d.width; img->height = d.height; img->bit_depth = d.bit_depth;
+    img->has_alpha = hasAlpha;
+    img->premultiplied_alpha = alphaState == AlphaState::Premultiplied;
+    if (output == AVIFGPU_OUT_YCBCR && !mono) { img->colorspace = AVIFGPU_COLORSPACE_YCBCR; img->chroma = d.chroma; }
+    else if (mono) { img->colorspace = AVIFGPU_COLORSPACE_MONOCHROME; img->chroma = AVIFGPU_CHROMA_MONOCHROME; }
+    else {
+        img->colorspace = AVIFGPU_COLORSPACE_RGB;
+        img->chroma = d.bit_depth == 8 ? (hasAlpha ? 11 : 10) : (hasAlpha ? 15 : 14);   // interleaved RGB(A) / RRGGBB(AA)_LE
+    }
+    if (!img->plane[0]) OSErrException::ThrowIfError(avifgpu_image_alloc(img));
+
+    const bool even = output == AVIFGPU_OUT_YCBCR && d.chroma == AVIFGPU_CHROMA_420;
+    const int ys = even ? 1 : 0;
+    const int tileRows = rows_per_tile(formatRecord->maxData, formatRecord->rowBytes, d.height, even);
+    TileBuffers buffers((size_t)tileRows * (size_t)formatRecord->rowBytes);
+
+    const int32_t left = 0, right = imageSize.h;
+    int slot = 0;
+    for (int32_t top = 0; top < imageSize.v; top += tileRows, slot ^= 1) {
+        if (formatRecord->abortProc && formatRecord->abortProc()) {                         // WriteHeifImage.cpp:1019-1022
+            (void)avifgpu::wait_slot(0); (void)avifgpu::wait_slot(1);
+            throw OSErrException(AVIFGPU_userCanceledErr);
+        }
+        const int32_t bottom = std::min(top + tileRows, imageSize.v);
+        // this buffer's previous tile (two iterations ago) must have left the host memory
+        OSErrException::ThrowIfError((OSErr)avifgpu::wait_slot(slot));
+        formatRecord->data = buffers[slot];
+        SetRect(formatRecord, top, left, bottom, right);
+        const OSErr herr = formatRecord->advanceState();                                    // host fills rows [top, bottom)
+        if (herr != AVIFGPU_noErr) { (void)avifgpu::wait_slot(0); (void)avifgpu::wait_slot(1); throw OSErrException(herr); }
+        // NOTE: ColorProfileConversion::ConvertRow (lcms2, WriteHeifImage.cpp:1031-1034) is the caller's hook: it is
+        // a no-op unless an ICC transform exists; INTEGRATION.md shows where the plug-in keeps calling it per row.
+
+        void* dst[4]; int64_t stride[4];
+        for (int pl = 0; pl < 4; ++pl) {
+            const bool chromaPlane = img->colorspace == AVIFGPU_COLORSPACE_YCBCR && (pl == 1 || pl == 2);
+            const int r = chromaPlane ? (top >> ys) : top;
+            dst[pl] = img->plane[pl] ? img->plane[pl] + (int64_t)r * img->stride[pl] : nullptr;
+            stride[pl] = img->stride[pl];
+        }
+        const int err = avifgpu::write_rows_host_enqueue(&d, top, bottom - top, formatRecord->data, formatRecord->rowBytes,
+                                                         dst, stride, slot);
+        if (err) { (void)avifgpu::wait_slot(0); (void)avifgpu::wait_slot(1); throw OSErrException((OSErr)err); }
+    }
+    OSErrException::ThrowIfError((OSErr)avifgpu::wait_slot(0));
+    OSErrException::ThrowIfError((OSErr)avifgpu::wait_slot(1));
+    formatRecord->data = nullptr;
+}
+
+ScopedHeifImage CreateOwned(FormatRecordPtr formatRecord, AlphaState alphaState, const VPoint& imageSize,
+                            const SaveUIOptions& saveOptions, int16_t depth, bool mono)
+{
+    if (formatRecord->depth != depth || IsMonochromeImage(formatRecord) != mono) throw OSErrException(AVIFGPU_formatBadParameters);
+    ScopedHeifImage image(new avifgpu_image());
+    std::memset(image.get(), 0, sizeof(avifgpu_image));
+    CreateHeifImageInto(formatRecord, alphaState, imageSize, saveOptions, AVIFGPU_OUT_REFERENCE,
+                        AVIFGPU_MATRIX_BT601, AVIFGPU_PRIMARIES_BT709, image.get());
+    return image;
+}
+
+// The reference's six names (WriteHeifImage.h:29-63).  Each returns what its namesake builds.
+ScopedHeifImage CreateHeifImageGrayEightBit(FormatRecordPtr fr, AlphaState a, const VPoint& s, const SaveUIOptions& o) { return CreateOwned(fr, a, s, o, 8, true); }
+ScopedHeifImage CreateHeifImageGraySixteenBit(FormatRecordPtr fr, AlphaState a, const VPoint& s, const SaveUIOptions& o) { return CreateOwned(fr, a, s, o, 16, true); }
+ScopedHeifImage CreateHeifImageGrayThirtyTwoBit(FormatRecordPtr fr, AlphaState a, const VPoint& s, const SaveUIOptions& o) { return CreateOwned(fr, a, s, o, 32, true); }
+ScopedHeifImage CreateHeifImageRGBEightBit(FormatRecordPtr fr, AlphaState a, const VPoint& s, const SaveUIOptions& o) { return CreateOwned(fr, a, s, o, 8, false); }
+ScopedHeifImage CreateHeifImageRGBSixteenBit(FormatRecordPtr fr, AlphaState a, const VPoint& s, const SaveUIOptions& o) { return CreateOwned(fr, a, s, o, 16, false); }
+ScopedHeifImage CreateHeifImageRGBThirtyTwoBit(FormatRecordPtr fr, AlphaState a, const VPoint& s, const SaveUIOptions& o) { return CreateOwned(fr, a, s, o, 32, false); }
+
+// ---- read ------------------------------------------------------------------------------------------------
+void ReadHeifImageCommon(const avifgpu_image* image, AlphaState alphaState, const avifgpu_nclx* nclxProfile,
+                         const LoadUIOptions* loadOptions, FormatRecordPtr formatRecord)
+{
+    if (formatRecord->depth == 32 && nclxProfile == nullptr) throw std::runtime_error("The nclxProfile is null.");   // ReadHeifImage.cpp:870,956
+    const VPoint imageSize = GetImageSize(formatRecord);
+    const bool hasAlpha = alphaState != AlphaState::None;
+
+    // SetupFormatRecord, ReadHeifImage.cpp:31-50
+    formatRecord->loPlane = 0;
+    formatRecord->hiPlane = (int16_t)(formatRecord->planes - 1);
+    formatRecord->planeBytes = (int16_t)((formatRecord->depth + 7) / 8);
+    formatRecord->colBytes = (int16_t)(formatRecord->planes * formatRecord->planeBytes);
+    const uint64_t rowBytes = (uint64_t)imageSize.h * (uint64_t)formatRecord->colBytes;
+    if (rowBytes > (uint64_t)std::numeric_limits<int32_t>::max()) throw std::bad_alloc();
+    formatRecord->rowBytes = (int32_t)rowBytes;
+
+    avifgpu_read_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.width = imageSize.h; d.height = imageSize.v;
+    d.colorspace = image->colorspace; d.chroma = image->chroma; d.bit_depth = image->bit_depth;
+    d.depth = formatRecord->depth; d.alpha_state = (int)alphaState;
+    d.has_nclx = nclxProfile != nullptr;
+    if (nclxProfile) {
+        d.color_primaries = nclxProfile->color_primaries; d.transfer_characteristics = nclxProfile->transfer_characteristics;
+        d.matrix_coefficients = nclxProfile->matrix_coefficients; d.full_range_flag = nclxProfile->full_range_flag;
+    }
+    if (loadOptions) {
+        d.pq_peak_nits = loadOptions->pq.nominalPeakBrightness;
+        d.hlg_apply_ootf = loadOptions->hlg.applyOOTF; d.hlg_display_gamma = loadOptions->hlg.displayGamma;
+        d.hlg_peak_nits = loadOptions->hlg.nominalPeakBrightness;
+    } else { d.pq_peak_nits = 80; d.hlg_display_gamma = 1.2f; d.hlg_peak_nits = 1000; }
+    const int expectPlanes = (d.colorspace == AVIFGPU_COLORSPACE_MONOCHROME ? 1 : 3) + (hasAlpha ? 1 : 0);
+    if (formatRecord->planes != expectPlanes) throw OSErrException(AVIFGPU_formatBadParameters);
+    if (d.depth == 16) formatRecord->maxValue = avifgpu_read_max_value(&d);              // ReadHeifImage.cpp:206,499,747
+
+    const bool even = d.colorspace == AVIFGPU_COLORSPACE_YCBCR && d.chroma == AVIFGPU_CHROMA_420;
+    const int ys = even ? 1 : 0;
+    const int tileRows = rows_per_tile(formatRecord->maxData, formatRecord->rowBytes, d.height, even);
+    TileBuffers buffers((size_t)tileRows * (size_t)formatRecord->rowBytes);
+
+    auto enqueue = [&](int32_t top, int slot) {
+        const int32_t bottom = std::min(top + tileRows, imageSize.v);
+        const void* src[4]; int64_t stride[4];
+        for (int pl = 0; pl < 4; ++pl) {
+            const bool chromaPlane = d.colorspace == AVIFGPU_COLORSPACE_YCBCR && (pl == 1 || pl == 2);
+            const int r = chromaPlane ? (top >> ys) : top;
+            src[pl] = image->plane[pl] ? image->plane[pl] + (int64_t)r * image->stride[pl] : nullptr;
+            stride[pl] = image->stride[pl];
+        }
+        const int err = avifgpu::read_rows_host_enqueue(&d, top, bottom - top, src, stride, buffers[slot], formatRecord->rowBytes, slot);
+        if (err) { (void)avifgpu::wait_slot(0); (void)avifgpu::wait_slot(1); throw OSErrException((OSErr)err); }
+    };
+
+    const int32_t left = 0, right = imageSize.h;
+    int slot = 0;
+    if (imageSize.v > 0) enqueue(0, 0);
+    for (int32_t top = 0; top < imageSize.v; top += tileRows, slot ^= 1) {
+        if (top + tileRows < imageSize.v) enqueue(top + tileRows, slot ^ 1);              // next tile converts while the host drains this one
+        OSErrException::ThrowIfError((OSErr)avifgpu::wait_slot(slot));
+        const int32_t bottom = std::min(top + tileRows, imageSize.v);
+        formatRecord->data = buffers[slot];
+        SetRect(formatRecord, top, left, bottom, right);
+        const OSErr herr = formatRecord->advanceState();                                   // ReadHeifImage.cpp:159
+        if (herr != AVIFGPU_noErr) { (void)avifgpu::wait_slot(0); (void)avifgpu::wait_slot(1); throw OSErrException(herr); }
+    }
+    formatRecord->data = nullptr;
+}
+
+// The reference's six names (ReadHeifImage.h:27-63).
+void ReadHeifImageGrayEightBit(const avifgpu_image* i, AlphaState a, const avifgpu_nclx* n, FormatRecordPtr fr) { ReadHeifImageCommon(i, a, n, nullptr, fr); }
+void ReadHeifImageGraySixteenBit(const avifgpu_image* i, AlphaState a, const avifgpu_nclx* n, FormatRecordPtr fr) { ReadHeifImageCommon(i, a, n, nullptr, fr); }
+void ReadHeifImageGrayThirtyTwoBit(const avifgpu_image* i, AlphaState a, const avifgpu_nclx* n, const LoadUIOptions& l, FormatRecordPtr fr) { ReadHeifImageCommon(i, a, n, &l, fr); }
+void ReadHeifImageRGBEightBit(const avifgpu_image* i, AlphaState a, const avifgpu_nclx* n, FormatRecordPtr fr) { ReadHeifImageCommon(i, a, n, nullptr, fr); }
+void ReadHeifImageRGBSixteenBit(const avifgpu_image* i, AlphaState a, const avifgpu_nclx* n, FormatRecordPtr fr) { ReadHeifImageCommon(i, a, n, nullptr, fr); }
+void ReadHeifImageRGBThirtyTwoBit(const avifgpu_image* i, AlphaState a, const avifgpu_nclx* n, const LoadUIOptions& l, FormatRecordPtr fr) { ReadHeifImageCommon(i, a, n, &l, fr); }
+
+// Exception -> OSErr exactly as the Do* drivers do it (Write.cpp:345-364, Read.cpp:659-678).
+template <typename F> OSErr guarded(F&& f, OSErr fallback)
+{
+    try { f(); return AVIFGPU_noErr; }
+    catch (const std::bad_alloc&) { avifgpu::set_error("out of memory"); return AVIFGPU_memFullErr; }
+    catch (const OSErrException& e) { return e.err; }
+    catch (const std::exception& e) { avifgpu::set_error(e.what()); return fallback; }
+    catch (...) { return fallback; }
+}
+
+} // namespace avifgpu::host
+
+using namespace avifgpu::host;
+
+extern "C" {
+
+avifgpu_OSErr avifgpu_image_alloc(avifgpu_image* img)
+{
+    if (!img || img->width <= 0 || img->height <= 0) return AVIFGPU_formatBadParameters;
+    const int ssz = img->bit_depth > 8 ? 2 : 1;
+    int w[4] = {0, 0, 0, 0}, h[4] = {0, 0, 0, 0};
+    if (img->colorspace == AVIFGPU_COLORSPACE_RGB && img->chroma >= 10) {                 // interleaved
+        const int comps = (img->chroma == 11 || img->chroma == 15) ? 4 : 3;
+        w[0] = img->width * comps; h[0] = img->height;
+    } else if (img->colorspace == AVIFGPU_COLORSPACE_MONOCHROME) {
+        w[0] = img->width; h[0] = img->height;
+    } else {
+        int xs = 0, ys = 0;
+        if (img->colorspace == AVIFGPU_COLORSPACE_YCBCR) {
+            if (img->chroma == AVIFGPU_CHROMA_420) { xs = 1; ys = 1; } else if (img->chroma == AVIFGPU_CHROMA_422) { xs = 1; }
+        }
+        w[0] = img->width; h[0] = img->height;
+        w[1] = w[2] = (img->width + xs) >> xs; h[1] = h[2] = (img->height + ys) >> ys;
+    }
+    size_t total = 0, off[4] = {0, 0, 0, 0};
+    for (int pl = 0; pl < 3; ++pl) {
+        if (!w[pl]) continue;
+        img->stride[pl] = ((w[pl] * ssz) + 15) & ~15;
+        off[pl] = total; total += (size_t)img->stride[pl] * h[pl];
+    }
+    const bool wantAlpha = img->has_alpha && !(img->colorspace == AVIFGPU_COLORSPACE_RGB && img->chroma >= 10);
+    if (wantAlpha) { w[3] = img->width; h[3] = img->height; img->stride[3] = ((w[3] * ssz) + 15) & ~15; off[3] = total; total += (size_t)img->stride[3] * h[3]; }
+    void* base = nullptr;
+    if (posix_memalign(&base, 64, total ? total : 64) != 0) return AVIFGPU_memFullErr;
+    std::memset(base, 0, total);
+    for (int pl = 0; pl < 4; ++pl) img->plane[pl] = w[pl] ? (uint8_t*)base + off[pl] : nullptr;
+    img->owner = base;
+    return AVIFGPU_noErr;
+}
+
+void avifgpu_image_free(avifgpu_image* img)
+{
+    if (img && img->owner) { free(img->owner); img->owner = nullptr; for (auto& p : img->plane) p = nullptr; }
+}
+
+avifgpu_OSErr avifgpu_host_create_heif_image(avifgpu_FormatRecord* formatRecord, int32_t alphaState,
+                                             const avifgpu_SaveUIOptions* saveOptions, int32_t output,
+                                             int32_t matrix_coefficients, int32_t color_primaries, avifgpu_image* img)
+{
+    if (!formatRecord || !saveOptions || !img || !formatRecord->advanceState) return AVIFGPU_formatBadParameters;
+    return guarded([&] {
+        const VPoint imageSize = GetImageSize(formatRecord);
+        switch (formatRecord->depth) {                                                      // Write.cpp:303-336
+        case 8: case 16: case 32: break;
+        default: throw OSErrException(AVIFGPU_formatBadParameters);
+        }
+        CreateHeifImageInto(formatRecord, (AlphaState)alphaState, imageSize, *saveOptions, output, matrix_coefficients,
+                            color_primaries, img);
+    }, AVIFGPU_writErr);
+}
+
+avifgpu_OSErr avifgpu_host_read_heif_image(const avifgpu_image* image, int32_t alphaState, const avifgpu_nclx* nclxProfile,
+                                           const avifgpu_LoadUIOptions* loadOptions, avifgpu_FormatRecord* formatRecord)
+{
+    if (!image || !formatRecord || !formatRecord->advanceState) return AVIFGPU_formatBadParameters;
+    return guarded([&] { ReadHeifImageCommon(image, (AlphaState)alphaState, nclxProfile, loadOptions, formatRecord); }, AVIFGPU_readErr);
+}
+
+} // extern "C"

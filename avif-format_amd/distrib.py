@@ -1,0 +1,59 @@
+"""One-process-per-GPU glue for bench.py (and its CPU test): ranks never exchange pixels -- row tiles / frames are
+independent -- so torch.distributed only supplies the barrier around the timed region and the
+MAX-over-ranks of its duration.  Backend "nccl" (= RCCL on ROCm) on GPUs, "gloo" in the CPU tests."""
+from __future__ import annotations
+
+import os
+import time
+
+
+class Ranks:
+    def __init__(self, backend: str | None = None, device=None):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = None
+        self.device = device
+        if self.world > 1:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                kw = {}
+                if backend == "nccl" and device is not None:
+                    kw["device_id"] = device
+                dist.init_process_group(backend=backend or "gloo", **kw)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max_over_ranks(self, seconds: float) -> float:
+        if self.dist is None:
+            return seconds
+        import torch
+        dev = self.device if (self.device is not None and self.dist.get_backend() == "nccl") else "cpu"
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(self, step, steps: int, sync=lambda: None) -> float:
+        """Barrier + sync, EXACTLY `steps` calls of step(), sync + barrier; returns MAX-over-ranks seconds."""
+        self.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        sync()
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+    def gather_objects(self, obj):
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def close(self):
+        if self.dist is not None and self.dist.is_initialized():
+            self.dist.destroy_process_group()

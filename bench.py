@@ -66,7 +66,6 @@ def main():
     pkg = entry.load_package()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -76,10 +75,8 @@ def main():
         raise SystemExit("bench.py needs a GPU; there is no CPU fallback")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)   # RCCL: barrier + MAX only, no pixel traffic
+    ranks = pkg.distrib.Ranks(backend="nccl", device=dev)        # RCCL: barrier + MAX only, no pixel traffic
+    rank = ranks.rank
 
     gpu = pkg.AvifGpu(local_rank)
     W, H = args.width, args.height
@@ -141,22 +138,12 @@ def main():
     # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides ----
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
+    def timed_step(i):
         starts[i].record(stream)          # same stream the kernel is launched on
         step()
         ends[i].record(stream)
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # barrier + synchronize, K steps, synchronize + barrier, MAX over ranks (avif-format_amd/distrib.py)
+    elapsed = ranks.timed(timed_step, args.steps, sync=lambda: torch.cuda.synchronize(dev))
     kernel_ms = sorted(s.elapsed_time(e) for s, e in zip(starts, ends))
     mean_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
     kernel_name = gpu.last_kernel()
@@ -247,8 +234,7 @@ def main():
             out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":

@@ -13,8 +13,8 @@ pkg = harness.pkg
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_symbols():
-    text = open(os.path.join(ROOT, "include", "avifgpu.h")).read()
+def _header_symbols(name="avifgpu.h"):
+    text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(avifgpu_[a-z0-9_]+)\s*\(", text)))
 
@@ -22,12 +22,16 @@ def _header_symbols():
 def test_library_exports_every_declared_symbol():
     lib = pkg.load()
     declared = _header_symbols()
-    assert len(declared) >= 13
+    assert len(declared) >= 14
     bound = {name for name, _, _ in pkg.ABI}
     assert set(declared) == bound, set(declared) ^ bound
     for name in declared:
         assert getattr(lib, name) is not None
     assert lib.avifgpu_abi_version() == 1
+    host_declared = [n for n in _header_symbols("avifgpu_host.h") if n.startswith(("avifgpu_host_", "avifgpu_image_"))]
+    assert sorted(host_declared) == sorted(n for n, _, _ in pkg.host.HOST_ABI)
+    for name in host_declared:
+        assert getattr(lib, name) is not None
 
 
 def test_descriptor_layout_matches_header():
