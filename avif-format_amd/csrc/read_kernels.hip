@@ -61,12 +61,23 @@ AG_DEV float table_uv(const ReadParams& p, int i)
 }
 AG_DEV float table_a(const ReadParams& p, int i) { return (float)i / (float)p.maxc; }
 
-struct Tables {
-    const float* ty; const float* tuv; const float* ta;   // LDS (bits <= 12) or nullptr
+// LUT = true : tables live in LDS (bits <= 12), a lookup is one ds_read_b32 -- no branch in the pixel loop.
+// LUT = false: 16-bit samples, the table formula is evaluated per sample (3 x 65536 floats would not fit LDS).
+template <bool LUT> struct Tables {
+    const float* ty; const float* tuv; const float* ta;
 };
-AG_DEV float look_y(const ReadParams& p, const Tables& t, uint32_t i)  { return t.ty ? t.ty[i] : table_y(p, (int)i); }
-AG_DEV float look_uv(const ReadParams& p, const Tables& t, uint32_t i) { return t.tuv ? t.tuv[i] : table_uv(p, (int)i); }
-AG_DEV float look_a(const ReadParams& p, const Tables& t, uint32_t i)  { return t.ta ? t.ta[i] : table_a(p, (int)i); }
+template <bool LUT> AG_DEV float look_y(const ReadParams& p, const Tables<LUT>& t, uint32_t i)
+{
+    if constexpr (LUT) return t.ty[i]; else return table_y(p, (int)i);
+}
+template <bool LUT> AG_DEV float look_uv(const ReadParams& p, const Tables<LUT>& t, uint32_t i)
+{
+    if constexpr (LUT) return t.tuv[i]; else return table_uv(p, (int)i);
+}
+template <bool LUT> AG_DEV float look_a(const ReadParams& p, const Tables<LUT>& t, uint32_t i)
+{
+    if constexpr (LUT) return t.ta[i]; else return table_a(p, (int)i);
+}
 
 // EOTF of one RGB triple, reference YuvDecode.cpp:563-591 / ReadHeifImage.cpp:1067-1095.
 template <int TRANSFER>
@@ -93,8 +104,8 @@ enum { kCsYcc = 0, kCsRgb = 1, kCsMono = 2 };
 
 // One pixel.  u[] = raw samples (Y,Cb,Cr | R,G,B | Y), ua = alpha sample.  out[] = NCH host samples
 // (u8/u16 values or f32 bit patterns).
-template <int CS, int DEPTH, bool ALPHA, int TRANSFER>
-AG_DEV void decode_pixel(const ReadParams& p, const Tables& t, uint32_t u0, uint32_t u1, uint32_t u2, uint32_t ua,
+template <int CS, int DEPTH, bool ALPHA, int TRANSFER, bool LUT>
+AG_DEV void decode_pixel(const ReadParams& p, const Tables<LUT>& t, uint32_t u0, uint32_t u1, uint32_t u2, uint32_t ua,
                          uint32_t* out)
 {
     const uint32_t maxc = (uint32_t)p.maxc;
@@ -198,19 +209,25 @@ AG_DEV void load_plane(const uint8_t* row, int i0, int count, uint32_t (&v)[N])
     }
 }
 
-template <int CS, int DEPTH, bool ALPHA, int XS, int YS, int TRANSFER>
+// samples of chroma per thread: 4 for u16 planes, 8 for u8 planes => every plane load is >= 8 bytes per lane
+template <int DEPTH, int XS> struct ReadShape {
+    static constexpr int NC = DEPTH == 8 ? 8 : 4;
+    static constexpr int PXT = NC << XS;
+};
+
+template <int CS, int DEPTH, bool ALPHA, int XS, int YS, int TRANSFER, bool LUT>
 __global__ __launch_bounds__(256) void read_px(const ReadParams p)
 {
     constexpr bool SRC16 = DEPTH != 8;
-    constexpr int PXT = 4 << XS;
+    constexpr int NC = ReadShape<DEPTH, XS>::NC;
+    constexpr int PXT = ReadShape<DEPTH, XS>::PXT;
     constexpr int VR = 1 << YS;
-    constexpr int NC = 4;
     constexpr int NCH = (CS == kCsMono ? 1 : 3) + (ALPHA ? 1 : 0);
     constexpr int OSZ = DEPTH / 8;
 
     extern __shared__ float lut[];
-    Tables t = { nullptr, nullptr, nullptr };
-    if (p.bits <= 12) {
+    Tables<LUT> t = { nullptr, nullptr, nullptr };
+    if constexpr (LUT) {
         const int count = 1 << p.bits;
         for (int i = threadIdx.x; i < count; i += 256) {
             lut[i] = table_y(p, i);
@@ -233,7 +250,9 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
         const int r0 = gy * VR;
         const int nvalid = min(PXT, p.width - x0);
 
-        uint32_t c1[NC] = {0, 0, 0, 0}, c2[NC] = {0, 0, 0, 0};
+        uint32_t c1[NC], c2[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) { c1[j] = 0; c2[j] = 0; }
         if constexpr (CS == kCsYcc) {                       // uvJ = y >> yChromaShift, uvI = x >> xChromaShift
             load_plane<SRC16, NC>(p.src[1] + (long long)gy * p.src_stride[1], x0 >> XS, cw, c1);
             load_plane<SRC16, NC>(p.src[2] + (long long)gy * p.src_stride[2], x0 >> XS, cw, c2);
@@ -256,7 +275,7 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
                 uint32_t u1 = 0, u2 = 0;
                 if constexpr (CS == kCsYcc) { u1 = c1[i >> XS]; u2 = c2[i >> XS]; }
                 if constexpr (CS == kCsRgb) { u1 = g1[i]; u2 = g2[i]; }
-                decode_pixel<CS, DEPTH, ALPHA, TRANSFER>(p, t, y[i], u1, u2, ALPHA ? a[i] : (uint32_t)p.maxc, &o[i * NCH]);
+                decode_pixel<CS, DEPTH, ALPHA, TRANSFER, LUT>(p, t, y[i], u1, u2, ALPHA ? a[i] : (uint32_t)p.maxc, &o[i * NCH]);
             }
             uint8_t* drow = p.dst + (long long)r * p.dst_row_bytes + (long long)x0 * NCH * OSZ;
             if constexpr (DEPTH == 32) {
@@ -277,7 +296,7 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
 template <int CS, int DEPTH, bool ALPHA, int XS, int YS, int TRANSFER>
 static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, const char** name)
 {
-    constexpr int PXT = 4 << XS;
+    constexpr int PXT = ReadShape<DEPTH, XS>::PXT;
     const long long groups = (long long)((p.width + PXT - 1) / PXT) * ((p.nrows + (1 << YS) - 1) >> YS);
     if (groups == 0) return hipSuccess;
     long long blocks = (groups + 255) / 256;
@@ -286,7 +305,12 @@ static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, const cha
     static thread_local char label[160];
     snprintf(label, sizeof(label), "read_px<cs=%d,depth=%d,alpha=%d,xs=%d,ys=%d,transfer=%d>", CS, DEPTH, (int)ALPHA, XS, YS, TRANSFER);
     *name = label;
-    hipLaunchKernelGGL((read_px<CS, DEPTH, ALPHA, XS, YS, TRANSFER>), dim3((int)blocks), dim3(256), lds, st, p);
+    if constexpr (DEPTH == 8) {
+        hipLaunchKernelGGL((read_px<CS, DEPTH, ALPHA, XS, YS, TRANSFER, true>), dim3((int)blocks), dim3(256), lds, st, p);
+    } else {
+        if (p.bits <= 12) hipLaunchKernelGGL((read_px<CS, DEPTH, ALPHA, XS, YS, TRANSFER, true>), dim3((int)blocks), dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((read_px<CS, DEPTH, ALPHA, XS, YS, TRANSFER, false>), dim3((int)blocks), dim3(256), lds, st, p);
+    }
     return hipGetLastError();
 }
 

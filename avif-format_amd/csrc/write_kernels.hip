@@ -5,7 +5,7 @@
 // RGB -> YCbCr + chroma-subsample stage behind them (reference call site src/common/Write.cpp:44).
 //
 // Work shape: pure streaming, HBM-bound, no reuse => no MFMA, no cross-block traffic, no XCD swizzle
-// (T1 only pays when neighbouring blocks share operands).  One thread owns PXT = 4 << XS horizontally
+// (T1 only pays when neighbouring blocks share operands).  One thread owns PXT = (4 or 8) << XS horizontally
 // adjacent pixels on 1 << YS rows, i.e. exactly the footprint of 4 chroma samples, so
 //   * every plane store is one 8-byte (u16) / 4-byte (u8) vector per lane, contiguous across the wave;
 //   * the chroma box filter needs no cross-lane traffic;
@@ -102,7 +102,7 @@ enum { kOutRefColor = 0, kOutRefGray = 1, kOutYcbcr = 2 };
 template <int DEPTH, int PLANES, int OUT, bool DST16, int XS, int YS, int TRANSFER>
 __global__ __launch_bounds__(256) void write_px(const WriteParams p)
 {
-    constexpr int PXT = 4 << XS;
+    constexpr int PXT = (DST16 ? 4 : 8) << XS;   // 4 (u16 planes) or 8 (u8 planes) chroma samples per thread: every plane store >= 8 B/lane
     constexpr int VR = 1 << YS;
     constexpr int BPP = PLANES * DEPTH / 8;
     constexpr int ND = PXT * BPP / 4;             // dwords per thread per row
@@ -391,7 +391,7 @@ static inline int grid_for(long long threads_needed)
 template <int DEPTH, int PLANES, int OUT, bool DST16, int XS, int YS, int TRANSFER>
 static hipError_t launch_one(const WriteParams& p, hipStream_t st, const char** name)
 {
-    constexpr int PXT = 4 << XS;
+    constexpr int PXT = (DST16 ? 4 : 8) << XS;
     const long long groups = (long long)((p.width + PXT - 1) / PXT) * ((p.nrows + (1 << YS) - 1) >> YS);
     if (groups == 0) return hipSuccess;
     static thread_local char label[160];

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Per-configuration kernel timings (BASELINE.json configs C2..C5 + the read direction) on one MI355X.
+Diagnostic companion of bench.py: prints one line per configuration with HIP-event kernel time, Mpx/s and
+algorithmic GB/s (input read once + output written once)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+import __graft_entry__ as entry  # noqa: E402
+
+pkg = entry.load_package()
+import harness  # noqa: E402
+
+dev = torch.device("cuda", 0)
+gpu = pkg.AvifGpu(0)
+stream = torch.cuda.Stream(dev)
+
+
+def time_launch(fn, iters=50, warm=10):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize(dev)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record(stream); fn(); b.record(stream)
+    torch.cuda.synchronize(dev)
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return sum(ts) / len(ts), ts[len(ts) // 2]
+
+
+def rand_src(d):
+    g = torch.Generator(device=dev); g.manual_seed(1234)
+    n = d.height * d.width * d.planes
+    if d.depth == 8:
+        return torch.randint(0, 256, (n,), generator=g, device=dev, dtype=torch.uint8).view(d.height, -1)
+    if d.depth == 16:
+        return torch.randint(0, 32769, (n,), generator=g, device=dev, dtype=torch.int32).to(torch.int16).view(d.height, -1)
+    t = torch.rand(n, generator=g, device=dev, dtype=torch.float32)
+    m = torch.rand(n, generator=g, device=dev, dtype=torch.float32)
+    t = torch.where(m < 0.10, 1.0 + 11.5 * t, t)
+    return t.view(d.height, -1)
+
+
+def bench_write(name, **kw):
+    d = pkg.WriteDesc(**kw)
+    src = rand_src(d)
+    ssz = 2 if d.bit_depth > 8 else 1
+    bufs, ptrs, strides = {}, [None] * 4, [0] * 4
+    for pl, (w, xs, ys) in harness.write_planes(d).items():
+        bufs[pl] = torch.empty(((d.height + ys) >> ys, w * ssz), dtype=torch.uint8, device=dev)
+        ptrs[pl], strides[pl] = bufs[pl].data_ptr(), bufs[pl].stride(0)
+    fn = lambda: gpu.write_rows(d, 0, d.height, src.data_ptr(), src.stride(0) * src.element_size(), ptrs, strides,
+                                mem=pkg.MEM_DEVICE, stream=stream.cuda_stream)
+    mean, p50 = time_launch(fn)
+    ab = gpu.write_algorithmic_bytes(d, d.height)
+    print(json.dumps({"config": name, "kernel": gpu.last_kernel(), "ms_mean": round(mean, 4), "ms_p50": round(p50, 4),
+                      "Mpx_s": round(d.width * d.height / mean / 1e3, 0), "GB_s": round(ab / mean / 1e6, 1),
+                      "frac_of_8TBs": round(ab / mean / 1e6 / 8000, 3), "bytes_per_px": ab / (d.width * d.height)}), flush=True)
+
+
+def bench_read(name, **kw):
+    d = pkg.ReadDesc(**kw)
+    g = torch.Generator(device=dev); g.manual_seed(99)
+    maxc = (1 << d.bit_depth) - 1
+    ssz = 2 if d.bit_depth > 8 else 1
+    ptrs, strides, keep = [None] * 4, [0] * 4, []
+    for pl, (w, xs, ys) in harness.read_planes(d).items():
+        h = (d.height + ys) >> ys
+        t = torch.randint(0, maxc + 1, (h, w), generator=g, device=dev, dtype=torch.int32)
+        t = t.to(torch.int16 if ssz == 2 else torch.uint8).contiguous()
+        keep.append(t); ptrs[pl], strides[pl] = t.data_ptr(), t.stride(0) * ssz
+    nch = harness.read_channels(d)
+    out = torch.empty((d.height, d.width * nch * (d.depth // 8)), dtype=torch.uint8, device=dev)
+    fn = lambda: gpu.read_rows(d, 0, d.height, ptrs, strides, out.data_ptr(), out.stride(0), mem=pkg.MEM_DEVICE,
+                               stream=stream.cuda_stream)
+    mean, p50 = time_launch(fn)
+    ab = gpu.read_algorithmic_bytes(d, d.height)
+    print(json.dumps({"config": name, "kernel": gpu.last_kernel(), "ms_mean": round(mean, 4), "ms_p50": round(p50, 4),
+                      "Mpx_s": round(d.width * d.height / mean / 1e3, 0), "GB_s": round(ab / mean / 1e6, 1),
+                      "frac_of_8TBs": round(ab / mean / 1e6 / 8000, 3), "bytes_per_px": ab / (d.width * d.height)}), flush=True)
+
+
+if __name__ == "__main__":
+    P = pkg
+    bench_write("C2 4096^2 RGB8 -> 8-bit 4:2:0 BT.709", width=4096, height=4096, depth=8, planes=3, bit_depth=8, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=P.MATRIX_BT709)
+    bench_write("C2' 8192^2 RGB8 -> 8-bit 4:2:0 BT.709", width=8192, height=8192, depth=8, planes=3, bit_depth=8, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=P.MATRIX_BT709)
+    bench_write("C3 8192^2 RGB16 -> 12-bit 4:4:4 BT.2020", width=8192, height=8192, depth=16, planes=3, bit_depth=12, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=P.MATRIX_BT2020_NCL, color_primaries=9)
+    bench_write("C4 8192^2 RGB f32 -> 10-bit PQ 4:4:4", width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=9, color_primaries=9)
+    bench_write("C4 8192^2 RGB f32 -> 10-bit PQ 4:2:2", width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_422, matrix_coefficients=9, color_primaries=9)
+    bench_write("C4 8192^2 RGB f32 -> 10-bit PQ 4:2:0", width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=9, color_primaries=9)
+    bench_write("C4 8192^2 RGB f32 -> 10-bit PQ interleaved RRGGBB (reference hand-off)", width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=0)
+    bench_write("C5 16384^2 RGBA f32 -> 12-bit PQ 4:4:4 + alpha", width=16384, height=16384, depth=32, planes=4, bit_depth=12, transfer=0, peak_nits=80, alpha_state=1, output=1, chroma=P.CHROMA_444, matrix_coefficients=9, color_primaries=9)
+    bench_write("RGBA8 premultiplied -> 8-bit interleaved (reference hand-off) 8192^2", width=8192, height=8192, depth=8, planes=4, bit_depth=8, alpha_state=2, output=0)
+    bench_read("R8 8192^2 8-bit 4:2:0 BT.709 -> RGB8", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_420, bit_depth=8, depth=8, alpha_state=0, matrix_coefficients=1)
+    bench_read("R16 8192^2 10-bit 4:4:4 BT.2020 -> RGB16", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_444, bit_depth=10, depth=16, alpha_state=0, matrix_coefficients=9, color_primaries=9)
+    bench_read("R16 8192^2 12-bit 4:2:0 BT.2020 + alpha premult -> RGBA16", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_420, bit_depth=12, depth=16, alpha_state=2, matrix_coefficients=9, color_primaries=9)
+    bench_read("R32 8192^2 10-bit 4:4:4 BT.2020 PQ -> RGB f32", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_444, bit_depth=10, depth=32, alpha_state=0, matrix_coefficients=9, color_primaries=9, transfer_characteristics=16, pq_peak_nits=80)
+    bench_read("R32 8192^2 10-bit 4:2:0 BT.2020 HLG+OOTF -> RGB f32", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_420, bit_depth=10, depth=32, alpha_state=0, matrix_coefficients=9, color_primaries=9, transfer_characteristics=18, hlg_apply_ootf=1, hlg_display_gamma=1.2, hlg_peak_nits=1000)
+    bench_read("R32 8192^2 12-bit planar RGB PQ -> RGB f32", width=8192, height=8192, colorspace=1, chroma=P.CHROMA_444, bit_depth=12, depth=32, alpha_state=0, matrix_coefficients=0, color_primaries=9, transfer_characteristics=16, pq_peak_nits=80)
