@@ -176,7 +176,13 @@ AG_DEV uint32_t ld_u8(const uint8_t* p)  { return *p; }
 AG_DEV uint32_t ld_u16(const uint8_t* p) { return *reinterpret_cast<const uint16_t*>(p); }
 AG_DEV uint32_t ld_u32(const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
 
-template <int ND>
+typedef uint32_t dm_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t dm_u32x2 __attribute__((ext_vector_type(2)));
+
+// NT = non-temporal (streaming) access: every byte of these images is touched exactly once, so keeping it out of
+// L2 / Infinity Cache is measurably faster for stores and for fully coalesced loads (profiles/r01/membench.txt);
+// lane-strided loads that rely on L1/L2 to merge their 16-B pieces must NOT use it.
+template <int ND, bool NT = false>
 AG_DEV void load_dwords(const uint8_t* p, uint32_t (&d)[ND])
 {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
@@ -184,7 +190,9 @@ AG_DEV void load_dwords(const uint8_t* p, uint32_t (&d)[ND])
         if ((a & 15) == 0) {
 #pragma unroll
             for (int j = 0; j < ND / 4; ++j) {
-                const uint4 v = reinterpret_cast<const uint4*>(p)[j];
+                dm_u32x4 v;
+                if constexpr (NT) v = __builtin_nontemporal_load(reinterpret_cast<const dm_u32x4*>(p) + j);
+                else v = reinterpret_cast<const dm_u32x4*>(p)[j];
                 d[4 * j] = v.x; d[4 * j + 1] = v.y; d[4 * j + 2] = v.z; d[4 * j + 3] = v.w;
             }
             return;
@@ -194,7 +202,9 @@ AG_DEV void load_dwords(const uint8_t* p, uint32_t (&d)[ND])
         if ((a & 7) == 0) {
 #pragma unroll
             for (int j = 0; j < ND / 2; ++j) {
-                const uint2 v = reinterpret_cast<const uint2*>(p)[j];
+                dm_u32x2 v;
+                if constexpr (NT) v = __builtin_nontemporal_load(reinterpret_cast<const dm_u32x2*>(p) + j);
+                else v = reinterpret_cast<const dm_u32x2*>(p)[j];
                 d[2 * j] = v.x; d[2 * j + 1] = v.y;
             }
             return;
@@ -210,22 +220,29 @@ AG_DEV void load_dwords(const uint8_t* p, uint32_t (&d)[ND])
         d[j] = (uint32_t)p[4 * j] | ((uint32_t)p[4 * j + 1] << 8) | ((uint32_t)p[4 * j + 2] << 16) | ((uint32_t)p[4 * j + 3] << 24);
 }
 
-template <int ND>
+template <int ND, bool NT = false>
 AG_DEV void store_dwords(uint8_t* p, const uint32_t (&d)[ND])
 {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
     if constexpr (ND % 4 == 0) {
         if ((a & 15) == 0) {
 #pragma unroll
-            for (int j = 0; j < ND / 4; ++j)
-                reinterpret_cast<uint4*>(p)[j] = make_uint4(d[4 * j], d[4 * j + 1], d[4 * j + 2], d[4 * j + 3]);
+            for (int j = 0; j < ND / 4; ++j) {
+                const dm_u32x4 v = { d[4 * j], d[4 * j + 1], d[4 * j + 2], d[4 * j + 3] };
+                if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<dm_u32x4*>(p) + j);
+                else reinterpret_cast<dm_u32x4*>(p)[j] = v;
+            }
             return;
         }
     }
     if constexpr (ND % 2 == 0) {
         if ((a & 7) == 0) {
 #pragma unroll
-            for (int j = 0; j < ND / 2; ++j) reinterpret_cast<uint2*>(p)[j] = make_uint2(d[2 * j], d[2 * j + 1]);
+            for (int j = 0; j < ND / 2; ++j) {
+                const dm_u32x2 v = { d[2 * j], d[2 * j + 1] };
+                if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<dm_u32x2*>(p) + j);
+                else reinterpret_cast<dm_u32x2*>(p)[j] = v;
+            }
             return;
         }
     }
@@ -242,7 +259,9 @@ AG_DEV void store_dwords(uint8_t* p, const uint32_t (&d)[ND])
 }
 
 // Store N samples (u8 or u16 containers) starting at `p`; `nvalid` < N only on the right image edge.
-template <bool DST16, int N>
+// NT only where the lanes of a wave write CONTIGUOUS memory (planar stores): a lane-strided non-temporal store leaves
+// partial cache lines that nothing merges (measured 3.5x slower on the interleaved f32 read output).
+template <bool DST16, int N, bool NT = false>
 AG_DEV void store_samples(uint8_t* p, const uint32_t (&v)[N], int nvalid)
 {
     constexpr int BYTES = N * (DST16 ? 2 : 1);
@@ -254,7 +273,7 @@ AG_DEV void store_samples(uint8_t* p, const uint32_t (&v)[N], int nvalid)
                 if constexpr (DST16) d[j] = v[2 * j] | (v[2 * j + 1] << 16);
                 else d[j] = v[4 * j] | (v[4 * j + 1] << 8) | (v[4 * j + 2] << 16) | (v[4 * j + 3] << 24);
             }
-            store_dwords<BYTES / 4>(p, d);
+            store_dwords<BYTES / 4, NT>(p, d);
             return;
         }
     }

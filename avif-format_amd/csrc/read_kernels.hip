@@ -193,7 +193,7 @@ AG_DEV void load_plane(const uint8_t* row, int i0, int count, uint32_t (&v)[N])
     if constexpr (BYTES % 4 == 0) {
         if (i0 + N <= count) {
             uint32_t d[BYTES / 4];
-            load_dwords<BYTES / 4>(row + (long long)i0 * SSZ, d);
+            load_dwords<BYTES / 4, true>(row + (long long)i0 * SSZ, d);   // planar, coalesced, read once: non-temporal
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 if constexpr (SRC16) v[j] = (d[j >> 1] >> (16 * (j & 1))) & 0xffffu;
@@ -240,12 +240,12 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
 
     const int gxn = (p.width + PXT - 1) / PXT;
     const int gyn = (p.nrows + VR - 1) >> YS;
-    const long long total = (long long)gxn * gyn;
+    const uint32_t total = (uint32_t)gxn * (uint32_t)gyn;     // < 2^31 for any image <= 32767^2 (host checks): 32-bit udiv per trip
     const int cw = (p.width + (1 << XS) - 1) >> XS;
 
-    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
-        const int gy = (int)(g / gxn);
-        const int gx = (int)(g - (long long)gy * gxn);
+    for (uint32_t g = blockIdx.x * 256 + threadIdx.x; g < total; g += gridDim.x * 256) {
+        const int gy = (int)(g / (uint32_t)gxn);
+        const int gx = (int)(g - (uint32_t)gy * (uint32_t)gxn);
         const int x0 = gx * PXT;
         const int r0 = gy * VR;
         const int nvalid = min(PXT, p.width - x0);
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
             }
             uint8_t* drow = p.dst + (long long)r * p.dst_row_bytes + (long long)x0 * NCH * OSZ;
             if constexpr (DEPTH == 32) {
-                if (nvalid == PXT) store_dwords<PXT * NCH>(drow, o);
+                if (nvalid == PXT) store_dwords<PXT * NCH>(drow, o);           // lane-strided: no NT
                 else {
 #pragma unroll
                     for (int j = 0; j < PXT * NCH; ++j)
@@ -299,6 +299,7 @@ static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, const cha
     constexpr int PXT = ReadShape<DEPTH, XS>::PXT;
     const long long groups = (long long)((p.width + PXT - 1) / PXT) * ((p.nrows + (1 << YS) - 1) >> YS);
     if (groups == 0) return hipSuccess;
+    if (groups >= 0x7fffffffLL - 256LL * 65536) return hipErrorInvalidValue;   // 32-bit group index in the kernel
     long long blocks = (groups + 255) / 256;
     if (blocks > 256LL * 8) blocks = 256LL * 8;          // tables are rebuilt per block: keep blocks persistent-ish
     const size_t lds = p.bits <= 12 ? (size_t)3 * (1u << p.bits) * sizeof(float) : 0;

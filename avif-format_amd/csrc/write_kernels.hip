@@ -111,11 +111,11 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
 
     const int gxn = (p.width + PXT - 1) / PXT;
     const int gyn = (p.nrows + VR - 1) >> YS;
-    const long long total = (long long)gxn * gyn;
+    const uint32_t total = (uint32_t)gxn * (uint32_t)gyn;     // < 2^31 for any image <= 32767^2 (host checks): 32-bit udiv per trip
 
-    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
-        const int gy = (int)(g / gxn);
-        const int gx = (int)(g - (long long)gy * gxn);
+    for (uint32_t g = blockIdx.x * 256 + threadIdx.x; g < total; g += gridDim.x * 256) {
+        const int gy = (int)(g / (uint32_t)gxn);
+        const int gx = (int)(g - (uint32_t)gy * (uint32_t)gxn);
         const int x0 = gx * PXT;
         const int r0 = gy * VR;
         const int nvalid = min(PXT, p.width - x0);
@@ -181,9 +181,9 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
                     else yv[i] = stage_b_luma(p, q[vr][i]);
                     av[i] = q[vr][i][3];
                 }
-                store_samples<DST16, PXT>(p.dst[0] + (long long)r * p.dst_stride[0] + (long long)x0 * DSZ, yv, nvalid);
+                store_samples<DST16, PXT, true>(p.dst[0] + (long long)r * p.dst_stride[0] + (long long)x0 * DSZ, yv, nvalid);
                 if constexpr (ALPHA)
-                    store_samples<DST16, PXT>(p.dst[3] + (long long)r * p.dst_stride[3] + (long long)x0 * DSZ, av, nvalid);
+                    store_samples<DST16, PXT, true>(p.dst[3] + (long long)r * p.dst_stride[3] + (long long)x0 * DSZ, av, nvalid);
             }
         }
 
@@ -211,8 +211,8 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
                 crv[j] = clip_round(cr + p.half, p.maxv);
             }
             const int ncvalid = (nvalid + (1 << XS) - 1) >> XS;
-            store_samples<DST16, NC>(p.dst[1] + (long long)gy * p.dst_stride[1] + (long long)(x0 >> XS) * DSZ, cbv, ncvalid);
-            store_samples<DST16, NC>(p.dst[2] + (long long)gy * p.dst_stride[2] + (long long)(x0 >> XS) * DSZ, crv, ncvalid);
+            store_samples<DST16, NC, true>(p.dst[1] + (long long)gy * p.dst_stride[1] + (long long)(x0 >> XS) * DSZ, cbv, ncvalid);
+            store_samples<DST16, NC, true>(p.dst[2] + (long long)gy * p.dst_stride[2] + (long long)(x0 >> XS) * DSZ, crv, ncvalid);
         }
     }
 }
@@ -394,6 +394,7 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, const char** 
     constexpr int PXT = (DST16 ? 4 : 8) << XS;
     const long long groups = (long long)((p.width + PXT - 1) / PXT) * ((p.nrows + (1 << YS) - 1) >> YS);
     if (groups == 0) return hipSuccess;
+    if (groups >= 0x7fffffffLL - 256LL * 65536) return hipErrorInvalidValue;   // 32-bit group index in the kernel
     static thread_local char label[160];
     snprintf(label, sizeof(label), "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d>",
              DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER);

@@ -17,15 +17,23 @@ class Ranks:
         if self.world > 1:
             import torch.distributed as dist
             if not dist.is_initialized():
-                kw = {}
-                if backend == "nccl" and device is not None:
-                    kw["device_id"] = device
-                dist.init_process_group(backend=backend or "gloo", **kw)
+                try:
+                    kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+                    dist.init_process_group(backend=backend or "gloo", **kw)
+                except Exception as exc:      # RCCL unavailable on this node: the barrier + MAX work over gloo just as well
+                    if backend != "nccl":
+                        raise
+                    import sys
+                    print(f"[distrib] nccl init failed ({exc}); using gloo for barrier/MAX", file=sys.stderr)
+                    dist.init_process_group(backend="gloo")
             self.dist = dist
 
     def barrier(self):
         if self.dist is not None:
-            self.dist.barrier()
+            if self.dist.get_backend() == "nccl" and self.device is not None:
+                self.dist.barrier(device_ids=[self.device.index if hasattr(self.device, "index") else int(self.device)])
+            else:
+                self.dist.barrier()
 
     def max_over_ranks(self, seconds: float) -> float:
         if self.dist is None:

@@ -6,6 +6,9 @@ Workload (BASELINE.json configs[3], the configuration `metric` is quoted on; it 
     = CreateHeifImageRGBThirtyTwoBit (reference WriteHeifImage.cpp:990-1139) fused with libheif's RGB->YCbCr stage
       (reference call site Write.cpp:44).
 A "step" is one pass of that path over one synthetic frame, input and output resident in HBM.
+Before the W warm-up steps an untimed set-up phase keeps the kernel running for --clock-ramp-ms (default 150 ms): an idle
+MI355X needs ~50 ms of work to reach its steady clock (profiles/r01/clock_ramp_series.txt); the timed region is still
+exactly K steps.
 
     python bench.py --gpus N --steps K --warmup W
 For N > 1 the driver launches one rank per GPU through torch.distributed.run; ranks never exchange pixels
@@ -58,6 +61,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=8192, help="rows of the frame the CPU baseline converts")
     ap.add_argument("--sweep", default="", help="comma list of hot-kernel tuning words to time (diagnostic table on stderr)")
+    ap.add_argument("--clock-ramp-ms", type=float, default=150.0,
+                    help="untimed setup: run the kernel this long before the W warm-up steps so the GPU leaves its idle "
+                         "clock state (measured: the first ~50 ms of launches run at up to 2x the steady-state time)")
     ap.add_argument("--pcie", action="store_true", help="also time the host-buffer (PCIe-inclusive) entry point")
     args = ap.parse_args()
 
@@ -131,6 +137,12 @@ def main():
                   f"{ab / (sum(ts)/len(ts)) / 1e6:8.1f} GB/s  {gpu.last_kernel()}", file=sys.stderr, flush=True)
         lib.avifgpu_set_hot_variant(1 | 2 | 4)
 
+    # untimed setup: bring the device out of its idle power state (DVFS ramp), then the W warm-up steps
+    t_ramp = time.perf_counter()
+    while (time.perf_counter() - t_ramp) * 1e3 < args.clock_ramp_ms:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
@@ -144,7 +156,10 @@ def main():
         ends[i].record(stream)
     # barrier + synchronize, K steps, synchronize + barrier, MAX over ranks (avif-format_amd/distrib.py)
     elapsed = ranks.timed(timed_step, args.steps, sync=lambda: torch.cuda.synchronize(dev))
-    kernel_ms = sorted(s.elapsed_time(e) for s, e in zip(starts, ends))
+    series = [s.elapsed_time(e) for s, e in zip(starts, ends)]
+    if os.environ.get("AVIFGPU_BENCH_SERIES"):
+        print("series_ms " + " ".join(f"{t:.4f}" for t in series), file=sys.stderr, flush=True)
+    kernel_ms = sorted(series)
     mean_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
     kernel_name = gpu.last_kernel()
 

@@ -20,7 +20,7 @@ gpu = pkg.AvifGpu(0)
 stream = torch.cuda.Stream(dev)
 
 
-def time_launch(fn, iters=50, warm=10):
+def time_launch(fn, iters=60, warm=150):   # warm: clock ramp of an idle MI355X takes ~50 ms
     for _ in range(warm):
         fn()
     torch.cuda.synchronize(dev)

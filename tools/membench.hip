@@ -102,10 +102,10 @@ __global__ __launch_bounds__(256) void k_px_strided(const float4* __restrict__ i
     }
 }
 
-template <typename F> float time_it(F f, int iters = 30)
+template <typename F> float time_it(F f, int iters = 60)
 {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    for (int i = 0; i < 5; ++i) f();
+    for (int i = 0; i < 300; ++i) f();   // clock ramp: an idle MI355X needs ~50 ms of work to reach steady clocks
     CK(hipDeviceSynchronize());
     std::vector<float> ts;
     for (int i = 0; i < iters; ++i) {
