@@ -182,10 +182,13 @@ typedef uint32_t dm_u32x2 __attribute__((ext_vector_type(2)));
 // NT = non-temporal (streaming) access: every byte of these images is touched exactly once, so keeping it out of
 // L2 / Infinity Cache is measurably faster for stores and for fully coalesced loads (profiles/r01/membench.txt);
 // lane-strided loads that rely on L1/L2 to merge their 16-B pieces must NOT use it.
-template <int ND, bool NT = false>
+// ALIGNED = the host verified that every base pointer and row stride of the launch is a multiple of 16, which makes
+// each thread's ND-dword run aligned to its widest vector (16 B if ND%4==0, 8 B if ND%2==0, else 4 B): the per-lane
+// alignment tests -- divergent branches as far as the compiler can tell -- disappear from the pixel loop.
+template <int ND, bool NT = false, bool ALIGNED = false>
 AG_DEV void load_dwords(const uint8_t* p, uint32_t (&d)[ND])
 {
-    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uintptr_t a = ALIGNED ? 0 : reinterpret_cast<uintptr_t>(p);
     if constexpr (ND % 4 == 0) {
         if ((a & 15) == 0) {
 #pragma unroll
@@ -220,10 +223,10 @@ AG_DEV void load_dwords(const uint8_t* p, uint32_t (&d)[ND])
         d[j] = (uint32_t)p[4 * j] | ((uint32_t)p[4 * j + 1] << 8) | ((uint32_t)p[4 * j + 2] << 16) | ((uint32_t)p[4 * j + 3] << 24);
 }
 
-template <int ND, bool NT = false>
+template <int ND, bool NT = false, bool ALIGNED = false>
 AG_DEV void store_dwords(uint8_t* p, const uint32_t (&d)[ND])
 {
-    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uintptr_t a = ALIGNED ? 0 : reinterpret_cast<uintptr_t>(p);
     if constexpr (ND % 4 == 0) {
         if ((a & 15) == 0) {
 #pragma unroll
@@ -261,7 +264,7 @@ AG_DEV void store_dwords(uint8_t* p, const uint32_t (&d)[ND])
 // Store N samples (u8 or u16 containers) starting at `p`; `nvalid` < N only on the right image edge.
 // NT only where the lanes of a wave write CONTIGUOUS memory (planar stores): a lane-strided non-temporal store leaves
 // partial cache lines that nothing merges (measured 3.5x slower on the interleaved f32 read output).
-template <bool DST16, int N, bool NT = false>
+template <bool DST16, int N, bool NT = false, bool ALIGNED = false>
 AG_DEV void store_samples(uint8_t* p, const uint32_t (&v)[N], int nvalid)
 {
     constexpr int BYTES = N * (DST16 ? 2 : 1);
@@ -273,7 +276,7 @@ AG_DEV void store_samples(uint8_t* p, const uint32_t (&v)[N], int nvalid)
                 if constexpr (DST16) d[j] = v[2 * j] | (v[2 * j + 1] << 16);
                 else d[j] = v[4 * j] | (v[4 * j + 1] << 8) | (v[4 * j + 2] << 16) | (v[4 * j + 3] << 24);
             }
-            store_dwords<BYTES / 4, NT>(p, d);
+            store_dwords<BYTES / 4, NT, ALIGNED>(p, d);
             return;
         }
     }

@@ -185,7 +185,7 @@ AG_DEV void decode_pixel(const ReadParams& p, const Tables<LUT>& t, uint32_t u0,
 }
 
 // Load N consecutive samples of a plane row starting at sample index i0 (right-edge replicated to `count`).
-template <bool SRC16, int N>
+template <bool SRC16, int N, bool ALIGNED>
 AG_DEV void load_plane(const uint8_t* row, int i0, int count, uint32_t (&v)[N])
 {
     constexpr int SSZ = SRC16 ? 2 : 1;
@@ -193,7 +193,7 @@ AG_DEV void load_plane(const uint8_t* row, int i0, int count, uint32_t (&v)[N])
     if constexpr (BYTES % 4 == 0) {
         if (i0 + N <= count) {
             uint32_t d[BYTES / 4];
-            load_dwords<BYTES / 4, true>(row + (long long)i0 * SSZ, d);   // planar, coalesced, read once: non-temporal
+            load_dwords<BYTES / 4, true, ALIGNED>(row + (long long)i0 * SSZ, d);   // planar, coalesced, read once: non-temporal
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 if constexpr (SRC16) v[j] = (d[j >> 1] >> (16 * (j & 1))) & 0xffffu;
@@ -215,7 +215,7 @@ template <int DEPTH, int XS> struct ReadShape {
     static constexpr int PXT = NC << XS;
 };
 
-template <int CS, int DEPTH, bool ALPHA, int XS, int YS, int TRANSFER, bool LUT>
+template <int CS, int DEPTH, bool ALPHA, int XS, int YS, int TRANSFER, bool LUT, bool ALIGNED>
 __global__ __launch_bounds__(256) void read_px(const ReadParams p)
 {
     constexpr bool SRC16 = DEPTH != 8;
@@ -254,8 +254,8 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
 #pragma unroll
         for (int j = 0; j < NC; ++j) { c1[j] = 0; c2[j] = 0; }
         if constexpr (CS == kCsYcc) {                       // uvJ = y >> yChromaShift, uvI = x >> xChromaShift
-            load_plane<SRC16, NC>(p.src[1] + (long long)gy * p.src_stride[1], x0 >> XS, cw, c1);
-            load_plane<SRC16, NC>(p.src[2] + (long long)gy * p.src_stride[2], x0 >> XS, cw, c2);
+            load_plane<SRC16, NC, ALIGNED>(p.src[1] + (long long)gy * p.src_stride[1], x0 >> XS, cw, c1);
+            load_plane<SRC16, NC, ALIGNED>(p.src[2] + (long long)gy * p.src_stride[2], x0 >> XS, cw, c2);
         }
 
 #pragma unroll
@@ -263,11 +263,11 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
             const int r = r0 + vr;
             if (r >= p.nrows) continue;
             uint32_t y[PXT], a[PXT], g1[PXT], g2[PXT];
-            load_plane<SRC16, PXT>(p.src[0] + (long long)r * p.src_stride[0], x0, p.width, y);
-            if constexpr (ALPHA) load_plane<SRC16, PXT>(p.src[3] + (long long)r * p.src_stride[3], x0, p.width, a);
+            load_plane<SRC16, PXT, ALIGNED>(p.src[0] + (long long)r * p.src_stride[0], x0, p.width, y);
+            if constexpr (ALPHA) load_plane<SRC16, PXT, ALIGNED>(p.src[3] + (long long)r * p.src_stride[3], x0, p.width, a);
             if constexpr (CS == kCsRgb) {
-                load_plane<SRC16, PXT>(p.src[1] + (long long)r * p.src_stride[1], x0, p.width, g1);
-                load_plane<SRC16, PXT>(p.src[2] + (long long)r * p.src_stride[2], x0, p.width, g2);
+                load_plane<SRC16, PXT, ALIGNED>(p.src[1] + (long long)r * p.src_stride[1], x0, p.width, g1);
+                load_plane<SRC16, PXT, ALIGNED>(p.src[2] + (long long)r * p.src_stride[2], x0, p.width, g2);
             }
             uint32_t o[PXT * NCH];
 #pragma unroll
@@ -279,14 +279,14 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
             }
             uint8_t* drow = p.dst + (long long)r * p.dst_row_bytes + (long long)x0 * NCH * OSZ;
             if constexpr (DEPTH == 32) {
-                if (nvalid == PXT) store_dwords<PXT * NCH>(drow, o);           // lane-strided: no NT
+                if (nvalid == PXT) store_dwords<PXT * NCH, false, ALIGNED>(drow, o);   // lane-strided: no NT
                 else {
 #pragma unroll
                     for (int j = 0; j < PXT * NCH; ++j)
                         if (j < nvalid * NCH) reinterpret_cast<uint32_t*>(drow)[j] = o[j];
                 }
             } else {
-                store_samples<DEPTH == 16, PXT * NCH>(drow, o, nvalid * NCH);
+                store_samples<DEPTH == 16, PXT * NCH, false, ALIGNED>(drow, o, nvalid * NCH);
             }
         }
     }
@@ -306,12 +306,17 @@ static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, const cha
     static thread_local char label[160];
     snprintf(label, sizeof(label), "read_px<cs=%d,depth=%d,alpha=%d,xs=%d,ys=%d,transfer=%d>", CS, DEPTH, (int)ALPHA, XS, YS, TRANSFER);
     *name = label;
+    uintptr_t bits = reinterpret_cast<uintptr_t>(p.dst) | (uintptr_t)p.dst_row_bytes;
+    for (int pl = 0; pl < 4; ++pl) if (p.src[pl]) bits |= reinterpret_cast<uintptr_t>(p.src[pl]) | (uintptr_t)p.src_stride[pl];
+    const bool aligned = (bits & 15) == 0;      // => branch-free vector loads/stores in the pixel loop
+#define AG_READ_LAUNCH(LUT_, AL_) hipLaunchKernelGGL((read_px<CS, DEPTH, ALPHA, XS, YS, TRANSFER, LUT_, AL_>), dim3((int)blocks), dim3(256), lds, st, p)
     if constexpr (DEPTH == 8) {
-        hipLaunchKernelGGL((read_px<CS, DEPTH, ALPHA, XS, YS, TRANSFER, true>), dim3((int)blocks), dim3(256), lds, st, p);
+        if (aligned) AG_READ_LAUNCH(true, true); else AG_READ_LAUNCH(true, false);
     } else {
-        if (p.bits <= 12) hipLaunchKernelGGL((read_px<CS, DEPTH, ALPHA, XS, YS, TRANSFER, true>), dim3((int)blocks), dim3(256), lds, st, p);
-        else hipLaunchKernelGGL((read_px<CS, DEPTH, ALPHA, XS, YS, TRANSFER, false>), dim3((int)blocks), dim3(256), lds, st, p);
+        if (p.bits <= 12) { if (aligned) AG_READ_LAUNCH(true, true); else AG_READ_LAUNCH(true, false); }
+        else { if (aligned) AG_READ_LAUNCH(false, true); else AG_READ_LAUNCH(false, false); }
     }
+#undef AG_READ_LAUNCH
     return hipGetLastError();
 }
 

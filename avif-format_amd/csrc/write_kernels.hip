@@ -99,7 +99,7 @@ AG_DEV uint32_t stage_b_luma(const WriteParams& p, const uint32_t (&q)[4])
 // ---- generic kernel ----------------------------------------------------------------------------
 enum { kOutRefColor = 0, kOutRefGray = 1, kOutYcbcr = 2 };
 
-template <int DEPTH, int PLANES, int OUT, bool DST16, int XS, int YS, int TRANSFER>
+template <int DEPTH, int PLANES, int OUT, bool DST16, int XS, int YS, int TRANSFER, bool ALIGNED>
 __global__ __launch_bounds__(256) void write_px(const WriteParams p)
 {
     constexpr int PXT = (DST16 ? 4 : 8) << XS;   // 4 (u16 planes) or 8 (u8 planes) chroma samples per thread: every plane store >= 8 B/lane
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
             uint32_t s[PXT][PLANES];
             if (full) {
                 uint32_t raw[ND];
-                load_dwords<ND>(rowp + (long long)x0 * BPP, raw);
+                load_dwords<ND, false, ALIGNED>(rowp + (long long)x0 * BPP, raw);
 #pragma unroll
                 for (int i = 0; i < PXT; ++i)
 #pragma unroll
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
                     v[i * PLANES + 0] = q[vr][i][0]; v[i * PLANES + 1] = q[vr][i][1]; v[i * PLANES + 2] = q[vr][i][2];
                     if constexpr (ALPHA) v[i * PLANES + 3] = q[vr][i][3];
                 }
-                store_samples<DST16, PXT * PLANES>(p.dst[0] + (long long)r * p.dst_stride[0] + (long long)x0 * PLANES * DSZ,
+                store_samples<DST16, PXT * PLANES, false, ALIGNED>(p.dst[0] + (long long)r * p.dst_stride[0] + (long long)x0 * PLANES * DSZ,
                                                    v, nvalid * PLANES);
             } else {
                 uint32_t yv[PXT], av[PXT];
@@ -181,9 +181,9 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
                     else yv[i] = stage_b_luma(p, q[vr][i]);
                     av[i] = q[vr][i][3];
                 }
-                store_samples<DST16, PXT, true>(p.dst[0] + (long long)r * p.dst_stride[0] + (long long)x0 * DSZ, yv, nvalid);
+                store_samples<DST16, PXT, true, ALIGNED>(p.dst[0] + (long long)r * p.dst_stride[0] + (long long)x0 * DSZ, yv, nvalid);
                 if constexpr (ALPHA)
-                    store_samples<DST16, PXT, true>(p.dst[3] + (long long)r * p.dst_stride[3] + (long long)x0 * DSZ, av, nvalid);
+                    store_samples<DST16, PXT, true, ALIGNED>(p.dst[3] + (long long)r * p.dst_stride[3] + (long long)x0 * DSZ, av, nvalid);
             }
         }
 
@@ -211,8 +211,8 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
                 crv[j] = clip_round(cr + p.half, p.maxv);
             }
             const int ncvalid = (nvalid + (1 << XS) - 1) >> XS;
-            store_samples<DST16, NC, true>(p.dst[1] + (long long)gy * p.dst_stride[1] + (long long)(x0 >> XS) * DSZ, cbv, ncvalid);
-            store_samples<DST16, NC, true>(p.dst[2] + (long long)gy * p.dst_stride[2] + (long long)(x0 >> XS) * DSZ, crv, ncvalid);
+            store_samples<DST16, NC, true, ALIGNED>(p.dst[1] + (long long)gy * p.dst_stride[1] + (long long)(x0 >> XS) * DSZ, cbv, ncvalid);
+            store_samples<DST16, NC, true, ALIGNED>(p.dst[2] + (long long)gy * p.dst_stride[2] + (long long)(x0 >> XS) * DSZ, crv, ncvalid);
         }
     }
 }
@@ -396,10 +396,15 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, const char** 
     if (groups == 0) return hipSuccess;
     if (groups >= 0x7fffffffLL - 256LL * 65536) return hipErrorInvalidValue;   // 32-bit group index in the kernel
     static thread_local char label[160];
-    snprintf(label, sizeof(label), "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d>",
-             DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER);
+    // every pointer and stride a multiple of 16 => the branch-free vector path
+    uintptr_t bits = reinterpret_cast<uintptr_t>(p.src) | (uintptr_t)p.src_row_bytes;
+    for (int pl = 0; pl < 4; ++pl) if (p.dst[pl]) bits |= reinterpret_cast<uintptr_t>(p.dst[pl]) | (uintptr_t)p.dst_stride[pl];
+    const bool aligned = (bits & 15) == 0;
+    snprintf(label, sizeof(label), "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d>",
+             DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned);
     *name = label;
-    hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER>), dim3(grid_for(groups)), dim3(256), 0, st, p);
+    if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true>), dim3(grid_for(groups)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false>), dim3(grid_for(groups)), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 

@@ -100,7 +100,13 @@ def write_cases():
         ("tiny-3x2-ref", dict(width=3, height=2, depth=16, planes=4, bit_depth=10, alpha_state=pkg.ALPHA_PREMULTIPLIED,
                               output=pkg.OUT_REFERENCE)),
     ]
-    return out + extra
+    # the same branches through the ALIGNED kernel instantiations (every pointer / stride a multiple of 16)
+    aligned = []
+    for cid, kw in (out + extra)[::3]:
+        if kw["width"] == W_ODD:
+            k2 = dict(kw, width=128, height=10)
+            aligned.append((cid + "-al", k2))
+    return out + extra + aligned
 
 
 def is_float_tier_write(kw):
@@ -183,7 +189,8 @@ def read_cases():
     out.append(("tiny-read-1x1", dict(width=1, height=1, colorspace=pkg.COLORSPACE_YCBCR, chroma=pkg.CHROMA_420,
                                        bit_depth=8, depth=8, alpha_state=pkg.ALPHA_NONE,
                                        matrix_coefficients=pkg.MATRIX_BT709)))
-    return out
+    aligned = [(cid + "-al", dict(kw, width=128, height=10)) for cid, kw in out[::3] if kw["width"] == W_ODD]
+    return out + aligned
 
 
 def is_float_tier_read(kw):

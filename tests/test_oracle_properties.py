@@ -109,7 +109,7 @@ def test_write_tile_invariance(cid, kw):
     d = pkg.WriteDesc(**kw)
     src = harness.make_write_source(d)
     whole = harness.oracle_write(d, src)
-    cuts = [0, 6, 14, d.height]
+    cuts = [0, 2 * (d.height // 6), 2 * (d.height // 3), d.height]
     for pl, (w, xs, ys) in harness.write_planes(d).items():
         parts = [harness.oracle_write(d, src, row0=a, nrows=b - a)[pl] for a, b in zip(cuts[:-1], cuts[1:])]
         assert np.array_equal(np.concatenate(parts, axis=0), whole[pl]), (cid, pl)
