@@ -279,6 +279,17 @@ int fill_read_params(const avifgpu_read_desc* d, int nrows, const ReadGeom& g, R
     p.transfer = g.transfer;
     float k[3]; yuv_coefficients(d->has_nclx, d->matrix_coefficients, d->color_primaries, k);
     p.kr = k[0]; p.kg = k[1]; p.kb = k[2];
+    // Every kg the reference's tables can produce (5 matrix rows + 10 chromaticity-derived rows).  For these divisors
+    // tools/divcheck.hip proved on the GPU, for all 1.7e9 floats with 2^-100 <= |x| < 8, that
+    //   q0 = x*r;  q = fma(fma(-q0, kg, x), r, q0)   with r = RN(1/kg)
+    // is bit-identical to the IEEE quotient x / kg (profiles/r01/divcheck.txt).  Anything else keeps IEEE division.
+    static const uint32_t kVerifiedKg[] = { 0x3f371759u, 0x3f170a3du, 0x3f1645a1u, 0x3f3374bcu, 0x3f2d9169u, 0x3f37154au, 0x3f161fb4u,
+                                            0x3f34e753u, 0x3f3378a8u, 0x3f2da76au, 0x3f2d9147u, 0x3f800000u, 0x3f38ba77u, 0x3f3115c6u, 0x3f2c18a0u };
+    uint32_t kg_bits; memcpy(&kg_bits, &p.kg, 4);
+    p.fast_div = 0;
+    for (uint32_t v : kVerifiedKg) if (v == kg_bits) p.fast_div = 1;
+    if (getenv("AVIFGPU_FORCE_IEEE_DIV")) p.fast_div = 0;        // test hook: exercise the fallback
+    p.rcp_kg = 1.0f / p.kg;
     if (d->depth == 32) {
         p.pq_mult = 10000.0f / (float)(d->pq_peak_nits > 0 ? d->pq_peak_nits : 1);                                 // ColorTransfer.cpp:114
         p.hlg_ootf = d->hlg_apply_ootf != 0;

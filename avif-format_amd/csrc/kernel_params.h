@@ -45,6 +45,8 @@ struct ReadParams {
     int32_t premultiplied;
     int32_t transfer;            // AVIFGPU_TRANSFER_* (depth 32)
     float   kr, kg, kb;
+    float   rcp_kg;              // RN(1/kg)
+    int32_t fast_div;            // kg is on the exhaustively verified list (tools/divcheck.hip): x/kg in 3 FMAs is exact
     float   pq_mult;             // 10000 / peak (ColorTransfer.cpp:114)
     int32_t hlg_ootf;
     float   hlg_gamma_m1;        // displayGamma - 1

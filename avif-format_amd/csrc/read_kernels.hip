@@ -102,6 +102,19 @@ AG_DEV void eotf_rgb(const ReadParams& p, float (&c)[3])
 
 enum { kCsYcc = 0, kCsRgb = 1, kCsMono = 2 };
 
+// x / kg of the G equation (YuvDecode.cpp:314).  Fast form: exact for the verified divisors (see avifgpu_api.hip).
+__device__ __attribute__((noinline)) float ieee_div_slow(float x, float d) { return x / d; }
+AG_DEV float div_by_kg(const ReadParams& p, float x)
+{
+    if (__builtin_expect(p.fast_div != 0, 1)) {
+        const float q0 = x * p.rcp_kg;
+        return __builtin_fmaf(__builtin_fmaf(-q0, p.kg, x), p.rcp_kg, q0);
+    }
+    return ieee_div_slow(x, p.kg);
+}
+// std::clamp(v, 0, 1) for the finite values this path produces (v_med3_f32; a NaN cannot arise from table values).
+AG_DEV float clamp01(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); }
+
 // One pixel.  u[] = raw samples (Y,Cb,Cr | R,G,B | Y), ua = alpha sample.  out[] = NCH host samples
 // (u8/u16 values or f32 bit patterns).
 template <int CS, int DEPTH, bool ALPHA, int TRANSFER, bool LUT>
@@ -155,11 +168,11 @@ AG_DEV void decode_pixel(const ReadParams& p, const Tables<LUT>& t, uint32_t u0,
             return;
         } else {                                                    // YCbCr, YuvDecode.cpp:281-696
             const float Y = look_y(p, t, u0), Cb = look_uv(p, t, u1), Cr = look_uv(p, t, u2);
-            const float kr = p.kr, kg = p.kg, kb = p.kb;
+            const float kr = p.kr, kb = p.kb;
             float R = Y + (2 * (1 - kr)) * Cr;                                          // :312
             float B = Y + (2 * (1 - kb)) * Cb;                                          // :313
-            float G = Y - ((2 * ((kr * (1 - kr) * Cr) + (kb * (1 - kb) * Cb))) / kg);   // :314
-            R = cxx_clamp(R, 0.0f, 1.0f); G = cxx_clamp(G, 0.0f, 1.0f); B = cxx_clamp(B, 0.0f, 1.0f);
+            float G = Y - div_by_kg(p, 2 * ((kr * (1 - kr) * Cr) + (kb * (1 - kb) * Cb)));  // :314, "/ kg"
+            R = clamp01(R); G = clamp01(G); B = clamp01(B);
             if constexpr (ALPHA) {
                 if (p.premultiplied && ua < maxc) {                                     // :369-388
                     if (ua == 0) { R = 0.0f; G = 0.0f; B = 0.0f; }
@@ -238,55 +251,115 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
         t.ty = lut; t.tuv = lut + count; t.ta = lut + 2 * count;
     }
 
+    // ---- work mapping: a WAVE owns 64 consecutive thread-footprints of ONE row group, so its output is one
+    // contiguous span of the interleaved host row (needed by the transposed store below) -----------------------
+    constexpr int ND_OUT = PXT * NCH * OSZ / 4;           // packed output dwords per lane per row
+    constexpr int VW = (ND_OUT % 4 == 0) ? 4 : ((ND_OUT % 2 == 0) ? 2 : 1);   // dwords per coalesced transfer
+    constexpr int NTR = ND_OUT / VW;                       // transfers per lane
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    uint32_t* strip = nullptr;
+    if constexpr (ALIGNED) strip = reinterpret_cast<uint32_t*>(lut) + (LUT ? 3 * (1 << p.bits) : 0) + wave * (64 * ND_OUT);
+
     const int gxn = (p.width + PXT - 1) / PXT;
     const int gyn = (p.nrows + VR - 1) >> YS;
-    const uint32_t total = (uint32_t)gxn * (uint32_t)gyn;     // < 2^31 for any image <= 32767^2 (host checks): 32-bit udiv per trip
+    const uint32_t wpr = (uint32_t)(gxn + 63) >> 6;        // waves per row group
+    const uint32_t total_waves = wpr * (uint32_t)gyn;      // < 2^31 (host checks)
     const int cw = (p.width + (1 << XS) - 1) >> XS;
 
-    for (uint32_t g = blockIdx.x * 256 + threadIdx.x; g < total; g += gridDim.x * 256) {
-        const int gy = (int)(g / (uint32_t)gxn);
-        const int gx = (int)(g - (uint32_t)gy * (uint32_t)gxn);
+    for (uint32_t wv = blockIdx.x * 4 + wave; wv < total_waves; wv += gridDim.x * 4) {
+        const int gy = (int)(wv / wpr);
+        const int wx = (int)(wv - (uint32_t)gy * wpr);
+        const int gx = wx * 64 + lane;
+        const bool active = gx < gxn;
         const int x0 = gx * PXT;
         const int r0 = gy * VR;
-        const int nvalid = min(PXT, p.width - x0);
+        const int nvalid = active ? min(PXT, p.width - x0) : 0;
 
         uint32_t c1[NC], c2[NC];
 #pragma unroll
         for (int j = 0; j < NC; ++j) { c1[j] = 0; c2[j] = 0; }
         if constexpr (CS == kCsYcc) {                       // uvJ = y >> yChromaShift, uvI = x >> xChromaShift
-            load_plane<SRC16, NC, ALIGNED>(p.src[1] + (long long)gy * p.src_stride[1], x0 >> XS, cw, c1);
-            load_plane<SRC16, NC, ALIGNED>(p.src[2] + (long long)gy * p.src_stride[2], x0 >> XS, cw, c2);
+            if (active) {
+                load_plane<SRC16, NC, ALIGNED>(p.src[1] + (long long)gy * p.src_stride[1], x0 >> XS, cw, c1);
+                load_plane<SRC16, NC, ALIGNED>(p.src[2] + (long long)gy * p.src_stride[2], x0 >> XS, cw, c2);
+            }
         }
 
 #pragma unroll
         for (int vr = 0; vr < VR; ++vr) {
             const int r = r0 + vr;
-            if (r >= p.nrows) continue;
-            uint32_t y[PXT], a[PXT], g1[PXT], g2[PXT];
-            load_plane<SRC16, PXT, ALIGNED>(p.src[0] + (long long)r * p.src_stride[0], x0, p.width, y);
-            if constexpr (ALPHA) load_plane<SRC16, PXT, ALIGNED>(p.src[3] + (long long)r * p.src_stride[3], x0, p.width, a);
-            if constexpr (CS == kCsRgb) {
-                load_plane<SRC16, PXT, ALIGNED>(p.src[1] + (long long)r * p.src_stride[1], x0, p.width, g1);
-                load_plane<SRC16, PXT, ALIGNED>(p.src[2] + (long long)r * p.src_stride[2], x0, p.width, g2);
-            }
+            if (r >= p.nrows) continue;                     // wave-uniform
             uint32_t o[PXT * NCH];
-#pragma unroll
-            for (int i = 0; i < PXT; ++i) {
-                uint32_t u1 = 0, u2 = 0;
-                if constexpr (CS == kCsYcc) { u1 = c1[i >> XS]; u2 = c2[i >> XS]; }
-                if constexpr (CS == kCsRgb) { u1 = g1[i]; u2 = g2[i]; }
-                decode_pixel<CS, DEPTH, ALPHA, TRANSFER, LUT>(p, t, y[i], u1, u2, ALPHA ? a[i] : (uint32_t)p.maxc, &o[i * NCH]);
-            }
-            uint8_t* drow = p.dst + (long long)r * p.dst_row_bytes + (long long)x0 * NCH * OSZ;
-            if constexpr (DEPTH == 32) {
-                if (nvalid == PXT) store_dwords<PXT * NCH, false, ALIGNED>(drow, o);   // lane-strided: no NT
-                else {
-#pragma unroll
-                    for (int j = 0; j < PXT * NCH; ++j)
-                        if (j < nvalid * NCH) reinterpret_cast<uint32_t*>(drow)[j] = o[j];
+            if (active) {
+                uint32_t y[PXT], a[PXT], g1[PXT], g2[PXT];
+                load_plane<SRC16, PXT, ALIGNED>(p.src[0] + (long long)r * p.src_stride[0], x0, p.width, y);
+                if constexpr (ALPHA) load_plane<SRC16, PXT, ALIGNED>(p.src[3] + (long long)r * p.src_stride[3], x0, p.width, a);
+                if constexpr (CS == kCsRgb) {
+                    load_plane<SRC16, PXT, ALIGNED>(p.src[1] + (long long)r * p.src_stride[1], x0, p.width, g1);
+                    load_plane<SRC16, PXT, ALIGNED>(p.src[2] + (long long)r * p.src_stride[2], x0, p.width, g2);
                 }
+#pragma unroll
+                for (int i = 0; i < PXT; ++i) {
+                    uint32_t u1 = 0, u2 = 0;
+                    if constexpr (CS == kCsYcc) { u1 = c1[i >> XS]; u2 = c2[i >> XS]; }
+                    if constexpr (CS == kCsRgb) { u1 = g1[i]; u2 = g2[i]; }
+                    decode_pixel<CS, DEPTH, ALPHA, TRANSFER, LUT>(p, t, y[i], u1, u2, ALPHA ? a[i] : (uint32_t)p.maxc, &o[i * NCH]);
+                }
+            }
+
+            if constexpr (ALIGNED) {
+                // ---- transposed store: lane-major packed dwords -> wave-private LDS strip -> transfer-major read-back,
+                // so that every global store instruction writes 64 x VW dwords of CONTIGUOUS memory (non-temporal).
+                // A lane-strided store leaves partial lines for L2 to merge and ran at 0.33-0.6 of the HBM rate. ----
+                uint32_t pk[ND_OUT];
+#pragma unroll
+                for (int j = 0; j < ND_OUT; ++j) {
+                    if constexpr (DEPTH == 8) pk[j] = o[4 * j] | (o[4 * j + 1] << 8) | (o[4 * j + 2] << 16) | (o[4 * j + 3] << 24);
+                    else if constexpr (DEPTH == 16) pk[j] = o[2 * j] | (o[2 * j + 1] << 16);
+                    else pk[j] = o[j];
+                }
+                if (active) {
+#pragma unroll
+                    for (int j = 0; j < NTR; ++j) {
+                        uint32_t* w = strip + lane * ND_OUT + j * VW;
+                        if constexpr (VW == 4) *reinterpret_cast<dm_u32x4*>(w) = dm_u32x4{ pk[4 * j], pk[4 * j + 1], pk[4 * j + 2], pk[4 * j + 3] };
+                        else if constexpr (VW == 2) *reinterpret_cast<dm_u32x2*>(w) = dm_u32x2{ pk[2 * j], pk[2 * j + 1] };
+                        else *w = pk[j];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                const int span_px = min(64 * PXT, p.width - wx * 64 * PXT);          // valid pixels of this wave's span
+                const int span_bytes = span_px * NCH * OSZ;
+                uint8_t* dspan = p.dst + (long long)r * p.dst_row_bytes + (long long)wx * (64 * PXT * NCH * OSZ);
+#pragma unroll
+                for (int j = 0; j < NTR; ++j) {
+                    const int off = (j * 64 + lane) * (VW * 4);
+                    const uint32_t* rd = strip + (j * 64 + lane) * VW;
+                    if (off + VW * 4 <= span_bytes) {
+                        if constexpr (VW == 4) __builtin_nontemporal_store(*reinterpret_cast<const dm_u32x4*>(rd), reinterpret_cast<dm_u32x4*>(dspan + off));
+                        else if constexpr (VW == 2) __builtin_nontemporal_store(*reinterpret_cast<const dm_u32x2*>(rd), reinterpret_cast<dm_u32x2*>(dspan + off));
+                        else __builtin_nontemporal_store(*rd, reinterpret_cast<uint32_t*>(dspan + off));
+                    } else if (off < span_bytes) {                                    // ragged right edge: byte tail
+                        const uint8_t* rb = reinterpret_cast<const uint8_t*>(rd);
+                        for (int k = 0; k < span_bytes - off; ++k) dspan[off + k] = rb[k];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             } else {
-                store_samples<DEPTH == 16, PXT * NCH, false, ALIGNED>(drow, o, nvalid * NCH);
+                if (active) {
+                    uint8_t* drow = p.dst + (long long)r * p.dst_row_bytes + (long long)x0 * NCH * OSZ;
+                    if constexpr (DEPTH == 32) {
+                        if (nvalid == PXT) store_dwords<PXT * NCH, false, false>(drow, o);   // lane-strided: no NT
+                        else {
+#pragma unroll
+                            for (int j = 0; j < PXT * NCH; ++j)
+                                if (j < nvalid * NCH) reinterpret_cast<uint32_t*>(drow)[j] = o[j];
+                        }
+                    } else {
+                        store_samples<DEPTH == 16, PXT * NCH, false, false>(drow, o, nvalid * NCH);
+                    }
+                }
             }
         }
     }
@@ -300,15 +373,20 @@ static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, const cha
     const long long groups = (long long)((p.width + PXT - 1) / PXT) * ((p.nrows + (1 << YS) - 1) >> YS);
     if (groups == 0) return hipSuccess;
     if (groups >= 0x7fffffffLL - 256LL * 65536) return hipErrorInvalidValue;   // 32-bit group index in the kernel
-    long long blocks = (groups + 255) / 256;
+    constexpr int NCHL = (CS == kCsMono ? 1 : 3) + (ALPHA ? 1 : 0);
+    constexpr int ND_OUT = PXT * NCHL * (DEPTH / 8) / 4;
+    const long long waves = (long long)(((p.width + PXT - 1) / PXT + 63) / 64) * ((p.nrows + (1 << YS) - 1) >> YS);
+    long long blocks = (waves + 3) / 4;
     if (blocks > 256LL * 8) blocks = 256LL * 8;          // tables are rebuilt per block: keep blocks persistent-ish
-    const size_t lds = p.bits <= 12 ? (size_t)3 * (1u << p.bits) * sizeof(float) : 0;
+    const size_t lut_bytes = p.bits <= 12 ? (size_t)3 * (1u << p.bits) * sizeof(float) : 0;
     static thread_local char label[160];
-    snprintf(label, sizeof(label), "read_px<cs=%d,depth=%d,alpha=%d,xs=%d,ys=%d,transfer=%d>", CS, DEPTH, (int)ALPHA, XS, YS, TRANSFER);
-    *name = label;
     uintptr_t bits = reinterpret_cast<uintptr_t>(p.dst) | (uintptr_t)p.dst_row_bytes;
     for (int pl = 0; pl < 4; ++pl) if (p.src[pl]) bits |= reinterpret_cast<uintptr_t>(p.src[pl]) | (uintptr_t)p.src_stride[pl];
-    const bool aligned = (bits & 15) == 0;      // => branch-free vector loads/stores in the pixel loop
+    const bool aligned = (bits & 15) == 0;      // => branch-free vector loads + LDS-transposed coalesced stores
+    const size_t lds = lut_bytes + (aligned ? (size_t)4 * 64 * ND_OUT * sizeof(uint32_t) : 0);
+    snprintf(label, sizeof(label), "read_px<cs=%d,depth=%d,alpha=%d,xs=%d,ys=%d,transfer=%d,aligned=%d>", CS, DEPTH, (int)ALPHA, XS, YS,
+             TRANSFER, (int)aligned);
+    *name = label;
 #define AG_READ_LAUNCH(LUT_, AL_) hipLaunchKernelGGL((read_px<CS, DEPTH, ALPHA, XS, YS, TRANSFER, LUT_, AL_>), dim3((int)blocks), dim3(256), lds, st, p)
     if constexpr (DEPTH == 8) {
         if (aligned) AG_READ_LAUNCH(true, true); else AG_READ_LAUNCH(true, false);

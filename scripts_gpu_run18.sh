@@ -1,0 +1,3 @@
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests -m gpu -q --maxfail=10 2>&1 | tail -3
+python tools/bench_configs.py 2>/dev/null | grep '"R' > gpurun_out/configs_read.jsonl; cat gpurun_out/configs_read.jsonl

@@ -190,6 +190,16 @@ def read_cases():
                                        bit_depth=8, depth=8, alpha_state=pkg.ALPHA_NONE,
                                        matrix_coefficients=pkg.MATRIX_BT709)))
     aligned = [(cid + "-al", dict(kw, width=128, height=10)) for cid, kw in out[::3] if kw["width"] == W_ODD]
+    # largest dynamic-LDS footprint of read_px: 12-bit tables (48 KiB) + RGBA f32 4:2:0 transpose strips (32 KiB)
+    aligned.append(("f32-maxlds-b12-420-rgba", dict(width=1024 + 32, height=6, colorspace=pkg.COLORSPACE_YCBCR,
+                                                     chroma=pkg.CHROMA_420, bit_depth=12, depth=32,
+                                                     alpha_state=pkg.ALPHA_PREMULTIPLIED,
+                                                     matrix_coefficients=pkg.MATRIX_BT2020_NCL,
+                                                     color_primaries=pkg.PRIMARIES_BT2020,
+                                                     transfer_characteristics=pkg.TC_PQ, pq_peak_nits=1000)))
+    aligned.append(("ycc-b8-wide-420", dict(width=2048 + 48, height=4, colorspace=pkg.COLORSPACE_YCBCR,
+                                             chroma=pkg.CHROMA_420, bit_depth=8, depth=8, alpha_state=pkg.ALPHA_NONE,
+                                             matrix_coefficients=pkg.MATRIX_BT709)))
     return out + aligned
 
 
