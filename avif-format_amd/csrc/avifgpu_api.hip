@@ -292,6 +292,7 @@ int fill_read_params(const avifgpu_read_desc* d, int nrows, const ReadGeom& g, R
     p.rcp_kg = 1.0f / p.kg;
     if (d->depth == 32) {
         p.pq_mult = 10000.0f / (float)(d->pq_peak_nits > 0 ? d->pq_peak_nits : 1);                                 // ColorTransfer.cpp:114
+        p.pq_log2_mult = (float)std::log2((double)p.pq_mult);
         p.hlg_ootf = d->hlg_apply_ootf != 0;
         p.hlg_gamma_m1 = d->hlg_display_gamma - 1.0f;
         p.hlg_peak = (float)d->hlg_peak_nits;

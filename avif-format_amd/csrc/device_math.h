@@ -82,27 +82,26 @@ AG_DEV float fast_linear_to_pq(float value, float mult)
 // result by up to 4.5e-5 relative, which is also the reference's own float noise floor.  Here delta = 1 - x =
 // -expm1(ln(v)/m2) is evaluated directly (|ln(v)/m2| <= 0.16 for every non-zero 12-bit code), and with
 // 1 - c1 = c2 - c3 = 0.1640625 exactly:  x - c1 = 0.1640625 - delta,  c2 - c3 x = 0.1640625 + c3 delta.
-AG_DEV float fast_pq_to_linear(float value, float mult)
+// log2_mult = log2(10000 / peak): the final "* luminanceMultiplier" is folded into the last exponent.
+// Cost: 4 quarter-rate transcendentals + 14 full-rate ops per sample.
+AG_DEV float fast_pq_to_linear_l2(float value, float log2_mult)
 {
-    if (!(value > 0.0f)) return 0.0f;                                   // v <= 0 (and NaN) -> 0
-    const float t = nat_log2(value) * (0.6931471805599453f / kPqM2);    // ln(v) / m2  (<= 0 for v <= 1)
-    float delta;
-    if (t > -0.25f && t < 0.25f) {
-        float p = __builtin_fmaf(t, 1.0f / 5040.0f, 1.0f / 720.0f);
-        p = __builtin_fmaf(p, t, 1.0f / 120.0f);
-        p = __builtin_fmaf(p, t, 1.0f / 24.0f);
-        p = __builtin_fmaf(p, t, 1.0f / 6.0f);
-        p = __builtin_fmaf(p, t, 0.5f);
-        p = __builtin_fmaf(p, t, 1.0f);
-        delta = -(t * p);                                               // 1 - e^t
-    } else {
-        delta = 1.0f - nat_exp2(t * 1.4426950408889634f);
-    }
+    // t = ln(v)/m2.  v <= 0 or NaN give -inf / NaN from v_log_f32; v_max_f32 turns both into -0.5, where
+    // delta = 0.39 > 1 - c1 and the result is exactly 0 -- the same 0 the reference returns for v <= c1^m2.
+    const float t = fmaxf(nat_log2(value) * (0.6931471805599453f / kPqM2), -0.5f);
+    float p = __builtin_fmaf(t, 1.0f / 5040.0f, 1.0f / 720.0f);
+    p = __builtin_fmaf(p, t, 1.0f / 120.0f);
+    p = __builtin_fmaf(p, t, 1.0f / 24.0f);
+    p = __builtin_fmaf(p, t, 1.0f / 6.0f);
+    p = __builtin_fmaf(p, t, 0.5f);
+    p = __builtin_fmaf(p, t, 1.0f);
+    const float delta = -(t * p);                                       // 1 - e^t, |t| <= 0.5: series error < 1e-9
     const float k = 1.0f - kPqC1;                                       // = c2 - c3 = 0.1640625
     const float num = fmaxf(k - delta, 0.0f);
     const float den = __builtin_fmaf(kPqC3, delta, k);
-    return fast_pow(num * fast_rcp_nr(den), 1.0f / kPqM1) * mult;
+    return nat_exp2(__builtin_fmaf(1.0f / kPqM1, nat_log2(num * nat_rcp(den)), log2_mult));
 }
+AG_DEV float fast_pq_to_linear(float value, float mult) { return fast_pq_to_linear_l2(value, nat_log2(mult)); }
 
 // LinearToSMPTE428 / SMPTE428ToLinear, reference ColorTransfer.cpp:119-139.
 AG_DEV float fast_linear_to_smpte428(float value)
@@ -259,6 +258,84 @@ AG_DEV void store_dwords(uint8_t* p, const uint32_t (&d)[ND])
         p[4 * j] = (uint8_t)d[j]; p[4 * j + 1] = (uint8_t)(d[j] >> 8);
         p[4 * j + 2] = (uint8_t)(d[j] >> 16); p[4 * j + 3] = (uint8_t)(d[j] >> 24);
     }
+}
+
+// ---- wave-private LDS transposes between "lane-major" (each lane owns NDW consecutive dwords) and "transfer-major"
+// (dword index (j*64 + lane)*VW) orderings of one wave's contiguous span of 64*NDW dwords in global memory.
+// Transfer-major is what a fully coalesced wave access looks like: 64 x VW dwords of contiguous memory per
+// instruction.  Lane-major is what the per-pixel math wants.  The strip is private to the wave: no s_barrier, DS ops
+// of one wave complete in order; wave_barrier only pins the compiler's schedule.  All pointers 16-byte aligned.
+template <int NDW> struct WaveSpan {
+    static constexpr int VW = (NDW % 4 == 0) ? 4 : ((NDW % 2 == 0) ? 2 : 1);   // dwords per transfer
+    static constexpr int NTR = NDW / VW;                                        // transfers per lane
+};
+
+// `w` / `r` are VW*4-byte aligned by construction; tell the compiler so it emits ds_*_b64 / b128, not dword pairs.
+template <int VW> AG_DEV void lds_put(uint32_t* w, const uint32_t* v)
+{
+    if constexpr (VW == 4) *reinterpret_cast<dm_u32x4*>(__builtin_assume_aligned(w, 16)) = dm_u32x4{ v[0], v[1], v[2], v[3] };
+    else if constexpr (VW == 2) *reinterpret_cast<dm_u32x2*>(__builtin_assume_aligned(w, 8)) = dm_u32x2{ v[0], v[1] };
+    else *w = v[0];
+}
+template <int VW> AG_DEV void lds_get(const uint32_t* r, uint32_t* v)
+{
+    if constexpr (VW == 4) { const dm_u32x4 t = *reinterpret_cast<const dm_u32x4*>(__builtin_assume_aligned(r, 16)); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else if constexpr (VW == 2) { const dm_u32x2 t = *reinterpret_cast<const dm_u32x2*>(__builtin_assume_aligned(r, 8)); v[0] = t.x; v[1] = t.y; }
+    else v[0] = *r;
+}
+
+// global (contiguous span, `span_bytes` valid) --coalesced NT loads--> LDS --> lane-major registers
+template <int NDW>
+AG_DEV void wave_span_load(uint32_t* strip, int lane, const uint8_t* span, int span_bytes, uint32_t (&out)[NDW])
+{
+    constexpr int VW = WaveSpan<NDW>::VW, NTR = WaveSpan<NDW>::NTR;
+#pragma unroll
+    for (int j = 0; j < NTR; ++j) {
+        const int off = (j * 64 + lane) * (VW * 4);
+        uint32_t v[4] = { 0, 0, 0, 0 };
+        if (off + VW * 4 <= span_bytes) {
+            if constexpr (VW == 4) { const dm_u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const dm_u32x4*>(span + off)); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+            else if constexpr (VW == 2) { const dm_u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const dm_u32x2*>(span + off)); v[0] = t.x; v[1] = t.y; }
+            else v[0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(span + off));
+        } else if (off < span_bytes) {                                // ragged right edge: byte tail
+#pragma clang loop vectorize(disable) unroll(disable)
+            for (int k = 0; k < span_bytes - off; ++k) v[k >> 2] |= (uint32_t)span[off + k] << (8 * (k & 3));
+        }
+        lds_put<VW>(strip + (j * 64 + lane) * VW, v);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < NTR; ++j) lds_get<VW>(strip + lane * NDW + j * VW, &out[j * VW]);
+    __builtin_amdgcn_wave_barrier();
+}
+
+// lane-major registers --> LDS --coalesced NT stores--> global (contiguous span, `span_bytes` valid)
+template <int NDW>
+AG_DEV void wave_span_store(uint32_t* strip, int lane, bool active, const uint32_t (&in)[NDW], uint8_t* span, int span_bytes)
+{
+    constexpr int VW = WaveSpan<NDW>::VW, NTR = WaveSpan<NDW>::NTR;
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < NTR; ++j) lds_put<VW>(strip + lane * NDW + j * VW, &in[j * VW]);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < NTR; ++j) {
+        const int off = (j * 64 + lane) * (VW * 4);
+        const uint32_t* rd = strip + (j * 64 + lane) * VW;
+        if (off + VW * 4 <= span_bytes) {
+            uint32_t v[4];
+            lds_get<VW>(rd, v);
+            if constexpr (VW == 4) __builtin_nontemporal_store(dm_u32x4{ v[0], v[1], v[2], v[3] }, reinterpret_cast<dm_u32x4*>(span + off));
+            else if constexpr (VW == 2) __builtin_nontemporal_store(dm_u32x2{ v[0], v[1] }, reinterpret_cast<dm_u32x2*>(span + off));
+            else __builtin_nontemporal_store(v[0], reinterpret_cast<uint32_t*>(span + off));
+        } else if (off < span_bytes) {
+            const uint8_t* rb = reinterpret_cast<const uint8_t*>(rd);
+#pragma clang loop vectorize(disable) unroll(disable)
+            for (int k = 0; k < span_bytes - off; ++k) span[off + k] = rb[k];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
 }
 
 // Store N samples (u8 or u16 containers) starting at `p`; `nvalid` < N only on the right image edge.

@@ -48,6 +48,7 @@ struct ReadParams {
     float   rcp_kg;              // RN(1/kg)
     int32_t fast_div;            // kg is on the exhaustively verified list (tools/divcheck.hip): x/kg in 3 FMAs is exact
     float   pq_mult;             // 10000 / peak (ColorTransfer.cpp:114)
+    float   pq_log2_mult;        // log2(pq_mult), folded into the EOTF's last exponent
     int32_t hlg_ootf;
     float   hlg_gamma_m1;        // displayGamma - 1
     float   hlg_peak;

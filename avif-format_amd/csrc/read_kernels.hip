@@ -85,7 +85,7 @@ AG_DEV void eotf_rgb(const ReadParams& p, float (&c)[3])
 {
     if constexpr (TRANSFER == AVIFGPU_TRANSFER_PQ) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) c[k] = fast_pq_to_linear(c[k], p.pq_mult);
+        for (int k = 0; k < 3; ++k) c[k] = fast_pq_to_linear_l2(c[k], p.pq_log2_mult);
     } else if constexpr (TRANSFER == AVIFGPU_TRANSFER_HLG) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) c[k] = fast_hlg_to_linear(c[k]);
@@ -154,7 +154,7 @@ AG_DEV void decode_pixel(const ReadParams& p, const Tables<LUT>& t, uint32_t u0,
                     if (p.premultiplied && ua < maxc)               // integer-domain unpremultiply, :247-260
                         u0 = (ua == 0) ? 0u : exact_unpremultiply(u0, ua, (float)p.maxc);
                 }
-                out[0] = __float_as_uint(fast_pq_to_linear(look_y(p, t, u0), p.pq_mult));
+                out[0] = __float_as_uint(fast_pq_to_linear_l2(look_y(p, t, u0), p.pq_log2_mult));
                 if constexpr (ALPHA) out[1] = __float_as_uint(look_a(p, t, ua));
             } else {
                 float Y = look_y(p, t, u0);
@@ -254,8 +254,6 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
     // ---- work mapping: a WAVE owns 64 consecutive thread-footprints of ONE row group, so its output is one
     // contiguous span of the interleaved host row (needed by the transposed store below) -----------------------
     constexpr int ND_OUT = PXT * NCH * OSZ / 4;           // packed output dwords per lane per row
-    constexpr int VW = (ND_OUT % 4 == 0) ? 4 : ((ND_OUT % 2 == 0) ? 2 : 1);   // dwords per coalesced transfer
-    constexpr int NTR = ND_OUT / VW;                       // transfers per lane
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint32_t* strip = nullptr;
@@ -319,33 +317,9 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
                     else if constexpr (DEPTH == 16) pk[j] = o[2 * j] | (o[2 * j + 1] << 16);
                     else pk[j] = o[j];
                 }
-                if (active) {
-#pragma unroll
-                    for (int j = 0; j < NTR; ++j) {
-                        uint32_t* w = strip + lane * ND_OUT + j * VW;
-                        if constexpr (VW == 4) *reinterpret_cast<dm_u32x4*>(w) = dm_u32x4{ pk[4 * j], pk[4 * j + 1], pk[4 * j + 2], pk[4 * j + 3] };
-                        else if constexpr (VW == 2) *reinterpret_cast<dm_u32x2*>(w) = dm_u32x2{ pk[2 * j], pk[2 * j + 1] };
-                        else *w = pk[j];
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
                 const int span_px = min(64 * PXT, p.width - wx * 64 * PXT);          // valid pixels of this wave's span
-                const int span_bytes = span_px * NCH * OSZ;
-                uint8_t* dspan = p.dst + (long long)r * p.dst_row_bytes + (long long)wx * (64 * PXT * NCH * OSZ);
-#pragma unroll
-                for (int j = 0; j < NTR; ++j) {
-                    const int off = (j * 64 + lane) * (VW * 4);
-                    const uint32_t* rd = strip + (j * 64 + lane) * VW;
-                    if (off + VW * 4 <= span_bytes) {
-                        if constexpr (VW == 4) __builtin_nontemporal_store(*reinterpret_cast<const dm_u32x4*>(rd), reinterpret_cast<dm_u32x4*>(dspan + off));
-                        else if constexpr (VW == 2) __builtin_nontemporal_store(*reinterpret_cast<const dm_u32x2*>(rd), reinterpret_cast<dm_u32x2*>(dspan + off));
-                        else __builtin_nontemporal_store(*rd, reinterpret_cast<uint32_t*>(dspan + off));
-                    } else if (off < span_bytes) {                                    // ragged right edge: byte tail
-                        const uint8_t* rb = reinterpret_cast<const uint8_t*>(rd);
-                        for (int k = 0; k < span_bytes - off; ++k) dspan[off + k] = rb[k];
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
+                wave_span_store<ND_OUT>(strip, lane, active, pk, p.dst + (long long)r * p.dst_row_bytes + (long long)wx * (64 * PXT * NCH * OSZ),
+                                        span_px * NCH * OSZ);
             } else {
                 if (active) {
                     uint8_t* drow = p.dst + (long long)r * p.dst_row_bytes + (long long)x0 * NCH * OSZ;

@@ -109,17 +109,31 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
     constexpr bool ALPHA = (PLANES == 2 || PLANES == 4);
     constexpr int DSZ = DST16 ? 2 : 1;
 
+    // ---- work mapping: a WAVE owns 64 consecutive thread-footprints of ONE row group => its interleaved source (and
+    // interleaved output, if any) is one contiguous span per row, moved with fully coalesced non-temporal accesses
+    // through a wave-private LDS strip (ALIGNED instantiation; the unaligned one keeps per-lane accesses). ----------
+    constexpr int NDO = (OUT == kOutRefColor) ? PXT * PLANES * DSZ / 4 : 1;     // interleaved-output dwords per lane per row
+    constexpr int NDS = NDO;
+    __shared__ __attribute__((aligned(16))) uint32_t strips[ALIGNED ? 4 : 1][ALIGNED ? 64 * NDS : 1];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    uint32_t* strip = strips[ALIGNED ? wave : 0];
+
     const int gxn = (p.width + PXT - 1) / PXT;
     const int gyn = (p.nrows + VR - 1) >> YS;
-    const uint32_t total = (uint32_t)gxn * (uint32_t)gyn;     // < 2^31 for any image <= 32767^2 (host checks): 32-bit udiv per trip
+    const uint32_t wpr = (uint32_t)(gxn + 63) >> 6;        // waves per row group
+    const uint32_t total_waves = wpr * (uint32_t)gyn;      // < 2^31 (host checks)
 
-    for (uint32_t g = blockIdx.x * 256 + threadIdx.x; g < total; g += gridDim.x * 256) {
-        const int gy = (int)(g / (uint32_t)gxn);
-        const int gx = (int)(g - (uint32_t)gy * (uint32_t)gxn);
+    for (uint32_t wv = blockIdx.x * 4 + wave; wv < total_waves; wv += gridDim.x * 4) {
+        const int gy = (int)(wv / wpr);
+        const int wx = (int)(wv - (uint32_t)gy * wpr);
+        const int gx = wx * 64 + lane;
+        const bool active = gx < gxn;
         const int x0 = gx * PXT;
         const int r0 = gy * VR;
-        const int nvalid = min(PXT, p.width - x0);
+        const int nvalid = active ? min(PXT, p.width - x0) : 0;
         const bool full = nvalid == PXT;
+        const int span_px = min(64 * PXT, p.width - wx * 64 * PXT);              // valid pixels of this wave's span
 
         uint32_t q[VR][PXT][4];
 
@@ -130,6 +144,9 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
             const uint8_t* rowp = p.src + (long long)r * p.src_row_bytes;
             uint32_t s[PXT][PLANES];
             if (full) {
+                // Per-lane vector loads of the lane's own ND dwords (lane stride = footprint): L1/L2 merge the 16-B pieces and
+                // this measured FASTER than a coalesced-NT + LDS-transpose load stage (which costs 12-20 VGPRs and a wave of
+                // occupancy: C4 4:2:0 0.69 -> 0.47 of peak, profiles/r01/transposed_load_experiment.txt).
                 uint32_t raw[ND];
                 load_dwords<ND, false, ALIGNED>(rowp + (long long)x0 * BPP, raw);
 #pragma unroll
@@ -141,7 +158,7 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
                         else if constexpr (DEPTH == 16) s[i][k] = (raw[e >> 1] >> (16 * (e & 1))) & 0xffffu;
                         else s[i][k] = raw[e];
                     }
-            } else {
+            } else if (active) {
 #pragma unroll
                 for (int i = 0; i < PXT; ++i) {
                     const int x = min(x0 + i, p.width - 1);     // right edge: replicate last pixel
@@ -153,6 +170,11 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
                         else s[i][k] = ld_u32(pp + 4 * k);
                     }
                 }
+            } else {
+#pragma unroll
+                for (int i = 0; i < PXT; ++i)
+#pragma unroll
+                    for (int k = 0; k < PLANES; ++k) s[i][k] = 0;
             }
 #pragma unroll
             for (int i = 0; i < PXT; ++i) stage_a<DEPTH, PLANES, TRANSFER>(p, s[i], q[vr][i]);
@@ -171,9 +193,20 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
                     v[i * PLANES + 0] = q[vr][i][0]; v[i * PLANES + 1] = q[vr][i][1]; v[i * PLANES + 2] = q[vr][i][2];
                     if constexpr (ALPHA) v[i * PLANES + 3] = q[vr][i][3];
                 }
-                store_samples<DST16, PXT * PLANES, false, ALIGNED>(p.dst[0] + (long long)r * p.dst_stride[0] + (long long)x0 * PLANES * DSZ,
-                                                   v, nvalid * PLANES);
-            } else {
+                if constexpr (ALIGNED) {
+                    uint32_t pk[NDO];
+#pragma unroll
+                    for (int j = 0; j < NDO; ++j) {
+                        if constexpr (DST16) pk[j] = v[2 * j] | (v[2 * j + 1] << 16);
+                        else pk[j] = v[4 * j] | (v[4 * j + 1] << 8) | (v[4 * j + 2] << 16) | (v[4 * j + 3] << 24);
+                    }
+                    wave_span_store<NDO>(strip, lane, active, pk, p.dst[0] + (long long)r * p.dst_stride[0] + (long long)wx * (64 * PXT * PLANES * DSZ),
+                                         span_px * PLANES * DSZ);
+                } else if (active) {
+                    store_samples<DST16, PXT * PLANES, false, false>(p.dst[0] + (long long)r * p.dst_stride[0] + (long long)x0 * PLANES * DSZ,
+                                                                     v, nvalid * PLANES);
+                }
+            } else if (active) {
                 uint32_t yv[PXT], av[PXT];
 #pragma unroll
                 for (int i = 0; i < PXT; ++i) {
@@ -187,7 +220,7 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
             }
         }
 
-        if constexpr (OUT == kOutYcbcr) {
+        if (OUT == kOutYcbcr && active) {
             constexpr int NC = PXT >> XS;       // 4 chroma samples per thread
             uint32_t cbv[NC], crv[NC];
 #pragma unroll
