@@ -65,6 +65,8 @@ AG_DEV float table_a(const ReadParams& p, int i) { return (float)i / (float)p.ma
 // LUT = false: 16-bit samples, the table formula is evaluated per sample (3 x 65536 floats would not fit LDS).
 template <bool LUT> struct Tables {
     const float* ty; const float* tuv; const float* ta;
+    const float* te;      // planar RGB -> f32: EOTF(T_A[i]) per code
+    float uv_sub;         // 0.5f when tuv aliases ty (full range): T_UV[i] = T_Y[i] - 0.5f at lookup; else 0 (x - 0.0f == x)
 };
 template <bool LUT> AG_DEV float look_y(const ReadParams& p, const Tables<LUT>& t, uint32_t i)
 {
@@ -72,11 +74,21 @@ template <bool LUT> AG_DEV float look_y(const ReadParams& p, const Tables<LUT>& 
 }
 template <bool LUT> AG_DEV float look_uv(const ReadParams& p, const Tables<LUT>& t, uint32_t i)
 {
-    if constexpr (LUT) return t.tuv[i]; else return table_uv(p, (int)i);
+    if constexpr (LUT) return t.tuv[i] - t.uv_sub; else return table_uv(p, (int)i);
 }
 template <bool LUT> AG_DEV float look_a(const ReadParams& p, const Tables<LUT>& t, uint32_t i)
 {
     if constexpr (LUT) return t.ta[i]; else return table_a(p, (int)i);
+}
+
+// ApplyHLGOOTF, reference ColorTransfer.cpp:192-205 (only when loadOptions.hlg.applyOOTF).
+AG_DEV void hlg_ootf(const ReadParams& p, float (&c)[3])
+{
+    if (p.hlg_ootf) {
+        const float luma = (c[0] * p.hlg_luma[0]) + (c[1] * p.hlg_luma[1]) + (c[2] * p.hlg_luma[2]);
+        const float factor = p.hlg_peak * fast_pow(luma, p.hlg_gamma_m1);
+        c[0] *= factor; c[1] *= factor; c[2] *= factor;
+    }
 }
 
 // EOTF of one RGB triple, reference YuvDecode.cpp:563-591 / ReadHeifImage.cpp:1067-1095.
@@ -89,11 +101,7 @@ AG_DEV void eotf_rgb(const ReadParams& p, float (&c)[3])
     } else if constexpr (TRANSFER == AVIFGPU_TRANSFER_HLG) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) c[k] = fast_hlg_to_linear(c[k]);
-        if (p.hlg_ootf) {                                   // ApplyHLGOOTF, ColorTransfer.cpp:192-205
-            const float luma = (c[0] * p.hlg_luma[0]) + (c[1] * p.hlg_luma[1]) + (c[2] * p.hlg_luma[2]);
-            const float factor = p.hlg_peak * fast_pow(luma, p.hlg_gamma_m1);
-            c[0] *= factor; c[1] *= factor; c[2] *= factor;
-        }
+        hlg_ootf(p, c);
     } else {
 #pragma unroll
         for (int k = 0; k < 3; ++k) c[k] = fast_smpte428_to_linear(c[k]);
@@ -135,8 +143,14 @@ AG_DEV void decode_pixel(const ReadParams& p, const Tables<LUT>& t, uint32_t u0,
             }
         }
         if constexpr (DEPTH == 32) {
-            float c[3] = { look_a(p, t, q[0]), look_a(p, t, q[1]), look_a(p, t, q[2]) };
-            eotf_rgb<TRANSFER>(p, c);
+            float c[3];
+            if constexpr (LUT) {                                    // curve already applied per code in the table
+                c[0] = t.te[q[0]]; c[1] = t.te[q[1]]; c[2] = t.te[q[2]];
+                if constexpr (TRANSFER == AVIFGPU_TRANSFER_HLG) hlg_ootf(p, c);
+            } else {
+                c[0] = look_a(p, t, q[0]); c[1] = look_a(p, t, q[1]); c[2] = look_a(p, t, q[2]);
+                eotf_rgb<TRANSFER>(p, c);
+            }
             out[0] = __float_as_uint(c[0]); out[1] = __float_as_uint(c[1]); out[2] = __float_as_uint(c[2]);
             if constexpr (ALPHA) out[3] = __float_as_uint(look_a(p, t, ua));
         } else {
@@ -239,16 +253,47 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
     constexpr int OSZ = DEPTH / 8;
 
     extern __shared__ float lut[];
-    Tables<LUT> t = { nullptr, nullptr, nullptr };
+    Tables<LUT> t = { nullptr, nullptr, nullptr, nullptr, 0.0f };
+    int lut_floats = 0;
     if constexpr (LUT) {
+        // Only the tables this configuration reads, aliased where the reference's formulas coincide (see
+        // read_table_count): 12-bit full-range YCbCr needs 16 KiB of LDS instead of 48.
         const int count = 1 << p.bits;
-        for (int i = threadIdx.x; i < count; i += 256) {
-            lut[i] = table_y(p, i);
-            lut[count + i] = table_uv(p, i);
-            lut[2 * count + i] = table_a(p, i);
+        float* next = lut;
+        if constexpr (CS == kCsRgb) {
+            float* fa = next; next += count;
+            float* fe = nullptr;
+            if constexpr (DEPTH == 32) { fe = next; next += count; }
+            for (int i = threadIdx.x; i < count; i += 256) {
+                const float a = table_a(p, i);
+                fa[i] = a;
+                if constexpr (DEPTH == 32) {
+                    float e;
+                    if constexpr (TRANSFER == AVIFGPU_TRANSFER_PQ) e = fast_pq_to_linear_l2(a, p.pq_log2_mult);
+                    else if constexpr (TRANSFER == AVIFGPU_TRANSFER_HLG) e = fast_hlg_to_linear(a);
+                    else e = fast_smpte428_to_linear(a);
+                    fe[i] = e;
+                }
+            }
+            t.ta = fa; t.te = fe; t.ty = fa; t.tuv = fa;
+        } else {
+            float* fy = next; next += count;
+            float* fuv = fy; float* fa = fy;
+            const bool sep_uv = (CS == kCsYcc) && !p.full_range && !p.identity_lut;
+            const bool sep_a = ALPHA && !p.full_range;
+            if (sep_uv) { fuv = next; next += count; }
+            if (sep_a) { fa = next; next += count; }
+            for (int i = threadIdx.x; i < count; i += 256) {
+                fy[i] = table_y(p, i);
+                if (sep_uv) fuv[i] = table_uv(p, i);
+                if (sep_a) fa[i] = table_a(p, i);
+            }
+            t.ty = fy; t.tuv = fuv; t.ta = fa;
+            // aliased UV table: subtract the 0.5 at lookup, except for the identity quirk (T_UV = T_Y, YuvLookupTables.cpp:177-180)
+            t.uv_sub = (CS == kCsYcc && !sep_uv && !p.identity_lut) ? 0.5f : 0.0f;
         }
+        lut_floats = (int)(next - lut);
         __syncthreads();
-        t.ty = lut; t.tuv = lut + count; t.ta = lut + 2 * count;
     }
 
     // ---- work mapping: a WAVE owns 64 consecutive thread-footprints of ONE row group, so its output is one
@@ -257,7 +302,7 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint32_t* strip = nullptr;
-    if constexpr (ALIGNED) strip = reinterpret_cast<uint32_t*>(lut) + (LUT ? 3 * (1 << p.bits) : 0) + wave * (64 * ND_OUT);
+    if constexpr (ALIGNED) strip = reinterpret_cast<uint32_t*>(lut) + lut_floats + wave * (64 * ND_OUT);
 
     const int gxn = (p.width + PXT - 1) / PXT;
     const int gyn = (p.nrows + VR - 1) >> YS;
@@ -352,7 +397,8 @@ static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, const cha
     const long long waves = (long long)(((p.width + PXT - 1) / PXT + 63) / 64) * ((p.nrows + (1 << YS) - 1) >> YS);
     long long blocks = (waves + 3) / 4;
     if (blocks > 256LL * 8) blocks = 256LL * 8;          // tables are rebuilt per block: keep blocks persistent-ish
-    const size_t lut_bytes = p.bits <= 12 ? (size_t)3 * (1u << p.bits) * sizeof(float) : 0;
+    const size_t lut_bytes = p.bits <= 12 ? (size_t)read_table_count(CS == kCsYcc, CS == kCsMono, ALPHA, DEPTH, p.full_range != 0, p.identity_lut != 0) *
+                                                (1u << p.bits) * sizeof(float) : 0;
     static thread_local char label[160];
     uintptr_t bits = reinterpret_cast<uintptr_t>(p.dst) | (uintptr_t)p.dst_row_bytes;
     for (int pl = 0; pl < 4; ++pl) if (p.src[pl]) bits |= reinterpret_cast<uintptr_t>(p.src[pl]) | (uintptr_t)p.src_stride[pl];
