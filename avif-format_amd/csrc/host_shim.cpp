@@ -87,20 +87,30 @@ bool HasAlphaChannel(const FormatRecordPtr formatRecord)
 }
 
 // ---- pinned double buffer the host fills / drains (replaces ScopedBufferSuiteBuffer, Write.cpp:297-299) ----
+// Pinning memory costs milliseconds per call, so the pair is cached for the life of the process and only grows
+// (Photoshop calls the plug-in serially: one conversion at a time).
 class TileBuffers {
 public:
     TileBuffers(size_t bytes_each)
     {
-        for (int i = 0; i < 2; ++i)
-            if (hipHostMalloc(&buf_[i], bytes_each, hipHostMallocDefault) != hipSuccess) { release(); throw std::bad_alloc(); }
+        Cache& c = cache();
+        if (c.bytes < bytes_each) {
+            c.release();
+            for (int i = 0; i < 2; ++i)
+                if (hipHostMalloc(&c.buf[i], bytes_each, hipHostMallocDefault) != hipSuccess) { c.release(); throw std::bad_alloc(); }
+            c.bytes = bytes_each;
+        }
     }
-    ~TileBuffers() { release(); }
     TileBuffers(const TileBuffers&) = delete;
     TileBuffers& operator=(const TileBuffers&) = delete;
-    void* operator[](int i) const { return buf_[i & 1]; }
+    void* operator[](int i) const { return cache().buf[i & 1]; }
 private:
-    void release() { for (auto& b : buf_) { if (b) (void)hipHostFree(b); b = nullptr; } }
-    void* buf_[2] = { nullptr, nullptr };
+    struct Cache {
+        void* buf[2] = { nullptr, nullptr };
+        size_t bytes = 0;
+        void release() { for (auto& b : buf) { if (b) (void)hipHostFree(b); b = nullptr; } bytes = 0; }
+    };
+    static Cache& cache() { static Cache c; return c; }
 };
 
 struct ImageDeleter { void operator()(avifgpu_image* img) const { if (img) { avifgpu_image_free(img); delete img; } } };
@@ -342,7 +352,6 @@ avifgpu_OSErr avifgpu_image_alloc(avifgpu_image* img)
     if (wantAlpha) { w[3] = img->width; h[3] = img->height; img->stride[3] = ((w[3] * ssz) + 15) & ~15; off[3] = total; total += (size_t)img->stride[3] * h[3]; }
     void* base = nullptr;
     if (posix_memalign(&base, 64, total ? total : 64) != 0) return AVIFGPU_memFullErr;
-    std::memset(base, 0, total);
     for (int pl = 0; pl < 4; ++pl) img->plane[pl] = w[pl] ? (uint8_t*)base + off[pl] : nullptr;
     img->owner = base;
     return AVIFGPU_noErr;

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""End-to-end (PCIe-inclusive) timing of the FormatRecord-protocol shim: a fake host feeds an 8192x8192 f32 RGB document
+through avifgpu_host_create_heif_image (pinned double-buffered tiles, H2D + kernel + D2H overlapped with the host's
+advanceState fill) and the result is compared with the device-resident kernel rate and the 1-thread CPU oracle."""
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import harness  # noqa: E402
+from fake_host import FakeHost  # noqa: E402
+
+pkg = harness.pkg
+H = pkg.host
+
+
+def run(width, height, max_data, output, chroma=pkg.CHROMA_444, reps=3):
+    gpu = pkg.AvifGpu(0)
+    rng = np.random.default_rng(1234)
+    src = rng.random((height, width * 3), dtype=np.float32)
+    best = None
+    for _ in range(reps):
+        host = FakeHost(width, height, 32, 3, max_data=max_data, image=src)
+        opts = H.SaveUIOptions(imageBitDepth=10, hdrTransferFunction=pkg.TRANSFER_PQ, pq=H.PQOptions(80), chromaSubsampling=chroma, lossless=0)
+        img = H.Image()
+        t0 = time.perf_counter()
+        code = gpu.lib.avifgpu_host_create_heif_image(ctypes.byref(host.fr), pkg.ALPHA_NONE, ctypes.byref(opts), output,
+                                                      pkg.MATRIX_BT2020_NCL, pkg.PRIMARIES_BT2020, ctypes.byref(img))
+        dt = time.perf_counter() - t0
+        assert code == 0, gpu.lib.avifgpu_last_error()
+        gpu.lib.avifgpu_image_free(ctypes.byref(img))
+        best = dt if best is None else min(best, dt)
+        tiles = len(host.rects)
+    # the host's own fill cost (numpy memcpy of every tile into the pinned buffer) for reference
+    t0 = time.perf_counter(); tmp = src.copy(); fill = time.perf_counter() - t0
+    print(json.dumps({"config": f"{width}x{height} RGB f32 -> 10-bit PQ, output={'YCbCr444' if output else 'interleaved'}",
+                      "maxData_MiB": max_data / 2**20, "tiles": tiles, "seconds": round(best, 4),
+                      "Mpx_s": round(width * height / best / 1e6, 1), "host_fill_memcpy_s": round(fill, 4),
+                      "H2D_GB_s_equiv": round(width * height * 12 / best / 1e9, 1)}), flush=True)
+
+
+if __name__ == "__main__":
+    for md in (16 << 20, 64 << 20, 256 << 20, 1024 << 20):
+        run(8192, 8192, md, pkg.OUT_YCBCR)
+    run(8192, 8192, 64 << 20, pkg.OUT_REFERENCE)
