@@ -83,6 +83,13 @@ class ReadDesc(ctypes.Structure):
             setattr(self, k, v)
 
 
+class IccTransform(ctypes.Structure):
+    _fields_ = [("trc_type", c_int32 * 3), ("reserved", c_int32), ("trc_params", (ctypes.c_double * 7) * 3),
+                ("matrix", ctypes.c_double * 9)]
+
+
+ICC_TARGET_REC2020_LINEAR = 0
+
 _PLANES4 = c_void_p * 4
 _STRIDES4 = c_int64 * 4
 
@@ -96,6 +103,9 @@ ABI = [
                                      POINTER(_PLANES4), POINTER(_STRIDES4), c_int32, c_void_p]),
     ("avifgpu_read_rows", c_int32, [POINTER(ReadDesc), c_int32, c_int32, POINTER(_PLANES4), POINTER(_STRIDES4),
                                     c_void_p, c_int64, c_int32, c_void_p]),
+    ("avifgpu_icc_prepare", c_int32, [c_void_p, ctypes.c_uint32, c_int32, POINTER(IccTransform)]),
+    ("avifgpu_write_rows_icc", c_int32, [POINTER(WriteDesc), POINTER(IccTransform), c_int32, c_int32, c_void_p, c_int64,
+                                         POINTER(_PLANES4), POINTER(_STRIDES4), c_int32, c_void_p]),
     ("avifgpu_get_yuv_coefficients", c_int32, [c_int32, c_int32, c_int32, POINTER(c_float * 3)]),
     ("avifgpu_read_max_value", c_int32, [POINTER(ReadDesc)]),
     ("avifgpu_write_plane_count", c_int32, [POINTER(WriteDesc)]),
@@ -175,10 +185,20 @@ class AvifGpu:
             raise AvifGpuError(code, self.lib.avifgpu_last_error().decode())
 
     def write_rows(self, desc: WriteDesc, row0, nrows, src_ptr, src_row_bytes, dst_ptrs, dst_strides,
-                   mem=MEM_DEVICE, stream=0):
+                   mem=MEM_DEVICE, stream=0, icc=None):
+        if icc is not None:
+            self._check(self.lib.avifgpu_write_rows_icc(ctypes.byref(desc), ctypes.byref(icc), row0, nrows, src_ptr, src_row_bytes,
+                                                        ctypes.byref(planes4(dst_ptrs)), ctypes.byref(strides4(dst_strides)),
+                                                        mem, stream or None))
+            return
         self._check(self.lib.avifgpu_write_rows(ctypes.byref(desc), row0, nrows, src_ptr, src_row_bytes,
                                                 ctypes.byref(planes4(dst_ptrs)), ctypes.byref(strides4(dst_strides)),
                                                 mem, stream or None))
+
+    def icc_prepare(self, profile_bytes: bytes, target=ICC_TARGET_REC2020_LINEAR) -> "IccTransform":
+        t = IccTransform()
+        self._check(self.lib.avifgpu_icc_prepare(profile_bytes, len(profile_bytes), target, ctypes.byref(t)))
+        return t
 
     def read_rows(self, desc: ReadDesc, row0, nrows, src_ptrs, src_strides, dst_ptr, dst_row_bytes,
                   mem=MEM_DEVICE, stream=0):

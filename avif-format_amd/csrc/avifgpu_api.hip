@@ -24,7 +24,7 @@ hipError_t launch_read(const ReadParams& p, int colorspace, int depth, bool alph
 namespace avifgpu {
 int wait_slot(int slot);
 int write_rows_host_enqueue(const avifgpu_write_desc* d, int row0, int nrows, const void* src, int64_t src_row_bytes,
-                            void* const dst[4], const int64_t dst_stride[4], int slot);
+                            void* const dst[4], const int64_t dst_stride[4], int slot, const avifgpu_icc_transform* icc = nullptr);
 int read_rows_host_enqueue(const avifgpu_read_desc* d, int row0, int nrows, const void* const src[4], const int64_t src_stride[4],
                            void* dst, int64_t dst_row_bytes, int slot);
 void set_error(const char* msg);
@@ -177,9 +177,20 @@ int check_write(const avifgpu_write_desc* d, int row0, int nrows, WriteGeom& g)
     return 0;
 }
 
+thread_local const avifgpu_icc_transform* g_icc = nullptr;    // set for the duration of an avifgpu_write_rows_icc call
+
 int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const WriteGeom& g, WriteParams& p)
 {
     memset(&p, 0, sizeof(p));
+    if (g_icc) {
+        if (d->depth != 32 || d->planes < 3) return fail(AVIFGPU_formatBadParameters, "the ICC row transform applies to 32-bit RGB(A) documents");
+        for (int c = 0; c < 3; ++c) {
+            if (g_icc->trc_type[c] < 1 || g_icc->trc_type[c] > 5) return fail(AVIFGPU_formatBadParameters, "bad ICC curve type");
+            p.icc_trc_type[c] = g_icc->trc_type[c];
+            for (int k = 0; k < 7; ++k) p.icc_trc[c][k] = g_icc->trc_params[c][k];
+        }
+        for (int k = 0; k < 9; ++k) p.icc_m[k] = g_icc->matrix[k];
+    }
     p.width = d->width; p.nrows = nrows; p.rows_to_end = d->height - row0;
     p.transfer = d->depth == 32 ? d->transfer : AVIFGPU_TRANSFER_CLIP;
     p.premultiply = d->alpha_state == AVIFGPU_ALPHA_PREMULTIPLIED;
@@ -477,6 +488,16 @@ int32_t avifgpu_write_rows(const avifgpu_write_desc* d, int32_t row0, int32_t nr
     return avifgpu::wait_slot(0);
 }
 
+int32_t avifgpu_write_rows_icc(const avifgpu_write_desc* d, const avifgpu_icc_transform* icc, int32_t row0, int32_t nrows,
+                               const void* src, int64_t src_row_bytes, void* const dst[4], const int64_t dst_stride[4],
+                               int32_t mem_kind, void* stream)
+{
+    g_icc = icc;
+    const int32_t rc = avifgpu_write_rows(d, row0, nrows, src, src_row_bytes, dst, dst_stride, mem_kind, stream);
+    g_icc = nullptr;
+    return rc;
+}
+
 int32_t avifgpu_read_rows(const avifgpu_read_desc* d, int32_t row0, int32_t nrows,
                           const void* const src[4], const int64_t src_stride[4],
                           void* dst, int64_t dst_row_bytes,
@@ -537,8 +558,13 @@ int wait_slot(int slot)
 }
 
 int write_rows_host_enqueue(const avifgpu_write_desc* d, int row0, int nrows, const void* src, int64_t src_row_bytes,
-                            void* const dst[4], const int64_t dst_stride[4], int slot)
+                            void* const dst[4], const int64_t dst_stride[4], int slot, const avifgpu_icc_transform* icc)
 {
+    struct IccScope {                      // fill_write_params picks the transform up from g_icc
+        const avifgpu_icc_transform* saved;
+        explicit IccScope(const avifgpu_icc_transform* t) : saved(g_icc) { if (t) g_icc = t; }
+        ~IccScope() { g_icc = saved; }
+    } icc_scope(icc);
     WriteGeom g;
     int err = check_write(d, row0, nrows, g);
     if (err) return err;

@@ -25,7 +25,7 @@
 namespace avifgpu {
 int wait_slot(int slot);
 int write_rows_host_enqueue(const avifgpu_write_desc* d, int row0, int nrows, const void* src, int64_t src_row_bytes,
-                            void* const dst[4], const int64_t dst_stride[4], int slot);
+                            void* const dst[4], const int64_t dst_stride[4], int slot, const avifgpu_icc_transform* icc = nullptr);
 int read_rows_host_enqueue(const avifgpu_read_desc* d, int row0, int nrows, const void* const src[4], const int64_t src_stride[4],
                            void* dst, int64_t dst_row_bytes, int slot);
 void set_error(const char* msg);
@@ -174,6 +174,18 @@ void CreateHeifImageInto(FormatRecordPtr formatRecord, AlphaState alphaState, co
     }
     if (!img->plane[0]) OSErrException::ThrowIfError(avifgpu_image_alloc(img));
 
+    // ICC row transform (replaces converter.ConvertRow, WriteHeifImage.cpp:1012,1031-1034) for the HDR case
+    avifgpu_icc_transform icc;
+    const avifgpu_icc_transform* iccp = nullptr;
+    if (saveOptions.convertToRec2020) {
+        if (formatRecord->depth != 32 || mono || !formatRecord->iCCprofileData || formatRecord->iCCprofileSize <= 0)
+            throw OSErrException(AVIFGPU_formatBadParameters);
+        const int rc = avifgpu_icc_prepare(formatRecord->iCCprofileData, (uint32_t)formatRecord->iCCprofileSize,
+                                           AVIFGPU_ICC_TARGET_REC2020_LINEAR, &icc);
+        if (rc) throw OSErrException((OSErr)rc);       // e.g. LUT-based profile: the caller falls back to its lcms2 path
+        iccp = &icc;
+    }
+
     const bool even = output == AVIFGPU_OUT_YCBCR && d.chroma == AVIFGPU_CHROMA_420;
     const int ys = even ? 1 : 0;
     const int tileRows = rows_per_tile(formatRecord->maxData, formatRecord->rowBytes, d.height, even);
@@ -204,7 +216,7 @@ void CreateHeifImageInto(FormatRecordPtr formatRecord, AlphaState alphaState, co
             stride[pl] = img->stride[pl];
         }
         const int err = avifgpu::write_rows_host_enqueue(&d, top, bottom - top, formatRecord->data, formatRecord->rowBytes,
-                                                         dst, stride, slot);
+                                                         dst, stride, slot, iccp);
         if (err) { (void)avifgpu::wait_slot(0); (void)avifgpu::wait_slot(1); throw OSErrException((OSErr)err); }
     }
     OSErrException::ThrowIfError((OSErr)avifgpu::wait_slot(0));

@@ -1,0 +1,164 @@
+// icc_profile.cpp -- host side of the ICC row transform (include/avifgpu.h "ICC row transform"): parse a matrix/TRC RGB
+// profile and build the single 3x3 double matrix + per-channel parametric curves that lcms2's float pipeline reduces to
+// for  document profile -> "Rec. 2020 (Linear RGB Profile)"  (reference ColorProfileConversion.cpp:235-266,
+// ColorProfileGeneration.cpp:141-178).  The arithmetic follows the published lcms2 algorithms (colorant matrix scaled by
+// 1/MAX_ENCODEABLE_XYZ, destination = inverse of the Bradford-adapted primaries matrix scaled by MAX_ENCODEABLE_XYZ,
+// adjacent matrices multiplied in double) so the result agrees with lcms2 2.12 to float rounding
+// (tests/test_gpu_icc.py checks it against the real library).
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#include "../../include/avifgpu.h"
+
+namespace avifgpu { void set_error(const char* msg); }
+
+namespace {
+
+struct M3 { double v[3][3]; };
+
+M3 mul(const M3& a, const M3& b)
+{
+    M3 r;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) r.v[i][j] = a.v[i][0] * b.v[0][j] + a.v[i][1] * b.v[1][j] + a.v[i][2] * b.v[2][j];
+    return r;
+}
+
+bool inverse(const M3& a, M3& b)
+{
+    const double c0 = a.v[1][1] * a.v[2][2] - a.v[1][2] * a.v[2][1];
+    const double c1 = -a.v[1][0] * a.v[2][2] + a.v[1][2] * a.v[2][0];
+    const double c2 = a.v[1][0] * a.v[2][1] - a.v[1][1] * a.v[2][0];
+    const double det = a.v[0][0] * c0 + a.v[0][1] * c1 + a.v[0][2] * c2;
+    if (std::fabs(det) < 0.0001) return false;                 // lcms2 MATRIX_DET_TOLERANCE
+    b.v[0][0] = c0 / det;
+    b.v[0][1] = (a.v[0][2] * a.v[2][1] - a.v[0][1] * a.v[2][2]) / det;
+    b.v[0][2] = (a.v[0][1] * a.v[1][2] - a.v[0][2] * a.v[1][1]) / det;
+    b.v[1][0] = c1 / det;
+    b.v[1][1] = (a.v[0][0] * a.v[2][2] - a.v[0][2] * a.v[2][0]) / det;
+    b.v[1][2] = (a.v[0][2] * a.v[1][0] - a.v[0][0] * a.v[1][2]) / det;
+    b.v[2][0] = c2 / det;
+    b.v[2][1] = (a.v[0][1] * a.v[2][0] - a.v[0][0] * a.v[2][1]) / det;
+    b.v[2][2] = (a.v[0][0] * a.v[1][1] - a.v[0][1] * a.v[1][0]) / det;
+    return true;
+}
+
+void apply(const M3& m, const double in[3], double out[3])
+{
+    for (int i = 0; i < 3; ++i) out[i] = m.v[i][0] * in[0] + m.v[i][1] * in[1] + m.v[i][2] * in[2];
+}
+
+// Bradford chromatic adaptation src white -> dst white (XYZ).
+bool adaptation(const double src[3], const double dst[3], M3& out)
+{
+    const M3 bfd = { { { 0.8951, 0.2664, -0.1614 }, { -0.7502, 1.7135, 0.0367 }, { 0.0389, -0.0685, 1.0296 } } };
+    M3 ibfd;
+    if (!inverse(bfd, ibfd)) return false;
+    double cs[3], cd[3];
+    apply(bfd, src, cs); apply(bfd, dst, cd);
+    const M3 cone = { { { cd[0] / cs[0], 0, 0 }, { 0, cd[1] / cs[1], 0 }, { 0, 0, cd[2] / cs[2] } } };
+    out = mul(ibfd, mul(cone, bfd));
+    return true;
+}
+
+// RGB -> XYZ(D50) colorant matrix of a primaries/white-point description (what cmsCreateRGBProfile stores).
+bool colorants_from_primaries(const double wp_xy[2], const double prim_xy[3][2], M3& out)
+{
+    const double xn = wp_xy[0], yn = wp_xy[1];
+    M3 P;
+    for (int c = 0; c < 3; ++c) { P.v[0][c] = prim_xy[c][0]; P.v[1][c] = prim_xy[c][1]; P.v[2][c] = 1.0 - prim_xy[c][0] - prim_xy[c][1]; }
+    M3 iP;
+    if (!inverse(P, iP)) return false;
+    const double W[3] = { xn / yn, 1.0, (1.0 - xn - yn) / yn };
+    double S[3];
+    apply(iP, W, S);
+    M3 r;
+    for (int c = 0; c < 3; ++c) { r.v[0][c] = S[c] * P.v[0][c]; r.v[1][c] = S[c] * P.v[1][c]; r.v[2][c] = S[c] * P.v[2][c]; }
+    const double wxyz[3] = { xn / yn, 1.0, (1.0 - xn - yn) / yn };
+    const double d50[3] = { 0.9642, 1.0, 0.8249 };               // cmsD50_XYZ
+    M3 bradford;
+    if (!adaptation(wxyz, d50, bradford)) return false;
+    out = mul(bradford, r);
+    return true;
+}
+
+uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+uint16_t be16(const uint8_t* p) { return (uint16_t)(((uint16_t)p[0] << 8) | p[1]); }
+double s15f16(const uint8_t* p) { return (double)(int32_t)be32(p) / 65536.0; }
+
+int fail(int code, const char* msg) { avifgpu::set_error(msg); return code; }
+
+bool find_tag(const uint8_t* icc, uint32_t size, const char* sig, uint32_t& off, uint32_t& len)
+{
+    const uint32_t count = be32(icc + 128);
+    if (132ULL + 12ULL * count > size) return false;
+    for (uint32_t i = 0; i < count; ++i) {
+        const uint8_t* e = icc + 132 + 12 * i;
+        if (std::memcmp(e, sig, 4) == 0) {
+            off = be32(e + 4); len = be32(e + 8);
+            return (uint64_t)off + len <= size && len >= 8;
+        }
+    }
+    return false;
+}
+
+} // namespace
+
+extern "C" int32_t avifgpu_icc_prepare(const void* icc_profile, uint32_t size, int32_t target, avifgpu_icc_transform* out)
+{
+    if (!icc_profile || !out || size < 132) return fail(AVIFGPU_formatBadParameters, "bad ICC profile buffer");
+    if (target != AVIFGPU_ICC_TARGET_REC2020_LINEAR) return fail(AVIFGPU_formatBadParameters, "unsupported ICC target");
+    const uint8_t* icc = static_cast<const uint8_t*>(icc_profile);
+    if (std::memcmp(icc + 36, "acsp", 4) != 0) return fail(AVIFGPU_formatCannotRead, "not an ICC profile");
+    if (std::memcmp(icc + 16, "RGB ", 4) != 0) return fail(AVIFGPU_formatCannotRead, "ICC profile is not RGB");
+    if (std::memcmp(icc + 20, "XYZ ", 4) != 0) return fail(AVIFGPU_formatCannotRead, "ICC profile PCS is not XYZ (LUT-based): keep the lcms2 path");
+    std::memset(out, 0, sizeof(*out));
+
+    // ---- source colorants, scaled like BuildRGBInputMatrixShaper ----
+    const double kMaxEncodeableXYZ = 1.0 + 32767.0 / 32768.0;
+    M3 src;
+    const char* xyz_tags[3] = { "rXYZ", "gXYZ", "bXYZ" };
+    for (int c = 0; c < 3; ++c) {
+        uint32_t off, len;
+        if (!find_tag(icc, size, xyz_tags[c], off, len) || len < 20 || std::memcmp(icc + off, "XYZ ", 4) != 0)
+            return fail(AVIFGPU_formatCannotRead, "ICC profile has no matrix colorants (LUT-based): keep the lcms2 path");
+        for (int k = 0; k < 3; ++k) src.v[k][c] = s15f16(icc + off + 8 + 4 * k);
+    }
+    const double inp_adj = 1.0 / kMaxEncodeableXYZ;
+    for (auto& row : src.v) for (double& e : row) e *= inp_adj;
+
+    // ---- tone curves ----
+    const char* trc_tags[3] = { "rTRC", "gTRC", "bTRC" };
+    for (int c = 0; c < 3; ++c) {
+        uint32_t off, len;
+        if (!find_tag(icc, size, trc_tags[c], off, len)) return fail(AVIFGPU_formatCannotRead, "ICC profile has no TRC tags: keep the lcms2 path");
+        const uint8_t* t = icc + off;
+        double* P = out->trc_params[c];
+        if (std::memcmp(t, "curv", 4) == 0 && len >= 12) {
+            const uint32_t n = be32(t + 8);
+            if (n == 0) { out->trc_type[c] = 1; P[0] = 1.0; }
+            else if (n == 1 && len >= 14) { out->trc_type[c] = 1; P[0] = (double)be16(t + 12) / 256.0; }     // u8Fixed8
+            else return fail(AVIFGPU_formatCannotRead, "sampled TRC tables are evaluated by lcms2 only: keep the lcms2 path");
+        } else if (std::memcmp(t, "para", 4) == 0 && len >= 16) {
+            const uint16_t fn = be16(t + 8);
+            static const int nparams[5] = { 1, 3, 4, 5, 7 };
+            if (fn > 4 || len < 12u + 4u * nparams[fn]) return fail(AVIFGPU_formatCannotRead, "unsupported parametric curve");
+            out->trc_type[c] = fn + 1;
+            for (int k = 0; k < nparams[fn]; ++k) P[k] = s15f16(t + 12 + 4 * k);
+        } else {
+            return fail(AVIFGPU_formatCannotRead, "unsupported TRC tag type: keep the lcms2 path");
+        }
+    }
+
+    // ---- destination: Rec. 2020 linear, D65 (ColorProfileGeneration.cpp:145-151), inverse scaled like BuildRGBOutputMatrixShaper ----
+    const double wp[2] = { 0.3127, 0.3290 };
+    const double prim[3][2] = { { 0.708, 0.292 }, { 0.170, 0.797 }, { 0.131, 0.046 } };
+    M3 dst, idst;
+    if (!colorants_from_primaries(wp, prim, dst) || !inverse(dst, idst)) return fail(AVIFGPU_writErr, "singular Rec.2020 matrix");
+    for (auto& row : idst.v) for (double& e : row) e *= kMaxEncodeableXYZ;
+
+    const M3 total = mul(idst, src);              // the two adjacent matrix stages, multiplied in double
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) out->matrix[3 * i + j] = total.v[i][j];
+    return 0;
+}

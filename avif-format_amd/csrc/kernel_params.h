@@ -29,6 +29,11 @@ struct WriteParams {
     float   log2_maxf;           // log2(maxf): the multiply by maxValue folded into the second exponent
     float   my[3], mcb[3], mcr[3];
     float   half;                // 1 << (bits-1)
+    // ICC row transform in front of stage A (include/avifgpu.h); used only by the ICC instantiations
+    int32_t icc_trc_type[3];
+    int32_t icc_pad;
+    double  icc_trc[3][7];
+    double  icc_m[9];
 };
 
 struct ReadParams {

@@ -35,9 +35,59 @@ AG_DEV uint32_t oetf_code(const WriteParams& p, float f)
     return (uint32_t)__builtin_amdgcn_fmed3f(scaled, 0.0f, p.maxf);
 }
 
+// ---- ICC row transform (lcms2 float pipeline of a matrix/TRC profile pair, see include/avifgpu.h) --------------------
+// One lcms2 parametric curve (types 1..5, DefaultEvalParametricFn) evaluated in double, returned as the float the
+// curves stage hands to the matrix stage.
+__device__ __attribute__((noinline)) float icc_trc(int type, const double* P, float in)
+{
+    const double R = (double)in;
+    double v;
+    switch (type) {
+    case 1:
+        if (R < 0) v = (fabs(P[0] - 1.0) < 0.0001) ? R : 0.0; else v = pow(R, P[0]);
+        break;
+    case 2: {
+        if (fabs(P[1]) < 0.0001) { v = 0.0; break; }
+        const double disc = -P[2] / P[1];
+        if (R >= disc) { const double e = P[1] * R + P[2]; v = e > 0 ? pow(e, P[0]) : 0.0; } else v = 0.0;
+        break; }
+    case 3: {
+        if (fabs(P[1]) < 0.0001) { v = 0.0; break; }
+        double disc = -P[2] / P[1]; if (disc < 0) disc = 0;
+        if (R >= disc) { const double e = P[1] * R + P[2]; v = e > 0 ? pow(e, P[0]) + P[3] : 0.0; } else v = P[3];
+        break; }
+    case 4:
+        if (R >= P[4]) { const double e = P[1] * R + P[2]; v = e > 0 ? pow(e, P[0]) : 0.0; } else v = R * P[3];
+        break;
+    default:
+        if (R >= P[4]) { const double e = P[1] * R + P[2]; v = e > 0 ? pow(e, P[0]) + P[5] : P[5]; } else v = R * P[3] + P[6];
+        break;
+    }
+    return (float)v;
+}
+
+AG_DEV void icc_apply(const WriteParams& p, float (&c)[3])
+{
+    float t[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        // gamma-1 curves are the identity on every float (the common case: Photoshop's 32-bit "Linear RGB" profiles)
+        const bool linear = p.icc_trc_type[k] == 1 && p.icc_trc[k][0] == 1.0;
+        t[k] = linear ? c[k] : icc_trc(p.icc_trc_type[k], p.icc_trc[k], c[k]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {                   // lcms2 matrix stage: double accumulation from 0, one rounding to float
+        double acc = 0.0;
+        acc += (double)t[0] * p.icc_m[3 * i + 0];
+        acc += (double)t[1] * p.icc_m[3 * i + 1];
+        acc += (double)t[2] * p.icc_m[3 * i + 2];
+        c[i] = (float)acc;
+    }
+}
+
 // ---- stage A: one source pixel -> integer codes (reference WriteHeifImage.cpp inner loops) --------
 // s[] holds the PLANES raw samples (u8/u16 values, or f32 bit patterns).  q[0..NCOL-1] colour, q[3] alpha.
-template <int DEPTH, int PLANES, int TRANSFER>
+template <int DEPTH, int PLANES, int TRANSFER, bool ICC = false>
 AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t (&q)[4])
 {
     constexpr bool COLOR = PLANES >= 3;
@@ -48,6 +98,7 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
         float col[NCOL];
 #pragma unroll
         for (int k = 0; k < NCOL; ++k) col[k] = __uint_as_float(s[k]);
+        if constexpr (ICC && COLOR) icc_apply(p, col);                  // ConvertRow runs before the pixel loop: WriteHeifImage.cpp:1031-1034
         float a = 1.0f;
         if constexpr (ALPHA) {
             a = cxx_clamp(__uint_as_float(s[PLANES - 1]), 0.0f, 1.0f);          // :558, :1047
@@ -99,7 +150,7 @@ AG_DEV uint32_t stage_b_luma(const WriteParams& p, const uint32_t (&q)[4])
 // ---- generic kernel ----------------------------------------------------------------------------
 enum { kOutRefColor = 0, kOutRefGray = 1, kOutYcbcr = 2 };
 
-template <int DEPTH, int PLANES, int OUT, bool DST16, int XS, int YS, int TRANSFER, bool ALIGNED>
+template <int DEPTH, int PLANES, int OUT, bool DST16, int XS, int YS, int TRANSFER, bool ALIGNED, bool ICC = false>
 __global__ __launch_bounds__(256) void write_px(const WriteParams p)
 {
     constexpr int PXT = (DST16 ? 4 : 8) << XS;   // 4 (u16 planes) or 8 (u8 planes) chroma samples per thread: every plane store >= 8 B/lane
@@ -177,7 +228,7 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
                     for (int k = 0; k < PLANES; ++k) s[i][k] = 0;
             }
 #pragma unroll
-            for (int i = 0; i < PXT; ++i) stage_a<DEPTH, PLANES, TRANSFER>(p, s[i], q[vr][i]);
+            for (int i = 0; i < PXT; ++i) stage_a<DEPTH, PLANES, TRANSFER, ICC>(p, s[i], q[vr][i]);
         }
 
         // ---------------- stores ----------------
@@ -436,6 +487,15 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, const char** 
     snprintf(label, sizeof(label), "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d>",
              DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned);
     *name = label;
+    if constexpr (DEPTH == 32 && PLANES >= 3) {
+        if (p.icc_trc_type[0] != 0) {               // ICC row transform requested: separate instantiations, the others pay nothing
+            snprintf(label, sizeof(label), "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=1>",
+                     DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned);
+            if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, true>), dim3(grid_for(groups)), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, true>), dim3(grid_for(groups)), dim3(256), 0, st, p);
+            return hipGetLastError();
+        }
+    }
     if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true>), dim3(grid_for(groups)), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false>), dim3(grid_for(groups)), dim3(256), 0, st, p);
     return hipGetLastError();
@@ -495,7 +555,7 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
     // hot path: RGB f32 (no alpha) -> YCbCr 4:4:4 u16 with aligned rows; `variant` is a tuning word:
     //   bit0 enable, bit1 PXL=8 (else 4), bit2 non-temporal, bit3 prefetch, bit4 XCD-contiguous mapping;
     //   bits 8.. = blocks (0 = default).
-    if ((variant & 1) && depth == 32 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 0 && ys == 0 &&
+    if ((variant & 1) && p.icc_trc_type[0] == 0 && depth == 32 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 0 && ys == 0 &&
         (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |
           (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2]) & 15) == 0) {

@@ -33,7 +33,7 @@ class FormatRecord(ctypes.Structure):
                 ("loPlane", c_int16), ("hiPlane", c_int16), ("colBytes", c_int16), ("planeBytes", c_int16),
                 ("rowBytes", c_int32), ("maxValue", c_int32), ("imageSize", Point), ("imageSize32", VPoint),
                 ("theRect", Rect), ("theRect32", VRect), ("HostSupports32BitCoordinates", c_uint8),
-                ("PluginUsing32BitCoordinates", c_uint8)]
+                ("PluginUsing32BitCoordinates", c_uint8), ("iCCprofileData", c_void_p), ("iCCprofileSize", c_int32)]
 
 
 class PQOptions(ctypes.Structure):
@@ -46,7 +46,7 @@ class HLGOptions(ctypes.Structure):
 
 class SaveUIOptions(ctypes.Structure):
     _fields_ = [("imageBitDepth", c_int32), ("hdrTransferFunction", c_int32), ("pq", PQOptions),
-                ("chromaSubsampling", c_int32), ("lossless", c_uint8)]
+                ("chromaSubsampling", c_int32), ("lossless", c_uint8), ("convertToRec2020", c_uint8)]
 
 
 class LoadUIOptions(ctypes.Structure):

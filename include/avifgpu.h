@@ -243,6 +243,34 @@ int32_t avifgpu_read_rows(const avifgpu_read_desc* desc,
                           void* dst, int64_t dst_row_bytes,
                           int32_t mem_kind, void* stream);
 
+/* ---- ICC row transform of the HDR save path ---------------------------------------------------
+ * The reference converts every 32-bit row to linear Rec.2020 with lcms2 before the pixel loop when the document
+ * carries a non-Rec.2020 profile (ColorProfileConversion::ConvertRow, src/common/ColorProfileConversion.cpp:159-187,
+ * transform built at :235-266 against CreateRec2020LinearRGBProfile, ColorProfileGeneration.cpp:141-178).  For
+ * matrix/TRC RGB profiles that lcms2 pipeline is [per-channel TRC] -> [one 3x3 matrix in double] -> float, which the
+ * write kernels can apply in place of the CPU call.  LUT-based profiles (A2B tags), sampled `curv` tables and the
+ * 32-bit-SDR -> sRGB case are NOT covered: avifgpu_icc_prepare returns AVIFGPU_formatCannotRead and the caller keeps
+ * its lcms2 path. */
+typedef struct avifgpu_icc_transform {
+    int32_t trc_type[3];         /* lcms2 parametric curve type 1..5 per channel (1 = plain gamma; gamma 1 = linear) */
+    int32_t reserved;
+    double  trc_params[3][7];    /* g, a, b, c, d, e, f as lcms2 orders them */
+    double  matrix[9];           /* row-major: out_i = (float) sum_j matrix[3i+j] * (double) trc_j(in_j) */
+} avifgpu_icc_transform;
+
+enum { AVIFGPU_ICC_TARGET_REC2020_LINEAR = 0 };
+
+/* Parse the document's ICC profile bytes (formatRecord->iCCprofileData) and build the transform to `target`. */
+int32_t avifgpu_icc_prepare(const void* icc_profile, uint32_t size, int32_t target, avifgpu_icc_transform* out);
+
+/* avifgpu_write_rows with the ICC transform applied to every pixel's R,G,B first (alpha is copied, as
+ * cmsFLAGS_COPY_ALPHA does).  depth must be 32 and planes 3 or 4.  icc == NULL behaves like avifgpu_write_rows. */
+int32_t avifgpu_write_rows_icc(const avifgpu_write_desc* desc, const avifgpu_icc_transform* icc,
+                               int32_t row0, int32_t nrows,
+                               const void* src, int64_t src_row_bytes,
+                               void* const dst[4], const int64_t dst_stride[4],
+                               int32_t mem_kind, void* stream);
+
 /* (kr, kg, kb) exactly as GetYUVCoefficiants derives them (reference YUVCoefficiants.cpp:154-188).
  * has_nclx == 0 => BT.601 default. */
 int32_t avifgpu_get_yuv_coefficients(int32_t has_nclx, int32_t matrix_coefficients,

@@ -65,6 +65,8 @@ typedef struct avifgpu_FormatRecord {
     avifgpu_VRect  theRect32;
     uint8_t      HostSupports32BitCoordinates;
     uint8_t      PluginUsing32BitCoordinates;
+    const void*  iCCprofileData;              /* locked document profile bytes (HostMetadata.cpp:63-69), may be NULL */
+    int32_t      iCCprofileSize;
 } avifgpu_FormatRecord;
 
 /* SaveUIOptions / LoadUIOptions fields the conversion layer reads (reference AvifFormat.h:61-101). */
@@ -76,6 +78,11 @@ typedef struct avifgpu_SaveUIOptions {
     avifgpu_PQOptions pq;
     int32_t chromaSubsampling;                /* AVIFGPU_CHROMA_420|422|444 (consulted by the fused output only) */
     uint8_t lossless;
+    /* 1 = convert the 32-bit document from formatRecord->iCCprofileData to linear Rec.2020 on the GPU, i.e. the case in
+     * which ColorProfileConversion's HDR constructor installs a transform (ColorProfileConversion.cpp:107-131: profile
+     * present, transfer != Clip, !IsRec2020ColorProfile).  The adapter makes that decision with the plug-in's own
+     * detection code; 0 = no transform (or the adapter keeps calling lcms2 from its advanceState trampoline). */
+    uint8_t convertToRec2020;
 } avifgpu_SaveUIOptions;
 typedef struct avifgpu_LoadUIOptions {
     avifgpu_HLGOptions hlg;

@@ -1,0 +1,154 @@
+"""the ICC row transform of the HDR save path on the GPU vs the REAL Little CMS 2 (the third-party
+library the reference calls, present in this image), driven exactly as the reference drives it
+(oracle/icc_oracle.c = ColorProfileConversion.cpp:98-132,159-187,235-266 + ColorProfileGeneration.cpp:141-178).
+
+Tolerance: the transformed linear values feed the PQ curve and a truncating quantiser, so the bar is the write tier's:
+|delta code| <= 1 and >= 99 % exact; the transform itself is also checked in isolation (Clip curve at 12 bit is a
+x4095 magnifier of the float result)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import harness
+
+pkg = harness.pkg
+pytestmark = pytest.mark.gpu
+
+ICC_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "liboracle_icc.so")
+
+
+@pytest.fixture(scope="module")
+def lcms():
+    if not os.path.exists(ICC_LIB):
+        pytest.skip("oracle/liboracle_icc.so not built (lcms2 absent)")
+    L = ctypes.CDLL(ICC_LIB)
+    L.oracle_icc_make_profile.restype = ctypes.c_int32
+    L.oracle_icc_make_profile.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_double, ctypes.c_void_p, ctypes.c_uint32]
+    L.oracle_icc_convert_rows_to_rec2020.restype = ctypes.c_int32
+    L.oracle_icc_convert_rows_to_rec2020.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p,
+                                                      ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+    return L
+
+
+def _profile(L, kind, trc, g):
+    buf = ctypes.create_string_buffer(1 << 16)
+    n = L.oracle_icc_make_profile(kind, trc, g, buf, len(buf))
+    assert n > 0
+    return buf.raw[:n]
+
+
+PROFILES = [("srgb-linear", 0, 0, 1.0), ("p3-linear", 1, 0, 1.0), ("prophoto-linear-d50", 2, 0, 1.0),
+            ("adobergb-gamma2.2", 3, 0, 2.19921875), ("srgb-parametric", 0, 1, 0.0), ("p3-para-gamma1.8", 1, 2, 1.8)]
+
+
+@pytest.mark.parametrize("name,kind,trc,g", PROFILES)
+@pytest.mark.parametrize("planes", [3, 4])
+def test_icc_then_pq_matches_lcms2(gpu, lcms, name, kind, trc, g, planes):
+    icc = _profile(lcms, kind, trc, g)
+    xf = gpu.icc_prepare(icc)
+    alpha = pkg.ALPHA_STRAIGHT if planes == 4 else pkg.ALPHA_NONE
+    for output, chroma, bits, transfer in ((pkg.OUT_YCBCR, pkg.CHROMA_444, 10, pkg.TRANSFER_PQ),
+                                           (pkg.OUT_YCBCR, pkg.CHROMA_420, 12, pkg.TRANSFER_PQ),
+                                           (pkg.OUT_REFERENCE, pkg.CHROMA_444, 12, pkg.TRANSFER_CLIP)):
+        d = pkg.WriteDesc(width=515, height=18, depth=32, planes=planes, bit_depth=bits, transfer=transfer, peak_nits=80,
+                          alpha_state=alpha, output=output, chroma=chroma, matrix_coefficients=pkg.MATRIX_BT2020_NCL,
+                          color_primaries=pkg.PRIMARIES_BT2020)
+        src = harness.make_write_source(d, seed=5)
+        if trc != 0 or g != 1.0:
+            src = np.abs(src)                     # non-linear curves: stay where every lcms2 build agrees (no negative inputs)
+        # reference flow: lcms2 converts each row in place, then the pixel loop runs on the converted row
+        conv = src.copy()
+        assert lcms.oracle_icc_convert_rows_to_rec2020(icc, len(icc), int(planes == 4), conv.ctypes.data, d.width, d.height,
+                                                       conv.strides[0]) == 0
+        want = harness.oracle_write(d, conv)
+        # GPU: one fused launch on the ORIGINAL rows
+        got = _gpu_write_icc(gpu, d, src, xf)
+        st = harness.compare_write(d, want, got)
+        assert st["max_abs"] <= 1, (name, output, st)
+        assert st["exact_frac"] >= (0.99 if transfer == pkg.TRANSFER_PQ else 0.985), (name, output, st)
+        assert "icc=1" in gpu.last_kernel()
+
+
+def _gpu_write_icc(gpu, d, src, xf):
+    import torch
+    dev = f"cuda:{gpu.device}"
+    bufs = harness._alloc_write_out(d, d.height)
+    d_src = torch.from_numpy(src.view(np.uint8).reshape(-1)).to(dev)
+    d_out = {pl: torch.from_numpy(b.view(np.uint8).reshape(-1).copy()).to(dev) for pl, b in bufs.items()}
+    ptrs = [d_out[i].data_ptr() if i in d_out else None for i in range(4)]
+    strides = [bufs[i].strides[0] if i in bufs else 0 for i in range(4)]
+    gpu.write_rows(d, 0, d.height, d_src.data_ptr(), src.strides[0], ptrs, strides, mem=pkg.MEM_DEVICE,
+                   stream=torch.cuda.current_stream(dev).cuda_stream, icc=xf)
+    torch.cuda.synchronize(dev)
+    for pl in bufs:
+        bufs[pl] = d_out[pl].cpu().numpy().view(bufs[pl].dtype).reshape(bufs[pl].shape)
+    return harness._trim(d, bufs, d.height, harness.write_planes)
+
+
+def test_icc_matrix_agrees_with_lcms2(gpu, lcms):
+    """The prepared 3x3 reproduces lcms2 on the unit vectors to float rounding, for every test profile."""
+    for name, kind, trc, g in PROFILES:
+        if trc != 0 or g != 1.0:
+            continue
+        icc = _profile(lcms, kind, trc, g)
+        xf = gpu.icc_prepare(icc)
+        rows = np.eye(3, dtype=np.float32).reshape(1, 9).copy()
+        assert lcms.oracle_icc_convert_rows_to_rec2020(icc, len(icc), 0, rows.ctypes.data, 3, 1, rows.strides[0]) == 0
+        m = np.array(list(xf.matrix)).reshape(3, 3)
+        assert np.allclose(rows.reshape(3, 3).T, m, rtol=0, atol=6e-8), name
+
+
+def test_icc_prepare_rejects_what_it_cannot_do(gpu):
+    bad = bytearray(200)
+    assert gpu.lib.avifgpu_icc_prepare(bytes(bad), len(bad), 0, ctypes.byref(pkg.IccTransform())) == pkg.formatCannotRead
+    d = pkg.WriteDesc(width=8, height=2, depth=8, planes=3, bit_depth=8, output=pkg.OUT_REFERENCE)
+    xf = pkg.IccTransform()
+    xf.trc_type[0] = xf.trc_type[1] = xf.trc_type[2] = 1
+    src = harness.make_write_source(d)
+    with pytest.raises(pkg.AvifGpuError) as e:
+        _gpu_write_icc(gpu, d, src, xf)
+    assert e.value.code == pkg.formatBadParameters
+
+
+def test_host_shim_converts_document_profile(gpu, lcms):
+    """The FormatRecord shim with saveOptions.convertToRec2020: document profile bytes in formatRecord->iCCprofileData,
+    tiles converted + encoded in one launch each; result == lcms2 ConvertRow per row followed by the pixel loop."""
+    from fake_host import FakeHost
+    H = pkg.host
+    icc = _profile(lcms, 1, 0, 1.0)                       # Display-P3 primaries, linear: a typical 32-bit document
+    d = pkg.WriteDesc(width=300, height=40, depth=32, planes=4, bit_depth=12, transfer=pkg.TRANSFER_PQ, peak_nits=1000,
+                      alpha_state=pkg.ALPHA_STRAIGHT, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_422,
+                      matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020)
+    src = harness.make_write_source(d, seed=11)
+    conv = src.copy()
+    assert lcms.oracle_icc_convert_rows_to_rec2020(icc, len(icc), 1, conv.ctypes.data, d.width, d.height, conv.strides[0]) == 0
+    want = harness.oracle_write(d, conv)
+
+    host = FakeHost(d.width, d.height, 32, 4, max_data=300 * 16 * 9, image=src)
+    keep = ctypes.create_string_buffer(icc, len(icc))
+    host.fr.iCCprofileData = ctypes.cast(keep, ctypes.c_void_p)
+    host.fr.iCCprofileSize = len(icc)
+    opts = H.SaveUIOptions(imageBitDepth=12, hdrTransferFunction=pkg.TRANSFER_PQ, pq=H.PQOptions(1000),
+                           chromaSubsampling=pkg.CHROMA_422, lossless=0, convertToRec2020=1)
+    img = H.Image()
+    code = gpu.lib.avifgpu_host_create_heif_image(ctypes.byref(host.fr), pkg.ALPHA_STRAIGHT, ctypes.byref(opts), pkg.OUT_YCBCR,
+                                                  pkg.MATRIX_BT2020_NCL, pkg.PRIMARIES_BT2020, ctypes.byref(img))
+    assert code == 0, gpu.lib.avifgpu_last_error()
+    got = {}
+    for pl, (w, xs, ys) in harness.write_planes(d).items():
+        h = (d.height + ys) >> ys
+        raw = (ctypes.c_uint8 * (img.stride[pl] * h)).from_address(img.plane[pl])
+        got[pl] = np.frombuffer(raw, dtype=np.uint8).reshape(h, img.stride[pl])[:, :w * 2].view(np.uint16).copy()
+    st = harness.compare_write(d, want, got)
+    assert st["max_abs"] <= 1 and st["exact_frac"] >= 0.99, st
+    gpu.lib.avifgpu_image_free(ctypes.byref(img))
+    # a profile the GPU stage cannot take (not an ICC blob) surfaces as an error so the caller can keep lcms2
+    host2 = FakeHost(d.width, d.height, 32, 4, image=src)
+    junk = ctypes.create_string_buffer(256)
+    host2.fr.iCCprofileData = ctypes.cast(junk, ctypes.c_void_p)
+    host2.fr.iCCprofileSize = 256
+    img2 = H.Image()
+    assert gpu.lib.avifgpu_host_create_heif_image(ctypes.byref(host2.fr), pkg.ALPHA_STRAIGHT, ctypes.byref(opts), pkg.OUT_YCBCR,
+                                                  pkg.MATRIX_BT2020_NCL, pkg.PRIMARIES_BT2020, ctypes.byref(img2)) == pkg.formatCannotRead
