@@ -197,6 +197,7 @@ int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const Wr
     p.nearest = d->chroma_downsampling == AVIFGPU_DOWNSAMPLE_NEAREST;
     p.maxv = (1 << d->bit_depth) - 1;
     p.maxf = (float)p.maxv;
+    p.rcp_maxf = 1.0f / p.maxf;
     p.pq_mult = (float)d->peak_nits / 10000.0f;          // ColorTransfer.cpp:86
     p.pq_log2_mult_m1 = (float)((2610.0 / 16384.0) * std::log2((double)p.pq_mult));
     p.log2_maxf = (float)std::log2((double)p.maxv);

@@ -152,6 +152,16 @@ AG_DEV uint32_t exact_premultiply(uint32_t color, uint32_t alpha, float maxf)
     const float v = (float)color * (float)alpha / maxf;
     return (uint32_t)cxx_min(roundf(v), maxf);
 }
+// Same result in 6 issue slots instead of ~20: for maxf in {255, 1023, 4095} tools/divcheck_premul.hip proved, over ALL
+// (colour, alpha) pairs, that the 3-FMA quotient with r = RN(1/maxf) equals the IEEE quotient and that floor(v + 0.5f)
+// equals roundf(v) on those quotients (profiles/r01/divcheck_premul.txt).
+AG_DEV uint32_t exact_premultiply_fast(uint32_t color, uint32_t alpha, float maxf, float rcp_maxf)
+{
+    const float x = (float)color * (float)alpha;
+    const float q0 = x * rcp_maxf;
+    const float v = __builtin_fmaf(__builtin_fmaf(-q0, maxf, x), rcp_maxf, q0);
+    return (uint32_t)cxx_min(floorf(v + 0.5f), maxf);
+}
 AG_DEV uint32_t exact_unpremultiply(uint32_t color, uint32_t alpha, float maxf)
 {
     const float v = cxx_min((float)color * maxf / (float)alpha, maxf);

@@ -24,6 +24,7 @@ struct WriteParams {
     int32_t identity;            // matrix == GBR
     int32_t maxv;                // 2^bits - 1
     float   maxf;
+    float   rcp_maxf;            // RN(1/maxf), for the exhaustively verified fast premultiply
     float   pq_mult;             // peak_nits / 10000 (ColorTransfer.cpp:86)
     float   pq_log2_mult_m1;     // m1 * log2(pq_mult): the multiply by pq_mult folded into the first exponent
     float   log2_maxf;           // log2(maxf): the multiply by maxValue folded into the second exponent

@@ -66,14 +66,16 @@ __device__ __attribute__((noinline)) float icc_trc(int type, const double* P, fl
     return (float)v;
 }
 
+// ICC = 1: all three curves are gamma 1 (identity on every float: the "Linear RGB Profile" Photoshop embeds in 32-bit
+// documents) -> matrix only, no call in the kernel.  ICC = 2: general parametric curves (double pow, out of line).
+template <int ICC>
 AG_DEV void icc_apply(const WriteParams& p, float (&c)[3])
 {
     float t[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        // gamma-1 curves are the identity on every float (the common case: Photoshop's 32-bit "Linear RGB" profiles)
-        const bool linear = p.icc_trc_type[k] == 1 && p.icc_trc[k][0] == 1.0;
-        t[k] = linear ? c[k] : icc_trc(p.icc_trc_type[k], p.icc_trc[k], c[k]);
+        if constexpr (ICC == 1) t[k] = c[k];
+        else t[k] = icc_trc(p.icc_trc_type[k], p.icc_trc[k], c[k]);
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {                   // lcms2 matrix stage: double accumulation from 0, one rounding to float
@@ -87,7 +89,7 @@ AG_DEV void icc_apply(const WriteParams& p, float (&c)[3])
 
 // ---- stage A: one source pixel -> integer codes (reference WriteHeifImage.cpp inner loops) --------
 // s[] holds the PLANES raw samples (u8/u16 values, or f32 bit patterns).  q[0..NCOL-1] colour, q[3] alpha.
-template <int DEPTH, int PLANES, int TRANSFER, bool ICC = false>
+template <int DEPTH, int PLANES, int TRANSFER, int ICC = 0>
 AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t (&q)[4])
 {
     constexpr bool COLOR = PLANES >= 3;
@@ -98,7 +100,7 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
         float col[NCOL];
 #pragma unroll
         for (int k = 0; k < NCOL; ++k) col[k] = __uint_as_float(s[k]);
-        if constexpr (ICC && COLOR) icc_apply(p, col);                  // ConvertRow runs before the pixel loop: WriteHeifImage.cpp:1031-1034
+        if constexpr (ICC != 0 && COLOR) icc_apply<ICC>(p, col);                  // ConvertRow runs before the pixel loop: WriteHeifImage.cpp:1031-1034
         float a = 1.0f;
         if constexpr (ALPHA) {
             a = cxx_clamp(__uint_as_float(s[PLANES - 1]), 0.0f, 1.0f);          // :558, :1047
@@ -131,7 +133,7 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
         if constexpr (ALPHA) {
             if (p.premultiply && a < (uint32_t)p.maxv) {                        // :691-708 etc.
 #pragma unroll
-                for (int k = 0; k < NCOL; ++k) v[k] = (a == 0) ? 0u : exact_premultiply(v[k], a, p.maxf);
+                for (int k = 0; k < NCOL; ++k) v[k] = (a == 0) ? 0u : exact_premultiply_fast(v[k], a, p.maxf, p.rcp_maxf);
             }
         }
 #pragma unroll
@@ -150,7 +152,7 @@ AG_DEV uint32_t stage_b_luma(const WriteParams& p, const uint32_t (&q)[4])
 // ---- generic kernel ----------------------------------------------------------------------------
 enum { kOutRefColor = 0, kOutRefGray = 1, kOutYcbcr = 2 };
 
-template <int DEPTH, int PLANES, int OUT, bool DST16, int XS, int YS, int TRANSFER, bool ALIGNED, bool ICC = false>
+template <int DEPTH, int PLANES, int OUT, bool DST16, int XS, int YS, int TRANSFER, bool ALIGNED, int ICC = 0>
 __global__ __launch_bounds__(256) void write_px(const WriteParams p)
 {
     constexpr int PXT = (DST16 ? 4 : 8) << XS;   // 4 (u16 planes) or 8 (u8 planes) chroma samples per thread: every plane store >= 8 B/lane
@@ -489,10 +491,17 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, const char** 
     *name = label;
     if constexpr (DEPTH == 32 && PLANES >= 3) {
         if (p.icc_trc_type[0] != 0) {               // ICC row transform requested: separate instantiations, the others pay nothing
-            snprintf(label, sizeof(label), "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=1>",
-                     DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned);
-            if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, true>), dim3(grid_for(groups)), dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, true>), dim3(grid_for(groups)), dim3(256), 0, st, p);
+            bool linear = true;
+            for (int c = 0; c < 3; ++c) linear = linear && p.icc_trc_type[c] == 1 && p.icc_trc[c][0] == 1.0;
+            snprintf(label, sizeof(label), "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=%d>",
+                     DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned, linear ? 1 : 2);
+            if (linear) {
+                if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 1>), dim3(grid_for(groups)), dim3(256), 0, st, p);
+                else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 1>), dim3(grid_for(groups)), dim3(256), 0, st, p);
+            } else {
+                if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 2>), dim3(grid_for(groups)), dim3(256), 0, st, p);
+                else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 2>), dim3(grid_for(groups)), dim3(256), 0, st, p);
+            }
             return hipGetLastError();
         }
     }

@@ -68,7 +68,7 @@ def test_icc_then_pq_matches_lcms2(gpu, lcms, name, kind, trc, g, planes):
         st = harness.compare_write(d, want, got)
         assert st["max_abs"] <= 1, (name, output, st)
         assert st["exact_frac"] >= (0.99 if transfer == pkg.TRANSFER_PQ else 0.985), (name, output, st)
-        assert "icc=1" in gpu.last_kernel()
+        assert ("icc=1" if (trc == 0 and g == 1.0) else "icc=2") in gpu.last_kernel()
 
 
 def _gpu_write_icc(gpu, d, src, xf):

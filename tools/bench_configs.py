@@ -45,7 +45,7 @@ def rand_src(d):
     return t.view(d.height, -1)
 
 
-def bench_write(name, **kw):
+def bench_write(name, icc=None, **kw):
     d = pkg.WriteDesc(**kw)
     src = rand_src(d)
     ssz = 2 if d.bit_depth > 8 else 1
@@ -54,7 +54,7 @@ def bench_write(name, **kw):
         bufs[pl] = torch.empty(((d.height + ys) >> ys, w * ssz), dtype=torch.uint8, device=dev)
         ptrs[pl], strides[pl] = bufs[pl].data_ptr(), bufs[pl].stride(0)
     fn = lambda: gpu.write_rows(d, 0, d.height, src.data_ptr(), src.stride(0) * src.element_size(), ptrs, strides,
-                                mem=pkg.MEM_DEVICE, stream=stream.cuda_stream)
+                                mem=pkg.MEM_DEVICE, stream=stream.cuda_stream, icc=icc)
     mean, p50 = time_launch(fn)
     ab = gpu.write_algorithmic_bytes(d, d.height)
     print(json.dumps({"config": name, "kernel": gpu.last_kernel(), "ms_mean": round(mean, 4), "ms_p50": round(p50, 4),
@@ -95,6 +95,20 @@ if __name__ == "__main__":
     bench_write("C4 8192^2 RGB f32 -> 10-bit PQ interleaved RRGGBB (reference hand-off)", width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=0)
     bench_write("C5 16384^2 RGBA f32 -> 12-bit PQ 4:4:4 + alpha", width=16384, height=16384, depth=32, planes=4, bit_depth=12, transfer=0, peak_nits=80, alpha_state=1, output=1, chroma=P.CHROMA_444, matrix_coefficients=9, color_primaries=9)
     bench_write("RGBA8 premultiplied -> 8-bit interleaved (reference hand-off) 8192^2", width=8192, height=8192, depth=8, planes=4, bit_depth=8, alpha_state=2, output=0)
+    bench_write("Gray16+alpha premultiplied -> 12-bit Y + A planes 8192^2", width=8192, height=8192, depth=16, planes=2, bit_depth=12, alpha_state=2, output=0)
+    bench_write("Gray32 -> 10-bit PQ Y plane 8192^2", width=8192, height=8192, depth=32, planes=1, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=0)
+    icc_lib = os.path.join(ROOT, "oracle", "liboracle_icc.so")
+    if os.path.exists(icc_lib):
+        import ctypes
+        L = ctypes.CDLL(icc_lib)
+        L.oracle_icc_make_profile.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_double, ctypes.c_void_p, ctypes.c_uint32]
+        buf = ctypes.create_string_buffer(1 << 16)
+        n = L.oracle_icc_make_profile(1, 0, 1.0, buf, len(buf))
+        xf = gpu.icc_prepare(buf.raw[:n])
+        bench_write("C4 + ICC (linear Display-P3 doc -> Rec.2020) 8192^2 RGB f32 -> 10-bit PQ 4:4:4", icc=xf, width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=9, color_primaries=9)
+        n = L.oracle_icc_make_profile(0, 1, 0.0, buf, len(buf))
+        xf2 = gpu.icc_prepare(buf.raw[:n])
+        bench_write("C4 + ICC (sRGB parametric TRC doc -> Rec.2020) 8192^2 RGB f32 -> 10-bit PQ 4:4:4", icc=xf2, width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=9, color_primaries=9)
     bench_read("R8 8192^2 8-bit 4:2:0 BT.709 -> RGB8", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_420, bit_depth=8, depth=8, alpha_state=0, matrix_coefficients=1)
     bench_read("R16 8192^2 10-bit 4:4:4 BT.2020 -> RGB16", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_444, bit_depth=10, depth=16, alpha_state=0, matrix_coefficients=9, color_primaries=9)
     bench_read("R16 8192^2 12-bit 4:2:0 BT.2020 + alpha premult -> RGBA16", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_420, bit_depth=12, depth=16, alpha_state=2, matrix_coefficients=9, color_primaries=9)
