@@ -65,12 +65,13 @@ struct ReadParams {
 // also T_Y, and T_UV[i] = T_Y[i] - 0.5f is the same float subtraction the reference's table builder performs
 // (YuvLookupTables.cpp:171,182), applied at lookup time.  Limited range needs separate Y / UV (/ alpha) tables.
 // Planar RGB -> f32 adds a table of EOTF(T_A[i]) so the transfer curve is evaluated per code, not per sample.
-inline int read_table_count(bool ycc, bool mono, bool alpha, int depth, bool full_range, bool identity_lut)
+inline int read_table_count(bool ycc, bool mono, bool alpha, int depth, bool full_range, bool identity_lut, bool premultiplied)
 {
     if (!ycc && !mono) return 1 + ((depth == 32) ? 1 : 0);            // RGB planar: T_A (+ EOTF table)
     int n = 1;                                                        // T_Y
     if (ycc && !full_range && !identity_lut) n += 1;                  // T_UV
     if (alpha && !full_range) n += 1;                                 // T_A
+    (void)premultiplied;
     return n;
 }
 

@@ -120,6 +120,20 @@ AG_DEV float div_by_kg(const ReadParams& p, float x)
     }
     return ieee_div_slow(x, p.kg);
 }
+// UnpremultiplyColor(c, A, 1.0f) = min(c * 1.0f / A, 1.0f) for the three colours of one pixel, reference
+// PremultipliedAlpha.cpp:72-75 / YuvDecode.cpp:383-387.  One IEEE reciprocal r = RN(1/A) per pixel, then each quotient
+// in 3 FMAs: tools/divcheck_unpremul_f.hip proved that form equal to IEEE c / A (after the min) for every alpha code of
+// 8/10/12-bit images and EVERY float c in {0} U [2^-64, 1] (2.2e12 pairs, profiles/r01/divcheck_unpremul_f.txt).
+// A colour outside that domain (cannot arise from table values, kept for rigour) takes the IEEE quotient.
+AG_DEV float unpremultiply_one(float c, float A, float r)
+{
+    if (__builtin_expect(c == 0.0f || c >= 5.5e-20f, 1)) {
+        const float q0 = c * r;
+        return cxx_min(__builtin_fmaf(__builtin_fmaf(-q0, A, c), r, q0), 1.0f);
+    }
+    return cxx_min(ieee_div_slow(c, A), 1.0f);
+}
+
 // std::clamp(v, 0, 1) for the finite values this path produces (v_med3_f32; a NaN cannot arise from table values).
 AG_DEV float clamp01(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); }
 
@@ -192,7 +206,12 @@ AG_DEV void decode_pixel(const ReadParams& p, const Tables<LUT>& t, uint32_t u0,
                     if (ua == 0) { R = 0.0f; G = 0.0f; B = 0.0f; }
                     else {
                         const float A = look_a(p, t, ua);
-                        R = exact_unpremultiply_f(R, A); G = exact_unpremultiply_f(G, A); B = exact_unpremultiply_f(B, A);
+                        if constexpr (LUT) {                        // bits <= 12: the proven domain
+                            const float r = 1.0f / A;
+                            R = unpremultiply_one(R, A, r); G = unpremultiply_one(G, A, r); B = unpremultiply_one(B, A, r);
+                        } else {
+                            R = exact_unpremultiply_f(R, A); G = exact_unpremultiply_f(G, A); B = exact_unpremultiply_f(B, A);
+                        }
                     }
                 }
             }
@@ -397,7 +416,7 @@ static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, const cha
     const long long waves = (long long)(((p.width + PXT - 1) / PXT + 63) / 64) * ((p.nrows + (1 << YS) - 1) >> YS);
     long long blocks = (waves + 3) / 4;
     if (blocks > 256LL * 8) blocks = 256LL * 8;          // tables are rebuilt per block: keep blocks persistent-ish
-    const size_t lut_bytes = p.bits <= 12 ? (size_t)read_table_count(CS == kCsYcc, CS == kCsMono, ALPHA, DEPTH, p.full_range != 0, p.identity_lut != 0) *
+    const size_t lut_bytes = p.bits <= 12 ? (size_t)read_table_count(CS == kCsYcc, CS == kCsMono, ALPHA, DEPTH, p.full_range != 0, p.identity_lut != 0, p.premultiplied != 0) *
                                                 (1u << p.bits) * sizeof(float) : 0;
     static thread_local char label[160];
     uintptr_t bits = reinterpret_cast<uintptr_t>(p.dst) | (uintptr_t)p.dst_row_bytes;
