@@ -361,6 +361,20 @@ int32_t avifgpu_init(int32_t device_index)
                     e == hipSuccess ? "device count 0" : hipGetErrorString(e));
     if (device_index < 0 || device_index >= n) return fail(AVIFGPU_formatBadParameters, "device %d out of range [0,%d)", device_index, n);
     if (g_ctx.ready && g_ctx.device == device_index) return 0;
+    if (g_ctx.ready) {
+        // One process binds one GPU (one rank per device).  Re-binding releases the old device's stream,
+        // events and staging first instead of silently reusing them on the new device.
+        (void)hipSetDevice(g_ctx.device);
+        (void)hipStreamSynchronize(g_ctx.stream);
+        for (auto& sl : g_ctx.slot) {
+            if (sl.d_in) (void)hipFree(sl.d_in);
+            if (sl.d_out) (void)hipFree(sl.d_out);
+            if (sl.done) (void)hipEventDestroy(sl.done);
+            sl = Context::Slot();
+        }
+        (void)hipStreamDestroy(g_ctx.stream);
+        g_ctx.stream = nullptr; g_ctx.ready = false; g_ctx.device = -1;
+    }
     if ((e = hipSetDevice(device_index)) != hipSuccess) return hip_fail(e, "hipSetDevice", AVIFGPU_formatBadParameters);
     if (!g_ctx.stream && (e = hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking)) != hipSuccess)
         return hip_fail(e, "hipStreamCreate", AVIFGPU_memFullErr);
