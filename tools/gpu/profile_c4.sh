@@ -1,3 +1,4 @@
+# Recipe used for profiles/r01: run on the GPU box through gpurun ("bash tools/gpu/profile_c4.sh"), then copy the summaries from gpurun_out/prof into profiles/.
 set -x
 mkdir -p gpurun_out/prof
 export TMPDIR=/tmp
