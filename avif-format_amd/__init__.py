@@ -90,6 +90,12 @@ class IccTransform(ctypes.Structure):
 
 ICC_TARGET_REC2020_LINEAR = 0
 
+
+class IccShaper8(ctypes.Structure):
+    _fields_ = [("shaper1", (c_int32 * 256) * 3), ("matrix", (c_int32 * 3) * 3), ("offset", c_int32 * 3), ("reserved", c_int32),
+                ("shaper2", (ctypes.c_uint8 * 16388) * 3)]
+
+
 _PLANES4 = c_void_p * 4
 _STRIDES4 = c_int64 * 4
 
@@ -106,6 +112,9 @@ ABI = [
     ("avifgpu_icc_prepare", c_int32, [c_void_p, ctypes.c_uint32, c_int32, POINTER(IccTransform)]),
     ("avifgpu_write_rows_icc", c_int32, [POINTER(WriteDesc), POINTER(IccTransform), c_int32, c_int32, c_void_p, c_int64,
                                          POINTER(_PLANES4), POINTER(_STRIDES4), c_int32, c_void_p]),
+    ("avifgpu_icc_prepare_shaper8", c_int32, [c_void_p, ctypes.c_uint32, POINTER(IccShaper8)]),
+    ("avifgpu_write_rows_icc8", c_int32, [POINTER(WriteDesc), POINTER(IccShaper8), c_int32, c_int32, c_void_p, c_int64,
+                                          POINTER(_PLANES4), POINTER(_STRIDES4), c_int32, c_void_p]),
     ("avifgpu_get_yuv_coefficients", c_int32, [c_int32, c_int32, c_int32, POINTER(c_float * 3)]),
     ("avifgpu_read_max_value", c_int32, [POINTER(ReadDesc)]),
     ("avifgpu_write_plane_count", c_int32, [POINTER(WriteDesc)]),
@@ -186,6 +195,11 @@ class AvifGpu:
 
     def write_rows(self, desc: WriteDesc, row0, nrows, src_ptr, src_row_bytes, dst_ptrs, dst_strides,
                    mem=MEM_DEVICE, stream=0, icc=None):
+        if isinstance(icc, IccShaper8):
+            self._check(self.lib.avifgpu_write_rows_icc8(ctypes.byref(desc), ctypes.byref(icc), row0, nrows, src_ptr, src_row_bytes,
+                                                         ctypes.byref(planes4(dst_ptrs)), ctypes.byref(strides4(dst_strides)),
+                                                         mem, stream or None))
+            return
         if icc is not None:
             self._check(self.lib.avifgpu_write_rows_icc(ctypes.byref(desc), ctypes.byref(icc), row0, nrows, src_ptr, src_row_bytes,
                                                         ctypes.byref(planes4(dst_ptrs)), ctypes.byref(strides4(dst_strides)),
@@ -194,6 +208,11 @@ class AvifGpu:
         self._check(self.lib.avifgpu_write_rows(ctypes.byref(desc), row0, nrows, src_ptr, src_row_bytes,
                                                 ctypes.byref(planes4(dst_ptrs)), ctypes.byref(strides4(dst_strides)),
                                                 mem, stream or None))
+
+    def icc_prepare_shaper8(self, profile_bytes: bytes) -> "IccShaper8":
+        t = IccShaper8()
+        self._check(self.lib.avifgpu_icc_prepare_shaper8(profile_bytes, len(profile_bytes), ctypes.byref(t)))
+        return t
 
     def icc_prepare(self, profile_bytes: bytes, target=ICC_TARGET_REC2020_LINEAR) -> "IccTransform":
         t = IccTransform()

@@ -178,6 +178,40 @@ int check_write(const avifgpu_write_desc* d, int row0, int nrows, WriteGeom& g)
 }
 
 thread_local const avifgpu_icc_transform* g_icc = nullptr;    // set for the duration of an avifgpu_write_rows_icc call
+thread_local const avifgpu_icc_shaper8* g_icc8 = nullptr;    // set for the duration of an avifgpu_write_rows_icc8 call
+
+// Device copy of the 8-bit shaper tables.  Re-uploaded only when the contents change (one image = one upload); a change
+// first drains the device so no in-flight kernel still reads the old tables (the plug-in converts one image at a time).
+struct Icc8Device {
+    void* dev = nullptr;                  // [3][256] int32 followed by 16388 bytes of shaper2
+    std::vector<uint8_t> host;            // contents of `dev`
+} g_icc8_dev;
+
+int upload_icc8(const avifgpu_icc_shaper8* t, hipStream_t st, WriteParams& p)
+{
+    if (memcmp(t->shaper2[0], t->shaper2[1], 16385) != 0 || memcmp(t->shaper2[0], t->shaper2[2], 16385) != 0)
+        return fail(AVIFGPU_formatBadParameters, "8-bit ICC shaper: the destination curve must be the same for R, G and B (sRGB)");
+    const size_t n1 = sizeof(t->shaper1), n2 = 16388;
+    std::vector<uint8_t> blob(n1 + n2);
+    memcpy(blob.data(), t->shaper1, n1);
+    memcpy(blob.data() + n1, t->shaper2[0], n2);
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    if (!g_icc8_dev.dev) {
+        const hipError_t e = hipMalloc(&g_icc8_dev.dev, n1 + n2);
+        if (e != hipSuccess) return hip_fail(e, "hipMalloc(icc8 tables)", AVIFGPU_memFullErr);
+    }
+    if (g_icc8_dev.host != blob) {
+        hipError_t e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(g_icc8_dev.dev, blob.data(), blob.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return hip_fail(e, "upload of ICC tables", AVIFGPU_writErr);
+        g_icc8_dev.host.swap(blob);
+    }
+    (void)st;
+    p.icc8_s1 = static_cast<const int32_t*>(g_icc8_dev.dev);
+    p.icc8_s2 = static_cast<const uint8_t*>(g_icc8_dev.dev) + n1;
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) p.icc8_m[3 * i + j] = t->matrix[i][j]; p.icc8_off[i] = t->offset[i]; }
+    return 0;
+}
 
 int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const WriteGeom& g, WriteParams& p)
 {
@@ -190,6 +224,12 @@ int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const Wr
             for (int k = 0; k < 7; ++k) p.icc_trc[c][k] = g_icc->trc_params[c][k];
         }
         for (int k = 0; k < 9; ++k) p.icc_m[k] = g_icc->matrix[k];
+    }
+    if (g_icc8) {
+        if (d->depth != 8 || d->planes < 3) return fail(AVIFGPU_formatBadParameters, "the 8-bit ICC shaper applies to 8-bit RGB(A) documents");
+        if (!g_ctx.ready) return fail(AVIFGPU_formatBadParameters, "avifgpu_init has not succeeded: no HIP device bound (no CPU fallback)");
+        const int rc = upload_icc8(g_icc8, nullptr, p);
+        if (rc) return rc;
     }
     p.width = d->width; p.nrows = nrows; p.rows_to_end = d->height - row0;
     p.transfer = d->depth == 32 ? d->transfer : AVIFGPU_TRANSFER_CLIP;
@@ -510,6 +550,16 @@ int32_t avifgpu_write_rows_icc(const avifgpu_write_desc* d, const avifgpu_icc_tr
     g_icc = icc;
     const int32_t rc = avifgpu_write_rows(d, row0, nrows, src, src_row_bytes, dst, dst_stride, mem_kind, stream);
     g_icc = nullptr;
+    return rc;
+}
+
+int32_t avifgpu_write_rows_icc8(const avifgpu_write_desc* d, const avifgpu_icc_shaper8* icc, int32_t row0, int32_t nrows,
+                                const void* src, int64_t src_row_bytes, void* const dst[4], const int64_t dst_stride[4],
+                                int32_t mem_kind, void* stream)
+{
+    g_icc8 = icc;
+    const int32_t rc = avifgpu_write_rows(d, row0, nrows, src, src_row_bytes, dst, dst_stride, mem_kind, stream);
+    g_icc8 = nullptr;
     return rc;
 }
 

@@ -103,6 +103,65 @@ bool find_tag(const uint8_t* icc, uint32_t size, const char* sig, uint32_t& off,
     return false;
 }
 
+// lcms2 DefaultEvalParametricFn for the forward types 1..5 and the inverse of type 4 (-4), in double.
+double eval_parametric(int type, const double* P, double R)
+{
+    const double tol = 0.0001;                                   // MATRIX_DET_TOLERANCE
+    double e, disc;
+    switch (type) {
+    case 1:
+        if (R < 0) return (std::fabs(P[0] - 1.0) < tol) ? R : 0.0;
+        return std::pow(R, P[0]);
+    case 2:
+        if (std::fabs(P[1]) < tol) return 0.0;
+        disc = -P[2] / P[1];
+        if (R >= disc) { e = P[1] * R + P[2]; return e > 0 ? std::pow(e, P[0]) : 0.0; }
+        return 0.0;
+    case 3:
+        if (std::fabs(P[1]) < tol) return 0.0;
+        disc = -P[2] / P[1]; if (disc < 0) disc = 0;
+        if (R >= disc) { e = P[1] * R + P[2]; return e > 0 ? std::pow(e, P[0]) + P[3] : 0.0; }
+        return P[3];
+    case 4:
+        if (R >= P[4]) { e = P[1] * R + P[2]; return e > 0 ? std::pow(e, P[0]) : 0.0; }
+        return R * P[3];
+    case 5:
+        if (R >= P[4]) { e = P[1] * R + P[2]; return e > 0 ? std::pow(e, P[0]) + P[5] : P[5]; }
+        return R * P[3] + P[6];
+    case -4:
+        e = P[1] * P[4] + P[2];
+        disc = e < 0 ? 0.0 : std::pow(e, P[0]);
+        if (R >= disc) {
+            if (std::fabs(P[0]) < tol || std::fabs(P[1]) < tol) return 0.0;
+            return (std::pow(R, 1.0 / P[0]) - P[2]) / P[1];
+        }
+        return std::fabs(P[3]) < tol ? 0.0 : R / P[3];
+    default: return 0.0;
+    }
+}
+
+// cmsEvalToneCurveFloat of a one-segment parametric curve: float in, double evaluation, float out.
+float eval_curve_float(int type, const double* P, float v) { return (float)eval_parametric(type, P, (double)v); }
+
+// lcms2's fast floor (the library's default build): floor of the value rounded to 2^-16 by a magic-number addition.
+int quick_floor(double val)
+{
+    const double magic = 68719476736.0 * 1.5;
+    union { double d; int32_t halves[2]; } t;
+    t.d = val + magic;
+    return t.halves[0] >> 16;                                     // little endian
+}
+uint16_t quick_saturate_word(double d)
+{
+    d += 0.5;
+    if (d <= 0) return 0;
+    if (d >= 65535.0) return 0xffff;
+    return (uint16_t)(quick_floor(d - 32767.0) + 32767);
+}
+int32_t to_1fixed14(double x) { return (int32_t)std::floor(x * 16384.0 + 0.5); }
+
+int parse_matrix_trc(const uint8_t* icc, uint32_t size, M3& src, int trc_type[3], double trc_params[3][7]);
+
 } // namespace
 
 extern "C" int32_t avifgpu_icc_prepare(const void* icc_profile, uint32_t size, int32_t target, avifgpu_icc_transform* out)
@@ -110,14 +169,71 @@ extern "C" int32_t avifgpu_icc_prepare(const void* icc_profile, uint32_t size, i
     if (!icc_profile || !out || size < 132) return fail(AVIFGPU_formatBadParameters, "bad ICC profile buffer");
     if (target != AVIFGPU_ICC_TARGET_REC2020_LINEAR) return fail(AVIFGPU_formatBadParameters, "unsupported ICC target");
     const uint8_t* icc = static_cast<const uint8_t*>(icc_profile);
+    std::memset(out, 0, sizeof(*out));
+    M3 src;
+    int rc = parse_matrix_trc(icc, size, src, out->trc_type, out->trc_params);
+    if (rc) return rc;
+    const double kMaxEncodeableXYZ = 1.0 + 32767.0 / 32768.0;
+    // ---- destination: Rec. 2020 linear, D65 (ColorProfileGeneration.cpp:145-151), inverse scaled like BuildRGBOutputMatrixShaper ----
+    const double wp[2] = { 0.3127, 0.3290 };
+    const double prim[3][2] = { { 0.708, 0.292 }, { 0.170, 0.797 }, { 0.131, 0.046 } };
+    M3 dst, idst;
+    if (!colorants_from_primaries(wp, prim, dst) || !inverse(dst, idst)) return fail(AVIFGPU_writErr, "singular Rec.2020 matrix");
+    for (auto& row : idst.v) for (double& e : row) e *= kMaxEncodeableXYZ;
+    const M3 total = mul(idst, src);              // the two adjacent matrix stages, multiplied in double
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) out->matrix[3 * i + j] = total.v[i][j];
+    return 0;
+}
+
+extern "C" int32_t avifgpu_icc_prepare_shaper8(const void* icc_profile, uint32_t size, avifgpu_icc_shaper8* out)
+{
+    if (!icc_profile || !out || size < 132) return fail(AVIFGPU_formatBadParameters, "bad ICC profile buffer");
+    const uint8_t* icc = static_cast<const uint8_t*>(icc_profile);
+    std::memset(out, 0, sizeof(*out));
+    M3 src;
+    int trc_type[3]; double trc_params[3][7] = {};
+    int rc = parse_matrix_trc(icc, size, src, trc_type, trc_params);
+    if (rc) return rc;
+    const double kMaxEncodeableXYZ = 1.0 + 32767.0 / 32768.0;
+    // destination: cmsCreate_sRGBProfile = D65, Rec.709 primaries, parametric type 4 curve
+    const double wp[2] = { 0.3127, 0.3290 };
+    const double prim[3][2] = { { 0.6400, 0.3300 }, { 0.3000, 0.6000 }, { 0.1500, 0.0600 } };
+    const double srgb[7] = { 2.4, 1.0 / 1.055, 0.055 / 1.055, 1.0 / 12.92, 0.04045, 0, 0 };
+    M3 dst, idst;
+    if (!colorants_from_primaries(wp, prim, dst) || !inverse(dst, idst)) return fail(AVIFGPU_writErr, "singular sRGB matrix");
+    for (auto& row : idst.v) for (double& e : row) e *= kMaxEncodeableXYZ;
+    const M3 total = mul(idst, src);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) out->matrix[i][j] = to_1fixed14(total.v[i][j]);   // SetMatShaper
+    for (int c = 0; c < 3; ++c) {
+        for (int i = 0; i < 256; ++i) {                                                   // FillFirstShaper
+            const float R = (float)(i / 255.0);
+            const float y = eval_curve_float(trc_type[c], trc_params[c], R);
+            out->shaper1[c][i] = (y < 131072.0f) ? to_1fixed14((double)y) : 0x7fffffff;
+        }
+        for (int i = 0; i < 16385; ++i) {                                                 // FillSecondShaper, 8-bit output
+            const float R = (float)(i / 16384.0);
+            float v = eval_curve_float(-4, srgb, R);
+            if (v < 0) v = 0;
+            if (v > 1.0f) v = 1.0f;
+            const uint16_t w = quick_saturate_word((double)v * 65535.0);
+            out->shaper2[c][i] = (uint8_t)(((uint32_t)w * 65281u + 8388608u) >> 24);      // FROM_16_TO_8
+        }
+    }
+    return 0;
+}
+
+namespace {
+
+int parse_matrix_trc(const uint8_t* icc, uint32_t size, M3& src, int trc_type_out[3], double trc_params_out[3][7])
+{
+    struct { int32_t trc_type[3]; double trc_params[3][7]; } tmp = {};
+    auto* out = &tmp;
     if (std::memcmp(icc + 36, "acsp", 4) != 0) return fail(AVIFGPU_formatCannotRead, "not an ICC profile");
     if (std::memcmp(icc + 16, "RGB ", 4) != 0) return fail(AVIFGPU_formatCannotRead, "ICC profile is not RGB");
     if (std::memcmp(icc + 20, "XYZ ", 4) != 0) return fail(AVIFGPU_formatCannotRead, "ICC profile PCS is not XYZ (LUT-based): keep the lcms2 path");
-    std::memset(out, 0, sizeof(*out));
 
     // ---- source colorants, scaled like BuildRGBInputMatrixShaper ----
     const double kMaxEncodeableXYZ = 1.0 + 32767.0 / 32768.0;
-    M3 src;
     const char* xyz_tags[3] = { "rXYZ", "gXYZ", "bXYZ" };
     for (int c = 0; c < 3; ++c) {
         uint32_t off, len;
@@ -151,14 +267,8 @@ extern "C" int32_t avifgpu_icc_prepare(const void* icc_profile, uint32_t size, i
         }
     }
 
-    // ---- destination: Rec. 2020 linear, D65 (ColorProfileGeneration.cpp:145-151), inverse scaled like BuildRGBOutputMatrixShaper ----
-    const double wp[2] = { 0.3127, 0.3290 };
-    const double prim[3][2] = { { 0.708, 0.292 }, { 0.170, 0.797 }, { 0.131, 0.046 } };
-    M3 dst, idst;
-    if (!colorants_from_primaries(wp, prim, dst) || !inverse(dst, idst)) return fail(AVIFGPU_writErr, "singular Rec.2020 matrix");
-    for (auto& row : idst.v) for (double& e : row) e *= kMaxEncodeableXYZ;
-
-    const M3 total = mul(idst, src);              // the two adjacent matrix stages, multiplied in double
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) out->matrix[3 * i + j] = total.v[i][j];
+    for (int c = 0; c < 3; ++c) { trc_type_out[c] = tmp.trc_type[c]; for (int k = 0; k < 7; ++k) trc_params_out[c][k] = tmp.trc_params[c][k]; }
     return 0;
 }
+
+} // namespace

@@ -35,6 +35,11 @@ struct WriteParams {
     int32_t icc_pad;
     double  icc_trc[3][7];
     double  icc_m[9];
+    // 8-bit matrix-shaper transform (avifgpu_icc_shaper8): tables live in device memory, matrix in kernarg
+    const int32_t* icc8_s1;      // [3][256] 1.14 fixed
+    const uint8_t* icc8_s2;      // [16385] 8-bit output curve (identical for R,G,B: the destination is sRGB)
+    int32_t icc8_m[9];
+    int32_t icc8_off[3];
 };
 
 struct ReadParams {

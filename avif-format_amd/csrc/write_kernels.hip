@@ -90,7 +90,8 @@ AG_DEV void icc_apply(const WriteParams& p, float (&c)[3])
 // ---- stage A: one source pixel -> integer codes (reference WriteHeifImage.cpp inner loops) --------
 // s[] holds the PLANES raw samples (u8/u16 values, or f32 bit patterns).  q[0..NCOL-1] colour, q[3] alpha.
 template <int DEPTH, int PLANES, int TRANSFER, int ICC = 0>
-AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t (&q)[4])
+AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t (&q)[4],
+                    const int32_t* icc8_lds_s1 = nullptr, const uint8_t* icc8_lds_s2 = nullptr)
 {
     constexpr bool COLOR = PLANES >= 3;
     constexpr bool ALPHA = (PLANES == 2 || PLANES == 4);
@@ -120,12 +121,25 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
         return;
     } else {
         uint32_t v[PLANES];
+        uint32_t sx[PLANES];
+#pragma unroll
+        for (int k = 0; k < PLANES; ++k) sx[k] = s[k];
+        if constexpr (ICC == 3 && DEPTH == 8 && COLOR) {
+            // lcms2's 8-bit matrix-shaper evaluation (MatShaperEval16), bit for bit: 1.14 fixed-point tables and matrix
+            const int r = icc8_lds_s1[sx[0]], g = icc8_lds_s1[256 + sx[1]], b = icc8_lds_s1[512 + sx[2]];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                int l = (p.icc8_m[3 * i] * r + p.icc8_m[3 * i + 1] * g + p.icc8_m[3 * i + 2] * b + p.icc8_off[i] + 0x2000) >> 14;
+                l = l < 0 ? 0 : (l > 16384 ? 16384 : l);
+                sx[i] = icc8_lds_s2[l];
+            }
+        }
 #pragma unroll
         for (int k = 0; k < PLANES; ++k) {
             if constexpr (DEPTH == 8) {
-                v[k] = (p.maxv > 255) ? exact_rescale(s[k], 255.0f, p.maxf, p.maxv) : s[k];          // :87-112
+                v[k] = (p.maxv > 255) ? exact_rescale(sx[k], 255.0f, p.maxf, p.maxv) : sx[k];        // :87-112
             } else {
-                const uint32_t i = s[k] > 32768u ? 32768u : s[k];  // reference reads past its LUT here
+                const uint32_t i = sx[k] > 32768u ? 32768u : sx[k];  // reference reads past its LUT here
                 v[k] = exact_rescale(i, 32768.0f, p.maxf, p.maxv);                                   // :114-166
             }
         }
@@ -171,6 +185,17 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint32_t* strip = strips[ALIGNED ? wave : 0];
+
+    // 8-bit ICC matrix-shaper tables: 3 KiB + 16 KiB per workgroup, copied once from device memory (L2-resident)
+    constexpr bool ICC8 = (ICC == 3);
+    __shared__ int32_t icc8_s1[ICC8 ? 768 : 1];
+    __shared__ __attribute__((aligned(16))) uint8_t icc8_s2[ICC8 ? 16400 : 16];
+    if constexpr (ICC8) {
+        for (int i = threadIdx.x; i < 768; i += 256) icc8_s1[i] = p.icc8_s1[i];
+        for (int i = threadIdx.x; i < 16388 / 4; i += 256)
+            reinterpret_cast<uint32_t*>(icc8_s2)[i] = reinterpret_cast<const uint32_t*>(p.icc8_s2)[i];
+        __syncthreads();
+    }
 
     const int gxn = (p.width + PXT - 1) / PXT;
     const int gyn = (p.nrows + VR - 1) >> YS;
@@ -230,7 +255,7 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
                     for (int k = 0; k < PLANES; ++k) s[i][k] = 0;
             }
 #pragma unroll
-            for (int i = 0; i < PXT; ++i) stage_a<DEPTH, PLANES, TRANSFER, ICC>(p, s[i], q[vr][i]);
+            for (int i = 0; i < PXT; ++i) stage_a<DEPTH, PLANES, TRANSFER, ICC>(p, s[i], q[vr][i], icc8_s1, icc8_s2);
         }
 
         // ---------------- stores ----------------
@@ -489,6 +514,16 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, const char** 
     snprintf(label, sizeof(label), "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d>",
              DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned);
     *name = label;
+    if constexpr (DEPTH == 8 && PLANES >= 3) {
+        if (p.icc8_s1 != nullptr) {                 // 8-bit matrix-shaper ICC transform requested
+            snprintf(label, sizeof(label), "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=3>",
+                     DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned);
+            const int blocks = grid_for(groups) > 2048 ? 2048 : grid_for(groups);     // tables are copied per block
+            if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 3>), dim3(blocks), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 3>), dim3(blocks), dim3(256), 0, st, p);
+            return hipGetLastError();
+        }
+    }
     if constexpr (DEPTH == 32 && PLANES >= 3) {
         if (p.icc_trc_type[0] != 0) {               // ICC row transform requested: separate instantiations, the others pay nothing
             bool linear = true;

@@ -271,6 +271,33 @@ int32_t avifgpu_write_rows_icc(const avifgpu_write_desc* desc, const avifgpu_icc
                                void* const dst[4], const int64_t dst_stride[4],
                                int32_t mem_kind, void* stream);
 
+/* ---- ICC row transform of the 8-bit SDR save path --------------------------------------------------------------------
+ * With keepColorProfile == false (the default, AvifFormat.cpp:96) every 8-bit row of a non-sRGB document goes through
+ * lcms2 to sRGB first (ColorProfileConversion.cpp:134-157, :268-331, TYPE_RGB[A]_8).  For a matrix/TRC profile lcms2
+ * runs its 8-bit "matrix-shaper" fast path: 256-entry curve tables in 1.14 fixed point, a 1.14 fixed-point 3x3, a
+ * 16385-entry output table -- pure integer arithmetic once the tables exist, reproduced here bit for bit
+ * (tests/test_icc8.py: all 2^24 RGB inputs against the real library). */
+typedef struct avifgpu_icc_shaper8 {
+    int32_t  shaper1[3][256];    /* per channel: round(TRC(i/255) * 16384) */
+    int32_t  matrix[3][3];       /* round(M * 16384) */
+    int32_t  offset[3];
+    int32_t  reserved;
+    uint8_t  shaper2[3][16388];  /* per channel, index 0..16384: 8-bit output of the inverse destination curve */
+} avifgpu_icc_shaper8;
+
+enum { AVIFGPU_ICC_TARGET_SRGB8 = 1 };
+
+/* Build the tables for document profile -> sRGB (the profile cmsCreate_sRGBProfile makes).  Same profile restrictions
+ * as avifgpu_icc_prepare. */
+int32_t avifgpu_icc_prepare_shaper8(const void* icc_profile, uint32_t size, avifgpu_icc_shaper8* out);
+
+/* avifgpu_write_rows for 8-bit RGB(A) documents with that transform applied to R,G,B first (alpha copied). */
+int32_t avifgpu_write_rows_icc8(const avifgpu_write_desc* desc, const avifgpu_icc_shaper8* icc,
+                                int32_t row0, int32_t nrows,
+                                const void* src, int64_t src_row_bytes,
+                                void* const dst[4], const int64_t dst_stride[4],
+                                int32_t mem_kind, void* stream);
+
 /* (kr, kg, kb) exactly as GetYUVCoefficiants derives them (reference YUVCoefficiants.cpp:154-188).
  * has_nclx == 0 => BT.601 default. */
 int32_t avifgpu_get_yuv_coefficients(int32_t has_nclx, int32_t matrix_coefficients,

@@ -85,3 +85,32 @@ int32_t oracle_icc_convert_rows_to_rec2020(const void* icc, uint32_t icc_size, i
     cmsDeleteContext(ctx);
     return rc;
 }
+
+/* 8-bit SDR save path: ColorProfileConversion(formatRecord, hasAlpha, 8, keepColorProfile) -> InitializeForSRGBConversion
+ * (ColorProfileConversion.cpp:134-157, :268-331): document profile -> cmsCreate_sRGBProfileTHR, TYPE_RGB[A]_8, perceptual,
+ * BPC (+ COPY_ALPHA), one cmsDoTransformLineStride per row, in place. */
+int32_t oracle_icc_convert_rows_to_srgb8(const void* icc, uint32_t icc_size, int32_t has_alpha,
+                                         void* rows, uint32_t width, uint32_t nrows, uint32_t row_bytes)
+{
+    cmsContext ctx = cmsCreateContext(NULL, NULL);
+    cmsHPROFILE doc = cmsOpenProfileFromMemTHR(ctx, icc, icc_size);
+    cmsHPROFILE out = cmsCreate_sRGBProfileTHR(ctx);
+    int32_t rc = -1;
+    if (doc && out) {
+        cmsUInt32Number fmt = TYPE_RGB_8, flags = cmsFLAGS_BLACKPOINTCOMPENSATION;
+        if (has_alpha) { fmt = TYPE_RGBA_8; flags |= cmsFLAGS_COPY_ALPHA; }
+        cmsHTRANSFORM t = cmsCreateTransformTHR(ctx, doc, fmt, out, fmt, INTENT_PERCEPTUAL, flags);
+        if (t) {
+            for (uint32_t y = 0; y < nrows; ++y) {
+                uint8_t* row = (uint8_t*)rows + (size_t)y * row_bytes;
+                cmsDoTransformLineStride(t, row, row, width, 1, row_bytes, row_bytes, 0, 0);
+            }
+            cmsDeleteTransform(t);
+            rc = 0;
+        }
+    }
+    if (doc) cmsCloseProfile(doc);
+    if (out) cmsCloseProfile(out);
+    cmsDeleteContext(ctx);
+    return rc;
+}

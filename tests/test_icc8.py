@@ -1,0 +1,126 @@
+"""8-bit SDR save path, ICC stage: lcms2's 8-bit matrix-shaper pipeline (document profile -> sRGB, the
+transform ColorProfileConversion installs when keepColorProfile is false, ColorProfileConversion.cpp:134-157,:268-331)
+reproduced BIT FOR BIT.  Checker: the real Little CMS 2 driven like the reference (oracle/icc_oracle.c).
+
+CPU part: the host-built tables (avifgpu_icc_prepare_shaper8) pushed through a numpy restatement of MatShaperEval16 on
+ALL 2^24 RGB triples.  GPU part: the same 2^24 triples through the fused kernel."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import harness
+
+pkg = harness.pkg
+ICC_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "liboracle_icc.so")
+PROFILES = [("adobergb-g2.2", 3, 0, 2.19921875), ("p3-srgb-trc", 1, 1, 0.0), ("prophoto-d50-g1.8", 2, 0, 1.8),
+            ("p3-para-g1.8", 1, 2, 1.8), ("srgb-primaries-linear", 0, 0, 1.0)]
+
+
+@pytest.fixture(scope="module")
+def lcms():
+    if not os.path.exists(ICC_LIB):
+        pytest.skip("oracle/liboracle_icc.so not built (lcms2 absent)")
+    L = ctypes.CDLL(ICC_LIB)
+    L.oracle_icc_make_profile.restype = ctypes.c_int32
+    L.oracle_icc_make_profile.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_double, ctypes.c_void_p, ctypes.c_uint32]
+    L.oracle_icc_convert_rows_to_srgb8.restype = ctypes.c_int32
+    L.oracle_icc_convert_rows_to_srgb8.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p,
+                                                    ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+    return L
+
+
+def _profile(L, kind, trc, g):
+    buf = ctypes.create_string_buffer(1 << 16)
+    n = L.oracle_icc_make_profile(kind, trc, g, buf, len(buf))
+    assert n > 0
+    return buf.raw[:n]
+
+
+def _all_rgb():
+    r, g, b = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), indexing="ij")
+    return np.stack([r, g, b], axis=-1).reshape(4096, 4096 * 3).copy()
+
+
+def _shaper(icc):
+    t = pkg.IccShaper8()
+    rc = pkg.load().avifgpu_icc_prepare_shaper8(icc, len(icc), ctypes.byref(t))
+    assert rc == 0, pkg.load().avifgpu_last_error()
+    return t
+
+
+@pytest.mark.parametrize("name,kind,trc,g", PROFILES[:2])
+def test_tables_reproduce_lcms2_on_every_rgb_triple(lcms, name, kind, trc, g):
+    icc = _profile(lcms, kind, trc, g)
+    sh = _shaper(icc)
+    src = _all_rgb()
+    want = src.copy()
+    assert lcms.oracle_icc_convert_rows_to_srgb8(icc, len(icc), 0, want.ctypes.data, 4096, 4096, want.strides[0]) == 0
+    s1 = np.array(sh.shaper1, dtype=np.int64)
+    M = np.array(sh.matrix, dtype=np.int64)
+    s2 = np.array(sh.shaper2, dtype=np.uint8)
+    px = src.reshape(-1, 3)
+    R, G, B = s1[0][px[:, 0]], s1[1][px[:, 1]], s1[2][px[:, 2]]
+    out = np.empty_like(px)
+    for i in range(3):                                       # MatShaperEval16
+        l = np.clip((M[i, 0] * R + M[i, 1] * G + M[i, 2] * B + 0x2000) >> 14, 0, 16384)
+        out[:, i] = s2[i][l]
+    assert np.array_equal(out, want.reshape(-1, 3)), name
+
+
+def test_prepare_rejects_non_profiles():
+    t = pkg.IccShaper8()
+    assert pkg.load().avifgpu_icc_prepare_shaper8(bytes(300), 300, ctypes.byref(t)) == pkg.formatCannotRead
+
+
+def _gpu(gpu, d, src, sh):
+    import torch
+    dev = f"cuda:{gpu.device}"
+    bufs = harness._alloc_write_out(d, d.height)
+    d_src = torch.from_numpy(src.reshape(-1)).to(dev)
+    d_out = {pl: torch.from_numpy(b.view(np.uint8).reshape(-1).copy()).to(dev) for pl, b in bufs.items()}
+    ptrs = [d_out[i].data_ptr() if i in d_out else None for i in range(4)]
+    strides = [bufs[i].strides[0] if i in bufs else 0 for i in range(4)]
+    gpu.write_rows(d, 0, d.height, d_src.data_ptr(), src.strides[0], ptrs, strides, mem=pkg.MEM_DEVICE,
+                   stream=torch.cuda.current_stream(dev).cuda_stream, icc=sh)
+    torch.cuda.synchronize(dev)
+    for pl in bufs:
+        bufs[pl] = d_out[pl].cpu().numpy().view(bufs[pl].dtype).reshape(bufs[pl].shape)
+    return harness._trim(d, bufs, d.height, harness.write_planes)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kind,trc,g", PROFILES)
+def test_gpu_every_rgb_triple_bit_exact(gpu, lcms, name, kind, trc, g):
+    """All 2^24 RGB8 triples: fused ICC + 8-bit copy (the reference hand-off) == lcms2 ConvertRow then the pixel loop."""
+    icc = _profile(lcms, kind, trc, g)
+    sh = gpu.icc_prepare_shaper8(icc)
+    src = _all_rgb()
+    want = src.copy()
+    assert lcms.oracle_icc_convert_rows_to_srgb8(icc, len(icc), 0, want.ctypes.data, 4096, 4096, want.strides[0]) == 0
+    d = pkg.WriteDesc(width=4096, height=4096, depth=8, planes=3, bit_depth=8, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_REFERENCE)
+    got = _gpu(gpu, d, src, sh)
+    assert np.array_equal(got[0], want), name
+    assert "icc=3" in gpu.last_kernel()
+
+
+@pytest.mark.gpu
+def test_gpu_icc8_then_every_output_kind(gpu, lcms):
+    """RGBA (alpha copied), premultiply, 10-bit rescale and fused YCbCr 4:2:0 after the ICC stage, ragged size, bit-exact."""
+    icc = _profile(lcms, 3, 0, 2.19921875)
+    sh = gpu.icc_prepare_shaper8(icc)
+    for kw in (dict(planes=4, bit_depth=8, alpha_state=pkg.ALPHA_PREMULTIPLIED, output=pkg.OUT_REFERENCE),
+               dict(planes=4, bit_depth=10, alpha_state=pkg.ALPHA_STRAIGHT, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420,
+                    matrix_coefficients=pkg.MATRIX_BT601),
+               dict(planes=3, bit_depth=8, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_422,
+                    matrix_coefficients=pkg.MATRIX_BT601)):
+        d = pkg.WriteDesc(width=333, height=41, depth=8, **kw)
+        src = harness.make_write_source(d, seed=21)
+        conv = src.copy()
+        assert lcms.oracle_icc_convert_rows_to_srgb8(icc, len(icc), int(d.planes == 4), conv.ctypes.data, d.width, d.height,
+                                                     conv.strides[0]) == 0
+        want = harness.oracle_write(d, conv)
+        got = _gpu(gpu, d, src, sh)
+        for pl in want:
+            assert np.array_equal(got[pl], want[pl]), (kw, pl)

@@ -1,0 +1,1 @@
+timeout 900 python -m pytest tests/test_icc8.py tests/test_gpu_icc.py -m gpu -q --maxfail=10 2>&1 | tail -12
