@@ -24,7 +24,8 @@ hipError_t launch_read(const ReadParams& p, int colorspace, int depth, bool alph
 namespace avifgpu {
 int wait_slot(int slot);
 int write_rows_host_enqueue(const avifgpu_write_desc* d, int row0, int nrows, const void* src, int64_t src_row_bytes,
-                            void* const dst[4], const int64_t dst_stride[4], int slot, const avifgpu_icc_transform* icc = nullptr);
+                            void* const dst[4], const int64_t dst_stride[4], int slot, const avifgpu_icc_transform* icc = nullptr,
+                            const avifgpu_icc_shaper8* icc8 = nullptr);
 int read_rows_host_enqueue(const avifgpu_read_desc* d, int row0, int nrows, const void* const src[4], const int64_t src_stride[4],
                            void* dst, int64_t dst_row_bytes, int slot);
 void set_error(const char* msg);
@@ -623,13 +624,14 @@ int wait_slot(int slot)
 }
 
 int write_rows_host_enqueue(const avifgpu_write_desc* d, int row0, int nrows, const void* src, int64_t src_row_bytes,
-                            void* const dst[4], const int64_t dst_stride[4], int slot, const avifgpu_icc_transform* icc)
+                            void* const dst[4], const int64_t dst_stride[4], int slot, const avifgpu_icc_transform* icc,
+                            const avifgpu_icc_shaper8* icc8)
 {
-    struct IccScope {                      // fill_write_params picks the transform up from g_icc
-        const avifgpu_icc_transform* saved;
-        explicit IccScope(const avifgpu_icc_transform* t) : saved(g_icc) { if (t) g_icc = t; }
-        ~IccScope() { g_icc = saved; }
-    } icc_scope(icc);
+    struct IccScope {                      // fill_write_params picks the transform up from g_icc / g_icc8
+        const avifgpu_icc_transform* saved; const avifgpu_icc_shaper8* saved8;
+        IccScope(const avifgpu_icc_transform* t, const avifgpu_icc_shaper8* t8) : saved(g_icc), saved8(g_icc8) { if (t) g_icc = t; if (t8) g_icc8 = t8; }
+        ~IccScope() { g_icc = saved; g_icc8 = saved8; }
+    } icc_scope(icc, icc8);
     WriteGeom g;
     int err = check_write(d, row0, nrows, g);
     if (err) return err;

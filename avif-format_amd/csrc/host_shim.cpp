@@ -25,7 +25,8 @@
 namespace avifgpu {
 int wait_slot(int slot);
 int write_rows_host_enqueue(const avifgpu_write_desc* d, int row0, int nrows, const void* src, int64_t src_row_bytes,
-                            void* const dst[4], const int64_t dst_stride[4], int slot, const avifgpu_icc_transform* icc = nullptr);
+                            void* const dst[4], const int64_t dst_stride[4], int slot, const avifgpu_icc_transform* icc = nullptr,
+                            const avifgpu_icc_shaper8* icc8 = nullptr);
 int read_rows_host_enqueue(const avifgpu_read_desc* d, int row0, int nrows, const void* const src[4], const int64_t src_stride[4],
                            void* dst, int64_t dst_row_bytes, int slot);
 void set_error(const char* msg);
@@ -185,6 +186,16 @@ void CreateHeifImageInto(FormatRecordPtr formatRecord, AlphaState alphaState, co
         if (rc) throw OSErrException((OSErr)rc);       // e.g. LUT-based profile: the caller falls back to its lcms2 path
         iccp = &icc;
     }
+    // ... and for the 8-bit SDR case (document profile -> sRGB, ColorProfileConversion.cpp:134-157): lcms2's own 8-bit
+    // matrix-shaper integer pipeline, bit-exact
+    std::unique_ptr<avifgpu_icc_shaper8> icc8;
+    if (saveOptions.convertToSRGB) {
+        if (formatRecord->depth != 8 || mono || !formatRecord->iCCprofileData || formatRecord->iCCprofileSize <= 0)
+            throw OSErrException(AVIFGPU_formatBadParameters);
+        icc8.reset(new avifgpu_icc_shaper8);
+        const int rc = avifgpu_icc_prepare_shaper8(formatRecord->iCCprofileData, (uint32_t)formatRecord->iCCprofileSize, icc8.get());
+        if (rc) throw OSErrException((OSErr)rc);
+    }
 
     const bool even = output == AVIFGPU_OUT_YCBCR && d.chroma == AVIFGPU_CHROMA_420;
     const int ys = even ? 1 : 0;
@@ -216,7 +227,7 @@ void CreateHeifImageInto(FormatRecordPtr formatRecord, AlphaState alphaState, co
             stride[pl] = img->stride[pl];
         }
         const int err = avifgpu::write_rows_host_enqueue(&d, top, bottom - top, formatRecord->data, formatRecord->rowBytes,
-                                                         dst, stride, slot, iccp);
+                                                         dst, stride, slot, iccp, icc8.get());
         if (err) { (void)avifgpu::wait_slot(0); (void)avifgpu::wait_slot(1); throw OSErrException((OSErr)err); }
     }
     OSErrException::ThrowIfError((OSErr)avifgpu::wait_slot(0));

@@ -83,6 +83,10 @@ typedef struct avifgpu_SaveUIOptions {
      * present, transfer != Clip, !IsRec2020ColorProfile).  The adapter makes that decision with the plug-in's own
      * detection code; 0 = no transform (or the adapter keeps calling lcms2 from its advanceState trampoline). */
     uint8_t convertToRec2020;
+    /* 1 = convert the 8-bit RGB document from formatRecord->iCCprofileData to sRGB on the GPU: the case in which the 8-bit
+     * constructor installs a transform (ColorProfileConversion.cpp:134-157: profile present, keepColorProfile off,
+     * !IsSRGBColorProfile).  lcms2's 8-bit matrix-shaper pipeline, bit-exact; formatCannotRead for non matrix/TRC profiles. */
+    uint8_t convertToSRGB;
 } avifgpu_SaveUIOptions;
 typedef struct avifgpu_LoadUIOptions {
     avifgpu_HLGOptions hlg;

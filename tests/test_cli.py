@@ -1,0 +1,116 @@
+"""avifgpu_cli: the raw <-> planes converter that plays Photoshop's side of the FormatRecord tile protocol.
+CPU: argument handling and the loud no-GPU failure.  GPU: file in -> file out equals the oracle on the same bytes."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import harness
+
+pkg = harness.pkg
+CLI = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "avif-format_amd", "avifgpu_cli")
+
+
+def _run(*args):
+    return subprocess.run([CLI, *map(str, args)], capture_output=True, text=True, timeout=300)
+
+
+def test_cli_is_built_and_explains_itself():
+    assert os.access(CLI, os.X_OK), "run `make -C avif-format_amd` (or __graft_entry__.build())"
+    r = _run()
+    assert r.returncode == 2 and "usage: avifgpu_cli write" in r.stderr
+    r = _run("write", "--width", 4, "--height", 4, "--transfer", "gamma", "a", "b")
+    assert r.returncode == 2 and "bad value for --transfer" in r.stderr
+    r = _run("convert", "a", "b")
+    assert r.returncode == 2
+
+
+def test_cli_fails_loudly_without_a_gpu(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    (tmp_path / "in.raw").write_bytes(bytes(4 * 4 * 3))
+    r = _run("write", "--width", 4, "--height", 4, tmp_path / "in.raw", tmp_path / "out.planes")
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr
+    assert not (tmp_path / "out.planes").exists()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth,planes,bits,transfer,alpha,ycbcr", [
+    (32, 3, 10, "pq", "none", "444"),
+    (32, 4, 12, "smpte428", "premultiplied", "420"),
+    (16, 4, 12, "clip", "straight", None),
+    (8, 3, 8, "clip", "none", "420"),
+    (8, 2, 8, "clip", "straight", None),
+])
+def test_cli_write_matches_oracle(tmp_path, depth, planes, bits, transfer, alpha, ycbcr):
+    A = {"none": pkg.ALPHA_NONE, "straight": pkg.ALPHA_STRAIGHT, "premultiplied": pkg.ALPHA_PREMULTIPLIED}
+    T = {"clip": pkg.TRANSFER_CLIP, "pq": pkg.TRANSFER_PQ, "smpte428": pkg.TRANSFER_SMPTE428}
+    C = {"444": pkg.CHROMA_444, "422": pkg.CHROMA_422, "420": pkg.CHROMA_420}
+    hdr = depth == 32
+    d = pkg.WriteDesc(width=301, height=58, depth=depth, planes=planes, bit_depth=bits, transfer=T[transfer], peak_nits=1000,
+                      alpha_state=A[alpha], output=pkg.OUT_YCBCR if ycbcr else pkg.OUT_REFERENCE,
+                      chroma=C[ycbcr] if ycbcr else pkg.CHROMA_444,
+                      matrix_coefficients=pkg.MATRIX_BT2020_NCL if hdr else pkg.MATRIX_BT601,
+                      color_primaries=pkg.PRIMARIES_BT2020 if hdr else pkg.PRIMARIES_BT709, full_range=1)
+    src = harness.make_write_source(d, seed=depth + planes)
+    want = harness.oracle_write(d, src)
+    (tmp_path / "in.raw").write_bytes(src.tobytes())
+    args = ["write", "--width", d.width, "--height", d.height, "--depth", depth, "--planes", planes, "--bits", bits,
+            "--transfer", transfer, "--peak", 1000, "--alpha", alpha, "--matrix", d.matrix_coefficients,
+            "--primaries", d.color_primaries, "--maxdata", src.strides[0] * 2 * 12]
+    if ycbcr:
+        args += ["--ycbcr", ycbcr]
+    r = _run(*args, tmp_path / "in.raw", tmp_path / "out.planes")
+    assert r.returncode == 0, r.stderr
+    assert " 3 tiles" in r.stderr, r.stderr                                  # 58 rows, maxData = 24 rows
+    blob = np.frombuffer((tmp_path / "out.planes").read_bytes(), dtype=np.uint8)
+    got, off = {}, 0
+    for pl, (w, xs, ys) in harness.write_planes(d).items():
+        h = (d.height + ys) >> ys
+        dt = want[pl].dtype
+        n = w * h * dt.itemsize
+        got[pl] = blob[off:off + n].view(dt).reshape(h, w)
+        off += n
+    assert off == blob.size
+    st = harness.compare_write(d, want, got)
+    if hdr:
+        assert st["max_abs"] <= 1 and st["exact_frac"] >= 0.99, st
+    else:
+        assert st["max_abs"] == 0, st
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth,bits,cs,chroma,alpha,extra", [
+    (8, 8, "ycbcr", "420", "none", []),
+    (16, 10, "ycbcr", "444", "straight", []),
+    (16, 12, "mono", "444", "none", []),
+    (32, 10, "ycbcr", "422", "premultiplied", ["--matrix", 9, "--primaries", 9, "--tc", 16, "--peak", 203]),
+    (32, 12, "rgb", "444", "none", ["--matrix", 0, "--primaries", 9, "--tc", 18, "--hlg-ootf", "--gamma", 1.2, "--peak", 1000]),
+])
+def test_cli_read_matches_oracle(tmp_path, depth, bits, cs, chroma, alpha, extra):
+    A = {"none": pkg.ALPHA_NONE, "straight": pkg.ALPHA_STRAIGHT, "premultiplied": pkg.ALPHA_PREMULTIPLIED}
+    CS = {"ycbcr": pkg.COLORSPACE_YCBCR, "rgb": pkg.COLORSPACE_RGB, "mono": pkg.COLORSPACE_MONOCHROME}
+    C = {"444": pkg.CHROMA_444, "422": pkg.CHROMA_422, "420": pkg.CHROMA_420}
+    kv = {extra[i]: extra[i + 1] for i in range(0, len(extra) - 1) if str(extra[i]).startswith("--") and not str(extra[i + 1]).startswith("--")}
+    d = pkg.ReadDesc(width=203, height=37, colorspace=CS[cs], chroma=pkg.CHROMA_MONOCHROME if cs == "mono" else C[chroma],
+                     bit_depth=bits, depth=depth, alpha_state=A[alpha], has_nclx=int(bool(extra)),
+                     color_primaries=int(kv.get("--primaries", 0)), transfer_characteristics=int(kv.get("--tc", 0)),
+                     matrix_coefficients=int(kv.get("--matrix", 0)), full_range_flag=1,
+                     pq_peak_nits=int(kv.get("--peak", 80)), hlg_apply_ootf=int("--hlg-ootf" in extra),
+                     hlg_display_gamma=float(kv.get("--gamma", 1.2)), hlg_peak_nits=int(kv.get("--peak", 1000)))
+    planes = harness.make_read_source(d, seed=bits)
+    want = harness.oracle_read(d, planes)
+    with open(tmp_path / "in.planes", "wb") as f:
+        for pl, (w, xs, ys) in harness.read_planes(d).items():
+            f.write(np.ascontiguousarray(planes[pl][:, :w]).tobytes())
+    row_bytes = d.width * harness.read_channels(d) * depth // 8
+    r = _run("read", "--width", d.width, "--height", d.height, "--depth", depth, "--bits", bits, "--colorspace", cs,
+             "--chroma", chroma, "--alpha", alpha, "--maxdata", row_bytes * 2 * 8, *extra, tmp_path / "in.planes", tmp_path / "out.raw")
+    assert r.returncode == 0, r.stderr
+    got = np.frombuffer((tmp_path / "out.raw").read_bytes(), dtype=want.dtype).reshape(want.shape)
+    if depth == 32:
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-9)
+    else:
+        assert np.array_equal(got, want)

@@ -124,3 +124,32 @@ def test_gpu_icc8_then_every_output_kind(gpu, lcms):
         got = _gpu(gpu, d, src, sh)
         for pl in want:
             assert np.array_equal(got[pl], want[pl]), (kw, pl)
+
+
+@pytest.mark.gpu
+def test_host_shim_converts_8bit_document_to_srgb(gpu, lcms):
+    """FormatRecord shim with saveOptions.convertToSRGB: tiles converted with lcms2's 8-bit pipeline and handed off like
+    CreateHeifImageRGBEightBit (interleaved RGBA, heif_chroma_interleaved_RGBA), byte-identical to lcms2 + the pixel loop."""
+    from fake_host import FakeHost
+    H = pkg.host
+    icc = _profile(lcms, 3, 0, 2.19921875)
+    d = pkg.WriteDesc(width=517, height=67, depth=8, planes=4, bit_depth=8, alpha_state=pkg.ALPHA_STRAIGHT, output=pkg.OUT_REFERENCE)
+    src = harness.make_write_source(d, seed=5)
+    conv = src.copy()
+    assert lcms.oracle_icc_convert_rows_to_srgb8(icc, len(icc), 1, conv.ctypes.data, d.width, d.height, conv.strides[0]) == 0
+    want = harness.oracle_write(d, conv)
+    host = FakeHost(d.width, d.height, 8, 4, max_data=517 * 4 * 2 * 10, image=src)
+    keep = ctypes.create_string_buffer(icc, len(icc))
+    host.fr.iCCprofileData = ctypes.cast(keep, ctypes.c_void_p)
+    host.fr.iCCprofileSize = len(icc)
+    opts = H.SaveUIOptions(imageBitDepth=8, hdrTransferFunction=pkg.TRANSFER_CLIP, pq=H.PQOptions(1000),
+                           chromaSubsampling=pkg.CHROMA_420, lossless=0, convertToRec2020=0, convertToSRGB=1)
+    img = H.Image()
+    code = gpu.lib.avifgpu_host_create_heif_image(ctypes.byref(host.fr), pkg.ALPHA_STRAIGHT, ctypes.byref(opts), pkg.OUT_REFERENCE,
+                                                  pkg.MATRIX_BT601, pkg.PRIMARIES_BT709, ctypes.byref(img))
+    assert code == 0, gpu.lib.avifgpu_last_error()
+    assert len(host.rects) > 3                                     # really tiled
+    raw = (ctypes.c_uint8 * (img.stride[0] * d.height)).from_address(img.plane[0])
+    got = np.frombuffer(raw, dtype=np.uint8).reshape(d.height, img.stride[0])[:, :d.width * 4]
+    assert np.array_equal(got, want[0])
+    gpu.lib.avifgpu_image_free(ctypes.byref(img))
