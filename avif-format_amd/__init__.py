@@ -84,11 +84,12 @@ class ReadDesc(ctypes.Structure):
 
 
 class IccTransform(ctypes.Structure):
-    _fields_ = [("trc_type", c_int32 * 3), ("reserved", c_int32), ("trc_params", (ctypes.c_double * 7) * 3),
-                ("matrix", ctypes.c_double * 9)]
+    _fields_ = [("trc_type", c_int32 * 3), ("out_curve", c_int32), ("trc_params", (ctypes.c_double * 7) * 3),
+                ("matrix", ctypes.c_double * 9), ("out_params", ctypes.c_double * 8)]
 
 
 ICC_TARGET_REC2020_LINEAR = 0
+ICC_TARGET_SRGB_FLOAT = 2
 
 
 class IccShaper8(ctypes.Structure):

@@ -225,6 +225,13 @@ int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const Wr
             for (int k = 0; k < 7; ++k) p.icc_trc[c][k] = g_icc->trc_params[c][k];
         }
         for (int k = 0; k < 9; ++k) p.icc_m[k] = g_icc->matrix[k];
+        if (g_icc->out_curve != 0) {
+            if (g_icc->out_curve != 4) return fail(AVIFGPU_formatBadParameters, "bad ICC output curve");
+            // the reference converts to sRGB only for the SDR save of a 32-bit document (ColorProfileConversion.cpp:118-123)
+            if (d->transfer != AVIFGPU_TRANSFER_CLIP) return fail(AVIFGPU_formatBadParameters, "the sRGB ICC target goes with transfer Clip");
+            p.icc_out = 4;
+            for (int k = 0; k < 8; ++k) p.icc_out_p[k] = g_icc->out_params[k];
+        }
     }
     if (g_icc8) {
         if (d->depth != 8 || d->planes < 3) return fail(AVIFGPU_formatBadParameters, "the 8-bit ICC shaper applies to 8-bit RGB(A) documents");

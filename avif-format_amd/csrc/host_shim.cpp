@@ -189,7 +189,15 @@ void CreateHeifImageInto(FormatRecordPtr formatRecord, AlphaState alphaState, co
     // ... and for the 8-bit SDR case (document profile -> sRGB, ColorProfileConversion.cpp:134-157): lcms2's own 8-bit
     // matrix-shaper integer pipeline, bit-exact
     std::unique_ptr<avifgpu_icc_shaper8> icc8;
-    if (saveOptions.convertToSRGB) {
+    if (saveOptions.convertToSRGB && formatRecord->depth == 32) {
+        // 32-bit document saved as SDR (Clip): always converted to sRGB (ColorProfileConversion.cpp:118-123), float pipeline
+        if (saveOptions.convertToRec2020 || mono || !formatRecord->iCCprofileData || formatRecord->iCCprofileSize <= 0)
+            throw OSErrException(AVIFGPU_formatBadParameters);
+        const int rc = avifgpu_icc_prepare(formatRecord->iCCprofileData, (uint32_t)formatRecord->iCCprofileSize,
+                                           AVIFGPU_ICC_TARGET_SRGB_FLOAT, &icc);
+        if (rc) throw OSErrException((OSErr)rc);
+        iccp = &icc;
+    } else if (saveOptions.convertToSRGB) {
         if (formatRecord->depth != 8 || mono || !formatRecord->iCCprofileData || formatRecord->iCCprofileSize <= 0)
             throw OSErrException(AVIFGPU_formatBadParameters);
         icc8.reset(new avifgpu_icc_shaper8);

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <vector>
 
 #include "../../include/avifgpu.h"
 
@@ -140,8 +141,37 @@ double eval_parametric(int type, const double* P, double R)
     }
 }
 
-// cmsEvalToneCurveFloat of a one-segment parametric curve: float in, double evaluation, float out.
+// A document tone curve as lcms2 holds it after Type_Curve_Read / Type_ParametricCurve_Read: one parametric segment
+// (type != 0) or a sampled 16-bit table (`curv` with count >= 2).
+struct Trc { int type = 0; double P[7] = {}; std::vector<uint16_t> table; };
+
+int quick_floor(double val);
+uint16_t quick_saturate_word(double d);
+
+// cmsEvalToneCurve16 on a sampled curve = LinLerp1D (cmsintrp.c): 15.16 fixed-point position, rounded linear blend, all
+// in 32-bit unsigned wrap-around arithmetic like the library.
+uint16_t eval_table16(const std::vector<uint16_t>& t, uint16_t v)
+{
+    const int domain = (int)t.size() - 1;
+    if (v == 0xffff || domain == 0) return t[(size_t)domain];
+    int val3 = domain * (int)v;
+    val3 = val3 + ((val3 + 0x7fff) / 0xffff);                    // _cmsToFixedDomain
+    const int cell0 = val3 >> 16, rest = val3 & 0xffff;
+    const int32_t y0 = t[(size_t)cell0], y1 = t[(size_t)cell0 + 1];
+    uint32_t dif = (uint32_t)(y1 - y0) * (uint32_t)rest + 0x8000u;
+    dif = (dif >> 16) + (uint32_t)y0;
+    return (uint16_t)dif;
+}
+
+// cmsEvalToneCurveFloat: a parametric segment is evaluated in double; a sampled curve is "limited precision": the input is
+// saturated to 16 bits, interpolated in 16 bits and divided back (cmsgamma.c).
 float eval_curve_float(int type, const double* P, float v) { return (float)eval_parametric(type, P, (double)v); }
+float eval_curve_float(const Trc& c, float v)
+{
+    if (c.type != 0) return eval_curve_float(c.type, c.P, v);
+    const uint16_t in = quick_saturate_word((double)v * 65535.0);
+    return (float)(eval_table16(c.table, in) / 65535.0);
+}
 
 // lcms2's fast floor (the library's default build): floor of the value rounded to 2^-16 by a magic-number addition.
 int quick_floor(double val)
@@ -160,28 +190,49 @@ uint16_t quick_saturate_word(double d)
 }
 int32_t to_1fixed14(double x) { return (int32_t)std::floor(x * 16384.0 + 0.5); }
 
-int parse_matrix_trc(const uint8_t* icc, uint32_t size, M3& src, int trc_type[3], double trc_params[3][7]);
+int parse_matrix_trc(const uint8_t* icc, uint32_t size, M3& src, Trc trc[3]);
 
 } // namespace
 
 extern "C" int32_t avifgpu_icc_prepare(const void* icc_profile, uint32_t size, int32_t target, avifgpu_icc_transform* out)
 {
     if (!icc_profile || !out || size < 132) return fail(AVIFGPU_formatBadParameters, "bad ICC profile buffer");
-    if (target != AVIFGPU_ICC_TARGET_REC2020_LINEAR) return fail(AVIFGPU_formatBadParameters, "unsupported ICC target");
+    if (target != AVIFGPU_ICC_TARGET_REC2020_LINEAR && target != AVIFGPU_ICC_TARGET_SRGB_FLOAT)
+        return fail(AVIFGPU_formatBadParameters, "unsupported ICC target");
     const uint8_t* icc = static_cast<const uint8_t*>(icc_profile);
     std::memset(out, 0, sizeof(*out));
     M3 src;
-    int rc = parse_matrix_trc(icc, size, src, out->trc_type, out->trc_params);
+    Trc trc[3];
+    int rc = parse_matrix_trc(icc, size, src, trc);
     if (rc) return rc;
+    for (int c = 0; c < 3; ++c) {
+        // Photoshop's 32-bit documents carry the linear variant of their profile (`curv` count 1, gamma 1.0); a sampled
+        // table on the float path would be quantised to 16 bits by lcms2 -- not reproduced here, the caller keeps lcms2.
+        if (trc[c].type == 0) return fail(AVIFGPU_formatCannotRead, "sampled TRC tables on the 32-bit path are evaluated by lcms2 only: keep the lcms2 path");
+        out->trc_type[c] = trc[c].type;
+        for (int k = 0; k < 7; ++k) out->trc_params[c][k] = trc[c].P[k];
+    }
     const double kMaxEncodeableXYZ = 1.0 + 32767.0 / 32768.0;
-    // ---- destination: Rec. 2020 linear, D65 (ColorProfileGeneration.cpp:145-151), inverse scaled like BuildRGBOutputMatrixShaper ----
+    // ---- destination, D65, inverse scaled like BuildRGBOutputMatrixShaper:
+    //      Rec. 2020 linear (ColorProfileGeneration.cpp:145-151) or cmsCreate_sRGBProfile (Rec.709 primaries, type-4 curve)
     const double wp[2] = { 0.3127, 0.3290 };
-    const double prim[3][2] = { { 0.708, 0.292 }, { 0.170, 0.797 }, { 0.131, 0.046 } };
+    const double prim2020[3][2] = { { 0.708, 0.292 }, { 0.170, 0.797 }, { 0.131, 0.046 } };
+    const double prim709[3][2] = { { 0.6400, 0.3300 }, { 0.3000, 0.6000 }, { 0.1500, 0.0600 } };
     M3 dst, idst;
-    if (!colorants_from_primaries(wp, prim, dst) || !inverse(dst, idst)) return fail(AVIFGPU_writErr, "singular Rec.2020 matrix");
+    if (!colorants_from_primaries(wp, target == AVIFGPU_ICC_TARGET_SRGB_FLOAT ? prim709 : prim2020, dst) || !inverse(dst, idst))
+        return fail(AVIFGPU_writErr, "singular destination matrix");
     for (auto& row : idst.v) for (double& e : row) e *= kMaxEncodeableXYZ;
     const M3 total = mul(idst, src);              // the two adjacent matrix stages, multiplied in double
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) out->matrix[3 * i + j] = total.v[i][j];
+    if (target == AVIFGPU_ICC_TARGET_SRGB_FLOAT) {
+        // cmsReverseToneCurve of the one-segment type-4 curve is the analytic type -4 (cmsgamma.c)
+        const double P[5] = { 2.4, 1.0 / 1.055, 0.055 / 1.055, 1.0 / 12.92, 0.04045 };
+        out->out_curve = 4;
+        for (int k = 0; k < 5; ++k) out->out_params[k] = P[k];
+        const double e = P[1] * P[4] + P[2];
+        out->out_params[5] = e < 0 ? 0.0 : std::pow(e, P[0]);
+        out->out_params[6] = 1.0 / P[0];
+    }
     return 0;
 }
 
@@ -191,8 +242,8 @@ extern "C" int32_t avifgpu_icc_prepare_shaper8(const void* icc_profile, uint32_t
     const uint8_t* icc = static_cast<const uint8_t*>(icc_profile);
     std::memset(out, 0, sizeof(*out));
     M3 src;
-    int trc_type[3]; double trc_params[3][7] = {};
-    int rc = parse_matrix_trc(icc, size, src, trc_type, trc_params);
+    Trc trc[3];
+    int rc = parse_matrix_trc(icc, size, src, trc);
     if (rc) return rc;
     const double kMaxEncodeableXYZ = 1.0 + 32767.0 / 32768.0;
     // destination: cmsCreate_sRGBProfile = D65, Rec.709 primaries, parametric type 4 curve
@@ -207,7 +258,7 @@ extern "C" int32_t avifgpu_icc_prepare_shaper8(const void* icc_profile, uint32_t
     for (int c = 0; c < 3; ++c) {
         for (int i = 0; i < 256; ++i) {                                                   // FillFirstShaper
             const float R = (float)(i / 255.0);
-            const float y = eval_curve_float(trc_type[c], trc_params[c], R);
+            const float y = eval_curve_float(trc[c], R);
             out->shaper1[c][i] = (y < 131072.0f) ? to_1fixed14((double)y) : 0x7fffffff;
         }
         for (int i = 0; i < 16385; ++i) {                                                 // FillSecondShaper, 8-bit output
@@ -224,10 +275,8 @@ extern "C" int32_t avifgpu_icc_prepare_shaper8(const void* icc_profile, uint32_t
 
 namespace {
 
-int parse_matrix_trc(const uint8_t* icc, uint32_t size, M3& src, int trc_type_out[3], double trc_params_out[3][7])
+int parse_matrix_trc(const uint8_t* icc, uint32_t size, M3& src, Trc trc[3])
 {
-    struct { int32_t trc_type[3]; double trc_params[3][7]; } tmp = {};
-    auto* out = &tmp;
     if (std::memcmp(icc + 36, "acsp", 4) != 0) return fail(AVIFGPU_formatCannotRead, "not an ICC profile");
     if (std::memcmp(icc + 16, "RGB ", 4) != 0) return fail(AVIFGPU_formatCannotRead, "ICC profile is not RGB");
     if (std::memcmp(icc + 20, "XYZ ", 4) != 0) return fail(AVIFGPU_formatCannotRead, "ICC profile PCS is not XYZ (LUT-based): keep the lcms2 path");
@@ -250,24 +299,28 @@ int parse_matrix_trc(const uint8_t* icc, uint32_t size, M3& src, int trc_type_ou
         uint32_t off, len;
         if (!find_tag(icc, size, trc_tags[c], off, len)) return fail(AVIFGPU_formatCannotRead, "ICC profile has no TRC tags: keep the lcms2 path");
         const uint8_t* t = icc + off;
-        double* P = out->trc_params[c];
-        if (std::memcmp(t, "curv", 4) == 0 && len >= 12) {
+        double* P = trc[c].P;
+        if (std::memcmp(t, "curv", 4) == 0 && len >= 12) {                               // Type_Curve_Read
             const uint32_t n = be32(t + 8);
-            if (n == 0) { out->trc_type[c] = 1; P[0] = 1.0; }
-            else if (n == 1 && len >= 14) { out->trc_type[c] = 1; P[0] = (double)be16(t + 12) / 256.0; }     // u8Fixed8
-            else return fail(AVIFGPU_formatCannotRead, "sampled TRC tables are evaluated by lcms2 only: keep the lcms2 path");
+            if (n == 0) { trc[c].type = 1; P[0] = 1.0; }
+            else if (n == 1 && len >= 14) { trc[c].type = 1; P[0] = (double)be16(t + 12) / 256.0; }          // u8Fixed8
+            else if (n <= 0x7530 && (uint64_t)len >= 12u + 2ull * n) {                   // lcms2's own sanity limit
+                trc[c].type = 0;
+                trc[c].table.resize(n);
+                for (uint32_t i = 0; i < n; ++i) trc[c].table[i] = be16(t + 12 + 2 * i);
+            }
+            else return fail(AVIFGPU_formatCannotRead, "malformed curv tag");
         } else if (std::memcmp(t, "para", 4) == 0 && len >= 16) {
             const uint16_t fn = be16(t + 8);
             static const int nparams[5] = { 1, 3, 4, 5, 7 };
             if (fn > 4 || len < 12u + 4u * nparams[fn]) return fail(AVIFGPU_formatCannotRead, "unsupported parametric curve");
-            out->trc_type[c] = fn + 1;
+            trc[c].type = fn + 1;
             for (int k = 0; k < nparams[fn]; ++k) P[k] = s15f16(t + 12 + 4 * k);
         } else {
             return fail(AVIFGPU_formatCannotRead, "unsupported TRC tag type: keep the lcms2 path");
         }
     }
 
-    for (int c = 0; c < 3; ++c) { trc_type_out[c] = tmp.trc_type[c]; for (int k = 0; k < 7; ++k) trc_params_out[c][k] = tmp.trc_params[c][k]; }
     return 0;
 }
 

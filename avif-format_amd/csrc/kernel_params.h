@@ -32,9 +32,10 @@ struct WriteParams {
     float   half;                // 1 << (bits-1)
     // ICC row transform in front of stage A (include/avifgpu.h); used only by the ICC instantiations
     int32_t icc_trc_type[3];
-    int32_t icc_pad;
+    int32_t icc_out;             // 0 | 4: output curve after the matrix (avifgpu_icc_transform::out_curve)
     double  icc_trc[3][7];
     double  icc_m[9];
+    double  icc_out_p[8];
     // 8-bit matrix-shaper transform (avifgpu_icc_shaper8): tables live in device memory, matrix in kernarg
     const int32_t* icc8_s1;      // [3][256] 1.14 fixed
     const uint8_t* icc8_s2;      // [16385] 8-bit output curve (identical for R,G,B: the destination is sRGB)

@@ -66,8 +66,20 @@ __device__ __attribute__((noinline)) float icc_trc(int type, const double* P, fl
     return (float)v;
 }
 
+// Inverse of lcms2's parametric type 4 (type -4, DefaultEvalParametricFn), the curve stage in front of an sRGB destination.
+// P = g, a, b, c, d, break point pow(a*d+b, g), 1/g.
+__device__ __attribute__((noinline)) float icc_inv4(const double* P, float in)
+{
+    const double R = (double)in;
+    double v;
+    if (R >= P[5]) v = (fabs(P[0]) < 0.0001 || fabs(P[1]) < 0.0001) ? 0.0 : (pow(R, P[6]) - P[2]) / P[1];
+    else v = fabs(P[3]) < 0.0001 ? 0.0 : R / P[3];
+    return (float)v;
+}
+
 // ICC = 1: all three curves are gamma 1 (identity on every float: the "Linear RGB Profile" Photoshop embeds in 32-bit
 // documents) -> matrix only, no call in the kernel.  ICC = 2: general parametric curves (double pow, out of line).
+// ICC = 4: as 2 (linear curves skipped at run time) plus the destination's inverse curve after the matrix (-> sRGB).
 template <int ICC>
 AG_DEV void icc_apply(const WriteParams& p, float (&c)[3])
 {
@@ -75,6 +87,7 @@ AG_DEV void icc_apply(const WriteParams& p, float (&c)[3])
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         if constexpr (ICC == 1) t[k] = c[k];
+        else if constexpr (ICC == 4) t[k] = (p.icc_trc_type[k] == 1 && p.icc_trc[k][0] == 1.0) ? c[k] : icc_trc(p.icc_trc_type[k], p.icc_trc[k], c[k]);
         else t[k] = icc_trc(p.icc_trc_type[k], p.icc_trc[k], c[k]);
     }
 #pragma unroll
@@ -84,6 +97,7 @@ AG_DEV void icc_apply(const WriteParams& p, float (&c)[3])
         acc += (double)t[1] * p.icc_m[3 * i + 1];
         acc += (double)t[2] * p.icc_m[3 * i + 2];
         c[i] = (float)acc;
+        if constexpr (ICC == 4) c[i] = icc_inv4(p.icc_out_p, c[i]);
     }
 }
 
@@ -528,6 +542,17 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, const char** 
         if (p.icc_trc_type[0] != 0) {               // ICC row transform requested: separate instantiations, the others pay nothing
             bool linear = true;
             for (int c = 0; c < 3; ++c) linear = linear && p.icc_trc_type[c] == 1 && p.icc_trc[c][0] == 1.0;
+            if (p.icc_out == 4) {                   // -> sRGB: the SDR (Clip) save of a 32-bit document
+                if constexpr (TRANSFER == 3) {
+                    snprintf(label, sizeof(label), "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=4>",
+                             DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned);
+                    if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 4>), dim3(grid_for(groups)), dim3(256), 0, st, p);
+                    else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 4>), dim3(grid_for(groups)), dim3(256), 0, st, p);
+                    return hipGetLastError();
+                } else {
+                    return hipErrorInvalidValue;    // rejected earlier by fill_write_params
+                }
+            }
             snprintf(label, sizeof(label), "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=%d>",
                      DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned, linear ? 1 : 2);
             if (linear) {

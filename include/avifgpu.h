@@ -248,17 +248,23 @@ int32_t avifgpu_read_rows(const avifgpu_read_desc* desc,
  * carries a non-Rec.2020 profile (ColorProfileConversion::ConvertRow, src/common/ColorProfileConversion.cpp:159-187,
  * transform built at :235-266 against CreateRec2020LinearRGBProfile, ColorProfileGeneration.cpp:141-178).  For
  * matrix/TRC RGB profiles that lcms2 pipeline is [per-channel TRC] -> [one 3x3 matrix in double] -> float, which the
- * write kernels can apply in place of the CPU call.  LUT-based profiles (A2B tags), sampled `curv` tables and the
- * 32-bit-SDR -> sRGB case are NOT covered: avifgpu_icc_prepare returns AVIFGPU_formatCannotRead and the caller keeps
+ * write kernels can apply in place of the CPU call.  LUT-based profiles (A2B tags), sampled `curv` tables (on this
+ * 32-bit path only; Photoshop's 32-bit documents carry linear profiles) are NOT covered: avifgpu_icc_prepare returns AVIFGPU_formatCannotRead and the caller keeps
  * its lcms2 path. */
 typedef struct avifgpu_icc_transform {
     int32_t trc_type[3];         /* lcms2 parametric curve type 1..5 per channel (1 = plain gamma; gamma 1 = linear) */
-    int32_t reserved;
+    int32_t out_curve;           /* 0 = none (linear destination); 4 = inverse of lcms2 parametric type 4 (sRGB) after the matrix */
     double  trc_params[3][7];    /* g, a, b, c, d, e, f as lcms2 orders them */
     double  matrix[9];           /* row-major: out_i = (float) sum_j matrix[3i+j] * (double) trc_j(in_j) */
+    double  out_params[8];       /* out_curve == 4: g, a, b, c, d of the forward curve, then the break point
+                                    pow(a*d + b, g) and 1/g, 0 */
 } avifgpu_icc_transform;
 
-enum { AVIFGPU_ICC_TARGET_REC2020_LINEAR = 0 };
+/* REC2020_LINEAR: HDR saves (transfer PQ / SMPTE 428), ColorProfileConversion.cpp:235-266.
+ * SRGB_FLOAT: 32-bit documents saved as SDR (transfer Clip) are ALWAYS converted to sRGB, "because the 32-bit mode uses
+ * linear gamma" (ColorProfileConversion.cpp:118-123, :268-331 with TYPE_RGB[A]_FLT): lcms2's float pipeline is then
+ * [TRC] -> [3x3 in double] -> [inverse sRGB parametric curve in double] -> float. */
+enum { AVIFGPU_ICC_TARGET_REC2020_LINEAR = 0, AVIFGPU_ICC_TARGET_SRGB_FLOAT = 2 };
 
 /* Parse the document's ICC profile bytes (formatRecord->iCCprofileData) and build the transform to `target`. */
 int32_t avifgpu_icc_prepare(const void* icc_profile, uint32_t size, int32_t target, avifgpu_icc_transform* out);
@@ -287,8 +293,9 @@ typedef struct avifgpu_icc_shaper8 {
 
 enum { AVIFGPU_ICC_TARGET_SRGB8 = 1 };
 
-/* Build the tables for document profile -> sRGB (the profile cmsCreate_sRGBProfile makes).  Same profile restrictions
- * as avifgpu_icc_prepare. */
+/* Build the tables for document profile -> sRGB (the profile cmsCreate_sRGBProfile makes).  Matrix/TRC RGB profiles with
+ * `para` curves, `curv` gammas or sampled `curv` tables (interpolated in 16-bit fixed point like cmsEvalToneCurve16);
+ * AVIFGPU_formatCannotRead for anything else. */
 int32_t avifgpu_icc_prepare_shaper8(const void* icc_profile, uint32_t size, avifgpu_icc_shaper8* out);
 
 /* avifgpu_write_rows for 8-bit RGB(A) documents with that transform applied to R,G,B first (alpha copied). */

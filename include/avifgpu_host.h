@@ -83,9 +83,11 @@ typedef struct avifgpu_SaveUIOptions {
      * present, transfer != Clip, !IsRec2020ColorProfile).  The adapter makes that decision with the plug-in's own
      * detection code; 0 = no transform (or the adapter keeps calling lcms2 from its advanceState trampoline). */
     uint8_t convertToRec2020;
-    /* 1 = convert the 8-bit RGB document from formatRecord->iCCprofileData to sRGB on the GPU: the case in which the 8-bit
-     * constructor installs a transform (ColorProfileConversion.cpp:134-157: profile present, keepColorProfile off,
-     * !IsSRGBColorProfile).  lcms2's 8-bit matrix-shaper pipeline, bit-exact; formatCannotRead for non matrix/TRC profiles. */
+    /* 1 = convert the RGB document from formatRecord->iCCprofileData to sRGB on the GPU.  depth 8: the case in which the
+     * 8-bit constructor installs a transform (ColorProfileConversion.cpp:134-157: profile present, keepColorProfile off,
+     * !IsSRGBColorProfile) -- lcms2's 8-bit matrix-shaper pipeline, bit-exact.  depth 32 with transfer Clip: the SDR save
+     * of a 32-bit document, always converted (:118-123) -- lcms2's float pipeline.  formatCannotRead for profiles that are
+     * not matrix/TRC; depth 16 is not offered (lcms2 resamples that case into a 3-D CLUT). */
     uint8_t convertToSRGB;
 } avifgpu_SaveUIOptions;
 typedef struct avifgpu_LoadUIOptions {

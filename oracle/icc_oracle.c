@@ -13,12 +13,15 @@
  * Build: make -C oracle icc   (links -llcms2 from /opt/conda; skipped where lcms2 is absent).
  */
 #include <lcms2.h>
+#include <math.h>
 #include <stdint.h>
 #include <string.h>
 
 /* kind: 0 sRGB primaries, 1 Display-P3 primaries (D65), 2 ProPhoto primaries (D50), 3 AdobeRGB primaries.
  * trc:  0 gamma `g` (curv, count 1; g = 1 -> the "Linear RGB Profile" Photoshop embeds in 32-bit documents),
- *       1 sRGB parametric (para type 3 = lcms type 4), 2 gamma via para type 0. */
+ *       1 sRGB parametric (para type 3 = lcms type 4), 2 gamma via para type 0,
+ *       3 sampled `curv` table of (int)g entries holding the sRGB EOTF, 4 sampled tables of (int)g entries, a different
+ *         power law per channel (1.8 / 2.2 / 2.4). */
 int32_t oracle_icc_make_profile(int32_t kind, int32_t trc, double g, void* out, uint32_t cap)
 {
     static const cmsCIExyYTRIPLE prim[4] = {
@@ -31,6 +34,31 @@ int32_t oracle_icc_make_profile(int32_t kind, int32_t trc, double g, void* out, 
     cmsXYZ2xyY(&d50, cmsD50_XYZ());
     if (kind < 0 || kind > 3) return -1;
     cmsToneCurve* c;
+    if (trc == 3 || trc == 4) {
+        const int n = (int)g;
+        if (n < 2 || n > 4096) return -1;
+        static cmsUInt16Number tab[3][4096];
+        static const double pw[3] = { 1.8, 2.2, 2.4 };
+        cmsToneCurve* t3[3];
+        for (int ch = 0; ch < 3; ++ch) {
+            for (int i = 0; i < n; ++i) {
+                const double x = (double)i / (n - 1);
+                const double y = trc == 3 ? (x <= 0.04045 ? x / 12.92 : pow((x + 0.055) / 1.055, 2.4)) : pow(x, pw[ch]);
+                tab[ch][i] = (cmsUInt16Number)floor(y * 65535.0 + 0.5);
+            }
+            t3[ch] = cmsBuildTabulatedToneCurve16(NULL, (cmsUInt32Number)n, tab[ch]);
+            if (!t3[ch]) return -1;
+        }
+        cmsHPROFILE h = cmsCreateRGBProfile(kind == 2 ? &d50 : &d65, &prim[kind], t3);
+        for (int ch = 0; ch < 3; ++ch) cmsFreeToneCurve(t3[ch]);
+        if (!h) return -1;
+        cmsUInt32Number nb = 0;
+        cmsSaveProfileToMem(h, NULL, &nb);
+        int32_t rc = -1;
+        if (nb && nb <= cap && cmsSaveProfileToMem(h, out, &nb)) rc = (int32_t)nb;
+        cmsCloseProfile(h);
+        return rc;
+    }
     if (trc == 1) { cmsFloat64Number p[5] = { 2.4, 1.0 / 1.055, 0.055 / 1.055, 1.0 / 12.92, 0.04045 }; c = cmsBuildParametricToneCurve(NULL, 4, p); }
     else if (trc == 2) { cmsFloat64Number p[1] = { g }; c = cmsBuildParametricToneCurve(NULL, 1, p); }
     else c = cmsBuildGamma(NULL, g);
@@ -99,6 +127,34 @@ int32_t oracle_icc_convert_rows_to_srgb8(const void* icc, uint32_t icc_size, int
     if (doc && out) {
         cmsUInt32Number fmt = TYPE_RGB_8, flags = cmsFLAGS_BLACKPOINTCOMPENSATION;
         if (has_alpha) { fmt = TYPE_RGBA_8; flags |= cmsFLAGS_COPY_ALPHA; }
+        cmsHTRANSFORM t = cmsCreateTransformTHR(ctx, doc, fmt, out, fmt, INTENT_PERCEPTUAL, flags);
+        if (t) {
+            for (uint32_t y = 0; y < nrows; ++y) {
+                uint8_t* row = (uint8_t*)rows + (size_t)y * row_bytes;
+                cmsDoTransformLineStride(t, row, row, width, 1, row_bytes, row_bytes, 0, 0);
+            }
+            cmsDeleteTransform(t);
+            rc = 0;
+        }
+    }
+    if (doc) cmsCloseProfile(doc);
+    if (out) cmsCloseProfile(out);
+    cmsDeleteContext(ctx);
+    return rc;
+}
+
+/* 32-bit document saved as SDR: ColorProfileConversion ctor (ColorProfileConversion.cpp:118-123) + InitializeForSRGBConversion
+ * (:268-331) with hostBitsPerChannel == 32 (TYPE_RGB[A]_FLT) + ConvertRow per row, in place. */
+int32_t oracle_icc_convert_rows_to_srgb_float(const void* icc, uint32_t icc_size, int32_t has_alpha,
+                                              void* rows, uint32_t width, uint32_t nrows, uint32_t row_bytes)
+{
+    cmsContext ctx = cmsCreateContext(NULL, NULL);
+    cmsHPROFILE doc = cmsOpenProfileFromMemTHR(ctx, icc, icc_size);
+    cmsHPROFILE out = cmsCreate_sRGBProfileTHR(ctx);
+    int32_t rc = -1;
+    if (doc && out) {
+        cmsUInt32Number fmt = TYPE_RGB_FLT, flags = cmsFLAGS_BLACKPOINTCOMPENSATION;
+        if (has_alpha) { fmt = TYPE_RGBA_FLT; flags |= cmsFLAGS_COPY_ALPHA; }
         cmsHTRANSFORM t = cmsCreateTransformTHR(ctx, doc, fmt, out, fmt, INTENT_PERCEPTUAL, flags);
         if (t) {
             for (uint32_t y = 0; y < nrows; ++y) {

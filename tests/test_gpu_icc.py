@@ -29,6 +29,8 @@ def lcms():
     L.oracle_icc_convert_rows_to_rec2020.restype = ctypes.c_int32
     L.oracle_icc_convert_rows_to_rec2020.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p,
                                                       ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+    L.oracle_icc_convert_rows_to_srgb_float.restype = ctypes.c_int32
+    L.oracle_icc_convert_rows_to_srgb_float.argtypes = L.oracle_icc_convert_rows_to_rec2020.argtypes
     return L
 
 
@@ -69,6 +71,42 @@ def test_icc_then_pq_matches_lcms2(gpu, lcms, name, kind, trc, g, planes):
         assert st["max_abs"] <= 1, (name, output, st)
         assert st["exact_frac"] >= (0.99 if transfer == pkg.TRANSFER_PQ else 0.985), (name, output, st)
         assert ("icc=1" if (trc == 0 and g == 1.0) else "icc=2") in gpu.last_kernel()
+
+
+@pytest.mark.parametrize("name,kind,trc,g", PROFILES)
+@pytest.mark.parametrize("planes", [3, 4])
+def test_icc_to_srgb_then_clip_matches_lcms2(gpu, lcms, name, kind, trc, g, planes):
+    """The SDR save of a 32-bit document: always converted to sRGB with TYPE_RGB[A]_FLT (ColorProfileConversion.cpp:118-123,
+    :268-331), then the Clip branch of the pixel loop.  [TRC] -> 3x3 -> inverse sRGB curve, all in FP64 like lcms2."""
+    icc = _profile(lcms, kind, trc, g)
+    xf = gpu.icc_prepare(icc, pkg.ICC_TARGET_SRGB_FLOAT)
+    assert xf.out_curve == 4
+    alpha = pkg.ALPHA_PREMULTIPLIED if planes == 4 else pkg.ALPHA_NONE
+    worst = 1.0
+    for output, chroma, bits in ((pkg.OUT_REFERENCE, pkg.CHROMA_444, 10), (pkg.OUT_REFERENCE, pkg.CHROMA_444, 12),
+                                 (pkg.OUT_YCBCR, pkg.CHROMA_420, 12)):
+        d = pkg.WriteDesc(width=515, height=18, depth=32, planes=planes, bit_depth=bits, transfer=pkg.TRANSFER_CLIP,
+                          alpha_state=alpha, output=output, chroma=chroma, matrix_coefficients=pkg.MATRIX_BT601,
+                          color_primaries=pkg.PRIMARIES_BT709)
+        src = harness.make_write_source(d, seed=9)
+        if trc != 0 or g != 1.0:
+            src = np.abs(src)
+        conv = src.copy()
+        assert lcms.oracle_icc_convert_rows_to_srgb_float(icc, len(icc), int(planes == 4), conv.ctypes.data, d.width, d.height,
+                                                          conv.strides[0]) == 0
+        want = harness.oracle_write(d, conv)
+        got = _gpu_write_icc(gpu, d, src, xf)
+        st = harness.compare_write(d, want, got)
+        assert st["max_abs"] <= 1, (name, output, st)
+        worst = min(worst, st["exact_frac"])
+        assert "icc=4" in gpu.last_kernel()
+    assert worst >= 0.985, (name, worst)
+    # the sRGB target belongs to the Clip save only (the reference never builds it for PQ / SMPTE 428)
+    d = pkg.WriteDesc(width=16, height=2, depth=32, planes=planes, bit_depth=10, transfer=pkg.TRANSFER_PQ, peak_nits=1000,
+                      alpha_state=alpha, output=pkg.OUT_REFERENCE)
+    with pytest.raises(pkg.AvifGpuError) as e:
+        _gpu_write_icc(gpu, d, harness.make_write_source(d), xf)
+    assert e.value.code == pkg.formatBadParameters
 
 
 def _gpu_write_icc(gpu, d, src, xf):
@@ -152,3 +190,37 @@ def test_host_shim_converts_document_profile(gpu, lcms):
     img2 = H.Image()
     assert gpu.lib.avifgpu_host_create_heif_image(ctypes.byref(host2.fr), pkg.ALPHA_STRAIGHT, ctypes.byref(opts), pkg.OUT_YCBCR,
                                                   pkg.MATRIX_BT2020_NCL, pkg.PRIMARIES_BT2020, ctypes.byref(img2)) == pkg.formatCannotRead
+
+
+def test_host_shim_sdr_save_of_32bit_document(gpu, lcms):
+    """FormatRecord shim, 32-bit document + transfer Clip + saveOptions.convertToSRGB: lcms2's float pipeline to sRGB fused
+    in front of the Clip branch, tile by tile."""
+    from fake_host import FakeHost
+    H = pkg.host
+    icc = _profile(lcms, 3, 0, 1.0)                       # AdobeRGB primaries, linear (what a 32-bit AdobeRGB document embeds)
+    d = pkg.WriteDesc(width=300, height=40, depth=32, planes=3, bit_depth=12, transfer=pkg.TRANSFER_CLIP,
+                      alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420,
+                      matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)
+    src = harness.make_write_source(d, seed=13)
+    conv = src.copy()
+    assert lcms.oracle_icc_convert_rows_to_srgb_float(icc, len(icc), 0, conv.ctypes.data, d.width, d.height, conv.strides[0]) == 0
+    want = harness.oracle_write(d, conv)
+    host = FakeHost(d.width, d.height, 32, 3, max_data=300 * 12 * 10, image=src)
+    keep = ctypes.create_string_buffer(icc, len(icc))
+    host.fr.iCCprofileData = ctypes.cast(keep, ctypes.c_void_p)
+    host.fr.iCCprofileSize = len(icc)
+    opts = H.SaveUIOptions(imageBitDepth=12, hdrTransferFunction=pkg.TRANSFER_CLIP, pq=H.PQOptions(1000),
+                           chromaSubsampling=pkg.CHROMA_420, lossless=0, convertToRec2020=0, convertToSRGB=1)
+    img = H.Image()
+    code = gpu.lib.avifgpu_host_create_heif_image(ctypes.byref(host.fr), pkg.ALPHA_NONE, ctypes.byref(opts), pkg.OUT_YCBCR,
+                                                  pkg.MATRIX_BT601, pkg.PRIMARIES_BT709, ctypes.byref(img))
+    assert code == 0, gpu.lib.avifgpu_last_error()
+    assert len(host.rects) == 4
+    got = {}
+    for pl, (w, xs, ys) in harness.write_planes(d).items():
+        h = (d.height + ys) >> ys
+        raw = (ctypes.c_uint8 * (img.stride[pl] * h)).from_address(img.plane[pl])
+        got[pl] = np.frombuffer(raw, dtype=np.uint8).reshape(h, img.stride[pl])[:, :w * 2].view(np.uint16).copy()
+    st = harness.compare_write(d, want, got)
+    assert st["max_abs"] <= 1 and st["exact_frac"] >= 0.985, st
+    gpu.lib.avifgpu_image_free(ctypes.byref(img))
