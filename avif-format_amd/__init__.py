@@ -90,6 +90,7 @@ class IccTransform(ctypes.Structure):
 
 ICC_TARGET_REC2020_LINEAR = 0
 ICC_TARGET_SRGB_FLOAT = 2
+ICC_IS_REC2020, ICC_IS_SRGB = 1, 2
 
 
 class IccShaper8(ctypes.Structure):
@@ -113,6 +114,7 @@ ABI = [
     ("avifgpu_icc_prepare", c_int32, [c_void_p, ctypes.c_uint32, c_int32, POINTER(IccTransform)]),
     ("avifgpu_write_rows_icc", c_int32, [POINTER(WriteDesc), POINTER(IccTransform), c_int32, c_int32, c_void_p, c_int64,
                                          POINTER(_PLANES4), POINTER(_STRIDES4), c_int32, c_void_p]),
+    ("avifgpu_icc_detect", c_int32, [c_void_p, ctypes.c_uint32]),
     ("avifgpu_icc_prepare_shaper8", c_int32, [c_void_p, ctypes.c_uint32, POINTER(IccShaper8)]),
     ("avifgpu_write_rows_icc8", c_int32, [POINTER(WriteDesc), POINTER(IccShaper8), c_int32, c_int32, c_void_p, c_int64,
                                           POINTER(_PLANES4), POINTER(_STRIDES4), c_int32, c_void_p]),

@@ -273,6 +273,108 @@ extern "C" int32_t avifgpu_icc_prepare_shaper8(const void* icc_profile, uint32_t
     return 0;
 }
 
+// ---- profile detection (reference ColorProfileDetection.cpp:331-374) ----------------------------------------------------
+namespace {
+
+// The profile description as cmsGetProfileInfo(cmsInfoDescription, "en", "US") returns it, as UTF-16 code units: a V2
+// textDescription's ASCII part, a bare text tag, or the best mluc record (exact language + country, else same language,
+// else the first record) -- lcms2's _cmsMLUgetWide selection.
+std::vector<uint16_t> profile_description(const uint8_t* icc, uint32_t size)
+{
+    std::vector<uint16_t> out;
+    uint32_t off, len;
+    if (!find_tag(icc, size, "desc", off, len)) return out;
+    const uint8_t* t = icc + off;
+    if (std::memcmp(t, "desc", 4) == 0 && len >= 12) {
+        uint32_t n = be32(t + 8);
+        if (n > len - 12) n = len - 12;
+        for (uint32_t i = 0; i < n && t[12 + i] != 0; ++i) out.push_back(t[12 + i]);
+    } else if (std::memcmp(t, "text", 4) == 0) {
+        for (uint32_t i = 8; i < len && t[i] != 0; ++i) out.push_back(t[i]);
+    } else if (std::memcmp(t, "mluc", 4) == 0 && len >= 16) {
+        const uint32_t count = be32(t + 8), rec = be32(t + 12);
+        if (rec != 12 || count == 0 || (uint64_t)16 + 12ull * count > len) return out;
+        int best = -1, same_lang = -1;
+        for (uint32_t i = 0; i < count; ++i) {
+            const uint8_t* r = t + 16 + 12 * i;
+            if (r[0] == 'e' && r[1] == 'n') {
+                if (same_lang < 0) same_lang = (int)i;
+                if (r[2] == 'U' && r[3] == 'S') { best = (int)i; break; }
+            }
+        }
+        if (best < 0) best = same_lang < 0 ? 0 : same_lang;
+        const uint8_t* r = t + 16 + 12 * best;
+        const uint32_t slen = be32(r + 4), soff = be32(r + 8);
+        if ((uint64_t)soff + slen > len) return out;
+        for (uint32_t i = 0; i + 1 < slen; i += 2) out.push_back(be16(t + soff + i));
+    }
+    return out;
+}
+
+bool starts_with(const std::vector<uint16_t>& d, const char* prefix)
+{
+    const size_t n = std::strlen(prefix);
+    if (d.size() < n) return false;
+    for (size_t i = 0; i < n; ++i) if (d[i] != (uint8_t)prefix[i]) return false;
+    return true;
+}
+
+// ProfileHasColorantsAndWhitepoint (ColorProfileDetection.cpp:161-223): colorants un-adapted from D50 to the media white
+// with Bradford, everything compared as xy chromaticities with a tolerance of 0.01.
+bool has_colorants_and_whitepoint(const uint8_t* icc, uint32_t size, const double want[4][2])
+{
+    if (std::memcmp(icc + 16, "RGB ", 4) != 0) return false;
+    double col[3][3];
+    const char* tags[3] = { "rXYZ", "gXYZ", "bXYZ" };
+    uint32_t off, len;
+    for (int c = 0; c < 3; ++c) {
+        if (!find_tag(icc, size, tags[c], off, len) || len < 20 || std::memcmp(icc + off, "XYZ ", 4) != 0) return false;
+        for (int k = 0; k < 3; ++k) col[c][k] = s15f16(icc + off + 8 + 4 * k);
+    }
+    const double d50[3] = { 0.9642, 1.0, 0.8249 };
+    double wp[3] = { d50[0], d50[1], d50[2] };
+    const bool v2_display = be32(icc + 8) < 0x04000000u && std::memcmp(icc + 12, "mntr", 4) == 0;
+    if (find_tag(icc, size, "wtpt", off, len) && len >= 20 && std::memcmp(icc + off, "XYZ ", 4) == 0 && !v2_display)
+        for (int k = 0; k < 3; ++k) wp[k] = s15f16(icc + off + 8 + 4 * k);
+    auto close = [](const double xyz[3], const double xy[2]) {
+        const double sum = xyz[0] + xyz[1] + xyz[2];
+        return std::fabs(xyz[0] / sum - xy[0]) < 0.01 && std::fabs(xyz[1] / sum - xy[1]) < 0.01;
+    };
+    if (!close(wp, want[3])) return false;
+    M3 bradford;
+    if (!adaptation(d50, wp, bradford)) return false;
+    for (int c = 0; c < 3; ++c) {
+        double adapted[3];
+        apply(bradford, col[c], adapted);
+        if (!close(adapted, want[c])) return false;
+    }
+    return true;
+}
+
+} // namespace
+
+extern "C" int32_t avifgpu_icc_detect(const void* icc_profile, uint32_t size)
+{
+    if (!icc_profile || size < 132) return fail(AVIFGPU_formatBadParameters, "bad ICC profile buffer");
+    const uint8_t* icc = static_cast<const uint8_t*>(icc_profile);
+    if (std::memcmp(icc + 36, "acsp", 4) != 0) return fail(AVIFGPU_formatCannotRead, "not an ICC profile");
+    static const double rec2020[4][2] = { { 0.708, 0.292 }, { 0.170, 0.797 }, { 0.131, 0.046 }, { 0.3127, 0.3290 } };
+    static const double srgb[4][2] = { { 0.64, 0.33 }, { 0.30, 0.60 }, { 0.15, 0.06 }, { 0.3127, 0.3290 } };
+    int32_t r = 0;
+    uint32_t off, len;
+    if (find_tag(icc, size, "cicp", off, len) && len >= 12) {              // the CICP tag wins when present (:339-345, :360-367)
+        const uint8_t primaries = icc[off + 8], transfer = icc[off + 9];
+        if (primaries == 9) r |= AVIFGPU_ICC_IS_REC2020;
+        if (primaries == 1 && transfer == 13) r |= AVIFGPU_ICC_IS_SRGB;
+        return r;
+    }
+    const std::vector<uint16_t> desc = profile_description(icc, size);
+    if (starts_with(desc, "Rec2020-elle-V") || starts_with(desc, "Colorist BT. 2020") || starts_with(desc, "ITU-R BT. 2020 Reference Display") ||
+        has_colorants_and_whitepoint(icc, size, rec2020)) r |= AVIFGPU_ICC_IS_REC2020;
+    if (starts_with(desc, "sRGB") || has_colorants_and_whitepoint(icc, size, srgb)) r |= AVIFGPU_ICC_IS_SRGB;
+    return r;
+}
+
 namespace {
 
 int parse_matrix_trc(const uint8_t* icc, uint32_t size, M3& src, Trc trc[3])

@@ -277,6 +277,14 @@ int32_t avifgpu_write_rows_icc(const avifgpu_write_desc* desc, const avifgpu_icc
                                void* const dst[4], const int64_t dst_stride[4],
                                int32_t mem_kind, void* stream);
 
+/* Which working space the document profile already is: the checks that decide whether the reference installs a transform
+ * at all -- IsRec2020ColorProfile / IsSRGBColorProfile (src/common/ColorProfileDetection.cpp:331-374): the cicp tag when
+ * present, else a description prefix ("Rec2020-elle-V", "Colorist BT. 2020", "ITU-R BT. 2020 Reference Display" / "sRGB"),
+ * else colorants + media white point within 0.01 in xy after un-adapting from D50 (V2 display profiles count as D50, as
+ * the reference does).  Returns a bit mask of AVIFGPU_ICC_IS_*, or a negative OSErr for a buffer that is not a profile. */
+enum { AVIFGPU_ICC_IS_REC2020 = 1, AVIFGPU_ICC_IS_SRGB = 2 };
+int32_t avifgpu_icc_detect(const void* icc_profile, uint32_t size);
+
 /* ---- ICC row transform of the 8-bit SDR save path --------------------------------------------------------------------
  * With keepColorProfile == false (the default, AvifFormat.cpp:96) every 8-bit row of a non-sRGB document goes through
  * lcms2 to sRGB first (ColorProfileConversion.cpp:134-157, :268-331, TYPE_RGB[A]_8).  For a matrix/TRC profile lcms2

@@ -16,23 +16,25 @@
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
+#include <wchar.h>
 
-/* kind: 0 sRGB primaries, 1 Display-P3 primaries (D65), 2 ProPhoto primaries (D50), 3 AdobeRGB primaries.
+/* kind: 0 sRGB primaries, 1 Display-P3 primaries (D65), 2 ProPhoto primaries (D50), 3 AdobeRGB primaries, 4 Rec.2020.
  * trc:  0 gamma `g` (curv, count 1; g = 1 -> the "Linear RGB Profile" Photoshop embeds in 32-bit documents),
  *       1 sRGB parametric (para type 3 = lcms type 4), 2 gamma via para type 0,
  *       3 sampled `curv` table of (int)g entries holding the sRGB EOTF, 4 sampled tables of (int)g entries, a different
  *         power law per channel (1.8 / 2.2 / 2.4). */
 int32_t oracle_icc_make_profile(int32_t kind, int32_t trc, double g, void* out, uint32_t cap)
 {
-    static const cmsCIExyYTRIPLE prim[4] = {
+    static const cmsCIExyYTRIPLE prim[5] = {
         { {0.64, 0.33, 1.0}, {0.30, 0.60, 1.0}, {0.15, 0.06, 1.0} },
         { {0.68, 0.32, 1.0}, {0.265, 0.69, 1.0}, {0.15, 0.06, 1.0} },
         { {0.7347, 0.2653, 1.0}, {0.1596, 0.8404, 1.0}, {0.0366, 0.0001, 1.0} },
         { {0.64, 0.33, 1.0}, {0.21, 0.71, 1.0}, {0.15, 0.06, 1.0} },
+        { {0.708, 0.292, 1.0}, {0.170, 0.797, 1.0}, {0.131, 0.046, 1.0} },
     };
     cmsCIExyY d65 = { 0.3127, 0.3290, 1.0 }, d50;
     cmsXYZ2xyY(&d50, cmsD50_XYZ());
-    if (kind < 0 || kind > 3) return -1;
+    if (kind < 0 || kind > 4) return -1;
     cmsToneCurve* c;
     if (trc == 3 || trc == 4) {
         const int n = (int)g;
@@ -168,5 +170,100 @@ int32_t oracle_icc_convert_rows_to_srgb_float(const void* icc, uint32_t icc_size
     if (doc) cmsCloseProfile(doc);
     if (out) cmsCloseProfile(out);
     cmsDeleteContext(ctx);
+    return rc;
+}
+
+/* ---- profile detection (ColorProfileDetection.cpp:331-374 and helpers :38-330), restated on the real lcms2 API ------------
+ * Returns bit 0 = IsRec2020ColorProfile, bit 1 = IsSRGBColorProfile, or -1 if the bytes do not open as a profile.
+ * lcms2 2.12 has no cmsSigcicpTag yet, so the tag is read raw ('cicp': type sig, 4 reserved, primaries, transfer, matrix, range). */
+static int xy_close(const cmsCIExyY* a, double x, double y) { return fabs(a->x - x) < 0.01 && fabs(a->y - y) < 0.01; }
+
+static int has_colorants_and_whitepoint(cmsHPROFILE h, const double want[4][2])      /* R, G, B, white */
+{
+    if (cmsGetColorSpace(h) != cmsSigRgbData) return 0;
+    const cmsCIEXYZ* tag[3] = { cmsReadTag(h, cmsSigRedColorantTag), cmsReadTag(h, cmsSigGreenColorantTag), cmsReadTag(h, cmsSigBlueColorantTag) };
+    if (!tag[0] || !tag[1] || !tag[2]) return 0;
+    /* media white point: missing -> D50; V2 display profiles -> D50 (ReadMediaWhitePoint, :53-79) */
+    cmsCIEXYZ wp = *cmsD50_XYZ();
+    const cmsCIEXYZ* wt = cmsReadTag(h, cmsSigMediaWhitePointTag);
+    if (wt && !(cmsGetEncodedICCversion(h) < 0x4000000 && cmsGetDeviceClass(h) == cmsSigDisplayClass)) wp = *wt;
+    cmsCIExyY wxy;
+    cmsXYZ2xyY(&wxy, &wp);
+    cmsCIEXYZ dn;
+    cmsxyY2XYZ(&dn, &wxy);
+    if (!xy_close(&wxy, want[3][0], want[3][1])) return 0;
+    for (int c = 0; c < 3; ++c) {                          /* Bradford from D50 to the media white, column by column (:81-160) */
+        cmsCIEXYZ adapted;
+        cmsCIExyY xy;
+        if (!cmsAdaptToIlluminant(&adapted, cmsD50_XYZ(), &dn, tag[c])) return 0;
+        cmsXYZ2xyY(&xy, &adapted);
+        if (!xy_close(&xy, want[c][0], want[c][1])) return 0;
+    }
+    return 1;
+}
+
+static int description_starts_with(cmsHPROFILE h, const wchar_t* const* names, int n)
+{
+    wchar_t buf[256];
+    memset(buf, 0, sizeof buf);
+    const size_t chars = cmsGetProfileInfo(h, cmsInfoDescription, "en", "US", buf, 255) / sizeof(wchar_t);
+    if (chars == 0) return 0;
+    for (int i = 0; i < n; ++i) {
+        const size_t len = wcslen(names[i]);
+        if (chars >= len && wcsncmp(buf, names[i], len) == 0) return 1;
+    }
+    return 0;
+}
+
+int32_t oracle_icc_detect(const void* icc, uint32_t size)
+{
+    cmsHPROFILE h = cmsOpenProfileFromMem(icc, size);
+    if (!h) return -1;
+    static const double rec2020[4][2] = { {0.708, 0.292}, {0.170, 0.797}, {0.131, 0.046}, {0.3127, 0.3290} };
+    static const double srgb[4][2] = { {0.64, 0.33}, {0.30, 0.60}, {0.15, 0.06}, {0.3127, 0.3290} };
+    static const wchar_t* const rec2020_names[3] = { L"Rec2020-elle-V", L"Colorist BT. 2020", L"ITU-R BT. 2020 Reference Display" };
+    static const wchar_t* const srgb_names[1] = { L"sRGB" };
+    int32_t r = 0;
+    uint8_t cicp[12];
+    if (cmsIsTag(h, (cmsTagSignature)0x63696370) && cmsReadRawTag(h, (cmsTagSignature)0x63696370, cicp, 12) == 12) {
+        if (cicp[8] == 9) r |= 1;                          /* heif_color_primaries_ITU_R_BT_2020_2_and_2100_0 */
+        if (cicp[8] == 1 && cicp[9] == 13) r |= 2;         /* BT.709 primaries + IEC 61966-2-1 transfer */
+    } else {
+        if (description_starts_with(h, rec2020_names, 3) || has_colorants_and_whitepoint(h, rec2020)) r |= 1;
+        if (description_starts_with(h, srgb_names, 1) || has_colorants_and_whitepoint(h, srgb)) r |= 2;
+    }
+    cmsCloseProfile(h);
+    return r;
+}
+
+/* Test-profile builder with the attributes detection looks at: description text, ICC version (2.x display profiles take the
+ * D50 shortcut), optional raw cicp tag (primaries < 0: none); flags bit 0: media white point tag = D65 (lcms2 itself writes
+ * D50), bit 1: device class 'scnr' instead of 'mntr', bit 2: description stored for language "de"/"DE" only. */
+int32_t oracle_icc_make_profile_ex(int32_t kind, double gamma, const char* description, double version,
+                                   int32_t cicp_primaries, int32_t cicp_transfer, int32_t flags, void* out, uint32_t cap)
+{
+    uint8_t tmp[8192];
+    int32_t n = oracle_icc_make_profile(kind, 0, gamma, tmp, sizeof tmp);
+    if (n <= 0) return -1;
+    cmsHPROFILE h = cmsOpenProfileFromMem(tmp, (cmsUInt32Number)n);
+    if (!h) return -1;
+    if (description) {
+        cmsMLU* mlu = cmsMLUalloc(NULL, 1);
+        cmsMLUsetASCII(mlu, (flags & 4) ? "de" : "en", (flags & 4) ? "DE" : "US", description);
+        cmsWriteTag(h, cmsSigProfileDescriptionTag, mlu);
+        cmsMLUfree(mlu);
+    }
+    if (version > 0) cmsSetProfileVersion(h, version);
+    if (flags & 1) { cmsCIEXYZ d65; cmsCIExyY xy = { 0.3127, 0.3290, 1.0 }; cmsxyY2XYZ(&d65, &xy); cmsWriteTag(h, cmsSigMediaWhitePointTag, &d65); }
+    if (flags & 2) cmsSetDeviceClass(h, cmsSigInputClass);
+    if (cicp_primaries >= 0) {
+        const uint8_t raw[12] = { 'c', 'i', 'c', 'p', 0, 0, 0, 0, (uint8_t)cicp_primaries, (uint8_t)cicp_transfer, 0, 1 };
+        cmsWriteRawTag(h, (cmsTagSignature)0x63696370, raw, 12);
+    }
+    cmsUInt32Number nb = 0;
+    cmsSaveProfileToMem(h, NULL, &nb);
+    int32_t rc = -1;
+    if (nb && nb <= cap && cmsSaveProfileToMem(h, out, &nb)) rc = (int32_t)nb;
+    cmsCloseProfile(h);
     return rc;
 }
