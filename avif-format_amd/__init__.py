@@ -18,7 +18,8 @@ from . import host  # noqa: E402,F401      (ctypes mirror of include/avifgpu_hos
 from . import distrib  # noqa: E402,F401   (barrier + MAX-over-ranks for bench.py)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libavifgpu.so")
+# AVIFGPU_LIB: developer switch for A/B-ing kernel builds (tools/ab_variants.sh); the product name is libavifgpu.so
+LIB_PATH = os.environ.get("AVIFGPU_LIB") or os.path.join(_HERE, "libavifgpu.so")
 
 # ---- enums (include/avifgpu.h) ----------------------------------------------------------------
 TRANSFER_PQ, TRANSFER_HLG, TRANSFER_SMPTE428, TRANSFER_CLIP = 0, 1, 2, 3

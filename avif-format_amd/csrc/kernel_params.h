@@ -70,10 +70,11 @@ struct ReadParams {
 // Number of 2^bits-entry float tables read_px keeps in LDS (bits <= 12).  Full-range images need ONE: T_A[i] = i/max is
 // also T_Y, and T_UV[i] = T_Y[i] - 0.5f is the same float subtraction the reference's table builder performs
 // (YuvLookupTables.cpp:171,182), applied at lookup time.  Limited range needs separate Y / UV (/ alpha) tables.
-// Planar RGB -> f32 adds a table of EOTF(T_A[i]) so the transfer curve is evaluated per code, not per sample.
+// Planar RGB -> f32 keeps ONE table, EOTF(T_A[i]), so the transfer curve is evaluated per code, not per sample (alpha's
+// T_A[i] = i / max is one division per pixel, computed in place: a second 16 KiB table would cost a wave of occupancy).
 inline int read_table_count(bool ycc, bool mono, bool alpha, int depth, bool full_range, bool identity_lut, bool premultiplied)
 {
-    if (!ycc && !mono) return 1 + ((depth == 32) ? 1 : 0);            // RGB planar: T_A (+ EOTF table)
+    if (!ycc && !mono) return depth == 32 ? 1 : 0;                    // RGB planar: EOTF(T_A[i]) per code for f32 hosts, else none
     int n = 1;                                                        // T_Y
     if (ycc && !full_range && !identity_lut) n += 1;                  // T_UV
     if (alpha && !full_range) n += 1;                                 // T_A

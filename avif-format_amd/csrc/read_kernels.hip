@@ -111,7 +111,7 @@ AG_DEV void eotf_rgb(const ReadParams& p, float (&c)[3])
 enum { kCsYcc = 0, kCsRgb = 1, kCsMono = 2 };
 
 // x / kg of the G equation (YuvDecode.cpp:314).  Fast form: exact for the verified divisors (see avifgpu_api.hip).
-__device__ __attribute__((noinline)) float ieee_div_slow(float x, float d) { return x / d; }
+AG_DEV float ieee_div_slow(float x, float d) { return x / d; }
 AG_DEV float div_by_kg(const ReadParams& p, float x)
 {
     if (__builtin_expect(p.fast_div != 0, 1)) {
@@ -137,11 +137,28 @@ AG_DEV float unpremultiply_one(float c, float A, float r)
 // std::clamp(v, 0, 1) for the finite values this path produces (v_med3_f32; a NaN cannot arise from table values).
 AG_DEV float clamp01(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); }
 
+// The chroma part of the YCbCr -> RGB equations (YuvDecode.cpp:312-314) depends on the chroma sample only: R = Y + r,
+// B = Y + b, G = Y - g.  Evaluated ONCE per chroma sample and shared by the 1/2/4 pixels of its footprint -- the same
+// IEEE operations on the same inputs, so every pixel still gets the bits the reference's per-pixel evaluation produces.
+struct ChromaTerms { float r, g, b; };
+template <int DEPTH, bool LUT>
+AG_DEV ChromaTerms chroma_terms(const ReadParams& p, const Tables<LUT>& t, uint32_t u1, uint32_t u2)
+{
+    if constexpr (DEPTH != 8) { u1 = min(u1, (uint32_t)p.maxc); u2 = min(u2, (uint32_t)p.maxc); }   // std::min(sample, yuvMaxChannel)
+    const float Cb = look_uv(p, t, u1), Cr = look_uv(p, t, u2);
+    const float kr = p.kr, kb = p.kb;
+    ChromaTerms c;
+    c.r = (2 * (1 - kr)) * Cr;                                                          // :312
+    c.b = (2 * (1 - kb)) * Cb;                                                          // :313
+    c.g = div_by_kg(p, 2 * ((kr * (1 - kr) * Cr) + (kb * (1 - kb) * Cb)));              // :314, "/ kg"
+    return c;
+}
+
 // One pixel.  u[] = raw samples (Y,Cb,Cr | R,G,B | Y), ua = alpha sample.  out[] = NCH host samples
 // (u8/u16 values or f32 bit patterns).
 template <int CS, int DEPTH, bool ALPHA, int TRANSFER, bool LUT>
 AG_DEV void decode_pixel(const ReadParams& p, const Tables<LUT>& t, uint32_t u0, uint32_t u1, uint32_t u2, uint32_t ua,
-                         uint32_t* out)
+                         uint32_t* out, const ChromaTerms& ct = ChromaTerms{})
 {
     const uint32_t maxc = (uint32_t)p.maxc;
     const float rgb_max = DEPTH == 8 ? 255.0f : 32768.0f;
@@ -166,7 +183,7 @@ AG_DEV void decode_pixel(const ReadParams& p, const Tables<LUT>& t, uint32_t u0,
                 eotf_rgb<TRANSFER>(p, c);
             }
             out[0] = __float_as_uint(c[0]); out[1] = __float_as_uint(c[1]); out[2] = __float_as_uint(c[2]);
-            if constexpr (ALPHA) out[3] = __float_as_uint(look_a(p, t, ua));
+            if constexpr (ALPHA) out[3] = __float_as_uint(table_a(p, (int)ua));
         } else {
             out[0] = q[0]; out[1] = q[1]; out[2] = q[2];
             if constexpr (ALPHA) out[3] = ua;
@@ -174,7 +191,7 @@ AG_DEV void decode_pixel(const ReadParams& p, const Tables<LUT>& t, uint32_t u0,
         return;
     } else {
         if constexpr (DEPTH != 8) {                                 // std::min(sample, yuvMaxChannel), YuvDecode.cpp:139,:424-427
-            u0 = min(u0, maxc); u1 = min(u1, maxc); u2 = min(u2, maxc); ua = min(ua, maxc);
+            u0 = min(u0, maxc); ua = min(ua, maxc);                 // (chroma: in chroma_terms)
         }
         if constexpr (CS == kCsMono) {                              // YuvDecode.cpp:55-279
             if constexpr (DEPTH == 32) {
@@ -195,11 +212,10 @@ AG_DEV void decode_pixel(const ReadParams& p, const Tables<LUT>& t, uint32_t u0,
             }
             return;
         } else {                                                    // YCbCr, YuvDecode.cpp:281-696
-            const float Y = look_y(p, t, u0), Cb = look_uv(p, t, u1), Cr = look_uv(p, t, u2);
-            const float kr = p.kr, kb = p.kb;
-            float R = Y + (2 * (1 - kr)) * Cr;                                          // :312
-            float B = Y + (2 * (1 - kb)) * Cb;                                          // :313
-            float G = Y - div_by_kg(p, 2 * ((kr * (1 - kr) * Cr) + (kb * (1 - kb) * Cb)));  // :314, "/ kg"
+            const float Y = look_y(p, t, u0);
+            float R = Y + ct.r;                                                         // :312
+            float B = Y + ct.b;                                                         // :313
+            float G = Y - ct.g;                                                         // :314
             R = clamp01(R); G = clamp01(G); B = clamp01(B);
             if constexpr (ALPHA) {
                 if (p.premultiplied && ua < maxc) {                                     // :369-388
@@ -230,34 +246,59 @@ AG_DEV void decode_pixel(const ReadParams& p, const Tables<LUT>& t, uint32_t u0,
     }
 }
 
-// Load N consecutive samples of a plane row starting at sample index i0 (right-edge replicated to `count`).
+// Load N consecutive samples of a plane row starting at sample index i0 (right-edge replicated to `count`), kept PACKED
+// as they sit in memory (N * sample-size / 4 dwords): a group's planes then cost a handful of VGPRs, which is what lets
+// the next group's loads be in flight while this one is decoded (AG_READ_PREFETCH).
 template <bool SRC16, int N, bool ALIGNED>
-AG_DEV void load_plane(const uint8_t* row, int i0, int count, uint32_t (&v)[N])
+AG_DEV void load_plane(const uint8_t* row, int i0, int count, uint32_t (&d)[N * (SRC16 ? 2 : 1) / 4])
 {
     constexpr int SSZ = SRC16 ? 2 : 1;
-    constexpr int BYTES = N * SSZ;
-    if constexpr (BYTES % 4 == 0) {
-        if (i0 + N <= count) {
-            uint32_t d[BYTES / 4];
-            load_dwords<BYTES / 4, true, ALIGNED>(row + (long long)i0 * SSZ, d);   // planar, coalesced, read once: non-temporal
-#pragma unroll
-            for (int j = 0; j < N; ++j) {
-                if constexpr (SRC16) v[j] = (d[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-                else v[j] = (d[j >> 2] >> (8 * (j & 3))) & 0xffu;
-            }
-            return;
-        }
+    constexpr int ND = N * SSZ / 4;
+    static_assert((N * SSZ) % 4 == 0, "whole dwords per lane");
+    if (i0 + N <= count) {
+        load_dwords<ND, true, ALIGNED>(row + (long long)i0 * SSZ, d);   // planar, coalesced, read once: non-temporal
+        return;
     }
+#pragma unroll
+    for (int k = 0; k < ND; ++k) d[k] = 0;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const int i = min(i0 + j, count - 1);
-        v[j] = SRC16 ? ld_u16(row + 2LL * i) : ld_u8(row + i);
+        const uint32_t v = SRC16 ? ld_u16(row + 2LL * i) : ld_u8(row + i);
+        if constexpr (SRC16) d[j >> 1] |= v << (16 * (j & 1)); else d[j >> 2] |= v << (8 * (j & 3));
     }
 }
+template <bool SRC16> AG_DEV uint32_t sample_of(const uint32_t* d, int j)
+{
+    if constexpr (SRC16) return (d[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+    else return (d[j >> 2] >> (8 * (j & 3))) & 0xffu;
+}
 
-// samples of chroma per thread: 4 for u16 planes, 8 for u8 planes => every plane load is >= 8 bytes per lane
-template <int DEPTH, int XS> struct ReadShape {
-    static constexpr int NC = DEPTH == 8 ? 8 : 4;
+#ifndef AG_READ_PREFETCH
+#define AG_READ_PREFETCH 0
+#endif
+#ifndef AG_R8_NC
+#define AG_R8_NC 8
+#endif
+#ifndef AG_R16_NC
+#define AG_R16_NC 4
+#endif
+#ifndef AG_RGB16_NC
+#define AG_RGB16_NC 8
+#endif
+#ifndef AG_MONO16_NC
+#define AG_MONO16_NC 8
+#endif
+// Measured on MI355X (profiles/r01/ab_read_variants.txt): YCbCr keeps 4 chroma samples per lane for u16 planes (8 cost a wave
+// of occupancy and 30-40 % on the 4:2:x kernels); planar RGB / mono have no chroma state and run 13 % faster with 16-byte loads.
+#ifndef AG_R8_NC_SMALL
+#define AG_R8_NC_SMALL 4
+#endif
+template <int CS, int DEPTH, bool ALPHA, int XS> struct ReadShape {
+    // u8 planes: 8 chroma samples per lane only where a lane's footprint stays small (4:2:x without alpha); 4:4:4 and the
+    // alpha variants ran 20 % faster with 4 (register pressure)
+    static constexpr int NC8 = (CS == 0 && (XS == 0 || ALPHA)) ? AG_R8_NC_SMALL : AG_R8_NC;
+    static constexpr int NC = DEPTH == 8 ? NC8 : (CS == 1 ? AG_RGB16_NC : (CS == 2 ? AG_MONO16_NC : AG_R16_NC));
     static constexpr int PXT = NC << XS;
 };
 
@@ -265,8 +306,8 @@ template <int CS, int DEPTH, bool ALPHA, int XS, int YS, int TRANSFER, bool LUT,
 __global__ __launch_bounds__(256) void read_px(const ReadParams p)
 {
     constexpr bool SRC16 = DEPTH != 8;
-    constexpr int NC = ReadShape<DEPTH, XS>::NC;
-    constexpr int PXT = ReadShape<DEPTH, XS>::PXT;
+    constexpr int NC = ReadShape<CS, DEPTH, ALPHA, XS>::NC;
+    constexpr int PXT = ReadShape<CS, DEPTH, ALPHA, XS>::PXT;
     constexpr int VR = 1 << YS;
     constexpr int NCH = (CS == kCsMono ? 1 : 3) + (ALPHA ? 1 : 0);
     constexpr int OSZ = DEPTH / 8;
@@ -280,13 +321,11 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
         const int count = 1 << p.bits;
         float* next = lut;
         if constexpr (CS == kCsRgb) {
-            float* fa = next; next += count;
             float* fe = nullptr;
-            if constexpr (DEPTH == 32) { fe = next; next += count; }
-            for (int i = threadIdx.x; i < count; i += 256) {
-                const float a = table_a(p, i);
-                fa[i] = a;
-                if constexpr (DEPTH == 32) {
+            if constexpr (DEPTH == 32) {
+                fe = next; next += count;
+                for (int i = threadIdx.x; i < count; i += 256) {
+                    const float a = table_a(p, i);
                     float e;
                     if constexpr (TRANSFER == AVIFGPU_TRANSFER_PQ) e = fast_pq_to_linear_l2(a, p.pq_log2_mult);
                     else if constexpr (TRANSFER == AVIFGPU_TRANSFER_HLG) e = fast_hlg_to_linear(a);
@@ -294,7 +333,7 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
                     fe[i] = e;
                 }
             }
-            t.ta = fa; t.te = fe; t.ty = fa; t.tuv = fa;
+            t.te = fe;
         } else {
             float* fy = next; next += count;
             float* fuv = fy; float* fa = fy;
@@ -329,7 +368,41 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
     const uint32_t total_waves = wpr * (uint32_t)gyn;      // < 2^31 (host checks)
     const int cw = (p.width + (1 << XS) - 1) >> XS;
 
-    for (uint32_t wv = blockIdx.x * 4 + wave; wv < total_waves; wv += gridDim.x * 4) {
+    // One group = the planes' samples under one lane's footprint (PXT pixels x VR rows + their chroma), packed.
+    constexpr int SSZ = SRC16 ? 2 : 1;
+    constexpr int NDY = PXT * SSZ / 4, NDC = NC * SSZ / 4;
+    struct Group {
+        uint32_t y[VR][NDY];
+        uint32_t a[ALPHA ? VR : 1][NDY];
+        uint32_t g1[CS == kCsRgb ? VR : 1][NDY], g2[CS == kCsRgb ? VR : 1][NDY];
+        uint32_t c1[NDC], c2[NDC];
+    };
+    auto load_group = [&](uint32_t wv, Group& g) {
+        const int gy = (int)(wv / wpr);
+        const int gx = (int)(wv - (uint32_t)gy * wpr) * 64 + lane;
+        if (gx >= gxn) return;
+        const int x0 = gx * PXT;
+        if constexpr (CS == kCsYcc) {                       // uvJ = y >> yChromaShift, uvI = x >> xChromaShift
+            load_plane<SRC16, NC, ALIGNED>(p.src[1] + (long long)gy * p.src_stride[1], x0 >> XS, cw, g.c1);
+            load_plane<SRC16, NC, ALIGNED>(p.src[2] + (long long)gy * p.src_stride[2], x0 >> XS, cw, g.c2);
+        }
+#pragma unroll
+        for (int vr = 0; vr < VR; ++vr) {
+            const int r = min(gy * VR + vr, p.nrows - 1);   // an odd last row: the duplicate load is never stored
+            load_plane<SRC16, PXT, ALIGNED>(p.src[0] + (long long)r * p.src_stride[0], x0, p.width, g.y[vr]);
+            if constexpr (ALPHA) load_plane<SRC16, PXT, ALIGNED>(p.src[3] + (long long)r * p.src_stride[3], x0, p.width, g.a[vr]);
+            if constexpr (CS == kCsRgb) {
+                load_plane<SRC16, PXT, ALIGNED>(p.src[1] + (long long)r * p.src_stride[1], x0, p.width, g.g1[vr]);
+                load_plane<SRC16, PXT, ALIGNED>(p.src[2] + (long long)r * p.src_stride[2], x0, p.width, g.g2[vr]);
+            }
+        }
+    };
+
+    const uint32_t wstep = gridDim.x * 4;
+    uint32_t wv = blockIdx.x * 4 + wave;
+    Group cur;
+    if (AG_READ_PREFETCH && wv < total_waves) load_group(wv, cur);
+    for (; wv < total_waves; wv += wstep) {
         const int gy = (int)(wv / wpr);
         const int wx = (int)(wv - (uint32_t)gy * wpr);
         const int gx = wx * 64 + lane;
@@ -338,13 +411,17 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
         const int r0 = gy * VR;
         const int nvalid = active ? min(PXT, p.width - x0) : 0;
 
-        uint32_t c1[NC], c2[NC];
-#pragma unroll
-        for (int j = 0; j < NC; ++j) { c1[j] = 0; c2[j] = 0; }
-        if constexpr (CS == kCsYcc) {                       // uvJ = y >> yChromaShift, uvI = x >> xChromaShift
+        Group nxt;
+        if constexpr (AG_READ_PREFETCH) { if (wv + wstep < total_waves) load_group(wv + wstep, nxt); }   // in flight during the decode below
+        else load_group(wv, cur);
+
+        ChromaTerms ct[NC];
+        if constexpr (CS == kCsYcc && XS + YS > 0) {
+            // shared by 2 or 4 pixels: evaluate once.  (4:4:4 keeps it in the pixel loop: hoisting there only lengthens
+            // live ranges and cost a wave of occupancy.)
             if (active) {
-                load_plane<SRC16, NC, ALIGNED>(p.src[1] + (long long)gy * p.src_stride[1], x0 >> XS, cw, c1);
-                load_plane<SRC16, NC, ALIGNED>(p.src[2] + (long long)gy * p.src_stride[2], x0 >> XS, cw, c2);
+#pragma unroll
+                for (int j = 0; j < NC; ++j) ct[j] = chroma_terms<DEPTH, LUT>(p, t, sample_of<SRC16>(cur.c1, j), sample_of<SRC16>(cur.c2, j));
             }
         }
 
@@ -354,19 +431,19 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
             if (r >= p.nrows) continue;                     // wave-uniform
             uint32_t o[PXT * NCH];
             if (active) {
-                uint32_t y[PXT], a[PXT], g1[PXT], g2[PXT];
-                load_plane<SRC16, PXT, ALIGNED>(p.src[0] + (long long)r * p.src_stride[0], x0, p.width, y);
-                if constexpr (ALPHA) load_plane<SRC16, PXT, ALIGNED>(p.src[3] + (long long)r * p.src_stride[3], x0, p.width, a);
-                if constexpr (CS == kCsRgb) {
-                    load_plane<SRC16, PXT, ALIGNED>(p.src[1] + (long long)r * p.src_stride[1], x0, p.width, g1);
-                    load_plane<SRC16, PXT, ALIGNED>(p.src[2] + (long long)r * p.src_stride[2], x0, p.width, g2);
-                }
 #pragma unroll
                 for (int i = 0; i < PXT; ++i) {
-                    uint32_t u1 = 0, u2 = 0;
-                    if constexpr (CS == kCsYcc) { u1 = c1[i >> XS]; u2 = c2[i >> XS]; }
-                    if constexpr (CS == kCsRgb) { u1 = g1[i]; u2 = g2[i]; }
-                    decode_pixel<CS, DEPTH, ALPHA, TRANSFER, LUT>(p, t, y[i], u1, u2, ALPHA ? a[i] : (uint32_t)p.maxc, &o[i * NCH]);
+                    const uint32_t yv = sample_of<SRC16>(cur.y[vr], i);
+                    const uint32_t av = ALPHA ? sample_of<SRC16>(cur.a[ALPHA ? vr : 0], i) : (uint32_t)p.maxc;
+                    if constexpr (CS == kCsYcc && XS + YS > 0)
+                        decode_pixel<CS, DEPTH, ALPHA, TRANSFER, LUT>(p, t, yv, 0, 0, av, &o[i * NCH], ct[i >> XS]);
+                    else if constexpr (CS == kCsYcc)
+                        decode_pixel<CS, DEPTH, ALPHA, TRANSFER, LUT>(p, t, yv, 0, 0, av, &o[i * NCH],
+                                                                      chroma_terms<DEPTH, LUT>(p, t, sample_of<SRC16>(cur.c1, i), sample_of<SRC16>(cur.c2, i)));
+                    else if constexpr (CS == kCsRgb)
+                        decode_pixel<CS, DEPTH, ALPHA, TRANSFER, LUT>(p, t, yv, sample_of<SRC16>(cur.g1[vr], i), sample_of<SRC16>(cur.g2[vr], i), av, &o[i * NCH]);
+                    else
+                        decode_pixel<CS, DEPTH, ALPHA, TRANSFER, LUT>(p, t, yv, 0, 0, av, &o[i * NCH]);
                 }
             }
 
@@ -400,6 +477,7 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
                 }
             }
         }
+        if constexpr (AG_READ_PREFETCH) cur = nxt;
     }
 }
 
@@ -407,7 +485,7 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
 template <int CS, int DEPTH, bool ALPHA, int XS, int YS, int TRANSFER>
 static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, const char** name)
 {
-    constexpr int PXT = ReadShape<DEPTH, XS>::PXT;
+    constexpr int PXT = ReadShape<CS, DEPTH, ALPHA, XS>::PXT;
     const long long groups = (long long)((p.width + PXT - 1) / PXT) * ((p.nrows + (1 << YS) - 1) >> YS);
     if (groups == 0) return hipSuccess;
     if (groups >= 0x7fffffffLL - 256LL * 65536) return hipErrorInvalidValue;   // 32-bit group index in the kernel

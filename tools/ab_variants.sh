@@ -1,0 +1,24 @@
+#!/bin/bash
+# Build A/B variants of libavifgpu.so that differ in one translation unit compiled with extra -D flags.
+#   tools/ab_variants.sh read_kernels "-DAG_X=1" name1 "-DAG_X=2" name2 ...
+# Results: avif-format_amd/variants/libavifgpu_<name>.so  (travels with gpurun; git-ignored as *.so)
+set -e
+cd "$(dirname "$0")/../avif-format_amd"
+unit=$1; shift
+mkdir -p variants build
+make -s libavifgpu.so
+while [ $# -gt 1 ]; do
+  flags=$1; name=$2; shift 2
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function $flags -c csrc/$unit.hip -o variants/$unit.$name.o &
+done
+wait
+for o in variants/$unit.*.o; do
+  name=$(basename $o .o); name=${name#$unit.}
+  objs=""
+  for f in avifgpu_api.hip write_kernels.hip read_kernels.hip host_shim.cpp icc_profile.cpp; do
+    if [ "$f" = "$unit.hip" ]; then objs="$objs $o"; else objs="$objs build/$f.o"; fi
+  done
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libavifgpu_$name.so $objs
+  echo built variants/libavifgpu_$name.so
+done
+rm -f variants/*.o

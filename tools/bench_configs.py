@@ -84,6 +84,20 @@ def bench_read(name, **kw):
                       "frac_of_8TBs": round(ab / mean / 1e6 / 8000, 3), "bytes_per_px": ab / (d.width * d.height)}), flush=True)
 
 
+ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]      # optional substrings: run matching configurations only
+_bw, _br = bench_write, bench_read
+
+
+def bench_write(name, **kw):
+    if not ONLY or any(o in name for o in ONLY):
+        _bw(name, **kw)
+
+
+def bench_read(name, **kw):
+    if not ONLY or any(o in name for o in ONLY):
+        _br(name, **kw)
+
+
 if __name__ == "__main__":
     P = pkg
     bench_write("C2 4096^2 RGB8 -> 8-bit 4:2:0 BT.709", width=4096, height=4096, depth=8, planes=3, bit_depth=8, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=P.MATRIX_BT709)
@@ -110,6 +124,9 @@ if __name__ == "__main__":
         xf2 = gpu.icc_prepare(buf.raw[:n])
         bench_write("C4 + ICC (sRGB parametric TRC doc -> Rec.2020) 8192^2 RGB f32 -> 10-bit PQ 4:4:4", icc=xf2, width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=9, color_primaries=9)
     bench_read("R8 8192^2 8-bit 4:2:0 BT.709 -> RGB8", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_420, bit_depth=8, depth=8, alpha_state=0, matrix_coefficients=1)
+    bench_read("R8 8192^2 8-bit 4:4:4 BT.601 -> RGB8", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_444, bit_depth=8, depth=8, alpha_state=0, matrix_coefficients=6)
+    bench_read("R8 8192^2 8-bit 4:2:0 BT.601 + alpha -> RGBA8", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_420, bit_depth=8, depth=8, alpha_state=1, matrix_coefficients=6)
+    bench_read("R16 8192^2 12-bit mono -> Gray16", width=8192, height=8192, colorspace=2, chroma=P.CHROMA_MONOCHROME, bit_depth=12, depth=16, alpha_state=0)
     bench_read("R16 8192^2 10-bit 4:4:4 BT.2020 -> RGB16", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_444, bit_depth=10, depth=16, alpha_state=0, matrix_coefficients=9, color_primaries=9)
     bench_read("R16 8192^2 12-bit 4:2:0 BT.2020 + alpha premult -> RGBA16", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_420, bit_depth=12, depth=16, alpha_state=2, matrix_coefficients=9, color_primaries=9)
     bench_read("R32 8192^2 10-bit 4:4:4 BT.2020 PQ -> RGB f32", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_444, bit_depth=10, depth=32, alpha_state=0, matrix_coefficients=9, color_primaries=9, transfer_characteristics=16, pq_peak_nits=80)
