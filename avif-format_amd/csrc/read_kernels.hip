@@ -298,7 +298,7 @@ template <int CS, int DEPTH, bool ALPHA, int XS> struct ReadShape {
     // u8 planes: 8 chroma samples per lane only where a lane's footprint stays small (4:2:x without alpha); 4:4:4 and the
     // alpha variants ran 20 % faster with 4 (register pressure)
     static constexpr int NC8 = (CS == 0 && (XS == 0 || ALPHA)) ? AG_R8_NC_SMALL : AG_R8_NC;
-    static constexpr int NC = DEPTH == 8 ? NC8 : (CS == 1 ? AG_RGB16_NC : (CS == 2 ? AG_MONO16_NC : AG_R16_NC));
+    static constexpr int NC = DEPTH == 8 ? NC8 : (CS == 1 ? AG_RGB16_NC : (CS == 2 ? (DEPTH == 32 ? 4 : AG_MONO16_NC) : AG_R16_NC));
     static constexpr int PXT = NC << XS;
 };
 
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint32_t* strip = nullptr;
-    if constexpr (ALIGNED) strip = reinterpret_cast<uint32_t*>(lut) + lut_floats + wave * (64 * ND_OUT);
+    if constexpr (ALIGNED && ND_OUT > 4) strip = reinterpret_cast<uint32_t*>(lut) + lut_floats + wave * (64 * ND_OUT);
 
     const int gxn = (p.width + PXT - 1) / PXT;
     const int gyn = (p.nrows + VR - 1) >> YS;
@@ -447,7 +447,29 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
                 }
             }
 
-            if constexpr (ALIGNED) {
+            if constexpr (ALIGNED && ND_OUT <= 4) {
+                // a lane's output is one <= 16-byte vector and adjacent lanes are adjacent in memory (gray without alpha):
+                // already a fully coalesced store, no transposition needed
+                if (active) {
+                    uint8_t* drow = p.dst + (long long)r * p.dst_row_bytes + (long long)x0 * NCH * OSZ;
+                    if (nvalid == PXT) {
+                        uint32_t pk[ND_OUT];
+#pragma unroll
+                        for (int j = 0; j < ND_OUT; ++j) {
+                            if constexpr (DEPTH == 8) pk[j] = o[4 * j] | (o[4 * j + 1] << 8) | (o[4 * j + 2] << 16) | (o[4 * j + 3] << 24);
+                            else if constexpr (DEPTH == 16) pk[j] = o[2 * j] | (o[2 * j + 1] << 16);
+                            else pk[j] = o[j];
+                        }
+                        store_dwords<ND_OUT, true, true>(drow, pk);
+                    } else if constexpr (DEPTH == 32) {
+#pragma unroll
+                        for (int j = 0; j < PXT * NCH; ++j)
+                            if (j < nvalid * NCH) reinterpret_cast<uint32_t*>(drow)[j] = o[j];
+                    } else {
+                        store_samples<DEPTH == 16, PXT * NCH, false, false>(drow, o, nvalid * NCH);
+                    }
+                }
+            } else if constexpr (ALIGNED) {
                 // ---- transposed store: lane-major packed dwords -> wave-private LDS strip -> transfer-major read-back,
                 // so that every global store instruction writes 64 x VW dwords of CONTIGUOUS memory (non-temporal).
                 // A lane-strided store leaves partial lines for L2 to merge and ran at 0.33-0.6 of the HBM rate. ----
@@ -500,7 +522,7 @@ static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, const cha
     uintptr_t bits = reinterpret_cast<uintptr_t>(p.dst) | (uintptr_t)p.dst_row_bytes;
     for (int pl = 0; pl < 4; ++pl) if (p.src[pl]) bits |= reinterpret_cast<uintptr_t>(p.src[pl]) | (uintptr_t)p.src_stride[pl];
     const bool aligned = (bits & 15) == 0;      // => branch-free vector loads + LDS-transposed coalesced stores
-    const size_t lds = lut_bytes + (aligned ? (size_t)4 * 64 * ND_OUT * sizeof(uint32_t) : 0);
+    const size_t lds = lut_bytes + ((aligned && ND_OUT > 4) ? (size_t)4 * 64 * ND_OUT * sizeof(uint32_t) : 0);
     snprintf(label, sizeof(label), "read_px<cs=%d,depth=%d,alpha=%d,xs=%d,ys=%d,transfer=%d,aligned=%d>", CS, DEPTH, (int)ALPHA, XS, YS,
              TRANSFER, (int)aligned);
     *name = label;

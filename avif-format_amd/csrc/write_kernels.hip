@@ -105,7 +105,7 @@ AG_DEV void icc_apply(const WriteParams& p, float (&c)[3])
 // s[] holds the PLANES raw samples (u8/u16 values, or f32 bit patterns).  q[0..NCOL-1] colour, q[3] alpha.
 template <int DEPTH, int PLANES, int TRANSFER, int ICC = 0>
 AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t (&q)[4],
-                    const int32_t* icc8_lds_s1 = nullptr, const uint8_t* icc8_lds_s2 = nullptr)
+                    const int32_t* icc8_lds_s1 = nullptr, const uint8_t* icc8_lds_s2 = nullptr, const uint16_t* lut8 = nullptr)
 {
     constexpr bool COLOR = PLANES >= 3;
     constexpr bool ALPHA = (PLANES == 2 || PLANES == 4);
@@ -151,7 +151,7 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
 #pragma unroll
         for (int k = 0; k < PLANES; ++k) {
             if constexpr (DEPTH == 8) {
-                v[k] = (p.maxv > 255) ? exact_rescale(sx[k], 255.0f, p.maxf, p.maxv) : sx[k];        // :87-112
+                v[k] = (p.maxv > 255) ? (uint32_t)lut8[sx[k]] : sx[k];        // the reference's 256-entry LUT, :87-112
             } else {
                 const uint32_t i = sx[k] > 32768u ? 32768u : sx[k];  // reference reads past its LUT here
                 v[k] = exact_rescale(i, 32768.0f, p.maxf, p.maxv);                                   // :114-166
@@ -180,10 +180,25 @@ AG_DEV uint32_t stage_b_luma(const WriteParams& p, const uint32_t (&q)[4])
 // ---- generic kernel ----------------------------------------------------------------------------
 enum { kOutRefColor = 0, kOutRefGray = 1, kOutYcbcr = 2 };
 
+#ifndef AG_W_PACK
+#define AG_W_PACK 2
+#endif
+#ifndef AG_W8_NC
+#define AG_W8_NC 8
+#endif
+#ifndef AG_W8_NC_ALPHA
+#define AG_W8_NC_ALPHA 4
+#endif
+// chroma samples per lane: 4 for u16 planes, AG_W8_NC for u8 planes (every plane store >= 8 / 4 bytes per lane)
+template <bool DST16, int PLANES, int XS> struct WriteShape {
+    static constexpr int NC = DST16 ? 4 : ((PLANES == 2 || PLANES == 4) ? AG_W8_NC_ALPHA : AG_W8_NC);
+    static constexpr int PXT = NC << XS;
+};
+
 template <int DEPTH, int PLANES, int OUT, bool DST16, int XS, int YS, int TRANSFER, bool ALIGNED, int ICC = 0>
 __global__ __launch_bounds__(256) void write_px(const WriteParams p)
 {
-    constexpr int PXT = (DST16 ? 4 : 8) << XS;   // 4 (u16 planes) or 8 (u8 planes) chroma samples per thread: every plane store >= 8 B/lane
+    constexpr int PXT = WriteShape<DST16, PLANES, XS>::PXT;
     constexpr int VR = 1 << YS;
     constexpr int BPP = PLANES * DEPTH / 8;
     constexpr int ND = PXT * BPP / 4;             // dwords per thread per row
@@ -211,6 +226,16 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
         __syncthreads();
     }
 
+    // 8-bit documents saved at 10/12 bit: the reference's 256-entry rescale LUT (WriteHeifImage.cpp:87-112), rebuilt per
+    // workgroup with the same IEEE expression -- one ds_read per sample instead of a division sequence in the pixel loop
+    __shared__ uint16_t lut8[DEPTH == 8 ? 256 : 2];
+    if constexpr (DEPTH == 8) {
+        if (p.maxv > 255) {
+            lut8[threadIdx.x] = (uint16_t)exact_rescale(threadIdx.x, 255.0f, p.maxf, p.maxv);
+            __syncthreads();
+        }
+    }
+
     const int gxn = (p.width + PXT - 1) / PXT;
     const int gyn = (p.nrows + VR - 1) >> YS;
     const uint32_t wpr = (uint32_t)(gxn + 63) >> 6;        // waves per row group
@@ -227,7 +252,17 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
         const bool full = nvalid == PXT;
         const int span_px = min(64 * PXT, p.width - wx * 64 * PXT);              // valid pixels of this wave's span
 
-        uint32_t q[VR][PXT][4];
+        // The integer codes of the footprint stay PACKED until they are stored (4 x u8 or 2 x 2 x u16 per pixel): a 4:2:0
+        // footprint of 2 x 16 pixels is 32 or 64 VGPRs instead of 128, which is worth 1-2 waves of occupancy on the SDR
+        // kernels (C2' 0.61 -> see profiles/r01/bench_configs.jsonl).
+        constexpr bool PACK = AG_W_PACK == 1 || (AG_W_PACK == 2 && DEPTH == 16 && !DST16);
+        constexpr int NQ = !PACK ? 4 : (DST16 ? 2 : 1);
+        uint32_t qp[VR][PXT][NQ];
+        auto qget = [&](int vr, int i, int k) -> uint32_t {
+            if constexpr (!PACK) return qp[vr][i][k];
+            else if constexpr (DST16) return (qp[vr][i][k >> 1] >> (16 * (k & 1))) & 0xffffu;
+            else return (qp[vr][i][0] >> (8 * k)) & 0xffu;
+        };
 
 #pragma unroll
         for (int vr = 0; vr < VR; ++vr) {
@@ -269,7 +304,13 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
                     for (int k = 0; k < PLANES; ++k) s[i][k] = 0;
             }
 #pragma unroll
-            for (int i = 0; i < PXT; ++i) stage_a<DEPTH, PLANES, TRANSFER, ICC>(p, s[i], q[vr][i], icc8_s1, icc8_s2);
+            for (int i = 0; i < PXT; ++i) {
+                uint32_t q[4] = { 0, 0, 0, 0 };            // gray fills [0] and [3] only
+                stage_a<DEPTH, PLANES, TRANSFER, ICC>(p, s[i], q, icc8_s1, icc8_s2, lut8);
+                if constexpr (!PACK) { qp[vr][i][0] = q[0]; qp[vr][i][1] = q[1]; qp[vr][i][2] = q[2]; qp[vr][i][3] = q[3]; }
+                else if constexpr (DST16) { qp[vr][i][0] = q[0] | (q[1] << 16); qp[vr][i][1] = q[2] | (q[3] << 16); }
+                else qp[vr][i][0] = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
+            }
         }
 
         // ---------------- stores ----------------
@@ -282,8 +323,8 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
                 uint32_t v[PXT * PLANES];
 #pragma unroll
                 for (int i = 0; i < PXT; ++i) {
-                    v[i * PLANES + 0] = q[vr][i][0]; v[i * PLANES + 1] = q[vr][i][1]; v[i * PLANES + 2] = q[vr][i][2];
-                    if constexpr (ALPHA) v[i * PLANES + 3] = q[vr][i][3];
+                    v[i * PLANES + 0] = qget(vr, i, 0); v[i * PLANES + 1] = qget(vr, i, 1); v[i * PLANES + 2] = qget(vr, i, 2);
+                    if constexpr (ALPHA) v[i * PLANES + 3] = qget(vr, i, 3);
                 }
                 if constexpr (ALIGNED) {
                     uint32_t pk[NDO];
@@ -302,9 +343,9 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
                 uint32_t yv[PXT], av[PXT];
 #pragma unroll
                 for (int i = 0; i < PXT; ++i) {
-                    if constexpr (OUT == kOutRefGray) yv[i] = q[vr][i][0];   // planar Y(+A): :247-252
-                    else yv[i] = stage_b_luma(p, q[vr][i]);
-                    av[i] = q[vr][i][3];
+                    if constexpr (OUT == kOutRefGray) yv[i] = qget(vr, i, 0);   // planar Y(+A): :247-252
+                    else { const uint32_t q4[4] = { qget(vr, i, 0), qget(vr, i, 1), qget(vr, i, 2), 0 }; yv[i] = stage_b_luma(p, q4); }
+                    av[i] = qget(vr, i, 3);
                 }
                 store_samples<DST16, PXT, true, ALIGNED>(p.dst[0] + (long long)r * p.dst_stride[0] + (long long)x0 * DSZ, yv, nvalid);
                 if constexpr (ALPHA)
@@ -318,16 +359,16 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
                 const int i0 = j << XS;
-                if (p.identity) { cbv[j] = q[0][i0][2]; crv[j] = q[0][i0][0]; continue; }   // GBR: Cb<-B, Cr<-R
-                float R = (float)q[0][i0][0], G = (float)q[0][i0][1], B = (float)q[0][i0][2];
+                if (p.identity) { cbv[j] = qget(0, i0, 2); crv[j] = qget(0, i0, 0); continue; }   // GBR: Cb<-B, Cr<-R
+                float R = (float)qget(0, i0, 0), G = (float)qget(0, i0, 1), B = (float)qget(0, i0, 2);
                 if constexpr (XS || YS) {
                     if (!p.nearest) {
                         constexpr int i1o = XS ? 1 : 0;
                         constexpr int v1 = YS ? 1 : 0;
                         // (x2, r2) replication at the image edges already happened in the loads above
-                        R = (R + (float)q[0][i0 + i1o][0] + (float)q[v1][i0][0] + (float)q[v1][i0 + i1o][0]) * 0.25f;
-                        G = (G + (float)q[0][i0 + i1o][1] + (float)q[v1][i0][1] + (float)q[v1][i0 + i1o][1]) * 0.25f;
-                        B = (B + (float)q[0][i0 + i1o][2] + (float)q[v1][i0][2] + (float)q[v1][i0 + i1o][2]) * 0.25f;
+                        R = (R + (float)qget(0, i0 + i1o, 0) + (float)qget(v1, i0, 0) + (float)qget(v1, i0 + i1o, 0)) * 0.25f;
+                        G = (G + (float)qget(0, i0 + i1o, 1) + (float)qget(v1, i0, 1) + (float)qget(v1, i0 + i1o, 1)) * 0.25f;
+                        B = (B + (float)qget(0, i0 + i1o, 2) + (float)qget(v1, i0, 2) + (float)qget(v1, i0 + i1o, 2)) * 0.25f;
                     }
                 }
                 const float cb = R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2];
@@ -516,7 +557,7 @@ static inline int grid_for(long long threads_needed)
 template <int DEPTH, int PLANES, int OUT, bool DST16, int XS, int YS, int TRANSFER>
 static hipError_t launch_one(const WriteParams& p, hipStream_t st, const char** name)
 {
-    constexpr int PXT = (DST16 ? 4 : 8) << XS;
+    constexpr int PXT = WriteShape<DST16, PLANES, XS>::PXT;
     const long long groups = (long long)((p.width + PXT - 1) / PXT) * ((p.nrows + (1 << YS) - 1) >> YS);
     if (groups == 0) return hipSuccess;
     if (groups >= 0x7fffffffLL - 256LL * 65536) return hipErrorInvalidValue;   // 32-bit group index in the kernel
