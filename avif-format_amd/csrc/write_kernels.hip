@@ -35,32 +35,62 @@ AG_DEV uint32_t oetf_code(const WriteParams& p, float f)
     return (uint32_t)__builtin_amdgcn_fmed3f(scaled, 0.0f, p.maxf);
 }
 
+// pow(x, g) for finite x > 0 in FP64, good to ~1e-14 relative (checked against libm on 1.5e6 points per exponent):
+// log2 by the atanh series on the mantissa in [sqrt(1/2), sqrt(2)), exp2 by a degree-13 Taylor polynomial.  lcms2 evaluates
+// its curves with libm's pow in double and rounds the result to float; at this accuracy the rounded floats agree except
+// for ~1e-7 of the samples, far inside the tier-2 bar.  ~45 DFMA-class instructions instead of the several hundred of the
+// device libm's pow (the general-TRC ICC kernel went from 0.06 to the figure in profiles/r01/bench_configs.jsonl).
+__device__ __attribute__((noinline)) double dpow_pos(double x, double g)
+{
+    double m = __builtin_amdgcn_frexp_mant(x);               // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    if (m < 0.70710678118654752) { m *= 2.0; e -= 1; }
+    const double s = (m - 1.0) / (m + 1.0);
+    const double s2 = s * s;
+    double p = 1.0 / 17.0;
+    p = __builtin_fma(p, s2, 1.0 / 15.0); p = __builtin_fma(p, s2, 1.0 / 13.0); p = __builtin_fma(p, s2, 1.0 / 11.0);
+    p = __builtin_fma(p, s2, 1.0 / 9.0);  p = __builtin_fma(p, s2, 1.0 / 7.0);  p = __builtin_fma(p, s2, 1.0 / 5.0);
+    p = __builtin_fma(p, s2, 1.0 / 3.0);  p = __builtin_fma(p, s2, 1.0);
+    const double l2 = 2.8853900817779268 * s * p;            // 2 / ln 2
+    const double y = g * ((double)e + l2);
+    const double n = __builtin_rint(y);
+    const double t = (y - n) * 0.69314718055994531;
+    double q = 1.0 / 6227020800.0;
+    q = __builtin_fma(q, t, 1.0 / 479001600.0); q = __builtin_fma(q, t, 1.0 / 39916800.0); q = __builtin_fma(q, t, 1.0 / 3628800.0);
+    q = __builtin_fma(q, t, 1.0 / 362880.0);    q = __builtin_fma(q, t, 1.0 / 40320.0);    q = __builtin_fma(q, t, 1.0 / 5040.0);
+    q = __builtin_fma(q, t, 1.0 / 720.0);       q = __builtin_fma(q, t, 1.0 / 120.0);      q = __builtin_fma(q, t, 1.0 / 24.0);
+    q = __builtin_fma(q, t, 1.0 / 6.0);         q = __builtin_fma(q, t, 0.5);              q = __builtin_fma(q, t, 1.0);
+    q = __builtin_fma(q, t, 1.0);
+    return __builtin_amdgcn_ldexp(q, (int)n);
+}
+AG_DEV double dpow(double x, double g) { return x > 0.0 ? dpow_pos(x, g) : 0.0; }     // callers pass x >= 0, g > 0
+
 // ---- ICC row transform (lcms2 float pipeline of a matrix/TRC profile pair, see include/avifgpu.h) --------------------
 // One lcms2 parametric curve (types 1..5, DefaultEvalParametricFn) evaluated in double, returned as the float the
 // curves stage hands to the matrix stage.
-__device__ __attribute__((noinline)) float icc_trc(int type, const double* P, float in)
+AG_DEV float icc_trc(int type, const double* P, float in)
 {
     const double R = (double)in;
     double v;
     switch (type) {
     case 1:
-        if (R < 0) v = (fabs(P[0] - 1.0) < 0.0001) ? R : 0.0; else v = pow(R, P[0]);
+        if (R < 0) v = (fabs(P[0] - 1.0) < 0.0001) ? R : 0.0; else v = (P[0] == 1.0) ? R : dpow(R, P[0]);   // pow(R, 1) == R exactly
         break;
     case 2: {
         if (fabs(P[1]) < 0.0001) { v = 0.0; break; }
         const double disc = -P[2] / P[1];
-        if (R >= disc) { const double e = P[1] * R + P[2]; v = e > 0 ? pow(e, P[0]) : 0.0; } else v = 0.0;
+        if (R >= disc) { const double e = P[1] * R + P[2]; v = e > 0 ? dpow(e, P[0]) : 0.0; } else v = 0.0;
         break; }
     case 3: {
         if (fabs(P[1]) < 0.0001) { v = 0.0; break; }
         double disc = -P[2] / P[1]; if (disc < 0) disc = 0;
-        if (R >= disc) { const double e = P[1] * R + P[2]; v = e > 0 ? pow(e, P[0]) + P[3] : 0.0; } else v = P[3];
+        if (R >= disc) { const double e = P[1] * R + P[2]; v = e > 0 ? dpow(e, P[0]) + P[3] : 0.0; } else v = P[3];
         break; }
     case 4:
-        if (R >= P[4]) { const double e = P[1] * R + P[2]; v = e > 0 ? pow(e, P[0]) : 0.0; } else v = R * P[3];
+        if (R >= P[4]) { const double e = P[1] * R + P[2]; v = e > 0 ? dpow(e, P[0]) : 0.0; } else v = R * P[3];
         break;
     default:
-        if (R >= P[4]) { const double e = P[1] * R + P[2]; v = e > 0 ? pow(e, P[0]) + P[5] : P[5]; } else v = R * P[3] + P[6];
+        if (R >= P[4]) { const double e = P[1] * R + P[2]; v = e > 0 ? dpow(e, P[0]) + P[5] : P[5]; } else v = R * P[3] + P[6];
         break;
     }
     return (float)v;
@@ -68,11 +98,11 @@ __device__ __attribute__((noinline)) float icc_trc(int type, const double* P, fl
 
 // Inverse of lcms2's parametric type 4 (type -4, DefaultEvalParametricFn), the curve stage in front of an sRGB destination.
 // P = g, a, b, c, d, break point pow(a*d+b, g), 1/g.
-__device__ __attribute__((noinline)) float icc_inv4(const double* P, float in)
+AG_DEV float icc_inv4(const double* P, float in)
 {
     const double R = (double)in;
     double v;
-    if (R >= P[5]) v = (fabs(P[0]) < 0.0001 || fabs(P[1]) < 0.0001) ? 0.0 : (pow(R, P[6]) - P[2]) / P[1];
+    if (R >= P[5]) v = (fabs(P[0]) < 0.0001 || fabs(P[1]) < 0.0001) ? 0.0 : (dpow(R, P[6]) - P[2]) / P[1];
     else v = fabs(P[3]) < 0.0001 ? 0.0 : R / P[3];
     return (float)v;
 }

@@ -127,6 +127,9 @@ if __name__ == "__main__":
         n = L.oracle_icc_make_profile(0, 1, 0.0, buf, len(buf))
         xf2 = gpu.icc_prepare(buf.raw[:n])
         bench_write("C4 + ICC (sRGB parametric TRC doc -> Rec.2020) 8192^2 RGB f32 -> 10-bit PQ 4:4:4", icc=xf2, width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=9, color_primaries=9)
+        n = L.oracle_icc_make_profile(1, 0, 1.0, buf, len(buf))
+        xf3 = gpu.icc_prepare(buf.raw[:n], P.ICC_TARGET_SRGB_FLOAT)
+        bench_write("SDR save of a 32-bit doc + ICC (linear Display-P3 -> sRGB) 8192^2 RGB f32 -> 12-bit Clip 4:2:0", icc=xf3, width=8192, height=8192, depth=32, planes=3, bit_depth=12, transfer=P.TRANSFER_CLIP, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=6, color_primaries=1)
     bench_read("R8 8192^2 8-bit 4:2:0 BT.709 -> RGB8", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_420, bit_depth=8, depth=8, alpha_state=0, matrix_coefficients=1)
     bench_read("R8 8192^2 8-bit 4:4:4 BT.601 -> RGB8", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_444, bit_depth=8, depth=8, alpha_state=0, matrix_coefficients=6)
     bench_read("R8 8192^2 8-bit 4:2:0 BT.601 + alpha -> RGBA8", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_420, bit_depth=8, depth=8, alpha_state=1, matrix_coefficients=6)
