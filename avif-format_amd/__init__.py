@@ -94,6 +94,10 @@ ICC_TARGET_SRGB_FLOAT = 2
 ICC_IS_REC2020, ICC_IS_SRGB = 1, 2
 
 
+class IccClut16(ctypes.Structure):
+    _fields_ = [("grid_points", c_int32), ("reserved", c_int32 * 3), ("table", (ctypes.c_uint16 * 4) * (33 * 33 * 33))]
+
+
 class IccShaper8(ctypes.Structure):
     _fields_ = [("shaper1", (c_int32 * 256) * 3), ("matrix", (c_int32 * 3) * 3), ("offset", c_int32 * 3), ("reserved", c_int32),
                 ("shaper2", (ctypes.c_uint8 * 16388) * 3)]
@@ -116,6 +120,9 @@ ABI = [
     ("avifgpu_write_rows_icc", c_int32, [POINTER(WriteDesc), POINTER(IccTransform), c_int32, c_int32, c_void_p, c_int64,
                                          POINTER(_PLANES4), POINTER(_STRIDES4), c_int32, c_void_p]),
     ("avifgpu_icc_detect", c_int32, [c_void_p, ctypes.c_uint32]),
+    ("avifgpu_icc_prepare_clut16", c_int32, [c_void_p, ctypes.c_uint32, POINTER(IccClut16)]),
+    ("avifgpu_write_rows_icc16", c_int32, [POINTER(WriteDesc), POINTER(IccClut16), c_int32, c_int32, c_void_p, c_int64,
+                                           POINTER(_PLANES4), POINTER(_STRIDES4), c_int32, c_void_p]),
     ("avifgpu_icc_prepare_shaper8", c_int32, [c_void_p, ctypes.c_uint32, POINTER(IccShaper8)]),
     ("avifgpu_write_rows_icc8", c_int32, [POINTER(WriteDesc), POINTER(IccShaper8), c_int32, c_int32, c_void_p, c_int64,
                                           POINTER(_PLANES4), POINTER(_STRIDES4), c_int32, c_void_p]),
@@ -199,6 +206,11 @@ class AvifGpu:
 
     def write_rows(self, desc: WriteDesc, row0, nrows, src_ptr, src_row_bytes, dst_ptrs, dst_strides,
                    mem=MEM_DEVICE, stream=0, icc=None):
+        if isinstance(icc, IccClut16):
+            self._check(self.lib.avifgpu_write_rows_icc16(ctypes.byref(desc), ctypes.byref(icc), row0, nrows, src_ptr, src_row_bytes,
+                                                          ctypes.byref(planes4(dst_ptrs)), ctypes.byref(strides4(dst_strides)),
+                                                          mem, stream or None))
+            return
         if isinstance(icc, IccShaper8):
             self._check(self.lib.avifgpu_write_rows_icc8(ctypes.byref(desc), ctypes.byref(icc), row0, nrows, src_ptr, src_row_bytes,
                                                          ctypes.byref(planes4(dst_ptrs)), ctypes.byref(strides4(dst_strides)),
@@ -212,6 +224,11 @@ class AvifGpu:
         self._check(self.lib.avifgpu_write_rows(ctypes.byref(desc), row0, nrows, src_ptr, src_row_bytes,
                                                 ctypes.byref(planes4(dst_ptrs)), ctypes.byref(strides4(dst_strides)),
                                                 mem, stream or None))
+
+    def icc_prepare_clut16(self, profile_bytes: bytes) -> "IccClut16":
+        t = IccClut16()
+        self._check(self.lib.avifgpu_icc_prepare_clut16(profile_bytes, len(profile_bytes), ctypes.byref(t)))
+        return t
 
     def icc_prepare_shaper8(self, profile_bytes: bytes) -> "IccShaper8":
         t = IccShaper8()

@@ -25,7 +25,7 @@ namespace avifgpu {
 int wait_slot(int slot);
 int write_rows_host_enqueue(const avifgpu_write_desc* d, int row0, int nrows, const void* src, int64_t src_row_bytes,
                             void* const dst[4], const int64_t dst_stride[4], int slot, const avifgpu_icc_transform* icc = nullptr,
-                            const avifgpu_icc_shaper8* icc8 = nullptr);
+                            const avifgpu_icc_shaper8* icc8 = nullptr, const avifgpu_icc_clut16* icc16 = nullptr);
 int read_rows_host_enqueue(const avifgpu_read_desc* d, int row0, int nrows, const void* const src[4], const int64_t src_stride[4],
                            void* dst, int64_t dst_row_bytes, int slot);
 void set_error(const char* msg);
@@ -179,6 +179,7 @@ int check_write(const avifgpu_write_desc* d, int row0, int nrows, WriteGeom& g)
 }
 
 thread_local const avifgpu_icc_transform* g_icc = nullptr;    // set for the duration of an avifgpu_write_rows_icc call
+thread_local const avifgpu_icc_clut16* g_icc16 = nullptr;   // set for the duration of an avifgpu_write_rows_icc16 call
 thread_local const avifgpu_icc_shaper8* g_icc8 = nullptr;    // set for the duration of an avifgpu_write_rows_icc8 call
 
 // Device copy of the 8-bit shaper tables.  Re-uploaded only when the contents change (one image = one upload); a change
@@ -187,6 +188,27 @@ struct Icc8Device {
     void* dev = nullptr;                  // [3][256] int32 followed by 16388 bytes of shaper2
     std::vector<uint8_t> host;            // contents of `dev`
 } g_icc8_dev;
+
+// The 33^3 table lives in device memory; re-uploaded only when its content changes (one profile per save).
+struct Icc16Dev { void* dev = nullptr; std::vector<uint8_t> host; } g_icc16_dev;
+int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p)
+{
+    if (t->grid_points != AVIFGPU_ICC_CLUT_GRID) return fail(AVIFGPU_formatBadParameters, "16-bit ICC table: grid_points must be 33");
+    const size_t n = sizeof(t->table);
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    if (!g_icc16_dev.dev) {
+        const hipError_t e = hipMalloc(&g_icc16_dev.dev, n);
+        if (e != hipSuccess) return hip_fail(e, "hipMalloc(icc16 table)", AVIFGPU_memFullErr);
+    }
+    if (g_icc16_dev.host.size() != n || memcmp(g_icc16_dev.host.data(), t->table, n) != 0) {
+        hipError_t e = hipDeviceSynchronize();                  // a launch may still be reading the previous table
+        if (e == hipSuccess) e = hipMemcpy(g_icc16_dev.dev, t->table, n, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return hip_fail(e, "upload of the ICC table", AVIFGPU_writErr);
+        g_icc16_dev.host.assign(reinterpret_cast<const uint8_t*>(t->table), reinterpret_cast<const uint8_t*>(t->table) + n);
+    }
+    p.icc16_clut = static_cast<const uint16_t*>(g_icc16_dev.dev);
+    return 0;
+}
 
 int upload_icc8(const avifgpu_icc_shaper8* t, hipStream_t st, WriteParams& p)
 {
@@ -232,6 +254,12 @@ int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const Wr
             p.icc_out = 4;
             for (int k = 0; k < 8; ++k) p.icc_out_p[k] = g_icc->out_params[k];
         }
+    }
+    if (g_icc16) {
+        if (d->depth != 16 || d->planes < 3) return fail(AVIFGPU_formatBadParameters, "the 16-bit ICC table applies to 16-bit RGB(A) documents");
+        if (!g_ctx.ready) return fail(AVIFGPU_formatBadParameters, "avifgpu_init has not succeeded: no HIP device bound (no CPU fallback)");
+        const int rc = upload_icc16(g_icc16, p);
+        if (rc) return rc;
     }
     if (g_icc8) {
         if (d->depth != 8 || d->planes < 3) return fail(AVIFGPU_formatBadParameters, "the 8-bit ICC shaper applies to 8-bit RGB(A) documents");
@@ -561,6 +589,16 @@ int32_t avifgpu_write_rows_icc(const avifgpu_write_desc* d, const avifgpu_icc_tr
     return rc;
 }
 
+int32_t avifgpu_write_rows_icc16(const avifgpu_write_desc* d, const avifgpu_icc_clut16* icc, int32_t row0, int32_t nrows,
+                                 const void* src, int64_t src_row_bytes, void* const dst[4], const int64_t dst_stride[4],
+                                 int32_t mem_kind, void* stream)
+{
+    g_icc16 = icc;
+    const int32_t rc = avifgpu_write_rows(d, row0, nrows, src, src_row_bytes, dst, dst_stride, mem_kind, stream);
+    g_icc16 = nullptr;
+    return rc;
+}
+
 int32_t avifgpu_write_rows_icc8(const avifgpu_write_desc* d, const avifgpu_icc_shaper8* icc, int32_t row0, int32_t nrows,
                                 const void* src, int64_t src_row_bytes, void* const dst[4], const int64_t dst_stride[4],
                                 int32_t mem_kind, void* stream)
@@ -632,13 +670,14 @@ int wait_slot(int slot)
 
 int write_rows_host_enqueue(const avifgpu_write_desc* d, int row0, int nrows, const void* src, int64_t src_row_bytes,
                             void* const dst[4], const int64_t dst_stride[4], int slot, const avifgpu_icc_transform* icc,
-                            const avifgpu_icc_shaper8* icc8)
+                            const avifgpu_icc_shaper8* icc8, const avifgpu_icc_clut16* icc16)
 {
     struct IccScope {                      // fill_write_params picks the transform up from g_icc / g_icc8
-        const avifgpu_icc_transform* saved; const avifgpu_icc_shaper8* saved8;
-        IccScope(const avifgpu_icc_transform* t, const avifgpu_icc_shaper8* t8) : saved(g_icc), saved8(g_icc8) { if (t) g_icc = t; if (t8) g_icc8 = t8; }
-        ~IccScope() { g_icc = saved; g_icc8 = saved8; }
-    } icc_scope(icc, icc8);
+        const avifgpu_icc_transform* saved; const avifgpu_icc_shaper8* saved8; const avifgpu_icc_clut16* saved16;
+        IccScope(const avifgpu_icc_transform* t, const avifgpu_icc_shaper8* t8, const avifgpu_icc_clut16* t16)
+            : saved(g_icc), saved8(g_icc8), saved16(g_icc16) { if (t) g_icc = t; if (t8) g_icc8 = t8; if (t16) g_icc16 = t16; }
+        ~IccScope() { g_icc = saved; g_icc8 = saved8; g_icc16 = saved16; }
+    } icc_scope(icc, icc8, icc16);
     WriteGeom g;
     int err = check_write(d, row0, nrows, g);
     if (err) return err;

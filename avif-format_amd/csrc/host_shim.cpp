@@ -26,7 +26,7 @@ namespace avifgpu {
 int wait_slot(int slot);
 int write_rows_host_enqueue(const avifgpu_write_desc* d, int row0, int nrows, const void* src, int64_t src_row_bytes,
                             void* const dst[4], const int64_t dst_stride[4], int slot, const avifgpu_icc_transform* icc = nullptr,
-                            const avifgpu_icc_shaper8* icc8 = nullptr);
+                            const avifgpu_icc_shaper8* icc8 = nullptr, const avifgpu_icc_clut16* icc16 = nullptr);
 int read_rows_host_enqueue(const avifgpu_read_desc* d, int row0, int nrows, const void* const src[4], const int64_t src_stride[4],
                            void* dst, int64_t dst_row_bytes, int slot);
 void set_error(const char* msg);
@@ -189,6 +189,7 @@ void CreateHeifImageInto(FormatRecordPtr formatRecord, AlphaState alphaState, co
     // ... and for the 8-bit SDR case (document profile -> sRGB, ColorProfileConversion.cpp:134-157): lcms2's own 8-bit
     // matrix-shaper integer pipeline, bit-exact
     std::unique_ptr<avifgpu_icc_shaper8> icc8;
+    std::unique_ptr<avifgpu_icc_clut16> icc16;
     if (saveOptions.convertToSRGB && formatRecord->depth == 32) {
         // 32-bit document saved as SDR (Clip): always converted to sRGB (ColorProfileConversion.cpp:118-123), float pipeline
         if (saveOptions.convertToRec2020 || mono || !formatRecord->iCCprofileData || formatRecord->iCCprofileSize <= 0)
@@ -197,6 +198,12 @@ void CreateHeifImageInto(FormatRecordPtr formatRecord, AlphaState alphaState, co
                                            AVIFGPU_ICC_TARGET_SRGB_FLOAT, &icc);
         if (rc) throw OSErrException((OSErr)rc);
         iccp = &icc;
+    } else if (saveOptions.convertToSRGB && formatRecord->depth == 16) {
+        // 16-bit document: lcms2's resampled 33^3 table + tetrahedral interpolation, bit-exact (include/avifgpu.h)
+        if (mono || !formatRecord->iCCprofileData || formatRecord->iCCprofileSize <= 0) throw OSErrException(AVIFGPU_formatBadParameters);
+        icc16.reset(new avifgpu_icc_clut16);
+        const int rc = avifgpu_icc_prepare_clut16(formatRecord->iCCprofileData, (uint32_t)formatRecord->iCCprofileSize, icc16.get());
+        if (rc) throw OSErrException((OSErr)rc);
     } else if (saveOptions.convertToSRGB) {
         if (formatRecord->depth != 8 || mono || !formatRecord->iCCprofileData || formatRecord->iCCprofileSize <= 0)
             throw OSErrException(AVIFGPU_formatBadParameters);
@@ -235,7 +242,7 @@ void CreateHeifImageInto(FormatRecordPtr formatRecord, AlphaState alphaState, co
             stride[pl] = img->stride[pl];
         }
         const int err = avifgpu::write_rows_host_enqueue(&d, top, bottom - top, formatRecord->data, formatRecord->rowBytes,
-                                                         dst, stride, slot, iccp, icc8.get());
+                                                         dst, stride, slot, iccp, icc8.get(), icc16.get());
         if (err) { (void)avifgpu::wait_slot(0); (void)avifgpu::wait_slot(1); throw OSErrException((OSErr)err); }
     }
     OSErrException::ThrowIfError((OSErr)avifgpu::wait_slot(0));

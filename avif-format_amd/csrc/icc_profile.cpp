@@ -7,6 +7,7 @@
 // (tests/test_gpu_icc.py checks it against the real library).
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -270,6 +271,50 @@ extern "C" int32_t avifgpu_icc_prepare_shaper8(const void* icc_profile, uint32_t
             out->shaper2[c][i] = (uint8_t)(((uint32_t)w * 65281u + 8388608u) >> 24);      // FROM_16_TO_8
         }
     }
+    return 0;
+}
+
+// ---- 16-bit path: lcms2's OptimizeByResampling, restated ---------------------------------------------------------------
+// The pre-optimised float pipeline [document TRC] -> [3x3, double accumulate] -> [inverse sRGB curve] is evaluated at the
+// 33^3 nodes exactly as XFormSampler16 does (node value _cmsQuantizeVal(i, 33) / 65535.0 as float in, float stage outputs,
+// _cmsQuickSaturateWord(out * 65535.0) back) and stored R-major like cmsStageAllocCLut16bit.
+extern "C" int32_t avifgpu_icc_prepare_clut16(const void* icc_profile, uint32_t size, avifgpu_icc_clut16* out)
+{
+    if (!icc_profile || !out || size < 132) return fail(AVIFGPU_formatBadParameters, "bad ICC profile buffer");
+    avifgpu_icc_transform xf;
+    const int rc = avifgpu_icc_prepare(icc_profile, size, AVIFGPU_ICC_TARGET_SRGB_FLOAT, &xf);
+    if (rc) return rc;
+    std::memset(out, 0, sizeof(*out));
+    constexpr int G = AVIFGPU_ICC_CLUT_GRID;
+    out->grid_points = G;
+    uint16_t node[G];
+    float curve_in[3][G];                                       // the curve stage sees only G distinct inputs per channel
+    for (int i = 0; i < G; ++i) {
+        node[i] = quick_saturate_word((double)i * 65535.0 / (double)(G - 1));                 // _cmsQuantizeVal
+        const float in = (float)(node[i] / 65535.0);
+        for (int c = 0; c < 3; ++c) curve_in[c][i] = eval_curve_float(xf.trc_type[c], xf.trc_params[c], in);
+    }
+    const double* P = xf.out_params;
+    for (int r = 0; r < G; ++r) for (int g = 0; g < G; ++g) for (int b = 0; b < G; ++b) {
+        const float t[3] = { curve_in[0][r], curve_in[1][g], curve_in[2][b] };
+        uint16_t* dst = out->table[(r * G + g) * G + b];
+        for (int i = 0; i < 3; ++i) {
+            double acc = 0.0;                                   // EvaluateMatrix: double accumulation, one rounding to float
+            for (int j = 0; j < 3; ++j) acc += (double)t[j] * xf.matrix[3 * i + j];
+            const float m = (float)acc;
+            const float o = eval_curve_float(-4, P, m);        // inverse sRGB curve (type -4), double inside, float out
+            dst[i] = quick_saturate_word((double)o * 65535.0);
+        }
+    }
+    // FixWhiteMisalignment (cmsopt.c): unless the obtained white is wildly off (WhitesAreEqual's 0xf000 guard, evaluated
+    // channel by channel in order), the white node is patched to the exact white of the output space.
+    uint16_t* white = out->table[G * G * G - 1];
+    bool patch = false;
+    for (int i = 0; i < 3; ++i) {
+        if (std::abs((int)white[i] - 0xffff) > 0xf000) break;
+        if (white[i] != 0xffff) { patch = true; break; }
+    }
+    if (patch) white[0] = white[1] = white[2] = 0xffff;
     return 0;
 }
 

@@ -41,6 +41,8 @@ struct WriteParams {
     const uint8_t* icc8_s2;      // [16385] 8-bit output curve (identical for R,G,B: the destination is sRGB)
     int32_t icc8_m[9];
     int32_t icc8_off[3];
+    // 16-bit CLUT transform (avifgpu_icc_clut16): 33^3 nodes x 4 u16 in device memory (L2-resident, 281 KiB)
+    const uint16_t* icc16_clut;
 };
 
 struct ReadParams {

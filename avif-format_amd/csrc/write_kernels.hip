@@ -131,6 +131,62 @@ AG_DEV void icc_apply(const WriteParams& p, float (&c)[3])
     }
 }
 
+// ---- 16-bit ICC stage: lcms2's resampled pipeline (include/avifgpu.h, "16-bit SDR save path") --------------------------------
+// BuildHostToLcmsLookup / BuildLcmsToHostLookup entries (ColorProfileConversion.cpp:37-95), evaluated instead of tabulated.
+AG_DEV uint32_t icc16_host_to_lcms(uint32_t i)
+{
+    const int v = (int)((((float)i / 32768.0f) * 65535.0f) + 0.5f);
+    return (uint32_t)(v < 0 ? 0 : (v > 65535 ? 65535 : v));
+}
+AG_DEV uint32_t icc16_lcms_to_host(uint32_t i)
+{
+    const int v = (int)((((float)i / 65535.0f) * 32768.0f) + 0.5f);
+    return (uint32_t)(v < 0 ? 0 : (v > 32768 ? 32768 : v));
+}
+// lcms2 TetrahedralInterp16 on the 33^3 table: 16.16 fixed-point cell position (_cmsToFixedDomain), the cell's tetrahedron
+// chosen by the order of the three fractions, and the library's rounding  t = Rest + 0x8001; out = c0 + ((t + (t >> 16)) >> 16)
+// in 32-bit two's-complement arithmetic.  in[] are [0, 65535] samples; out[] likewise.
+AG_DEV void icc16_tetrahedral(const uint16_t* __restrict__ clut, const uint32_t (&in)[3], uint32_t (&out)[3])
+{
+    constexpr int G = AVIFGPU_ICC_CLUT_GRID;
+    int f[3], c0i[3], r[3], step[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int a = (int)in[k] * (G - 1);
+        f[k] = a + ((a + 0x7fff) / 0xffff);
+        c0i[k] = f[k] >> 16;
+        r[k] = f[k] & 0xffff;
+    }
+    step[0] = in[0] == 0xffffu ? 0 : G * G;                 // node index strides, in nodes (table is [r][g][b][4])
+    step[1] = in[1] == 0xffffu ? 0 : G;
+    step[2] = in[2] == 0xffffu ? 0 : 1;
+    const int base = (c0i[0] * G + c0i[1]) * G + c0i[2];
+    // order the axes by decreasing fraction exactly as the library's if-tree does (ties included)
+    int a0, a1, a2;
+    if (r[0] >= r[1]) {
+        if (r[1] >= r[2]) { a0 = 0; a1 = 1; a2 = 2; }
+        else if (r[2] >= r[0]) { a0 = 2; a1 = 0; a2 = 1; }
+        else { a0 = 0; a1 = 2; a2 = 1; }
+    } else {
+        if (r[0] >= r[2]) { a0 = 1; a1 = 0; a2 = 2; }
+        else if (r[1] >= r[2]) { a0 = 1; a1 = 2; a2 = 0; }
+        else { a0 = 2; a1 = 1; a2 = 0; }
+    }
+    const int n1 = base + step[a0], n2 = n1 + step[a1], n3 = n2 + step[a2];
+    const uint32_t ra = (uint32_t)r[a0], rb = (uint32_t)r[a1], rc = (uint32_t)r[a2];
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    const u2 v0 = *reinterpret_cast<const u2*>(clut + 4 * base), v1 = *reinterpret_cast<const u2*>(clut + 4 * n1);
+    const u2 v2 = *reinterpret_cast<const u2*>(clut + 4 * n2),   v3 = *reinterpret_cast<const u2*>(clut + 4 * n3);
+    const uint32_t p0[3] = { v0.x & 0xffffu, v0.x >> 16, v0.y & 0xffffu }, p1[3] = { v1.x & 0xffffu, v1.x >> 16, v1.y & 0xffffu };
+    const uint32_t p2[3] = { v2.x & 0xffffu, v2.x >> 16, v2.y & 0xffffu }, p3[3] = { v3.x & 0xffffu, v3.x >> 16, v3.y & 0xffffu };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t rest = (p1[k] - p0[k]) * ra + (p2[k] - p1[k]) * rb + (p3[k] - p2[k]) * rc + 0x8001u;   // wraps like int32
+        const int32_t t = (int32_t)rest;
+        out[k] = (p0[k] + (uint32_t)((t + (t >> 16)) >> 16)) & 0xffffu;
+    }
+}
+
 // ---- stage A: one source pixel -> integer codes (reference WriteHeifImage.cpp inner loops) --------
 // s[] holds the PLANES raw samples (u8/u16 values, or f32 bit patterns).  q[0..NCOL-1] colour, q[3] alpha.
 template <int DEPTH, int PLANES, int TRANSFER, int ICC = 0>
@@ -168,6 +224,17 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
         uint32_t sx[PLANES];
 #pragma unroll
         for (int k = 0; k < PLANES; ++k) sx[k] = s[k];
+        if constexpr (ICC == 5 && DEPTH == 16 && COLOR) {
+            // ConvertRow for 16-bit rows (ColorProfileConversion.cpp:159-187): range map, lcms2 transform, range map back --
+            // all PLANES samples take the two maps, the three colours also the table
+#pragma unroll
+            for (int k = 0; k < PLANES; ++k) sx[k] = icc16_host_to_lcms(sx[k] > 32768u ? 32768u : sx[k]);
+            uint32_t cin[3] = { sx[0], sx[1], sx[2] }, cout[3];
+            icc16_tetrahedral(p.icc16_clut, cin, cout);
+            sx[0] = cout[0]; sx[1] = cout[1]; sx[2] = cout[2];
+#pragma unroll
+            for (int k = 0; k < PLANES; ++k) sx[k] = icc16_lcms_to_host(sx[k]);
+        }
         if constexpr (ICC == 3 && DEPTH == 8 && COLOR) {
             // lcms2's 8-bit matrix-shaper evaluation (MatShaperEval16), bit for bit: 1.14 fixed-point tables and matrix
             const int r = icc8_lds_s1[sx[0]], g = icc8_lds_s1[256 + sx[1]], b = icc8_lds_s1[512 + sx[2]];
@@ -606,6 +673,15 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, const char** 
             const int blocks = grid_for(groups) > 2048 ? 2048 : grid_for(groups);     // tables are copied per block
             if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 3>), dim3(blocks), dim3(256), 0, st, p);
             else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 3>), dim3(blocks), dim3(256), 0, st, p);
+            return hipGetLastError();
+        }
+    }
+    if constexpr (DEPTH == 16 && PLANES >= 3) {
+        if (p.icc16_clut != nullptr) {              // 16-bit CLUT ICC transform requested
+            snprintf(label, sizeof(label), "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=5>",
+                     DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned);
+            if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 5>), dim3(grid_for(groups)), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 5>), dim3(grid_for(groups)), dim3(256), 0, st, p);
             return hipGetLastError();
         }
     }

@@ -337,6 +337,32 @@ void avifgpu_set_hot_variant(int32_t variant);
 /* Name + last launch geometry of the kernel the previous *_rows call dispatched (for bench/profiles). */
 const char* avifgpu_last_kernel_name(void);
 
+/* ---- ICC row transform of the 16-bit SDR save path ------------------------------------------------------------------
+ * 16-bit rows of a non-sRGB document go through lcms2 as TYPE_RGB[A]_16 between two range maps ([0, 32768] <-> [0, 65535],
+ * ColorProfileConversion.cpp:37-95,:159-187,:268-331).  For 16-bit data lcms2 does not run the matrix/curve pipeline per
+ * pixel: at transform creation it resamples it into a 33 x 33 x 33 table of 16-bit RGB nodes (float pipeline evaluated at
+ * the nodes) and then interpolates that table tetrahedrally in 16.16 fixed point.  Both halves are reproduced: the table is
+ * built on the host from the profile bytes, the interpolation (integer arithmetic) runs in the write kernel; the result is
+ * bit-identical to lcms2 2.12 (tests/test_icc16.py). */
+enum { AVIFGPU_ICC_CLUT_GRID = 33 };
+typedef struct avifgpu_icc_clut16 {
+    int32_t  grid_points;                                   /* 33 */
+    int32_t  reserved[3];
+    uint16_t table[AVIFGPU_ICC_CLUT_GRID * AVIFGPU_ICC_CLUT_GRID * AVIFGPU_ICC_CLUT_GRID][4];   /* [r][g][b] -> R, G, B, 0 */
+} avifgpu_icc_clut16;
+
+/* Build the table for document profile -> sRGB.  Matrix/TRC RGB profiles with `para` curves or `curv` gammas
+ * (AVIFGPU_formatCannotRead otherwise: the caller keeps lcms2). */
+int32_t avifgpu_icc_prepare_clut16(const void* icc_profile, uint32_t size, avifgpu_icc_clut16* out);
+
+/* avifgpu_write_rows for 16-bit RGB(A) documents with that transform applied first; alpha takes the reference's
+ * [0,32768] -> [0,65535] -> [0,32768] round trip (cmsFLAGS_COPY_ALPHA in between). */
+int32_t avifgpu_write_rows_icc16(const avifgpu_write_desc* desc, const avifgpu_icc_clut16* icc,
+                                 int32_t row0, int32_t nrows,
+                                 const void* src, int64_t src_row_bytes,
+                                 void* const dst[4], const int64_t dst_stride[4],
+                                 int32_t mem_kind, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,7 +87,7 @@ typedef struct avifgpu_SaveUIOptions {
      * 8-bit constructor installs a transform (ColorProfileConversion.cpp:134-157: profile present, keepColorProfile off,
      * !IsSRGBColorProfile) -- lcms2's 8-bit matrix-shaper pipeline, bit-exact.  depth 32 with transfer Clip: the SDR save
      * of a 32-bit document, always converted (:118-123) -- lcms2's float pipeline.  formatCannotRead for profiles that are
-     * not matrix/TRC; depth 16 is not offered (lcms2 resamples that case into a 3-D CLUT). */
+     * not matrix/TRC.  depth 16: lcms2's resampled 33^3 table + tetrahedral interpolation, bit-exact. */
     uint8_t convertToSRGB;
 } avifgpu_SaveUIOptions;
 typedef struct avifgpu_LoadUIOptions {

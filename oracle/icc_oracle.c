@@ -267,3 +267,48 @@ int32_t oracle_icc_make_profile_ex(int32_t kind, double gamma, const char* descr
     cmsCloseProfile(h);
     return rc;
 }
+
+/* 16-bit documents, keepColorProfile off: ColorProfileConversion ctor (ColorProfileConversion.cpp:134-157) +
+ * InitializeForSRGBConversion (:268-331) with hostBitsPerChannel == 16 (TYPE_RGB[A]_16) + ConvertRow (:159-187): every row
+ * is mapped from Photoshop's [0, 32768] to [0, 65535] (BuildHostToLcmsLookup, :37-65 -- alpha included), transformed in
+ * place, and mapped back (BuildLcmsToHostLookup, :67-95). */
+static uint16_t host_to_lcms(uint16_t i)
+{
+    int v = (int)((((float)i / 32768.0f) * 65535.0f) + 0.5f);
+    return (uint16_t)(v < 0 ? 0 : (v > 65535 ? 65535 : v));
+}
+static uint16_t lcms_to_host(uint16_t i)
+{
+    int v = (int)((((float)i / 65535.0f) * 32768.0f) + 0.5f);
+    return (uint16_t)(v < 0 ? 0 : (v > 32768 ? 32768 : v));
+}
+/* raw != 0: plain lcms2 16-bit transform on [0, 65535] data (used to pin the CLUT restatement); raw == 0: the reference flow.
+ * Samples above 32768 are outside Photoshop's range (the reference would index past its table): callers do not pass them. */
+int32_t oracle_icc_convert_rows_to_srgb16(const void* icc, uint32_t icc_size, int32_t has_alpha, int32_t raw,
+                                          void* rows, uint32_t width, uint32_t nrows, uint32_t row_bytes)
+{
+    cmsContext ctx = cmsCreateContext(NULL, NULL);
+    cmsHPROFILE doc = cmsOpenProfileFromMemTHR(ctx, icc, icc_size);
+    cmsHPROFILE out = cmsCreate_sRGBProfileTHR(ctx);
+    int32_t rc = -1;
+    if (doc && out) {
+        cmsUInt32Number fmt = TYPE_RGB_16, flags = cmsFLAGS_BLACKPOINTCOMPENSATION;
+        if (has_alpha) { fmt = TYPE_RGBA_16; flags |= cmsFLAGS_COPY_ALPHA; }
+        cmsHTRANSFORM t = cmsCreateTransformTHR(ctx, doc, fmt, out, fmt, INTENT_PERCEPTUAL, flags);
+        if (t) {
+            const uint32_t n = width * (has_alpha ? 4u : 3u);
+            for (uint32_t y = 0; y < nrows; ++y) {
+                uint16_t* row = (uint16_t*)((uint8_t*)rows + (size_t)y * row_bytes);
+                if (!raw) for (uint32_t i = 0; i < n; ++i) row[i] = host_to_lcms(row[i]);
+                cmsDoTransformLineStride(t, row, row, width, 1, row_bytes, row_bytes, 0, 0);
+                if (!raw) for (uint32_t i = 0; i < n; ++i) row[i] = lcms_to_host(row[i]);
+            }
+            cmsDeleteTransform(t);
+            rc = 0;
+        }
+    }
+    if (doc) cmsCloseProfile(doc);
+    if (out) cmsCloseProfile(out);
+    cmsDeleteContext(ctx);
+    return rc;
+}

@@ -1,0 +1,190 @@
+"""16-bit SDR save path, ICC stage: lcms2's 16-bit transform of a matrix/TRC document profile to sRGB is a
+33^3 table resampled from the float pipeline + tetrahedral interpolation in 16.16 fixed point, wrapped by the reference in two
+range maps ([0,32768] <-> [0,65535], ColorProfileConversion.cpp:37-95,:159-187,:268-331).  Checker: the real Little CMS 2
+driven like the reference (oracle/icc_oracle.c).  Bar: bit-exact.
+
+CPU part: the host-built table (avifgpu_icc_prepare_clut16) + a numpy restatement of the interpolation against lcms2's raw
+TYPE_RGB_16 transform.  GPU part: the fused kernel against the whole reference flow."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import harness
+
+pkg = harness.pkg
+ICC_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "liboracle_icc.so")
+PROFILES = [("adobergb-g2.2", 3, 0, 2.19921875), ("p3-srgb-trc", 1, 1, 0.0), ("prophoto-d50-g1.8", 2, 0, 1.8),
+            ("p3-para-g1.8", 1, 2, 1.8), ("rec2020-g2.4", 4, 0, 2.4)]
+
+
+@pytest.fixture(scope="module")
+def lcms():
+    if not os.path.exists(ICC_LIB):
+        pytest.skip("oracle/liboracle_icc.so not built (lcms2 absent)")
+    L = ctypes.CDLL(ICC_LIB)
+    L.oracle_icc_make_profile.restype = ctypes.c_int32
+    L.oracle_icc_make_profile.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_double, ctypes.c_void_p, ctypes.c_uint32]
+    L.oracle_icc_convert_rows_to_srgb16.restype = ctypes.c_int32
+    L.oracle_icc_convert_rows_to_srgb16.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+                                                     ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+    return L
+
+
+def _profile(L, kind, trc, g):
+    buf = ctypes.create_string_buffer(1 << 18)
+    n = L.oracle_icc_make_profile(kind, trc, g, buf, len(buf))
+    assert n > 0
+    return buf.raw[:n]
+
+
+def _clut(icc):
+    t = pkg.IccClut16()
+    rc = pkg.load().avifgpu_icc_prepare_clut16(icc, len(icc), ctypes.byref(t))
+    assert rc == 0, pkg.load().avifgpu_last_error()
+    return t
+
+
+def _tetrahedral(table, inp):
+    """TetrahedralInterp16 on int64 (the true sums fit int32 for these tables, so no wrap is needed here)."""
+    G = 33
+    inp = inp.astype(np.int64)
+    a = inp * (G - 1)
+    f = a + (a + 0x7fff) // 0xffff
+    c0, r = f >> 16, f & 0xffff
+    c1 = np.where(inp == 0xffff, c0, c0 + 1)
+    rx, ry, rz = r[:, 0], r[:, 1], r[:, 2]
+    conds = [(rx >= ry) & (ry >= rz), (rx >= ry) & (ry < rz) & (rz >= rx), (rx >= ry) & (ry < rz) & (rz < rx),
+             (rx < ry) & (rx >= rz), (rx < ry) & (rx < rz) & (ry >= rz), (rx < ry) & (rx < rz) & (ry < rz)]
+    orders = [(0, 1, 2), (2, 0, 1), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 1, 0)]
+    base = table[c0[:, 0], c0[:, 1], c0[:, 2]].astype(np.int64)
+    out = np.zeros_like(base)
+    for cond, order in zip(conds, orders):
+        pos = [c0[:, 0], c0[:, 1], c0[:, 2]]
+        prev, rest = base, np.zeros_like(base)
+        for ax in order:
+            pos = list(pos); pos[ax] = c1[:, ax]
+            v = table[pos[0], pos[1], pos[2]].astype(np.int64)
+            rest = rest + (v - prev) * r[:, ax][:, None]
+            prev = v
+        t = rest + 0x8001
+        o = (base + ((t + (t >> 16)) >> 16)) & 0xffff
+        out[cond] = o[cond]
+    return out
+
+
+def _samples(n, hi, seed):
+    rng = np.random.default_rng(seed)
+    s = rng.integers(0, hi + 1, size=(n, 3))
+    edge = np.array([0, 1, hi - 1, hi, hi // 2, hi // 32, hi // 32 + 1])
+    s[:4000] = rng.choice(edge, size=(4000, 3))
+    g = rng.integers(0, hi + 1, size=2000)
+    s[4000:6000] = g[:, None]                                  # neutrals: all three fractions tie
+    return s
+
+
+@pytest.mark.parametrize("name,kind,trc,g", PROFILES[:3])
+def test_table_and_interpolation_reproduce_lcms2(lcms, name, kind, trc, g):
+    icc = _profile(lcms, kind, trc, g)
+    t = _clut(icc)
+    assert t.grid_points == 33
+    table = np.ctypeslib.as_array(t.table).reshape(33, 33, 33, 4)
+    assert not table[..., 3].any()
+    inp = _samples(300000, 65535, 7).astype(np.uint16)
+    want = inp.copy()
+    assert lcms.oracle_icc_convert_rows_to_srgb16(icc, len(icc), 0, 1, want.ctypes.data, len(inp), 1, len(inp) * 6) == 0
+    got = _tetrahedral(table[..., :3], inp)
+    assert np.array_equal(got, want.astype(np.int64)), name
+
+
+def test_prepare_clut16_rejects_what_it_cannot_do(lcms):
+    t = pkg.IccClut16()
+    assert pkg.load().avifgpu_icc_prepare_clut16(bytes(300), 300, ctypes.byref(t)) == pkg.formatCannotRead
+    sampled = _profile(lcms, 1, 3, 1024)                       # sampled curv table: float-pipeline restatement not built
+    assert pkg.load().avifgpu_icc_prepare_clut16(sampled, len(sampled), ctypes.byref(t)) == pkg.formatCannotRead
+
+
+def _gpu(gpu, d, src, icc16):
+    import torch
+    dev = f"cuda:{gpu.device}"
+    bufs = harness._alloc_write_out(d, d.height)
+    d_src = torch.from_numpy(src.view(np.uint8).reshape(-1)).to(dev)
+    d_out = {pl: torch.from_numpy(b.view(np.uint8).reshape(-1).copy()).to(dev) for pl, b in bufs.items()}
+    ptrs = [d_out[i].data_ptr() if i in d_out else None for i in range(4)]
+    strides = [bufs[i].strides[0] if i in bufs else 0 for i in range(4)]
+    gpu.write_rows(d, 0, d.height, d_src.data_ptr(), src.strides[0], ptrs, strides, mem=pkg.MEM_DEVICE,
+                   stream=torch.cuda.current_stream(dev).cuda_stream, icc=icc16)
+    torch.cuda.synchronize(dev)
+    for pl in bufs:
+        bufs[pl] = d_out[pl].cpu().numpy().view(bufs[pl].dtype).reshape(bufs[pl].shape)
+    return harness._trim(d, bufs, d.height, harness.write_planes)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kind,trc,g", PROFILES)
+def test_gpu_16bit_rows_bit_exact(gpu, lcms, name, kind, trc, g):
+    """4 M pixels over Photoshop's whole 16-bit range (edges, neutrals, random): fused ICC + 12-bit rescale == range map,
+    lcms2, range map back, then the pixel loop."""
+    icc = _profile(lcms, kind, trc, g)
+    clut = gpu.icc_prepare_clut16(icc)
+    w, h = 2048, 2048
+    src = _samples(w * h, 32768, 11).astype(np.uint16).reshape(h, w * 3).copy()
+    conv = src.copy()
+    assert lcms.oracle_icc_convert_rows_to_srgb16(icc, len(icc), 0, 0, conv.ctypes.data, w, h, conv.strides[0]) == 0
+    d = pkg.WriteDesc(width=w, height=h, depth=16, planes=3, bit_depth=12, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_REFERENCE)
+    want = harness.oracle_write(d, conv)
+    got = _gpu(gpu, d, src, clut)
+    assert np.array_equal(got[0], want[0]), name
+    assert "icc=5" in gpu.last_kernel()
+
+
+@pytest.mark.gpu
+def test_gpu_icc16_then_every_output_kind(gpu, lcms):
+    """RGBA (alpha takes the two range maps), premultiply, 8/10-bit rescale, fused YCbCr 4:2:0 / 4:2:2, ragged size."""
+    icc = _profile(lcms, 2, 0, 1.8)
+    clut = gpu.icc_prepare_clut16(icc)
+    for kw in (dict(planes=4, bit_depth=8, alpha_state=pkg.ALPHA_PREMULTIPLIED, output=pkg.OUT_REFERENCE),
+               dict(planes=4, bit_depth=10, alpha_state=pkg.ALPHA_STRAIGHT, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420,
+                    matrix_coefficients=pkg.MATRIX_BT601),
+               dict(planes=3, bit_depth=12, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_422,
+                    matrix_coefficients=pkg.MATRIX_BT601),
+               dict(planes=3, bit_depth=8, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444,
+                    matrix_coefficients=pkg.MATRIX_BT601)):
+        d = pkg.WriteDesc(width=333, height=41, depth=16, **kw)
+        src = harness.make_write_source(d, seed=23)
+        src = np.minimum(src, 32768)                           # Photoshop's range (the reference indexes its table with the sample)
+        conv = src.copy()
+        assert lcms.oracle_icc_convert_rows_to_srgb16(icc, len(icc), int(d.planes == 4), 0, conv.ctypes.data, d.width, d.height,
+                                                      conv.strides[0]) == 0
+        want = harness.oracle_write(d, conv)
+        got = _gpu(gpu, d, src, clut)
+        for pl in want:
+            assert np.array_equal(got[pl], want[pl]), (kw, pl)
+
+
+@pytest.mark.gpu
+def test_host_shim_converts_16bit_document_to_srgb(gpu, lcms):
+    from fake_host import FakeHost
+    H = pkg.host
+    icc = _profile(lcms, 3, 0, 2.19921875)
+    d = pkg.WriteDesc(width=517, height=67, depth=16, planes=3, bit_depth=10, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_REFERENCE)
+    src = np.minimum(harness.make_write_source(d, seed=5), 32768)
+    conv = src.copy()
+    assert lcms.oracle_icc_convert_rows_to_srgb16(icc, len(icc), 0, 0, conv.ctypes.data, d.width, d.height, conv.strides[0]) == 0
+    want = harness.oracle_write(d, conv)
+    host = FakeHost(d.width, d.height, 16, 3, max_data=517 * 6 * 10, image=src)
+    keep = ctypes.create_string_buffer(icc, len(icc))
+    host.fr.iCCprofileData = ctypes.cast(keep, ctypes.c_void_p)
+    host.fr.iCCprofileSize = len(icc)
+    opts = H.SaveUIOptions(imageBitDepth=10, hdrTransferFunction=pkg.TRANSFER_CLIP, pq=H.PQOptions(1000),
+                           chromaSubsampling=pkg.CHROMA_420, lossless=0, convertToRec2020=0, convertToSRGB=1)
+    img = H.Image()
+    code = gpu.lib.avifgpu_host_create_heif_image(ctypes.byref(host.fr), pkg.ALPHA_NONE, ctypes.byref(opts), pkg.OUT_REFERENCE,
+                                                  pkg.MATRIX_BT601, pkg.PRIMARIES_BT709, ctypes.byref(img))
+    assert code == 0, gpu.lib.avifgpu_last_error()
+    assert len(host.rects) > 3
+    raw = (ctypes.c_uint8 * (img.stride[0] * d.height)).from_address(img.plane[0])
+    got = np.frombuffer(raw, dtype=np.uint8).reshape(d.height, img.stride[0])[:, :d.width * 6].view(np.uint16)
+    assert np.array_equal(got, want[0])
+    gpu.lib.avifgpu_image_free(ctypes.byref(img))
