@@ -195,7 +195,17 @@ int parse_matrix_trc(const uint8_t* icc, uint32_t size, M3& src, Trc trc[3]);
 
 } // namespace
 
+namespace {
+int prepare_float_pipeline(const void* icc_profile, uint32_t size, int32_t target, avifgpu_icc_transform* out, Trc trc[3], bool tables_ok);
+}
 extern "C" int32_t avifgpu_icc_prepare(const void* icc_profile, uint32_t size, int32_t target, avifgpu_icc_transform* out)
+{
+    Trc trc[3];
+    return prepare_float_pipeline(icc_profile, size, target, out, trc, false);
+}
+namespace {
+// Shared by the 32-bit slice (parametric curves only: they travel in the struct) and the 16-bit table builder (any curve).
+int prepare_float_pipeline(const void* icc_profile, uint32_t size, int32_t target, avifgpu_icc_transform* out, Trc trc[3], bool tables_ok)
 {
     if (!icc_profile || !out || size < 132) return fail(AVIFGPU_formatBadParameters, "bad ICC profile buffer");
     if (target != AVIFGPU_ICC_TARGET_REC2020_LINEAR && target != AVIFGPU_ICC_TARGET_SRGB_FLOAT)
@@ -203,13 +213,12 @@ extern "C" int32_t avifgpu_icc_prepare(const void* icc_profile, uint32_t size, i
     const uint8_t* icc = static_cast<const uint8_t*>(icc_profile);
     std::memset(out, 0, sizeof(*out));
     M3 src;
-    Trc trc[3];
     int rc = parse_matrix_trc(icc, size, src, trc);
     if (rc) return rc;
     for (int c = 0; c < 3; ++c) {
         // Photoshop's 32-bit documents carry the linear variant of their profile (`curv` count 1, gamma 1.0); a sampled
-        // table on the float path would be quantised to 16 bits by lcms2 -- not reproduced here, the caller keeps lcms2.
-        if (trc[c].type == 0) return fail(AVIFGPU_formatCannotRead, "sampled TRC tables on the 32-bit path are evaluated by lcms2 only: keep the lcms2 path");
+        // table on the float path would be quantised to 16 bits by lcms2 -- not reproduced in the kernel, the caller keeps lcms2.
+        if (trc[c].type == 0 && !tables_ok) return fail(AVIFGPU_formatCannotRead, "sampled TRC tables on the 32-bit path are evaluated by lcms2 only: keep the lcms2 path");
         out->trc_type[c] = trc[c].type;
         for (int k = 0; k < 7; ++k) out->trc_params[c][k] = trc[c].P[k];
     }
@@ -236,6 +245,7 @@ extern "C" int32_t avifgpu_icc_prepare(const void* icc_profile, uint32_t size, i
     }
     return 0;
 }
+} // namespace
 
 extern "C" int32_t avifgpu_icc_prepare_shaper8(const void* icc_profile, uint32_t size, avifgpu_icc_shaper8* out)
 {
@@ -282,7 +292,8 @@ extern "C" int32_t avifgpu_icc_prepare_clut16(const void* icc_profile, uint32_t 
 {
     if (!icc_profile || !out || size < 132) return fail(AVIFGPU_formatBadParameters, "bad ICC profile buffer");
     avifgpu_icc_transform xf;
-    const int rc = avifgpu_icc_prepare(icc_profile, size, AVIFGPU_ICC_TARGET_SRGB_FLOAT, &xf);
+    Trc trc[3];                                                 // sampled `curv` tables included (cmsEvalToneCurveFloat's 16-bit path)
+    const int rc = prepare_float_pipeline(icc_profile, size, AVIFGPU_ICC_TARGET_SRGB_FLOAT, &xf, trc, true);
     if (rc) return rc;
     std::memset(out, 0, sizeof(*out));
     constexpr int G = AVIFGPU_ICC_CLUT_GRID;
@@ -292,7 +303,7 @@ extern "C" int32_t avifgpu_icc_prepare_clut16(const void* icc_profile, uint32_t 
     for (int i = 0; i < G; ++i) {
         node[i] = quick_saturate_word((double)i * 65535.0 / (double)(G - 1));                 // _cmsQuantizeVal
         const float in = (float)(node[i] / 65535.0);
-        for (int c = 0; c < 3; ++c) curve_in[c][i] = eval_curve_float(xf.trc_type[c], xf.trc_params[c], in);
+        for (int c = 0; c < 3; ++c) curve_in[c][i] = eval_curve_float(trc[c], in);
     }
     const double* P = xf.out_params;
     for (int r = 0; r < G; ++r) for (int g = 0; g < G; ++g) for (int b = 0; b < G; ++b) {

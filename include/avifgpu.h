@@ -351,8 +351,8 @@ typedef struct avifgpu_icc_clut16 {
     uint16_t table[AVIFGPU_ICC_CLUT_GRID * AVIFGPU_ICC_CLUT_GRID * AVIFGPU_ICC_CLUT_GRID][4];   /* [r][g][b] -> R, G, B, 0 */
 } avifgpu_icc_clut16;
 
-/* Build the table for document profile -> sRGB.  Matrix/TRC RGB profiles with `para` curves or `curv` gammas
- * (AVIFGPU_formatCannotRead otherwise: the caller keeps lcms2). */
+/* Build the table for document profile -> sRGB.  Matrix/TRC RGB profiles with `para` curves, `curv` gammas or sampled
+ * `curv` tables (AVIFGPU_formatCannotRead otherwise: the caller keeps lcms2). */
 int32_t avifgpu_icc_prepare_clut16(const void* icc_profile, uint32_t size, avifgpu_icc_clut16* out);
 
 /* avifgpu_write_rows for 16-bit RGB(A) documents with that transform applied first; alpha takes the reference's

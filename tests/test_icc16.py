@@ -16,7 +16,8 @@ import harness
 pkg = harness.pkg
 ICC_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "liboracle_icc.so")
 PROFILES = [("adobergb-g2.2", 3, 0, 2.19921875), ("p3-srgb-trc", 1, 1, 0.0), ("prophoto-d50-g1.8", 2, 0, 1.8),
-            ("p3-para-g1.8", 1, 2, 1.8), ("rec2020-g2.4", 4, 0, 2.4)]
+            ("p3-para-g1.8", 1, 2, 1.8), ("rec2020-g2.4", 4, 0, 2.4),
+            ("p3-sampled-srgb-1024", 1, 3, 1024), ("adobergb-sampled-per-channel-256", 3, 4, 256)]
 
 
 @pytest.fixture(scope="module")
@@ -84,7 +85,7 @@ def _samples(n, hi, seed):
     return s
 
 
-@pytest.mark.parametrize("name,kind,trc,g", PROFILES[:3])
+@pytest.mark.parametrize("name,kind,trc,g", PROFILES[:3] + PROFILES[5:])
 def test_table_and_interpolation_reproduce_lcms2(lcms, name, kind, trc, g):
     icc = _profile(lcms, kind, trc, g)
     t = _clut(icc)
@@ -101,8 +102,9 @@ def test_table_and_interpolation_reproduce_lcms2(lcms, name, kind, trc, g):
 def test_prepare_clut16_rejects_what_it_cannot_do(lcms):
     t = pkg.IccClut16()
     assert pkg.load().avifgpu_icc_prepare_clut16(bytes(300), 300, ctypes.byref(t)) == pkg.formatCannotRead
-    sampled = _profile(lcms, 1, 3, 1024)                       # sampled curv table: float-pipeline restatement not built
-    assert pkg.load().avifgpu_icc_prepare_clut16(sampled, len(sampled), ctypes.byref(t)) == pkg.formatCannotRead
+    sampled = _profile(lcms, 1, 3, 1024)                       # sampled curv table: fine here, not on the 32-bit path
+    assert pkg.load().avifgpu_icc_prepare_clut16(sampled, len(sampled), ctypes.byref(t)) == 0
+    assert pkg.load().avifgpu_icc_prepare(sampled, len(sampled), pkg.ICC_TARGET_SRGB_FLOAT, ctypes.byref(pkg.IccTransform())) == pkg.formatCannotRead
 
 
 def _gpu(gpu, d, src, icc16):
