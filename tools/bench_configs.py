@@ -20,15 +20,21 @@ gpu = pkg.AvifGpu(0)
 stream = torch.cuda.Stream(dev)
 
 
-def time_launch(fn, iters=60, warm=150):   # warm: clock ramp of an idle MI355X takes ~50 ms
+def time_launch(fn, iters=60, warm=150, batch=10):   # warm: clock ramp of an idle MI355X takes ~50 ms
+    """Mean / median ms per launch.  Launches are timed in back-to-back batches between one pair of HIP events (as bench.py
+    does): an event pair around every single launch adds ~5 us of record/launch gap, which is 10-25 % of the small kernels
+    (kernel-trace durations in profiles/r01/configs_traffic.json are the cross-check)."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize(dev)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters // batch)]
     for a, b in evs:
-        a.record(stream); fn(); b.record(stream)
+        a.record(stream)
+        for _ in range(batch):
+            fn()
+        b.record(stream)
     torch.cuda.synchronize(dev)
-    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    ts = sorted(a.elapsed_time(b) / batch for a, b in evs)
     return sum(ts) / len(ts), ts[len(ts) // 2]
 
 
