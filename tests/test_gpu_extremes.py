@@ -1,0 +1,42 @@
+"""Extreme geometries (Photoshop's PSB limit is 300,000 pixels per side; FormatRecord carries 32-bit coordinates,
+AvifFormat.cpp:113-116): very wide and very tall frames against the oracle, both directions, plus a 1-pixel frame.
+Index arithmetic (64-bit row offsets, 32-bit group indices, grid-stride launch) is what these exercise."""
+import numpy as np
+import pytest
+
+import harness
+
+pkg = harness.pkg
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(300000, 6), (7, 300000), (299999, 3), (1, 1), (2, 1), (1, 2), (65537, 33)]
+
+
+@pytest.mark.parametrize("w,h", SHAPES)
+def test_write_extreme_shapes(gpu, w, h):
+    for kw in (dict(depth=8, planes=3, bit_depth=8, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420, matrix_coefficients=pkg.MATRIX_BT709),
+               dict(depth=16, planes=4, bit_depth=12, alpha_state=pkg.ALPHA_PREMULTIPLIED, output=pkg.OUT_REFERENCE),
+               dict(depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_PQ, peak_nits=1000, output=pkg.OUT_YCBCR,
+                    chroma=pkg.CHROMA_422, matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020)):
+        d = pkg.WriteDesc(width=w, height=h, **kw)
+        src = harness.make_write_source(d, seed=w % 97)
+        want = harness.oracle_write(d, src)
+        got = harness.gpu_write(gpu, d, src, mem="device")
+        st = harness.compare_write(d, want, got)
+        if d.depth == 32:
+            assert st["max_abs"] <= 1 and (st["n"] < 1000 or st["exact_frac"] >= 0.99), (w, h, st)
+        else:
+            assert st["max_abs"] == 0, (w, h, kw, st)
+
+
+@pytest.mark.parametrize("w,h", SHAPES)
+def test_read_extreme_shapes(gpu, w, h):
+    for kw in (dict(colorspace=pkg.COLORSPACE_YCBCR, chroma=pkg.CHROMA_420, bit_depth=8, depth=8, alpha_state=pkg.ALPHA_NONE),
+               dict(colorspace=pkg.COLORSPACE_YCBCR, chroma=pkg.CHROMA_422, bit_depth=12, depth=16, alpha_state=pkg.ALPHA_PREMULTIPLIED,
+                    matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020),
+               dict(colorspace=pkg.COLORSPACE_MONOCHROME, chroma=pkg.CHROMA_MONOCHROME, bit_depth=10, depth=16, alpha_state=pkg.ALPHA_STRAIGHT)):
+        d = pkg.ReadDesc(width=w, height=h, **kw)
+        planes = harness.make_read_source(d, seed=h % 89)
+        want = harness.oracle_read(d, planes)
+        got = harness.gpu_read(gpu, d, planes, mem="device")
+        assert np.array_equal(got, want), (w, h, kw)
