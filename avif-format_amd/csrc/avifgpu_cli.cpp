@@ -160,8 +160,17 @@ int do_write(const Args& a)
     avifgpu_SaveUIOptions o{};
     o.imageBitDepth = a.bits; o.hdrTransferFunction = a.transfer; o.pq.nominalPeakBrightness = a.peak;
     o.chromaSubsampling = a.chroma; o.lossless = (uint8_t)a.lossless;
-    o.convertToRec2020 = !a.icc.empty() && a.depth == 32;      // the CLI user asserts the profile is not Rec.2020 / sRGB already
-    o.convertToSRGB = !a.icc.empty() && a.depth == 8;
+    if (!a.icc.empty()) {
+        // the plug-in's own gate (ColorProfileConversion.cpp:107-131,:143-156): HDR saves convert to Rec.2020 unless the
+        // document already is Rec.2020; everything else converts to sRGB unless it already is sRGB (32-bit Clip: always)
+        const int32_t is = avifgpu_icc_detect(profile.data(), (uint32_t)profile.size());
+        if (is < 0) return fail("avifgpu_icc_detect", is);
+        const bool hdr = a.depth == 32 && a.transfer != AVIFGPU_TRANSFER_CLIP;
+        o.convertToRec2020 = hdr && !(is & AVIFGPU_ICC_IS_REC2020);
+        o.convertToSRGB = !hdr && (a.depth == 32 || !(is & AVIFGPU_ICC_IS_SRGB));
+        fprintf(stderr, "icc: document profile is%s Rec.2020,%s sRGB -> %s\n", (is & AVIFGPU_ICC_IS_REC2020) ? "" : " not",
+                (is & AVIFGPU_ICC_IS_SRGB) ? "" : " not", o.convertToRec2020 ? "convert to Rec.2020" : o.convertToSRGB ? "convert to sRGB" : "no conversion");
+    }
     avifgpu_image img{};
     const int rc = avifgpu_host_create_heif_image(&g_host.fr, a.alpha, &o, a.output, a.lossless ? AVIFGPU_MATRIX_RGB_GBR : a.matrix,
                                                   a.primaries, &img);

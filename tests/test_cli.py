@@ -114,3 +114,37 @@ def test_cli_read_matches_oracle(tmp_path, depth, bits, cs, chroma, alpha, extra
         np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-9)
     else:
         assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_cli_write_with_document_profile(tmp_path):
+    """--icc: the CLI applies the plug-in's gate (avifgpu_icc_detect) and converts a 16-bit AdobeRGB document to sRGB on the way;
+    result == lcms2 driven like the reference, then the pixel loop (bit-exact).  An sRGB-tagged document is left alone."""
+    import ctypes
+    icc_lib = os.path.join(os.path.dirname(CLI), "..", "oracle", "liboracle_icc.so")
+    if not os.path.exists(icc_lib):
+        pytest.skip("lcms2 oracle not built")
+    L = ctypes.CDLL(icc_lib)
+    L.oracle_icc_make_profile_ex.restype = ctypes.c_int32
+    L.oracle_icc_make_profile_ex.argtypes = [ctypes.c_int32, ctypes.c_double, ctypes.c_char_p, ctypes.c_double, ctypes.c_int32,
+                                             ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_uint32]
+    L.oracle_icc_convert_rows_to_srgb16.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+                                                     ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+    d = pkg.WriteDesc(width=301, height=58, depth=16, planes=3, bit_depth=10, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_REFERENCE)
+    src = np.minimum(harness.make_write_source(d, seed=3), 32768)
+    (tmp_path / "in.raw").write_bytes(src.tobytes())
+    for desc, expect_convert in ((b"Adobe RGB (1998)", True), (b"sRGB look-alike", False)):
+        buf = ctypes.create_string_buffer(1 << 14)
+        n = L.oracle_icc_make_profile_ex(3, 2.19921875, desc, 0.0, -1, 0, 0, buf, len(buf))
+        icc = buf.raw[:n]
+        (tmp_path / "doc.icc").write_bytes(icc)
+        conv = src.copy()
+        if expect_convert:
+            assert L.oracle_icc_convert_rows_to_srgb16(icc, len(icc), 0, 0, conv.ctypes.data, d.width, d.height, conv.strides[0]) == 0
+        want = harness.oracle_write(d, conv)
+        r = _run("write", "--width", d.width, "--height", d.height, "--depth", 16, "--planes", 3, "--bits", 10,
+                 "--icc", tmp_path / "doc.icc", tmp_path / "in.raw", tmp_path / "out.planes")
+        assert r.returncode == 0, r.stderr
+        assert ("convert to sRGB" in r.stderr) == expect_convert, r.stderr
+        got = np.frombuffer((tmp_path / "out.planes").read_bytes(), dtype=np.uint16).reshape(d.height, d.width * 3)
+        assert np.array_equal(got, want[0]), desc
