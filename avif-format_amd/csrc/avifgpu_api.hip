@@ -19,6 +19,7 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
                         int variant, hipStream_t st, const char** name);
 hipError_t launch_read(const ReadParams& p, int colorspace, int depth, bool alpha, int xs, int ys,
                        hipStream_t st, const char** name);
+void release_read_tables();
 }
 
 namespace avifgpu {
@@ -467,7 +468,10 @@ void avifgpu_shutdown(void)
 {
     std::lock_guard<std::mutex> lk(g_ctx.mu);
     if (!g_ctx.ready) return;
-    (void)hipStreamSynchronize(g_ctx.stream);
+    (void)hipDeviceSynchronize();                      // caller-stream launches may still read the cached tables
+    release_read_tables();
+    if (g_icc8_dev.dev) { (void)hipFree(g_icc8_dev.dev); g_icc8_dev.dev = nullptr; g_icc8_dev.host.clear(); }
+    if (g_icc16_dev.dev) { (void)hipFree(g_icc16_dev.dev); g_icc16_dev.dev = nullptr; g_icc16_dev.host.clear(); }
     for (auto& sl : g_ctx.slot) {
         if (sl.d_in) (void)hipFree(sl.d_in);
         if (sl.d_out) (void)hipFree(sl.d_out);

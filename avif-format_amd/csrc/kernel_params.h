@@ -67,6 +67,7 @@ struct ReadParams {
     float   hlg_gamma_m1;        // displayGamma - 1
     float   hlg_peak;
     float   hlg_luma[3];
+    const float* tables;         // device copy of this parameter set's unorm->float tables (read_tables layout), bits <= 12
 };
 
 // Number of 2^bits-entry float tables read_px keeps in LDS (bits <= 12).  Full-range images need ONE: T_A[i] = i/max is

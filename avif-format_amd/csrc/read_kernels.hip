@@ -12,6 +12,8 @@
 // IEEE operations and gathered with ds_read_b32; 16-bit images evaluate the table formula per sample.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
+#include <mutex>
 #include "kernel_params.h"
 #include "device_math.h"
 #include "../../include/avifgpu.h"
@@ -274,6 +276,60 @@ template <bool SRC16> AG_DEV uint32_t sample_of(const uint32_t* d, int j)
     else return (d[j >> 2] >> (8 * (j & 3))) & 0xffu;
 }
 
+// The table set of one read configuration: its layout and, with fill = true, its contents.  Only the tables the
+// configuration reads, aliased where the reference's formulas coincide (see read_table_count): 12-bit full-range YCbCr needs
+// 16 KiB instead of 48.  Used twice: build_read_tables fills a device buffer ONCE per parameter set (cached by
+// launch_read_one), read_px copies that buffer into LDS and points its lookups at the same layout -- so a workgroup pays a
+// 4-48 KiB L2 read instead of re-evaluating up to 3 x 4096 IEEE divisions / transfer curves.
+template <int CS, int DEPTH, bool ALPHA, int TRANSFER>
+AG_DEV int read_tables(const ReadParams& p, float* base, Tables<true>& t, bool fill, int tid, int nthreads)
+{
+    const int count = 1 << p.bits;
+    float* next = base;
+    t.ty = t.tuv = t.ta = t.te = nullptr; t.uv_sub = 0.0f;
+    if constexpr (CS == kCsRgb) {
+        if constexpr (DEPTH == 32) {
+            float* fe = next; next += count;
+            if (fill) {
+                for (int i = tid; i < count; i += nthreads) {
+                    const float a = table_a(p, i);
+                    float e;
+                    if constexpr (TRANSFER == AVIFGPU_TRANSFER_PQ) e = fast_pq_to_linear_l2(a, p.pq_log2_mult);
+                    else if constexpr (TRANSFER == AVIFGPU_TRANSFER_HLG) e = fast_hlg_to_linear(a);
+                    else e = fast_smpte428_to_linear(a);
+                    fe[i] = e;
+                }
+            }
+            t.te = fe;
+        }
+    } else {
+        float* fy = next; next += count;
+        float* fuv = fy; float* fa = fy;
+        const bool sep_uv = (CS == kCsYcc) && !p.full_range && !p.identity_lut;
+        const bool sep_a = ALPHA && !p.full_range;
+        if (sep_uv) { fuv = next; next += count; }
+        if (sep_a) { fa = next; next += count; }
+        if (fill) {
+            for (int i = tid; i < count; i += nthreads) {
+                fy[i] = table_y(p, i);
+                if (sep_uv) fuv[i] = table_uv(p, i);
+                if (sep_a) fa[i] = table_a(p, i);
+            }
+        }
+        t.ty = fy; t.tuv = fuv; t.ta = fa;
+        // aliased UV table: subtract the 0.5 at lookup, except for the identity quirk (T_UV = T_Y, YuvLookupTables.cpp:177-180)
+        t.uv_sub = (CS == kCsYcc && !sep_uv && !p.identity_lut) ? 0.5f : 0.0f;
+    }
+    return (int)(next - base);
+}
+
+template <int CS, int DEPTH, bool ALPHA, int TRANSFER>
+__global__ __launch_bounds__(256) void build_read_tables(const ReadParams p, float* dst)
+{
+    Tables<true> t;
+    (void)read_tables<CS, DEPTH, ALPHA, TRANSFER>(p, dst, t, true, (int)(blockIdx.x * 256 + threadIdx.x), (int)(gridDim.x * 256));
+}
+
 #ifndef AG_READ_PREFETCH
 #define AG_READ_PREFETCH 0
 #endif
@@ -316,41 +372,11 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
     Tables<LUT> t = { nullptr, nullptr, nullptr, nullptr, 0.0f };
     int lut_floats = 0;
     if constexpr (LUT) {
-        // Only the tables this configuration reads, aliased where the reference's formulas coincide (see
-        // read_table_count): 12-bit full-range YCbCr needs 16 KiB of LDS instead of 48.
-        const int count = 1 << p.bits;
-        float* next = lut;
-        if constexpr (CS == kCsRgb) {
-            float* fe = nullptr;
-            if constexpr (DEPTH == 32) {
-                fe = next; next += count;
-                for (int i = threadIdx.x; i < count; i += 256) {
-                    const float a = table_a(p, i);
-                    float e;
-                    if constexpr (TRANSFER == AVIFGPU_TRANSFER_PQ) e = fast_pq_to_linear_l2(a, p.pq_log2_mult);
-                    else if constexpr (TRANSFER == AVIFGPU_TRANSFER_HLG) e = fast_hlg_to_linear(a);
-                    else e = fast_smpte428_to_linear(a);
-                    fe[i] = e;
-                }
-            }
-            t.te = fe;
-        } else {
-            float* fy = next; next += count;
-            float* fuv = fy; float* fa = fy;
-            const bool sep_uv = (CS == kCsYcc) && !p.full_range && !p.identity_lut;
-            const bool sep_a = ALPHA && !p.full_range;
-            if (sep_uv) { fuv = next; next += count; }
-            if (sep_a) { fa = next; next += count; }
-            for (int i = threadIdx.x; i < count; i += 256) {
-                fy[i] = table_y(p, i);
-                if (sep_uv) fuv[i] = table_uv(p, i);
-                if (sep_a) fa[i] = table_a(p, i);
-            }
-            t.ty = fy; t.tuv = fuv; t.ta = fa;
-            // aliased UV table: subtract the 0.5 at lookup, except for the identity quirk (T_UV = T_Y, YuvLookupTables.cpp:177-180)
-            t.uv_sub = (CS == kCsYcc && !sep_uv && !p.identity_lut) ? 0.5f : 0.0f;
-        }
-        lut_floats = (int)(next - lut);
+        lut_floats = read_tables<CS, DEPTH, ALPHA, TRANSFER>(p, lut, t, false, 0, 1);          // layout only
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4* src4 = reinterpret_cast<const f4*>(p.tables);
+        f4* dst4 = reinterpret_cast<f4*>(lut);
+        for (int i = threadIdx.x; i < (lut_floats >> 2); i += 256) dst4[i] = src4[i];           // L2-resident, built once
         __syncthreads();
     }
 
@@ -503,6 +529,57 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
     }
 }
 
+// ---- device-side cache of table sets ------------------------------------------------------------------------------------
+// Keyed by everything read_tables depends on.  A miss launches build_read_tables on the caller's stream and waits for it once
+// (~20 us per NEW parameter set: a decode session has one); hits cost a mutex and a 40-byte compare.
+struct TableKey {
+    int device, cs, depth, alpha, transfer, bits, maxc, full_range, identity_lut;
+    float pq_log2_mult;
+};
+struct TableSlot { TableKey key; float* dev = nullptr; bool valid = false; };
+static std::mutex g_table_mu;
+static TableSlot g_table_slots[16];
+static int g_table_next = 0;
+constexpr size_t kTableSlotFloats = 3 * 4096;
+
+// avifgpu_shutdown: nothing may be in flight any more.
+void release_read_tables()
+{
+    std::lock_guard<std::mutex> lk(g_table_mu);
+    for (TableSlot& sl : g_table_slots) {
+        if (sl.dev) (void)hipFree(sl.dev);
+        sl.dev = nullptr; sl.valid = false;
+    }
+}
+
+template <int CS, int DEPTH, bool ALPHA, int TRANSFER>
+static hipError_t cached_tables(const ReadParams& p, hipStream_t st, const float** out)
+{
+    TableKey key;
+    std::memset(&key, 0, sizeof(key));
+    hipError_t e = hipGetDevice(&key.device);
+    if (e != hipSuccess) return e;
+    key.cs = CS; key.depth = DEPTH; key.alpha = ALPHA; key.transfer = (CS == kCsRgb && DEPTH == 32) ? TRANSFER : 0;
+    key.bits = p.bits; key.maxc = p.maxc; key.full_range = p.full_range; key.identity_lut = p.identity_lut;
+    key.pq_log2_mult = (CS == kCsRgb && DEPTH == 32 && TRANSFER == AVIFGPU_TRANSFER_PQ) ? p.pq_log2_mult : 0.0f;
+    std::lock_guard<std::mutex> lk(g_table_mu);
+    for (TableSlot& sl : g_table_slots)
+        if (sl.valid && std::memcmp(&sl.key, &key, sizeof(key)) == 0) { *out = sl.dev; return hipSuccess; }
+    TableSlot& sl = g_table_slots[g_table_next];
+    g_table_next = (g_table_next + 1) % 16;
+    if (sl.valid) {                                 // recycling a set some in-flight launch may still be copying from
+        sl.valid = false;
+        if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+    }
+    if (!sl.dev && (e = hipMalloc(reinterpret_cast<void**>(&sl.dev), kTableSlotFloats * sizeof(float))) != hipSuccess) return e;
+    hipLaunchKernelGGL((build_read_tables<CS, DEPTH, ALPHA, TRANSFER>), dim3(16), dim3(256), 0, st, p, sl.dev);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    sl.key = key; sl.valid = true;
+    *out = sl.dev;
+    return hipSuccess;
+}
+
 // ---- dispatch --------------------------------------------------------------------------------------
 template <int CS, int DEPTH, bool ALPHA, int XS, int YS, int TRANSFER>
 static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, const char** name)
@@ -515,7 +592,12 @@ static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, const cha
     constexpr int ND_OUT = PXT * NCHL * (DEPTH / 8) / 4;
     const long long waves = (long long)(((p.width + PXT - 1) / PXT + 63) / 64) * ((p.nrows + (1 << YS) - 1) >> YS);
     long long blocks = (waves + 3) / 4;
-    if (blocks > 256LL * 8) blocks = 256LL * 8;          // tables are rebuilt per block: keep blocks persistent-ish
+    // Grid cap, measured (profiles/r01/ab_read_variants.txt, second table): with the tables copied from the device cache
+    // instead of rebuilt per workgroup, a 16k-block grid beats 2k by 5-10 % on the f32 and 10-bit kernels.
+#ifndef AG_READ_BLOCK_CAP
+#define AG_READ_BLOCK_CAP (256LL * 64)
+#endif
+    if (blocks > AG_READ_BLOCK_CAP) blocks = AG_READ_BLOCK_CAP;
     const size_t lut_bytes = p.bits <= 12 ? (size_t)read_table_count(CS == kCsYcc, CS == kCsMono, ALPHA, DEPTH, p.full_range != 0, p.identity_lut != 0, p.premultiplied != 0) *
                                                 (1u << p.bits) * sizeof(float) : 0;
     static thread_local char label[160];
@@ -526,7 +608,12 @@ static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, const cha
     snprintf(label, sizeof(label), "read_px<cs=%d,depth=%d,alpha=%d,xs=%d,ys=%d,transfer=%d,aligned=%d>", CS, DEPTH, (int)ALPHA, XS, YS,
              TRANSFER, (int)aligned);
     *name = label;
-#define AG_READ_LAUNCH(LUT_, AL_) hipLaunchKernelGGL((read_px<CS, DEPTH, ALPHA, XS, YS, TRANSFER, LUT_, AL_>), dim3((int)blocks), dim3(256), lds, st, p)
+    ReadParams q = p;
+    if (lut_bytes) {
+        const hipError_t e = cached_tables<CS, DEPTH, ALPHA, TRANSFER>(p, st, &q.tables);
+        if (e != hipSuccess) return e;
+    }
+#define AG_READ_LAUNCH(LUT_, AL_) hipLaunchKernelGGL((read_px<CS, DEPTH, ALPHA, XS, YS, TRANSFER, LUT_, AL_>), dim3((int)blocks), dim3(256), lds, st, q)
     if constexpr (DEPTH == 8) {
         if (aligned) AG_READ_LAUNCH(true, true); else AG_READ_LAUNCH(true, false);
     } else {

@@ -1,7 +1,7 @@
 # A/B of read-kernel variants (built by tools/ab_variants.sh): same bench, one library per run
 mkdir -p gpurun_out
 : > gpurun_out/ab_read.jsonl
-for v in "" head pf1 small8 pf1r16nc8; do
+for v in ""; do
   if [ -z "$v" ]; then lib=""; name=base; else lib=$PWD/avif-format_amd/variants/libavifgpu_$v.so; name=$v; fi
   [ -n "$lib" ] && [ ! -f "$lib" ] && continue
   AVIFGPU_LIB=$lib python tools/bench_configs.py R8 R16 R32 2>/dev/null | sed "s/^{/{\"variant\": \"$name\", /" >> gpurun_out/ab_read.jsonl
