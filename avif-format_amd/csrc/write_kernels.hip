@@ -645,7 +645,10 @@ __global__ __launch_bounds__(256) void write_rgb32_ycbcr444_hot(const WriteParam
 static inline int grid_for(long long threads_needed)
 {
     long long blocks = (threads_needed + 255) / 256;
-    const long long cap = 256LL * 64;          // grid-stride beyond 16k blocks (larger grids measured faster than 2-4k)
+#ifndef AG_WRITE_BLOCK_CAP
+#define AG_WRITE_BLOCK_CAP (256LL * 64)
+#endif
+    const long long cap = AG_WRITE_BLOCK_CAP;   // grid-stride beyond 16k blocks (larger grids measured faster than 2-4k)
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
