@@ -400,11 +400,39 @@ void avifgpu_image_free(avifgpu_image* img)
     if (img && img->owner) { free(img->owner); img->owner = nullptr; for (auto& p : img->plane) p = nullptr; }
 }
 
+// AddColorProfileToImage (WriteMetadata.cpp:107-149): the nclx the plug-in attaches to the image it hands to libheif --
+// and therefore the matrix a fused YCbCr output has to use so that libheif has nothing left to convert.
+avifgpu_OSErr avifgpu_host_save_nclx(const avifgpu_FormatRecord* formatRecord, const avifgpu_SaveUIOptions* saveOptions,
+                                     avifgpu_nclx* out)
+{
+    if (!formatRecord || !saveOptions || !out) return AVIFGPU_formatBadParameters;
+    if (formatRecord->depth == 32 && saveOptions->hdrTransferFunction != AVIFGPU_TRANSFER_CLIP) {
+        out->color_primaries = AVIFGPU_PRIMARIES_BT2020;
+        out->matrix_coefficients = AVIFGPU_MATRIX_BT2020_NCL;
+        if (saveOptions->hdrTransferFunction == AVIFGPU_TRANSFER_PQ) out->transfer_characteristics = AVIFGPU_TC_PQ;
+        else if (saveOptions->hdrTransferFunction == AVIFGPU_TRANSFER_SMPTE428) out->transfer_characteristics = AVIFGPU_TC_SMPTE428;
+        else { avifgpu::set_error("Unsupported color transfer function."); return AVIFGPU_writErr; }   // :130-131 via Write.cpp:359-362
+    } else {
+        out->color_primaries = AVIFGPU_PRIMARIES_BT709;
+        out->transfer_characteristics = AVIFGPU_TC_SRGB;
+        out->matrix_coefficients = AVIFGPU_MATRIX_BT601;
+    }
+    if (saveOptions->lossless && !IsMonochromeImage(const_cast<avifgpu_FormatRecord*>(formatRecord))) out->matrix_coefficients = AVIFGPU_MATRIX_RGB_GBR;
+    out->full_range_flag = 1;                                                                         // :46
+    return AVIFGPU_noErr;
+}
+
 avifgpu_OSErr avifgpu_host_create_heif_image(avifgpu_FormatRecord* formatRecord, int32_t alphaState,
                                              const avifgpu_SaveUIOptions* saveOptions, int32_t output,
                                              int32_t matrix_coefficients, int32_t color_primaries, avifgpu_image* img)
 {
     if (!formatRecord || !saveOptions || !img || !formatRecord->advanceState) return AVIFGPU_formatBadParameters;
+    if (matrix_coefficients < 0) {                          // "what the plug-in will attach"
+        avifgpu_nclx nclx;
+        const avifgpu_OSErr e = avifgpu_host_save_nclx(formatRecord, saveOptions, &nclx);
+        if (e != AVIFGPU_noErr) return e;
+        matrix_coefficients = nclx.matrix_coefficients; color_primaries = nclx.color_primaries;
+    }
     return guarded([&] {
         const VPoint imageSize = GetImageSize(formatRecord);
         switch (formatRecord->depth) {                                                      // Write.cpp:303-336

@@ -128,6 +128,13 @@ void          avifgpu_image_free(avifgpu_image* img);
  * img->plane[] may point at libheif-owned planes (heif_image_get_plane) or be allocated with avifgpu_image_alloc.
  * Returns noErr, userCanceledErr (abortProc), the host's advanceState error, memFullErr, writErr, formatBadParameters.
  */
+/* The nclx colour profile the plug-in attaches on save (AddColorProfileToImage, reference WriteMetadata.cpp:107-149):
+ * HDR PQ / SMPTE 428 -> BT.2020 primaries + BT.2020-NCL matrix; everything else -> BT.709 primaries, sRGB transfer, BT.601
+ * matrix; lossless colour images -> identity (GBR) matrix; always full range.  writErr for a transfer the plug-in cannot
+ * save (HLG).  Passing matrix_coefficients < 0 to avifgpu_host_create_heif_image selects exactly this. */
+avifgpu_OSErr avifgpu_host_save_nclx(const avifgpu_FormatRecord* formatRecord, const avifgpu_SaveUIOptions* saveOptions,
+                                     avifgpu_nclx* out);
+
 avifgpu_OSErr avifgpu_host_create_heif_image(avifgpu_FormatRecord* formatRecord, int32_t alphaState,
                                              const avifgpu_SaveUIOptions* saveOptions, int32_t output,
                                              int32_t matrix_coefficients, int32_t color_primaries,
