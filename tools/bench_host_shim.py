@@ -44,7 +44,42 @@ def run(width, height, max_data, output, chroma=pkg.CHROMA_444, reps=3):
                       "H2D_GB_s_equiv": round(width * height * 12 / best / 1e9, 1)}), flush=True)
 
 
+def run_read(width, height, max_data, bits, depth, chroma, tc, reps=3):
+    """Open direction: planes in pageable host memory -> avifgpu_host_read_heif_image -> the fake host drains every tile."""
+    gpu = pkg.AvifGpu(0)
+    d = pkg.ReadDesc(width=width, height=height, colorspace=pkg.COLORSPACE_YCBCR, chroma=chroma, bit_depth=bits, depth=depth,
+                     alpha_state=pkg.ALPHA_NONE, matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020,
+                     transfer_characteristics=tc)
+    planes = harness.make_read_source(d, seed=7)
+    img = H.Image()
+    img.width, img.height, img.colorspace, img.chroma, img.bit_depth = width, height, d.colorspace, chroma, bits
+    for pl, a in planes.items():
+        img.plane[pl] = a.ctypes.data
+        img.stride[pl] = a.strides[0]
+    nclx = H.Nclx(color_primaries=d.color_primaries, transfer_characteristics=tc, matrix_coefficients=d.matrix_coefficients, full_range_flag=1)
+    lo = H.LoadUIOptions()
+    lo.pq.nominalPeakBrightness = 1000
+    lo.hlg.displayGamma = 1.2
+    lo.hlg.nominalPeakBrightness = 1000
+    best = None
+    for _ in range(reps):
+        host = FakeHost(width, height, depth, 3, max_data=max_data)
+        t0 = time.perf_counter()
+        code = gpu.lib.avifgpu_host_read_heif_image(ctypes.byref(img), pkg.ALPHA_NONE, ctypes.byref(nclx), ctypes.byref(lo), ctypes.byref(host.fr))
+        dt = time.perf_counter() - t0
+        assert code == 0, gpu.lib.avifgpu_last_error()
+        best = dt if best is None else min(best, dt)
+        tiles = len(host.rects)
+    t0 = time.perf_counter(); tmp = host.image.copy(); drain = time.perf_counter() - t0
+    print(json.dumps({"config": f"{width}x{height} {bits}-bit YCbCr {'4:2:0' if chroma == pkg.CHROMA_420 else '4:4:4'} -> host depth {depth}",
+                      "maxData_MiB": max_data / 2**20, "tiles": tiles, "seconds": round(best, 4),
+                      "Mpx_s": round(width * height / best / 1e6, 1), "host_drain_memcpy_s": round(drain, 4)}), flush=True)
+
+
 if __name__ == "__main__":
+    run_read(8192, 8192, 64 << 20, 10, 32, pkg.CHROMA_444, pkg.TC_PQ)
+    run_read(8192, 8192, 64 << 20, 8, 8, pkg.CHROMA_420, pkg.TC_SRGB)
+    run_read(8192, 8192, 64 << 20, 12, 16, pkg.CHROMA_420, pkg.TC_SRGB)
     for md in (16 << 20, 64 << 20, 256 << 20, 1024 << 20):
         run(8192, 8192, md, pkg.OUT_YCBCR)
     run(8192, 8192, 64 << 20, pkg.OUT_REFERENCE)
