@@ -641,6 +641,95 @@ __global__ __launch_bounds__(256) void write_rgb32_ycbcr444_hot(const WriteParam
     }
 }
 
+// ---- the same streaming structure for 4:2:2 / 4:2:0 (the AVIF default) -----------------------------------------------------
+// A wave owns a span of 512 pixels on 1 (4:2:2) or 2 (4:2:0) consecutive rows.  Per row: coalesced non-temporal float4 loads,
+// curve on the samples as loaded, packed codes through the wave-private LDS strip (reused for the second row), read back
+// pixel-major: lane l then holds pixels [8l, 8l+8) of both rows = the footprint of 4 chroma samples, so the box filter
+// (same operand order as write_px / the oracle) needs no cross-lane traffic.  Stores: 16 B/lane per luma row, 8 B/lane per chroma
+// plane, contiguous across the wave, non-temporal.
+template <int TRANSFER, int XS, int YS>
+__global__ __launch_bounds__(256) void write_rgb32_ycbcr_sub_hot(const WriteParams p)
+{
+    static_assert(XS == 1, "4:2:2 or 4:2:0");
+    constexpr int PXL = 8, K = 6, SPAN_PX = 512, SPAN_DW = SPAN_PX * 3 / 2, LDW = 12, VR = 1 << YS;
+    __shared__ __attribute__((aligned(16))) uint32_t strip[4][SPAN_DW];
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    uint32_t* my = strip[wave];
+
+    const uint32_t spans_per_row = (uint32_t)p.width / SPAN_PX;        // host guarantees divisibility and alignment
+    const uint32_t groups = ((uint32_t)p.nrows + VR - 1) >> YS;
+    const uint32_t total = spans_per_row * groups;
+    for (uint32_t sidx = blockIdx.x * 4 + wave; sidx < total; sidx += gridDim.x * 4) {
+        const uint32_t gy = sidx / spans_per_row;
+        const uint32_t sx = sidx - gy * spans_per_row;
+        uint32_t dw[VR][LDW];
+        f32x4 v[VR][K];
+#pragma unroll
+        for (int vr = 0; vr < VR; ++vr) {                              // both rows' loads in flight before any math
+            const int r = min((int)(gy * VR) + vr, p.rows_to_end - 1);  // bottom edge: replicate the last IMAGE row
+            const f32x4* sp = reinterpret_cast<const f32x4*>(p.src + (long long)r * p.src_row_bytes) + (long long)sx * (64 * K);
+#pragma unroll
+            for (int k = 0; k < K; ++k) v[vr][k] = stream_load<true>(sp + 64 * k + lane);
+        }
+#pragma unroll
+        for (int vr = 0; vr < VR; ++vr) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint32_t c0 = oetf_code<TRANSFER>(p, v[vr][k].x), c1 = oetf_code<TRANSFER>(p, v[vr][k].y);
+                const uint32_t c2 = oetf_code<TRANSFER>(p, v[vr][k].z), c3 = oetf_code<TRANSFER>(p, v[vr][k].w);
+                u32x2 pk = { c0 | (c1 << 16), c2 | (c3 << 16) };
+                reinterpret_cast<u32x2*>(my)[64 * k + lane] = pk;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const u32x4 t = reinterpret_cast<const u32x4*>(my)[3 * lane + j];
+                dw[vr][4 * j] = t.x; dw[vr][4 * j + 1] = t.y; dw[vr][4 * j + 2] = t.z; dw[vr][4 * j + 3] = t.w;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        auto code = [&](int vr, int i, int c) -> uint32_t {
+            const int e = 3 * i + c;
+            return (e & 1) ? (dw[vr][e >> 1] >> 16) : (dw[vr][e >> 1] & 0xffffu);
+        };
+        const long long xoff = ((long long)sx * SPAN_PX + (long long)PXL * lane) * 2;
+#pragma unroll
+        for (int vr = 0; vr < VR; ++vr) {
+            const int r = (int)(gy * VR) + vr;
+            if (r >= p.nrows) continue;                                // odd last row of the tile: replicated for chroma only
+            uint32_t yv[PXL];
+#pragma unroll
+            for (int i = 0; i < PXL; ++i) {
+                const uint32_t q[4] = { code(vr, i, 0), code(vr, i, 1), code(vr, i, 2), 0 };
+                yv[i] = stage_b_luma(p, q);
+            }
+            u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
+            stream_store<true>(reinterpret_cast<u32x4*>(p.dst[0] + (long long)r * p.dst_stride[0] + xoff), a);
+        }
+        uint32_t cbv[4], crv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i0 = 2 * j;
+            constexpr int v1 = YS ? 1 : 0;
+            if (p.identity) { cbv[j] = code(0, i0, 2); crv[j] = code(0, i0, 0); continue; }
+            float R = (float)code(0, i0, 0), G = (float)code(0, i0, 1), B = (float)code(0, i0, 2);
+            if (!p.nearest) {
+                R = (R + (float)code(0, i0 + 1, 0) + (float)code(v1, i0, 0) + (float)code(v1, i0 + 1, 0)) * 0.25f;
+                G = (G + (float)code(0, i0 + 1, 1) + (float)code(v1, i0, 1) + (float)code(v1, i0 + 1, 1)) * 0.25f;
+                B = (B + (float)code(0, i0 + 1, 2) + (float)code(v1, i0, 2) + (float)code(v1, i0 + 1, 2)) * 0.25f;
+            }
+            cbv[j] = clip_round(R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2] + p.half, p.maxv);
+            crv[j] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
+        }
+        const long long coff = ((long long)sx * (SPAN_PX / 2) + 4LL * lane) * 2;
+        u32x2 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16) };
+        u32x2 c = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16) };
+        stream_store<true>(reinterpret_cast<u32x2*>(p.dst[1] + (long long)gy * p.dst_stride[1] + coff), b);
+        stream_store<true>(reinterpret_cast<u32x2*>(p.dst[2] + (long long)gy * p.dst_stride[2] + coff), c);
+    }
+}
+
 // ---- dispatch --------------------------------------------------------------------------------------
 static inline int grid_for(long long threads_needed)
 {
@@ -774,6 +863,30 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
     // hot path: RGB f32 (no alpha) -> YCbCr 4:4:4 u16 with aligned rows; `variant` is a tuning word:
     //   bit0 enable, bit1 PXL=8 (else 4), bit2 non-temporal, bit3 prefetch, bit4 XCD-contiguous mapping;
     //   bits 8.. = blocks (0 = default).
+    if ((variant & 1) && p.icc_trc_type[0] == 0 && depth == 32 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 1 &&
+        (p.width % 512) == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
+        ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |
+          (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2]) & 15) == 0) {
+        const long long spans = (long long)(p.width / 512) * ((p.nrows + (1 << ys) - 1) >> ys);
+        if (spans == 0) return hipSuccess;
+        if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
+            long long blocks = (spans + 3) / 4;
+            if (blocks > 256LL * 64) blocks = 256LL * 64;
+            static thread_local char label[96];
+            snprintf(label, sizeof(label), "write_rgb32_ycbcr_sub_hot<transfer=%d,xs=1,ys=%d>", p.transfer, ys);
+            *name = label;
+#define AG_SUB(TR) do { if (ys) hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<TR, 1, 1>), dim3((int)blocks), dim3(256), 0, st, p); \
+                        else hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<TR, 1, 0>), dim3((int)blocks), dim3(256), 0, st, p); } while (0)
+            switch (p.transfer) {
+            case AVIFGPU_TRANSFER_PQ:       AG_SUB(AVIFGPU_TRANSFER_PQ); break;
+            case AVIFGPU_TRANSFER_HLG:      AG_SUB(AVIFGPU_TRANSFER_HLG); break;
+            case AVIFGPU_TRANSFER_SMPTE428: AG_SUB(AVIFGPU_TRANSFER_SMPTE428); break;
+            default:                        AG_SUB(AVIFGPU_TRANSFER_CLIP); break;
+            }
+#undef AG_SUB
+            return hipGetLastError();
+        }
+    }
     if ((variant & 1) && p.icc_trc_type[0] == 0 && depth == 32 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 0 && ys == 0 &&
         (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |

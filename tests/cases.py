@@ -91,6 +91,22 @@ def write_cases():
                                             output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444,
                                             matrix_coefficients=pkg.MATRIX_BT2020_NCL,
                                             color_primaries=pkg.PRIMARIES_BT2020)),
+        # ... and its 4:2:0 / 4:2:2 sibling width % 512 == 0 (odd heights: the last chroma row replicates the image edge)
+        ("ycc-d32-p3-b10-420-hot", dict(width=1024, height=7, depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_PQ,
+                                        peak_nits=80, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR,
+                                        chroma=pkg.CHROMA_420, matrix_coefficients=pkg.MATRIX_BT2020_NCL,
+                                        color_primaries=pkg.PRIMARIES_BT2020)),
+        ("ycc-d32-p3-b12-422-hot428", dict(width=512, height=5, depth=32, planes=3, bit_depth=12,
+                                           transfer=pkg.TRANSFER_SMPTE428, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR,
+                                           chroma=pkg.CHROMA_422, matrix_coefficients=pkg.MATRIX_BT2020_NCL,
+                                           color_primaries=pkg.PRIMARIES_BT2020)),
+        ("ycc-d32-p3-b10-420-hot-nearest-clip", dict(width=512, height=4, depth=32, planes=3, bit_depth=10,
+                                                     transfer=pkg.TRANSFER_CLIP, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR,
+                                                     chroma=pkg.CHROMA_420, matrix_coefficients=pkg.MATRIX_BT601,
+                                                     chroma_downsampling=pkg.DOWNSAMPLE_NEAREST)),
+        ("ycc-d32-p3-b10-422-hot-hlg", dict(width=1536, height=3, depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_HLG,
+                                            alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_422,
+                                            matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020)),
         # BASELINE.json config 1 at its real size: 512x512 RGBA8 -> 8-bit 4:2:0 BT.709
         ("baseline-c1-512", dict(width=512, height=512, depth=8, planes=4, bit_depth=8, alpha_state=pkg.ALPHA_STRAIGHT,
                                  output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420, matrix_coefficients=pkg.MATRIX_BT709)),

@@ -1,0 +1,2 @@
+timeout 900 python -m pytest tests/test_gpu_write.py tests/test_gpu_tiles.py tests/test_gpu_fullsize.py tests/test_gpu_fullsize_roundtrip.py tests/test_gpu_fuzz.py -m gpu -q -x 2>&1 | tail -5
+python tools/bench_configs.py "C4 8192" 2>/dev/null | cut -c1-330
