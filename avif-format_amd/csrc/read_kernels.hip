@@ -353,7 +353,10 @@ __global__ __launch_bounds__(256) void build_read_tables(const ReadParams p, flo
 template <int CS, int DEPTH, bool ALPHA, int XS> struct ReadShape {
     // u8 planes: 8 chroma samples per lane only where a lane's footprint stays small (4:2:x without alpha); 4:4:4 and the
     // alpha variants ran 20 % faster with 4 (register pressure)
-    static constexpr int NC8 = (CS == 0 && (XS == 0 || ALPHA)) ? AG_R8_NC_SMALL : AG_R8_NC;
+#ifndef AG_MONO8_NC
+#define AG_MONO8_NC 16   /* 16-byte loads and stores: 0.037 -> 0.030 ms at 8192^2 */
+#endif
+    static constexpr int NC8 = CS == 2 ? (ALPHA ? 8 : AG_MONO8_NC) : ((CS == 0 && (XS == 0 || ALPHA)) ? AG_R8_NC_SMALL : AG_R8_NC);
     static constexpr int NC = DEPTH == 8 ? NC8 : (CS == 1 ? AG_RGB16_NC : (CS == 2 ? (DEPTH == 32 ? 4 : AG_MONO16_NC) : AG_R16_NC));
     static constexpr int PXT = NC << XS;
 };
