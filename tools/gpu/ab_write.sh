@@ -1,7 +1,7 @@
 # A/B of write-kernel variants (built by tools/ab_variants.sh): same bench, one library per run
 mkdir -p gpurun_out
 : > gpurun_out/ab_write.jsonl
-for v in "" w8k w32k w64k; do
+for v in ""; do
   if [ -z "$v" ]; then lib=""; name=base; else lib=$PWD/avif-format_amd/variants/libavifgpu_$v.so; name=$v; fi
   [ -n "$lib" ] && [ ! -f "$lib" ] && continue
   AVIFGPU_LIB=$lib python tools/bench_configs.py "C2" "W8" "W16" "RGBA8" "C3" "C4" "C5" "Gray" 2>/dev/null | sed "s/^{/{\"variant\": \"$name\", /" >> gpurun_out/ab_write.jsonl
