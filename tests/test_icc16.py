@@ -107,6 +107,26 @@ def test_prepare_clut16_rejects_what_it_cannot_do(lcms):
     assert pkg.load().avifgpu_icc_prepare(sampled, len(sampled), pkg.ICC_TARGET_SRGB_FLOAT, ctypes.byref(pkg.IccTransform())) == pkg.formatCannotRead
 
 
+def test_fast_division_by_65535_is_exact():
+    """The kernel's lcms->host range map divides by 65535 with q0 = x*r, q = fma(fma(-q0, d, x), r, q0), r = RN(1/d).
+    Proof over the whole input domain (0..65535) in exact rational arithmetic that q == RN(x / d)."""
+    from fractions import Fraction
+
+    def rn32(fr):
+        g = np.float32(float(fr))
+        cands = [np.nextafter(g, np.float32(-np.inf)), g, np.nextafter(g, np.float32(np.inf))]
+        return np.float32(min(cands, key=lambda c: (abs(Fraction(float(c)) - fr), int(np.float32(c).view(np.uint32)) & 1)))
+
+    d = np.float32(65535.0)
+    r = np.float32(1.0) / d
+    for x in range(65536):
+        xf = np.float32(x)
+        q0 = np.float32(xf * r)
+        t = rn32(Fraction(float(-q0)) * Fraction(float(d)) + Fraction(float(xf)))
+        q = rn32(Fraction(float(t)) * Fraction(float(r)) + Fraction(float(q0)))
+        assert q == np.float32(xf / d), x
+
+
 def _gpu(gpu, d, src, icc16):
     import torch
     dev = f"cuda:{gpu.device}"

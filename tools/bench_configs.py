@@ -51,9 +51,23 @@ def rand_src(d):
     return t.view(d.height, -1)
 
 
-def bench_write(name, icc=None, **kw):
+def smooth_src(d):
+    """Photograph-like 16-bit content: large-scale gradients + a few codes of noise, so neighbouring pixels fall into the same
+    cells of the ICC table (uniform random input is the worst case for those gathers)."""
+    g = torch.Generator(device=dev); g.manual_seed(77)
+    y = torch.linspace(0, 1, d.height, device=dev).view(-1, 1, 1)
+    x = torch.linspace(0, 1, d.width, device=dev).view(1, -1, 1)
+    ph = torch.tensor([0.0, 2.1, 4.2], device=dev).view(1, 1, 3)
+    img = 0.5 + 0.45 * torch.sin(6.0 * x + 3.0 * y + ph) * torch.cos(2.0 * y - x)
+    img = (img * 32768.0 + 40.0 * torch.randn(img.shape, generator=g, device=dev)).clamp_(0, 32768)
+    if d.depth == 8:
+        return (img / 128.5).to(torch.uint8).reshape(d.height, -1)
+    return img.to(torch.int32).to(torch.int16).reshape(d.height, -1)
+
+
+def bench_write(name, icc=None, smooth=False, **kw):
     d = pkg.WriteDesc(**kw)
-    src = rand_src(d)
+    src = smooth_src(d) if smooth else rand_src(d)
     ssz = 2 if d.bit_depth > 8 else 1
     bufs, ptrs, strides = {}, [None] * 4, [0] * 4
     for pl, (w, xs, ys) in harness.write_planes(d).items():
@@ -138,6 +152,7 @@ if __name__ == "__main__":
         bench_write("SDR save of a 32-bit doc + ICC (linear Display-P3 -> sRGB) 8192^2 RGB f32 -> 12-bit Clip 4:2:0", icc=xf3, width=8192, height=8192, depth=32, planes=3, bit_depth=12, transfer=P.TRANSFER_CLIP, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=6, color_primaries=1)
         n = L.oracle_icc_make_profile(3, 0, 2.19921875, buf, len(buf))
         bench_write("16-bit doc + ICC (AdobeRGB -> sRGB, 33^3 table) 8192^2 RGB16 -> 12-bit 4:4:4", icc=gpu.icc_prepare_clut16(buf.raw[:n]), width=8192, height=8192, depth=16, planes=3, bit_depth=12, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=6, color_primaries=1)
+        bench_write("16-bit doc + ICC, photograph-like input (smooth + noise) 8192^2 RGB16 -> 12-bit 4:4:4", icc=gpu.icc_prepare_clut16(buf.raw[:n]), smooth=True, width=8192, height=8192, depth=16, planes=3, bit_depth=12, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=6, color_primaries=1)
         bench_write("8-bit doc + ICC (AdobeRGB -> sRGB, matrix-shaper) 8192^2 RGB8 -> 8-bit 4:2:0", icc=gpu.icc_prepare_shaper8(buf.raw[:n]), width=8192, height=8192, depth=8, planes=3, bit_depth=8, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=6, color_primaries=1)
     bench_read("R8 8192^2 8-bit 4:2:0 BT.709 -> RGB8", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_420, bit_depth=8, depth=8, alpha_state=0, matrix_coefficients=1)
     bench_read("R8 8192^2 8-bit 4:4:4 BT.601 -> RGB8", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_444, bit_depth=8, depth=8, alpha_state=0, matrix_coefficients=6)
