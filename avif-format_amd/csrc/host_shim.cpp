@@ -139,6 +139,11 @@ void CreateHeifImageInto(FormatRecordPtr formatRecord, AlphaState alphaState, co
     const bool hasAlpha = alphaState != AlphaState::None;
     const bool mono = IsMonochromeImage(formatRecord);
     if (hasAlpha != HasAlphaChannel(formatRecord)) throw OSErrException(AVIFGPU_formatBadParameters);
+    // The plug-in cannot save HLG: every 32-bit branch throws for it (WriteHeifImage.cpp:581-582,:1088-1089,:1123-1124).  The
+    // C-ABI below offers LinearToHLG (ColorTransfer.cpp:141-164, defined but unreachable in the reference) as an extension;
+    // the reference-named entry points keep the reference's behaviour.
+    if (formatRecord->depth == 32 && saveOptions.hdrTransferFunction == AVIFGPU_TRANSFER_HLG)
+        throw std::runtime_error("Unsupported color transfer function.");
 
     formatRecord->planeBytes = (int16_t)((formatRecord->depth + 7) / 8);
     formatRecord->loPlane = 0;

@@ -44,7 +44,9 @@ extern "C" {
 
 /* ---- enums (numeric values follow the reference / libheif / ITU-T H.273) -------------------- */
 
-/* ColorTransferFunction, reference src/common/ColorTransfer.h:28-34 (same order). */
+/* ColorTransferFunction, reference src/common/ColorTransfer.h:28-34 (same order).  HLG on the WRITE side is an extension:
+ * the reference defines LinearToHLG (ColorTransfer.cpp:141-164) but its save loops throw for it; avifgpu_write_rows accepts it
+ * for colour images, the FormatRecord-protocol shim (avifgpu_host.h) rejects it with writErr like the plug-in. */
 enum {
     AVIFGPU_TRANSFER_PQ       = 0,
     AVIFGPU_TRANSFER_HLG      = 1,

@@ -43,3 +43,18 @@ def test_save_nclx_matches_the_plugin(depth, mode, transfer, lossless, expected)
 def test_save_nclx_rejects_hlg_like_the_plugin():
     rc, _ = _ask(32, H.plugInModeRGB96, pkg.TRANSFER_HLG, 0)
     assert rc == pkg.writErr
+
+
+def test_shim_rejects_hlg_saves_like_the_plugin():
+    """Every 32-bit save loop of the reference throws "Unsupported color transfer function." for HLG
+    (WriteHeifImage.cpp:1088-1089); the shim does so before any tile is requested (so this runs without a GPU)."""
+    from fake_host import FakeHost
+    import numpy as np
+    host = FakeHost(8, 2, 32, 3, image=np.zeros((2, 24), dtype=np.float32))
+    o = H.SaveUIOptions(imageBitDepth=10, hdrTransferFunction=pkg.TRANSFER_HLG, pq=H.PQOptions(1000), chromaSubsampling=pkg.CHROMA_420,
+                        lossless=0, convertToRec2020=0, convertToSRGB=0)
+    img = H.Image()
+    rc = pkg.load().avifgpu_host_create_heif_image(ctypes.byref(host.fr), pkg.ALPHA_NONE, ctypes.byref(o), pkg.OUT_REFERENCE,
+                                                   pkg.MATRIX_BT2020_NCL, pkg.PRIMARIES_BT2020, ctypes.byref(img))
+    assert rc == pkg.writErr and host.rects == []
+    assert b"Unsupported color transfer function" in pkg.load().avifgpu_last_error()
