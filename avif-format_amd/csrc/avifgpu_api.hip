@@ -215,6 +215,16 @@ int upload_icc8(const avifgpu_icc_shaper8* t, hipStream_t st, WriteParams& p)
 {
     if (memcmp(t->shaper2[0], t->shaper2[1], 16385) != 0 || memcmp(t->shaper2[0], t->shaper2[2], 16385) != 0)
         return fail(AVIFGPU_formatBadParameters, "8-bit ICC shaper: the destination curve must be the same for R, G and B (sRGB)");
+    // the kernel multiplies with v_mul_i32_i24: every factor must fit 24 signed bits (always true for real profiles: curve
+    // values <= 1.0 -> 16384, matrix coefficients of a few units)
+    for (int c = 0; c < 3; ++c) {
+        for (int i = 0; i < 256; ++i)
+            if (t->shaper1[c][i] < -(1 << 23) || t->shaper1[c][i] >= (1 << 23))
+                return fail(AVIFGPU_formatCannotRead, "8-bit ICC shaper: curve value out of the 24-bit range, keep the lcms2 path");
+        for (int j = 0; j < 3; ++j)
+            if (t->matrix[c][j] < -(1 << 23) || t->matrix[c][j] >= (1 << 23))
+                return fail(AVIFGPU_formatCannotRead, "8-bit ICC shaper: matrix coefficient out of the 24-bit range, keep the lcms2 path");
+    }
     const size_t n1 = sizeof(t->shaper1), n2 = 16388;
     std::vector<uint8_t> blob(n1 + n2);
     memcpy(blob.data(), t->shaper1, n1);

@@ -250,7 +250,9 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
             const int r = icc8_lds_s1[sx[0]], g = icc8_lds_s1[256 + sx[1]], b = icc8_lds_s1[512 + sx[2]];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                int l = (p.icc8_m[3 * i] * r + p.icc8_m[3 * i + 1] * g + p.icc8_m[3 * i + 2] * b + p.icc8_off[i] + 0x2000) >> 14;
+                // table values <= 16384 and 1.14 coefficients both fit 24 bits: v_mul_i32_i24 (full rate) instead of the
+                // quarter-rate 32-bit multiply; the low 32 bits are the same wrapping product the library computes
+                int l = (__mul24(p.icc8_m[3 * i], r) + __mul24(p.icc8_m[3 * i + 1], g) + __mul24(p.icc8_m[3 * i + 2], b) + p.icc8_off[i] + 0x2000) >> 14;
                 l = l < 0 ? 0 : (l > 16384 ? 16384 : l);
                 sx[i] = icc8_lds_s2[l];
             }
