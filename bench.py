@@ -247,7 +247,7 @@ def main():
             sub = pkg.WriteDesc(**{n: getattr(desc, n) for n, _ in pkg.WriteDesc._fields_})
             sub.height = rows
             harness.oracle_write(sub, h_src[:8], row0=0, nrows=8)        # page in the library
-            passes = 3                                                   # ~10 s of CPU work on the box's EPYC
+            passes = 4                                                   # ~12 s of CPU work on the box's EPYC
             t1 = time.perf_counter()
             for _ in range(passes):
                 harness.oracle_write(sub, h_src, return_raw=True)
