@@ -143,3 +143,18 @@ def test_read_max_value():
     assert lib.avifgpu_read_max_value(ctypes.byref(d)) == 32768
     d.colorspace = pkg.COLORSPACE_RGB
     assert lib.avifgpu_read_max_value(ctypes.byref(d)) == 1023      # host rescales, ReadHeifImage.cpp:744-747
+
+
+def test_headers_are_plain_c(tmp_path):
+    """The drop-in boundary is a C ABI: both public headers compile as strict C99 and as C++11 with no other include path
+    (no torch / HIP / libheif / SDK types in any signature)."""
+    import subprocess
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "avifgpu.h"\n#include "avifgpu_host.h"\n'
+                   "int main(void) { avifgpu_write_desc d; avifgpu_read_desc r; avifgpu_icc_clut16* t = 0; (void)d; (void)r; (void)t;\n"
+                   "  return (int)sizeof(avifgpu_FormatRecord) == 0; }\n")
+    for cc, flags in (("gcc", ["-std=c99"]), ("g++", ["-std=c++11", "-x", "c++"])):
+        r = subprocess.run([cc, *flags, "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, "-fsyntax-only", str(src)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
