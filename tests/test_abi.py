@@ -158,3 +158,31 @@ def test_headers_are_plain_c(tmp_path):
         r = subprocess.run([cc, *flags, "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, "-fsyntax-only", str(src)],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def _build_c_client(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "c_abi_smoke"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                        os.path.join(root, "tests", "c_abi_smoke.c"), "-o", str(exe), "-L", os.path.join(root, "avif-format_amd"),
+                        "-lavifgpu", "-Wl,-rpath," + os.path.join(root, "avif-format_amd"), "-Wl,-rpath,/opt/rocm/lib"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+
+
+def test_plain_c_client_links_and_fails_loudly_without_gpu(tmp_path):
+    """tests/c_abi_smoke.c: gcc -std=c99 + -lavifgpu is all a C host needs; without a device it gets the no-fallback error."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present (see the gpu-marked twin)")
+    r = _build_c_client(tmp_path)
+    assert r.returncode == 3 and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+def test_plain_c_client_converts_on_the_gpu(tmp_path):
+    r = _build_c_client(tmp_path)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "write_px" in r.stdout
