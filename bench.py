@@ -89,12 +89,16 @@ def main():
         raise SystemExit(f"WORLD_SIZE {world} != --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU; there is no CPU fallback")
-    dev = torch.device("cuda", local_rank)
+    # AVIFGPU_BENCH_SHARE_DEVICE=1 (rehearsal only): ranks wrap around the visible devices and meet over gloo, so the N > 1
+    # code path can be exercised on a 1-GPU box; the numbers of such a run mean nothing.
+    share = os.environ.get("AVIFGPU_BENCH_SHARE_DEVICE") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if share else local_rank
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
-    ranks = pkg.distrib.Ranks(backend="nccl", device=dev)        # RCCL: barrier + MAX only, no pixel traffic
+    ranks = pkg.distrib.Ranks(backend="gloo" if share else "nccl", device=dev)   # RCCL: barrier + MAX only, no pixel traffic
     rank = ranks.rank
 
-    gpu = pkg.AvifGpu(local_rank)
+    gpu = pkg.AvifGpu(dev_index)
     W, H = args.width, args.height
     chroma = {"444": pkg.CHROMA_444, "422": pkg.CHROMA_422, "420": pkg.CHROMA_420}[args.chroma]
     desc = pkg.WriteDesc(width=W, height=H, depth=32, planes=3, bit_depth=args.bits,
