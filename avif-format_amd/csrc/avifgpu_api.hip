@@ -292,7 +292,11 @@ int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const Wr
     if (d->output == AVIFGPU_OUT_YCBCR) {
         if (d->matrix_coefficients == AVIFGPU_MATRIX_RGB_GBR) {       // lossless, WriteMetadata.cpp:143-146
             if (d->chroma != AVIFGPU_CHROMA_444) return fail(AVIFGPU_formatBadParameters, "identity (GBR) matrix requires 4:4:4");
+            // Y <- G, Cb <- B, Cr <- R as a matrix: 0*R + 1*G + 0*B (+ 0.5, truncate) is the integer code G exactly, so the
+            // kernels need no special case
             p.identity = 1;
+            p.my[1] = 1.0f; p.mcb[2] = 1.0f; p.mcr[0] = 1.0f;
+            p.half = 0.0f;
         } else {
             float kr, kb;
             if (!kr_kb_from_nclx(d->matrix_coefficients, d->color_primaries, kr, kb))

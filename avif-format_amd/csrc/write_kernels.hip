@@ -14,6 +14,7 @@
 // (write_rgb32_ycbcr444_lds) whose global loads are fully coalesced 1-KiB wave transactions.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <type_traits>
 #include "kernel_params.h"
 #include "device_math.h"
 #include "../../include/avifgpu.h"
@@ -199,7 +200,8 @@ AG_DEV void icc16_tetrahedral(const uint16_t* __restrict__ clut, const uint32_t 
 
 // ---- stage A: one source pixel -> integer codes (reference WriteHeifImage.cpp inner loops) --------
 // s[] holds the PLANES raw samples (u8/u16 values, or f32 bit patterns).  q[0..NCOL-1] colour, q[3] alpha.
-template <int DEPTH, int PLANES, int TRANSFER, int ICC = 0>
+// RESCALE8: an 8-bit document saved at 10/12 bit -- decided once per row by the caller where that pays (no alpha), else here.
+template <int DEPTH, int PLANES, int TRANSFER, int ICC = 0, int RESCALE8 = 2>   // 0 no, 1 yes, 2 decide per sample (p.maxv)
 AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t (&q)[4],
                     const int32_t* icc8_lds_s1 = nullptr, const uint8_t* icc8_lds_s2 = nullptr, const uint16_t* lut8 = nullptr)
 {
@@ -260,7 +262,7 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
 #pragma unroll
         for (int k = 0; k < PLANES; ++k) {
             if constexpr (DEPTH == 8) {
-                v[k] = (p.maxv > 255) ? (uint32_t)lut8[sx[k]] : sx[k];        // the reference's 256-entry LUT, :87-112
+                v[k] = (RESCALE8 == 1 || (RESCALE8 == 2 && p.maxv > 255)) ? (uint32_t)lut8[sx[k]] : sx[k];   // the reference's 256-entry LUT, :87-112
             } else {
                 const uint32_t i = sx[k] > 32768u ? 32768u : sx[k];  // reference reads past its LUT here
                 v[k] = exact_rescale(i, 32768.0f, p.maxf, p.maxv);                                   // :114-166
@@ -280,10 +282,11 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
 }
 
 // ---- stage B on integer codes (libheif restatement) --------------------------------
-AG_DEV uint32_t stage_b_luma(const WriteParams& p, const uint32_t (&q)[4])
+// Stage B has no special case for the identity (GBR, lossless) matrix: the host passes my = (0,1,0), mcb = (0,0,1),
+// mcr = (1,0,0), half = 0, and 0*R + 1*G + 0*B (+ 0.5, truncate) returns the integer code G exactly.
+AG_DEV uint32_t luma_code(const WriteParams& p, uint32_t r, uint32_t g, uint32_t b)
 {
-    if (p.identity) return q[1];
-    return clip_round((float)q[0] * p.my[0] + (float)q[1] * p.my[1] + (float)q[2] * p.my[2], p.maxv);
+    return clip_round((float)r * p.my[0] + (float)g * p.my[1] + (float)b * p.my[2], p.maxv);
 }
 
 // ---- generic kernel ----------------------------------------------------------------------------
@@ -412,13 +415,23 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
 #pragma unroll
                     for (int k = 0; k < PLANES; ++k) s[i][k] = 0;
             }
+            auto stage_row = [&](auto rescale8) {
 #pragma unroll
-            for (int i = 0; i < PXT; ++i) {
-                uint32_t q[4] = { 0, 0, 0, 0 };            // gray fills [0] and [3] only
-                stage_a<DEPTH, PLANES, TRANSFER, ICC>(p, s[i], q, icc8_s1, icc8_s2, lut8);
-                if constexpr (!PACK) { qp[vr][i][0] = q[0]; qp[vr][i][1] = q[1]; qp[vr][i][2] = q[2]; qp[vr][i][3] = q[3]; }
-                else if constexpr (DST16) { qp[vr][i][0] = q[0] | (q[1] << 16); qp[vr][i][1] = q[2] | (q[3] << 16); }
-                else qp[vr][i][0] = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
+                for (int i = 0; i < PXT; ++i) {
+                    uint32_t q[4] = { 0, 0, 0, 0 };        // gray fills [0] and [3] only
+                    stage_a<DEPTH, PLANES, TRANSFER, ICC, decltype(rescale8)::value>(p, s[i], q, icc8_s1, icc8_s2, lut8);
+                    if constexpr (!PACK) { qp[vr][i][0] = q[0]; qp[vr][i][1] = q[1]; qp[vr][i][2] = q[2]; qp[vr][i][3] = q[3]; }
+                    else if constexpr (DST16) { qp[vr][i][0] = q[0] | (q[1] << 16); qp[vr][i][1] = q[2] | (q[3] << 16); }
+                    else qp[vr][i][0] = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
+                }
+            };
+            // 8-bit RGB / gray without alpha: one uniform branch per row instead of one per sample (96 scalar branches per
+            // lane-iteration, C2' 0.058 -> 0.054 ms); with alpha the duplicated premultiply code costs a wave of occupancy
+            // (RGBA8 4:2:0 0.075 -> 0.082 ms), so those keep the per-sample test
+            if constexpr (DEPTH == 8 && !ALPHA) {
+                if (p.maxv > 255) stage_row(std::integral_constant<int, 1>{}); else stage_row(std::integral_constant<int, 0>{});
+            } else {
+                stage_row(std::integral_constant<int, 2>{});
             }
         }
 
@@ -453,9 +466,10 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
 #pragma unroll
                 for (int i = 0; i < PXT; ++i) {
                     if constexpr (OUT == kOutRefGray) yv[i] = qget(vr, i, 0);   // planar Y(+A): :247-252
-                    else { const uint32_t q4[4] = { qget(vr, i, 0), qget(vr, i, 1), qget(vr, i, 2), 0 }; yv[i] = stage_b_luma(p, q4); }
-                    av[i] = qget(vr, i, 3);
+                    else yv[i] = luma_code(p, qget(vr, i, 0), qget(vr, i, 1), qget(vr, i, 2));
                 }
+#pragma unroll
+                for (int i = 0; i < PXT; ++i) av[i] = qget(vr, i, 3);
                 store_samples<DST16, PXT, true, ALIGNED>(p.dst[0] + (long long)r * p.dst_stride[0] + (long long)x0 * DSZ, yv, nvalid);
                 if constexpr (ALPHA)
                     store_samples<DST16, PXT, true, ALIGNED>(p.dst[3] + (long long)r * p.dst_stride[3] + (long long)x0 * DSZ, av, nvalid);
@@ -468,7 +482,6 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
                 const int i0 = j << XS;
-                if (p.identity) { cbv[j] = qget(0, i0, 2); crv[j] = qget(0, i0, 0); continue; }   // GBR: Cb<-B, Cr<-R
                 float R = (float)qget(0, i0, 0), G = (float)qget(0, i0, 1), B = (float)qget(0, i0, 2);
                 if constexpr (XS || YS) {
                     if (!p.nearest) {
@@ -601,22 +614,17 @@ __global__ __launch_bounds__(256) void write_rgb32_ycbcr444_hot(const WriteParam
         __builtin_amdgcn_wave_barrier();
 
         uint32_t yv[PXL], cbv[PXL], crv[PXL];
+        auto code = [&](int i, int c) -> uint32_t {
+            const int e = 3 * i + c;
+            return (e & 1) ? (dw[e >> 1] >> 16) : (dw[e >> 1] & 0xffffu);
+        };
 #pragma unroll
         for (int i = 0; i < PXL; ++i) {
-            uint32_t q[4];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int e = 3 * i + c;
-                q[c] = (e & 1) ? (dw[e >> 1] >> 16) : (dw[e >> 1] & 0xffffu);
-            }
-            q[3] = 0;
-            yv[i] = stage_b_luma(p, q);
-            if (p.identity) { cbv[i] = q[2]; crv[i] = q[0]; }
-            else {
-                const float R = (float)q[0], G = (float)q[1], B = (float)q[2];
-                cbv[i] = clip_round(R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2] + p.half, p.maxv);
-                crv[i] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
-            }
+            const uint32_t q0 = code(i, 0), q1 = code(i, 1), q2 = code(i, 2);
+            yv[i] = luma_code(p, q0, q1, q2);
+            const float R = (float)q0, G = (float)q1, B = (float)q2;
+            cbv[i] = clip_round(R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2] + p.half, p.maxv);
+            crv[i] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
         }
         const uint32_t r = sidx / spans_per_row;
         const uint32_t sx = sidx - r * spans_per_row;
@@ -712,10 +720,7 @@ __global__ __launch_bounds__(256) void write_rgb32_ycbcr_sub_hot(const WritePara
             if (r >= p.nrows) continue;                                // odd last row of the tile: replicated for chroma only
             uint32_t yv[PXL];
 #pragma unroll
-            for (int i = 0; i < PXL; ++i) {
-                const uint32_t q[4] = { code(vr, i, 0), code(vr, i, 1), code(vr, i, 2), 0 };
-                yv[i] = stage_b_luma(p, q);
-            }
+            for (int i = 0; i < PXL; ++i) yv[i] = luma_code(p, code(vr, i, 0), code(vr, i, 1), code(vr, i, 2));   // (GBR needs 4:4:4)
             u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
             stream_store<true>(reinterpret_cast<u32x4*>(p.dst[0] + (long long)r * p.dst_stride[0] + xoff), a);
         }
@@ -724,7 +729,6 @@ __global__ __launch_bounds__(256) void write_rgb32_ycbcr_sub_hot(const WritePara
         for (int j = 0; j < 4; ++j) {
             const int i0 = 2 * j;
             constexpr int v1 = YS ? 1 : 0;
-            if (p.identity) { cbv[j] = code(0, i0, 2); crv[j] = code(0, i0, 0); continue; }
             float R = (float)code(0, i0, 0), G = (float)code(0, i0, 1), B = (float)code(0, i0, 2);
             if (!p.nearest) {
                 R = (R + (float)code(0, i0 + 1, 0) + (float)code(v1, i0, 0) + (float)code(v1, i0 + 1, 0)) * 0.25f;
