@@ -170,9 +170,11 @@ AG_DEV void decode_pixel(const ReadParams& p, const Tables<LUT>& t, uint32_t u0,
         if constexpr (DEPTH == 16) { q[0] &= maxc; q[1] &= maxc; q[2] &= maxc; ua &= maxc; }       // :787-790
         if constexpr (DEPTH == 32) { q[0] = min(q[0], maxc); q[1] = min(q[1], maxc); q[2] = min(q[2], maxc); ua = min(ua, maxc); }
         if constexpr (ALPHA) {
-            if (p.premultiplied && ua < maxc) {
+            // The reference skips fully opaque pixels (ua == max); the formula returns the colour unchanged there anyway
+            // (c*max/max == c exactly), so only the ua == 0 case needs a select -- no data-dependent branch.
+            if (p.premultiplied) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) q[k] = (ua == 0) ? 0u : exact_unpremultiply(q[k], ua, (float)p.maxc);
+                for (int k = 0; k < 3; ++k) { const uint32_t u = exact_unpremultiply(q[k], ua, (float)p.maxc); q[k] = (ua == 0) ? 0u : u; }
             }
         }
         if constexpr (DEPTH == 32) {
@@ -198,16 +200,20 @@ AG_DEV void decode_pixel(const ReadParams& p, const Tables<LUT>& t, uint32_t u0,
         if constexpr (CS == kCsMono) {                              // YuvDecode.cpp:55-279
             if constexpr (DEPTH == 32) {
                 if constexpr (ALPHA) {
-                    if (p.premultiplied && ua < maxc)               // integer-domain unpremultiply, :247-260
-                        u0 = (ua == 0) ? 0u : exact_unpremultiply(u0, ua, (float)p.maxc);
+                    if (p.premultiplied) {                          // integer-domain unpremultiply, :247-260 (ua == max: identity)
+                        const uint32_t u = exact_unpremultiply(u0, ua, (float)p.maxc);
+                        u0 = (ua == 0) ? 0u : u;
+                    }
                 }
                 out[0] = __float_as_uint(fast_pq_to_linear_l2(look_y(p, t, u0), p.pq_log2_mult));
                 if constexpr (ALPHA) out[1] = __float_as_uint(look_a(p, t, ua));
             } else {
                 float Y = look_y(p, t, u0);
                 if constexpr (ALPHA) {
-                    if (p.premultiplied && ua < maxc)               // :97-112, :172-185
-                        Y = (ua == 0) ? 0.0f : exact_unpremultiply_f(Y, look_a(p, t, ua));
+                    if (p.premultiplied) {                          // :97-112, :172-185 (A == 1: min(Y / 1, 1) == Y)
+                        const float u = exact_unpremultiply_f(Y, look_a(p, t, ua));
+                        Y = (ua == 0) ? 0.0f : u;
+                    }
                 }
                 out[0] = (uint32_t)(0.5f + (Y * rgb_max));
                 if constexpr (ALPHA) out[1] = (DEPTH == 8) ? ua : (uint32_t)(0.5f + (look_a(p, t, ua) * rgb_max)); // :116, :188
@@ -220,17 +226,18 @@ AG_DEV void decode_pixel(const ReadParams& p, const Tables<LUT>& t, uint32_t u0,
             float G = Y - ct.g;                                                         // :314
             R = clamp01(R); G = clamp01(G); B = clamp01(B);
             if constexpr (ALPHA) {
-                if (p.premultiplied && ua < maxc) {                                     // :369-388
-                    if (ua == 0) { R = 0.0f; G = 0.0f; B = 0.0f; }
-                    else {
-                        const float A = look_a(p, t, ua);
-                        if constexpr (LUT) {                        // bits <= 12: the proven domain
-                            const float r = 1.0f / A;
-                            R = unpremultiply_one(R, A, r); G = unpremultiply_one(G, A, r); B = unpremultiply_one(B, A, r);
-                        } else {
-                            R = exact_unpremultiply_f(R, A); G = exact_unpremultiply_f(G, A); B = exact_unpremultiply_f(B, A);
-                        }
+                if (p.premultiplied) {                                                  // :369-388
+                    // opaque pixels (A == 1): min(c / 1, 1) == c for the clamped colours, so the reference's early-out needs no
+                    // branch; transparent ones (ua == 0, A == 0) take the select below, whatever the division produced
+                    const float A = look_a(p, t, ua);
+                    float uR, uG, uB;
+                    if constexpr (LUT) {                            // bits <= 12: the proven domain
+                        const float r = 1.0f / A;
+                        uR = unpremultiply_one(R, A, r); uG = unpremultiply_one(G, A, r); uB = unpremultiply_one(B, A, r);
+                    } else {
+                        uR = exact_unpremultiply_f(R, A); uG = exact_unpremultiply_f(G, A); uB = exact_unpremultiply_f(B, A);
                     }
+                    R = (ua == 0) ? 0.0f : uR; G = (ua == 0) ? 0.0f : uG; B = (ua == 0) ? 0.0f : uB;
                 }
             }
             if constexpr (DEPTH == 32) {

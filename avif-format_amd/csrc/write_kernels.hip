@@ -270,9 +270,11 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
         }
         const uint32_t a = ALPHA ? v[PLANES - 1] : (uint32_t)p.maxv;
         if constexpr (ALPHA) {
-            if (p.premultiply && a < (uint32_t)p.maxv) {                        // :691-708 etc.
+            if (p.premultiply) {                                                // :691-708 etc.
+                // the reference's early-outs (a == max: unchanged, a == 0: zero) are what the formula returns anyway --
+                // c*max/max == c and c*0/max == 0 exactly -- so no data-dependent branch is needed here
 #pragma unroll
-                for (int k = 0; k < NCOL; ++k) v[k] = (a == 0) ? 0u : exact_premultiply_fast(v[k], a, p.maxf, p.rcp_maxf);
+                for (int k = 0; k < NCOL; ++k) v[k] = exact_premultiply_fast(v[k], a, p.maxf, p.rcp_maxf);
             }
         }
 #pragma unroll
