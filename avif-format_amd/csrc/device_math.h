@@ -118,17 +118,21 @@ AG_DEV float fast_smpte428_to_linear(float value)
 constexpr float kHlgA = 0.17883277f, kHlgB = 0.28466892f, kHlgC = 0.55991073f;
 constexpr float kLn2 = 0.6931471805599453f, kLog2e = 1.4426950408889634f;
 
+// Both pieces are evaluated and selected (v_cndmask): per-sample divergent branches cost more than the one extra
+// transcendental, and every wave of a real image takes both sides anyway.
 AG_DEV float fast_linear_to_hlg(float value)
 {
-    if (!(value >= 0.0f)) return 0.0f;
-    if (value > (1.0f / 12.0f)) return __builtin_fmaf(kHlgA * kLn2, nat_log2(value * 12.0f - kHlgB), kHlgC);
-    return nat_sqrt(value * 3.0f);
+    const float hi = __builtin_fmaf(kHlgA * kLn2, nat_log2(fmaxf(value * 12.0f - kHlgB, 1e-30f)), kHlgC);
+    const float lo = nat_sqrt(fmaxf(value, 0.0f) * 3.0f);
+    const float r = value > (1.0f / 12.0f) ? hi : lo;
+    return value >= 0.0f ? r : 0.0f;                          // negative and NaN -> 0
 }
 AG_DEV float fast_hlg_to_linear(float value)
 {
-    if (!(value >= 0.0f)) return 0.0f;
-    if (value > 0.5f) return (nat_exp2((value - kHlgC) * (kLog2e / kHlgA)) + kHlgB) * (1.0f / 12.0f);
-    return (value * value) * (1.0f / 3.0f);
+    const float hi = (nat_exp2((value - kHlgC) * (kLog2e / kHlgA)) + kHlgB) * (1.0f / 12.0f);
+    const float lo = (value * value) * (1.0f / 3.0f);
+    const float r = value > 0.5f ? hi : lo;
+    return value >= 0.0f ? r : 0.0f;
 }
 
 // ---- exact tier -------------------------------------------------------------------------------
