@@ -210,3 +210,27 @@ def test_host_shim_converts_16bit_document_to_srgb(gpu, lcms):
     got = np.frombuffer(raw, dtype=np.uint8).reshape(d.height, img.stride[0])[:, :d.width * 6].view(np.uint16)
     assert np.array_equal(got, want[0])
     gpu.lib.avifgpu_image_free(ctypes.byref(img))
+
+
+@pytest.mark.gpu
+def test_icc_tables_are_bound_to_their_document_depth(gpu, lcms):
+    """A 16-bit table on an 8-bit document (and vice versa), or a table with a foreign grid size, is a caller error."""
+    icc = _profile(lcms, 3, 0, 2.19921875)
+    clut = gpu.icc_prepare_clut16(icc)
+    sh8 = gpu.icc_prepare_shaper8(icc)
+    d8 = pkg.WriteDesc(width=16, height=2, depth=8, planes=3, bit_depth=8, output=pkg.OUT_REFERENCE)
+    d16 = pkg.WriteDesc(width=16, height=2, depth=16, planes=3, bit_depth=10, output=pkg.OUT_REFERENCE)
+    for d, table in ((d8, clut), (d16, sh8)):
+        with pytest.raises(pkg.AvifGpuError) as e:
+            _gpu(gpu, d, harness.make_write_source(d), table)
+        assert e.value.code == pkg.formatBadParameters
+    bad = pkg.IccClut16()
+    ctypes.memmove(ctypes.byref(bad), ctypes.byref(clut), ctypes.sizeof(bad))
+    bad.grid_points = 17
+    with pytest.raises(pkg.AvifGpuError) as e:
+        _gpu(gpu, d16, harness.make_write_source(d16), bad)
+    assert e.value.code == pkg.formatBadParameters
+    gray = pkg.WriteDesc(width=16, height=2, depth=16, planes=2, bit_depth=10, alpha_state=pkg.ALPHA_STRAIGHT, output=pkg.OUT_REFERENCE)
+    with pytest.raises(pkg.AvifGpuError) as e:
+        _gpu(gpu, gray, harness.make_write_source(gray), clut)
+    assert e.value.code == pkg.formatBadParameters
