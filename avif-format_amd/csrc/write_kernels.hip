@@ -748,6 +748,82 @@ __global__ __launch_bounds__(256) void write_rgb32_ycbcr_sub_hot(const WritePara
     }
 }
 
+// ---- RGBA f32 -> Y, Cb, Cr, A planes (4:4:4, BASELINE config C5): the streaming structure with one float4 = one pixel ----
+// A wave owns 256 consecutive pixels of a row.  Lane l loads pixels 64k + l (k = 0..3): four fully coalesced 1-KiB
+// non-temporal wave-loads.  Alpha clamp / premultiply / curve per pixel as loaded; the four u16 codes of a pixel go to the
+// wave-private strip as one 8-byte write, then lane l reads back pixels [4l, 4l+4) (two ds_read_b128 at a padded 12-dword lane
+// stride: conflict-free for the 16-lane service groups) and writes 8 contiguous bytes per plane, non-temporal.
+#ifndef AG_RGBA_HOT_PXL
+#define AG_RGBA_HOT_PXL 4
+#endif
+template <int TRANSFER>
+__global__ __launch_bounds__(256) void write_rgba32_ycbcra444_hot(const WriteParams p)
+{
+    constexpr int PXL = AG_RGBA_HOT_PXL, SPAN_PX = 64 * PXL;
+    constexpr int LSTRIDE = PXL == 4 ? 12 : 20;                        // dwords per lane in the strip (2 * PXL used + 4 pad)
+    __shared__ __attribute__((aligned(16))) uint32_t strip[4][64 * LSTRIDE];
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    uint32_t* my = strip[wave];
+
+    const uint32_t spans_per_row = (uint32_t)p.width / SPAN_PX;        // host guarantees divisibility and alignment
+    const uint32_t total = spans_per_row * (uint32_t)p.nrows;
+    for (uint32_t sidx = blockIdx.x * 4 + wave; sidx < total; sidx += gridDim.x * 4) {
+        const uint32_t r = sidx / spans_per_row;
+        const uint32_t sx = sidx - r * spans_per_row;
+        const f32x4* sp = reinterpret_cast<const f32x4*>(p.src + (long long)r * p.src_row_bytes) + (long long)sx * SPAN_PX;
+        f32x4 v[PXL];
+#pragma unroll
+        for (int k = 0; k < PXL; ++k) v[k] = stream_load<true>(sp + 64 * k + lane);
+#pragma unroll
+        for (int k = 0; k < PXL; ++k) {
+            float col[3] = { v[k].x, v[k].y, v[k].z };
+            const float a = cxx_clamp(v[k].w, 0.0f, 1.0f);                          // WriteHeifImage.cpp:1047
+            if (p.premultiply && a < 1.0f) {                                        // :1049-1066
+#pragma unroll
+                for (int c = 0; c < 3; ++c) col[c] = (a == 0.0f) ? 0.0f : cxx_clamp(col[c], 0.0f, 1.0f) * a;
+            }
+            const uint32_t c0 = oetf_code<TRANSFER>(p, col[0]), c1 = oetf_code<TRANSFER>(p, col[1]), c2 = oetf_code<TRANSFER>(p, col[2]);
+            const uint32_t c3 = (uint32_t)__builtin_amdgcn_fmed3f(a * p.maxf, 0.0f, p.maxf);   // :1096
+            const int pidx = 64 * k + lane;
+            u32x2 pk = { c0 | (c1 << 16), c2 | (c3 << 16) };
+            *reinterpret_cast<u32x2*>(my + (pidx / PXL) * LSTRIDE + (pidx % PXL) * 2) = pk;
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t dw[2 * PXL];
+#pragma unroll
+        for (int j = 0; j < PXL / 2; ++j) {
+            const u32x4 t = *reinterpret_cast<const u32x4*>(my + lane * LSTRIDE + 4 * j);
+            dw[4 * j] = t.x; dw[4 * j + 1] = t.y; dw[4 * j + 2] = t.z; dw[4 * j + 3] = t.w;
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t yv[PXL], cbv[PXL], crv[PXL], av[PXL];
+#pragma unroll
+        for (int i = 0; i < PXL; ++i) {
+            const uint32_t q0 = dw[2 * i] & 0xffffu, q1 = dw[2 * i] >> 16, q2 = dw[2 * i + 1] & 0xffffu;
+            av[i] = dw[2 * i + 1] >> 16;
+            yv[i] = luma_code(p, q0, q1, q2);
+            const float R = (float)q0, G = (float)q1, B = (float)q2;
+            cbv[i] = clip_round(R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2] + p.half, p.maxv);
+            crv[i] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
+        }
+        const long long xoff = ((long long)sx * SPAN_PX + (long long)PXL * lane) * 2;
+        const uint32_t* planes_v[4] = { yv, cbv, crv, av };
+#pragma unroll
+        for (int pl = 0; pl < 4; ++pl) {
+            const uint32_t* q = planes_v[pl];
+            uint8_t* dst = p.dst[pl] + (long long)r * p.dst_stride[pl] + xoff;
+            if constexpr (PXL == 4) {
+                u32x2 o = { q[0] | (q[1] << 16), q[2] | (q[3] << 16) };
+                stream_store<true>(reinterpret_cast<u32x2*>(dst), o);
+            } else {
+                u32x4 o = { q[0] | (q[1] << 16), q[2] | (q[3] << 16), q[4] | (q[5] << 16), q[6] | (q[7] << 16) };
+                stream_store<true>(reinterpret_cast<u32x4*>(dst), o);
+            }
+        }
+    }
+}
+
 // ---- dispatch --------------------------------------------------------------------------------------
 static inline int grid_for(long long threads_needed)
 {
@@ -881,6 +957,31 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
     // hot path: RGB f32 (no alpha) -> YCbCr 4:4:4 u16 with aligned rows; `variant` is a tuning word:
     //   bit0 enable, bit1 PXL=8 (else 4), bit2 non-temporal, bit3 prefetch, bit4 XCD-contiguous mapping;
     //   bits 8.. = blocks (0 = default).
+#ifndef AG_RGBA_HOT_ENABLE
+#define AG_RGBA_HOT_ENABLE 1
+#endif
+    if (AG_RGBA_HOT_ENABLE && (variant & 1) && p.icc_trc_type[0] == 0 && depth == 32 && planes == 4 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 0 && ys == 0 &&
+        (p.width % (64 * AG_RGBA_HOT_PXL)) == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 && p.dst[3] != nullptr &&
+        ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |
+          reinterpret_cast<uintptr_t>(p.dst[3]) | (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2] |
+          (uintptr_t)p.dst_stride[3]) & 15) == 0) {
+        const long long spans = (long long)(p.width / (64 * AG_RGBA_HOT_PXL)) * p.nrows;
+        if (spans == 0) return hipSuccess;
+        if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
+            long long blocks = (spans + 3) / 4;
+            if (blocks > 256LL * 64) blocks = 256LL * 64;
+            static thread_local char label[96];
+            snprintf(label, sizeof(label), "write_rgba32_ycbcra444_hot<transfer=%d>", p.transfer);
+            *name = label;
+            switch (p.transfer) {
+            case AVIFGPU_TRANSFER_PQ:       hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<AVIFGPU_TRANSFER_PQ>), dim3((int)blocks), dim3(256), 0, st, p); break;
+            case AVIFGPU_TRANSFER_HLG:      hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<AVIFGPU_TRANSFER_HLG>), dim3((int)blocks), dim3(256), 0, st, p); break;
+            case AVIFGPU_TRANSFER_SMPTE428: hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<AVIFGPU_TRANSFER_SMPTE428>), dim3((int)blocks), dim3(256), 0, st, p); break;
+            default:                        hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<AVIFGPU_TRANSFER_CLIP>), dim3((int)blocks), dim3(256), 0, st, p); break;
+            }
+            return hipGetLastError();
+        }
+    }
     if ((variant & 1) && p.icc_trc_type[0] == 0 && depth == 32 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 1 &&
         (p.width % 512) == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |

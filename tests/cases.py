@@ -107,6 +107,18 @@ def write_cases():
         ("ycc-d32-p3-b10-422-hot-hlg", dict(width=1536, height=3, depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_HLG,
                                             alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_422,
                                             matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020)),
+        # ... and the RGBA f32 -> Y, Cb, Cr, A streaming kernel (width % 256 == 0): straight + premultiplied alpha
+        ("ycc-d32-p4-b12-444-hot-straight", dict(width=512, height=5, depth=32, planes=4, bit_depth=12, transfer=pkg.TRANSFER_PQ,
+                                                 peak_nits=1000, alpha_state=pkg.ALPHA_STRAIGHT, output=pkg.OUT_YCBCR,
+                                                 chroma=pkg.CHROMA_444, matrix_coefficients=pkg.MATRIX_BT2020_NCL,
+                                                 color_primaries=pkg.PRIMARIES_BT2020)),
+        ("ycc-d32-p4-b10-444-hot-premul-clip", dict(width=256, height=6, depth=32, planes=4, bit_depth=10,
+                                                    transfer=pkg.TRANSFER_CLIP, alpha_state=pkg.ALPHA_PREMULTIPLIED,
+                                                    output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444,
+                                                    matrix_coefficients=pkg.MATRIX_BT601)),
+        ("ycc-d32-p4-b10-444-hot-gbr-428", dict(width=768, height=3, depth=32, planes=4, bit_depth=10,
+                                                transfer=pkg.TRANSFER_SMPTE428, alpha_state=pkg.ALPHA_STRAIGHT, output=pkg.OUT_YCBCR,
+                                                chroma=pkg.CHROMA_444, matrix_coefficients=pkg.MATRIX_RGB_GBR)),
         # BASELINE.json config 1 at its real size: 512x512 RGBA8 -> 8-bit 4:2:0 BT.709
         ("baseline-c1-512", dict(width=512, height=512, depth=8, planes=4, bit_depth=8, alpha_state=pkg.ALPHA_STRAIGHT,
                                  output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420, matrix_coefficients=pkg.MATRIX_BT709)),

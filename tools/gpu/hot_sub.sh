@@ -1,2 +1,2 @@
 timeout 900 python -m pytest tests/test_gpu_write.py tests/test_gpu_tiles.py tests/test_gpu_fullsize.py tests/test_gpu_fullsize_roundtrip.py tests/test_gpu_fuzz.py -m gpu -q -x 2>&1 | tail -5
-python tools/bench_configs.py "C4 8192" 2>/dev/null | cut -c1-330
+python tools/bench_configs.py "C5" "C4 8192^2 RGB f32 -> 10-bit PQ 4:4:4" 2>/dev/null | cut -c1-330
