@@ -824,6 +824,53 @@ __global__ __launch_bounds__(256) void write_rgba32_ycbcra444_hot(const WritePar
     }
 }
 
+// ---- RGB(A) f32 -> interleaved RRGGBB(AA) u16: the reference's own hand-off (CreateHeifImageRGBThirtyTwoBit) ------------------
+// Output sample i is a function of input sample i (RGB) or of its own pixel's float4 (RGBA): no transposition at all.  A wave
+// streams 64 x 4 float4 per trip: coalesced non-temporal 16-byte loads, the curve, 8-byte non-temporal stores at the same index.
+template <int TRANSFER, int PLANES>
+__global__ __launch_bounds__(256) void write_f32_ref_stream(const WriteParams p)
+{
+    constexpr int K = 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t n4 = (uint32_t)p.width * PLANES / 4;                // float4 per row (host: width * PLANES % 4 == 0)
+    const uint32_t chunks = (n4 + 64 * K - 1) / (64 * K);
+    const uint32_t total = chunks * (uint32_t)p.nrows;
+    for (uint32_t widx = blockIdx.x * 4 + wave; widx < total; widx += gridDim.x * 4) {
+        const uint32_t r = widx / chunks;
+        const uint32_t c = widx - r * chunks;
+        const f32x4* sp = reinterpret_cast<const f32x4*>(p.src + (long long)r * p.src_row_bytes);
+        u32x2* dp = reinterpret_cast<u32x2*>(p.dst[0] + (long long)r * p.dst_stride[0]);
+        f32x4 v[K];
+        uint32_t idx[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            idx[k] = c * (64 * K) + 64 * k + lane;
+            if (idx[k] < n4) v[k] = stream_load<true>(sp + idx[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (idx[k] >= n4) continue;
+            float s0 = v[k].x, s1 = v[k].y, s2 = v[k].z, s3 = v[k].w;
+            uint32_t c0, c1, c2, c3;
+            if constexpr (PLANES == 4) {
+                const float a = cxx_clamp(s3, 0.0f, 1.0f);                          // WriteHeifImage.cpp:1047
+                if (p.premultiply && a < 1.0f) {                                    // :1049-1066
+                    s0 = (a == 0.0f) ? 0.0f : cxx_clamp(s0, 0.0f, 1.0f) * a;
+                    s1 = (a == 0.0f) ? 0.0f : cxx_clamp(s1, 0.0f, 1.0f) * a;
+                    s2 = (a == 0.0f) ? 0.0f : cxx_clamp(s2, 0.0f, 1.0f) * a;
+                }
+                c3 = (uint32_t)__builtin_amdgcn_fmed3f(a * p.maxf, 0.0f, p.maxf);   // :1096
+            } else {
+                c3 = oetf_code<TRANSFER>(p, s3);
+            }
+            c0 = oetf_code<TRANSFER>(p, s0); c1 = oetf_code<TRANSFER>(p, s1); c2 = oetf_code<TRANSFER>(p, s2);
+            u32x2 o = { c0 | (c1 << 16), c2 | (c3 << 16) };
+            stream_store<true>(dp + idx[k], o);
+        }
+    }
+}
+
 // ---- dispatch --------------------------------------------------------------------------------------
 static inline int grid_for(long long threads_needed)
 {
@@ -957,6 +1004,30 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
     // hot path: RGB f32 (no alpha) -> YCbCr 4:4:4 u16 with aligned rows; `variant` is a tuning word:
     //   bit0 enable, bit1 PXL=8 (else 4), bit2 non-temporal, bit3 prefetch, bit4 XCD-contiguous mapping;
     //   bits 8.. = blocks (0 = default).
+    if ((variant & 1) && p.icc_trc_type[0] == 0 && depth == 32 && planes >= 3 && dst16 && output == AVIFGPU_OUT_REFERENCE &&
+        ((long long)p.width * planes) % 4 == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
+        ((reinterpret_cast<uintptr_t>(p.dst[0]) | (uintptr_t)p.dst_stride[0]) & 7) == 0) {
+        const long long n4 = (long long)p.width * planes / 4;
+        const long long waves = ((n4 + 255) / 256) * p.nrows;
+        if (waves == 0) return hipSuccess;
+        if (waves + 8LL * 65536 * 4 < 0x7fffffffLL) {
+            long long blocks = (waves + 3) / 4;
+            if (blocks > 256LL * 64) blocks = 256LL * 64;
+            static thread_local char label[96];
+            snprintf(label, sizeof(label), "write_f32_ref_stream<transfer=%d,planes=%d>", p.transfer, planes);
+            *name = label;
+#define AG_REF(TR) do { if (planes == 4) hipLaunchKernelGGL((write_f32_ref_stream<TR, 4>), dim3((int)blocks), dim3(256), 0, st, p); \
+                        else hipLaunchKernelGGL((write_f32_ref_stream<TR, 3>), dim3((int)blocks), dim3(256), 0, st, p); } while (0)
+            switch (p.transfer) {
+            case AVIFGPU_TRANSFER_PQ:       AG_REF(AVIFGPU_TRANSFER_PQ); break;
+            case AVIFGPU_TRANSFER_HLG:      AG_REF(AVIFGPU_TRANSFER_HLG); break;
+            case AVIFGPU_TRANSFER_SMPTE428: AG_REF(AVIFGPU_TRANSFER_SMPTE428); break;
+            default:                        AG_REF(AVIFGPU_TRANSFER_CLIP); break;
+            }
+#undef AG_REF
+            return hipGetLastError();
+        }
+    }
 #ifndef AG_RGBA_HOT_ENABLE
 #define AG_RGBA_HOT_ENABLE 1
 #endif
