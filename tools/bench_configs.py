@@ -133,6 +133,9 @@ if __name__ == "__main__":
     bench_write("C4 8192^2 RGB f32 -> 10-bit PQ interleaved RRGGBB (reference hand-off)", width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=0)
     bench_write("C5 16384^2 RGBA f32 -> 12-bit PQ 4:4:4 + alpha", width=16384, height=16384, depth=32, planes=4, bit_depth=12, transfer=0, peak_nits=80, alpha_state=1, output=1, chroma=P.CHROMA_444, matrix_coefficients=9, color_primaries=9)
     bench_write("RGBA8 premultiplied -> 8-bit interleaved (reference hand-off) 8192^2", width=8192, height=8192, depth=8, planes=4, bit_depth=8, alpha_state=2, output=0)
+    bench_write("REF RGB16 -> 12-bit interleaved (reference hand-off) 8192^2", width=8192, height=8192, depth=16, planes=3, bit_depth=12, alpha_state=0, output=0)
+    bench_write("REF RGB8 -> 8-bit interleaved (reference hand-off = copy) 8192^2", width=8192, height=8192, depth=8, planes=3, bit_depth=8, alpha_state=0, output=0)
+    bench_write("REF RGBA16 premultiplied -> 10-bit interleaved (reference hand-off) 8192^2", width=8192, height=8192, depth=16, planes=4, bit_depth=10, alpha_state=2, output=0)
     bench_write("Gray16+alpha premultiplied -> 12-bit Y + A planes 8192^2", width=8192, height=8192, depth=16, planes=2, bit_depth=12, alpha_state=2, output=0)
     bench_write("Gray32 -> 10-bit PQ Y plane 8192^2", width=8192, height=8192, depth=32, planes=1, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=0)
     icc_lib = os.path.join(ROOT, "oracle", "liboracle_icc.so")
