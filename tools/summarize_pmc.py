@@ -13,7 +13,7 @@ import re
 import sys
 
 LAUNCHES = 210
-PAT = re.compile(r"write_px|read_px|write_rgb32")
+PAT = re.compile(r"write_px|read_px|write_rgb32|write_rgba32|write_f32_ref|write_int_ref")
 
 
 def rows(path_glob):
