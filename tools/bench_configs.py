@@ -169,4 +169,6 @@ if __name__ == "__main__":
     bench_read("R32 8192^2 12-bit 4:2:0 BT.2020 PQ + alpha -> RGBA f32", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_420, bit_depth=12, depth=32, alpha_state=1, matrix_coefficients=9, color_primaries=9, transfer_characteristics=16, pq_peak_nits=80)
     bench_read("R32 8192^2 10-bit 4:4:4 BT.2020 PQ -> RGB f32", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_444, bit_depth=10, depth=32, alpha_state=0, matrix_coefficients=9, color_primaries=9, transfer_characteristics=16, pq_peak_nits=80)
     bench_read("R32 8192^2 10-bit 4:2:0 BT.2020 HLG+OOTF -> RGB f32", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_420, bit_depth=10, depth=32, alpha_state=0, matrix_coefficients=9, color_primaries=9, transfer_characteristics=18, hlg_apply_ootf=1, hlg_display_gamma=1.2, hlg_peak_nits=1000)
+    bench_read("R8 8192^2 8-bit planar RGB (lossless GBR) -> RGB8", width=8192, height=8192, colorspace=1, chroma=P.CHROMA_444, bit_depth=8, depth=8, alpha_state=0, matrix_coefficients=0)
+    bench_read("R16 8192^2 12-bit planar RGB + alpha premult -> RGBA16", width=8192, height=8192, colorspace=1, chroma=P.CHROMA_444, bit_depth=12, depth=16, alpha_state=2, matrix_coefficients=0)
     bench_read("R32 8192^2 12-bit planar RGB PQ -> RGB f32", width=8192, height=8192, colorspace=1, chroma=P.CHROMA_444, bit_depth=12, depth=32, alpha_state=0, matrix_coefficients=0, color_primaries=9, transfer_characteristics=16, pq_peak_nits=80)
