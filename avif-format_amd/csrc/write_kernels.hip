@@ -942,13 +942,21 @@ __global__ __launch_bounds__(256) void write_int_ref_stream(const WriteParams p)
 }
 
 // ---- dispatch --------------------------------------------------------------------------------------
+#ifndef AG_RGBA_BLOCK_CAP
+#define AG_RGBA_BLOCK_CAP (256LL * 512)       // C5 (1 M spans): 1.18 ms at 16k blocks, 1.01 at 64k, 0.99 at 128k, 1.01 at 256k
+#endif
+#ifndef AG_STREAM_BLOCK_CAP
+#define AG_STREAM_BLOCK_CAP (256LL * 512)     // grid cap of the streaming kernels (grid-stride beyond it); see AG_WRITE_BLOCK_CAP
+#endif
 static inline int grid_for(long long threads_needed)
 {
     long long blocks = (threads_needed + 255) / 256;
 #ifndef AG_WRITE_BLOCK_CAP
-#define AG_WRITE_BLOCK_CAP (256LL * 64)
+#define AG_WRITE_BLOCK_CAP (256LL * 512)
 #endif
-    const long long cap = AG_WRITE_BLOCK_CAP;   // grid-stride beyond 16k blocks (larger grids measured faster than 2-4k)
+    // 8192^2 frames are indifferent to 16k...128k blocks; 16384^2 frames are not (RGB16 -> 12-bit 4:4:4: 0.684 ms at 16k,
+    // 0.543 ms at 128k -- profiles/r01/ab_write_variants.txt): keep a wave's grid-stride loop short
+    const long long cap = AG_WRITE_BLOCK_CAP;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
@@ -1083,7 +1091,7 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
         if (waves == 0) return hipSuccess;
         if (waves + 8LL * 65536 * 4 < 0x7fffffffLL) {
             long long blocks = (waves + 3) / 4;
-            if (blocks > 256LL * 64) blocks = 256LL * 64;
+            if (blocks > AG_STREAM_BLOCK_CAP) blocks = AG_STREAM_BLOCK_CAP;
             static thread_local char label[96];
             snprintf(label, sizeof(label), "write_int_ref_stream<depth=%d,planes=%d,dst16=%d>", depth, planes, (int)dst16);
             *name = label;
@@ -1102,7 +1110,7 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
         if (waves == 0) return hipSuccess;
         if (waves + 8LL * 65536 * 4 < 0x7fffffffLL) {
             long long blocks = (waves + 3) / 4;
-            if (blocks > 256LL * 64) blocks = 256LL * 64;
+            if (blocks > AG_STREAM_BLOCK_CAP) blocks = AG_STREAM_BLOCK_CAP;
             static thread_local char label[96];
             snprintf(label, sizeof(label), "write_f32_ref_stream<transfer=%d,planes=%d>", p.transfer, planes);
             *name = label;
@@ -1130,7 +1138,7 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
         if (spans == 0) return hipSuccess;
         if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
             long long blocks = (spans + 3) / 4;
-            if (blocks > 256LL * 64) blocks = 256LL * 64;
+            if (blocks > AG_RGBA_BLOCK_CAP) blocks = AG_RGBA_BLOCK_CAP;
             static thread_local char label[96];
             snprintf(label, sizeof(label), "write_rgba32_ycbcra444_hot<transfer=%d>", p.transfer);
             *name = label;
@@ -1151,7 +1159,7 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
         if (spans == 0) return hipSuccess;
         if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
             long long blocks = (spans + 3) / 4;
-            if (blocks > 256LL * 64) blocks = 256LL * 64;
+            if (blocks > AG_STREAM_BLOCK_CAP) blocks = AG_STREAM_BLOCK_CAP;
             static thread_local char label[96];
             snprintf(label, sizeof(label), "write_rgb32_ycbcr_sub_hot<transfer=%d,xs=1,ys=%d>", p.transfer, ys);
             *name = label;
@@ -1178,7 +1186,7 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
             if (spans == 0) return hipSuccess;
             if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
             long long blocks = (spans + 3) / 4;
-            const long long cap = (variant >> 8) ? (variant >> 8) : 256LL * 64;
+            const long long cap = (variant >> 8) ? (variant >> 8) : 256LL * 512;   // 8192^2: one span per wave (32k blocks) measured 5-6 % faster than two (16k)
             if (blocks > cap) blocks = cap;
             if (xm) blocks = (blocks + 7) & ~7LL;
             static thread_local char label[96];
