@@ -62,16 +62,17 @@ def test_tables_reproduce_lcms2_on_every_rgb_triple(lcms, name, kind, trc, g):
     src = _all_rgb()
     want = src.copy()
     assert lcms.oracle_icc_convert_rows_to_srgb8(icc, len(icc), 0, want.ctypes.data, 4096, 4096, want.strides[0]) == 0
-    s1 = np.array(sh.shaper1, dtype=np.int64)
-    M = np.array(sh.matrix, dtype=np.int64)
+    s1 = np.array(sh.shaper1, dtype=np.int32)
+    M = np.array(sh.matrix, dtype=np.int32)
     s2 = np.array(sh.shaper2, dtype=np.uint8)
-    px = src.reshape(-1, 3)
-    R, G, B = s1[0][px[:, 0]], s1[1][px[:, 1]], s1[2][px[:, 2]]
-    out = np.empty_like(px)
-    for i in range(3):                                       # MatShaperEval16
-        l = np.clip((M[i, 0] * R + M[i, 1] * G + M[i, 2] * B + 0x2000) >> 14, 0, 16384)
-        out[:, i] = s2[i][l]
-    assert np.array_equal(out, want.reshape(-1, 3)), name
+    px_all, want_all = src.reshape(-1, 3), want.reshape(-1, 3)
+    step = 1 << 20                                           # chunked: 16 M-element int64 temporaries cost more in page faults than in math
+    for lo in range(0, len(px_all), step):
+        px = px_all[lo:lo + step]
+        R, G, B = s1[0][px[:, 0]], s1[1][px[:, 1]], s1[2][px[:, 2]]
+        for i in range(3):                                   # MatShaperEval16 (products fit int32: |m| * 16384 * 3 < 2^31 for these profiles)
+            l = np.clip((M[i, 0] * R + M[i, 1] * G + M[i, 2] * B + 0x2000) >> 14, 0, 16384)
+            assert np.array_equal(s2[i][l], want_all[lo:lo + step, i]), (name, lo, i)
 
 
 def test_prepare_rejects_non_profiles():
