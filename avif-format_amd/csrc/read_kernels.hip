@@ -363,7 +363,11 @@ template <int CS, int DEPTH, bool ALPHA, int XS> struct ReadShape {
 #ifndef AG_MONO8_NC
 #define AG_MONO8_NC 16   /* 16-byte loads and stores: 0.037 -> 0.030 ms at 8192^2 */
 #endif
-    static constexpr int NC8 = CS == 2 ? (ALPHA ? 8 : AG_MONO8_NC) : ((CS == 0 && (XS == 0 || ALPHA)) ? AG_R8_NC_SMALL : AG_R8_NC);
+#ifndef AG_R8_NC_444
+#define AG_R8_NC_444 8   /* 4:4:4 without alpha: 4 -> 0.095 ms, 8 -> 0.088 ms, 16 -> 0.097 ms at 8192^2 */
+#endif
+    static constexpr int NC8 = CS == 2 ? (ALPHA ? 8 : AG_MONO8_NC)
+                             : ((CS == 0 && XS == 0 && !ALPHA) ? AG_R8_NC_444 : ((CS == 0 && (XS == 0 || ALPHA)) ? AG_R8_NC_SMALL : AG_R8_NC));
     static constexpr int NC = DEPTH == 8 ? NC8 : (CS == 1 ? AG_RGB16_NC : (CS == 2 ? (DEPTH == 32 ? 4 : AG_MONO16_NC) : AG_R16_NC));
     static constexpr int PXT = NC << XS;
 };
