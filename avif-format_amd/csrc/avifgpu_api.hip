@@ -51,7 +51,8 @@ struct Context {
     std::mutex mu;
     bool ready = false;
     int device = -1;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;         // slot 0 / the synchronous host-pointer entry points
+    hipStream_t stream1 = nullptr;        // slot 1: tile k+1's H2D overlaps tile k's D2H (PCIe is full duplex)
     // device staging for host-pointer calls: two slots so the host shim can have one tile in flight while the
     // host fills / drains the other (grown on demand, reused across tiles)
     struct Slot {
@@ -457,6 +458,7 @@ int32_t avifgpu_init(int32_t device_index)
         // events and staging first instead of silently reusing them on the new device.
         (void)hipSetDevice(g_ctx.device);
         (void)hipStreamSynchronize(g_ctx.stream);
+        (void)hipStreamSynchronize(g_ctx.stream1);
         for (auto& sl : g_ctx.slot) {
             if (sl.d_in) (void)hipFree(sl.d_in);
             if (sl.d_out) (void)hipFree(sl.d_out);
@@ -464,10 +466,13 @@ int32_t avifgpu_init(int32_t device_index)
             sl = Context::Slot();
         }
         (void)hipStreamDestroy(g_ctx.stream);
-        g_ctx.stream = nullptr; g_ctx.ready = false; g_ctx.device = -1;
+        (void)hipStreamDestroy(g_ctx.stream1);
+        g_ctx.stream = nullptr; g_ctx.stream1 = nullptr; g_ctx.ready = false; g_ctx.device = -1;
     }
     if ((e = hipSetDevice(device_index)) != hipSuccess) return hip_fail(e, "hipSetDevice", AVIFGPU_formatBadParameters);
     if (!g_ctx.stream && (e = hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking)) != hipSuccess)
+        return hip_fail(e, "hipStreamCreate", AVIFGPU_memFullErr);
+    if (!g_ctx.stream1 && (e = hipStreamCreateWithFlags(&g_ctx.stream1, hipStreamNonBlocking)) != hipSuccess)
         return hip_fail(e, "hipStreamCreate", AVIFGPU_memFullErr);
     for (auto& sl : g_ctx.slot)
         if (!sl.done && (e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming)) != hipSuccess)
@@ -493,7 +498,8 @@ void avifgpu_shutdown(void)
         sl = Context::Slot();
     }
     (void)hipStreamDestroy(g_ctx.stream);
-    g_ctx.stream = nullptr; g_ctx.ready = false; g_ctx.device = -1;
+    (void)hipStreamDestroy(g_ctx.stream1);
+    g_ctx.stream = nullptr; g_ctx.stream1 = nullptr; g_ctx.ready = false; g_ctx.device = -1;
 }
 
 int32_t avifgpu_get_yuv_coefficients(int32_t has_nclx, int32_t matrix_coefficients, int32_t color_primaries, float out[3])
@@ -707,7 +713,7 @@ int write_rows_host_enqueue(const avifgpu_write_desc* d, int row0, int nrows, co
 
     std::lock_guard<std::mutex> lk(g_ctx.mu);
     Context::Slot& sl = g_ctx.slot[slot & 1];
-    hipStream_t st = g_ctx.stream;
+    hipStream_t st = (slot & 1) ? g_ctx.stream1 : g_ctx.stream;     // one stream per staging slot
     const int64_t min_src_row = (int64_t)d->width * d->planes * (d->depth / 8);
     const size_t in_pitch = align256((size_t)min_src_row);
     if ((err = ensure(&sl.d_in, &sl.d_in_cap, in_pitch * (size_t)nrows))) return err;
@@ -754,7 +760,7 @@ int read_rows_host_enqueue(const avifgpu_read_desc* d, int row0, int nrows, cons
 
     std::lock_guard<std::mutex> lk(g_ctx.mu);
     Context::Slot& sl = g_ctx.slot[slot & 1];
-    hipStream_t st = g_ctx.stream;
+    hipStream_t st = (slot & 1) ? g_ctx.stream1 : g_ctx.stream;     // one stream per staging slot
     const int64_t min_dst_row = (int64_t)d->width * g.nch * (d->depth / 8);
     size_t off[4] = {0, 0, 0, 0}, pitch[4] = {0, 0, 0, 0}, in_total = 0;
     int prow[4] = {0, 0, 0, 0}; int64_t pbytes[4] = {0, 0, 0, 0};
