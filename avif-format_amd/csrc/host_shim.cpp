@@ -17,6 +17,8 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <mutex>
+#include <set>
 #include <new>
 #include <stdexcept>
 
@@ -365,6 +367,11 @@ template <typename F> OSErr guarded(F&& f, OSErr fallback)
 
 using namespace avifgpu::host;
 
+namespace {
+std::mutex g_pinned_mu;
+std::set<void*> g_pinned;          // plane blocks avifgpu_image_alloc obtained from hipHostMalloc
+}
+
 extern "C" {
 
 avifgpu_OSErr avifgpu_image_alloc(avifgpu_image* img)
@@ -393,8 +400,14 @@ avifgpu_OSErr avifgpu_image_alloc(avifgpu_image* img)
     }
     const bool wantAlpha = img->has_alpha && !(img->colorspace == AVIFGPU_COLORSPACE_RGB && img->chroma >= 10);
     if (wantAlpha) { w[3] = img->width; h[3] = img->height; img->stride[3] = ((w[3] * ssz) + 15) & ~15; off[3] = total; total += (size_t)img->stride[3] * h[3]; }
+    // Pinned when a device is bound (the planes are the D2H target of every tile: pageable memory makes that copy the serial
+    // part of the save pipeline); ordinary memory otherwise, so the function also works in a process without a GPU.
     void* base = nullptr;
-    if (posix_memalign(&base, 64, total ? total : 64) != 0) return AVIFGPU_memFullErr;
+    bool pinned = false;
+    int dev = -1;
+    if (hipGetDevice(&dev) == hipSuccess && hipHostMalloc(&base, total ? total : 64, hipHostMallocDefault) == hipSuccess) pinned = true;
+    else { (void)hipGetLastError(); base = nullptr; if (posix_memalign(&base, 64, total ? total : 64) != 0) return AVIFGPU_memFullErr; }
+    if (pinned) { std::lock_guard<std::mutex> lk(g_pinned_mu); g_pinned.insert(base); }
     for (int pl = 0; pl < 4; ++pl) img->plane[pl] = w[pl] ? (uint8_t*)base + off[pl] : nullptr;
     img->owner = base;
     return AVIFGPU_noErr;
@@ -402,7 +415,38 @@ avifgpu_OSErr avifgpu_image_alloc(avifgpu_image* img)
 
 void avifgpu_image_free(avifgpu_image* img)
 {
-    if (img && img->owner) { free(img->owner); img->owner = nullptr; for (auto& p : img->plane) p = nullptr; }
+    if (!img || !img->owner) return;
+    bool pinned = false;
+    { std::lock_guard<std::mutex> lk(g_pinned_mu); pinned = g_pinned.erase(img->owner) != 0; }
+    if (pinned) (void)hipHostFree(img->owner); else free(img->owner);
+    img->owner = nullptr;
+    for (auto& p : img->plane) p = nullptr;
+}
+
+// Page-lock planes the caller owns (libheif's, from heif_image_get_plane) for the duration of a save / open, so the per-tile
+// copies between them and the device are true asynchronous DMA.  Optional: everything works on pageable planes, slower.
+avifgpu_OSErr avifgpu_host_pin_planes(const avifgpu_image* img)
+{
+    if (!img) return AVIFGPU_formatBadParameters;
+    if (img->owner) return AVIFGPU_noErr;                  // avifgpu_image_alloc already pinned (or could not)
+    for (int pl = 0; pl < 4; ++pl) {
+        if (!img->plane[pl]) continue;
+        const bool chromaPlane = img->colorspace == AVIFGPU_COLORSPACE_YCBCR && (pl == 1 || pl == 2);
+        const int rows = (chromaPlane && img->chroma == AVIFGPU_CHROMA_420) ? (img->height + 1) / 2 : img->height;
+        if (hipHostRegister(img->plane[pl], (size_t)img->stride[pl] * rows, hipHostRegisterDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            for (int q = 0; q < pl; ++q) if (img->plane[q]) (void)hipHostUnregister(img->plane[q]);
+            avifgpu::set_error("hipHostRegister failed: continuing with pageable planes is fine");
+            return AVIFGPU_memFullErr;
+        }
+    }
+    return AVIFGPU_noErr;
+}
+
+void avifgpu_host_unpin_planes(const avifgpu_image* img)
+{
+    if (!img || img->owner) return;
+    for (int pl = 0; pl < 4; ++pl) if (img->plane[pl]) (void)hipHostUnregister(img->plane[pl]);
 }
 
 // AddColorProfileToImage (WriteMetadata.cpp:107-149): the nclx the plug-in attaches to the image it hands to libheif --
