@@ -53,7 +53,7 @@ def run(width, height, max_data, output, chroma=pkg.CHROMA_444, reps=3, nofill=F
                       "H2D_GB_s_equiv": round(width * height * 12 / best / 1e9, 1)}), flush=True)
 
 
-def run_read(width, height, max_data, bits, depth, chroma, tc, reps=3):
+def run_read(width, height, max_data, bits, depth, chroma, tc, reps=3, pin=False):
     """Open direction: planes in pageable host memory -> avifgpu_host_read_heif_image -> the fake host drains every tile."""
     gpu = pkg.AvifGpu(0)
     d = pkg.ReadDesc(width=width, height=height, colorspace=pkg.COLORSPACE_YCBCR, chroma=chroma, bit_depth=bits, depth=depth,
@@ -74,13 +74,17 @@ def run_read(width, height, max_data, bits, depth, chroma, tc, reps=3):
     for _ in range(reps):
         host = FakeHost(width, height, depth, 3, max_data=max_data)
         t0 = time.perf_counter()
+        if pin:
+            assert gpu.lib.avifgpu_host_pin_planes(ctypes.byref(img)) == 0
         code = gpu.lib.avifgpu_host_read_heif_image(ctypes.byref(img), pkg.ALPHA_NONE, ctypes.byref(nclx), ctypes.byref(lo), ctypes.byref(host.fr))
+        if pin:
+            gpu.lib.avifgpu_host_unpin_planes(ctypes.byref(img))
         dt = time.perf_counter() - t0
         assert code == 0, gpu.lib.avifgpu_last_error()
         best = dt if best is None else min(best, dt)
         tiles = len(host.rects)
     t0 = time.perf_counter(); tmp = host.image.copy(); drain = time.perf_counter() - t0
-    print(json.dumps({"config": f"{width}x{height} {bits}-bit YCbCr {'4:2:0' if chroma == pkg.CHROMA_420 else '4:4:4'} -> host depth {depth}",
+    print(json.dumps({"config": f"{width}x{height} {bits}-bit YCbCr {'4:2:0' if chroma == pkg.CHROMA_420 else '4:4:4'} -> host depth {depth}" + (", planes page-locked for the call" if pin else ""),
                       "maxData_MiB": max_data / 2**20, "tiles": tiles, "seconds": round(best, 4),
                       "Mpx_s": round(width * height / best / 1e6, 1), "host_drain_memcpy_s": round(drain, 4)}), flush=True)
 
@@ -122,7 +126,9 @@ if __name__ == "__main__":
     run_caller_planes(8192, 8192, 64 << 20, pin=False)
     run_caller_planes(8192, 8192, 64 << 20, pin=True)
     run_read(8192, 8192, 64 << 20, 10, 32, pkg.CHROMA_444, pkg.TC_PQ)
+    run_read(8192, 8192, 64 << 20, 10, 32, pkg.CHROMA_444, pkg.TC_PQ, pin=True)
     run_read(8192, 8192, 64 << 20, 8, 8, pkg.CHROMA_420, pkg.TC_SRGB)
+    run_read(8192, 8192, 64 << 20, 8, 8, pkg.CHROMA_420, pkg.TC_SRGB, pin=True)
     run_read(8192, 8192, 64 << 20, 12, 16, pkg.CHROMA_420, pkg.TC_SRGB)
     for md in (16 << 20, 64 << 20, 256 << 20, 1024 << 20):
         run(8192, 8192, md, pkg.OUT_YCBCR)
