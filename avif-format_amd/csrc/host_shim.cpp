@@ -423,32 +423,6 @@ void avifgpu_image_free(avifgpu_image* img)
     for (auto& p : img->plane) p = nullptr;
 }
 
-// Page-lock planes the caller owns (libheif's, from heif_image_get_plane) for the duration of a save / open, so the per-tile
-// copies between them and the device are true asynchronous DMA.  Optional: everything works on pageable planes, slower.
-avifgpu_OSErr avifgpu_host_pin_planes(const avifgpu_image* img)
-{
-    if (!img) return AVIFGPU_formatBadParameters;
-    if (img->owner) return AVIFGPU_noErr;                  // avifgpu_image_alloc already pinned (or could not)
-    for (int pl = 0; pl < 4; ++pl) {
-        if (!img->plane[pl]) continue;
-        const bool chromaPlane = img->colorspace == AVIFGPU_COLORSPACE_YCBCR && (pl == 1 || pl == 2);
-        const int rows = (chromaPlane && img->chroma == AVIFGPU_CHROMA_420) ? (img->height + 1) / 2 : img->height;
-        if (hipHostRegister(img->plane[pl], (size_t)img->stride[pl] * rows, hipHostRegisterDefault) != hipSuccess) {
-            (void)hipGetLastError();
-            for (int q = 0; q < pl; ++q) if (img->plane[q]) (void)hipHostUnregister(img->plane[q]);
-            avifgpu::set_error("hipHostRegister failed: continuing with pageable planes is fine");
-            return AVIFGPU_memFullErr;
-        }
-    }
-    return AVIFGPU_noErr;
-}
-
-void avifgpu_host_unpin_planes(const avifgpu_image* img)
-{
-    if (!img || img->owner) return;
-    for (int pl = 0; pl < 4; ++pl) if (img->plane[pl]) (void)hipHostUnregister(img->plane[pl]);
-}
-
 // AddColorProfileToImage (WriteMetadata.cpp:107-149): the nclx the plug-in attaches to the image it hands to libheif --
 // and therefore the matrix a fused YCbCr output has to use so that libheif has nothing left to convert.
 avifgpu_OSErr avifgpu_host_save_nclx(const avifgpu_FormatRecord* formatRecord, const avifgpu_SaveUIOptions* saveOptions,

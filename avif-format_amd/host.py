@@ -68,8 +68,6 @@ class Image(ctypes.Structure):
 HOST_ABI = [
     ("avifgpu_image_alloc", c_int16, [POINTER(Image)]),
     ("avifgpu_image_free", None, [POINTER(Image)]),
-    ("avifgpu_host_pin_planes", c_int16, [POINTER(Image)]),
-    ("avifgpu_host_unpin_planes", None, [POINTER(Image)]),
     ("avifgpu_host_save_nclx", c_int16, [POINTER(FormatRecord), POINTER(SaveUIOptions), POINTER(Nclx)]),
     ("avifgpu_host_create_heif_image", c_int16, [POINTER(FormatRecord), c_int32, POINTER(SaveUIOptions), c_int32, c_int32,
                                                  c_int32, POINTER(Image)]),

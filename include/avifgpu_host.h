@@ -128,12 +128,6 @@ void          avifgpu_image_free(avifgpu_image* img);
  * img->plane[] may point at libheif-owned planes (heif_image_get_plane) or be allocated with avifgpu_image_alloc.
  * Returns noErr, userCanceledErr (abortProc), the host's advanceState error, memFullErr, writErr, formatBadParameters.
  */
-/* Optional: page-lock planes the caller owns (libheif's) around avifgpu_host_create_heif_image / ..._read_heif_image, so the
- * per-tile copies are asynchronous DMA (8192^2 f32 save: 0.066 s with pageable planes, 0.048 s with pinned ones).  Planes from
- * avifgpu_image_alloc are pinned already.  memFullErr if the registration fails: carry on unpinned. */
-avifgpu_OSErr avifgpu_host_pin_planes(const avifgpu_image* img);
-void          avifgpu_host_unpin_planes(const avifgpu_image* img);
-
 /* The nclx colour profile the plug-in attaches on save (AddColorProfileToImage, reference WriteMetadata.cpp:107-149):
  * HDR PQ / SMPTE 428 -> BT.2020 primaries + BT.2020-NCL matrix; everything else -> BT.709 primaries, sRGB transfer, BT.601
  * matrix; lossless colour images -> identity (GBR) matrix; always full range.  writErr for a transfer the plug-in cannot

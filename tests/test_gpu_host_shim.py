@@ -128,30 +128,3 @@ def test_open_hdr_requires_nclx(gpu):
     code = gpu.lib.avifgpu_host_read_heif_image(ctypes.byref(img), pkg.ALPHA_NONE, None, None, ctypes.byref(host.fr))
     assert code == pkg.readErr and b"nclxProfile is null" in gpu.lib.avifgpu_last_error()
 
-
-def test_caller_owned_planes_pinned_for_the_call(gpu):
-    """Planes the caller owns (libheif's in the plug-in; numpy here) with libheif-like padded strides, page-locked around the
-    call with avifgpu_host_pin_planes: same bytes as the oracle, padding untouched, unpin leaves the memory usable."""
-    d = pkg.WriteDesc(width=203, height=37, depth=16, planes=4, bit_depth=10, alpha_state=pkg.ALPHA_STRAIGHT, output=pkg.OUT_YCBCR,
-                      chroma=pkg.CHROMA_420, matrix_coefficients=pkg.MATRIX_BT601)
-    src = harness.make_write_source(d)
-    want = harness.oracle_write(d, src)
-    host = FakeHost(d.width, d.height, 16, 4, max_data=203 * 8 * 2 * 6, image=src)
-    opts = H.SaveUIOptions(imageBitDepth=10, hdrTransferFunction=pkg.TRANSFER_CLIP, pq=H.PQOptions(1000), chromaSubsampling=pkg.CHROMA_420, lossless=0)
-    img = H.Image()
-    img.width, img.height, img.colorspace, img.chroma, img.bit_depth, img.has_alpha = d.width, d.height, pkg.COLORSPACE_YCBCR, pkg.CHROMA_420, 10, 1
-    keep = {}
-    for pl, (w, xs, ys) in harness.write_planes(d).items():
-        h = (d.height + ys) >> ys
-        keep[pl] = np.full((h, w + 13), 0xBEEF, dtype=np.uint16)
-        img.plane[pl] = keep[pl].ctypes.data
-        img.stride[pl] = keep[pl].strides[0]
-    assert gpu.lib.avifgpu_host_pin_planes(ctypes.byref(img)) == 0, gpu.lib.avifgpu_last_error()
-    code = gpu.lib.avifgpu_host_create_heif_image(ctypes.byref(host.fr), pkg.ALPHA_STRAIGHT, ctypes.byref(opts), pkg.OUT_YCBCR, -1, -1,
-                                                  ctypes.byref(img))
-    gpu.lib.avifgpu_host_unpin_planes(ctypes.byref(img))
-    assert code == 0, gpu.lib.avifgpu_last_error()
-    for pl, (w, xs, ys) in harness.write_planes(d).items():
-        assert np.array_equal(keep[pl][:, :w], want[pl]), pl
-        assert (keep[pl][:, w:] == 0xBEEF).all()
-        keep[pl][:] = 0                                     # still ordinary writable memory after unpin

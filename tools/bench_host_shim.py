@@ -53,7 +53,7 @@ def run(width, height, max_data, output, chroma=pkg.CHROMA_444, reps=3, nofill=F
                       "H2D_GB_s_equiv": round(width * height * 12 / best / 1e9, 1)}), flush=True)
 
 
-def run_read(width, height, max_data, bits, depth, chroma, tc, reps=3, pin=False):
+def run_read(width, height, max_data, bits, depth, chroma, tc, reps=3):
     """Open direction: planes in pageable host memory -> avifgpu_host_read_heif_image -> the fake host drains every tile."""
     gpu = pkg.AvifGpu(0)
     d = pkg.ReadDesc(width=width, height=height, colorspace=pkg.COLORSPACE_YCBCR, chroma=chroma, bit_depth=bits, depth=depth,
@@ -74,61 +74,20 @@ def run_read(width, height, max_data, bits, depth, chroma, tc, reps=3, pin=False
     for _ in range(reps):
         host = FakeHost(width, height, depth, 3, max_data=max_data)
         t0 = time.perf_counter()
-        if pin:
-            assert gpu.lib.avifgpu_host_pin_planes(ctypes.byref(img)) == 0
         code = gpu.lib.avifgpu_host_read_heif_image(ctypes.byref(img), pkg.ALPHA_NONE, ctypes.byref(nclx), ctypes.byref(lo), ctypes.byref(host.fr))
-        if pin:
-            gpu.lib.avifgpu_host_unpin_planes(ctypes.byref(img))
         dt = time.perf_counter() - t0
         assert code == 0, gpu.lib.avifgpu_last_error()
         best = dt if best is None else min(best, dt)
         tiles = len(host.rects)
     t0 = time.perf_counter(); tmp = host.image.copy(); drain = time.perf_counter() - t0
-    print(json.dumps({"config": f"{width}x{height} {bits}-bit YCbCr {'4:2:0' if chroma == pkg.CHROMA_420 else '4:4:4'} -> host depth {depth}" + (", planes page-locked for the call" if pin else ""),
+    print(json.dumps({"config": f"{width}x{height} {bits}-bit YCbCr {'4:2:0' if chroma == pkg.CHROMA_420 else '4:4:4'} -> host depth {depth}",
                       "maxData_MiB": max_data / 2**20, "tiles": tiles, "seconds": round(best, 4),
                       "Mpx_s": round(width * height / best / 1e6, 1), "host_drain_memcpy_s": round(drain, 4)}), flush=True)
 
 
-def run_caller_planes(width, height, max_data, pin, reps=3):
-    """Save into planes the CALLER owns (numpy = pageable, like libheif's), optionally page-locked for the call."""
-    gpu = pkg.AvifGpu(0)
-    rng = np.random.default_rng(1234)
-    src = rng.random((height, width * 3), dtype=np.float32)
-    planes = [np.zeros((height, width), dtype=np.uint16) for _ in range(3)]
-    best = best_pin = None
-    for _ in range(reps):
-        host = FakeHost(width, height, 32, 3, max_data=max_data, image=src)
-        opts = H.SaveUIOptions(imageBitDepth=10, hdrTransferFunction=pkg.TRANSFER_PQ, pq=H.PQOptions(80), chromaSubsampling=pkg.CHROMA_444, lossless=0)
-        img = H.Image()
-        for pl in range(3):
-            img.plane[pl] = planes[pl].ctypes.data
-            img.stride[pl] = planes[pl].strides[0]
-        img.width, img.height, img.colorspace, img.chroma, img.bit_depth = width, height, pkg.COLORSPACE_YCBCR, pkg.CHROMA_444, 10
-        t0 = time.perf_counter()
-        if pin:
-            assert gpu.lib.avifgpu_host_pin_planes(ctypes.byref(img)) == 0, gpu.lib.avifgpu_last_error()
-        t1 = time.perf_counter()
-        code = gpu.lib.avifgpu_host_create_heif_image(ctypes.byref(host.fr), pkg.ALPHA_NONE, ctypes.byref(opts), pkg.OUT_YCBCR,
-                                                      pkg.MATRIX_BT2020_NCL, pkg.PRIMARIES_BT2020, ctypes.byref(img))
-        t2 = time.perf_counter()
-        if pin:
-            gpu.lib.avifgpu_host_unpin_planes(ctypes.byref(img))
-        t3 = time.perf_counter()
-        assert code == 0, gpu.lib.avifgpu_last_error()
-        if best is None or t3 - t0 < best:
-            best, best_pin = t3 - t0, (t1 - t0) + (t3 - t2)
-    print(json.dumps({"config": f"{width}x{height} RGB f32 -> 10-bit PQ YCbCr444 into caller-owned planes, {'page-locked for the call' if pin else 'pageable'}",
-                      "maxData_MiB": max_data / 2**20, "seconds": round(best, 4), "of_which_pin_unpin_s": round(best_pin, 4),
-                      "Mpx_s": round(width * height / best / 1e6, 1)}), flush=True)
-
-
 if __name__ == "__main__":
-    run_caller_planes(8192, 8192, 64 << 20, pin=False)
-    run_caller_planes(8192, 8192, 64 << 20, pin=True)
     run_read(8192, 8192, 64 << 20, 10, 32, pkg.CHROMA_444, pkg.TC_PQ)
-    run_read(8192, 8192, 64 << 20, 10, 32, pkg.CHROMA_444, pkg.TC_PQ, pin=True)
     run_read(8192, 8192, 64 << 20, 8, 8, pkg.CHROMA_420, pkg.TC_SRGB)
-    run_read(8192, 8192, 64 << 20, 8, 8, pkg.CHROMA_420, pkg.TC_SRGB, pin=True)
     run_read(8192, 8192, 64 << 20, 12, 16, pkg.CHROMA_420, pkg.TC_SRGB)
     for md in (16 << 20, 64 << 20, 256 << 20, 1024 << 20):
         run(8192, 8192, md, pkg.OUT_YCBCR)
