@@ -21,7 +21,7 @@
  *     (libheif/color-conversion, Op_RGB_to_YCbCr: full-range Kr/Kb matrix on integer codes,
  *     `(long)(v + 0.5f)` rounding with clip, chroma offset 1 << (bits-1)); parity for that stage is
  *     anchored only by the round trip through the reference's own decoder equations
- *     (tests/test_roundtrip.py).  It is "parity unpinned".
+ *     (tests/test_oracle_properties.py::test_roundtrip_through_reference_decoder, tests/test_gpu_fullsize_roundtrip.py).  It is "parity unpinned".
  *
  * Deliberate divergences from reference undefined behaviour (inputs excluded from parity):
  *   * 16-bit source samples > 32768 index past the reference LUT (WriteHeifImage.cpp:141-145,:942);
