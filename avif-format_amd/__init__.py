@@ -110,6 +110,8 @@ _STRIDES4 = c_int64 * 4
 ABI = [
     ("avifgpu_abi_version", c_int32, []),
     ("avifgpu_init", c_int32, [c_int32]),
+    ("avifgpu_init_devices", c_int32, [POINTER(c_int32), c_int32]),
+    ("avifgpu_device_count", c_int32, []),
     ("avifgpu_shutdown", None, []),
     ("avifgpu_last_error", c_char_p, []),
     ("avifgpu_write_rows", c_int32, [POINTER(WriteDesc), c_int32, c_int32, c_void_p, c_int64,
@@ -193,12 +195,16 @@ def strides4(vals):
 class AvifGpu:
     """One bound device.  Thin wrapper: raises AvifGpuError on any non-zero OSErr."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, devices=None):
+        """Bind `device`, or the list `devices` (one context per entry; an ordinal may repeat: N contexts on one GPU)."""
         self.lib = load()
-        code = self.lib.avifgpu_init(device)
+        devs = [int(device)] if devices is None else [int(x) for x in devices]
+        arr = (c_int32 * len(devs))(*devs)
+        code = self.lib.avifgpu_init_devices(arr, len(devs))
         if code != 0:
             raise AvifGpuError(code, self.lib.avifgpu_last_error().decode())
-        self.device = device
+        self.device = devs[0]
+        self.devices = devs
 
     def _check(self, code):
         if code != 0:

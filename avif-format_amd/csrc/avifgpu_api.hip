@@ -1,43 +1,34 @@
-// avifgpu_api.hip -- the C-ABI of include/avifgpu.h: validation, nclx -> coefficients, staging, launches.
+// avifgpu_api.hip -- the C-ABI of include/avifgpu.h: validation, nclx -> coefficients, kernel parameters, launches.
 //
 // There is no CPU fallback anywhere in this file: without a HIP device avifgpu_init fails and every
-// *_rows call returns an error.
+// *_rows call returns an error.  Host-pointer calls go through the bound device contexts of pipeline.hip
+// (one worker thread + staging slots per context, row tiles dealt across contexts); device-pointer calls
+// launch directly on the caller's stream and device.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <vector>
 
 #include "../../include/avifgpu.h"
 #include "kernel_params.h"
+#include "staging.h"
 
-namespace avifgpu {
-hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16, int output, int xs, int ys,
-                        int variant, hipStream_t st, const char** name);
-hipError_t launch_read(const ReadParams& p, int colorspace, int depth, bool alpha, int xs, int ys,
-                       hipStream_t st, const char** name);
-void release_read_tables();
-}
-
-namespace avifgpu {
-int wait_slot(int slot);
-int write_rows_host_enqueue(const avifgpu_write_desc* d, int row0, int nrows, const void* src, int64_t src_row_bytes,
-                            void* const dst[4], const int64_t dst_stride[4], int slot, const avifgpu_icc_transform* icc = nullptr,
-                            const avifgpu_icc_shaper8* icc8 = nullptr, const avifgpu_icc_clut16* icc16 = nullptr);
-int read_rows_host_enqueue(const avifgpu_read_desc* d, int row0, int nrows, const void* const src[4], const int64_t src_stride[4],
-                           void* dst, int64_t dst_row_bytes, int slot);
-void set_error(const char* msg);
-}
+namespace avifgpu { void release_read_tables(); }
 
 using namespace avifgpu;
 
 namespace {
-
 thread_local char g_err[512] = "";
-thread_local const char* g_kernel = "";
+thread_local char g_kernel[kLabelBytes] = "";
+int g_hot_variant = kHotDefault;
+}
+
+namespace avifgpu {
 
 int fail(int code, const char* fmt, ...)
 {
@@ -47,37 +38,19 @@ int fail(int code, const char* fmt, ...)
     return code;
 }
 
-struct Context {
-    std::mutex mu;
-    bool ready = false;
-    int device = -1;
-    hipStream_t stream = nullptr;         // slot 0 / the synchronous host-pointer entry points
-    hipStream_t stream1 = nullptr;        // slot 1: tile k+1's H2D overlaps tile k's D2H (PCIe is full duplex)
-    // device staging for host-pointer calls: two slots so the host shim can have one tile in flight while the
-    // host fills / drains the other (grown on demand, reused across tiles)
-    struct Slot {
-        void* d_in = nullptr;  size_t d_in_cap = 0;
-        void* d_out = nullptr; size_t d_out_cap = 0;
-        hipEvent_t done = nullptr;
-        bool pending = false;
-    } slot[2];
-    int hot_variant = kHotDefault;
-} g_ctx;
-
 int hip_fail(hipError_t e, const char* what, int code)
 {
     return fail(code, "%s: %s", what, hipGetErrorString(e));
 }
 
-int ensure(void** p, size_t* cap, size_t need)
-{
-    if (need <= *cap) return 0;
-    if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
-    const hipError_t e = hipMalloc(p, need);
-    if (e != hipSuccess) { *p = nullptr; return hip_fail(e, "hipMalloc(staging)", AVIFGPU_memFullErr); }
-    *cap = need;
-    return 0;
-}
+void set_error(const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
+const char* last_error() { return g_err; }
+void set_last_kernel(const char* label) { snprintf(g_kernel, sizeof(g_kernel), "%s", label); }
+int hot_variant() { return g_hot_variant; }
+
+} // namespace avifgpu
+
+namespace {
 
 // ---- nclx -> (kr, kg, kb), the same derivation the plug-in performs (YUVCoefficiants.cpp:110-188) ----
 struct PrimariesRow { int code; float rX, rY, gX, gY, bX, bY, wX, wY; };
@@ -137,9 +110,11 @@ bool chroma_shift(int chroma, int& xs, int& ys)
     }
 }
 
-// ---- write-side validation (same rules as the plug-in's option fix-ups and default branches) --------
-struct WriteGeom { bool color, alpha, dst16; int xs, ys, nplanes; };
+} // namespace
 
+namespace avifgpu {
+
+// ---- write-side validation (same rules as the plug-in's option fix-ups and default branches) --------
 int check_write(const avifgpu_write_desc* d, int row0, int nrows, WriteGeom& g)
 {
     if (!d) return fail(AVIFGPU_formatBadParameters, "null descriptor");
@@ -180,39 +155,40 @@ int check_write(const avifgpu_write_desc* d, int row0, int nrows, WriteGeom& g)
     return 0;
 }
 
-thread_local const avifgpu_icc_transform* g_icc = nullptr;    // set for the duration of an avifgpu_write_rows_icc call
-thread_local const avifgpu_icc_clut16* g_icc16 = nullptr;   // set for the duration of an avifgpu_write_rows_icc16 call
-thread_local const avifgpu_icc_shaper8* g_icc8 = nullptr;    // set for the duration of an avifgpu_write_rows_icc8 call
+// Device copies of the ICC tables, one set per HIP device (the row-tile scheduler converts one image on several GPUs).
+// Re-uploaded only when the contents change (one image = one upload per device); a change first drains that device so no
+// in-flight kernel still reads the old tables.  Callers run on the thread whose CURRENT device is the one they launch on.
+struct IccDeviceTables {
+    void* icc8 = nullptr;  std::vector<uint8_t> icc8_host;     // [3][256] int32 followed by 16388 bytes of shaper2
+    void* icc16 = nullptr; std::vector<uint8_t> icc16_host;    // 33^3 x 4 u16
+};
+static std::mutex g_icc_mu;
+static std::map<int, IccDeviceTables> g_icc_tables;            // keyed by HIP device ordinal
 
-// Device copy of the 8-bit shaper tables.  Re-uploaded only when the contents change (one image = one upload); a change
-// first drains the device so no in-flight kernel still reads the old tables (the plug-in converts one image at a time).
-struct Icc8Device {
-    void* dev = nullptr;                  // [3][256] int32 followed by 16388 bytes of shaper2
-    std::vector<uint8_t> host;            // contents of `dev`
-} g_icc8_dev;
-
-// The 33^3 table lives in device memory; re-uploaded only when its content changes (one profile per save).
-struct Icc16Dev { void* dev = nullptr; std::vector<uint8_t> host; } g_icc16_dev;
 int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p)
 {
     if (t->grid_points != AVIFGPU_ICC_CLUT_GRID) return fail(AVIFGPU_formatBadParameters, "16-bit ICC table: grid_points must be 33");
     const size_t n = sizeof(t->table);
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    if (!g_icc16_dev.dev) {
-        const hipError_t e = hipMalloc(&g_icc16_dev.dev, n);
-        if (e != hipSuccess) return hip_fail(e, "hipMalloc(icc16 table)", AVIFGPU_memFullErr);
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDevice", AVIFGPU_writErr);
+    std::lock_guard<std::mutex> lk(g_icc_mu);
+    IccDeviceTables& c = g_icc_tables[dev];
+    if (!c.icc16) {
+        e = hipMalloc(&c.icc16, n);
+        if (e != hipSuccess) { c.icc16 = nullptr; return hip_fail(e, "hipMalloc(icc16 table)", AVIFGPU_memFullErr); }
     }
-    if (g_icc16_dev.host.size() != n || memcmp(g_icc16_dev.host.data(), t->table, n) != 0) {
-        hipError_t e = hipDeviceSynchronize();                  // a launch may still be reading the previous table
-        if (e == hipSuccess) e = hipMemcpy(g_icc16_dev.dev, t->table, n, hipMemcpyHostToDevice);
+    if (c.icc16_host.size() != n || memcmp(c.icc16_host.data(), t->table, n) != 0) {
+        e = hipDeviceSynchronize();                             // a launch may still be reading the previous table
+        if (e == hipSuccess) e = hipMemcpy(c.icc16, t->table, n, hipMemcpyHostToDevice);
         if (e != hipSuccess) return hip_fail(e, "upload of the ICC table", AVIFGPU_writErr);
-        g_icc16_dev.host.assign(reinterpret_cast<const uint8_t*>(t->table), reinterpret_cast<const uint8_t*>(t->table) + n);
+        c.icc16_host.assign(reinterpret_cast<const uint8_t*>(t->table), reinterpret_cast<const uint8_t*>(t->table) + n);
     }
-    p.icc16_clut = static_cast<const uint16_t*>(g_icc16_dev.dev);
+    p.icc16_clut = static_cast<const uint16_t*>(c.icc16);
     return 0;
 }
 
-int upload_icc8(const avifgpu_icc_shaper8* t, hipStream_t st, WriteParams& p)
+int upload_icc8(const avifgpu_icc_shaper8* t, WriteParams& p)
 {
     if (memcmp(t->shaper2[0], t->shaper2[1], 16385) != 0 || memcmp(t->shaper2[0], t->shaper2[2], 16385) != 0)
         return fail(AVIFGPU_formatBadParameters, "8-bit ICC shaper: the destination curve must be the same for R, G and B (sRGB)");
@@ -230,27 +206,49 @@ int upload_icc8(const avifgpu_icc_shaper8* t, hipStream_t st, WriteParams& p)
     std::vector<uint8_t> blob(n1 + n2);
     memcpy(blob.data(), t->shaper1, n1);
     memcpy(blob.data() + n1, t->shaper2[0], n2);
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    if (!g_icc8_dev.dev) {
-        const hipError_t e = hipMalloc(&g_icc8_dev.dev, n1 + n2);
-        if (e != hipSuccess) return hip_fail(e, "hipMalloc(icc8 tables)", AVIFGPU_memFullErr);
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDevice", AVIFGPU_writErr);
+    std::lock_guard<std::mutex> lk(g_icc_mu);
+    IccDeviceTables& c = g_icc_tables[dev];
+    if (!c.icc8) {
+        e = hipMalloc(&c.icc8, n1 + n2);
+        if (e != hipSuccess) { c.icc8 = nullptr; return hip_fail(e, "hipMalloc(icc8 tables)", AVIFGPU_memFullErr); }
     }
-    if (g_icc8_dev.host != blob) {
-        hipError_t e = hipDeviceSynchronize();
-        if (e == hipSuccess) e = hipMemcpy(g_icc8_dev.dev, blob.data(), blob.size(), hipMemcpyHostToDevice);
+    if (c.icc8_host != blob) {
+        e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(c.icc8, blob.data(), blob.size(), hipMemcpyHostToDevice);
         if (e != hipSuccess) return hip_fail(e, "upload of ICC tables", AVIFGPU_writErr);
-        g_icc8_dev.host.swap(blob);
+        c.icc8_host.swap(blob);
     }
-    (void)st;
-    p.icc8_s1 = static_cast<const int32_t*>(g_icc8_dev.dev);
-    p.icc8_s2 = static_cast<const uint8_t*>(g_icc8_dev.dev) + n1;
+    p.icc8_s1 = static_cast<const int32_t*>(c.icc8);
+    p.icc8_s2 = static_cast<const uint8_t*>(c.icc8) + n1;
     for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) p.icc8_m[3 * i + j] = t->matrix[i][j]; p.icc8_off[i] = t->offset[i]; }
     return 0;
 }
 
-int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const WriteGeom& g, WriteParams& p)
+// avifgpu_shutdown: nothing is in flight any more.
+void release_device_caches()
+{
+    release_read_tables();
+    std::lock_guard<std::mutex> lk(g_icc_mu);
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    for (auto& kv : g_icc_tables) {
+        (void)hipSetDevice(kv.first);
+        if (kv.second.icc8) (void)hipFree(kv.second.icc8);
+        if (kv.second.icc16) (void)hipFree(kv.second.icc16);
+    }
+    g_icc_tables.clear();
+    if (cur >= 0) (void)hipSetDevice(cur);
+}
+
+int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const WriteGeom& g, const IccArgs& icc, WriteParams& p)
 {
     memset(&p, 0, sizeof(p));
+    const avifgpu_icc_transform* g_icc = icc.f32;
+    const avifgpu_icc_clut16* g_icc16 = icc.c16;
+    const avifgpu_icc_shaper8* g_icc8 = icc.s8;
     if (g_icc) {
         if (d->depth != 32 || d->planes < 3) return fail(AVIFGPU_formatBadParameters, "the ICC row transform applies to 32-bit RGB(A) documents");
         for (int c = 0; c < 3; ++c) {
@@ -269,14 +267,12 @@ int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const Wr
     }
     if (g_icc16) {
         if (d->depth != 16 || d->planes < 3) return fail(AVIFGPU_formatBadParameters, "the 16-bit ICC table applies to 16-bit RGB(A) documents");
-        if (!g_ctx.ready) return fail(AVIFGPU_formatBadParameters, "avifgpu_init has not succeeded: no HIP device bound (no CPU fallback)");
         const int rc = upload_icc16(g_icc16, p);
         if (rc) return rc;
     }
     if (g_icc8) {
         if (d->depth != 8 || d->planes < 3) return fail(AVIFGPU_formatBadParameters, "the 8-bit ICC shaper applies to 8-bit RGB(A) documents");
-        if (!g_ctx.ready) return fail(AVIFGPU_formatBadParameters, "avifgpu_init has not succeeded: no HIP device bound (no CPU fallback)");
-        const int rc = upload_icc8(g_icc8, nullptr, p);
+        const int rc = upload_icc8(g_icc8, p);
         if (rc) return rc;
     }
     p.width = d->width; p.nrows = nrows; p.rows_to_end = d->height - row0;
@@ -330,8 +326,6 @@ bool write_plane_used(const avifgpu_write_desc* d, const WriteGeom& g, int plane
 }
 
 // ---- read-side validation (runtime_error / OSErr conditions of ReadHeifImage.cpp) --------------------
-struct ReadGeom { int xs, ys, nch, transfer; bool alpha; };
-
 int transfer_from_tc(int tc)
 {
     switch (tc) {                                       // ColorTransfer.cpp:47-67
@@ -429,7 +423,69 @@ void read_plane_extent(const avifgpu_read_desc* d, const ReadGeom& g, int plane,
     rows = nrows; row_bytes = (int64_t)d->width * ssz;
 }
 
-size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+// Buffer checks shared by the direct (device-pointer) entry and the staged (host-pointer) path.
+int check_write_buffers(const avifgpu_write_desc* d, const WriteGeom& g, int nrows, const void* src, int64_t src_row_bytes,
+                        void* const dst[4], const int64_t dst_stride[4])
+{
+    if (!src || !dst || !dst_stride) return fail(AVIFGPU_formatBadParameters, "null buffer");
+    const int64_t min_src_row = (int64_t)d->width * d->planes * (d->depth / 8);
+    if (src_row_bytes < min_src_row) return fail(AVIFGPU_formatBadParameters, "src_row_bytes %lld < %lld", (long long)src_row_bytes, (long long)min_src_row);
+    for (int pl = 0; pl < 4; ++pl) {
+        if (!write_plane_used(d, g, pl)) continue;
+        int rows; int64_t rb; write_plane_extent(d, g, pl, nrows, rows, rb);
+        if (!dst[pl]) return fail(AVIFGPU_formatBadParameters, "destination plane %d is null", pl);
+        if (dst_stride[pl] < rb) return fail(AVIFGPU_formatBadParameters, "dst_stride[%d] %lld < %lld", pl, (long long)dst_stride[pl], (long long)rb);
+    }
+    return 0;
+}
+
+int check_read_buffers(const avifgpu_read_desc* d, const ReadGeom& g, int nrows, const void* const src[4], const int64_t src_stride[4],
+                       const void* dst, int64_t dst_row_bytes)
+{
+    if (!src || !src_stride || !dst) return fail(AVIFGPU_formatBadParameters, "null buffer");
+    const int64_t min_dst_row = (int64_t)d->width * g.nch * (d->depth / 8);
+    if (min_dst_row > 0x7fffffffLL) return fail(AVIFGPU_memFullErr, "rowBytes exceeds int32");                      // SetupFormatRecord, ReadHeifImage.cpp:40-47
+    if (dst_row_bytes < min_dst_row) return fail(AVIFGPU_formatBadParameters, "dst_row_bytes too small");
+    for (int pl = 0; pl < 4; ++pl) {
+        if (!read_plane_used(d, g, pl)) continue;
+        int rows; int64_t rb; read_plane_extent(d, g, pl, nrows, rows, rb);
+        if (!src[pl]) return fail(AVIFGPU_formatBadParameters, "source plane %d is null", pl);
+        if (src_stride[pl] < rb) return fail(AVIFGPU_formatBadParameters, "src_stride[%d] too small", pl);
+    }
+    return 0;
+}
+
+} // namespace avifgpu
+
+namespace {
+
+const char* const kNoDevice = "avifgpu_init has not succeeded: no HIP device bound (no CPU fallback)";
+
+int write_rows_any(const avifgpu_write_desc* d, const IccArgs& icc, int32_t row0, int32_t nrows, const void* src, int64_t src_row_bytes,
+                   void* const dst[4], const int64_t dst_stride[4], int32_t mem_kind, void* stream)
+{
+    g_err[0] = 0;
+    WriteGeom g;
+    int err = check_write(d, row0, nrows, g);
+    if (err) return err;
+    if ((err = check_write_buffers(d, g, nrows, src, src_row_bytes, dst, dst_stride))) return err;
+    if (context_count() == 0) return fail(AVIFGPU_formatBadParameters, "%s", kNoDevice);
+    if (nrows == 0) return 0;
+
+    if (mem_kind == AVIFGPU_MEM_DEVICE) {
+        // zero-copy: the kernel is enqueued on the caller's stream, on the caller's current device (where the pointers live)
+        WriteParams p;
+        if ((err = fill_write_params(d, row0, nrows, g, icc, p))) return err;
+        hipStream_t st = (hipStream_t)stream;          // NULL = HIP's default stream, as in every HIP API
+        p.src = (const uint8_t*)src; p.src_row_bytes = src_row_bytes;
+        for (int pl = 0; pl < 4; ++pl) { p.dst[pl] = (uint8_t*)dst[pl]; p.dst_stride[pl] = dst_stride[pl]; }
+        const hipError_t e = launch_write(p, d->depth, d->planes, g.dst16, d->output, g.xs, g.ys, g_hot_variant, st, g_kernel);
+        if (e != hipSuccess) return hip_fail(e, "kernel launch", AVIFGPU_writErr);
+        return 0;
+    }
+    if (mem_kind != AVIFGPU_MEM_HOST) return fail(AVIFGPU_formatBadParameters, "bad mem_kind %d", mem_kind);
+    return write_rows_host(d, row0, nrows, src, src_row_bytes, dst, dst_stride, icc);
+}
 
 } // namespace
 
@@ -441,65 +497,31 @@ int32_t avifgpu_abi_version(void) { return AVIFGPU_ABI_VERSION; }
 const char* avifgpu_last_error(void) { return g_err; }
 const char* avifgpu_last_kernel_name(void) { return g_kernel; }
 
-void avifgpu_set_hot_variant(int32_t variant) { g_ctx.hot_variant = variant; }
+void avifgpu_set_hot_variant(int32_t variant) { g_hot_variant = variant; }
 
-int32_t avifgpu_init(int32_t device_index)
+int32_t avifgpu_init_devices(const int32_t* device_indices, int32_t count)
 {
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0)
-        return fail(AVIFGPU_formatBadParameters, "no HIP device available (%s); this library has no CPU fallback",
-                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
-    if (device_index < 0 || device_index >= n) return fail(AVIFGPU_formatBadParameters, "device %d out of range [0,%d)", device_index, n);
-    if (g_ctx.ready && g_ctx.device == device_index) return 0;
-    if (g_ctx.ready) {
-        // One process binds one GPU (one rank per device).  Re-binding releases the old device's stream,
-        // events and staging first instead of silently reusing them on the new device.
-        (void)hipSetDevice(g_ctx.device);
-        (void)hipStreamSynchronize(g_ctx.stream);
-        (void)hipStreamSynchronize(g_ctx.stream1);
-        for (auto& sl : g_ctx.slot) {
-            if (sl.d_in) (void)hipFree(sl.d_in);
-            if (sl.d_out) (void)hipFree(sl.d_out);
-            if (sl.done) (void)hipEventDestroy(sl.done);
-            sl = Context::Slot();
-        }
-        (void)hipStreamDestroy(g_ctx.stream);
-        (void)hipStreamDestroy(g_ctx.stream1);
-        g_ctx.stream = nullptr; g_ctx.stream1 = nullptr; g_ctx.ready = false; g_ctx.device = -1;
-    }
-    if ((e = hipSetDevice(device_index)) != hipSuccess) return hip_fail(e, "hipSetDevice", AVIFGPU_formatBadParameters);
-    if (!g_ctx.stream && (e = hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking)) != hipSuccess)
-        return hip_fail(e, "hipStreamCreate", AVIFGPU_memFullErr);
-    if (!g_ctx.stream1 && (e = hipStreamCreateWithFlags(&g_ctx.stream1, hipStreamNonBlocking)) != hipSuccess)
-        return hip_fail(e, "hipStreamCreate", AVIFGPU_memFullErr);
-    for (auto& sl : g_ctx.slot)
-        if (!sl.done && (e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming)) != hipSuccess)
-            return hip_fail(e, "hipEventCreate", AVIFGPU_memFullErr);
-    g_ctx.device = device_index;
-    g_ctx.ready = true;
-    if (const char* v = getenv("AVIFGPU_HOT_VARIANT")) g_ctx.hot_variant = (int)strtol(v, nullptr, 0);   // tuning only
-    return 0;
+    g_err[0] = 0;
+    if (const char* v = getenv("AVIFGPU_HOT_VARIANT")) g_hot_variant = (int)strtol(v, nullptr, 0);   // tuning only
+    return contexts_init(device_indices, count);
 }
+
+int32_t avifgpu_init(int32_t device_index) { return avifgpu_init_devices(&device_index, 1); }
+
+int32_t avifgpu_device_count(void) { return bound_device_count(); }
 
 void avifgpu_shutdown(void)
 {
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    if (!g_ctx.ready) return;
-    (void)hipDeviceSynchronize();                      // caller-stream launches may still read the cached tables
-    release_read_tables();
-    if (g_icc8_dev.dev) { (void)hipFree(g_icc8_dev.dev); g_icc8_dev.dev = nullptr; g_icc8_dev.host.clear(); }
-    if (g_icc16_dev.dev) { (void)hipFree(g_icc16_dev.dev); g_icc16_dev.dev = nullptr; g_icc16_dev.host.clear(); }
-    for (auto& sl : g_ctx.slot) {
-        if (sl.d_in) (void)hipFree(sl.d_in);
-        if (sl.d_out) (void)hipFree(sl.d_out);
-        if (sl.done) (void)hipEventDestroy(sl.done);
-        sl = Context::Slot();
+    if (context_count() == 0) return;
+    contexts_shutdown();                               // joins the workers: nothing staged is in flight any more
+    int n = 0;
+    if (hipGetDeviceCount(&n) == hipSuccess) {         // caller-stream (device-pointer) launches may still read the cached tables
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        for (int dev = 0; dev < n; ++dev) { if (hipSetDevice(dev) == hipSuccess) (void)hipDeviceSynchronize(); }
+        if (cur >= 0) (void)hipSetDevice(cur);
     }
-    (void)hipStreamDestroy(g_ctx.stream);
-    (void)hipStreamDestroy(g_ctx.stream1);
-    g_ctx.stream = nullptr; g_ctx.stream1 = nullptr; g_ctx.ready = false; g_ctx.device = -1;
+    release_device_caches();
 }
 
 int32_t avifgpu_get_yuv_coefficients(int32_t has_nclx, int32_t matrix_coefficients, int32_t color_primaries, float out[3])
@@ -569,68 +591,31 @@ int32_t avifgpu_write_rows(const avifgpu_write_desc* d, int32_t row0, int32_t nr
                            void* const dst[4], const int64_t dst_stride[4],
                            int32_t mem_kind, void* stream)
 {
-    g_err[0] = 0;
-    WriteGeom g;
-    int err = check_write(d, row0, nrows, g);
-    if (err) return err;
-    if (!src || !dst || !dst_stride) return fail(AVIFGPU_formatBadParameters, "null buffer");
-    const int64_t min_src_row = (int64_t)d->width * d->planes * (d->depth / 8);
-    if (src_row_bytes < min_src_row) return fail(AVIFGPU_formatBadParameters, "src_row_bytes %lld < %lld", (long long)src_row_bytes, (long long)min_src_row);
-    for (int pl = 0; pl < 4; ++pl) {
-        if (!write_plane_used(d, g, pl)) continue;
-        int rows; int64_t rb; write_plane_extent(d, g, pl, nrows, rows, rb);
-        if (!dst[pl]) return fail(AVIFGPU_formatBadParameters, "destination plane %d is null", pl);
-        if (dst_stride[pl] < rb) return fail(AVIFGPU_formatBadParameters, "dst_stride[%d] %lld < %lld", pl, (long long)dst_stride[pl], (long long)rb);
-    }
-    if (!g_ctx.ready) return fail(AVIFGPU_formatBadParameters, "avifgpu_init has not succeeded: no HIP device bound (no CPU fallback)");
-    if (nrows == 0) return 0;
-
-    WriteParams p;
-    if ((err = fill_write_params(d, row0, nrows, g, p))) return err;
-
-    if (mem_kind == AVIFGPU_MEM_DEVICE) {
-        hipStream_t st = (hipStream_t)stream;          // NULL = HIP's default stream, as in every HIP API
-        p.src = (const uint8_t*)src; p.src_row_bytes = src_row_bytes;
-        for (int pl = 0; pl < 4; ++pl) { p.dst[pl] = (uint8_t*)dst[pl]; p.dst_stride[pl] = dst_stride[pl]; }
-        const hipError_t e = launch_write(p, d->depth, d->planes, g.dst16, d->output, g.xs, g.ys, g_ctx.hot_variant, st, &g_kernel);
-        if (e != hipSuccess) return hip_fail(e, "kernel launch", AVIFGPU_writErr);
-        return 0;
-    }
-    if (mem_kind != AVIFGPU_MEM_HOST) return fail(AVIFGPU_formatBadParameters, "bad mem_kind %d", mem_kind);
-
-    err = avifgpu::write_rows_host_enqueue(d, row0, nrows, src, src_row_bytes, dst, dst_stride, 0);
-    if (err) return err;
-    return avifgpu::wait_slot(0);
+    return write_rows_any(d, IccArgs{}, row0, nrows, src, src_row_bytes, dst, dst_stride, mem_kind, stream);
 }
 
 int32_t avifgpu_write_rows_icc(const avifgpu_write_desc* d, const avifgpu_icc_transform* icc, int32_t row0, int32_t nrows,
                                const void* src, int64_t src_row_bytes, void* const dst[4], const int64_t dst_stride[4],
                                int32_t mem_kind, void* stream)
 {
-    g_icc = icc;
-    const int32_t rc = avifgpu_write_rows(d, row0, nrows, src, src_row_bytes, dst, dst_stride, mem_kind, stream);
-    g_icc = nullptr;
-    return rc;
+    IccArgs a; a.f32 = icc;
+    return write_rows_any(d, a, row0, nrows, src, src_row_bytes, dst, dst_stride, mem_kind, stream);
 }
 
 int32_t avifgpu_write_rows_icc16(const avifgpu_write_desc* d, const avifgpu_icc_clut16* icc, int32_t row0, int32_t nrows,
                                  const void* src, int64_t src_row_bytes, void* const dst[4], const int64_t dst_stride[4],
                                  int32_t mem_kind, void* stream)
 {
-    g_icc16 = icc;
-    const int32_t rc = avifgpu_write_rows(d, row0, nrows, src, src_row_bytes, dst, dst_stride, mem_kind, stream);
-    g_icc16 = nullptr;
-    return rc;
+    IccArgs a; a.c16 = icc;
+    return write_rows_any(d, a, row0, nrows, src, src_row_bytes, dst, dst_stride, mem_kind, stream);
 }
 
 int32_t avifgpu_write_rows_icc8(const avifgpu_write_desc* d, const avifgpu_icc_shaper8* icc, int32_t row0, int32_t nrows,
                                 const void* src, int64_t src_row_bytes, void* const dst[4], const int64_t dst_stride[4],
                                 int32_t mem_kind, void* stream)
 {
-    g_icc8 = icc;
-    const int32_t rc = avifgpu_write_rows(d, row0, nrows, src, src_row_bytes, dst, dst_stride, mem_kind, stream);
-    g_icc8 = nullptr;
-    return rc;
+    IccArgs a; a.s8 = icc;
+    return write_rows_any(d, a, row0, nrows, src, src_row_bytes, dst, dst_stride, mem_kind, stream);
 }
 
 int32_t avifgpu_read_rows(const avifgpu_read_desc* d, int32_t row0, int32_t nrows,
@@ -642,155 +627,22 @@ int32_t avifgpu_read_rows(const avifgpu_read_desc* d, int32_t row0, int32_t nrow
     ReadGeom g;
     int err = check_read(d, row0, nrows, g);
     if (err) return err;
-    if (!src || !src_stride || !dst) return fail(AVIFGPU_formatBadParameters, "null buffer");
-    const int64_t min_dst_row = (int64_t)d->width * g.nch * (d->depth / 8);
-    if (min_dst_row > 0x7fffffffLL) return fail(AVIFGPU_memFullErr, "rowBytes exceeds int32");                      // SetupFormatRecord, ReadHeifImage.cpp:40-47
-    if (dst_row_bytes < min_dst_row) return fail(AVIFGPU_formatBadParameters, "dst_row_bytes too small");
-    for (int pl = 0; pl < 4; ++pl) {
-        if (!read_plane_used(d, g, pl)) continue;
-        int rows; int64_t rb; read_plane_extent(d, g, pl, nrows, rows, rb);
-        if (!src[pl]) return fail(AVIFGPU_formatBadParameters, "source plane %d is null", pl);
-        if (src_stride[pl] < rb) return fail(AVIFGPU_formatBadParameters, "src_stride[%d] too small", pl);
-    }
-    if (!g_ctx.ready) return fail(AVIFGPU_formatBadParameters, "avifgpu_init has not succeeded: no HIP device bound (no CPU fallback)");
+    if ((err = check_read_buffers(d, g, nrows, src, src_stride, dst, dst_row_bytes))) return err;
+    if (context_count() == 0) return fail(AVIFGPU_formatBadParameters, "%s", kNoDevice);
     if (nrows == 0) return 0;
 
-    ReadParams p;
-    if ((err = fill_read_params(d, nrows, g, p))) return err;
-
     if (mem_kind == AVIFGPU_MEM_DEVICE) {
+        ReadParams p;
+        if ((err = fill_read_params(d, nrows, g, p))) return err;
         hipStream_t st = (hipStream_t)stream;          // NULL = HIP's default stream
         for (int pl = 0; pl < 4; ++pl) { p.src[pl] = (const uint8_t*)src[pl]; p.src_stride[pl] = src_stride[pl]; }
         p.dst = (uint8_t*)dst; p.dst_row_bytes = dst_row_bytes;
-        const hipError_t e = launch_read(p, d->colorspace, d->depth, g.alpha, g.xs, g.ys, st, &g_kernel);
+        const hipError_t e = launch_read(p, d->colorspace, d->depth, g.alpha, g.xs, g.ys, st, g_kernel);
         if (e != hipSuccess) return hip_fail(e, "kernel launch", AVIFGPU_readErr);
         return 0;
     }
     if (mem_kind != AVIFGPU_MEM_HOST) return fail(AVIFGPU_formatBadParameters, "bad mem_kind %d", mem_kind);
-
-    err = avifgpu::read_rows_host_enqueue(d, row0, nrows, src, src_stride, dst, dst_row_bytes, 0);
-    if (err) return err;
-    return avifgpu::wait_slot(0);
+    return read_rows_host(d, row0, nrows, src, src_stride, dst, dst_row_bytes);
 }
 
 } // extern "C"
-
-
-// ======================================================================================================
-// Internal (C++) staging API, also used by host_shim.cpp to pipeline tiles: enqueue on the library stream,
-// return immediately, wait per slot.
-// ======================================================================================================
-namespace avifgpu {
-
-int wait_slot(int slot)
-{
-    Context::Slot& sl = g_ctx.slot[slot & 1];
-    if (!sl.pending) return 0;
-    const hipError_t e = hipEventSynchronize(sl.done);
-    sl.pending = false;
-    if (e != hipSuccess) return hip_fail(e, "event synchronize", AVIFGPU_writErr);
-    return 0;
-}
-
-int write_rows_host_enqueue(const avifgpu_write_desc* d, int row0, int nrows, const void* src, int64_t src_row_bytes,
-                            void* const dst[4], const int64_t dst_stride[4], int slot, const avifgpu_icc_transform* icc,
-                            const avifgpu_icc_shaper8* icc8, const avifgpu_icc_clut16* icc16)
-{
-    struct IccScope {                      // fill_write_params picks the transform up from g_icc / g_icc8
-        const avifgpu_icc_transform* saved; const avifgpu_icc_shaper8* saved8; const avifgpu_icc_clut16* saved16;
-        IccScope(const avifgpu_icc_transform* t, const avifgpu_icc_shaper8* t8, const avifgpu_icc_clut16* t16)
-            : saved(g_icc), saved8(g_icc8), saved16(g_icc16) { if (t) g_icc = t; if (t8) g_icc8 = t8; if (t16) g_icc16 = t16; }
-        ~IccScope() { g_icc = saved; g_icc8 = saved8; g_icc16 = saved16; }
-    } icc_scope(icc, icc8, icc16);
-    WriteGeom g;
-    int err = check_write(d, row0, nrows, g);
-    if (err) return err;
-    if (!g_ctx.ready) return fail(AVIFGPU_formatBadParameters, "avifgpu_init has not succeeded: no HIP device bound (no CPU fallback)");
-    if (nrows == 0) return 0;
-    WriteParams p;
-    if ((err = fill_write_params(d, row0, nrows, g, p))) return err;
-    if ((err = wait_slot(slot))) return err;
-
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    Context::Slot& sl = g_ctx.slot[slot & 1];
-    hipStream_t st = (slot & 1) ? g_ctx.stream1 : g_ctx.stream;     // one stream per staging slot
-    const int64_t min_src_row = (int64_t)d->width * d->planes * (d->depth / 8);
-    const size_t in_pitch = align256((size_t)min_src_row);
-    if ((err = ensure(&sl.d_in, &sl.d_in_cap, in_pitch * (size_t)nrows))) return err;
-    size_t off[4] = {0, 0, 0, 0}, pitch[4] = {0, 0, 0, 0}, out_total = 0;
-    int prow[4] = {0, 0, 0, 0}; int64_t pbytes[4] = {0, 0, 0, 0};
-    for (int pl = 0; pl < 4; ++pl) {
-        if (!write_plane_used(d, g, pl)) continue;
-        write_plane_extent(d, g, pl, nrows, prow[pl], pbytes[pl]);
-        pitch[pl] = align256((size_t)pbytes[pl]);
-        off[pl] = out_total;
-        out_total += pitch[pl] * (size_t)prow[pl];
-    }
-    if ((err = ensure(&sl.d_out, &sl.d_out_cap, out_total))) return err;
-    hipError_t e = hipMemcpy2DAsync(sl.d_in, in_pitch, src, (size_t)src_row_bytes, (size_t)min_src_row, (size_t)nrows, hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) return hip_fail(e, "H2D copy", AVIFGPU_writErr);
-    p.src = (const uint8_t*)sl.d_in; p.src_row_bytes = (int64_t)in_pitch;
-    for (int pl = 0; pl < 4; ++pl) {
-        p.dst[pl] = write_plane_used(d, g, pl) ? (uint8_t*)sl.d_out + off[pl] : nullptr;
-        p.dst_stride[pl] = (int64_t)pitch[pl];
-    }
-    e = launch_write(p, d->depth, d->planes, g.dst16, d->output, g.xs, g.ys, g_ctx.hot_variant, st, &g_kernel);
-    if (e != hipSuccess) return hip_fail(e, "kernel launch", AVIFGPU_writErr);
-    for (int pl = 0; pl < 4; ++pl) {
-        if (!write_plane_used(d, g, pl)) continue;
-        e = hipMemcpy2DAsync(dst[pl], (size_t)dst_stride[pl], (uint8_t*)sl.d_out + off[pl], pitch[pl], (size_t)pbytes[pl], (size_t)prow[pl], hipMemcpyDeviceToHost, st);
-        if (e != hipSuccess) return hip_fail(e, "D2H copy", AVIFGPU_writErr);
-    }
-    if ((e = hipEventRecord(sl.done, st)) != hipSuccess) return hip_fail(e, "event record", AVIFGPU_writErr);
-    sl.pending = true;
-    return 0;
-}
-
-int read_rows_host_enqueue(const avifgpu_read_desc* d, int row0, int nrows, const void* const src[4], const int64_t src_stride[4],
-                           void* dst, int64_t dst_row_bytes, int slot)
-{
-    ReadGeom g;
-    int err = check_read(d, row0, nrows, g);
-    if (err) return err;
-    if (!g_ctx.ready) return fail(AVIFGPU_formatBadParameters, "avifgpu_init has not succeeded: no HIP device bound (no CPU fallback)");
-    if (nrows == 0) return 0;
-    ReadParams p;
-    if ((err = fill_read_params(d, nrows, g, p))) return err;
-    if ((err = wait_slot(slot))) return err;
-
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    Context::Slot& sl = g_ctx.slot[slot & 1];
-    hipStream_t st = (slot & 1) ? g_ctx.stream1 : g_ctx.stream;     // one stream per staging slot
-    const int64_t min_dst_row = (int64_t)d->width * g.nch * (d->depth / 8);
-    size_t off[4] = {0, 0, 0, 0}, pitch[4] = {0, 0, 0, 0}, in_total = 0;
-    int prow[4] = {0, 0, 0, 0}; int64_t pbytes[4] = {0, 0, 0, 0};
-    for (int pl = 0; pl < 4; ++pl) {
-        if (!read_plane_used(d, g, pl)) continue;
-        read_plane_extent(d, g, pl, nrows, prow[pl], pbytes[pl]);
-        pitch[pl] = align256((size_t)pbytes[pl]);
-        off[pl] = in_total;
-        in_total += pitch[pl] * (size_t)prow[pl];
-    }
-    if ((err = ensure(&sl.d_in, &sl.d_in_cap, in_total))) return err;
-    const size_t out_pitch = align256((size_t)min_dst_row);
-    if ((err = ensure(&sl.d_out, &sl.d_out_cap, out_pitch * (size_t)nrows))) return err;
-    hipError_t e;
-    for (int pl = 0; pl < 4; ++pl) {
-        if (!read_plane_used(d, g, pl)) continue;
-        e = hipMemcpy2DAsync((uint8_t*)sl.d_in + off[pl], pitch[pl], src[pl], (size_t)src_stride[pl], (size_t)pbytes[pl], (size_t)prow[pl], hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) return hip_fail(e, "H2D copy", AVIFGPU_readErr);
-        p.src[pl] = (const uint8_t*)sl.d_in + off[pl]; p.src_stride[pl] = (int64_t)pitch[pl];
-    }
-    p.dst = (uint8_t*)sl.d_out; p.dst_row_bytes = (int64_t)out_pitch;
-    e = launch_read(p, d->colorspace, d->depth, g.alpha, g.xs, g.ys, st, &g_kernel);
-    if (e != hipSuccess) return hip_fail(e, "kernel launch", AVIFGPU_readErr);
-    e = hipMemcpy2DAsync(dst, (size_t)dst_row_bytes, sl.d_out, out_pitch, (size_t)min_dst_row, (size_t)nrows, hipMemcpyDeviceToHost, st);
-    if (e != hipSuccess) return hip_fail(e, "D2H copy", AVIFGPU_readErr);
-    if ((e = hipEventRecord(sl.done, st)) != hipSuccess) return hip_fail(e, "event record", AVIFGPU_readErr);
-    sl.pending = true;
-    return 0;
-}
-
-void set_error(const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
-
-} // namespace avifgpu

@@ -1,15 +1,17 @@
 // host_shim.cpp -- host-side mirror of the plug-in's conversion-layer entry points, above the C-ABI.
 //
-// Keeps the reference's operator interface for this path: the twelve free functions
-//   CreateHeifImage{Gray,RGB}{Eight,Sixteen,ThirtyTwo}Bit(formatRecord, alphaState, imageSize, saveOptions)
-//   ReadHeifImage{Gray,RGB}{Eight,Sixteen,ThirtyTwo}Bit(image, alphaState, nclxProfile, [loadOptions,] formatRecord)
-// (reference src/common/WriteHeifImage.h:29-63, ReadHeifImage.h:27-63) with the same argument meaning and the same
-// error behaviour (OSErrException / std::runtime_error / std::bad_alloc, mapped to OSErr at the C boundary the way
-// DoWriteStart / DoReadContinue map them, Write.cpp:345-364, Read.cpp:659-678).
+// One body for the reference's six CreateHeifImage{Gray,RGB}{Eight,Sixteen,ThirtyTwo}Bit functions and one for its six
+// ReadHeifImage{Gray,RGB}{Eight,Sixteen,ThirtyTwo}Bit functions (reference src/common/WriteHeifImage.h:29-63,
+// ReadHeifImage.h:27-63): same argument meaning, same error behaviour (OSErrException / std::runtime_error /
+// std::bad_alloc, mapped to OSErr at the C boundary the way DoWriteStart / DoReadContinue map them, Write.cpp:345-364,
+// Read.cpp:659-678).  The twelve reference-named, reference-typed functions themselves live where they can be compiled:
+// integration/WriteHeifImage_gpu.cpp and integration/ReadHeifImage_gpu.cpp, against the real SDK and libheif headers.
 //
-// What is different by design (MI355X-first): the row loop asks the host for multi-row TILES sized from maxData
-// and keeps TWO tiles in flight -- while the GPU converts tile k (H2D -> kernel -> D2H on the library stream) the
-// host's advanceState() is already filling tile k+1 into the other pinned buffer.  abortProc is polled per tile.
+// What is different by design (MI355X-first): the row loop asks the host for multi-row TILES sized from maxData and
+// deals them round-robin to the bound device contexts (pipeline.hip: one worker thread + pinned staging slots per
+// context), so while GPU k converts tile t (H2D -> kernel -> D2H on the slot's stream) the host's advanceState() is
+// already filling tile t+1 into another pinned buffer -- for another GPU when several are bound.  Everything the host
+// sees (callbacks, rectangles, order) happens on the ONE calling thread; abortProc is polled per tile.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdint>
@@ -17,22 +19,11 @@
 #include <cstring>
 #include <limits>
 #include <memory>
-#include <mutex>
-#include <set>
 #include <new>
 #include <stdexcept>
 
 #include "../../include/avifgpu_host.h"
-
-namespace avifgpu {
-int wait_slot(int slot);
-int write_rows_host_enqueue(const avifgpu_write_desc* d, int row0, int nrows, const void* src, int64_t src_row_bytes,
-                            void* const dst[4], const int64_t dst_stride[4], int slot, const avifgpu_icc_transform* icc = nullptr,
-                            const avifgpu_icc_shaper8* icc8 = nullptr, const avifgpu_icc_clut16* icc16 = nullptr);
-int read_rows_host_enqueue(const avifgpu_read_desc* d, int row0, int nrows, const void* const src[4], const int64_t src_stride[4],
-                           void* dst, int64_t dst_row_bytes, int slot);
-void set_error(const char* msg);
-}
+#include "staging.h"
 
 namespace avifgpu::host {
 
@@ -89,46 +80,28 @@ bool HasAlphaChannel(const FormatRecordPtr formatRecord)
     }
 }
 
-// ---- pinned double buffer the host fills / drains (replaces ScopedBufferSuiteBuffer, Write.cpp:297-299) ----
-// Pinning memory costs milliseconds per call, so the pair is cached for the life of the process and only grows
-// (Photoshop calls the plug-in serially: one conversion at a time).
-class TileBuffers {
-public:
-    TileBuffers(size_t bytes_each)
-    {
-        Cache& c = cache();
-        if (c.bytes < bytes_each) {
-            c.release();
-            for (int i = 0; i < 2; ++i)
-                if (hipHostMalloc(&c.buf[i], bytes_each, hipHostMallocDefault) != hipSuccess) { c.release(); throw std::bad_alloc(); }
-            c.bytes = bytes_each;
-        }
-    }
-    TileBuffers(const TileBuffers&) = delete;
-    TileBuffers& operator=(const TileBuffers&) = delete;
-    void* operator[](int i) const { return cache().buf[i & 1]; }
-private:
-    struct Cache {
-        void* buf[2] = { nullptr, nullptr };
-        size_t bytes = 0;
-        void release() { for (auto& b : buf) { if (b) (void)hipHostFree(b); b = nullptr; } bytes = 0; }
-    };
-    static Cache& cache() { static Cache c; return c; }
-};
-
-struct ImageDeleter { void operator()(avifgpu_image* img) const { if (img) { avifgpu_image_free(img); delete img; } } };
-using ScopedHeifImage = std::unique_ptr<avifgpu_image, ImageDeleter>;      // reference ScopedHeif.h:37,50
-
+// Rows per advanceState() request: as many as fit the host's maxData budget (Write.cpp:214-221 halves what Photoshop offers;
+// the reference then asks for ONE row at a time and never compares its row buffer with maxData, Write.cpp:297-299), even for
+// 4:2:0 so that no 2x2 chroma block straddles a tile.  Like the reference the minimum request -- one row, two for 4:2:0 -- is
+// made whatever maxData says; every larger tile stays within the budget.
 int rows_per_tile(int32_t max_data, int64_t row_bytes, int height, bool even)
 {
     int64_t budget = max_data > 0 ? max_data : (64LL << 20);
     budget = std::min<int64_t>(budget, std::numeric_limits<int32_t>::max());
-    int64_t rows = std::max<int64_t>(1, budget / std::max<int64_t>(row_bytes, 1));
+    int64_t rows = budget / std::max<int64_t>(row_bytes, 1);
     rows = std::min<int64_t>(rows, height);
-    if (even && rows > 1) rows -= rows & 1;
-    if (even && rows < 2 && height > 1) rows = 2;           // a 4:2:0 block never straddles a tile
-    return (int)rows;
+    if (even && rows > 1 && rows < height) rows -= rows & 1;
+    const int64_t minimum = (even && height > 1) ? 2 : 1;
+    return (int)std::max<int64_t>(rows, minimum);
 }
+
+// tile t -> (context, slot): consecutive tiles go to different GPUs, a context's slots are used in rotation
+struct TileSlots {
+    int nctx = avifgpu::context_count(), nslots = avifgpu::slots_per_context();
+    int ctx(int t) const { return t % nctx; }
+    int slot(int t) const { return (t / nctx) % nslots; }
+    int depth() const { return nctx * nslots; }              // tiles that can be outstanding at once
+};
 
 // ---- write ---------------------------------------------------------------------------------------------
 struct WritePlan { avifgpu_write_desc desc; int output; };
@@ -167,8 +140,12 @@ void CreateHeifImageInto(FormatRecordPtr formatRecord, AlphaState alphaState, co
     d.chroma = saveOptions.lossless ? AVIFGPU_CHROMA_444 : saveOptions.chromaSubsampling;   // Write.cpp:98-127
     d.matrix_coefficients = matrix; d.color_primaries = primaries;
     d.full_range = 1;                                                                        // WriteMetadata.cpp:46
-    d.chroma_downsampling = AVIFGPU_DOWNSAMPLE_AVERAGE;
+    // stage B as libheif 1.14.0 performs it: co-sited (top-left) chroma sample, zero point 1 << (bits-1)
+    d.chroma_downsampling = saveOptions.chromaDownsampling ? AVIFGPU_DOWNSAMPLE_AVERAGE : AVIFGPU_DOWNSAMPLE_NEAREST;
     d.chroma_zero_point = AVIFGPU_CHROMA_ZERO_LIBHEIF;
+    // a gray document has no chroma to convert: planar Y(+Alpha) IS the reference's hand-off (WriteHeifImage.cpp:181-194), so a
+    // caller that asks for the fused output on every save gets it for gray documents too
+    if (mono) d.output = AVIFGPU_OUT_REFERENCE;
 
     // describe the image the way CreateHeifImage / heif_image_add_plane do (WriteHeifImage.cpp:31-39,:63-85,:181-194)
     img->width = d.width; img->height = d.height; img->bit_depth = d.bit_depth;
@@ -219,25 +196,33 @@ void CreateHeifImageInto(FormatRecordPtr formatRecord, AlphaState alphaState, co
         if (rc) throw OSErrException((OSErr)rc);
     }
 
-    const bool even = output == AVIFGPU_OUT_YCBCR && d.chroma == AVIFGPU_CHROMA_420;
+    const bool even = d.output == AVIFGPU_OUT_YCBCR && d.chroma == AVIFGPU_CHROMA_420;
     const int ys = even ? 1 : 0;
     const int tileRows = rows_per_tile(formatRecord->maxData, formatRecord->rowBytes, d.height, even);
-    TileBuffers buffers((size_t)tileRows * (size_t)formatRecord->rowBytes);
+    const size_t tileBytes = (size_t)tileRows * (size_t)formatRecord->rowBytes;
+    const TileSlots ts;
+    if (ts.nctx == 0) { avifgpu::set_error("avifgpu_init has not succeeded: no HIP device bound (no CPU fallback)"); throw OSErrException(AVIFGPU_formatBadParameters); }
+    avifgpu::IccArgs iccArgs;
+    iccArgs.f32 = iccp; iccArgs.s8 = icc8.get(); iccArgs.c16 = icc16.get();
+
+    // Every exit path drains the contexts: no tile may still be reading a pinned buffer or writing a plane afterwards.
+    auto bail = [&](OSErr e) { (void)avifgpu::wait_all(); formatRecord->data = nullptr; throw OSErrException(e); };
 
     const int32_t left = 0, right = imageSize.h;
-    int slot = 0;
-    for (int32_t top = 0; top < imageSize.v; top += tileRows, slot ^= 1) {
-        if (formatRecord->abortProc && formatRecord->abortProc()) {                         // WriteHeifImage.cpp:1019-1022
-            (void)avifgpu::wait_slot(0); (void)avifgpu::wait_slot(1);
-            throw OSErrException(AVIFGPU_userCanceledErr);
-        }
+    int t = 0;
+    for (int32_t top = 0; top < imageSize.v; top += tileRows, ++t) {
+        if (formatRecord->abortProc && formatRecord->abortProc()) bail(AVIFGPU_userCanceledErr);   // WriteHeifImage.cpp:1019-1022
         const int32_t bottom = std::min(top + tileRows, imageSize.v);
-        // this buffer's previous tile (two iterations ago) must have left the host memory
-        OSErrException::ThrowIfError((OSErr)avifgpu::wait_slot(slot));
-        formatRecord->data = buffers[slot];
+        const int ctx = ts.ctx(t), slot = ts.slot(t);
+        // this buffer's previous tile (depth() tiles ago) must have left the host memory
+        const int werr = avifgpu::wait_slot(ctx, slot);
+        if (werr) bail((OSErr)werr);
+        void* tile = avifgpu::tile_buffer(ctx, slot, tileBytes);
+        if (!tile) { (void)avifgpu::wait_all(); throw std::bad_alloc(); }
+        formatRecord->data = tile;
         SetRect(formatRecord, top, left, bottom, right);
         const OSErr herr = formatRecord->advanceState();                                    // host fills rows [top, bottom)
-        if (herr != AVIFGPU_noErr) { (void)avifgpu::wait_slot(0); (void)avifgpu::wait_slot(1); throw OSErrException(herr); }
+        if (herr != AVIFGPU_noErr) bail(herr);
         // NOTE: ColorProfileConversion::ConvertRow (lcms2, WriteHeifImage.cpp:1031-1034) is the caller's hook: it is
         // a no-op unless an ICC transform exists; INTEGRATION.md shows where the plug-in keeps calling it per row.
 
@@ -248,33 +233,12 @@ void CreateHeifImageInto(FormatRecordPtr formatRecord, AlphaState alphaState, co
             dst[pl] = img->plane[pl] ? img->plane[pl] + (int64_t)r * img->stride[pl] : nullptr;
             stride[pl] = img->stride[pl];
         }
-        const int err = avifgpu::write_rows_host_enqueue(&d, top, bottom - top, formatRecord->data, formatRecord->rowBytes,
-                                                         dst, stride, slot, iccp, icc8.get(), icc16.get());
-        if (err) { (void)avifgpu::wait_slot(0); (void)avifgpu::wait_slot(1); throw OSErrException((OSErr)err); }
+        const int err = avifgpu::write_tile_enqueue(ctx, slot, &d, top, bottom - top, tile, formatRecord->rowBytes, dst, stride, iccArgs);
+        if (err) bail((OSErr)err);
     }
-    OSErrException::ThrowIfError((OSErr)avifgpu::wait_slot(0));
-    OSErrException::ThrowIfError((OSErr)avifgpu::wait_slot(1));
     formatRecord->data = nullptr;
+    OSErrException::ThrowIfError((OSErr)avifgpu::wait_all());
 }
-
-ScopedHeifImage CreateOwned(FormatRecordPtr formatRecord, AlphaState alphaState, const VPoint& imageSize,
-                            const SaveUIOptions& saveOptions, int16_t depth, bool mono)
-{
-    if (formatRecord->depth != depth || IsMonochromeImage(formatRecord) != mono) throw OSErrException(AVIFGPU_formatBadParameters);
-    ScopedHeifImage image(new avifgpu_image());
-    std::memset(image.get(), 0, sizeof(avifgpu_image));
-    CreateHeifImageInto(formatRecord, alphaState, imageSize, saveOptions, AVIFGPU_OUT_REFERENCE,
-                        AVIFGPU_MATRIX_BT601, AVIFGPU_PRIMARIES_BT709, image.get());
-    return image;
-}
-
-// The reference's six names (WriteHeifImage.h:29-63).  Each returns what its namesake builds.
-ScopedHeifImage CreateHeifImageGrayEightBit(FormatRecordPtr fr, AlphaState a, const VPoint& s, const SaveUIOptions& o) { return CreateOwned(fr, a, s, o, 8, true); }
-ScopedHeifImage CreateHeifImageGraySixteenBit(FormatRecordPtr fr, AlphaState a, const VPoint& s, const SaveUIOptions& o) { return CreateOwned(fr, a, s, o, 16, true); }
-ScopedHeifImage CreateHeifImageGrayThirtyTwoBit(FormatRecordPtr fr, AlphaState a, const VPoint& s, const SaveUIOptions& o) { return CreateOwned(fr, a, s, o, 32, true); }
-ScopedHeifImage CreateHeifImageRGBEightBit(FormatRecordPtr fr, AlphaState a, const VPoint& s, const SaveUIOptions& o) { return CreateOwned(fr, a, s, o, 8, false); }
-ScopedHeifImage CreateHeifImageRGBSixteenBit(FormatRecordPtr fr, AlphaState a, const VPoint& s, const SaveUIOptions& o) { return CreateOwned(fr, a, s, o, 16, false); }
-ScopedHeifImage CreateHeifImageRGBThirtyTwoBit(FormatRecordPtr fr, AlphaState a, const VPoint& s, const SaveUIOptions& o) { return CreateOwned(fr, a, s, o, 32, false); }
 
 // ---- read ------------------------------------------------------------------------------------------------
 void ReadHeifImageCommon(const avifgpu_image* image, AlphaState alphaState, const avifgpu_nclx* nclxProfile,
@@ -315,10 +279,16 @@ void ReadHeifImageCommon(const avifgpu_image* image, AlphaState alphaState, cons
     const bool even = d.colorspace == AVIFGPU_COLORSPACE_YCBCR && d.chroma == AVIFGPU_CHROMA_420;
     const int ys = even ? 1 : 0;
     const int tileRows = rows_per_tile(formatRecord->maxData, formatRecord->rowBytes, d.height, even);
-    TileBuffers buffers((size_t)tileRows * (size_t)formatRecord->rowBytes);
+    const size_t tileBytes = (size_t)tileRows * (size_t)formatRecord->rowBytes;
+    const TileSlots ts;
+    if (ts.nctx == 0) { avifgpu::set_error("avifgpu_init has not succeeded: no HIP device bound (no CPU fallback)"); throw OSErrException(AVIFGPU_formatBadParameters); }
+    const int ntiles = (imageSize.v + tileRows - 1) / tileRows;
+    auto bail = [&](OSErr e) { (void)avifgpu::wait_all(); formatRecord->data = nullptr; throw OSErrException(e); };
 
-    auto enqueue = [&](int32_t top, int slot) {
-        const int32_t bottom = std::min(top + tileRows, imageSize.v);
+    // tile t converts into the pinned buffer of its (context, slot); the host drains the buffers in row order while up to
+    // depth() - 1 later tiles are being converted on the other slots / GPUs
+    auto enqueue = [&](int t) {
+        const int32_t top = t * tileRows, bottom = std::min(top + tileRows, imageSize.v);
         const void* src[4]; int64_t stride[4];
         for (int pl = 0; pl < 4; ++pl) {
             const bool chromaPlane = d.colorspace == AVIFGPU_COLORSPACE_YCBCR && (pl == 1 || pl == 2);
@@ -326,32 +296,27 @@ void ReadHeifImageCommon(const avifgpu_image* image, AlphaState alphaState, cons
             src[pl] = image->plane[pl] ? image->plane[pl] + (int64_t)r * image->stride[pl] : nullptr;
             stride[pl] = image->stride[pl];
         }
-        const int err = avifgpu::read_rows_host_enqueue(&d, top, bottom - top, src, stride, buffers[slot], formatRecord->rowBytes, slot);
-        if (err) { (void)avifgpu::wait_slot(0); (void)avifgpu::wait_slot(1); throw OSErrException((OSErr)err); }
+        void* tile = avifgpu::tile_buffer(ts.ctx(t), ts.slot(t), tileBytes);
+        if (!tile) { (void)avifgpu::wait_all(); throw std::bad_alloc(); }
+        const int err = avifgpu::read_tile_enqueue(ts.ctx(t), ts.slot(t), &d, top, bottom - top, src, stride, tile, formatRecord->rowBytes);
+        if (err) bail((OSErr)err);
     };
 
     const int32_t left = 0, right = imageSize.h;
-    int slot = 0;
-    if (imageSize.v > 0) enqueue(0, 0);
-    for (int32_t top = 0; top < imageSize.v; top += tileRows, slot ^= 1) {
-        if (top + tileRows < imageSize.v) enqueue(top + tileRows, slot ^ 1);              // next tile converts while the host drains this one
-        OSErrException::ThrowIfError((OSErr)avifgpu::wait_slot(slot));
-        const int32_t bottom = std::min(top + tileRows, imageSize.v);
-        formatRecord->data = buffers[slot];
+    for (int t = 0; t < std::min(ntiles, ts.depth()); ++t) enqueue(t);
+    for (int t = 0; t < ntiles; ++t) {
+        const int werr = avifgpu::wait_slot(ts.ctx(t), ts.slot(t));
+        if (werr) bail((OSErr)werr);
+        const int32_t top = t * tileRows, bottom = std::min(top + tileRows, imageSize.v);
+        formatRecord->data = avifgpu::tile_buffer(ts.ctx(t), ts.slot(t), tileBytes);
         SetRect(formatRecord, top, left, bottom, right);
         const OSErr herr = formatRecord->advanceState();                                   // ReadHeifImage.cpp:159
-        if (herr != AVIFGPU_noErr) { (void)avifgpu::wait_slot(0); (void)avifgpu::wait_slot(1); throw OSErrException(herr); }
+        if (herr != AVIFGPU_noErr) bail(herr);
+        if (t + ts.depth() < ntiles) enqueue(t + ts.depth());                              // this buffer is free again
     }
     formatRecord->data = nullptr;
+    OSErrException::ThrowIfError((OSErr)avifgpu::wait_all());
 }
-
-// The reference's six names (ReadHeifImage.h:27-63).
-void ReadHeifImageGrayEightBit(const avifgpu_image* i, AlphaState a, const avifgpu_nclx* n, FormatRecordPtr fr) { ReadHeifImageCommon(i, a, n, nullptr, fr); }
-void ReadHeifImageGraySixteenBit(const avifgpu_image* i, AlphaState a, const avifgpu_nclx* n, FormatRecordPtr fr) { ReadHeifImageCommon(i, a, n, nullptr, fr); }
-void ReadHeifImageGrayThirtyTwoBit(const avifgpu_image* i, AlphaState a, const avifgpu_nclx* n, const LoadUIOptions& l, FormatRecordPtr fr) { ReadHeifImageCommon(i, a, n, &l, fr); }
-void ReadHeifImageRGBEightBit(const avifgpu_image* i, AlphaState a, const avifgpu_nclx* n, FormatRecordPtr fr) { ReadHeifImageCommon(i, a, n, nullptr, fr); }
-void ReadHeifImageRGBSixteenBit(const avifgpu_image* i, AlphaState a, const avifgpu_nclx* n, FormatRecordPtr fr) { ReadHeifImageCommon(i, a, n, nullptr, fr); }
-void ReadHeifImageRGBThirtyTwoBit(const avifgpu_image* i, AlphaState a, const avifgpu_nclx* n, const LoadUIOptions& l, FormatRecordPtr fr) { ReadHeifImageCommon(i, a, n, &l, fr); }
 
 // Exception -> OSErr exactly as the Do* drivers do it (Write.cpp:345-364, Read.cpp:659-678).
 template <typename F> OSErr guarded(F&& f, OSErr fallback)
@@ -366,11 +331,6 @@ template <typename F> OSErr guarded(F&& f, OSErr fallback)
 } // namespace avifgpu::host
 
 using namespace avifgpu::host;
-
-namespace {
-std::mutex g_pinned_mu;
-std::set<void*> g_pinned;          // plane blocks avifgpu_image_alloc obtained from hipHostMalloc
-}
 
 extern "C" {
 
@@ -400,14 +360,11 @@ avifgpu_OSErr avifgpu_image_alloc(avifgpu_image* img)
     }
     const bool wantAlpha = img->has_alpha && !(img->colorspace == AVIFGPU_COLORSPACE_RGB && img->chroma >= 10);
     if (wantAlpha) { w[3] = img->width; h[3] = img->height; img->stride[3] = ((w[3] * ssz) + 15) & ~15; off[3] = total; total += (size_t)img->stride[3] * h[3]; }
-    // Pinned when a device is bound (the planes are the D2H target of every tile: pageable memory makes that copy the serial
-    // part of the save pipeline); ordinary memory otherwise, so the function also works in a process without a GPU.
+    // Ordinary heap memory, like the planes heif_image_add_plane hands the plug-in: the library's workers bounce each tile
+    // through their pinned staging.  (Page-locking the planes per save costs more than it buys: hipHostMalloc of the 403 MB of
+    // an 8192^2 10-bit 4:4:4 image takes ~25 ms, the whole save ~24 ms -- profiles/r02/host_shim_end_to_end.jsonl.)
     void* base = nullptr;
-    bool pinned = false;
-    int dev = -1;
-    if (hipGetDevice(&dev) == hipSuccess && hipHostMalloc(&base, total ? total : 64, hipHostMallocDefault) == hipSuccess) pinned = true;
-    else { (void)hipGetLastError(); base = nullptr; if (posix_memalign(&base, 64, total ? total : 64) != 0) return AVIFGPU_memFullErr; }
-    if (pinned) { std::lock_guard<std::mutex> lk(g_pinned_mu); g_pinned.insert(base); }
+    if (posix_memalign(&base, 64, total ? total : 64) != 0) return AVIFGPU_memFullErr;
     for (int pl = 0; pl < 4; ++pl) img->plane[pl] = w[pl] ? (uint8_t*)base + off[pl] : nullptr;
     img->owner = base;
     return AVIFGPU_noErr;
@@ -416,9 +373,7 @@ avifgpu_OSErr avifgpu_image_alloc(avifgpu_image* img)
 void avifgpu_image_free(avifgpu_image* img)
 {
     if (!img || !img->owner) return;
-    bool pinned = false;
-    { std::lock_guard<std::mutex> lk(g_pinned_mu); pinned = g_pinned.erase(img->owner) != 0; }
-    if (pinned) (void)hipHostFree(img->owner); else free(img->owner);
+    free(img->owner);
     img->owner = nullptr;
     for (auto& p : img->plane) p = nullptr;
 }

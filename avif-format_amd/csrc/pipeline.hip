@@ -1,0 +1,661 @@
+// pipeline.hip -- the bound device contexts and the in-process multi-GPU row-tile scheduler.
+//
+// What the reference does on this path: ONE thread, one row per advanceState(), convert, next row
+// (WriteHeifImage.cpp:1017-1029, ReadHeifImage.cpp:141-160; buffer sized at Write.cpp:279-299).  What an 8-GPU MI355X node
+// wants instead: the image cut into contiguous even-row tiles, one per GPU, no exchange step between them,
+// every tile streamed through its GPU in sub-tiles so that the H2D of sub-tile k+1, the kernel of k and the D2H of k-1 overlap
+// -- and all of it driven from the one calling thread the host application gives the plug-in.
+//
+// Structure:
+//   * avifgpu_init_devices binds N contexts.  A context = a HIP device ordinal + ONE worker thread whose current device is
+//     that ordinal for its whole life (the caller's current device is never touched) + kSlots staging slots.  A slot owns a
+//     stream, a completion event, device in/out buffers and (lazily) two pinned host buffers.
+//   * The calling thread only queues tiles (write_tile_enqueue / read_tile_enqueue) and waits for slots; the worker issues the
+//     copies and the launch, and finishes tiles in order.  A host buffer that is already page-locked (the shim's tile buffers,
+//     planes from avifgpu_image_alloc, memory the caller registered) is the DMA source / target itself; a pageable buffer
+//     (libheif's planes, numpy arrays) is bounced through the slot's pinned buffer with the WORKER's memcpy, so N contexts
+//     also give N memcpy streams and the caller's memory is never registered / unregistered behind its back.
+//   * write_rows_host / read_rows_host cut a row range into one tile per context (row_cut: the rule of sharding.row_cut) and
+//     deal sub-tiles round-robin, so every device's DMA engines and its x16 link are busy at the same time.  No collective,
+//     no peer traffic: a tile's output bytes depend on its own rows only, so the planes are byte-identical for any N.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "staging.h"
+
+namespace avifgpu {
+namespace {
+
+constexpr int kMaxSlots = 8;
+constexpr int kDefaultLanes = 2;        // workers per bound device (AVIFGPU_LANES): see contexts_init
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+// Device staging pitch of a row of `bytes`: tight when that keeps every row 16-byte aligned (then a contiguous host tile is ONE
+// linear DMA transfer and the kernels take their aligned paths), padded otherwise.
+size_t staging_pitch(size_t bytes) { return (bytes % 16 == 0) ? bytes : align256(bytes); }
+
+struct Job {
+    bool is_write = true;
+    int slot = 0;
+    avifgpu_write_desc wd{};
+    avifgpu_read_desc rd{};
+    int row0 = 0, nrows = 0;
+    const void* rows_in = nullptr;   int64_t rows_in_stride = 0;      // write: interleaved host rows
+    void* planes_out[4] = {};        int64_t planes_out_stride[4] = {};
+    const void* planes_in[4] = {};   int64_t planes_in_stride[4] = {}; // read
+    void* rows_out = nullptr;        int64_t rows_out_stride = 0;
+    IccArgs icc;
+    // filled by start(): what finish() still has to copy out of the pinned bounce buffer
+    struct Bounce { uint8_t* dst; int64_t dst_stride; size_t off, pitch, bytes; int rows; } bounce[4];
+    int nbounce = 0;
+    char label[kLabelBytes] = "";
+    double t_queued = 0, t_start = 0, t_issued = 0;        // AVIFGPU_TRACE
+};
+
+struct Slot {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    void* d_in = nullptr;  size_t d_in_cap = 0;
+    void* d_out = nullptr; size_t d_out_cap = 0;
+    void* h_rows = nullptr;   size_t h_rows_cap = 0;      // pinned: the shim's tile buffer / bounce of pageable rows
+    void* h_planes = nullptr; size_t h_planes_cap = 0;    // pinned: bounce of pageable planes
+    bool busy = false;                                    // queued or in flight (guarded by Ctx::mu)
+};
+
+struct Ctx {
+    int device = -1;
+    int nslots = 4;
+    Slot slot[kMaxSlots];
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::deque<Job> queue;
+    bool stop = false, started = false;
+    int init_err = 0; char init_msg[256] = "";
+    int err = 0; char err_msg[512] = "";                   // first failure of any tile since the last wait_all
+    char last_label[kLabelBytes] = "";
+};
+
+std::mutex g_ctx_mu;                                       // init / shutdown
+std::vector<Ctx*>* g_ctxs = nullptr;                       // heap-held on purpose: a process that never calls avifgpu_shutdown
+                                                           // must not run thread destructors at exit
+std::vector<int> g_bound;                                  // the ordinals of the current binding (as passed by the caller)
+
+// AVIFGPU_TRACE=1: one stderr line per tile with the worker-side timeline (microseconds since the context was created)
+bool g_trace = false;
+double now_us()
+{
+    using namespace std::chrono;
+    static const steady_clock::time_point t0 = steady_clock::now();
+    return duration<double, std::micro>(steady_clock::now() - t0).count();
+}
+
+int env_int(const char* name, int dflt, int lo, int hi)
+{
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    const long x = strtol(v, nullptr, 0);
+    return (int)std::min<long>(std::max<long>(x, lo), hi);
+}
+
+// Is [p, p + bytes) page-locked memory HIP can DMA to directly?
+bool is_pinned(const void* p, size_t bytes)
+{
+    auto one = [](const void* q) {
+        hipPointerAttribute_t a;
+        std::memset(&a, 0, sizeof(a));
+        if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return a.type == hipMemoryTypeHost;
+    };
+    if (!p) return false;
+    return one(p) && (bytes <= 1 || one(static_cast<const uint8_t*>(p) + bytes - 1));
+}
+
+int grow_device(void** p, size_t* cap, size_t need)
+{
+    if (need <= *cap) return 0;
+    if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+    const hipError_t e = hipMalloc(p, need);
+    if (e != hipSuccess) { *p = nullptr; return hip_fail(e, "hipMalloc(staging)", AVIFGPU_memFullErr); }
+    *cap = need;
+    return 0;
+}
+
+int grow_pinned(void** p, size_t* cap, size_t need)
+{
+    if (need <= *cap) return 0;
+    if (*p) { (void)hipHostFree(*p); *p = nullptr; *cap = 0; }
+    const hipError_t e = hipHostMalloc(p, need, hipHostMallocPortable);
+    if (e != hipSuccess) { *p = nullptr; (void)hipGetLastError(); return fail(AVIFGPU_memFullErr, "hipHostMalloc(%zu bytes of pinned staging) failed", need); }
+    *cap = need;
+    return 0;
+}
+
+// rows x bytes, host -> device (or back), ONE linear transfer when both sides are contiguous
+hipError_t copy_rows(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t bytes, size_t rows, hipMemcpyKind kind, hipStream_t st)
+{
+    if (rows == 0 || bytes == 0) return hipSuccess;
+    if (dst_pitch == bytes && src_pitch == bytes) return hipMemcpyAsync(dst, src, bytes * rows, kind, st);
+    return hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, bytes, rows, kind, st);
+}
+
+void host_copy_rows(uint8_t* dst, size_t dst_pitch, const uint8_t* src, size_t src_pitch, size_t bytes, size_t rows)
+{
+    if (dst_pitch == bytes && src_pitch == bytes) { std::memcpy(dst, src, bytes * rows); return; }
+    for (size_t r = 0; r < rows; ++r) std::memcpy(dst + r * dst_pitch, src + r * src_pitch, bytes);
+}
+
+// ---- worker side -------------------------------------------------------------------------------------------------------
+// Issue the copies and the launch of one tile on its slot's stream.  Returns an OSErr; the message is in this thread's
+// last_error().  After the first asynchronous operation any failure drains the stream before returning, so no DMA is left
+// running into (or out of) caller memory behind an error return.
+int start_write(Ctx& c, Job& j)
+{
+    Slot& sl = c.slot[j.slot];
+    const avifgpu_write_desc* d = &j.wd;
+    WriteGeom g;
+    int err = check_write(d, j.row0, j.nrows, g);
+    if (err) return err;
+    WriteParams p;
+    if ((err = fill_write_params(d, j.row0, j.nrows, g, j.icc, p))) return err;
+
+    const size_t row_bytes = (size_t)d->width * d->planes * (d->depth / 8);
+    const size_t in_pitch = staging_pitch(row_bytes);
+    if ((err = grow_device(&sl.d_in, &sl.d_in_cap, in_pitch * (size_t)j.nrows))) return err;
+    size_t off[4] = {}, pitch[4] = {}, out_total = 0;
+    int prow[4] = {}; int64_t pbytes[4] = {};
+    for (int pl = 0; pl < 4; ++pl) {
+        if (!write_plane_used(d, g, pl)) continue;
+        write_plane_extent(d, g, pl, j.nrows, prow[pl], pbytes[pl]);
+        pitch[pl] = staging_pitch((size_t)pbytes[pl]);
+        off[pl] = out_total;
+        out_total += align256(pitch[pl] * (size_t)prow[pl]);
+    }
+    if ((err = grow_device(&sl.d_out, &sl.d_out_cap, out_total))) return err;
+
+    hipStream_t st = sl.stream;
+    hipError_t e;
+    const size_t src_span = (size_t)j.rows_in_stride * (size_t)(j.nrows - 1) + row_bytes;
+    const bool own_tile = j.rows_in == sl.h_rows;            // the shim's pinned tile buffer
+    if (own_tile || is_pinned(j.rows_in, src_span)) {
+        e = copy_rows(sl.d_in, in_pitch, j.rows_in, (size_t)j.rows_in_stride, row_bytes, (size_t)j.nrows, hipMemcpyHostToDevice, st);
+    } else {
+        if ((err = grow_pinned(&sl.h_rows, &sl.h_rows_cap, in_pitch * (size_t)j.nrows))) return err;
+        host_copy_rows(static_cast<uint8_t*>(sl.h_rows), in_pitch, static_cast<const uint8_t*>(j.rows_in), (size_t)j.rows_in_stride, row_bytes, (size_t)j.nrows);
+        e = hipMemcpyAsync(sl.d_in, sl.h_rows, in_pitch * (size_t)j.nrows, hipMemcpyHostToDevice, st);
+    }
+    if (e != hipSuccess) { (void)hipStreamSynchronize(st); return hip_fail(e, "H2D copy", AVIFGPU_writErr); }
+
+    p.src = static_cast<const uint8_t*>(sl.d_in); p.src_row_bytes = (int64_t)in_pitch;
+    for (int pl = 0; pl < 4; ++pl) {
+        p.dst[pl] = write_plane_used(d, g, pl) ? static_cast<uint8_t*>(sl.d_out) + off[pl] : nullptr;
+        p.dst_stride[pl] = (int64_t)pitch[pl];
+    }
+    e = launch_write(p, d->depth, d->planes, g.dst16, d->output, g.xs, g.ys, hot_variant(), st, j.label);
+    if (e != hipSuccess) { (void)hipStreamSynchronize(st); return hip_fail(e, "kernel launch", AVIFGPU_writErr); }
+
+    // planes back: straight into page-locked destinations, through the pinned bounce buffer otherwise
+    j.nbounce = 0;
+    bool any_pageable = false;
+    bool pinned_dst[4] = {};
+    for (int pl = 0; pl < 4; ++pl) {
+        if (!write_plane_used(d, g, pl) || prow[pl] == 0) continue;
+        const size_t span = (size_t)j.planes_out_stride[pl] * (size_t)(prow[pl] - 1) + (size_t)pbytes[pl];
+        pinned_dst[pl] = is_pinned(j.planes_out[pl], span);
+        any_pageable = any_pageable || !pinned_dst[pl];
+    }
+    if (any_pageable && (err = grow_pinned(&sl.h_planes, &sl.h_planes_cap, out_total))) { (void)hipStreamSynchronize(st); return err; }
+    for (int pl = 0; pl < 4; ++pl) {
+        if (!write_plane_used(d, g, pl) || prow[pl] == 0) continue;
+        const uint8_t* dev = static_cast<const uint8_t*>(sl.d_out) + off[pl];
+        if (pinned_dst[pl]) {
+            e = copy_rows(j.planes_out[pl], (size_t)j.planes_out_stride[pl], dev, pitch[pl], (size_t)pbytes[pl], (size_t)prow[pl], hipMemcpyDeviceToHost, st);
+        } else {
+            e = hipMemcpyAsync(static_cast<uint8_t*>(sl.h_planes) + off[pl], dev, pitch[pl] * (size_t)prow[pl], hipMemcpyDeviceToHost, st);
+            j.bounce[j.nbounce++] = { static_cast<uint8_t*>(j.planes_out[pl]), j.planes_out_stride[pl], off[pl], pitch[pl], (size_t)pbytes[pl], prow[pl] };
+        }
+        if (e != hipSuccess) { (void)hipStreamSynchronize(st); return hip_fail(e, "D2H copy", AVIFGPU_writErr); }
+    }
+    if ((e = hipEventRecord(sl.done, st)) != hipSuccess) { (void)hipStreamSynchronize(st); return hip_fail(e, "event record", AVIFGPU_writErr); }
+    return 0;
+}
+
+int start_read(Ctx& c, Job& j)
+{
+    Slot& sl = c.slot[j.slot];
+    const avifgpu_read_desc* d = &j.rd;
+    ReadGeom g;
+    int err = check_read(d, j.row0, j.nrows, g);
+    if (err) return err;
+    ReadParams p;
+    if ((err = fill_read_params(d, j.nrows, g, p))) return err;
+
+    size_t off[4] = {}, pitch[4] = {}, in_total = 0;
+    int prow[4] = {}; int64_t pbytes[4] = {};
+    for (int pl = 0; pl < 4; ++pl) {
+        if (!read_plane_used(d, g, pl)) continue;
+        read_plane_extent(d, g, pl, j.nrows, prow[pl], pbytes[pl]);
+        pitch[pl] = staging_pitch((size_t)pbytes[pl]);
+        off[pl] = in_total;
+        in_total += align256(pitch[pl] * (size_t)prow[pl]);
+    }
+    if ((err = grow_device(&sl.d_in, &sl.d_in_cap, in_total))) return err;
+    const size_t row_bytes = (size_t)d->width * g.nch * (d->depth / 8);
+    const size_t out_pitch = staging_pitch(row_bytes);
+    if ((err = grow_device(&sl.d_out, &sl.d_out_cap, out_pitch * (size_t)j.nrows))) return err;
+
+    hipStream_t st = sl.stream;
+    hipError_t e = hipSuccess;
+    bool pinned_src[4] = {}, any_pageable = false;
+    for (int pl = 0; pl < 4; ++pl) {
+        if (!read_plane_used(d, g, pl) || prow[pl] == 0) continue;
+        const size_t span = (size_t)j.planes_in_stride[pl] * (size_t)(prow[pl] - 1) + (size_t)pbytes[pl];
+        pinned_src[pl] = is_pinned(j.planes_in[pl], span);
+        any_pageable = any_pageable || !pinned_src[pl];
+    }
+    if (any_pageable && (err = grow_pinned(&sl.h_planes, &sl.h_planes_cap, in_total))) return err;
+    for (int pl = 0; pl < 4; ++pl) {
+        if (!read_plane_used(d, g, pl)) continue;
+        uint8_t* dev = static_cast<uint8_t*>(sl.d_in) + off[pl];
+        p.src[pl] = dev; p.src_stride[pl] = (int64_t)pitch[pl];
+        if (prow[pl] == 0) continue;
+        if (pinned_src[pl]) {
+            e = copy_rows(dev, pitch[pl], j.planes_in[pl], (size_t)j.planes_in_stride[pl], (size_t)pbytes[pl], (size_t)prow[pl], hipMemcpyHostToDevice, st);
+        } else {
+            uint8_t* hb = static_cast<uint8_t*>(sl.h_planes) + off[pl];
+            host_copy_rows(hb, pitch[pl], static_cast<const uint8_t*>(j.planes_in[pl]), (size_t)j.planes_in_stride[pl], (size_t)pbytes[pl], (size_t)prow[pl]);
+            e = hipMemcpyAsync(dev, hb, pitch[pl] * (size_t)prow[pl], hipMemcpyHostToDevice, st);
+        }
+        if (e != hipSuccess) { (void)hipStreamSynchronize(st); return hip_fail(e, "H2D copy", AVIFGPU_readErr); }
+    }
+    p.dst = static_cast<uint8_t*>(sl.d_out); p.dst_row_bytes = (int64_t)out_pitch;
+    e = launch_read(p, d->colorspace, d->depth, g.alpha, g.xs, g.ys, st, j.label);
+    if (e != hipSuccess) { (void)hipStreamSynchronize(st); return hip_fail(e, "kernel launch", AVIFGPU_readErr); }
+
+    j.nbounce = 0;
+    const size_t dst_span = (size_t)j.rows_out_stride * (size_t)(j.nrows - 1) + row_bytes;
+    if (j.rows_out == sl.h_rows || is_pinned(j.rows_out, dst_span)) {
+        e = copy_rows(j.rows_out, (size_t)j.rows_out_stride, sl.d_out, out_pitch, row_bytes, (size_t)j.nrows, hipMemcpyDeviceToHost, st);
+    } else {
+        if ((err = grow_pinned(&sl.h_rows, &sl.h_rows_cap, out_pitch * (size_t)j.nrows))) { (void)hipStreamSynchronize(st); return err; }
+        e = hipMemcpyAsync(sl.h_rows, sl.d_out, out_pitch * (size_t)j.nrows, hipMemcpyDeviceToHost, st);
+        j.bounce[j.nbounce++] = { static_cast<uint8_t*>(j.rows_out), j.rows_out_stride, 0, out_pitch, row_bytes, j.nrows };
+    }
+    if (e != hipSuccess) { (void)hipStreamSynchronize(st); return hip_fail(e, "D2H copy", AVIFGPU_readErr); }
+    if ((e = hipEventRecord(sl.done, st)) != hipSuccess) { (void)hipStreamSynchronize(st); return hip_fail(e, "event record", AVIFGPU_readErr); }
+    return 0;
+}
+
+// Wait for a started tile and land what went through the bounce buffer.
+int finish(Ctx& c, Job& j)
+{
+    Slot& sl = c.slot[j.slot];
+    const hipError_t e = hipEventSynchronize(sl.done);
+    if (e != hipSuccess) return hip_fail(e, "event synchronize", j.is_write ? AVIFGPU_writErr : AVIFGPU_readErr);
+    const uint8_t* hb = static_cast<const uint8_t*>(j.is_write ? sl.h_planes : sl.h_rows);
+    for (int i = 0; i < j.nbounce; ++i) {
+        const Job::Bounce& b = j.bounce[i];
+        host_copy_rows(b.dst, (size_t)b.dst_stride, hb + b.off, b.pitch, b.bytes, (size_t)b.rows);
+    }
+    return 0;
+}
+
+void record_error(Ctx& c, int code)
+{
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (!c.err) { c.err = code; snprintf(c.err_msg, sizeof(c.err_msg), "%s", last_error()); }
+}
+
+void release_slot(Ctx& c, const Job& j)
+{
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        c.slot[j.slot].busy = false;
+        if (j.label[0]) snprintf(c.last_label, sizeof(c.last_label), "%s", j.label);
+    }
+    c.cv_done.notify_all();
+}
+
+void worker_main(Ctx* cp)
+{
+    Ctx& c = *cp;
+    hipError_t e = hipSetDevice(c.device);
+    for (int s = 0; e == hipSuccess && s < c.nslots; ++s) {
+        e = hipStreamCreateWithFlags(&c.slot[s].stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c.slot[s].done, hipEventDisableTiming);
+    }
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        if (e != hipSuccess) { c.init_err = AVIFGPU_memFullErr; snprintf(c.init_msg, sizeof(c.init_msg), "device %d: %s", c.device, hipGetErrorString(e)); }
+        c.started = true;
+    }
+    c.cv_done.notify_all();
+    if (e != hipSuccess) return;
+
+    // Issue every queued tile at once (copies and launches are asynchronous: ~10 us per tile) and land finished tiles in order.
+    // The worker never sleeps inside the runtime while tiles may arrive: it polls the oldest tile's event and naps on the
+    // work condition variable in between, so a newly queued tile is issued within microseconds and the copy queues stay fed
+    // (blocking in hipEventSynchronize here left the H2D queue dry for ~1 ms per tile: 38 -> 4x GB/s, profiles/r02/pcie_pipeline.md).
+    std::deque<Job> inflight;
+    for (;;) {
+        Job j;
+        bool have = false;
+        {
+            std::unique_lock<std::mutex> lk(c.mu);
+            if (inflight.empty()) c.cv_work.wait(lk, [&] { return c.stop || !c.queue.empty(); });
+            if (!c.queue.empty()) { j = c.queue.front(); c.queue.pop_front(); have = true; }
+            else if (c.stop && inflight.empty()) break;
+        }
+        if (have) {
+            // a slot never holds two tiles: the producer waited for it before queueing
+            if (g_trace) j.t_start = now_us();
+            const int rc = j.is_write ? start_write(c, j) : start_read(c, j);
+            if (g_trace) j.t_issued = now_us();
+            if (rc) { record_error(c, rc); release_slot(c, j); }
+            else inflight.push_back(j);
+            continue;
+        }
+        const hipError_t q = hipEventQuery(c.slot[inflight.front().slot].done);
+        if (q == hipErrorNotReady) {
+            (void)hipGetLastError();
+            std::unique_lock<std::mutex> lk(c.mu);
+            c.cv_work.wait_for(lk, std::chrono::microseconds(30), [&] { return c.stop || !c.queue.empty(); });
+            continue;
+        }
+        Job done = inflight.front();
+        inflight.pop_front();
+        const double t_wait = g_trace ? now_us() : 0;
+        const int rc = finish(c, done);                  // event already complete (or failed): returns at once, then the bounce copy
+        if (g_trace)
+            fprintf(stderr, "[avifgpu trace] dev %d ctx %p slot %d rows [%d,+%d) queued %.0f start %.0f issued %.0f ready %.0f done %.0f us\n",
+                    c.device, (void*)&c, done.slot, done.row0, done.nrows, done.t_queued, done.t_start, done.t_issued, t_wait, now_us());
+        if (rc) record_error(c, rc);
+        release_slot(c, done);
+    }
+    for (int s = 0; s < c.nslots; ++s) {
+        Slot& sl = c.slot[s];
+        if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+        if (sl.d_in) (void)hipFree(sl.d_in);
+        if (sl.d_out) (void)hipFree(sl.d_out);
+        if (sl.h_rows) (void)hipHostFree(sl.h_rows);
+        if (sl.h_planes) (void)hipHostFree(sl.h_planes);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.stream) (void)hipStreamDestroy(sl.stream);
+        sl = Slot();
+    }
+}
+
+Ctx* ctx_at(int i)
+{
+    if (!g_ctxs || i < 0 || i >= (int)g_ctxs->size()) return nullptr;
+    return (*g_ctxs)[i];
+}
+
+int enqueue(int ctx, Job& j)
+{
+    Ctx* c = ctx_at(ctx);
+    if (!c || j.slot < 0 || j.slot >= c->nslots) return fail(AVIFGPU_formatBadParameters, "bad context / slot (%d, %d)", ctx, j.slot);
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (c->slot[j.slot].busy) return fail(AVIFGPU_formatBadParameters, "staging slot (%d, %d) is still busy", ctx, j.slot);
+        c->slot[j.slot].busy = true;
+        if (g_trace) j.t_queued = now_us();
+        c->queue.push_back(j);
+    }
+    c->cv_work.notify_one();
+    return 0;
+}
+
+} // namespace
+
+// =========================================================================================================================
+int row_cut(int height, int world, int k, bool even)
+{
+    if (k >= world) return height;
+    int b = (int)(((long long)height * k) / world);
+    if (even) b -= b & 1;
+    return b;
+}
+
+int context_count() { return g_ctxs ? (int)g_ctxs->size() : 0; }
+int bound_device_count() { return g_ctxs ? (int)g_bound.size() : 0; }
+int context_device(int ctx) { Ctx* c = ctx_at(ctx); return c ? c->device : -1; }
+int slots_per_context() { Ctx* c = ctx_at(0); return c ? c->nslots : 0; }
+
+void contexts_shutdown()
+{
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    if (!g_ctxs) return;
+    for (Ctx* c : *g_ctxs) {
+        { std::lock_guard<std::mutex> l2(c->mu); c->stop = true; }
+        c->cv_work.notify_all();
+        if (c->worker.joinable()) c->worker.join();
+        delete c;
+    }
+    delete g_ctxs;
+    g_ctxs = nullptr;
+    g_bound.clear();
+}
+
+int contexts_init(const int32_t* devices, int count)
+{
+    if (!devices || count < 1 || count > 64) return fail(AVIFGPU_formatBadParameters, "avifgpu_init_devices: bad device list");
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(AVIFGPU_formatBadParameters, "no HIP device available (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    for (int i = 0; i < count; ++i)
+        if (devices[i] < 0 || devices[i] >= n) return fail(AVIFGPU_formatBadParameters, "device %d out of range [0,%d)", devices[i], n);
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        if (g_ctxs && g_bound == std::vector<int>(devices, devices + count)) return 0;     // same binding: nothing to do
+    }
+    contexts_shutdown();                                   // re-binding releases every stream, event and buffer of the old devices
+    release_device_caches();                               // ... and their table caches (never reused on another device)
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    auto* v = new std::vector<Ctx*>();
+    const int nslots = env_int("AVIFGPU_SLOTS", 4, 2, kMaxSlots);
+    // Lanes: contexts per bound device.  One worker keeps one copy queue per direction busy; a second lane on the same device
+    // overlaps its submissions with the first one's (measured: see profiles/r02/pcie_pipeline.jsonl).
+    const int lanes = env_int("AVIFGPU_LANES", kDefaultLanes, 1, 4);
+    g_trace = env_int("AVIFGPU_TRACE", 0, 0, 1) != 0;
+    int rc = 0;
+    for (int i = 0; i < count * lanes && !rc; ++i) {
+        Ctx* c = new Ctx();
+        c->device = devices[i / lanes];
+        c->nslots = nslots;
+        c->worker = std::thread(worker_main, c);
+        v->push_back(c);
+        std::unique_lock<std::mutex> l2(c->mu);
+        c->cv_done.wait(l2, [&] { return c->started; });
+        if (c->init_err) rc = fail(c->init_err, "%s", c->init_msg);
+    }
+    g_ctxs = v;
+    g_bound.assign(devices, devices + count);
+    if (rc) {
+        // unwind outside the lock-free helpers: same steps as contexts_shutdown
+        for (Ctx* c : *g_ctxs) {
+            { std::lock_guard<std::mutex> l2(c->mu); c->stop = true; }
+            c->cv_work.notify_all();
+            if (c->worker.joinable()) c->worker.join();
+            delete c;
+        }
+        delete g_ctxs; g_ctxs = nullptr; g_bound.clear();
+    }
+    return rc;
+}
+
+void* tile_buffer(int ctx, int slot, size_t bytes)
+{
+    Ctx* c = ctx_at(ctx);
+    if (!c || slot < 0 || slot >= c->nslots) return nullptr;
+    Slot& sl = c->slot[slot];                              // the slot is idle (the producer owns it between wait_slot and enqueue)
+    if (grow_pinned(&sl.h_rows, &sl.h_rows_cap, bytes ? bytes : 64)) return nullptr;
+    return sl.h_rows;
+}
+
+int write_tile_enqueue(int ctx, int slot, const avifgpu_write_desc* d, int row0, int nrows, const void* src, int64_t src_row_bytes,
+                       void* const dst[4], const int64_t dst_stride[4], const IccArgs& icc)
+{
+    WriteGeom g;
+    int err = check_write(d, row0, nrows, g);              // early, on the calling thread: parameter errors come back synchronously
+    if (err) return err;
+    if ((err = check_write_buffers(d, g, nrows, src, src_row_bytes, dst, dst_stride))) return err;
+    if (nrows == 0) return 0;
+    Job j;
+    j.is_write = true; j.slot = slot; j.wd = *d; j.row0 = row0; j.nrows = nrows;
+    j.rows_in = src; j.rows_in_stride = src_row_bytes;
+    for (int pl = 0; pl < 4; ++pl) { j.planes_out[pl] = dst[pl]; j.planes_out_stride[pl] = dst_stride[pl]; }
+    j.icc = icc;
+    return enqueue(ctx, j);
+}
+
+int read_tile_enqueue(int ctx, int slot, const avifgpu_read_desc* d, int row0, int nrows, const void* const src[4],
+                      const int64_t src_stride[4], void* dst, int64_t dst_row_bytes)
+{
+    ReadGeom g;
+    int err = check_read(d, row0, nrows, g);
+    if (err) return err;
+    if ((err = check_read_buffers(d, g, nrows, src, src_stride, dst, dst_row_bytes))) return err;
+    if (nrows == 0) return 0;
+    Job j;
+    j.is_write = false; j.slot = slot; j.rd = *d; j.row0 = row0; j.nrows = nrows;
+    for (int pl = 0; pl < 4; ++pl) { j.planes_in[pl] = src[pl]; j.planes_in_stride[pl] = src_stride[pl]; }
+    j.rows_out = dst; j.rows_out_stride = dst_row_bytes;
+    return enqueue(ctx, j);
+}
+
+int wait_slot(int ctx, int slot)
+{
+    Ctx* c = ctx_at(ctx);
+    if (!c || slot < 0 || slot >= c->nslots) return fail(AVIFGPU_formatBadParameters, "bad context / slot (%d, %d)", ctx, slot);
+    std::unique_lock<std::mutex> lk(c->mu);
+    c->cv_done.wait(lk, [&] { return !c->slot[slot].busy; });
+    if (c->last_label[0]) set_last_kernel(c->last_label);
+    if (c->err) { set_error(c->err_msg); return c->err; }  // sticky until wait_all: the caller stops queueing and drains
+    return 0;
+}
+
+int wait_all()
+{
+    int first = 0;
+    char msg[512] = "";
+    for (int i = 0; i < context_count(); ++i) {
+        Ctx* c = ctx_at(i);
+        std::unique_lock<std::mutex> lk(c->mu);
+        c->cv_done.wait(lk, [&] {
+            if (!c->queue.empty()) return false;
+            for (int s = 0; s < c->nslots; ++s) if (c->slot[s].busy) return false;
+            return true;
+        });
+        if (c->last_label[0]) set_last_kernel(c->last_label);
+        if (c->err && !first) { first = c->err; snprintf(msg, sizeof(msg), "%s", c->err_msg); }
+        c->err = 0; c->err_msg[0] = 0;
+    }
+    if (first) set_error(msg);
+    return first;
+}
+
+// ---- whole-range host conversions ---------------------------------------------------------------------------------------
+namespace {
+
+// rows per sub-tile: AVIFGPU_CHUNK_MB of the larger side (rows in / planes out), even, at least 2
+int chunk_rows_for(size_t bytes_per_row)
+{
+    const size_t budget = (size_t)env_int("AVIFGPU_CHUNK_MB", 32, 1, 4096) << 20;
+    size_t rows = budget / std::max<size_t>(bytes_per_row, 1);
+    rows = std::max<size_t>(rows & ~(size_t)1, 2);
+    return (int)std::min<size_t>(rows, 1u << 30);
+}
+
+} // namespace
+
+int write_rows_host(const avifgpu_write_desc* d, int row0, int nrows, const void* src, int64_t src_row_bytes,
+                    void* const dst[4], const int64_t dst_stride[4], const IccArgs& icc)
+{
+    const int n = context_count();
+    if (n == 0) return fail(AVIFGPU_formatBadParameters, "avifgpu_init has not succeeded: no HIP device bound (no CPU fallback)");
+    WriteGeom g;
+    int err = check_write(d, row0, nrows, g);
+    if (err) return err;
+    const int nslots = slots_per_context();
+    const size_t row_bytes = (size_t)d->width * d->planes * (d->depth / 8);
+    const int chunk = chunk_rows_for(row_bytes);
+    const bool ycc = d->output == AVIFGPU_OUT_YCBCR;
+    std::vector<int> next(n), end(n);
+    for (int c = 0; c < n; ++c) { next[c] = row0 + row_cut(nrows, n, c, true); end[c] = row0 + row_cut(nrows, n, c + 1, true); }
+    bool failed = false;
+    for (int step = 0; !failed; ++step) {
+        bool any = false;
+        for (int c = 0; c < n && !failed; ++c) {
+            if (next[c] >= end[c]) continue;
+            any = true;
+            const int r0 = next[c], nr = std::min(chunk, end[c] - r0);
+            next[c] = r0 + nr;
+            const int slot = step % nslots;
+            if ((err = wait_slot(c, slot))) { failed = true; break; }
+            void* tdst[4];
+            for (int pl = 0; pl < 4; ++pl) {
+                const bool chroma = ycc && (pl == 1 || pl == 2);
+                const int64_t r = chroma ? ((r0 - row0) >> g.ys) : (r0 - row0);
+                tdst[pl] = dst[pl] ? static_cast<uint8_t*>(dst[pl]) + r * dst_stride[pl] : nullptr;
+            }
+            const uint8_t* tsrc = static_cast<const uint8_t*>(src) + (int64_t)(r0 - row0) * src_row_bytes;
+            if ((err = write_tile_enqueue(c, slot, d, r0, nr, tsrc, src_row_bytes, tdst, dst_stride, icc))) failed = true;
+        }
+        if (!any) break;
+    }
+    const int werr = wait_all();                          // drains everything, also after a failure
+    return err ? err : werr;
+}
+
+int read_rows_host(const avifgpu_read_desc* d, int row0, int nrows, const void* const src[4], const int64_t src_stride[4],
+                   void* dst, int64_t dst_row_bytes)
+{
+    const int n = context_count();
+    if (n == 0) return fail(AVIFGPU_formatBadParameters, "avifgpu_init has not succeeded: no HIP device bound (no CPU fallback)");
+    ReadGeom g;
+    int err = check_read(d, row0, nrows, g);
+    if (err) return err;
+    const int nslots = slots_per_context();
+    const size_t row_bytes = (size_t)d->width * g.nch * (d->depth / 8);
+    const int chunk = chunk_rows_for(row_bytes);
+    const bool ycc = d->colorspace == AVIFGPU_COLORSPACE_YCBCR;
+    std::vector<int> next(n), end(n);
+    for (int c = 0; c < n; ++c) { next[c] = row0 + row_cut(nrows, n, c, true); end[c] = row0 + row_cut(nrows, n, c + 1, true); }
+    bool failed = false;
+    for (int step = 0; !failed; ++step) {
+        bool any = false;
+        for (int c = 0; c < n && !failed; ++c) {
+            if (next[c] >= end[c]) continue;
+            any = true;
+            const int r0 = next[c], nr = std::min(chunk, end[c] - r0);
+            next[c] = r0 + nr;
+            const int slot = step % nslots;
+            if ((err = wait_slot(c, slot))) { failed = true; break; }
+            const void* tsrc[4];
+            for (int pl = 0; pl < 4; ++pl) {
+                const bool chroma = ycc && (pl == 1 || pl == 2);
+                const int64_t r = chroma ? ((r0 - row0) >> g.ys) : (r0 - row0);
+                tsrc[pl] = src[pl] ? static_cast<const uint8_t*>(src[pl]) + r * src_stride[pl] : nullptr;
+            }
+            uint8_t* tdst = static_cast<uint8_t*>(dst) + (int64_t)(r0 - row0) * dst_row_bytes;
+            if ((err = read_tile_enqueue(c, slot, d, r0, nr, tsrc, src_stride, tdst, dst_row_bytes))) failed = true;
+        }
+        if (!any) break;
+    }
+    const int werr = wait_all();
+    return err ? err : werr;
+}
+
+} // namespace avifgpu

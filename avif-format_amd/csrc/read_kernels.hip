@@ -13,8 +13,10 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include "kernel_params.h"
+#include "staging.h"
 #include "device_math.h"
 #include "../../include/avifgpu.h"
 
@@ -88,7 +90,10 @@ AG_DEV void hlg_ootf(const ReadParams& p, float (&c)[3])
 {
     if (p.hlg_ootf) {
         const float luma = (c[0] * p.hlg_luma[0]) + (c[1] * p.hlg_luma[1]) + (c[2] * p.hlg_luma[2]);
-        const float factor = p.hlg_peak * fast_pow(luma, p.hlg_gamma_m1);
+        // powf(luma, gamma - 1): luma >= 0 here (clamped colours, positive weights).  exp2(e * log2(0)) is 0 for e > 0 like
+        // powf, but 0 * -inf = NaN for e == 0 (displayGamma 1.0, the reference's minimum, AvifFormat.h:49) where powf(x, 0) = 1
+        const float pw = fast_pow(luma, p.hlg_gamma_m1);
+        const float factor = p.hlg_peak * (p.hlg_gamma_m1 == 0.0f ? 1.0f : pw);
         c[0] *= factor; c[1] *= factor; c[2] *= factor;
     }
 }
@@ -544,26 +549,34 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
 }
 
 // ---- device-side cache of table sets ------------------------------------------------------------------------------------
-// Keyed by everything read_tables depends on.  A miss launches build_read_tables on the caller's stream and waits for it once
-// (~20 us per NEW parameter set: a decode session has one); hits cost a mutex and a 40-byte compare.
+// One 16-slot cache PER HIP DEVICE (the row-tile scheduler runs one image on several GPUs, and a process may re-bind), keyed by
+// everything read_tables depends on.  A miss launches build_read_tables on the caller's stream and waits for it once (~20 us per
+// NEW parameter set: a decode session has one); hits cost a mutex and a 40-byte compare.
 struct TableKey {
-    int device, cs, depth, alpha, transfer, bits, maxc, full_range, identity_lut;
+    int cs, depth, alpha, transfer, bits, maxc, full_range, identity_lut;
     float pq_log2_mult;
 };
 struct TableSlot { TableKey key; float* dev = nullptr; bool valid = false; };
+struct DeviceTables { TableSlot slots[16]; int next = 0; };
 static std::mutex g_table_mu;
-static TableSlot g_table_slots[16];
-static int g_table_next = 0;
+static std::map<int, DeviceTables> g_tables;        // HIP device ordinal -> its cache
 constexpr size_t kTableSlotFloats = 3 * 4096;
 
 // avifgpu_shutdown: nothing may be in flight any more.
 void release_read_tables()
 {
     std::lock_guard<std::mutex> lk(g_table_mu);
-    for (TableSlot& sl : g_table_slots) {
-        if (sl.dev) (void)hipFree(sl.dev);
-        sl.dev = nullptr; sl.valid = false;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    for (auto& kv : g_tables) {
+        (void)hipSetDevice(kv.first);
+        for (TableSlot& sl : kv.second.slots) {
+            if (sl.dev) (void)hipFree(sl.dev);
+            sl.dev = nullptr; sl.valid = false;
+        }
     }
+    g_tables.clear();
+    if (cur >= 0) (void)hipSetDevice(cur);
 }
 
 template <int CS, int DEPTH, bool ALPHA, int TRANSFER>
@@ -571,16 +584,18 @@ static hipError_t cached_tables(const ReadParams& p, hipStream_t st, const float
 {
     TableKey key;
     std::memset(&key, 0, sizeof(key));
-    hipError_t e = hipGetDevice(&key.device);
+    int device = -1;
+    hipError_t e = hipGetDevice(&device);            // the launch goes to the calling thread's current device
     if (e != hipSuccess) return e;
     key.cs = CS; key.depth = DEPTH; key.alpha = ALPHA; key.transfer = (CS == kCsRgb && DEPTH == 32) ? TRANSFER : 0;
     key.bits = p.bits; key.maxc = p.maxc; key.full_range = p.full_range; key.identity_lut = p.identity_lut;
     key.pq_log2_mult = (CS == kCsRgb && DEPTH == 32 && TRANSFER == AVIFGPU_TRANSFER_PQ) ? p.pq_log2_mult : 0.0f;
     std::lock_guard<std::mutex> lk(g_table_mu);
-    for (TableSlot& sl : g_table_slots)
+    DeviceTables& dt = g_tables[device];
+    for (TableSlot& sl : dt.slots)
         if (sl.valid && std::memcmp(&sl.key, &key, sizeof(key)) == 0) { *out = sl.dev; return hipSuccess; }
-    TableSlot& sl = g_table_slots[g_table_next];
-    g_table_next = (g_table_next + 1) % 16;
+    TableSlot& sl = dt.slots[dt.next];
+    dt.next = (dt.next + 1) % 16;
     if (sl.valid) {                                 // recycling a set some in-flight launch may still be copying from
         sl.valid = false;
         if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
@@ -596,7 +611,7 @@ static hipError_t cached_tables(const ReadParams& p, hipStream_t st, const float
 
 // ---- dispatch --------------------------------------------------------------------------------------
 template <int CS, int DEPTH, bool ALPHA, int XS, int YS, int TRANSFER>
-static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, const char** name)
+static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, char* label)
 {
     constexpr int PXT = ReadShape<CS, DEPTH, ALPHA, XS>::PXT;
     const long long groups = (long long)((p.width + PXT - 1) / PXT) * ((p.nrows + (1 << YS) - 1) >> YS);
@@ -614,14 +629,12 @@ static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, const cha
     if (blocks > AG_READ_BLOCK_CAP) blocks = AG_READ_BLOCK_CAP;
     const size_t lut_bytes = p.bits <= 12 ? (size_t)read_table_count(CS == kCsYcc, CS == kCsMono, ALPHA, DEPTH, p.full_range != 0, p.identity_lut != 0, p.premultiplied != 0) *
                                                 (1u << p.bits) * sizeof(float) : 0;
-    static thread_local char label[160];
     uintptr_t bits = reinterpret_cast<uintptr_t>(p.dst) | (uintptr_t)p.dst_row_bytes;
     for (int pl = 0; pl < 4; ++pl) if (p.src[pl]) bits |= reinterpret_cast<uintptr_t>(p.src[pl]) | (uintptr_t)p.src_stride[pl];
     const bool aligned = (bits & 15) == 0;      // => branch-free vector loads + LDS-transposed coalesced stores
     const size_t lds = lut_bytes + ((aligned && ND_OUT > 4) ? (size_t)4 * 64 * ND_OUT * sizeof(uint32_t) : 0);
-    snprintf(label, sizeof(label), "read_px<cs=%d,depth=%d,alpha=%d,xs=%d,ys=%d,transfer=%d,aligned=%d>", CS, DEPTH, (int)ALPHA, XS, YS,
+    snprintf(label, kLabelBytes, "read_px<cs=%d,depth=%d,alpha=%d,xs=%d,ys=%d,transfer=%d,aligned=%d>", CS, DEPTH, (int)ALPHA, XS, YS,
              TRANSFER, (int)aligned);
-    *name = label;
     ReadParams q = p;
     if (lut_bytes) {
         const hipError_t e = cached_tables<CS, DEPTH, ALPHA, TRANSFER>(p, st, &q.tables);
@@ -639,48 +652,48 @@ static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, const cha
 }
 
 template <int CS, int DEPTH, bool ALPHA, int XS, int YS>
-static hipError_t launch_read_tr(const ReadParams& p, hipStream_t st, const char** name)
+static hipError_t launch_read_tr(const ReadParams& p, hipStream_t st, char* label)
 {
     if constexpr (DEPTH == 32 && CS != kCsMono) {
         switch (p.transfer) {
-        case AVIFGPU_TRANSFER_PQ:  return launch_read_one<CS, DEPTH, ALPHA, XS, YS, AVIFGPU_TRANSFER_PQ>(p, st, name);
-        case AVIFGPU_TRANSFER_HLG: return launch_read_one<CS, DEPTH, ALPHA, XS, YS, AVIFGPU_TRANSFER_HLG>(p, st, name);
-        default:                   return launch_read_one<CS, DEPTH, ALPHA, XS, YS, AVIFGPU_TRANSFER_SMPTE428>(p, st, name);
+        case AVIFGPU_TRANSFER_PQ:  return launch_read_one<CS, DEPTH, ALPHA, XS, YS, AVIFGPU_TRANSFER_PQ>(p, st, label);
+        case AVIFGPU_TRANSFER_HLG: return launch_read_one<CS, DEPTH, ALPHA, XS, YS, AVIFGPU_TRANSFER_HLG>(p, st, label);
+        default:                   return launch_read_one<CS, DEPTH, ALPHA, XS, YS, AVIFGPU_TRANSFER_SMPTE428>(p, st, label);
         }
     } else {
-        return launch_read_one<CS, DEPTH, ALPHA, XS, YS, AVIFGPU_TRANSFER_PQ>(p, st, name);
+        return launch_read_one<CS, DEPTH, ALPHA, XS, YS, AVIFGPU_TRANSFER_PQ>(p, st, label);
     }
 }
 
 template <int CS, int DEPTH, bool ALPHA>
-static hipError_t launch_read_chroma(const ReadParams& p, int xs, int ys, hipStream_t st, const char** name)
+static hipError_t launch_read_chroma(const ReadParams& p, int xs, int ys, hipStream_t st, char* label)
 {
     if constexpr (CS == kCsYcc) {
-        if (xs == 0) return launch_read_tr<CS, DEPTH, ALPHA, 0, 0>(p, st, name);
-        if (ys == 0) return launch_read_tr<CS, DEPTH, ALPHA, 1, 0>(p, st, name);
-        return launch_read_tr<CS, DEPTH, ALPHA, 1, 1>(p, st, name);
+        if (xs == 0) return launch_read_tr<CS, DEPTH, ALPHA, 0, 0>(p, st, label);
+        if (ys == 0) return launch_read_tr<CS, DEPTH, ALPHA, 1, 0>(p, st, label);
+        return launch_read_tr<CS, DEPTH, ALPHA, 1, 1>(p, st, label);
     } else {
-        return launch_read_tr<CS, DEPTH, ALPHA, 0, 0>(p, st, name);
+        return launch_read_tr<CS, DEPTH, ALPHA, 0, 0>(p, st, label);
     }
 }
 
 template <int CS>
-static hipError_t launch_read_cs(const ReadParams& p, int depth, bool alpha, int xs, int ys, hipStream_t st, const char** name)
+static hipError_t launch_read_cs(const ReadParams& p, int depth, bool alpha, int xs, int ys, hipStream_t st, char* label)
 {
     switch (depth) {
-    case 8:  return alpha ? launch_read_chroma<CS, 8, true>(p, xs, ys, st, name)  : launch_read_chroma<CS, 8, false>(p, xs, ys, st, name);
-    case 16: return alpha ? launch_read_chroma<CS, 16, true>(p, xs, ys, st, name) : launch_read_chroma<CS, 16, false>(p, xs, ys, st, name);
-    default: return alpha ? launch_read_chroma<CS, 32, true>(p, xs, ys, st, name) : launch_read_chroma<CS, 32, false>(p, xs, ys, st, name);
+    case 8:  return alpha ? launch_read_chroma<CS, 8, true>(p, xs, ys, st, label)  : launch_read_chroma<CS, 8, false>(p, xs, ys, st, label);
+    case 16: return alpha ? launch_read_chroma<CS, 16, true>(p, xs, ys, st, label) : launch_read_chroma<CS, 16, false>(p, xs, ys, st, label);
+    default: return alpha ? launch_read_chroma<CS, 32, true>(p, xs, ys, st, label) : launch_read_chroma<CS, 32, false>(p, xs, ys, st, label);
     }
 }
 
 hipError_t launch_read(const ReadParams& p, int colorspace, int depth, bool alpha, int xs, int ys,
-                       hipStream_t st, const char** name)
+                       hipStream_t st, char* label)
 {
     switch (colorspace) {
-    case AVIFGPU_COLORSPACE_YCBCR: return launch_read_cs<kCsYcc>(p, depth, alpha, xs, ys, st, name);
-    case AVIFGPU_COLORSPACE_RGB:   return launch_read_cs<kCsRgb>(p, depth, alpha, xs, ys, st, name);
-    default:                       return launch_read_cs<kCsMono>(p, depth, alpha, xs, ys, st, name);
+    case AVIFGPU_COLORSPACE_YCBCR: return launch_read_cs<kCsYcc>(p, depth, alpha, xs, ys, st, label);
+    case AVIFGPU_COLORSPACE_RGB:   return launch_read_cs<kCsRgb>(p, depth, alpha, xs, ys, st, label);
+    default:                       return launch_read_cs<kCsMono>(p, depth, alpha, xs, ys, st, label);
     }
 }
 

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <type_traits>
 #include "kernel_params.h"
+#include "staging.h"
 #include "device_math.h"
 #include "../../include/avifgpu.h"
 
@@ -963,23 +964,21 @@ static inline int grid_for(long long threads_needed)
 }
 
 template <int DEPTH, int PLANES, int OUT, bool DST16, int XS, int YS, int TRANSFER>
-static hipError_t launch_one(const WriteParams& p, hipStream_t st, const char** name)
+static hipError_t launch_one(const WriteParams& p, hipStream_t st, char* label)
 {
     constexpr int PXT = WriteShape<DST16, PLANES, XS>::PXT;
     const long long groups = (long long)((p.width + PXT - 1) / PXT) * ((p.nrows + (1 << YS) - 1) >> YS);
     if (groups == 0) return hipSuccess;
     if (groups >= 0x7fffffffLL - 256LL * 65536) return hipErrorInvalidValue;   // 32-bit group index in the kernel
-    static thread_local char label[160];
     // every pointer and stride a multiple of 16 => the branch-free vector path
     uintptr_t bits = reinterpret_cast<uintptr_t>(p.src) | (uintptr_t)p.src_row_bytes;
     for (int pl = 0; pl < 4; ++pl) if (p.dst[pl]) bits |= reinterpret_cast<uintptr_t>(p.dst[pl]) | (uintptr_t)p.dst_stride[pl];
     const bool aligned = (bits & 15) == 0;
-    snprintf(label, sizeof(label), "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d>",
+    snprintf(label, kLabelBytes, "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d>",
              DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned);
-    *name = label;
     if constexpr (DEPTH == 8 && PLANES >= 3) {
         if (p.icc8_s1 != nullptr) {                 // 8-bit matrix-shaper ICC transform requested
-            snprintf(label, sizeof(label), "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=3>",
+            snprintf(label, kLabelBytes, "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=3>",
                      DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned);
             const int blocks = grid_for(groups) > 2048 ? 2048 : grid_for(groups);     // tables are copied per block
             if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 3>), dim3(blocks), dim3(256), 0, st, p);
@@ -989,7 +988,7 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, const char** 
     }
     if constexpr (DEPTH == 16 && PLANES >= 3) {
         if (p.icc16_clut != nullptr) {              // 16-bit CLUT ICC transform requested
-            snprintf(label, sizeof(label), "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=5>",
+            snprintf(label, kLabelBytes, "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=5>",
                      DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned);
             if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 5>), dim3(grid_for(groups)), dim3(256), 0, st, p);
             else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 5>), dim3(grid_for(groups)), dim3(256), 0, st, p);
@@ -1002,7 +1001,7 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, const char** 
             for (int c = 0; c < 3; ++c) linear = linear && p.icc_trc_type[c] == 1 && p.icc_trc[c][0] == 1.0;
             if (p.icc_out == 4) {                   // -> sRGB: the SDR (Clip) save of a 32-bit document
                 if constexpr (TRANSFER == 3) {
-                    snprintf(label, sizeof(label), "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=4>",
+                    snprintf(label, kLabelBytes, "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=4>",
                              DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned);
                     if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 4>), dim3(grid_for(groups)), dim3(256), 0, st, p);
                     else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 4>), dim3(grid_for(groups)), dim3(256), 0, st, p);
@@ -1011,7 +1010,7 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, const char** 
                     return hipErrorInvalidValue;    // rejected earlier by fill_write_params
                 }
             }
-            snprintf(label, sizeof(label), "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=%d>",
+            snprintf(label, kLabelBytes, "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=%d>",
                      DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned, linear ? 1 : 2);
             if (linear) {
                 if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 1>), dim3(grid_for(groups)), dim3(256), 0, st, p);
@@ -1029,10 +1028,10 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, const char** 
 }
 
 #define AG_LAUNCH(DEPTH, PLANES, OUT, DST16, XS, YS, TR) \
-    return launch_one<DEPTH, PLANES, OUT, DST16, XS, YS, TR>(p, st, name)
+    return launch_one<DEPTH, PLANES, OUT, DST16, XS, YS, TR>(p, st, label)
 
 template <int DEPTH, int PLANES, int OUT, bool DST16, int XS, int YS>
-static hipError_t launch_tr(const WriteParams& p, hipStream_t st, const char** name)
+static hipError_t launch_tr(const WriteParams& p, hipStream_t st, char* label)
 {
     if constexpr (DEPTH == 32) {
         switch (p.transfer) {
@@ -1047,37 +1046,37 @@ static hipError_t launch_tr(const WriteParams& p, hipStream_t st, const char** n
 }
 
 template <int DEPTH, int PLANES, bool DST16>
-static hipError_t launch_out(const WriteParams& p, int output, int xs, int ys, hipStream_t st, const char** name)
+static hipError_t launch_out(const WriteParams& p, int output, int xs, int ys, hipStream_t st, char* label)
 {
     if constexpr (PLANES <= 2) {
-        return launch_tr<DEPTH, PLANES, kOutRefGray, DST16, 0, 0>(p, st, name);
+        return launch_tr<DEPTH, PLANES, kOutRefGray, DST16, 0, 0>(p, st, label);
     } else {
-        if (output == AVIFGPU_OUT_REFERENCE) return launch_tr<DEPTH, PLANES, kOutRefColor, DST16, 0, 0>(p, st, name);
-        if (xs == 0) return launch_tr<DEPTH, PLANES, kOutYcbcr, DST16, 0, 0>(p, st, name);
-        if (ys == 0) return launch_tr<DEPTH, PLANES, kOutYcbcr, DST16, 1, 0>(p, st, name);
-        return launch_tr<DEPTH, PLANES, kOutYcbcr, DST16, 1, 1>(p, st, name);
+        if (output == AVIFGPU_OUT_REFERENCE) return launch_tr<DEPTH, PLANES, kOutRefColor, DST16, 0, 0>(p, st, label);
+        if (xs == 0) return launch_tr<DEPTH, PLANES, kOutYcbcr, DST16, 0, 0>(p, st, label);
+        if (ys == 0) return launch_tr<DEPTH, PLANES, kOutYcbcr, DST16, 1, 0>(p, st, label);
+        return launch_tr<DEPTH, PLANES, kOutYcbcr, DST16, 1, 1>(p, st, label);
     }
 }
 
 template <int DEPTH>
 static hipError_t launch_planes(const WriteParams& p, int planes, bool dst16, int output, int xs, int ys,
-                                hipStream_t st, const char** name)
+                                hipStream_t st, char* label)
 {
     switch (planes) {
-    case 1: return dst16 ? launch_out<DEPTH, 1, true>(p, output, xs, ys, st, name)
-                         : (DEPTH == 32 ? hipErrorInvalidValue : launch_out<DEPTH == 32 ? 16 : DEPTH, 1, false>(p, output, xs, ys, st, name));
-    case 2: return dst16 ? launch_out<DEPTH, 2, true>(p, output, xs, ys, st, name)
-                         : (DEPTH == 32 ? hipErrorInvalidValue : launch_out<DEPTH == 32 ? 16 : DEPTH, 2, false>(p, output, xs, ys, st, name));
-    case 3: return dst16 ? launch_out<DEPTH, 3, true>(p, output, xs, ys, st, name)
-                         : (DEPTH == 32 ? hipErrorInvalidValue : launch_out<DEPTH == 32 ? 16 : DEPTH, 3, false>(p, output, xs, ys, st, name));
-    default: return dst16 ? launch_out<DEPTH, 4, true>(p, output, xs, ys, st, name)
-                          : (DEPTH == 32 ? hipErrorInvalidValue : launch_out<DEPTH == 32 ? 16 : DEPTH, 4, false>(p, output, xs, ys, st, name));
+    case 1: return dst16 ? launch_out<DEPTH, 1, true>(p, output, xs, ys, st, label)
+                         : (DEPTH == 32 ? hipErrorInvalidValue : launch_out<DEPTH == 32 ? 16 : DEPTH, 1, false>(p, output, xs, ys, st, label));
+    case 2: return dst16 ? launch_out<DEPTH, 2, true>(p, output, xs, ys, st, label)
+                         : (DEPTH == 32 ? hipErrorInvalidValue : launch_out<DEPTH == 32 ? 16 : DEPTH, 2, false>(p, output, xs, ys, st, label));
+    case 3: return dst16 ? launch_out<DEPTH, 3, true>(p, output, xs, ys, st, label)
+                         : (DEPTH == 32 ? hipErrorInvalidValue : launch_out<DEPTH == 32 ? 16 : DEPTH, 3, false>(p, output, xs, ys, st, label));
+    default: return dst16 ? launch_out<DEPTH, 4, true>(p, output, xs, ys, st, label)
+                          : (DEPTH == 32 ? hipErrorInvalidValue : launch_out<DEPTH == 32 ? 16 : DEPTH, 4, false>(p, output, xs, ys, st, label));
     }
 }
 
 // Entry used by avifgpu_api.hip.  `variant` selects the hot-path implementation when it applies.
 hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16, int output, int xs, int ys,
-                        int variant, hipStream_t st, const char** name)
+                        int variant, hipStream_t st, char* label)
 {
     // hot path: RGB f32 (no alpha) -> YCbCr 4:4:4 u16 with aligned rows; `variant` is a tuning word:
     //   bit0 enable, bit1 PXL=8 (else 4), bit2 non-temporal, bit3 prefetch, bit4 XCD-contiguous mapping;
@@ -1092,9 +1091,7 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
         if (waves + 8LL * 65536 * 4 < 0x7fffffffLL) {
             long long blocks = (waves + 3) / 4;
             if (blocks > AG_STREAM_BLOCK_CAP) blocks = AG_STREAM_BLOCK_CAP;
-            static thread_local char label[96];
-            snprintf(label, sizeof(label), "write_int_ref_stream<depth=%d,planes=%d,dst16=%d>", depth, planes, (int)dst16);
-            *name = label;
+            snprintf(label, kLabelBytes, "write_int_ref_stream<depth=%d,planes=%d,dst16=%d>", depth, planes, (int)dst16);
 #define AG_IREF(D, P) do { if (dst16) hipLaunchKernelGGL((write_int_ref_stream<D, P, true>), dim3((int)blocks), dim3(256), 0, st, p); \
                            else hipLaunchKernelGGL((write_int_ref_stream<D, P, false>), dim3((int)blocks), dim3(256), 0, st, p); } while (0)
             if (planes == 4) AG_IREF(16, 4); else AG_IREF(16, 3);
@@ -1111,9 +1108,7 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
         if (waves + 8LL * 65536 * 4 < 0x7fffffffLL) {
             long long blocks = (waves + 3) / 4;
             if (blocks > AG_STREAM_BLOCK_CAP) blocks = AG_STREAM_BLOCK_CAP;
-            static thread_local char label[96];
-            snprintf(label, sizeof(label), "write_f32_ref_stream<transfer=%d,planes=%d>", p.transfer, planes);
-            *name = label;
+            snprintf(label, kLabelBytes, "write_f32_ref_stream<transfer=%d,planes=%d>", p.transfer, planes);
 #define AG_REF(TR) do { if (planes == 4) hipLaunchKernelGGL((write_f32_ref_stream<TR, 4>), dim3((int)blocks), dim3(256), 0, st, p); \
                         else hipLaunchKernelGGL((write_f32_ref_stream<TR, 3>), dim3((int)blocks), dim3(256), 0, st, p); } while (0)
             switch (p.transfer) {
@@ -1139,9 +1134,7 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
         if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
             long long blocks = (spans + 3) / 4;
             if (blocks > AG_RGBA_BLOCK_CAP) blocks = AG_RGBA_BLOCK_CAP;
-            static thread_local char label[96];
-            snprintf(label, sizeof(label), "write_rgba32_ycbcra444_hot<transfer=%d>", p.transfer);
-            *name = label;
+            snprintf(label, kLabelBytes, "write_rgba32_ycbcra444_hot<transfer=%d>", p.transfer);
             switch (p.transfer) {
             case AVIFGPU_TRANSFER_PQ:       hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<AVIFGPU_TRANSFER_PQ>), dim3((int)blocks), dim3(256), 0, st, p); break;
             case AVIFGPU_TRANSFER_HLG:      hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<AVIFGPU_TRANSFER_HLG>), dim3((int)blocks), dim3(256), 0, st, p); break;
@@ -1160,9 +1153,7 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
         if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
             long long blocks = (spans + 3) / 4;
             if (blocks > AG_STREAM_BLOCK_CAP) blocks = AG_STREAM_BLOCK_CAP;
-            static thread_local char label[96];
-            snprintf(label, sizeof(label), "write_rgb32_ycbcr_sub_hot<transfer=%d,xs=1,ys=%d>", p.transfer, ys);
-            *name = label;
+            snprintf(label, kLabelBytes, "write_rgb32_ycbcr_sub_hot<transfer=%d,xs=1,ys=%d>", p.transfer, ys);
 #define AG_SUB(TR) do { if (ys) hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<TR, 1, 1>), dim3((int)blocks), dim3(256), 0, st, p); \
                         else hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<TR, 1, 0>), dim3((int)blocks), dim3(256), 0, st, p); } while (0)
             switch (p.transfer) {
@@ -1189,10 +1180,8 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
             const long long cap = (variant >> 8) ? (variant >> 8) : 256LL * 512;   // 8192^2: one span per wave (32k blocks) measured 5-6 % faster than two (16k)
             if (blocks > cap) blocks = cap;
             if (xm) blocks = (blocks + 7) & ~7LL;
-            static thread_local char label[96];
-            snprintf(label, sizeof(label), "write_rgb32_ycbcr444_hot<transfer=%d,pxl=%d,nt=%d,prefetch=%d,xcdmap=%d>",
+            snprintf(label, kLabelBytes, "write_rgb32_ycbcr444_hot<transfer=%d,pxl=%d,nt=%d,prefetch=%d,xcdmap=%d>",
                      p.transfer, px8 ? 8 : 4, (int)nt, (int)pf, (int)xm);
-            *name = label;
 #define AG_HOT5(TR, PX, NT_, PF_, XM_) hipLaunchKernelGGL((write_rgb32_ycbcr444_hot<TR, PX, NT_, PF_, XM_>), dim3((int)blocks), dim3(256), 0, st, p)
 #define AG_HOT4(TR, PX, NT_, PF_) do { if (xm) AG_HOT5(TR, PX, NT_, PF_, true); else AG_HOT5(TR, PX, NT_, PF_, false); } while (0)
 #define AG_HOT3(TR, PX, NT_) do { if (pf) AG_HOT4(TR, PX, NT_, true); else AG_HOT4(TR, PX, NT_, false); } while (0)
@@ -1209,9 +1198,9 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
         }
     }
     switch (depth) {
-    case 8:  return launch_planes<8>(p, planes, dst16, output, xs, ys, st, name);
-    case 16: return launch_planes<16>(p, planes, dst16, output, xs, ys, st, name);
-    default: return launch_planes<32>(p, planes, dst16, output, xs, ys, st, name);
+    case 8:  return launch_planes<8>(p, planes, dst16, output, xs, ys, st, label);
+    case 16: return launch_planes<16>(p, planes, dst16, output, xs, ys, st, label);
+    default: return launch_planes<32>(p, planes, dst16, output, xs, ys, st, label);
     }
 }
 

@@ -47,7 +47,7 @@ class HLGOptions(ctypes.Structure):
 class SaveUIOptions(ctypes.Structure):
     _fields_ = [("imageBitDepth", c_int32), ("hdrTransferFunction", c_int32), ("pq", PQOptions),
                 ("chromaSubsampling", c_int32), ("lossless", c_uint8), ("convertToRec2020", c_uint8),
-                ("convertToSRGB", c_uint8)]
+                ("convertToSRGB", c_uint8), ("chromaDownsampling", c_uint8)]
 
 
 class LoadUIOptions(ctypes.Structure):

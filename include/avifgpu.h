@@ -13,11 +13,12 @@
  *     (reference src/common/YUVDecode.h:29-145, bodies YuvDecode.cpp:55-696).
  *
  * Everything crossing this boundary is plain C: PODs, raw pointers, sizes.  No C++ types, no
- * torch types.  Pointers are either all host pointers (AVIFGPU_MEM_HOST: the library stages the tile
- * through its own device buffers on its own stream and returns when the planes are back in host
- * memory; `stream` is ignored) or all device pointers (AVIFGPU_MEM_DEVICE: zero-copy, the kernel is
- * enqueued on `stream` -- a hipStream_t, NULL = HIP's default stream -- and the call returns without
- * synchronising).
+ * torch types.  Pointers are either all host pointers (AVIFGPU_MEM_HOST: the library cuts the rows into
+ * one tile per bound device, streams each through its own device buffers and returns when the planes
+ * are back in host memory; page-locked buffers are used for DMA directly, pageable ones are bounced
+ * through pinned staging by the library's worker threads; `stream` is ignored) or all device pointers
+ * (AVIFGPU_MEM_DEVICE: zero-copy, the kernel is enqueued on `stream` -- a hipStream_t, NULL = HIP's
+ * default stream -- on the caller's current device and the call returns without synchronising).
  *
  * Return values are Photoshop OSErr codes (reference error convention: src/common/Write.cpp:345-364,
  * src/common/Read.cpp:531-550): 0 = noErr.
@@ -31,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AVIFGPU_ABI_VERSION 1
+#define AVIFGPU_ABI_VERSION 2
 
 /* ---- OSErr codes used by the hot path (Photoshop SDK values) ------------------------------- */
 #define AVIFGPU_noErr                0
@@ -128,10 +129,15 @@ enum {
     AVIFGPU_OUT_YCBCR = 1
 };
 
-/* Chroma down-sampling filter of the fused path (libheif stage, un-vendored => spec'd here). */
+/* Chroma down-sampling filter of the fused path (libheif's stage; libheif is not vendored by the reference).
+ * NEAREST is what libheif 1.14.0 -- the version the reference pins (3rd-party/README.md:44) -- does when it converts the plug-in's
+ * interleaved RGB(A) / RRGGBB(AA)_LE hand-off itself (heif_colorconversion.cc: Op_RGB24_32_to_YCbCr, Op_RRGGBBxx_HDR_to_YCbCr420,
+ * Op_RGB_to_YCbCr<>: the chroma loops step by the sub-sampling factors and read the block's top-left pixel); the FormatRecord shim
+ * (avifgpu_host.h) uses it by default.  AVERAGE is the box filter later libheif versions (>= 1.16, heif_chroma_downsampling_average)
+ * default to; it is kept as an option and for comparison. */
 enum {
     AVIFGPU_DOWNSAMPLE_AVERAGE = 0,  /* box average of the 2x1 / 2x2 footprint, edge-replicated */
-    AVIFGPU_DOWNSAMPLE_NEAREST = 1   /* top-left (co-sited) sample */
+    AVIFGPU_DOWNSAMPLE_NEAREST = 1   /* top-left (co-sited) sample: libheif 1.14.0's own behaviour */
 };
 
 /* Zero point of the full-range chroma codes written by the fused path.
@@ -206,9 +212,22 @@ typedef struct avifgpu_read_desc {
 /* ABI version of the loaded library (== AVIFGPU_ABI_VERSION of the header it was built from). */
 int32_t avifgpu_abi_version(void);
 
-/* Bind the calling process to one HIP device and create the library's stream + staging buffers.
+/* Bind the calling process to one HIP device: avifgpu_init_devices(&device_index, 1).
  * Fails with AVIFGPU_formatBadParameters if no HIP device is present: there is NO CPU fallback. */
 int32_t avifgpu_init(int32_t device_index);
+
+/* Bind `count` device contexts (the GPUs of the node: {0,1,...,7}).  Host-pointer conversions -- avifgpu_write_rows /
+ * avifgpu_read_rows with AVIFGPU_MEM_HOST and the FormatRecord shim of avifgpu_host.h -- are then cut into contiguous even-row
+ * tiles, one per context (tile k = rows [k*H/N, (k+1)*H/N) rounded to even: no 2x2 chroma block straddles a tile, no tile
+ * depends on another, no device-to-device traffic), each streamed through its GPU in sub-tiles with copies and kernels
+ * overlapped; the planes are gathered in place at plane + row * stride.  The result is byte-identical for every N.
+ * Everything is driven from the calling thread (the plug-in is called serially on Photoshop's main thread,
+ * AvifFormat.cpp:104-199); each context owns one internal worker thread that feeds its device.  An ordinal may appear more
+ * than once (N contexts on one GPU: how the scheduler is tested on a single-GPU machine).  Re-binding a different list
+ * releases the previous contexts first.  Replaces the single-threaded row loops WriteHeifImage.cpp:1017-1029 /
+ * ReadHeifImage.cpp:141-160 as the unit of parallelism. */
+int32_t avifgpu_init_devices(const int32_t* device_indices, int32_t count);
+int32_t avifgpu_device_count(void);            /* contexts currently bound (0 before avifgpu_init*) */
 void    avifgpu_shutdown(void);
 
 /* Message for the last non-zero return on this thread (what LibHeifException / runtime_error carry

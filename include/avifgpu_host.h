@@ -89,6 +89,10 @@ typedef struct avifgpu_SaveUIOptions {
      * of a 32-bit document, always converted (:118-123) -- lcms2's float pipeline.  formatCannotRead for profiles that are
      * not matrix/TRC.  depth 16: lcms2's resampled 33^3 table + tetrahedral interpolation, bit-exact. */
     uint8_t convertToSRGB;
+    /* Chroma down-sampling of the fused 4:2:0 / 4:2:2 output: 0 = what libheif 1.14.0's own conversion does for the plug-in's
+     * interleaved hand-off (the co-sited top-left sample) -- the drop-in default; 1 = box average of the
+     * 2x1 / 2x2 footprint (AVIFGPU_DOWNSAMPLE_AVERAGE), which later libheif versions made their default. */
+    uint8_t chromaDownsampling;
 } avifgpu_SaveUIOptions;
 typedef struct avifgpu_LoadUIOptions {
     avifgpu_HLGOptions hlg;

@@ -62,6 +62,10 @@ def write_cases():
                         if depth == 32:
                             kw.update(transfer=pkg.TRANSFER_PQ, peak_nits=80)
                         out.append((f"ycc-d{depth}-p{planes}-b{bits}-c{chroma}-m{m}", kw))
+                        if chroma != pkg.CHROMA_444:
+                            # libheif 1.14.0's own down-sampling (top-left sample) = the FormatRecord shim's default
+                            out.append((f"ycc-d{depth}-p{planes}-b{bits}-c{chroma}-m{m}-near",
+                                        dict(kw, chroma_downsampling=pkg.DOWNSAMPLE_NEAREST)))
     extra = [
         ("ycc-d8-p3-b8-420-nearest", dict(width=W_ODD, height=H_ODD, depth=8, planes=3, bit_depth=8,
                                           alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420,
@@ -214,6 +218,12 @@ def read_cases():
                                              matrix_coefficients=pkg.MATRIX_RGB_GBR, color_primaries=pkg.PRIMARIES_BT709,
                                              transfer_characteristics=pkg.TC_HLG, hlg_apply_ootf=1,
                                              hlg_display_gamma=1.5, hlg_peak_nits=400)))
+    # displayGamma 1.0 is the reference's minimum (AvifFormat.h:49): powf(luma, 0) = 1 also for black pixels
+    out.append(("f32-ycc-hlg-ootf-gamma1", dict(width=W_ODD, height=H_ODD, colorspace=pkg.COLORSPACE_YCBCR,
+                                                 chroma=pkg.CHROMA_444, bit_depth=10, depth=32, alpha_state=pkg.ALPHA_NONE,
+                                                 matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020,
+                                                 transfer_characteristics=pkg.TC_HLG, hlg_apply_ootf=1, hlg_display_gamma=1.0,
+                                                 hlg_peak_nits=1000)))
     out.append(("tiny-read-1x1", dict(width=1, height=1, colorspace=pkg.COLORSPACE_YCBCR, chroma=pkg.CHROMA_420,
                                        bit_depth=8, depth=8, alpha_state=pkg.ALPHA_NONE,
                                        matrix_coefficients=pkg.MATRIX_BT709)))

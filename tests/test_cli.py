@@ -51,7 +51,7 @@ def test_cli_write_matches_oracle(tmp_path, depth, planes, bits, transfer, alpha
     hdr = depth == 32
     d = pkg.WriteDesc(width=301, height=58, depth=depth, planes=planes, bit_depth=bits, transfer=T[transfer], peak_nits=1000,
                       alpha_state=A[alpha], output=pkg.OUT_YCBCR if ycbcr else pkg.OUT_REFERENCE,
-                      chroma=C[ycbcr] if ycbcr else pkg.CHROMA_444,
+                      chroma=C[ycbcr] if ycbcr else pkg.CHROMA_444, chroma_downsampling=pkg.DOWNSAMPLE_NEAREST,   # the shim's default (libheif 1.14.0)
                       matrix_coefficients=pkg.MATRIX_BT2020_NCL if hdr else pkg.MATRIX_BT601,
                       color_primaries=pkg.PRIMARIES_BT2020 if hdr else pkg.PRIMARIES_BT709, full_range=1)
     src = harness.make_write_source(d, seed=depth + planes)

@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _save(gpu, desc_kw, max_data, output, abort_after=None, fail_at_row=None, matrix=pkg.MATRIX_BT601, chroma=pkg.CHROMA_444):
-    d = pkg.WriteDesc(**desc_kw)
+    # the shim's stage B is libheif 1.14.0's: co-sited chroma sample (SaveUIOptions.chromaDownsampling = 0)
+    d = pkg.WriteDesc(**dict(desc_kw, chroma_downsampling=pkg.DOWNSAMPLE_NEAREST))
     src = harness.make_write_source(d)
     host = FakeHost(d.width, d.height, d.depth, d.planes, max_data=max_data, image=src, abort_after=abort_after,
                     fail_at_row=fail_at_row)

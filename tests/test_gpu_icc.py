@@ -158,6 +158,7 @@ def test_host_shim_converts_document_profile(gpu, lcms):
     icc = _profile(lcms, 1, 0, 1.0)                       # Display-P3 primaries, linear: a typical 32-bit document
     d = pkg.WriteDesc(width=300, height=40, depth=32, planes=4, bit_depth=12, transfer=pkg.TRANSFER_PQ, peak_nits=1000,
                       alpha_state=pkg.ALPHA_STRAIGHT, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_422,
+                      chroma_downsampling=pkg.DOWNSAMPLE_NEAREST,          # the shim's default: libheif 1.14.0's co-sited sample
                       matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020)
     src = harness.make_write_source(d, seed=11)
     conv = src.copy()
@@ -200,6 +201,7 @@ def test_host_shim_sdr_save_of_32bit_document(gpu, lcms):
     icc = _profile(lcms, 3, 0, 1.0)                       # AdobeRGB primaries, linear (what a 32-bit AdobeRGB document embeds)
     d = pkg.WriteDesc(width=300, height=40, depth=32, planes=3, bit_depth=12, transfer=pkg.TRANSFER_CLIP,
                       alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420,
+                      chroma_downsampling=pkg.DOWNSAMPLE_NEAREST,
                       matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)
     src = harness.make_write_source(d, seed=13)
     conv = src.copy()

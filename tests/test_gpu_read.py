@@ -98,3 +98,26 @@ def test_read_ieee_division_fallback(gpu, monkeypatch):
         d = pkg.ReadDesc(**kw)
         planes = harness.make_read_source(d)
         assert np.array_equal(harness.gpu_read(gpu, d, planes), harness.oracle_read(d, planes)), cid
+
+
+def test_hlg_ootf_black_pixels_gamma_one(gpu):
+    """ApplyHLGOOTF with displayGamma 1.0 (the reference's minimum, AvifFormat.h:49) on black pixels: powf(0, 0) = 1, so
+    the result is 0, not NaN (ColorTransfer.cpp:192-205).  Also gamma > 1 on black: powf(0, e) = 0."""
+    W, H = 64, 8
+    for gamma in (1.0, 1.2):
+        for cs in (pkg.COLORSPACE_YCBCR, pkg.COLORSPACE_RGB):
+            d = pkg.ReadDesc(width=W, height=H, colorspace=cs, chroma=pkg.CHROMA_444, bit_depth=10, depth=32,
+                             alpha_state=pkg.ALPHA_NONE, matrix_coefficients=pkg.MATRIX_BT2020_NCL if cs == 0 else pkg.MATRIX_RGB_GBR,
+                             color_primaries=pkg.PRIMARIES_BT2020, transfer_characteristics=pkg.TC_HLG, hlg_apply_ootf=1,
+                             hlg_display_gamma=gamma, hlg_peak_nits=1000)
+            planes = harness.make_read_source(d, seed=5)
+            planes[0][:, :32] = 0                               # black: Y = 0 with neutral chroma / R = G = B = 0
+            planes[1][:, :32] = 512 if cs == 0 else 0
+            planes[2][:, :32] = 512 if cs == 0 else 0
+            want = harness.oracle_read(d, planes)
+            got = harness.gpu_read(gpu, d, planes)
+            assert np.all(np.isfinite(got)), (gamma, cs)
+            assert np.all(np.isfinite(want))
+            _check("hlg-black", dict(depth=32), got, want)
+            if cs == pkg.COLORSPACE_RGB:
+                assert np.all(got.reshape(H, W, 3)[:, :32] == 0)

@@ -17,7 +17,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, chroma, q):
+def _worker(rank, world, port, chroma, q, use_gpu=False):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
@@ -31,10 +31,17 @@ def _worker(rank, world, port, chroma, q):
     src = harness.make_write_source(d)                     # same seed on every rank = the same frame
     r0, n = pkg.sharding.row_tile(d.height, world, rank, even=True)
     calls = []
+    gpu = None
+    if use_gpu:
+        import torch
+        gpu = pkg.AvifGpu(rank % max(torch.cuda.device_count(), 1))    # one rank per GPU (ranks share it on a 1-GPU box)
 
     def step(i):
         calls.append(i)
-        step.out = harness.oracle_write(d, src, row0=r0, nrows=n)     # the checker stands in for the converter on CPU
+        if gpu is not None:                                            # the PRODUCT converts this rank's tile
+            step.out = harness.gpu_write(gpu, d, src, row0=r0, nrows=n, mem="host")
+        else:                                                          # no GPU here: the checker stands in, the glue is what runs
+            step.out = harness.oracle_write(d, src, row0=r0, nrows=n)
     elapsed = ranks.timed(step, steps=3)
     assert calls == [0, 1, 2] and elapsed > 0
     slow = ranks.max_over_ranks(10.0 if rank == 1 else 1.0)
@@ -51,19 +58,31 @@ def _worker(rank, world, port, chroma, q):
     ranks.close()
 
 
-@pytest.mark.parametrize("chroma", [1, 3])       # 4:2:0 and 4:4:4
-def test_two_rank_tiles(chroma):
+def _run_ranks(chroma, use_gpu):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, chroma, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, chroma, q, use_gpu)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(timeout=180)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert q.get(timeout=5) == "ok"
+
+
+@pytest.mark.parametrize("chroma", [1, 3])       # 4:2:0 and 4:4:4
+def test_two_rank_tiles(chroma):
+    _run_ranks(chroma, use_gpu=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chroma", [1, 3])
+def test_two_rank_tiles_library(chroma):
+    """Same two-rank run with libavifgpu.so converting each rank's tile (rank 0 still checks the assembled frame against the
+    oracle's whole-frame result: the document is 16-bit, so bit-exact)."""
+    _run_ranks(chroma, use_gpu=True)
 
 
 def test_row_tiles_partition():

@@ -28,26 +28,56 @@ class NoFillHost(FakeHost):
         return 0
 
 
-def run(width, height, max_data, output, chroma=pkg.CHROMA_444, reps=3, nofill=False):
-    gpu = pkg.AvifGpu(0)
+def run(width, height, max_data, output, chroma=pkg.CHROMA_444, reps=3, nofill=False, planes="pinned", contexts=1):
+    """planes: "pinned"   = avifgpu_image_alloc'ed once, outside the timed call (page-locked: DMA target),
+               "pageable" = ordinary heap memory with libheif-like 16-byte strides (what heif_image_add_plane gives the plug-in):
+                            the library bounces every tile through its pinned staging,
+               "inside"   = allocated by the call itself (hipHostMalloc of the planes is then part of the time)."""
+    import torch
+    ndev = max(torch.cuda.device_count(), 1)
+    gpu = pkg.AvifGpu(devices=[i % ndev for i in range(contexts)])
     rng = np.random.default_rng(1234)
     src = rng.random((height, width * 3), dtype=np.float32)
     best = None
+    keep = []
+    pre = H.Image()
+    if planes != "inside":
+        pre.width, pre.height, pre.bit_depth = width, height, 10
+        if output == pkg.OUT_YCBCR:
+            pre.colorspace, pre.chroma = pkg.COLORSPACE_YCBCR, chroma
+        else:
+            pre.colorspace, pre.chroma = pkg.COLORSPACE_RGB, 14
+        if planes == "pinned":
+            assert gpu.lib.avifgpu_image_alloc(ctypes.byref(pre)) == 0
+        else:
+            xs, ys = harness.chroma_shift(chroma)
+            for pl in range(3 if output == pkg.OUT_YCBCR else 1):
+                w = (width * 3 if output != pkg.OUT_YCBCR else (width if pl == 0 else (width + xs) >> xs)) * 2
+                h = height if (pl == 0 or output != pkg.OUT_YCBCR) else (height + ys) >> ys
+                a = np.zeros((h, (w + 15) // 16 * 16), dtype=np.uint8)
+                keep.append(a)
+                pre.plane[pl] = a.ctypes.data
+                pre.stride[pl] = a.strides[0]
     for _ in range(reps):
         host = (NoFillHost if nofill else FakeHost)(width, height, 32, 3, max_data=max_data, image=src)
         opts = H.SaveUIOptions(imageBitDepth=10, hdrTransferFunction=pkg.TRANSFER_PQ, pq=H.PQOptions(80), chromaSubsampling=chroma, lossless=0)
-        img = H.Image()
+        img = H.Image() if planes == "inside" else pre
         t0 = time.perf_counter()
         code = gpu.lib.avifgpu_host_create_heif_image(ctypes.byref(host.fr), pkg.ALPHA_NONE, ctypes.byref(opts), output,
                                                       pkg.MATRIX_BT2020_NCL, pkg.PRIMARIES_BT2020, ctypes.byref(img))
         dt = time.perf_counter() - t0
         assert code == 0, gpu.lib.avifgpu_last_error()
-        gpu.lib.avifgpu_image_free(ctypes.byref(img))
+        if planes == "inside":
+            gpu.lib.avifgpu_image_free(ctypes.byref(img))
         best = dt if best is None else min(best, dt)
         tiles = len(host.rects)
+    if planes == "pinned":
+        gpu.lib.avifgpu_image_free(ctypes.byref(pre))
     # the host's own fill cost (numpy memcpy of every tile into the pinned buffer) for reference
     t0 = time.perf_counter(); tmp = src.copy(); fill = time.perf_counter() - t0
-    print(json.dumps({"config": f"{width}x{height} RGB f32 -> 10-bit PQ, output={'YCbCr444' if output else 'interleaved'}" + (" (host fill skipped: pipeline floor)" if nofill else ""),
+    print(json.dumps({"config": f"{width}x{height} RGB f32 -> 10-bit PQ, output={'YCbCr' + {3: '444', 2: '422', 1: '420'}[chroma] if output else 'interleaved'}"
+                                + (" (host fill skipped: pipeline floor)" if nofill else ""),
+                      "planes": planes, "contexts": contexts, "lanes": int(os.environ.get("AVIFGPU_LANES", "1")),
                       "maxData_MiB": max_data / 2**20, "tiles": tiles, "seconds": round(best, 4),
                       "Mpx_s": round(width * height / best / 1e6, 1), "host_fill_memcpy_s": round(fill, 4),
                       "H2D_GB_s_equiv": round(width * height * 12 / best / 1e9, 1)}), flush=True)
@@ -86,10 +116,21 @@ def run_read(width, height, max_data, bits, depth, chroma, tc, reps=3):
 
 
 if __name__ == "__main__":
-    run_read(8192, 8192, 64 << 20, 10, 32, pkg.CHROMA_444, pkg.TC_PQ)
-    run_read(8192, 8192, 64 << 20, 8, 8, pkg.CHROMA_420, pkg.TC_SRGB)
-    run_read(8192, 8192, 64 << 20, 12, 16, pkg.CHROMA_420, pkg.TC_SRGB)
-    for md in (16 << 20, 64 << 20, 256 << 20, 1024 << 20):
-        run(8192, 8192, md, pkg.OUT_YCBCR)
-    run(8192, 8192, 64 << 20, pkg.OUT_REFERENCE)
-    run(8192, 8192, 64 << 20, pkg.OUT_YCBCR, nofill=True)
+    mode = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if mode in ("all", "read"):
+        run_read(8192, 8192, 64 << 20, 10, 32, pkg.CHROMA_444, pkg.TC_PQ)
+        run_read(8192, 8192, 64 << 20, 8, 8, pkg.CHROMA_420, pkg.TC_SRGB)
+        run_read(8192, 8192, 64 << 20, 12, 16, pkg.CHROMA_420, pkg.TC_SRGB)
+    if mode in ("all", "write"):
+        for md in (16 << 20, 64 << 20, 256 << 20):
+            run(8192, 8192, md, pkg.OUT_YCBCR)
+        run(8192, 8192, 64 << 20, pkg.OUT_REFERENCE)
+        run(8192, 8192, 64 << 20, pkg.OUT_YCBCR, planes="pageable")
+        run(8192, 8192, 64 << 20, pkg.OUT_YCBCR, planes="inside")
+    if mode in ("all", "write", "floor"):
+        for md in (16 << 20, 64 << 20):
+            run(8192, 8192, md, pkg.OUT_YCBCR, nofill=True)
+        run(8192, 8192, 64 << 20, pkg.OUT_YCBCR, nofill=True, planes="pageable")
+        run(8192, 8192, 64 << 20, pkg.OUT_YCBCR, nofill=True, contexts=2)
+        run(8192, 8192, 64 << 20, pkg.OUT_YCBCR, nofill=True, planes="pageable", contexts=2)
+    pkg.AvifGpu(0)
