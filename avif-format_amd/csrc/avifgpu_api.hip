@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -243,6 +244,35 @@ void release_device_caches()
     if (cur >= 0) (void)hipSetDevice(cur);
 }
 
+// lcms2's parametric curve types 1..5 (DefaultEvalParametricFn; P = g, a, b, c, d, e, f as the library orders them) rewritten as
+//     y = R >= thr ? (a*R + b > 0 ? pow(a*R + b, g) + add : nonpos) : c*R + f
+// so that the kernel evaluates one branch-free expression.  Q = g, a, b, thr, c, f, add, nonpos.
+static void normalise_trc(int type, const double* P, double* Q)
+{
+    const double inf = std::numeric_limits<double>::infinity();
+    double g = P[0], a = 1, b = 0, thr = 0, c = 0, f = 0, add = 0, nonpos = 0;
+    switch (type) {
+    case 1:                                   // R < 0: R when |g - 1| < 1e-4, else 0;  R >= 0: pow(R, g)   (pow(0, g) = 0 = nonpos)
+        c = std::fabs(g - 1.0) < 0.0001 ? 1.0 : 0.0;
+        break;
+    case 2:                                   // |a| < 1e-4: 0;  R >= -b/a: (a*R + b > 0 ? pow : 0), else 0
+        if (std::fabs(P[1]) < 0.0001) { thr = inf; break; }
+        a = P[1]; b = P[2]; thr = -P[2] / P[1];
+        break;
+    case 3:                                   // as 2 with + c above and c below the (non-negative) break
+        if (std::fabs(P[1]) < 0.0001) { thr = inf; break; }
+        a = P[1]; b = P[2]; thr = std::max(-P[2] / P[1], 0.0); add = P[3]; f = P[3];
+        break;
+    case 4:                                   // R >= d: (a*R + b > 0 ? pow : 0), else c*R
+        a = P[1]; b = P[2]; thr = P[4]; c = P[3];
+        break;
+    default:                                  // 5: R >= d: (a*R + b > 0 ? pow + e : e), else c*R + f
+        a = P[1]; b = P[2]; thr = P[4]; c = P[3]; f = P[6]; add = P[5]; nonpos = P[5];
+        break;
+    }
+    Q[0] = g; Q[1] = a; Q[2] = b; Q[3] = thr; Q[4] = c; Q[5] = f; Q[6] = add; Q[7] = nonpos;
+}
+
 int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const WriteGeom& g, const IccArgs& icc, WriteParams& p)
 {
     memset(&p, 0, sizeof(p));
@@ -254,7 +284,8 @@ int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const Wr
         for (int c = 0; c < 3; ++c) {
             if (g_icc->trc_type[c] < 1 || g_icc->trc_type[c] > 5) return fail(AVIFGPU_formatBadParameters, "bad ICC curve type");
             p.icc_trc_type[c] = g_icc->trc_type[c];
-            for (int k = 0; k < 7; ++k) p.icc_trc[c][k] = g_icc->trc_params[c][k];
+            p.icc_trc_linear[c] = g_icc->trc_type[c] == 1 && g_icc->trc_params[c][0] == 1.0;
+            normalise_trc(g_icc->trc_type[c], g_icc->trc_params[c], p.icc_trc[c]);
         }
         for (int k = 0; k < 9; ++k) p.icc_m[k] = g_icc->matrix[k];
         if (g_icc->out_curve != 0) {
@@ -263,6 +294,8 @@ int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const Wr
             if (d->transfer != AVIFGPU_TRANSFER_CLIP) return fail(AVIFGPU_formatBadParameters, "the sRGB ICC target goes with transfer Clip");
             p.icc_out = 4;
             for (int k = 0; k < 8; ++k) p.icc_out_p[k] = g_icc->out_params[k];
+            p.icc_out_rcp[0] = std::fabs(g_icc->out_params[1]) < 0.0001 ? 0.0 : 1.0 / g_icc->out_params[1];
+            p.icc_out_rcp[1] = std::fabs(g_icc->out_params[3]) < 0.0001 ? 0.0 : 1.0 / g_icc->out_params[3];
         }
     }
     if (g_icc16) {

@@ -6,8 +6,8 @@
 namespace avifgpu {
 
 // Tuning word of the dominant kernel (RGB f32 -> curve -> YCbCr 4:4:4 u16), see launch_write():
-//   bit0 enable hot kernel, bit1 8 px/lane (else 4), bit2 non-temporal loads+stores, bit3 register prefetch,
-//   bit4 XCD-contiguous span mapping, bits 8.. = block cap (0 = default).
+//   bit0 enable the streaming kernels, bit1 8 px/lane (else 4), bit2 non-temporal loads+stores, bits 8.. = block cap (0 = default).
+//   (bits 3 and 4 selected a register-prefetch and an XCD-contiguous variant in round 1; both lost and were removed.)
 enum : int { kHotDefault = 1 | 2 | 4 };
 
 struct WriteParams {
@@ -31,11 +31,14 @@ struct WriteParams {
     float   my[3], mcb[3], mcr[3];
     float   half;                // 1 << (bits-1)
     // ICC row transform in front of stage A (include/avifgpu.h); used only by the ICC instantiations
-    int32_t icc_trc_type[3];
+    int32_t icc_trc_type[3];     // lcms2 parametric type per channel (0 = no ICC stage)
     int32_t icc_out;             // 0 | 4: output curve after the matrix (avifgpu_icc_transform::out_curve)
-    double  icc_trc[3][7];
+    int32_t icc_trc_linear[3];   // channel curve is gamma 1 (identity on every float)
+    int32_t icc_pad;
+    double  icc_trc[3][8];       // normalised: g, a, b, thr, c, f, add, nonpos (see icc_trc in write_kernels.hip)
     double  icc_m[9];
     double  icc_out_p[8];
+    double  icc_out_rcp[2];      // 1/a, 1/c of the output curve (0 where the coefficient is ~0)
     // 8-bit matrix-shaper transform (avifgpu_icc_shaper8): tables live in device memory, matrix in kernarg
     const int32_t* icc8_s1;      // [3][256] 1.14 fixed
     const uint8_t* icc8_s2;      // [16385] 8-bit output curve (identical for R,G,B: the destination is sRGB)

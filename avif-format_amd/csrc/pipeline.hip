@@ -572,7 +572,7 @@ namespace {
 // rows per sub-tile: AVIFGPU_CHUNK_MB of the larger side (rows in / planes out), even, at least 2
 int chunk_rows_for(size_t bytes_per_row)
 {
-    const size_t budget = (size_t)env_int("AVIFGPU_CHUNK_MB", 32, 1, 4096) << 20;
+    const size_t budget = (size_t)env_int("AVIFGPU_CHUNK_MB", 16, 1, 4096) << 20;
     size_t rows = budget / std::max<size_t>(bytes_per_row, 1);
     rows = std::max<size_t>(rows & ~(size_t)1, 2);
     return (int)std::min<size_t>(rows, 1u << 30);

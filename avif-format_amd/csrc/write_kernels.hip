@@ -37,75 +37,82 @@ AG_DEV uint32_t oetf_code(const WriteParams& p, float f)
     return (uint32_t)__builtin_amdgcn_fmed3f(scaled, 0.0f, p.maxf);
 }
 
-// pow(x, g) for finite x > 0 in FP64, good to ~1e-14 relative (checked against libm on 1.5e6 points per exponent):
-// log2 by the atanh series on the mantissa in [sqrt(1/2), sqrt(2)), exp2 by a degree-13 Taylor polynomial.  lcms2 evaluates
-// its curves with libm's pow in double and rounds the result to float; at this accuracy the rounded floats agree except
-// for ~1e-7 of the samples, far inside the tier-2 bar.  ~45 DFMA-class instructions instead of the several hundred of the
-// device libm's pow (the general-TRC ICC kernel went from 0.06 to the figure in profiles/r01/bench_configs.jsonl).
-__device__ __attribute__((noinline)) double dpow_pos(double x, double g)
+// ---- pow(x, g) for the ICC curves --------------------------------------------------------------------------------------
+// lcms2 evaluates its parametric curves with libm's pow in double and hands the result to the next stage as a FLOAT; the tier-2
+// bar is on the integer code behind that.  So what the kernel needs is pow to ~1 ulp of float -- not of double.  Built for the
+// hardware: the mantissa's top 7 bits index a 128-entry table in LDS (c = RN_float(1 / bin centre), L = -log2(c) in double),
+//     x = m * 2^e,  r = fma(m, c, -1) in [-2^-8, 2^-8]   (one rounding: 2^-33 absolute)
+//     log2(x) = e + L + log2(1 + r),   log2(1 + r) by a degree-5 fp32 polynomial (truncation 7e-15, rounding 3e-10)
+//     t = g * log2(x) in double (the one place 30+ bits are needed: |t| reaches ~50),  n = rint(t),  f = float(t - n)
+//     x^g = ldexp(v_exp_f32(f), n)
+// i.e. 8 fp32 ops + one LDS read + 5 FP64 ops + one transcendental instead of ~50 FP64 FMAs.  A double argument that is not a
+// float (a*R + b of the parametric types) keeps its low bits through the residual term dx.  Against libm on 28 M points
+// (tools/fastpow_check.c, seven exponents): max relative error 6.0e-8 with a correctly rounded exp2 -- add v_exp_f32's 1 ulp
+// on the device; the rounded floats agree with (float)pow() in 96 % of the samples and differ by 1 ulp otherwise.
+struct IccPowTable { const double* L; const float* c; };     // LDS, 128 entries each
+constexpr int kIccPowBins = 128;
+
+AG_DEV double icc_pow_pos(const IccPowTable& T, double x, double g)          // straight-line: no branch, no early return
 {
-    double m = __builtin_amdgcn_frexp_mant(x);               // [0.5, 1)
-    int e = __builtin_amdgcn_frexp_exp(x);
-    if (m < 0.70710678118654752) { m *= 2.0; e -= 1; }
-    const double s = (m - 1.0) / (m + 1.0);
-    const double s2 = s * s;
-    double p = 1.0 / 17.0;
-    p = __builtin_fma(p, s2, 1.0 / 15.0); p = __builtin_fma(p, s2, 1.0 / 13.0); p = __builtin_fma(p, s2, 1.0 / 11.0);
-    p = __builtin_fma(p, s2, 1.0 / 9.0);  p = __builtin_fma(p, s2, 1.0 / 7.0);  p = __builtin_fma(p, s2, 1.0 / 5.0);
-    p = __builtin_fma(p, s2, 1.0 / 3.0);  p = __builtin_fma(p, s2, 1.0);
-    const double l2 = 2.8853900817779268 * s * p;            // 2 / ln 2
-    const double y = g * ((double)e + l2);
-    const double n = __builtin_rint(y);
-    const double t = (y - n) * 0.69314718055994531;
-    double q = 1.0 / 6227020800.0;
-    q = __builtin_fma(q, t, 1.0 / 479001600.0); q = __builtin_fma(q, t, 1.0 / 39916800.0); q = __builtin_fma(q, t, 1.0 / 3628800.0);
-    q = __builtin_fma(q, t, 1.0 / 362880.0);    q = __builtin_fma(q, t, 1.0 / 40320.0);    q = __builtin_fma(q, t, 1.0 / 5040.0);
-    q = __builtin_fma(q, t, 1.0 / 720.0);       q = __builtin_fma(q, t, 1.0 / 120.0);      q = __builtin_fma(q, t, 1.0 / 24.0);
-    q = __builtin_fma(q, t, 1.0 / 6.0);         q = __builtin_fma(q, t, 0.5);              q = __builtin_fma(q, t, 1.0);
-    q = __builtin_fma(q, t, 1.0);
-    return __builtin_amdgcn_ldexp(q, (int)n);
+    const float xf = fmaxf((float)x, 1e-37f);                  // x <= 1e-37 (incl. <= 0 and NaN) evaluates on 1e-37 and is zeroed at the end:
+                                                                // below every code step of every supported depth, and no denormals here
+    const float m = __builtin_amdgcn_frexp_mantf(xf);           // [0.5, 1)
+    const int e = __builtin_amdgcn_frexp_expf(xf);
+    const int idx = (int)((__float_as_uint(m) >> 16) & (kIccPowBins - 1));
+    const float c = T.c[idx];
+    float r = __builtin_fmaf(m, c, -1.0f);
+    const float dx = (float)(x - (double)xf);                   // 0 when x is a float (plain gamma curves, the inverse curve)
+    r = __builtin_fmaf(__builtin_amdgcn_ldexpf(dx, -e), c, r);
+    float p = __builtin_fmaf(r, 0.2885390081777927f, -0.36067376022224085f);
+    p = __builtin_fmaf(r, p, 0.4808983469629878f);
+    p = __builtin_fmaf(r, p, -0.7213475204444817f);
+    p = __builtin_fmaf(r, p, 1.4426950408889634f);
+    p = r * p;
+    const double t = g * ((double)e + T.L[idx] + (double)p);
+    const double n = __builtin_rint(t);
+    const float f = (float)(t - n);
+    const float v = __builtin_amdgcn_ldexpf(nat_exp2(f), (int)n);
+    return (double)(x > 1e-37 ? v : 0.0f);
 }
-AG_DEV double dpow(double x, double g) { return x > 0.0 ? dpow_pos(x, g) : 0.0; }     // callers pass x >= 0, g > 0
+AG_DEV double dpow(const IccPowTable& T, double x, double g) { return icc_pow_pos(T, x, g); }     // x <= 0 -> 0, as the callers' "e > 0 ? pow : 0"
+
+// Fill the table (once per workgroup, 128 threads): the double log2 here is the device libm's, ~1e-16.
+AG_DEV void icc_pow_table_fill(double* L, float* c, int tid)
+{
+    if (tid < kIccPowBins) {
+        const double centre = 0.5 + ((double)tid + 0.5) * (1.0 / 256.0);
+        const float cf = (float)(1.0 / centre);
+        c[tid] = cf;
+        L[tid] = -log2((double)cf);
+    }
+}
 
 // ---- ICC row transform (lcms2 float pipeline of a matrix/TRC profile pair, see include/avifgpu.h) --------------------
 // One lcms2 parametric curve (types 1..5, DefaultEvalParametricFn) evaluated in double, returned as the float the
 // curves stage hands to the matrix stage.
-AG_DEV float icc_trc(int type, const double* P, float in)
+// All five types are one expression once the host has normalised the parameters (avifgpu_api.hip, normalise_trc):
+//     Q = g, a, b, thr, c, f, add, nonpos:   y = R >= thr ? (a*R + b > 0 ? pow(a*R + b, g) + add : nonpos) : c*R + f
+// (type 1: a = 1, b = 0, thr = 0, the R < 0 side c*R with c = 1 or 0; type 4: thr = d, c*R below it; ...).  The conditions are
+// per lane, so both sides are evaluated and selected: no divergent branch, ONE inlined pow per call site.
+AG_DEV float icc_trc(const IccPowTable& T, const double* Q, float in)
 {
     const double R = (double)in;
-    double v;
-    switch (type) {
-    case 1:
-        if (R < 0) v = (fabs(P[0] - 1.0) < 0.0001) ? R : 0.0; else v = (P[0] == 1.0) ? R : dpow(R, P[0]);   // pow(R, 1) == R exactly
-        break;
-    case 2: {
-        if (fabs(P[1]) < 0.0001) { v = 0.0; break; }
-        const double disc = -P[2] / P[1];
-        if (R >= disc) { const double e = P[1] * R + P[2]; v = e > 0 ? dpow(e, P[0]) : 0.0; } else v = 0.0;
-        break; }
-    case 3: {
-        if (fabs(P[1]) < 0.0001) { v = 0.0; break; }
-        double disc = -P[2] / P[1]; if (disc < 0) disc = 0;
-        if (R >= disc) { const double e = P[1] * R + P[2]; v = e > 0 ? dpow(e, P[0]) + P[3] : 0.0; } else v = P[3];
-        break; }
-    case 4:
-        if (R >= P[4]) { const double e = P[1] * R + P[2]; v = e > 0 ? dpow(e, P[0]) : 0.0; } else v = R * P[3];
-        break;
-    default:
-        if (R >= P[4]) { const double e = P[1] * R + P[2]; v = e > 0 ? dpow(e, P[0]) + P[5] : P[5]; } else v = R * P[3] + P[6];
-        break;
-    }
-    return (float)v;
+    const double lin = Q[1] * R + Q[2];
+    const double pw = dpow(T, lin, Q[0]);
+    const double hi = lin > 0 ? pw + Q[6] : Q[7];
+    const double lo = Q[4] * R + Q[5];
+    return (float)(R >= Q[3] ? hi : lo);
 }
 
 // Inverse of lcms2's parametric type 4 (type -4, DefaultEvalParametricFn), the curve stage in front of an sRGB destination.
-// P = g, a, b, c, d, break point pow(a*d+b, g), 1/g.
-AG_DEV float icc_inv4(const double* P, float in)
+// P = g, a, b, c, d, break point pow(a*d+b, g), 1/g; Q = 1/a, 1/c (host-computed: the two divisions of the library become
+// multiplications by the correctly rounded reciprocals -- a difference of one double ulp, far below the float this returns).
+AG_DEV float icc_inv4(const IccPowTable& T, const double* P, const double* Q, float in)
 {
     const double R = (double)in;
     double v;
-    if (R >= P[5]) v = (fabs(P[0]) < 0.0001 || fabs(P[1]) < 0.0001) ? 0.0 : (dpow(R, P[6]) - P[2]) / P[1];
-    else v = fabs(P[3]) < 0.0001 ? 0.0 : R / P[3];
+    if (R >= P[5]) v = (fabs(P[0]) < 0.0001 || fabs(P[1]) < 0.0001) ? 0.0 : (dpow(T, R, P[6]) - P[2]) * Q[0];
+    else v = fabs(P[3]) < 0.0001 ? 0.0 : R * Q[1];
     return (float)v;
 }
 
@@ -113,14 +120,13 @@ AG_DEV float icc_inv4(const double* P, float in)
 // documents) -> matrix only, no call in the kernel.  ICC = 2: general parametric curves (double pow, out of line).
 // ICC = 4: as 2 (linear curves skipped at run time) plus the destination's inverse curve after the matrix (-> sRGB).
 template <int ICC>
-AG_DEV void icc_apply(const WriteParams& p, float (&c)[3])
+AG_DEV void icc_apply(const WriteParams& p, const IccPowTable& T, float (&c)[3])
 {
     float t[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         if constexpr (ICC == 1) t[k] = c[k];
-        else if constexpr (ICC == 4) t[k] = (p.icc_trc_type[k] == 1 && p.icc_trc[k][0] == 1.0) ? c[k] : icc_trc(p.icc_trc_type[k], p.icc_trc[k], c[k]);
-        else t[k] = icc_trc(p.icc_trc_type[k], p.icc_trc[k], c[k]);
+        else t[k] = p.icc_trc_linear[k] ? c[k] : icc_trc(T, p.icc_trc[k], c[k]);     // pow(R, 1) == R exactly: gamma-1 channels skip the curve (wave-uniform)
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {                   // lcms2 matrix stage: double accumulation from 0, one rounding to float
@@ -129,59 +135,49 @@ AG_DEV void icc_apply(const WriteParams& p, float (&c)[3])
         acc += (double)t[1] * p.icc_m[3 * i + 1];
         acc += (double)t[2] * p.icc_m[3 * i + 2];
         c[i] = (float)acc;
-        if constexpr (ICC == 4) c[i] = icc_inv4(p.icc_out_p, c[i]);
+        if constexpr (ICC == 4) c[i] = icc_inv4(T, p.icc_out_p, p.icc_out_rcp, c[i]);
     }
 }
 
 // ---- 16-bit ICC stage: lcms2's resampled pipeline (include/avifgpu.h, "16-bit SDR save path") --------------------------------
 // BuildHostToLcmsLookup / BuildLcmsToHostLookup entries (ColorProfileConversion.cpp:37-95), evaluated instead of tabulated.
-AG_DEV uint32_t icc16_host_to_lcms(uint32_t i)
-{
-    const int v = (int)((((float)i / 32768.0f) * 65535.0f) + 0.5f);
-    return (uint32_t)(v < 0 ? 0 : (v > 65535 ? 65535 : v));
-}
-AG_DEV uint32_t icc16_lcms_to_host(uint32_t i)
-{
-    // i / 65535.0f as a 3-FMA quotient with r = RN(1/65535): equal to the IEEE quotient for every i in [0, 65535]
-    // (tests/test_icc16.py proves it in exact rational arithmetic), a third of the instructions of the division sequence
-    const float x = (float)i, r = 1.0f / 65535.0f;
-    const float q0 = x * r;
-    const float quot = __builtin_fmaf(__builtin_fmaf(-q0, 65535.0f, x), r, q0);
-    const int v = (int)((quot * 32768.0f) + 0.5f);
-    return (uint32_t)(v < 0 ? 0 : (v > 32768 ? 32768 : v));
-}
+// The reference's float expressions -- (int)(i / 32768f * 65535f + .5f) and (int)(i / 65535f * 32768f + .5f) with IEEE single
+// operations -- are step functions of an integer; over their whole domains ([0, 32768] and [0, 65535]) they equal the integer forms
+// below, INCLUDING where float rounding of the product moves a step off its real-arithmetic position (16448 instead of 16384; the
+// +1 from 65408 on).  tests/test_icc16.py::test_range_maps_equal_the_float_expressions checks every input against the oracle.
+AG_DEV uint32_t icc16_host_to_lcms(uint32_t i) { return 2u * i - (i > 16448u ? 1u : 0u); }              // i <= 32768
+AG_DEV uint32_t icc16_lcms_to_host(uint32_t j) { return (j + 1u + (j >= 65408u ? 1u : 0u)) >> 1; }       // j <= 65535
 // lcms2 TetrahedralInterp16 on the 33^3 table: 16.16 fixed-point cell position (_cmsToFixedDomain), the cell's tetrahedron
 // chosen by the order of the three fractions, and the library's rounding  t = Rest + 0x8001; out = c0 + ((t + (t >> 16)) >> 16)
 // in 32-bit two's-complement arithmetic.  in[] are [0, 65535] samples; out[] likewise.
+//
+// The path through the cell is base -> +step(axis of the largest fraction) -> ... -> +all three steps, so only the axis of the
+// largest and of the smallest fraction matter: n1 = base + step[max axis], n3 = base + all, n2 = n3 - step[min axis].  With tied
+// fractions the library's if-tree picks one order; any order gives the same sum, because the tied terms (p1-p0)*r + (p2-p1)*r
+// collapse to (p2-p0)*r -- exactly, also modulo 2^32 -- so the intermediate node drops out.  That makes the selection a few
+// compares and selects (v_max3 / v_med3 / v_min3) instead of a divergent six-way branch.
 AG_DEV void icc16_tetrahedral(const uint16_t* __restrict__ clut, const uint32_t (&in)[3], uint32_t (&out)[3])
 {
     constexpr int G = AVIFGPU_ICC_CLUT_GRID;
-    int f[3], c0i[3], r[3], step[3];
+    uint32_t c0i[3], r[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int a = (int)in[k] * (G - 1);
         const int b = a + 0x7fff;
-        f[k] = a + ((b + (b >> 16) + 1) >> 16);             // == a + b / 0xffff for every 16-bit input (checked exhaustively)
-        c0i[k] = f[k] >> 16;
-        r[k] = f[k] & 0xffff;
+        const int f = a + ((b + (b >> 16) + 1) >> 16);      // == a + b / 0xffff for every 16-bit input (checked exhaustively)
+        c0i[k] = (uint32_t)f >> 16;
+        r[k] = (uint32_t)f & 0xffffu;
     }
-    step[0] = in[0] == 0xffffu ? 0 : G * G;                 // node index strides, in nodes (table is [r][g][b][4])
-    step[1] = in[1] == 0xffffu ? 0 : G;
-    step[2] = in[2] == 0xffffu ? 0 : 1;
-    const int base = (c0i[0] * G + c0i[1]) * G + c0i[2];
-    // order the axes by decreasing fraction exactly as the library's if-tree does (ties included)
-    int a0, a1, a2;
-    if (r[0] >= r[1]) {
-        if (r[1] >= r[2]) { a0 = 0; a1 = 1; a2 = 2; }
-        else if (r[2] >= r[0]) { a0 = 2; a1 = 0; a2 = 1; }
-        else { a0 = 0; a1 = 2; a2 = 1; }
-    } else {
-        if (r[0] >= r[2]) { a0 = 1; a1 = 0; a2 = 2; }
-        else if (r[1] >= r[2]) { a0 = 1; a1 = 2; a2 = 0; }
-        else { a0 = 2; a1 = 1; a2 = 0; }
-    }
-    const int n1 = base + step[a0], n2 = n1 + step[a1], n3 = n2 + step[a2];
-    const uint32_t ra = (uint32_t)r[a0], rb = (uint32_t)r[a1], rc = (uint32_t)r[a2];
+    const uint32_t s0 = in[0] == 0xffffu ? 0u : (uint32_t)(G * G);   // node index strides (table is [r][g][b][4])
+    const uint32_t s1 = in[1] == 0xffffu ? 0u : (uint32_t)G;
+    const uint32_t s2 = in[2] == 0xffffu ? 0u : 1u;
+    const uint32_t base = (c0i[0] * G + c0i[1]) * G + c0i[2];
+    const uint32_t mx = max(max(r[0], r[1]), r[2]), mn = min(min(r[0], r[1]), r[2]);
+    const uint32_t md = r[0] + r[1] + r[2] - mx - mn;
+    const uint32_t smax = r[0] == mx ? s0 : (r[1] == mx ? s1 : s2);  // first axis holding the maximum ...
+    const uint32_t smin = r[2] == mn ? s2 : (r[1] == mn ? s1 : s0);  // ... last axis holding the minimum: distinct axes even when all tie
+    const uint32_t n1 = base + smax, n3 = base + s0 + s1 + s2, n2 = n3 - smin;
+    const uint32_t ra = mx, rb = md, rc = mn;
     typedef uint32_t u2 __attribute__((ext_vector_type(2)));
     const u2 v0 = *reinterpret_cast<const u2*>(clut + 4 * base), v1 = *reinterpret_cast<const u2*>(clut + 4 * n1);
     const u2 v2 = *reinterpret_cast<const u2*>(clut + 4 * n2),   v3 = *reinterpret_cast<const u2*>(clut + 4 * n3);
@@ -204,7 +200,8 @@ AG_DEV void icc16_tetrahedral(const uint16_t* __restrict__ clut, const uint32_t 
 // RESCALE8: an 8-bit document saved at 10/12 bit -- decided once per row by the caller where that pays (no alpha), else here.
 template <int DEPTH, int PLANES, int TRANSFER, int ICC = 0, int RESCALE8 = 2>   // 0 no, 1 yes, 2 decide per sample (p.maxv)
 AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t (&q)[4],
-                    const int32_t* icc8_lds_s1 = nullptr, const uint8_t* icc8_lds_s2 = nullptr, const uint16_t* lut8 = nullptr)
+                    const int32_t* icc8_lds_s1 = nullptr, const uint8_t* icc8_lds_s2 = nullptr, const uint16_t* lut8 = nullptr,
+                    const IccPowTable& powT = IccPowTable{ nullptr, nullptr })
 {
     constexpr bool COLOR = PLANES >= 3;
     constexpr bool ALPHA = (PLANES == 2 || PLANES == 4);
@@ -214,7 +211,7 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
         float col[NCOL];
 #pragma unroll
         for (int k = 0; k < NCOL; ++k) col[k] = __uint_as_float(s[k]);
-        if constexpr (ICC != 0 && COLOR) icc_apply<ICC>(p, col);                  // ConvertRow runs before the pixel loop: WriteHeifImage.cpp:1031-1034
+        if constexpr (ICC != 0 && COLOR) icc_apply<ICC>(p, powT, col);                  // ConvertRow runs before the pixel loop: WriteHeifImage.cpp:1031-1034
         float a = 1.0f;
         if constexpr (ALPHA) {
             a = cxx_clamp(__uint_as_float(s[PLANES - 1]), 0.0f, 1.0f);          // :558, :1047
@@ -341,6 +338,13 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
         __syncthreads();
     }
 
+    // parametric-curve ICC variants: the pow() table (1.5 KiB), filled once per workgroup
+    constexpr bool ICCPOW = (ICC == 2 || ICC == 4);
+    __shared__ double icc_pow_L[ICCPOW ? kIccPowBins : 1];
+    __shared__ float icc_pow_c[ICCPOW ? kIccPowBins : 1];
+    if constexpr (ICCPOW) { icc_pow_table_fill(icc_pow_L, icc_pow_c, threadIdx.x); __syncthreads(); }
+    const IccPowTable powT = { icc_pow_L, icc_pow_c };
+
     // 8-bit documents saved at 10/12 bit: the reference's 256-entry rescale LUT (WriteHeifImage.cpp:87-112), rebuilt per
     // workgroup with the same IEEE expression -- one ds_read per sample instead of a division sequence in the pixel loop
     __shared__ uint16_t lut8[DEPTH == 8 ? 256 : 2];
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
 #pragma unroll
                 for (int i = 0; i < PXT; ++i) {
                     uint32_t q[4] = { 0, 0, 0, 0 };        // gray fills [0] and [3] only
-                    stage_a<DEPTH, PLANES, TRANSFER, ICC, decltype(rescale8)::value>(p, s[i], q, icc8_s1, icc8_s2, lut8);
+                    stage_a<DEPTH, PLANES, TRANSFER, ICC, decltype(rescale8)::value>(p, s[i], q, icc8_s1, icc8_s2, lut8, powT);
                     if constexpr (!PACK) { qp[vr][i][0] = q[0]; qp[vr][i][1] = q[1]; qp[vr][i][2] = q[2]; qp[vr][i][3] = q[3]; }
                     else if constexpr (DST16) { qp[vr][i][0] = q[0] | (q[1] << 16); qp[vr][i][1] = q[2] | (q[3] << 16); }
                     else qp[vr][i][0] = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
@@ -523,9 +527,10 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
 //            wave's own in-order DS queue (lgkmcnt) is the only ordering needed.
 //   matrix : 3x3 on exact integer codes, libheif rounding; plane stores are PXL*2 = 8 or 16 B per lane,
 //            contiguous across the wave, non-temporal.
-//   PREFETCH: the next span's loads are issued before the current span's math (register double-buffer).
-//   XCDMAP : block b runs on XCD b % 8 (observed, speed only); give each XCD one contiguous eighth of the
-//            frame so its L2/TLB working set is a single moving window instead of eight interleaved ones.
+//   tail   : any width that is a multiple of 4 (rows stay 16-byte aligned): the last span of a row is masked -- float4s
+//            beyond the row load as zero, a lane stores 16 B, 8 B (4 pixels: widths are multiples of 4) or nothing.
+// Variants measured and dropped in round 1 (profiles/r01/hot_variant_sweep*.txt): register prefetch of the next span
+// (-5...-25 %: occupancy) and XCD-contiguous span mapping (+-1 %: nothing is shared between spans).
 typedef float    f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -539,7 +544,7 @@ template <bool NT, typename V> AG_DEV void stream_store(V* p, V v)
     if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
 }
 
-template <int TRANSFER, int PXL, bool NT, bool PREFETCH, bool XCDMAP>
+template <int TRANSFER, int PXL, bool NT>
 __global__ __launch_bounds__(256) void write_rgb32_ycbcr444_hot(const WriteParams p)
 {
     constexpr int K = 3 * PXL / 4;               // float4 per lane per span
@@ -553,43 +558,21 @@ __global__ __launch_bounds__(256) void write_rgb32_ycbcr444_hot(const WriteParam
     uint32_t* my = strip[wave];
 
     // span indices fit 32 bits (host checks): 32-bit udiv instead of a 64-bit software divide per trip
-    const uint32_t spans_per_row = (uint32_t)p.width / SPAN_PX;        // host guarantees divisibility and alignment
+    const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;      // host guarantees width % 4 == 0 and alignment
     const uint32_t total = spans_per_row * (uint32_t)p.nrows;
-    uint32_t sidx, step, limit;
-    if constexpr (XCDMAP) {
-        const uint32_t xcd = blockIdx.x & 7;
-        const uint32_t chunk = (total + 7) >> 3;
-        const uint32_t lo = chunk * xcd;
-        limit = lo + chunk < total ? lo + chunk : total;
-        sidx = lo + (blockIdx.x >> 3) * 4 + wave;
-        step = (gridDim.x >> 3) * 4;
-    } else {
-        sidx = blockIdx.x * 4 + wave;
-        step = gridDim.x * 4;
-        limit = total;
-    }
-    if (sidx >= limit) return;
+    const uint32_t step = gridDim.x * 4;
 
-    auto span_src = [&](uint32_t s) -> const f32x4* {
-        const uint32_t r = s / spans_per_row;
-        const uint32_t sx = s - r * spans_per_row;
-        return reinterpret_cast<const f32x4*>(p.src + (long long)r * p.src_row_bytes) + (long long)sx * (64 * K);
-    };
-
-    f32x4 cur[K];
-    {
-        const f32x4* sp = span_src(sidx);
+    for (uint32_t sidx = blockIdx.x * 4 + wave; sidx < total; sidx += step) {
+        const uint32_t r = sidx / spans_per_row;
+        const uint32_t sx = sidx - r * spans_per_row;
+        const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);             // < SPAN_PX only for the last span of a row
+        const int span_f4 = span_px * 3 / 4;
+        const f32x4* sp = reinterpret_cast<const f32x4*>(p.src + (long long)r * p.src_row_bytes) + (long long)sx * (64 * K);
+        f32x4 cur[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) cur[k] = stream_load<NT>(sp + 64 * k + lane);
-    }
-
-    for (; sidx < limit; sidx += step) {
-        f32x4 nxt[K];
-        if constexpr (PREFETCH) {
-            const uint32_t sn = sidx + step < limit ? sidx + step : sidx;      // last trip re-reads its own span (L2 hit)
-            const f32x4* sp = span_src(sn);
-#pragma unroll
-            for (int k = 0; k < K; ++k) nxt[k] = stream_load<NT>(sp + 64 * k + lane);
+        for (int k = 0; k < K; ++k) {
+            cur[k] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+            if (64 * k + lane < span_f4) cur[k] = stream_load<NT>(sp + 64 * k + lane);
         }
 
 #pragma unroll
@@ -629,36 +612,35 @@ __global__ __launch_bounds__(256) void write_rgb32_ycbcr444_hot(const WriteParam
             cbv[i] = clip_round(R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2] + p.half, p.maxv);
             crv[i] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
         }
-        const uint32_t r = sidx / spans_per_row;
-        const uint32_t sx = sidx - r * spans_per_row;
         const long long xoff = ((long long)sx * SPAN_PX + (long long)PXL * lane) * 2;
         uint8_t* d0 = p.dst[0] + (long long)r * p.dst_stride[0] + xoff;
         uint8_t* d1 = p.dst[1] + (long long)r * p.dst_stride[1] + xoff;
         uint8_t* d2 = p.dst[2] + (long long)r * p.dst_stride[2] + xoff;
+        const int nv = span_px - PXL * lane;                                       // pixels of this lane inside the row: >= PXL, 4 or <= 0
         if constexpr (PXL == 4) {
-            u32x2 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16) };
-            u32x2 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16) };
-            u32x2 c = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16) };
-            stream_store<NT>(reinterpret_cast<u32x2*>(d0), a);
-            stream_store<NT>(reinterpret_cast<u32x2*>(d1), b);
-            stream_store<NT>(reinterpret_cast<u32x2*>(d2), c);
+            if (nv >= 4) {
+                u32x2 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16) };
+                u32x2 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16) };
+                u32x2 c = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16) };
+                stream_store<NT>(reinterpret_cast<u32x2*>(d0), a);
+                stream_store<NT>(reinterpret_cast<u32x2*>(d1), b);
+                stream_store<NT>(reinterpret_cast<u32x2*>(d2), c);
+            }
         } else {
-            u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
-            u32x4 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16), cbv[4] | (cbv[5] << 16), cbv[6] | (cbv[7] << 16) };
-            u32x4 c = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16), crv[4] | (crv[5] << 16), crv[6] | (crv[7] << 16) };
-            stream_store<NT>(reinterpret_cast<u32x4*>(d0), a);
-            stream_store<NT>(reinterpret_cast<u32x4*>(d1), b);
-            stream_store<NT>(reinterpret_cast<u32x4*>(d2), c);
-        }
-
-        if constexpr (PREFETCH) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) cur[k] = nxt[k];
-        } else {
-            if (sidx + step < limit) {
-                const f32x4* sp = span_src(sidx + step);
-#pragma unroll
-                for (int k = 0; k < K; ++k) cur[k] = stream_load<NT>(sp + 64 * k + lane);
+            if (nv >= 8) {
+                u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
+                u32x4 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16), cbv[4] | (cbv[5] << 16), cbv[6] | (cbv[7] << 16) };
+                u32x4 c = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16), crv[4] | (crv[5] << 16), crv[6] | (crv[7] << 16) };
+                stream_store<NT>(reinterpret_cast<u32x4*>(d0), a);
+                stream_store<NT>(reinterpret_cast<u32x4*>(d1), b);
+                stream_store<NT>(reinterpret_cast<u32x4*>(d2), c);
+            } else if (nv >= 4) {
+                u32x2 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16) };
+                u32x2 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16) };
+                u32x2 c = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16) };
+                stream_store<NT>(reinterpret_cast<u32x2*>(d0), a);
+                stream_store<NT>(reinterpret_cast<u32x2*>(d1), b);
+                stream_store<NT>(reinterpret_cast<u32x2*>(d2), c);
             }
         }
     }
@@ -680,7 +662,7 @@ __global__ __launch_bounds__(256) void write_rgb32_ycbcr_sub_hot(const WritePara
     const int lane = threadIdx.x & 63;
     uint32_t* my = strip[wave];
 
-    const uint32_t spans_per_row = (uint32_t)p.width / SPAN_PX;        // host guarantees divisibility and alignment
+    const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;    // host guarantees width % 4 == 0 and alignment
     const uint32_t groups = ((uint32_t)p.nrows + VR - 1) >> YS;
     const uint32_t total = spans_per_row * groups;
     for (uint32_t sidx = blockIdx.x * 4 + wave; sidx < total; sidx += gridDim.x * 4) {
@@ -688,12 +670,17 @@ __global__ __launch_bounds__(256) void write_rgb32_ycbcr_sub_hot(const WritePara
         const uint32_t sx = sidx - gy * spans_per_row;
         uint32_t dw[VR][LDW];
         f32x4 v[VR][K];
+        const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);             // < SPAN_PX only for the last span of a row
+        const int span_f4 = span_px * 3 / 4;
 #pragma unroll
         for (int vr = 0; vr < VR; ++vr) {                              // both rows' loads in flight before any math
             const int r = min((int)(gy * VR) + vr, p.rows_to_end - 1);  // bottom edge: replicate the last IMAGE row
             const f32x4* sp = reinterpret_cast<const f32x4*>(p.src + (long long)r * p.src_row_bytes) + (long long)sx * (64 * K);
 #pragma unroll
-            for (int k = 0; k < K; ++k) v[vr][k] = stream_load<true>(sp + 64 * k + lane);
+            for (int k = 0; k < K; ++k) {
+                v[vr][k] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+                if (64 * k + lane < span_f4) v[vr][k] = stream_load<true>(sp + 64 * k + lane);
+            }
         }
 #pragma unroll
         for (int vr = 0; vr < VR; ++vr) {
@@ -717,6 +704,7 @@ __global__ __launch_bounds__(256) void write_rgb32_ycbcr_sub_hot(const WritePara
             return (e & 1) ? (dw[vr][e >> 1] >> 16) : (dw[vr][e >> 1] & 0xffffu);
         };
         const long long xoff = ((long long)sx * SPAN_PX + (long long)PXL * lane) * 2;
+        const int nv = span_px - PXL * lane;                           // pixels of this lane inside the row: >= 8, 4 or <= 0 (width % 4 == 0)
 #pragma unroll
         for (int vr = 0; vr < VR; ++vr) {
             const int r = (int)(gy * VR) + vr;
@@ -724,8 +712,14 @@ __global__ __launch_bounds__(256) void write_rgb32_ycbcr_sub_hot(const WritePara
             uint32_t yv[PXL];
 #pragma unroll
             for (int i = 0; i < PXL; ++i) yv[i] = luma_code(p, code(vr, i, 0), code(vr, i, 1), code(vr, i, 2));   // (GBR needs 4:4:4)
-            u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
-            stream_store<true>(reinterpret_cast<u32x4*>(p.dst[0] + (long long)r * p.dst_stride[0] + xoff), a);
+            uint8_t* dy = p.dst[0] + (long long)r * p.dst_stride[0] + xoff;
+            if (nv >= 8) {
+                u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
+                stream_store<true>(reinterpret_cast<u32x4*>(dy), a);
+            } else if (nv >= 4) {
+                u32x2 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16) };
+                stream_store<true>(reinterpret_cast<u32x2*>(dy), a);
+            }
         }
         uint32_t cbv[4], crv[4];
 #pragma unroll
@@ -742,10 +736,17 @@ __global__ __launch_bounds__(256) void write_rgb32_ycbcr_sub_hot(const WritePara
             crv[j] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
         }
         const long long coff = ((long long)sx * (SPAN_PX / 2) + 4LL * lane) * 2;
-        u32x2 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16) };
-        u32x2 c = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16) };
-        stream_store<true>(reinterpret_cast<u32x2*>(p.dst[1] + (long long)gy * p.dst_stride[1] + coff), b);
-        stream_store<true>(reinterpret_cast<u32x2*>(p.dst[2] + (long long)gy * p.dst_stride[2] + coff), c);
+        uint8_t* dcb = p.dst[1] + (long long)gy * p.dst_stride[1] + coff;
+        uint8_t* dcr = p.dst[2] + (long long)gy * p.dst_stride[2] + coff;
+        if (nv >= 8) {
+            u32x2 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16) };
+            u32x2 c = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16) };
+            stream_store<true>(reinterpret_cast<u32x2*>(dcb), b);
+            stream_store<true>(reinterpret_cast<u32x2*>(dcr), c);
+        } else if (nv >= 4) {                                          // 4 pixels = 2 chroma samples
+            stream_store<true>(reinterpret_cast<uint32_t*>(dcb), cbv[0] | (cbv[1] << 16));
+            stream_store<true>(reinterpret_cast<uint32_t*>(dcr), crv[0] | (crv[1] << 16));
+        }
     }
 }
 
@@ -767,15 +768,19 @@ __global__ __launch_bounds__(256) void write_rgba32_ycbcra444_hot(const WritePar
     const int lane = threadIdx.x & 63;
     uint32_t* my = strip[wave];
 
-    const uint32_t spans_per_row = (uint32_t)p.width / SPAN_PX;        // host guarantees divisibility and alignment
+    const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;    // any width: the last span of a row is masked
     const uint32_t total = spans_per_row * (uint32_t)p.nrows;
     for (uint32_t sidx = blockIdx.x * 4 + wave; sidx < total; sidx += gridDim.x * 4) {
         const uint32_t r = sidx / spans_per_row;
         const uint32_t sx = sidx - r * spans_per_row;
+        const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);
         const f32x4* sp = reinterpret_cast<const f32x4*>(p.src + (long long)r * p.src_row_bytes) + (long long)sx * SPAN_PX;
         f32x4 v[PXL];
 #pragma unroll
-        for (int k = 0; k < PXL; ++k) v[k] = stream_load<true>(sp + 64 * k + lane);
+        for (int k = 0; k < PXL; ++k) {
+            v[k] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+            if (64 * k + lane < span_px) v[k] = stream_load<true>(sp + 64 * k + lane);
+        }
 #pragma unroll
         for (int k = 0; k < PXL; ++k) {
             float col[3] = { v[k].x, v[k].y, v[k].z };
@@ -810,16 +815,22 @@ __global__ __launch_bounds__(256) void write_rgba32_ycbcra444_hot(const WritePar
         }
         const long long xoff = ((long long)sx * SPAN_PX + (long long)PXL * lane) * 2;
         const uint32_t* planes_v[4] = { yv, cbv, crv, av };
+        const int nv = span_px - PXL * lane;                           // pixels of this lane inside the row
 #pragma unroll
         for (int pl = 0; pl < 4; ++pl) {
             const uint32_t* q = planes_v[pl];
             uint8_t* dst = p.dst[pl] + (long long)r * p.dst_stride[pl] + xoff;
-            if constexpr (PXL == 4) {
-                u32x2 o = { q[0] | (q[1] << 16), q[2] | (q[3] << 16) };
-                stream_store<true>(reinterpret_cast<u32x2*>(dst), o);
+            if (nv >= PXL) {
+                if constexpr (PXL == 4) {
+                    u32x2 o = { q[0] | (q[1] << 16), q[2] | (q[3] << 16) };
+                    stream_store<true>(reinterpret_cast<u32x2*>(dst), o);
+                } else {
+                    u32x4 o = { q[0] | (q[1] << 16), q[2] | (q[3] << 16), q[4] | (q[5] << 16), q[6] | (q[7] << 16) };
+                    stream_store<true>(reinterpret_cast<u32x4*>(dst), o);
+                }
             } else {
-                u32x4 o = { q[0] | (q[1] << 16), q[2] | (q[3] << 16), q[4] | (q[5] << 16), q[6] | (q[7] << 16) };
-                stream_store<true>(reinterpret_cast<u32x4*>(dst), o);
+#pragma unroll
+                for (int i = 0; i < PXL; ++i) if (i < nv) reinterpret_cast<uint16_t*>(dst)[i] = (uint16_t)q[i];   // the one ragged lane of a row
             }
         }
     }
@@ -998,7 +1009,7 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, char* label)
     if constexpr (DEPTH == 32 && PLANES >= 3) {
         if (p.icc_trc_type[0] != 0) {               // ICC row transform requested: separate instantiations, the others pay nothing
             bool linear = true;
-            for (int c = 0; c < 3; ++c) linear = linear && p.icc_trc_type[c] == 1 && p.icc_trc[c][0] == 1.0;
+            for (int c = 0; c < 3; ++c) linear = linear && p.icc_trc_linear[c] != 0;
             if (p.icc_out == 4) {                   // -> sRGB: the SDR (Clip) save of a 32-bit document
                 if constexpr (TRANSFER == 3) {
                     snprintf(label, kLabelBytes, "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=4>",
@@ -1079,8 +1090,7 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
                         int variant, hipStream_t st, char* label)
 {
     // hot path: RGB f32 (no alpha) -> YCbCr 4:4:4 u16 with aligned rows; `variant` is a tuning word:
-    //   bit0 enable, bit1 PXL=8 (else 4), bit2 non-temporal, bit3 prefetch, bit4 XCD-contiguous mapping;
-    //   bits 8.. = blocks (0 = default).
+    //   bit0 enable, bit1 PXL=8 (else 4), bit2 non-temporal; bits 8.. = blocks (0 = default).
     // (8-bit documents stay on write_px: measured 0.057 vs 0.069 ms for the RGB8 copy, 0.090 vs 0.095 ms for RGBA8 premultiplied)
     if ((variant & 1) && p.icc16_clut == nullptr && depth == 16 && planes >= 3 && output == AVIFGPU_OUT_REFERENCE &&
         ((long long)p.width * planes * (depth / 8)) % 16 == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
@@ -1125,11 +1135,11 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
 #define AG_RGBA_HOT_ENABLE 1
 #endif
     if (AG_RGBA_HOT_ENABLE && (variant & 1) && p.icc_trc_type[0] == 0 && depth == 32 && planes == 4 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 0 && ys == 0 &&
-        (p.width % (64 * AG_RGBA_HOT_PXL)) == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 && p.dst[3] != nullptr &&
+        (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 && p.dst[3] != nullptr &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |
           reinterpret_cast<uintptr_t>(p.dst[3]) | (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2] |
           (uintptr_t)p.dst_stride[3]) & 15) == 0) {
-        const long long spans = (long long)(p.width / (64 * AG_RGBA_HOT_PXL)) * p.nrows;
+        const long long spans = (long long)((p.width + 64 * AG_RGBA_HOT_PXL - 1) / (64 * AG_RGBA_HOT_PXL)) * p.nrows;
         if (spans == 0) return hipSuccess;
         if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
             long long blocks = (spans + 3) / 4;
@@ -1145,10 +1155,10 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
         }
     }
     if ((variant & 1) && p.icc_trc_type[0] == 0 && depth == 32 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 1 &&
-        (p.width % 512) == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
+        (p.width % 4) == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |
           (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2]) & 15) == 0) {
-        const long long spans = (long long)(p.width / 512) * ((p.nrows + (1 << ys) - 1) >> ys);
+        const long long spans = (long long)((p.width + 511) / 512) * ((p.nrows + (1 << ys) - 1) >> ys);
         if (spans == 0) return hipSuccess;
         if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
             long long blocks = (spans + 3) / 4;
@@ -1170,21 +1180,17 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
         (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |
           (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2]) & 15) == 0) {
-        const bool px8 = (variant & 2) && (p.width % 512) == 0;
-        if (px8 || (p.width % 256) == 0) {
-            const bool nt = variant & 4, pf = variant & 8, xm = variant & 16;
-            const long long spans = (long long)(p.width / (px8 ? 512 : 256)) * p.nrows;
+        if ((p.width % 4) == 0) {                     // rows stay 16-byte aligned; the last span of a row is masked in the kernel
+            const bool px8 = variant & 2, nt = variant & 4;
+            const int span_px = px8 ? 512 : 256;
+            const long long spans = (long long)((p.width + span_px - 1) / span_px) * p.nrows;
             if (spans == 0) return hipSuccess;
             if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
             long long blocks = (spans + 3) / 4;
             const long long cap = (variant >> 8) ? (variant >> 8) : 256LL * 512;   // 8192^2: one span per wave (32k blocks) measured 5-6 % faster than two (16k)
             if (blocks > cap) blocks = cap;
-            if (xm) blocks = (blocks + 7) & ~7LL;
-            snprintf(label, kLabelBytes, "write_rgb32_ycbcr444_hot<transfer=%d,pxl=%d,nt=%d,prefetch=%d,xcdmap=%d>",
-                     p.transfer, px8 ? 8 : 4, (int)nt, (int)pf, (int)xm);
-#define AG_HOT5(TR, PX, NT_, PF_, XM_) hipLaunchKernelGGL((write_rgb32_ycbcr444_hot<TR, PX, NT_, PF_, XM_>), dim3((int)blocks), dim3(256), 0, st, p)
-#define AG_HOT4(TR, PX, NT_, PF_) do { if (xm) AG_HOT5(TR, PX, NT_, PF_, true); else AG_HOT5(TR, PX, NT_, PF_, false); } while (0)
-#define AG_HOT3(TR, PX, NT_) do { if (pf) AG_HOT4(TR, PX, NT_, true); else AG_HOT4(TR, PX, NT_, false); } while (0)
+            snprintf(label, kLabelBytes, "write_rgb32_ycbcr444_hot<transfer=%d,pxl=%d,nt=%d>", p.transfer, px8 ? 8 : 4, (int)nt);
+#define AG_HOT3(TR, PX, NT_) hipLaunchKernelGGL((write_rgb32_ycbcr444_hot<TR, PX, NT_>), dim3((int)blocks), dim3(256), 0, st, p)
 #define AG_HOT2(TR, PX) do { if (nt) AG_HOT3(TR, PX, true); else AG_HOT3(TR, PX, false); } while (0)
 #define AG_HOT1(TR) do { if (px8) AG_HOT2(TR, 8); else AG_HOT2(TR, 4); } while (0)
             switch (p.transfer) {

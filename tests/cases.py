@@ -123,6 +123,33 @@ def write_cases():
         ("ycc-d32-p4-b10-444-hot-gbr-428", dict(width=768, height=3, depth=32, planes=4, bit_depth=10,
                                                 transfer=pkg.TRANSFER_SMPTE428, alpha_state=pkg.ALPHA_STRAIGHT, output=pkg.OUT_YCBCR,
                                                 chroma=pkg.CHROMA_444, matrix_coefficients=pkg.MATRIX_RGB_GBR)),
+        # the streaming kernels on widths that are not whole spans (document sizes like 7952 x 5304): masked last span of each row
+        ("ycc-d32-p3-b10-444-hot-tail520", dict(width=520, height=5, depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_PQ,
+                                                peak_nits=80, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR,
+                                                chroma=pkg.CHROMA_444, matrix_coefficients=pkg.MATRIX_BT2020_NCL,
+                                                color_primaries=pkg.PRIMARIES_BT2020)),
+        ("ycc-d32-p3-b12-444-hot-tail252", dict(width=252, height=4, depth=32, planes=3, bit_depth=12, transfer=pkg.TRANSFER_CLIP,
+                                                alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444,
+                                                matrix_coefficients=pkg.MATRIX_BT601)),
+        ("ycc-d32-p3-b10-420-hot-tail1004", dict(width=1004, height=7, depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_PQ,
+                                                 peak_nits=1000, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR,
+                                                 chroma=pkg.CHROMA_420, matrix_coefficients=pkg.MATRIX_BT2020_NCL,
+                                                 color_primaries=pkg.PRIMARIES_BT2020)),
+        ("ycc-d32-p3-b10-420-hot-tail516-near", dict(width=516, height=6, depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_PQ,
+                                                     peak_nits=80, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR,
+                                                     chroma=pkg.CHROMA_420, matrix_coefficients=pkg.MATRIX_BT2020_NCL,
+                                                     color_primaries=pkg.PRIMARIES_BT2020, chroma_downsampling=pkg.DOWNSAMPLE_NEAREST)),
+        ("ycc-d32-p3-b12-422-hot-tail260", dict(width=260, height=3, depth=32, planes=3, bit_depth=12, transfer=pkg.TRANSFER_SMPTE428,
+                                                alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_422,
+                                                matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020)),
+        ("ycc-d32-p4-b12-444-hot-tail259", dict(width=259, height=5, depth=32, planes=4, bit_depth=12, transfer=pkg.TRANSFER_PQ,
+                                                peak_nits=1000, alpha_state=pkg.ALPHA_STRAIGHT, output=pkg.OUT_YCBCR,
+                                                chroma=pkg.CHROMA_444, matrix_coefficients=pkg.MATRIX_BT2020_NCL,
+                                                color_primaries=pkg.PRIMARIES_BT2020)),
+        ("ycc-d32-p4-b10-444-hot-tail513-premul", dict(width=513, height=3, depth=32, planes=4, bit_depth=10,
+                                                       transfer=pkg.TRANSFER_CLIP, alpha_state=pkg.ALPHA_PREMULTIPLIED,
+                                                       output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444,
+                                                       matrix_coefficients=pkg.MATRIX_BT601)),
         # BASELINE.json config 1 at its real size: 512x512 RGBA8 -> 8-bit 4:2:0 BT.709
         ("baseline-c1-512", dict(width=512, height=512, depth=8, planes=4, bit_depth=8, alpha_state=pkg.ALPHA_STRAIGHT,
                                  output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420, matrix_coefficients=pkg.MATRIX_BT709)),

@@ -19,6 +19,19 @@ CASES = [
                                        output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_422, **BT2020)),
     ("write_rgba32_ycbcra444_hot", dict(width=768, height=6, depth=32, planes=4, bit_depth=12, transfer=pkg.TRANSFER_PQ, peak_nits=80,
                                         alpha_state=pkg.ALPHA_PREMULTIPLIED, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444, **BT2020)),
+    # widths that are not whole spans: the masked last span of every row (real document geometries, e.g. 7952 x 5304)
+    ("write_rgb32_ycbcr444_hot", dict(width=1004, height=9, depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_PQ, peak_nits=80,
+                                      output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444, **BT2020)),
+    ("write_rgb32_ycbcr444_hot", dict(width=36, height=3, depth=32, planes=3, bit_depth=12, transfer=pkg.TRANSFER_CLIP,
+                                      output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444, **BT2020)),
+    ("write_rgb32_ycbcr_sub_hot", dict(width=1500, height=7, depth=32, planes=3, bit_depth=12, transfer=pkg.TRANSFER_PQ, peak_nits=1000,
+                                       output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420, **BT2020)),
+    ("write_rgb32_ycbcr_sub_hot", dict(width=1500, height=6, depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_PQ, peak_nits=1000,
+                                       output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420, chroma_downsampling=pkg.DOWNSAMPLE_NEAREST, **BT2020)),
+    ("write_rgb32_ycbcr_sub_hot", dict(width=524, height=5, depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_HLG,
+                                       output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_422, **BT2020)),
+    ("write_rgba32_ycbcra444_hot", dict(width=771, height=6, depth=32, planes=4, bit_depth=12, transfer=pkg.TRANSFER_PQ, peak_nits=80,
+                                        alpha_state=pkg.ALPHA_STRAIGHT, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444, **BT2020)),
     ("write_f32_ref_stream", dict(width=1000, height=5, depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_PQ, peak_nits=80,
                                   output=pkg.OUT_REFERENCE)),
     ("write_f32_ref_stream", dict(width=333, height=4, depth=32, planes=4, bit_depth=12, transfer=pkg.TRANSFER_CLIP,

@@ -107,24 +107,18 @@ def test_prepare_clut16_rejects_what_it_cannot_do(lcms):
     assert pkg.load().avifgpu_icc_prepare(sampled, len(sampled), pkg.ICC_TARGET_SRGB_FLOAT, ctypes.byref(pkg.IccTransform())) == pkg.formatCannotRead
 
 
-def test_fast_division_by_65535_is_exact():
-    """The kernel's lcms->host range map divides by 65535 with q0 = x*r, q = fma(fma(-q0, d, x), r, q0), r = RN(1/d).
-    Proof over the whole input domain (0..65535) in exact rational arithmetic that q == RN(x / d)."""
-    from fractions import Fraction
-
-    def rn32(fr):
-        g = np.float32(float(fr))
-        cands = [np.nextafter(g, np.float32(-np.inf)), g, np.nextafter(g, np.float32(np.inf))]
-        return np.float32(min(cands, key=lambda c: (abs(Fraction(float(c)) - fr), int(np.float32(c).view(np.uint32)) & 1)))
-
-    d = np.float32(65535.0)
-    r = np.float32(1.0) / d
-    for x in range(65536):
-        xf = np.float32(x)
-        q0 = np.float32(xf * r)
-        t = rn32(Fraction(float(-q0)) * Fraction(float(d)) + Fraction(float(xf)))
-        q = rn32(Fraction(float(t)) * Fraction(float(r)) + Fraction(float(q0)))
-        assert q == np.float32(xf / d), x
+def test_range_maps_equal_the_float_expressions():
+    """The kernel's integer forms of BuildHostToLcmsLookup / BuildLcmsToHostLookup (ColorProfileConversion.cpp:37-95) equal the
+    reference's IEEE single expressions for EVERY table index -- including the two places where the float rounding of the
+    product moves a step off its real-arithmetic position (numpy float32 = the same IEEE operations, one at a time)."""
+    i = np.arange(32769, dtype=np.float32)
+    want = np.clip((((i / np.float32(32768.0)) * np.float32(65535.0)) + np.float32(0.5)).astype(np.int32), 0, 65535)
+    ii = np.arange(32769)
+    assert np.array_equal(want, 2 * ii - (ii > 16448))                     # icc16_host_to_lcms
+    j = np.arange(65536, dtype=np.float32)
+    want = np.clip((((j / np.float32(65535.0)) * np.float32(32768.0)) + np.float32(0.5)).astype(np.int32), 0, 32768)
+    jj = np.arange(65536)
+    assert np.array_equal(want, (jj + 1 + (jj >= 65408)) >> 1)             # icc16_lcms_to_host
 
 
 def _gpu(gpu, d, src, icc16):

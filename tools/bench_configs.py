@@ -71,7 +71,8 @@ def bench_write(name, icc=None, smooth=False, **kw):
     ssz = 2 if d.bit_depth > 8 else 1
     bufs, ptrs, strides = {}, [None] * 4, [0] * 4
     for pl, (w, xs, ys) in harness.write_planes(d).items():
-        bufs[pl] = torch.empty(((d.height + ys) >> ys, w * ssz), dtype=torch.uint8, device=dev)
+        # plane rows padded to 16 bytes, as heif_image_add_plane allocates them
+        bufs[pl] = torch.empty(((d.height + ys) >> ys, (w * ssz + 15) // 16 * 16), dtype=torch.uint8, device=dev)
         ptrs[pl], strides[pl] = bufs[pl].data_ptr(), bufs[pl].stride(0)
     fn = lambda: gpu.write_rows(d, 0, d.height, src.data_ptr(), src.stride(0) * src.element_size(), ptrs, strides,
                                 mem=pkg.MEM_DEVICE, stream=stream.cuda_stream, icc=icc)
@@ -90,7 +91,8 @@ def bench_read(name, **kw):
     ptrs, strides, keep = [None] * 4, [0] * 4, []
     for pl, (w, xs, ys) in harness.read_planes(d).items():
         h = (d.height + ys) >> ys
-        t = torch.randint(0, maxc + 1, (h, w), generator=g, device=dev, dtype=torch.int32)
+        wp = (w * ssz + 15) // 16 * 16 // ssz                # rows padded to 16 bytes, as libheif allocates planes
+        t = torch.randint(0, maxc + 1, (h, wp), generator=g, device=dev, dtype=torch.int32)
         t = t.to(torch.int16 if ssz == 2 else torch.uint8).contiguous()
         keep.append(t); ptrs[pl], strides[pl] = t.data_ptr(), t.stride(0) * ssz
     nch = harness.read_channels(d)
@@ -143,6 +145,17 @@ if __name__ == "__main__":
     bench_write("REF RGBA16 premultiplied -> 10-bit interleaved (reference hand-off) 8192^2", width=8192, height=8192, depth=16, planes=4, bit_depth=10, alpha_state=2, output=0)
     bench_write("Gray16+alpha premultiplied -> 12-bit Y + A planes 8192^2", width=8192, height=8192, depth=16, planes=2, bit_depth=12, alpha_state=2, output=0)
     bench_write("Gray32 -> 10-bit PQ Y plane 8192^2", width=8192, height=8192, depth=32, planes=1, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=0)
+    # real document geometries (not powers of two): 42 Mpx / 24 Mpx camera frames and an odd width (rows not 16-byte aligned:
+    # the generic kernel's unaligned instantiation)
+    hdr = dict(depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, matrix_coefficients=9, color_primaries=9)
+    bench_write("GEO 7952x5304 RGB f32 -> 10-bit PQ 4:4:4", width=7952, height=5304, chroma=P.CHROMA_444, **hdr)
+    bench_write("GEO 7952x5304 RGB f32 -> 10-bit PQ 4:2:0 nearest (shim default)", width=7952, height=5304, chroma=P.CHROMA_420, chroma_downsampling=P.DOWNSAMPLE_NEAREST, **hdr)
+    bench_write("GEO 6000x4000 RGB f32 -> 10-bit PQ 4:4:4", width=6000, height=4000, chroma=P.CHROMA_444, **hdr)
+    bench_write("GEO 6000x4000 RGB f32 -> 10-bit PQ 4:2:2", width=6000, height=4000, chroma=P.CHROMA_422, **hdr)
+    bench_write("GEO 6001x4001 (odd) RGB f32 -> 10-bit PQ 4:4:4", width=6001, height=4001, chroma=P.CHROMA_444, **hdr)
+    bench_write("GEO 7952x5304 RGBA f32 -> 12-bit PQ 4:4:4 + alpha", width=7952, height=5304, depth=32, planes=4, bit_depth=12, transfer=0, peak_nits=80, alpha_state=1, output=1, chroma=P.CHROMA_444, matrix_coefficients=9, color_primaries=9)
+    bench_write("GEO 7952x5304 RGB8 -> 8-bit 4:2:0 BT.601", width=7952, height=5304, depth=8, planes=3, bit_depth=8, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=6)
+    bench_write("GEO 6000x4000 RGB16 -> 12-bit 4:4:4 BT.601", width=6000, height=4000, depth=16, planes=3, bit_depth=12, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=6)
     icc_lib = os.path.join(ROOT, "oracle", "liboracle_icc.so")
     if os.path.exists(icc_lib):
         import ctypes
@@ -178,4 +191,6 @@ if __name__ == "__main__":
     bench_read("R16 8192^2 12-bit planar RGB + alpha premult -> RGBA16", width=8192, height=8192, colorspace=1, chroma=P.CHROMA_444, bit_depth=12, depth=16, alpha_state=2, matrix_coefficients=0)
     bench_read("BIG 16384^2 10-bit 4:2:0 BT.2020 PQ -> RGB f32", width=16384, height=16384, colorspace=0, chroma=P.CHROMA_420, bit_depth=10, depth=32, alpha_state=0, matrix_coefficients=9, color_primaries=9, transfer_characteristics=16, pq_peak_nits=80)
     bench_read("BIG 16384^2 8-bit 4:2:0 BT.709 -> RGB8", width=16384, height=16384, colorspace=0, chroma=P.CHROMA_420, bit_depth=8, depth=8, alpha_state=0, matrix_coefficients=1)
+    bench_read("GEO 7952x5304 8-bit 4:2:0 BT.601 -> RGB8", width=7952, height=5304, colorspace=0, chroma=P.CHROMA_420, bit_depth=8, depth=8, alpha_state=0, matrix_coefficients=6)
+    bench_read("GEO 6000x4000 10-bit 4:4:4 BT.2020 PQ -> RGB f32", width=6000, height=4000, colorspace=0, chroma=P.CHROMA_444, bit_depth=10, depth=32, alpha_state=0, matrix_coefficients=9, color_primaries=9, transfer_characteristics=16, pq_peak_nits=80)
     bench_read("R32 8192^2 12-bit planar RGB PQ -> RGB f32", width=8192, height=8192, colorspace=1, chroma=P.CHROMA_444, bit_depth=12, depth=32, alpha_state=0, matrix_coefficients=0, color_primaries=9, transfer_characteristics=16, pq_peak_nits=80)

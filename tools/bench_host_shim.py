@@ -77,7 +77,7 @@ def run(width, height, max_data, output, chroma=pkg.CHROMA_444, reps=3, nofill=F
     t0 = time.perf_counter(); tmp = src.copy(); fill = time.perf_counter() - t0
     print(json.dumps({"config": f"{width}x{height} RGB f32 -> 10-bit PQ, output={'YCbCr' + {3: '444', 2: '422', 1: '420'}[chroma] if output else 'interleaved'}"
                                 + (" (host fill skipped: pipeline floor)" if nofill else ""),
-                      "planes": planes, "contexts": contexts, "lanes": int(os.environ.get("AVIFGPU_LANES", "1")),
+                      "planes": planes, "contexts": contexts, "lanes": int(os.environ.get("AVIFGPU_LANES", "2")),
                       "maxData_MiB": max_data / 2**20, "tiles": tiles, "seconds": round(best, 4),
                       "Mpx_s": round(width * height / best / 1e6, 1), "host_fill_memcpy_s": round(fill, 4),
                       "H2D_GB_s_equiv": round(width * height * 12 / best / 1e9, 1)}), flush=True)
