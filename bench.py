@@ -12,12 +12,18 @@ exactly K steps.
 
     python bench.py --gpus N --steps K --warmup W
 For N > 1 the driver launches one rank per GPU through torch.distributed.run; ranks never exchange pixels
-(row tiles / frames are independent -- SURVEY.md 8e), torch.distributed (RCCL) only provides the barrier and the
-MAX-over-ranks of the timed region.  --scaling weak (default): every rank converts one full frame per step.
---scaling strong: ONE frame is split into N even-row tiles.
+(row tiles are independent -- SURVEY.md 8e), torch.distributed (RCCL) only provides the barrier and the
+MAX-over-ranks of the timed region.  --scaling strong (default): ONE 8192 x 8192 frame is cut into N even-row tiles, rank k
+converts rows [k*H/N, (k+1)*H/N) -- BASELINE.json configs[3] ("row-tiled across 8 MI355X") and the north-star's split of one
+image.  --scaling weak: every rank converts one full frame per step (a batch of N frames).
 
 Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per launch (18 B/px: 12 in + 6 out,
-SURVEY.md 8d) / mean kernel time from HIP events recorded on the launch stream.
+SURVEY.md 8d) / mean kernel time from HIP events recorded on the launch stream.  Extra objects on the same line:
+  c5              BASELINE.json configs[4] (16384 x 16384 RGBA f32 -> 12-bit PQ Y,Cb,Cr,A), the same N-way row split, device-resident
+  pcie_inclusive  rank 0 alone, ONE process, the library's in-process row-tile scheduler on the N GPUs of the run
+                  (avifgpu_init_devices): page-locked host rows in, host planes out -- what N x16 links buy this path
+  cpu_baseline    N = 1 only: the C restatement on the host cores (1 thread whole frame = the comparator; the reference's
+                  one-row-buffer loop and an OpenMP all-cores run as sub-fields)
 """
 from __future__ import annotations
 
@@ -66,7 +72,7 @@ def main():
     ap.add_argument("--height", type=int, default=8192)
     ap.add_argument("--bits", type=int, default=10)
     ap.add_argument("--chroma", choices=["444", "422", "420"], default="444")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong")
     ap.add_argument("--transfer", choices=["pq", "clip"], default="pq", help="clip = same traffic without the PQ math (diagnostic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=8192, help="rows of the frame the CPU baseline converts")
@@ -74,7 +80,8 @@ def main():
     ap.add_argument("--clock-ramp-ms", type=float, default=150.0,
                     help="untimed setup: run the kernel this long before the W warm-up steps so the GPU leaves its idle "
                          "clock state (measured: the first ~50 ms of launches run at up to 2x the steady-state time)")
-    ap.add_argument("--pcie", action="store_true", help="also time the host-buffer (PCIe-inclusive) entry point")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive (host pointers, in-process N-device) figure")
+    ap.add_argument("--no-c5", action="store_true", help="skip the configs[4] (16384^2 RGBA f32) sub-measurement")
     args = ap.parse_args()
 
     import torch
@@ -129,7 +136,10 @@ def main():
     stream = torch.cuda.Stream(dev)            # the launch stream; the HIP events below are recorded on it
     torch.cuda.synchronize(dev)
 
+    launches = [0]                             # kernel launches so far (tools/summarize_kernel_trace.py picks the timed ones)
+
     def step():
+        launches[0] += 1
         gpu.write_rows(desc, row0, nrows, src.data_ptr(), src.stride(0) * 4, ptrs, strides,
                        mem=pkg.MEM_DEVICE, stream=stream.cuda_stream)
 
@@ -167,6 +177,8 @@ def main():
     # launch would serialise the launches against the event records and was measured 4-5 % slower per launch than the same
     # kernel in a plain back-to-back stream (rocprofv3 kernel-trace agrees with the back-to-back figure).
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    launches_before_timed = launches[0]
+
     def timed_step(i):
         if i == 0:
             ev0.record(stream)            # same stream the kernel is launched on
@@ -232,41 +244,90 @@ def main():
             "read_only_frac": round((12.0 * W * nrows) / mean_kernel_s / 1e9 / HBM_PEAK_GBPS, 4),
         },
     }
-    # PMC-derived HBM traffic per launch, if a profile of this round was parsed into profiles/traffic.json
+    out["profile_window"] = {"kernel": kernel_name, "launches_before_timed_region": launches_before_timed, "timed_launches": args.steps}
+    # PMC-derived HBM traffic per launch: NOT measured in this run (counters need their own rocprofv3 --pmc passes, which the
+    # driver's plain run cannot do) -- read from the committed summary of those passes and labelled as such
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and world == 1:
         try:
             tj = json.load(open(tpath))
             if tj.get("workload") == f"{W}x{H}-{args.chroma}-{args.bits}":
                 out["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
+                out["roofline"]["traffic_source"] = "profiles/traffic.json (" + tj.get("source", "rocprofv3 --pmc passes") + ")"
         except Exception:
             pass
 
-    if rank == 0 and world == 1:
-        if args.pcie:
-            import numpy as np
-            rows = min(1024, nrows)
-            h_src = src[:rows].cpu().numpy()
-            h_out = [np.empty((rows if pl == 0 else (rows + ys) >> ys, planes[pl].shape[1]), dtype=np.uint8) for pl in range(3)]
-            sub = pkg.WriteDesc(**{n: getattr(desc, n) for n, _ in pkg.WriteDesc._fields_})
-            def host_step():
-                gpu.write_rows(sub, 0, rows, h_src.ctypes.data, h_src.strides[0], [a.ctypes.data for a in h_out] + [None],
-                               [a.strides[0] for a in h_out] + [0], mem=pkg.MEM_HOST)
-            host_step()
-            t1 = time.perf_counter()
-            for _ in range(5):
+    # ---- configs[4]: 16384^2 RGBA f32 -> 12-bit PQ Y,Cb,Cr,A, the same N-way row split (device-resident) ----
+    if not args.no_c5:
+        W5 = H5 = 16384
+        d5 = pkg.WriteDesc(width=W5, height=H5, depth=32, planes=4, bit_depth=12, transfer=pkg.TRANSFER_PQ, peak_nits=80,
+                           alpha_state=pkg.ALPHA_STRAIGHT, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444,
+                           matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020)
+        r5, n5 = sharding.row_tile(H5, world, rank, even=True) if args.scaling == "strong" else (0, H5)
+        f5 = make_frame(torch, dev, W5, n5, 4, 4321 + rank)                     # this rank's rows only
+        f5.view(-1, 4)[:, 3].clamp_(0.0, 1.0)
+        p5 = [torch.empty((n5, W5 * 2), dtype=torch.uint8, device=dev) for _ in range(4)]
+        k5 = max(5, min(args.steps, 40))
+
+        def step5(i=0):
+            gpu.write_rows(d5, r5, n5, f5.data_ptr(), f5.stride(0) * 4, [p.data_ptr() for p in p5], [p.stride(0) for p in p5],
+                           mem=pkg.MEM_DEVICE, stream=stream.cuda_stream)
+        for _ in range(5):
+            step5()
+        torch.cuda.synchronize(dev)
+        e5 = ranks.timed(step5, k5, sync=lambda: torch.cuda.synchronize(dev))
+        rows5 = H5 if args.scaling == "strong" else H5 * world
+        ab5 = gpu.write_algorithmic_bytes(d5, n5)
+        out["c5"] = {"workload": f"{W5}x{H5} RGBA f32 -> PQ(80 nits) -> 12-bit Y,Cb,Cr,A planes (BASELINE.json configs[4])",
+                     "value": round(W5 * rows5 * k5 / e5 / 1e6, 1), "unit": "Mpixels/s", "steps": k5, "ms_per_step": round(e5 / k5 * 1e3, 4),
+                     "rows_per_gpu": n5, "kernel": gpu.last_kernel(),
+                     "per_gpu_GB_s": round(ab5 * k5 / e5 / 1e9, 1), "per_gpu_frac_of_8TBs": round(ab5 * k5 / e5 / 1e9 / HBM_PEAK_GBPS, 4)}
+        del f5, p5
+
+    # ---- PCIe-inclusive: ONE process (rank 0), the library's in-process scheduler on the N GPUs of this run ----
+    ranks.barrier()
+    if rank == 0 and not args.no_pcie:
+        ndev = torch.cuda.device_count()
+        if ndev >= world:
+            try:
+                multi = pkg.AvifGpu(devices=list(range(world)))
+                h_src = torch.empty((H, W * 3), dtype=torch.float32).pin_memory()
+                h_src.copy_(frame)
+                h_out = [torch.empty((H, W * 2), dtype=torch.uint8).pin_memory() for _ in range(3)]
+                full = pkg.WriteDesc(**{n: getattr(desc, n) for n, _ in pkg.WriteDesc._fields_})
+
+                def host_step():
+                    multi.write_rows(full, 0, H, h_src.data_ptr(), h_src.stride(0) * 4, [o.data_ptr() for o in h_out] + [None],
+                                     [o.stride(0) for o in h_out] + [0], mem=pkg.MEM_HOST)
                 host_step()
-            dt = (time.perf_counter() - t1) / 5
-            out["pcie_inclusive"] = {"value": round(W * rows / dt / 1e6, 1), "unit": "Mpixels/s", "rows": rows,
-                                     "note": "pageable host buffers in, planes out, synchronous (avifgpu_write_rows MEM_HOST)"}
+                best = None
+                for _ in range(5):
+                    t1 = time.perf_counter(); host_step(); dt = time.perf_counter() - t1
+                    best = dt if best is None else min(best, dt)
+                out["pcie_inclusive"] = {"value": round(W * H / best / 1e6, 1), "unit": "Mpixels/s", "seconds": round(best, 5),
+                                         "gpus": world, "H2D_GB_s": round(W * H * 12 / best / 1e9, 1), "D2H_GB_s": round(W * H * 6 / best / 1e9, 1),
+                                         "note": "one process, one calling thread: avifgpu_init_devices + avifgpu_write_rows(MEM_HOST); whole "
+                                                 f"{W}x{H} frame, page-locked rows in / planes out, row tiles dealt across the GPUs, best of 5"}
+                del h_src, h_out
+                gpu = pkg.AvifGpu(dev_index)
+            except Exception as exc:      # noqa: BLE001 -- a diagnostic must not lose the headline line
+                out["pcie_inclusive"] = {"value": None, "note": f"skipped: {exc}"}
+        else:
+            out["pcie_inclusive"] = {"value": None, "note": f"skipped: {ndev} device(s) visible to rank 0, {world} needed"}
+    ranks.barrier()
+
+    if rank == 0 and world == 1:
         if not args.no_cpu_baseline:
+            import ctypes
             import harness
+            import oracle_binding
+            L = oracle_binding.load()
             rows = min(args.cpu_rows, nrows)
             h_src = src[:rows].cpu().numpy()
             sub = pkg.WriteDesc(**{n: getattr(desc, n) for n, _ in pkg.WriteDesc._fields_})
             sub.height = rows
             harness.oracle_write(sub, h_src[:8], row0=0, nrows=8)        # page in the library
-            passes = 4                                                   # ~12 s of CPU work on the box's EPYC
+            passes = 3                                                   # ~9 s of CPU work on the box's EPYC
             t1 = time.perf_counter()
             for _ in range(passes):
                 harness.oracle_write(sub, h_src, return_raw=True)
@@ -275,8 +336,36 @@ def main():
                 "value": round(W * rows / dt / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port",
                 "sample": f"{passes} passes over the first {rows} rows of the same {W}x{H} frame ({W * rows / 1e6:.1f} Mpx, "
                           f"{dt:.1f} s per pass), scalar C restatement oracle/avif_oracle.c (gcc -O2, glibc powf), "
-                          f"1 thread like the reference",
+                          f"1 thread like the reference, whole frame in one call",
             }
+            # the reference's own loop shape: one row buffer, the host delivers each row through advanceState (a memcpy here)
+            bufs = harness._alloc_write_out(sub, rows)
+            pp = pkg.planes4([bufs[i].ctypes.data if i in bufs else None for i in range(4)])
+            ss = pkg.strides4([bufs[i].strides[0] if i in bufs else 0 for i in range(4)])
+            rsub = pkg.WriteDesc(**{n: getattr(desc, n) for n, _ in pkg.WriteDesc._fields_})
+            rrows = min(rows, 2048)
+            rsub.height = rrows
+            t1 = time.perf_counter()
+            rc = L.oracle_write_image_row_callback(ctypes.byref(rsub), h_src.ctypes.data, h_src.strides[0], ctypes.byref(pp), ctypes.byref(ss))
+            dt = time.perf_counter() - t1
+            if rc == 0:
+                out["cpu_baseline"]["row_callback"] = {
+                    "value": round(W * rrows / dt / 1e6, 3), "unit": "Mpixels/s", "cores": 1,
+                    "sample": f"first {rrows} rows, one-row buffer filled per row (WriteHeifImage.cpp:1017-1035 structure), {dt:.2f} s"}
+            n_thr = ctypes.c_int32(0)
+            L.oracle_write_image_all_cores(ctypes.byref(sub), h_src.ctypes.data, h_src.strides[0], ctypes.byref(pp), ctypes.byref(ss), ctypes.byref(n_thr))
+            t1 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                rc = L.oracle_write_image_all_cores(ctypes.byref(sub), h_src.ctypes.data, h_src.strides[0], ctypes.byref(pp), ctypes.byref(ss),
+                                                    ctypes.byref(n_thr))
+            dt = (time.perf_counter() - t1) / reps
+            if rc == 0:
+                out["cpu_baseline"]["all_cores"] = {
+                    "value": round(W * rows / dt / 1e6, 2), "unit": "Mpixels/s", "cores": int(n_thr.value),
+                    "host_logical_cpus": os.cpu_count(),
+                    "sample": f"OpenMP over 32-row blocks, {reps} passes over {rows} rows, {dt * 1e3:.0f} ms per pass "
+                              f"(courtesy figure: the reference is single-threaded)"}
         else:
             out["cpu_baseline"] = None
     if rank == 0:

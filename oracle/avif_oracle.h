@@ -58,6 +58,12 @@ int32_t oracle_read_rows(const avifgpu_read_desc* desc, int32_t row0, int32_t nr
                          const void* const src[4], const int64_t src_stride[4],
                          void* dst, int64_t dst_row_bytes);
 
+/* cpu_baseline.c: whole-image drivers with the reference's one-row-buffer structure / on all host cores (bench.py cpu_baseline) */
+int32_t oracle_write_image_row_callback(const avifgpu_write_desc* desc, const void* image, int64_t image_row_bytes,
+                                        void* const dst[4], const int64_t dst_stride[4]);
+int32_t oracle_write_image_all_cores(const avifgpu_write_desc* desc, const void* image, int64_t image_row_bytes,
+                                     void* const dst[4], const int64_t dst_stride[4], int32_t* threads_used);
+
 #ifdef __cplusplus
 }
 #endif

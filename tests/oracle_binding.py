@@ -18,7 +18,8 @@ def load() -> ctypes.CDLL:
     if _lib is not None:
         return _lib
     src = os.path.join(ORACLE_DIR, "avif_oracle.c")
-    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+    src2 = os.path.join(ORACLE_DIR, "cpu_baseline.c")
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(src), os.path.getmtime(src2)):
         subprocess.run(["make", "-C", ORACLE_DIR], check=True, stdout=subprocess.DEVNULL)
     L = ctypes.CDLL(LIB)
     f = c_float
@@ -50,5 +51,9 @@ def load() -> ctypes.CDLL:
     L.oracle_write_rows.argtypes = [c_void_p, c_int32, c_int32, c_void_p, c_int64, POINTER(P4), POINTER(S4)]
     L.oracle_read_rows.restype = c_int32
     L.oracle_read_rows.argtypes = [c_void_p, c_int32, c_int32, POINTER(P4), POINTER(S4), c_void_p, c_int64]
+    L.oracle_write_image_row_callback.restype = c_int32
+    L.oracle_write_image_row_callback.argtypes = [c_void_p, c_void_p, c_int64, POINTER(P4), POINTER(S4)]
+    L.oracle_write_image_all_cores.restype = c_int32
+    L.oracle_write_image_all_cores.argtypes = [c_void_p, c_void_p, c_int64, POINTER(P4), POINTER(S4), POINTER(c_int32)]
     _lib = L
     return L

@@ -1,0 +1,106 @@
+"""Tier-2 (float) bars earned against float64 truth, not only against the oracle.
+
+The oracle is the reference's formulas in float32 with glibc's powf/expf/logf; the kernels use v_log_f32 / v_exp_f32 and a
+cancellation-free rewrite of PQToLinear.  Comparing the two with each other says how far apart they are, not which one is
+wrong.  Here both are compared with the SAME formulas (ColorTransfer.cpp:69-190, the reference's float32 constants kept as
+they are, including its float-rounded exponents 1/m1, 1/m2 and multipliers) evaluated in float64:
+
+ * read direction (EOTF -> f32): the kernel's error against truth is bounded tightly (1e-5 relative for PQ, 2e-6 for HLG and
+   SMPTE 428) and, code by code, is no larger than the oracle's own error plus that epsilon -- the 1e-4 bar of
+   tests/test_gpu_read.py exists because the REFERENCE formula's float32 evaluation (c2 - c3*x cancels) is up to ~5e-5 off
+   the truth, not because the kernel is;
+ * write direction (OETF -> integer code, truncating): the exact-match rate is asserted per bit depth at the measured level
+   (>= 99.9 % at 10 bit, >= 99.6 % at 12 bit: the same relative error meets four times as many code boundaries), and every
+   mismatching sample is shown to sit within 6e-6 relative of a code boundary of the exact function -- a truncation artefact
+   of two correct evaluations, never a wrong value."""
+import numpy as np
+import pytest
+
+import harness
+
+pkg = harness.pkg
+pytestmark = pytest.mark.gpu
+
+f32 = np.float32
+M1, M2 = f32(2610.0) / f32(16384.0), f32(2523.0) / f32(4096.0) * f32(128.0)
+C1, C2, C3 = f32(3424.0) / f32(4096.0), f32(2413.0) / f32(4096.0) * f32(32.0), f32(2392.0) / f32(4096.0) * f32(32.0)
+HA, HB, HC = f32(0.17883277), f32(0.28466892), f32(0.55991073)
+
+
+def pq_to_linear64(v, peak):                      # ColorTransfer.cpp:94-117
+    v = v.astype(np.float64)
+    e2, e1 = float(f32(1.0) / M2), float(f32(1.0) / M1)
+    mult = float(f32(10000.0) / f32(peak))
+    x = np.power(v, e2)
+    t = np.maximum(x - float(C1), 0.0) / (float(C2) - float(C3) * x)
+    return np.where(v < 0, 0.0, np.power(t, e1) * mult)
+
+
+def hlg_to_linear64(v):                           # :166-190
+    v = v.astype(np.float64)
+    hi = (np.exp((v - float(HC)) / float(HA)) + float(HB)) / 12.0
+    lo = v * v * float(f32(1.0) / f32(3.0))
+    return np.where(v > 0.5, hi, lo)
+
+
+def smpte428_to_linear64(v):                      # :129-139
+    return np.power(v.astype(np.float64), float(f32(2.6))) * float(f32(52.37) / f32(48.0))
+
+
+def linear_to_pq64(x, peak):                      # :69-92
+    x = x.astype(np.float64)
+    mult = float(f32(peak) / f32(10000.0))
+    X = np.power(np.maximum(x, 0.0) * mult, float(M1))
+    return np.where(x < 0, 0.0, np.power((float(C1) + float(C2) * X) / (1.0 + float(C3) * X), float(M2)))
+
+
+@pytest.mark.parametrize("bits", [10, 12])
+@pytest.mark.parametrize("curve", ["pq80", "pq1000", "pq10000", "hlg", "smpte428"])
+def test_eotf_error_against_float64_truth(gpu, bits, curve):
+    n = 1 << bits
+    W = 256
+    codes = np.arange(n, dtype=np.uint16).reshape(n // W, W)
+    planes = {0: codes, 1: codes.copy(), 2: codes.copy()}
+    tc = {"pq": pkg.TC_PQ, "hl": pkg.TC_HLG, "sm": pkg.TC_SMPTE428}[curve[:2]]
+    peak = int(curve[2:]) if curve.startswith("pq") else 80
+    d = pkg.ReadDesc(width=W, height=n // W, colorspace=pkg.COLORSPACE_RGB, chroma=pkg.CHROMA_444, bit_depth=bits, depth=32,
+                     alpha_state=pkg.ALPHA_NONE, matrix_coefficients=pkg.MATRIX_RGB_GBR, color_primaries=pkg.PRIMARIES_BT2020,
+                     transfer_characteristics=tc, pq_peak_nits=peak)
+    got = harness.gpu_read(gpu, d, planes).reshape(-1, 3)[:, 0].astype(np.float64)
+    orc = harness.oracle_read(d, planes).reshape(-1, 3)[:, 0].astype(np.float64)
+    v = (np.arange(n, dtype=np.float32) / f32(n - 1))            # T_A[i] = (float)i / (float)max, ReadHeifImage.cpp:402-415
+    truth = {"pq": lambda: pq_to_linear64(v, peak), "hl": lambda: hlg_to_linear64(v), "sm": lambda: smpte428_to_linear64(v)}[curve[:2]]()
+    scale = np.maximum(np.abs(truth), 1e-300)
+    e_gpu, e_orc = np.abs(got - truth), np.abs(orc - truth)
+    eps_rel = 1e-5 if curve.startswith("pq") else 2e-6
+    print(f"EOTF {curve} {bits}-bit vs float64 truth: kernel max rel {np.max(e_gpu / scale):.2e}, oracle max rel {np.max(e_orc / scale):.2e}, "
+          f"kernel vs oracle {np.max(np.abs(got - orc) / np.maximum(np.abs(orc), 1e-300)):.2e}")
+    assert np.all(np.isfinite(got))
+    assert np.all(e_gpu <= eps_rel * np.abs(truth) + 1e-12), float(np.max(e_gpu / scale))          # the kernel's own error
+    assert np.all(e_gpu <= e_orc + eps_rel * np.abs(truth) + 1e-12)                               # never worse than the oracle + eps
+
+
+@pytest.mark.parametrize("bits,peak,min_exact", [(10, 80, 0.999), (10, 1000, 0.999), (10, 10000, 0.999),
+                                                 (12, 80, 0.996), (12, 1000, 0.996)])
+def test_pq_write_mismatches_are_code_boundary_cases(gpu, bits, peak, min_exact):
+    x = np.concatenate([np.linspace(0, 1, 400_000, dtype=np.float32),
+                        np.geomspace(1e-9, 12.5, 400_000).astype(np.float32),
+                        np.linspace(1, 130, 100_000, dtype=np.float32)])
+    n = (x.size // 3) * 3
+    src = x[:n].reshape(1, n)
+    d = pkg.WriteDesc(width=n // 3, height=1, depth=32, planes=3, bit_depth=bits, transfer=pkg.TRANSFER_PQ, peak_nits=peak,
+                      alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_REFERENCE)
+    want = harness.oracle_write(d, src)[0].reshape(-1).astype(np.int64)
+    got = harness.gpu_write(gpu, d, src)[0].reshape(-1).astype(np.int64)
+    maxv = (1 << bits) - 1
+    exact = float(np.mean(want == got))
+    print(f"PQ OETF {bits}-bit peak {peak}: exact {exact:.6f}, max |dcode| {int(np.max(np.abs(want - got)))}")
+    assert np.max(np.abs(want - got)) <= 1
+    assert exact >= min_exact, exact
+    bad = np.nonzero(want != got)[0]
+    truth = np.clip(linear_to_pq64(src.reshape(-1)[bad], peak) * maxv, 0, maxv)
+    boundary = np.maximum(want[bad], got[bad]).astype(np.float64)          # the integer that lies between the two evaluations
+    dist = np.abs(truth - boundary)
+    print(f"   {bad.size} mismatches; exact value at most {np.max(dist) if bad.size else 0:.2e} codes from the boundary "
+          f"({np.max(dist / np.maximum(truth, 1)) if bad.size else 0:.2e} relative)")
+    assert np.all(dist <= 6e-6 * truth + 1e-3)

@@ -1,6 +1,8 @@
 """GPU parity, write direction: libavifgpu.so (HIP kernels, through the C-ABI) vs the CPU oracle on the same seeded
 inputs.  Integer-source paths and the Clip curve are bit-exact (tier T1); paths through the PQ / HLG / SMPTE-428
-curves are held to |delta code| <= 1 with >= 99 % exact (tier T2: native v_log/v_exp vs glibc powf, then truncation)."""
+curves are held to |delta code| <= 1 with >= 99.7 % exact at 10 bit and >= 99 % at 12 bit on these few-thousand-sample cases
+(tier T2: native v_log/v_exp vs glibc powf, then truncation; the same relative error meets four times as many code boundaries
+at 12 bit).  The million-sample sweeps below and tests/test_gpu_t2_truth.py hold the measured rates: >= 99.9 % / >= 99.6 %."""
 import numpy as np
 import pytest
 
@@ -11,7 +13,7 @@ pkg = harness.pkg
 pytestmark = pytest.mark.gpu
 
 T2_MAX_CODE_DELTA = 1
-T2_MIN_EXACT = 0.99
+T2_MIN_EXACT = {10: 0.997, 12: 0.99}
 
 
 def _check(cid, kw, got, want):
@@ -19,7 +21,7 @@ def _check(cid, kw, got, want):
     if cases.is_float_tier_write(kw):
         assert st["max_abs"] <= T2_MAX_CODE_DELTA, (cid, st)
         if st["n"] >= 1000:
-            assert st["exact_frac"] >= T2_MIN_EXACT, (cid, st)
+            assert st["exact_frac"] >= T2_MIN_EXACT[kw["bit_depth"]], (cid, st)
     else:
         assert st["max_abs"] == 0, (cid, st)
     return st
@@ -89,7 +91,7 @@ def test_write_pq_code_boundaries(gpu):
         got = harness.gpu_write(gpu, d, src)
         st = harness.compare_write(d, want, got)
         print(f"PQ sweep bits={bits} peak={peak}: max|dcode|={st['max_abs']} exact={st['exact_frac']:.6f}")
-        assert st["max_abs"] <= 1 and st["exact_frac"] >= 0.995, st
+        assert st["max_abs"] <= 1 and st["exact_frac"] >= (0.999 if bits == 10 else 0.996), st
 
 
 def test_write_rejects_and_reports(gpu):

@@ -217,3 +217,29 @@ def test_read_error_paths():
     assert code(bit_depth=9) == pkg.readErr
     assert code(transfer_characteristics=pkg.TC_HLG, hlg_apply_ootf=1, color_primaries=pkg.PRIMARIES_SMPTE432) == pkg.readErr
     assert code(depth=8) == pkg.readErr
+
+
+@pytest.mark.parametrize("chroma,down", [(pkg.CHROMA_444, 0), (pkg.CHROMA_420, 0), (pkg.CHROMA_420, 1), (pkg.CHROMA_422, 0)])
+def test_cpu_baseline_structures_equal_whole_frame(oracle, chroma, down):
+    """bench.py's two extra cpu_baseline structures -- the reference's one-row-buffer loop (WriteHeifImage.cpp:1017-1035) and
+    the OpenMP all-cores run -- produce the planes of the plain whole-frame conversion, byte for byte."""
+    import ctypes
+    d = pkg.WriteDesc(width=131, height=77, depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_PQ, peak_nits=80,
+                      alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR, chroma=chroma, chroma_downsampling=down,
+                      matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020)
+    src = harness.make_write_source(d, seed=9)
+    want = harness.oracle_write(d, src, return_raw=True)
+    for which in ("row_callback", "all_cores"):
+        bufs = harness._alloc_write_out(d, d.height)
+        ptrs = pkg.planes4([bufs[i].ctypes.data if i in bufs else None for i in range(4)])
+        strides = pkg.strides4([bufs[i].strides[0] if i in bufs else 0 for i in range(4)])
+        if which == "row_callback":
+            rc = oracle.oracle_write_image_row_callback(ctypes.byref(d), src.ctypes.data, src.strides[0], ctypes.byref(ptrs), ctypes.byref(strides))
+        else:
+            n = ctypes.c_int32(0)
+            rc = oracle.oracle_write_image_all_cores(ctypes.byref(d), src.ctypes.data, src.strides[0], ctypes.byref(ptrs), ctypes.byref(strides),
+                                                     ctypes.byref(n))
+            assert n.value >= 1
+        assert rc == 0
+        for pl in want:
+            assert np.array_equal(bufs[pl], want[pl]), (which, pl)
