@@ -11,8 +11,10 @@ they are, including its float-rounded exponents 1/m1, 1/m2 and multipliers) eval
    the truth, not because the kernel is;
  * write direction (OETF -> integer code, truncating): the exact-match rate is asserted per bit depth at the measured level
    (>= 99.9 % at 10 bit, >= 99.6 % at 12 bit: the same relative error meets four times as many code boundaries), and every
-   mismatching sample is shown to sit within 6e-6 relative of a code boundary of the exact function -- a truncation artefact
-   of two correct evaluations, never a wrong value."""
+   mismatching sample is shown to sit within 2e-5 relative of a code boundary of the exact function.  2e-5 is the float32
+   evaluation noise of the reference formula itself: q = (c1 + c2 x) / (1 + c3 x) carries 2-3 roundings of 6e-8 and q^78.84
+   multiplies them by 78.84 (measured: up to 1.3e-5).  A mismatch is therefore a truncation artefact of two evaluations that
+   both sit inside the formula's own noise band around a code boundary -- never a wrong value."""
 import numpy as np
 import pytest
 
@@ -103,4 +105,4 @@ def test_pq_write_mismatches_are_code_boundary_cases(gpu, bits, peak, min_exact)
     dist = np.abs(truth - boundary)
     print(f"   {bad.size} mismatches; exact value at most {np.max(dist) if bad.size else 0:.2e} codes from the boundary "
           f"({np.max(dist / np.maximum(truth, 1)) if bad.size else 0:.2e} relative)")
-    assert np.all(dist <= 6e-6 * truth + 1e-3)
+    assert np.all(dist <= 2e-5 * truth + 1e-3)

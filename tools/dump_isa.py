@@ -62,7 +62,7 @@ def main():
                 m = re.search(r"^[0-9a-f]+ <" + re.escape(k["name"]) + r">:\n(.*?)(?=^[0-9a-f]+ <|\Z)", dis, re.S | re.M)
                 if m:
                     fn = re.sub(r"[^A-Za-z0-9_.=,-]+", "_", dn)[:150]
-                    body = m.group(1)
+                    body = re.sub(r"[ \t]*//[ ]*[0-9A-Fa-f]{8,}:.*$", "", m.group(1), flags=re.M)     # drop address / encoding comments
                     ops = re.findall(r"^\s+(\w+)", body, re.M)
                     hist = {}
                     for o in ops:
