@@ -150,6 +150,12 @@ AG_DEV uint32_t exact_rescale(uint32_t i, float src_max, float dst_max, int dst_
     return (uint32_t)v;
 }
 
+// BuildSixteenBitToEightBitLookup entry (WriteHeifImage.cpp:114-139): (int)(i / 32768f * 255f + 0.5f) for i in [0, 32768] is, for
+// EVERY i, the integer (i * 255 + 16384) >> 15 -- three integer ops instead of six float ones (tests/test_oracle_properties.py
+// checks all 32769 entries against the float expression; the 10- and 12-bit tables differ from their integer forms at 1 and 3
+// indices where float rounding lands the product exactly on .5, so those keep the float expression).
+AG_DEV uint32_t rescale16_to_8(uint32_t i) { return (i * 255u + 16384u) >> 15; }                    // i <= 32768
+
 // PremultiplyColor(uint, uint, max) / UnpremultiplyColor, reference PremultipliedAlpha.cpp:54-93.
 AG_DEV uint32_t exact_premultiply(uint32_t color, uint32_t alpha, float maxf)
 {

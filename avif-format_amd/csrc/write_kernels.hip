@@ -198,7 +198,7 @@ AG_DEV void icc16_tetrahedral(const uint16_t* __restrict__ clut, const uint32_t 
 // ---- stage A: one source pixel -> integer codes (reference WriteHeifImage.cpp inner loops) --------
 // s[] holds the PLANES raw samples (u8/u16 values, or f32 bit patterns).  q[0..NCOL-1] colour, q[3] alpha.
 // RESCALE8: an 8-bit document saved at 10/12 bit -- decided once per row by the caller where that pays (no alpha), else here.
-template <int DEPTH, int PLANES, int TRANSFER, int ICC = 0, int RESCALE8 = 2>   // 0 no, 1 yes, 2 decide per sample (p.maxv)
+template <int DEPTH, int PLANES, int TRANSFER, int ICC = 0, int RESCALE8 = 2, bool TO8 = false>   // RESCALE8: 0 no, 1 yes, 2 decide per sample (p.maxv); TO8: u8 planes
 AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t (&q)[4],
                     const int32_t* icc8_lds_s1 = nullptr, const uint8_t* icc8_lds_s2 = nullptr, const uint16_t* lut8 = nullptr,
                     const IccPowTable& powT = IccPowTable{ nullptr, nullptr })
@@ -263,7 +263,8 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
                 v[k] = (RESCALE8 == 1 || (RESCALE8 == 2 && p.maxv > 255)) ? (uint32_t)lut8[sx[k]] : sx[k];   // the reference's 256-entry LUT, :87-112
             } else {
                 const uint32_t i = sx[k] > 32768u ? 32768u : sx[k];  // reference reads past its LUT here
-                v[k] = exact_rescale(i, 32768.0f, p.maxf, p.maxv);                                   // :114-166
+                if constexpr (TO8) v[k] = rescale16_to_8(i);                                         // :114-139, exact integer form
+                else v[k] = exact_rescale(i, 32768.0f, p.maxf, p.maxv);                              // :141-166
             }
         }
         const uint32_t a = ALPHA ? v[PLANES - 1] : (uint32_t)p.maxv;
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
 #pragma unroll
                 for (int i = 0; i < PXT; ++i) {
                     uint32_t q[4] = { 0, 0, 0, 0 };        // gray fills [0] and [3] only
-                    stage_a<DEPTH, PLANES, TRANSFER, ICC, decltype(rescale8)::value>(p, s[i], q, icc8_s1, icc8_s2, lut8, powT);
+                    stage_a<DEPTH, PLANES, TRANSFER, ICC, decltype(rescale8)::value, !DST16>(p, s[i], q, icc8_s1, icc8_s2, lut8, powT);
                     if constexpr (!PACK) { qp[vr][i][0] = q[0]; qp[vr][i][1] = q[1]; qp[vr][i][2] = q[2]; qp[vr][i][3] = q[3]; }
                     else if constexpr (DST16) { qp[vr][i][0] = q[0] | (q[1] << 16); qp[vr][i][1] = q[2] | (q[3] << 16); }
                     else qp[vr][i][0] = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
@@ -925,7 +926,8 @@ __global__ __launch_bounds__(256) void write_int_ref_stream(const WriteParams p)
                     q[j] = (p.maxv > 255) ? (uint32_t)lut8[sv] : sv;
                 } else {
                     const uint32_t sv = (in[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-                    q[j] = exact_rescale(sv > 32768u ? 32768u : sv, 32768.0f, p.maxf, p.maxv);   // :114-166
+                    if constexpr (!DST16) q[j] = rescale16_to_8(sv > 32768u ? 32768u : sv);      // :114-139, exact integer form
+                    else q[j] = exact_rescale(sv > 32768u ? 32768u : sv, 32768.0f, p.maxf, p.maxv);   // :141-166
                 }
             }
             if constexpr (PLANES == 4) {

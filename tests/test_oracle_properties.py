@@ -26,6 +26,19 @@ def test_rescale_luts(oracle):
     assert lut8[0] == 0 and lut8[32768] == 255 and lut8[16384] == 128
 
 
+def test_sixteen_to_eight_lut_is_an_integer_expression(oracle):
+    """The kernels' rescale16_to_8: BuildSixteenBitToEightBitLookup (WriteHeifImage.cpp:114-139) == (i * 255 + 16384) >> 15 for all
+    32769 entries; the 10/12-bit tables are NOT their integer forms (1 and 3 entries differ), so the kernels keep the float path."""
+    lut = (ctypes.c_uint8 * 32769)()
+    oracle.oracle_build_lut_16_to_8(lut)
+    i = np.arange(32769, dtype=np.int64)
+    assert np.array_equal(np.frombuffer(lut, dtype=np.uint8), (i * 255 + 16384) >> 15)
+    for bits, nbad in ((10, 1), (12, 3)):
+        l16 = (ctypes.c_uint16 * 32769)()
+        oracle.oracle_build_lut_16_to_n(bits, l16)
+        assert int(np.sum(np.frombuffer(l16, dtype=np.uint16) != ((i * ((1 << bits) - 1) + 16384) >> 15))) == nbad
+
+
 def test_limited_to_full(oracle):
     # reference YuvLookupTables.cpp:69-109 ranges
     for depth, (ylo, yhi, clo, chi) in {8: (16, 235, 16, 240), 10: (64, 940, 64, 960), 12: (256, 3760, 256, 3840)}.items():

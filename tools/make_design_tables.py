@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""Regenerate the measured tables of DESIGN.md (between the BEGIN/END markers) from profiles/r01/bench_configs.jsonl and
-profiles/r01/configs_traffic.json, so the document cannot drift from the committed measurements."""
+"""Regenerate the measured tables of DESIGN.md (between the BEGIN/END markers) from profiles/r02/bench_configs.jsonl and
+profiles/r02/configs_traffic.json, so the document cannot drift from the committed measurements."""
 import json
 import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rows = [json.loads(l) for l in open(os.path.join(ROOT, "profiles/r01/bench_configs.jsonl")) if l.startswith("{")]
-traffic = {e["config"]: e for e in json.load(open(os.path.join(ROOT, "profiles/r01/configs_traffic.json")))}
+rows = [json.loads(l) for l in open(os.path.join(ROOT, "profiles/r02/bench_configs.jsonl")) if l.startswith("{")]
+traffic = {e["config"]: e for e in json.load(open(os.path.join(ROOT, "profiles/r02/configs_traffic.json")))}
 
 
 def table(pred):
