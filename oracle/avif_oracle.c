@@ -10,7 +10,9 @@
  *   * The reference's own translation units cannot be compiled in this image: every one of them
  *     includes <libheif/heif.h> and/or the Adobe Photoshop SDK headers (src/common/ColorTransfer.h:26,
  *     src/common/Common.h:32-35,50), neither of which exists here, and the build rules forbid
- *     writing stand-in headers.  So there is no oracle/_ref.
+ *     writing stand-in headers.  `make -C oracle _ref` builds oracle/_ref from the reference's own
+ *     sources wherever those headers DO exist (and prints "skipped" here); tests/test_ref_pin.py
+ *     then diffs this file against it on every case.  Until that has run: parity unpinned.
  *   * What this file IS checked against: the known-answer values recorded in SURVEY.md section 8(c)
  *     ("Starter known-answer values"), which the surveyor obtained from the reference's own code
  *     with glibc 2.35 powf.  tests/test_oracle_kat.py asserts every one of them, bit-for-bit where
@@ -18,8 +20,11 @@
  *     BT.2020 coefficients, one write pixel and two read pixels.
  *   * The RGB->YCbCr + chroma-subsample stage lives in libheif v1.14.0 (3rd-party/README.md:44), which
  *     is not vendored under /root/reference.  oracle_stage_b_* restate its published algorithm
- *     (libheif/color-conversion, Op_RGB_to_YCbCr: full-range Kr/Kb matrix on integer codes,
- *     `(long)(v + 0.5f)` rounding with clip, chroma offset 1 << (bits-1)); parity for that stage is
+ *     (libheif/heif_colorconversion.cc @ v1.14.0, Op_RGB24_32_to_YCbCr / Op_RRGGBBxx_HDR_to_YCbCr420 /
+ *     Op_RGB_to_YCbCr<>: full-range Kr/Kb matrix on integer codes, `(long)(v + 0.5f)` rounding with
+ *     clip, chroma offset 1 << (bits-1), chroma taken from the block's top-left pixel =
+ *     AVIFGPU_DOWNSAMPLE_NEAREST; the box average is the later libheif default, kept as an option);
+ *     DESIGN.md section 3.1.  Parity for that stage is
  *     anchored only by the round trip through the reference's own decoder equations
  *     (tests/test_oracle_properties.py::test_roundtrip_through_reference_decoder, tests/test_gpu_fullsize_roundtrip.py).  It is "parity unpinned".
  *
