@@ -68,7 +68,7 @@ AG_DEV double icc_pow_pos(const IccPowTable& T, double x, double g)          // 
     p = __builtin_fmaf(r, p, -0.7213475204444817f);
     p = __builtin_fmaf(r, p, 1.4426950408889634f);
     p = r * p;
-    const double t = g * ((double)e + T.L[idx] + (double)p);
+    const double t = g * ((double)e + (T.L[idx] + (double)p));
     const double n = __builtin_rint(t);
     const float f = (float)(t - n);
     const float v = __builtin_amdgcn_ldexpf(nat_exp2(f), (int)n);
@@ -87,6 +87,42 @@ AG_DEV void icc_pow_table_fill(double* L, float* c, int tid)
     }
 }
 
+// The parametric variants read up to 43 double parameters per pixel.  As kernel arguments they live in SGPRs, more than the
+// scalar file holds next to everything else: the compiler spills them to VGPR lanes and reads them back with v_readlane_b32
+// (~21 per pixel).  They are wave-uniform but nothing says they must sit in scalar registers: copied ONCE into ordinary VGPRs
+// (through an opaque v_mov so the optimiser does not "re-uniformise" them) every use is a plain VGPR operand.  86 VGPRs for the
+// sRGB-target variant; these kernels are VALU-bound, 4 waves per SIMD are enough.
+AG_DEV double icc_to_vgpr(double x)
+{
+    uint32_t lo = (uint32_t)__double2loint(x), hi = (uint32_t)__double2hiint(x), vlo, vhi;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vlo) : "s"(lo));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vhi) : "s"(hi));
+    return __hiloint2double((int)vhi, (int)vlo);
+}
+struct IccRegs {
+    double trc[3][8];            // normalised curves (kernel_params.h)
+    double m[9];
+    double out_p[8];             // ICC == 4 only
+    double out_rcp[2];
+};
+template <int ICC>
+AG_DEV void icc_regs_load(const WriteParams& p, IccRegs& r)
+{
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r.m[k] = icc_to_vgpr(p.icc_m[k]);
+    if constexpr (ICC == 2 || ICC == 4) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r.trc[c][k] = icc_to_vgpr(p.icc_trc[c][k]);
+    }
+    if constexpr (ICC == 4) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r.out_p[k] = icc_to_vgpr(p.icc_out_p[k]);
+        r.out_rcp[0] = icc_to_vgpr(p.icc_out_rcp[0]); r.out_rcp[1] = icc_to_vgpr(p.icc_out_rcp[1]);
+    }
+}
+
 // ---- ICC row transform (lcms2 float pipeline of a matrix/TRC profile pair, see include/avifgpu.h) --------------------
 // One lcms2 parametric curve (types 1..5, DefaultEvalParametricFn) evaluated in double, returned as the float the
 // curves stage hands to the matrix stage.
@@ -96,12 +132,14 @@ AG_DEV void icc_pow_table_fill(double* L, float* c, int tid)
 // per lane, so both sides are evaluated and selected: no divergent branch, ONE inlined pow per call site.
 AG_DEV float icc_trc(const IccPowTable& T, const double* Q, float in)
 {
+    // The library evaluates a*R + b, pow(...) + e and c*R + f as separately rounded double operations; fused here (differences of
+    // one double ulp, 2^-29 of the float this returns), and the two sides are rounded to float before the select.
     const double R = (double)in;
-    const double lin = Q[1] * R + Q[2];
+    const double lin = __builtin_fma(Q[1], R, Q[2]);
     const double pw = dpow(T, lin, Q[0]);
-    const double hi = lin > 0 ? pw + Q[6] : Q[7];
-    const double lo = Q[4] * R + Q[5];
-    return (float)(R >= Q[3] ? hi : lo);
+    const float hi = lin > 0 ? (float)(pw + Q[6]) : (float)Q[7];
+    const float lo = (float)__builtin_fma(Q[4], R, Q[5]);
+    return R >= Q[3] ? hi : lo;
 }
 
 // Inverse of lcms2's parametric type 4 (type -4, DefaultEvalParametricFn), the curve stage in front of an sRGB destination.
@@ -120,22 +158,21 @@ AG_DEV float icc_inv4(const IccPowTable& T, const double* P, const double* Q, fl
 // documents) -> matrix only, no call in the kernel.  ICC = 2: general parametric curves (double pow, out of line).
 // ICC = 4: as 2 (linear curves skipped at run time) plus the destination's inverse curve after the matrix (-> sRGB).
 template <int ICC>
-AG_DEV void icc_apply(const WriteParams& p, const IccPowTable& T, float (&c)[3])
+AG_DEV void icc_apply(const WriteParams& p, const IccRegs& q, const IccPowTable& T, float (&c)[3])
 {
     float t[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         if constexpr (ICC == 1) t[k] = c[k];
-        else t[k] = p.icc_trc_linear[k] ? c[k] : icc_trc(T, p.icc_trc[k], c[k]);     // pow(R, 1) == R exactly: gamma-1 channels skip the curve (wave-uniform)
+        else t[k] = p.icc_trc_linear[k] ? c[k] : icc_trc(T, q.trc[k], c[k]);     // pow(R, 1) == R exactly: gamma-1 channels skip the curve (wave-uniform)
     }
+    const double t0 = (double)t[0], t1 = (double)t[1], t2 = (double)t[2];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {                   // lcms2 matrix stage: double accumulation from 0, one rounding to float
-        double acc = 0.0;
-        acc += (double)t[0] * p.icc_m[3 * i + 0];
-        acc += (double)t[1] * p.icc_m[3 * i + 1];
-        acc += (double)t[2] * p.icc_m[3 * i + 2];
+    for (int i = 0; i < 3; ++i) {                   // lcms2 matrix stage: double accumulation, one rounding to float.  The library's
+                                                    // three mul + add pairs are fused (<= 1 double ulp apart: 2^-29 of the float result)
+        const double acc = __builtin_fma(t2, q.m[3 * i + 2], __builtin_fma(t1, q.m[3 * i + 1], t0 * q.m[3 * i + 0]));
         c[i] = (float)acc;
-        if constexpr (ICC == 4) c[i] = icc_inv4(T, p.icc_out_p, p.icc_out_rcp, c[i]);
+        if constexpr (ICC == 4) c[i] = icc_inv4(T, q.out_p, q.out_rcp, c[i]);
     }
 }
 
@@ -201,7 +238,7 @@ AG_DEV void icc16_tetrahedral(const uint16_t* __restrict__ clut, const uint32_t 
 template <int DEPTH, int PLANES, int TRANSFER, int ICC = 0, int RESCALE8 = 2, bool TO8 = false>   // RESCALE8: 0 no, 1 yes, 2 decide per sample (p.maxv); TO8: u8 planes
 AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t (&q)[4],
                     const int32_t* icc8_lds_s1 = nullptr, const uint8_t* icc8_lds_s2 = nullptr, const uint16_t* lut8 = nullptr,
-                    const IccPowTable& powT = IccPowTable{ nullptr, nullptr })
+                    const IccPowTable& powT = IccPowTable{ nullptr, nullptr }, const IccRegs* iccRegs = nullptr)
 {
     constexpr bool COLOR = PLANES >= 3;
     constexpr bool ALPHA = (PLANES == 2 || PLANES == 4);
@@ -211,7 +248,7 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
         float col[NCOL];
 #pragma unroll
         for (int k = 0; k < NCOL; ++k) col[k] = __uint_as_float(s[k]);
-        if constexpr (ICC != 0 && COLOR) icc_apply<ICC>(p, powT, col);                  // ConvertRow runs before the pixel loop: WriteHeifImage.cpp:1031-1034
+        if constexpr (ICC != 0 && COLOR) icc_apply<ICC>(p, *iccRegs, powT, col);                  // ConvertRow runs before the pixel loop: WriteHeifImage.cpp:1031-1034
         float a = 1.0f;
         if constexpr (ALPHA) {
             a = cxx_clamp(__uint_as_float(s[PLANES - 1]), 0.0f, 1.0f);          // :558, :1047
@@ -303,15 +340,18 @@ enum { kOutRefColor = 0, kOutRefGray = 1, kOutYcbcr = 2 };
 #define AG_W8_NC_ALPHA 4
 #endif
 // chroma samples per lane: 4 for u16 planes, AG_W8_NC for u8 planes (every plane store >= 8 / 4 bytes per lane)
-template <bool DST16, int PLANES, int XS> struct WriteShape {
-    static constexpr int NC = DST16 ? 4 : ((PLANES == 2 || PLANES == 4) ? AG_W8_NC_ALPHA : AG_W8_NC);
+// The parametric ICC variants (2, 4) carry ~300 instructions and up to 86 parameter VGPRs per pixel stream: with sub-sampled chroma
+// 2 chroma samples per lane keep a 4:2:0 footprint at 8 pixels (16: 197 VGPRs, 2 waves/SIMD, 6.9 k instructions; measured
+// 0.412 -> 0.370 ms).  4:4:4 keeps 4 pixels per lane (2 measured slower: 0.487 -> 0.507 ms, narrower loads and stores).
+template <bool DST16, int PLANES, int XS, int ICC = 0> struct WriteShape {
+    static constexpr int NC = ((ICC == 2 || ICC == 4) && XS == 1) ? 2 : (DST16 ? 4 : ((PLANES == 2 || PLANES == 4) ? AG_W8_NC_ALPHA : AG_W8_NC));
     static constexpr int PXT = NC << XS;
 };
 
 template <int DEPTH, int PLANES, int OUT, bool DST16, int XS, int YS, int TRANSFER, bool ALIGNED, int ICC = 0>
 __global__ __launch_bounds__(256) void write_px(const WriteParams p)
 {
-    constexpr int PXT = WriteShape<DST16, PLANES, XS>::PXT;
+    constexpr int PXT = WriteShape<DST16, PLANES, XS, ICC>::PXT;
     constexpr int VR = 1 << YS;
     constexpr int BPP = PLANES * DEPTH / 8;
     constexpr int ND = PXT * BPP / 4;             // dwords per thread per row
@@ -345,6 +385,8 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
     __shared__ float icc_pow_c[ICCPOW ? kIccPowBins : 1];
     if constexpr (ICCPOW) { icc_pow_table_fill(icc_pow_L, icc_pow_c, threadIdx.x); __syncthreads(); }
     const IccPowTable powT = { icc_pow_L, icc_pow_c };
+    IccRegs iccRegs;
+    if constexpr (DEPTH == 32 && (ICC == 1 || ICC == 2 || ICC == 4)) icc_regs_load<ICC>(p, iccRegs);
 
     // 8-bit documents saved at 10/12 bit: the reference's 256-entry rescale LUT (WriteHeifImage.cpp:87-112), rebuilt per
     // workgroup with the same IEEE expression -- one ds_read per sample instead of a division sequence in the pixel loop
@@ -427,7 +469,7 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
 #pragma unroll
                 for (int i = 0; i < PXT; ++i) {
                     uint32_t q[4] = { 0, 0, 0, 0 };        // gray fills [0] and [3] only
-                    stage_a<DEPTH, PLANES, TRANSFER, ICC, decltype(rescale8)::value, !DST16>(p, s[i], q, icc8_s1, icc8_s2, lut8, powT);
+                    stage_a<DEPTH, PLANES, TRANSFER, ICC, decltype(rescale8)::value, !DST16>(p, s[i], q, icc8_s1, icc8_s2, lut8, powT, &iccRegs);
                     if constexpr (!PACK) { qp[vr][i][0] = q[0]; qp[vr][i][1] = q[1]; qp[vr][i][2] = q[2]; qp[vr][i][3] = q[3]; }
                     else if constexpr (DST16) { qp[vr][i][0] = q[0] | (q[1] << 16); qp[vr][i][1] = q[2] | (q[3] << 16); }
                     else qp[vr][i][0] = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
@@ -980,8 +1022,16 @@ template <int DEPTH, int PLANES, int OUT, bool DST16, int XS, int YS, int TRANSF
 static hipError_t launch_one(const WriteParams& p, hipStream_t st, char* label)
 {
     constexpr int PXT = WriteShape<DST16, PLANES, XS>::PXT;
-    const long long groups = (long long)((p.width + PXT - 1) / PXT) * ((p.nrows + (1 << YS) - 1) >> YS);
+    long long groups = (long long)((p.width + PXT - 1) / PXT) * ((p.nrows + (1 << YS) - 1) >> YS);
     if (groups == 0) return hipSuccess;
+    if constexpr (DEPTH == 32 && PLANES >= 3) {
+        bool linear = true;
+        for (int c = 0; c < 3; ++c) linear = linear && p.icc_trc_linear[c] != 0;
+        if (p.icc_trc_type[0] != 0 && (p.icc_out == 4 || !linear)) {      // variants 2 and 4 use a smaller footprint
+            constexpr int PXT2 = WriteShape<DST16, PLANES, XS, 2>::PXT;
+            groups = (long long)((p.width + PXT2 - 1) / PXT2) * ((p.nrows + (1 << YS) - 1) >> YS);
+        }
+    }
     if (groups >= 0x7fffffffLL - 256LL * 65536) return hipErrorInvalidValue;   // 32-bit group index in the kernel
     // every pointer and stride a multiple of 16 => the branch-free vector path
     uintptr_t bits = reinterpret_cast<uintptr_t>(p.src) | (uintptr_t)p.src_row_bytes;
