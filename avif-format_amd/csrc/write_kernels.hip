@@ -570,8 +570,8 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
 //            wave's own in-order DS queue (lgkmcnt) is the only ordering needed.
 //   matrix : 3x3 on exact integer codes, libheif rounding; plane stores are PXL*2 = 8 or 16 B per lane,
 //            contiguous across the wave, non-temporal.
-//   tail   : any width that is a multiple of 4 (rows stay 16-byte aligned): the last span of a row is masked -- float4s
-//            beyond the row load as zero, a lane stores 16 B, 8 B (4 pixels: widths are multiples of 4) or nothing.
+//   tail   : any width that is a multiple of 4 (rows stay 16-byte aligned): the last span of a row is masked -- loads beyond
+//            the row are clamped to its last float4, a lane stores 16 B, 8 B (4 pixels: widths are multiples of 4) or nothing.
 // Variants measured and dropped in round 1 (profiles/r01/hot_variant_sweep*.txt): register prefetch of the next span
 // (-5...-25 %: occupancy) and XCD-contiguous span mapping (+-1 %: nothing is shared between spans).
 typedef float    f32x4 __attribute__((ext_vector_type(4)));
@@ -611,12 +611,11 @@ __global__ __launch_bounds__(256) void write_rgb32_ycbcr444_hot(const WriteParam
         const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);             // < SPAN_PX only for the last span of a row
         const int span_f4 = span_px * 3 / 4;
         const f32x4* sp = reinterpret_cast<const f32x4*>(p.src + (long long)r * p.src_row_bytes) + (long long)sx * (64 * K);
+        // Branch-free masking: a lane whose float4 lies beyond the row re-reads the row's last float4 (a valid address); whatever it
+        // computes lands in strip positions that only lanes beyond the row read back, and those store nothing.
         f32x4 cur[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            cur[k] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-            if (64 * k + lane < span_f4) cur[k] = stream_load<NT>(sp + 64 * k + lane);
-        }
+        for (int k = 0; k < K; ++k) cur[k] = stream_load<NT>(sp + min(64 * k + lane, span_f4 - 1));
 
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -720,10 +719,7 @@ __global__ __launch_bounds__(256) void write_rgb32_ycbcr_sub_hot(const WritePara
             const int r = min((int)(gy * VR) + vr, p.rows_to_end - 1);  // bottom edge: replicate the last IMAGE row
             const f32x4* sp = reinterpret_cast<const f32x4*>(p.src + (long long)r * p.src_row_bytes) + (long long)sx * (64 * K);
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                v[vr][k] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-                if (64 * k + lane < span_f4) v[vr][k] = stream_load<true>(sp + 64 * k + lane);
-            }
+            for (int k = 0; k < K; ++k) v[vr][k] = stream_load<true>(sp + min(64 * k + lane, span_f4 - 1));   // branch-free mask, as in the 4:4:4 kernel
         }
 #pragma unroll
         for (int vr = 0; vr < VR; ++vr) {
@@ -820,10 +816,7 @@ __global__ __launch_bounds__(256) void write_rgba32_ycbcra444_hot(const WritePar
         const f32x4* sp = reinterpret_cast<const f32x4*>(p.src + (long long)r * p.src_row_bytes) + (long long)sx * SPAN_PX;
         f32x4 v[PXL];
 #pragma unroll
-        for (int k = 0; k < PXL; ++k) {
-            v[k] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-            if (64 * k + lane < span_px) v[k] = stream_load<true>(sp + 64 * k + lane);
-        }
+        for (int k = 0; k < PXL; ++k) v[k] = stream_load<true>(sp + min(64 * k + lane, span_px - 1));       // branch-free mask: see the RGB kernel
 #pragma unroll
         for (int k = 0; k < PXL; ++k) {
             float col[3] = { v[k].x, v[k].y, v[k].z };
