@@ -20,6 +20,14 @@ AG_DEV float nat_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f
 AG_DEV float nat_rcp(float x)  { return __builtin_amdgcn_rcpf(x); }   // v_rcp_f32
 AG_DEV float nat_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }  // v_sqrt_f32
 
+// max(v, 0) in ONE instruction: fmaxf() costs two (clang quiets a possible signalling NaN with a v_max_f32 v, v first).  On the
+// bit pattern instead: every float with the sign bit set -- negative values, -0, -inf, negative NaNs -- is a negative integer and
+// becomes +0; non-negative floats are unchanged.  A positive NaN passes through, is quieted by the v_log_f32 / v_sqrt_f32 that
+// follows, propagates, and ends as code 0 in the final v_med3_f32 + v_cvt_u32_f32 -- the "NaN -> 0" of DESIGN.md section 3.1 for
+// quiet and signalling patterns alike (tests/test_gpu_extremes.py; v_med3_f32 itself turned out to map a signalling NaN to its
+// upper bound, which is why this is not a med3).
+AG_DEV float max0(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
+
 // x^e for x >= 0 (x == 0 -> 0 for e > 0; log2(0) = -inf, exp2(-inf) = 0).
 AG_DEV float fast_pow(float x, float e) { return nat_exp2(e * nat_log2(x)); }
 
@@ -63,7 +71,7 @@ AG_DEV float near_ieee_div(float n, float d)
 //   log2_mult_m1 = m1 * log2(mult),  log2_max = log2(maxValue).  Returns pq * maxValue (unclamped).
 AG_DEV float fast_linear_to_pq_scaled(float value, float log2_mult_m1, float log2_max)
 {
-    const float l = nat_log2(fmaxf(value, 0.0f));
+    const float l = nat_log2(max0(value));
     const float x = nat_exp2(__builtin_fmaf(kPqM1, l, log2_mult_m1));
     const float n = kPqC1 + kPqC2 * x;                   // -ffp-contract=off: v_mul_f32 + v_add_f32, as the reference
     const float d = 1.0f + kPqC3 * x;
@@ -106,7 +114,7 @@ AG_DEV float fast_pq_to_linear(float value, float mult) { return fast_pq_to_line
 // LinearToSMPTE428 / SMPTE428ToLinear, reference ColorTransfer.cpp:119-139.
 AG_DEV float fast_linear_to_smpte428(float value)
 {
-    const float t = fmaxf(value * 48.0f, 0.0f) * (1.0f / 52.37f);
+    const float t = max0(value * 48.0f) * (1.0f / 52.37f);
     return fast_pow(t, 1.0f / 2.6f);
 }
 AG_DEV float fast_smpte428_to_linear(float value)
@@ -123,7 +131,7 @@ constexpr float kLn2 = 0.6931471805599453f, kLog2e = 1.4426950408889634f;
 AG_DEV float fast_linear_to_hlg(float value)
 {
     const float hi = __builtin_fmaf(kHlgA * kLn2, nat_log2(fmaxf(value * 12.0f - kHlgB, 1e-30f)), kHlgC);
-    const float lo = nat_sqrt(fmaxf(value, 0.0f) * 3.0f);
+    const float lo = nat_sqrt(max0(value) * 3.0f);
     const float r = value > (1.0f / 12.0f) ? hi : lo;
     return value >= 0.0f ? r : 0.0f;                          // negative and NaN -> 0
 }

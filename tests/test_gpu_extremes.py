@@ -40,3 +40,33 @@ def test_read_extreme_shapes(gpu, w, h):
         want = harness.oracle_read(d, planes)
         got = harness.gpu_read(gpu, d, planes, mem="device")
         assert np.array_equal(got, want), (w, h, kw)
+
+
+@pytest.mark.parametrize("transfer", [pkg.TRANSFER_PQ, pkg.TRANSFER_HLG, pkg.TRANSFER_SMPTE428, pkg.TRANSFER_CLIP])
+@pytest.mark.parametrize("width,output", [(512, pkg.OUT_YCBCR), (67, pkg.OUT_YCBCR), (512, pkg.OUT_REFERENCE)])
+def test_non_finite_samples_stay_in_range(gpu, transfer, width, output):
+    """NaN and +-Inf samples are outside the parity contract (the reference casts NaN to uint16_t: undefined behaviour,
+    WriteHeifImage.cpp:1093).  What the library guarantees instead: no crash, every code inside [0, max], NaN (quiet or
+    signalling) and -Inf -> 0, +Inf -> 0 or the maximum code (inf/inf inside the PQ curve is a NaN, the other curves saturate),
+    and finite neighbours unaffected (streaming and generic kernels alike)."""
+    d = pkg.WriteDesc(width=width, height=4, depth=32, planes=3, bit_depth=10, transfer=transfer, peak_nits=80,
+                      alpha_state=pkg.ALPHA_NONE, output=output, chroma=pkg.CHROMA_444, matrix_coefficients=pkg.MATRIX_RGB_GBR)
+    src = harness.make_write_source(d, seed=1)
+    clean = harness.gpu_write(gpu, d, src)
+    bad = src.copy().reshape(4, width, 3)
+    bad[0, 5, :] = np.nan
+    bad[1, 6, :] = np.inf
+    bad[2, 7, :] = -np.inf
+    bad[3, 8, 1] = np.array([0x7fa00000], dtype=np.uint32).view(np.float32)[0]          # a signalling NaN bit pattern
+    got = harness.gpu_write(gpu, d, bad.reshape(4, -1))
+    if output == pkg.OUT_YCBCR:                                # identity matrix: Y <- G, Cb <- B, Cr <- R, so planes are the codes
+        g = np.stack([got[2], got[0], got[1]], axis=-1)        # back to R, G, B order
+        c = np.stack([clean[2], clean[0], clean[1]], axis=-1)
+    else:
+        g, c = got[0].reshape(4, width, 3), clean[0].reshape(4, width, 3)
+    assert g.max() <= 1023
+    assert np.all(g[0, 5] == 0) and np.all(g[2, 7] == 0) and g[3, 8, 1] == 0
+    assert np.all((g[1, 6] == 1023) | (g[1, 6] == 0))
+    mask = np.ones((4, width), bool)
+    mask[0, 5] = mask[1, 6] = mask[2, 7] = mask[3, 8] = False
+    assert np.array_equal(g[mask], c[mask])
