@@ -170,14 +170,19 @@ int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p)
 {
     if (t->grid_points != AVIFGPU_ICC_CLUT_GRID) return fail(AVIFGPU_formatBadParameters, "16-bit ICC table: grid_points must be 33");
     const size_t n = sizeof(t->table);
+    // one plane + one row + one node of zero padding behind the table: the kernel steps past the last node of an axis whose
+    // input is 0xffff (with weight 0, see icc16_tetrahedral)
+    constexpr size_t G = AVIFGPU_ICC_CLUT_GRID;
+    const size_t pad = (G * G + G + 1) * sizeof(t->table[0]);
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return hip_fail(e, "hipGetDevice", AVIFGPU_writErr);
     std::lock_guard<std::mutex> lk(g_icc_mu);
     IccDeviceTables& c = g_icc_tables[dev];
     if (!c.icc16) {
-        e = hipMalloc(&c.icc16, n);
-        if (e != hipSuccess) { c.icc16 = nullptr; return hip_fail(e, "hipMalloc(icc16 table)", AVIFGPU_memFullErr); }
+        e = hipMalloc(&c.icc16, n + pad);
+        if (e == hipSuccess) e = hipMemset(static_cast<uint8_t*>(c.icc16) + n, 0, pad);
+        if (e != hipSuccess) { if (c.icc16) (void)hipFree(c.icc16); c.icc16 = nullptr; return hip_fail(e, "hipMalloc(icc16 table)", AVIFGPU_memFullErr); }
     }
     if (c.icc16_host.size() != n || memcmp(c.icc16_host.data(), t->table, n) != 0) {
         e = hipDeviceSynchronize();                             // a launch may still be reading the previous table

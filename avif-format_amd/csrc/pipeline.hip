@@ -466,7 +466,7 @@ int contexts_init(const int32_t* devices, int count)
     auto* v = new std::vector<Ctx*>();
     const int nslots = env_int("AVIFGPU_SLOTS", 4, 2, kMaxSlots);
     // Lanes: contexts per bound device.  One worker keeps one copy queue per direction busy; a second lane on the same device
-    // overlaps its submissions with the first one's (measured: see profiles/r02/pcie_pipeline.jsonl).
+    // overlaps its submissions with the first one's (measured: see profiles/r02/pcie_host_pointer_path.jsonl).
     const int lanes = env_int("AVIFGPU_LANES", kDefaultLanes, 1, 4);
     g_trace = env_int("AVIFGPU_TRACE", 0, 0, 1) != 0;
     int rc = 0;

@@ -199,15 +199,16 @@ AG_DEV void icc16_tetrahedral(const uint16_t* __restrict__ clut, const uint32_t 
     uint32_t c0i[3], r[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const int a = (int)in[k] * (G - 1);
-        const int b = a + 0x7fff;
-        const int f = a + ((b + (b >> 16) + 1) >> 16);      // == a + b / 0xffff for every 16-bit input (checked exhaustively)
-        c0i[k] = (uint32_t)f >> 16;
-        r[k] = (uint32_t)f & 0xffffu;
+        // _cmsToFixedDomain(in * 32) = a + (a + 0x7fff) / 0xffff with a = 32 * in; for every 16-bit input the quotient equals
+        // (in + 1024) >> 11 (tests/test_icc16.py checks all 65536 values): shift, add, shift-add instead of six operations
+        const uint32_t f = (in[k] << 5) + ((in[k] + 1024u) >> 11);
+        c0i[k] = f >> 16;
+        r[k] = f & 0xffffu;
     }
-    const uint32_t s0 = in[0] == 0xffffu ? 0u : (uint32_t)(G * G);   // node index strides (table is [r][g][b][4])
-    const uint32_t s1 = in[1] == 0xffffu ? 0u : (uint32_t)G;
-    const uint32_t s2 = in[2] == 0xffffu ? 0u : 1u;
+    // Node index strides (table is [r][g][b][4]).  The library zeroes the stride of an axis whose input is 0xffff (cell index 32,
+    // the last node); its fraction is then 0, so whatever node the full stride reaches is multiplied by 0 -- the device copy of the
+    // table is padded by one plane + one row + one node of zeros (upload_icc16) and the three compare/select pairs disappear.
+    constexpr uint32_t s0 = (uint32_t)(G * G), s1 = (uint32_t)G, s2 = 1u;
     const uint32_t base = (c0i[0] * G + c0i[1]) * G + c0i[2];
     const uint32_t mx = max(max(r[0], r[1]), r[2]), mn = min(min(r[0], r[1]), r[2]);
     const uint32_t md = r[0] + r[1] + r[2] - mx - mn;

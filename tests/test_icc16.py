@@ -119,6 +119,9 @@ def test_range_maps_equal_the_float_expressions():
     want = np.clip((((j / np.float32(65535.0)) * np.float32(32768.0)) + np.float32(0.5)).astype(np.int32), 0, 32768)
     jj = np.arange(65536)
     assert np.array_equal(want, (jj + 1 + (jj >= 65408)) >> 1)             # icc16_lcms_to_host
+    # _cmsToFixedDomain(32 * in) = a + (a + 0x7fff) / 0xffff: the quotient is (in + 1024) >> 11 for every 16-bit input
+    a = jj * 32
+    assert np.array_equal(a + (a + 0x7fff) // 0xffff, a + ((jj + 1024) >> 11))
 
 
 def _gpu(gpu, d, src, icc16):
