@@ -12,6 +12,7 @@
 #include "OSErrException.h"
 #include "Utilities.h"
 
+#include <new>
 #include <stdexcept>
 
 #include "avifgpu_host.h"

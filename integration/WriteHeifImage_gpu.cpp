@@ -22,6 +22,7 @@
 #include "Utilities.h"
 
 #include <memory>
+#include <new>
 #include <stdexcept>
 
 #include "avifgpu_host.h"

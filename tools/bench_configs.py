@@ -125,6 +125,7 @@ if __name__ == "__main__":
     bench_write("C2 4096^2 RGB8 -> 8-bit 4:2:0 BT.709", width=4096, height=4096, depth=8, planes=3, bit_depth=8, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=P.MATRIX_BT709)
     bench_write("C2' 8192^2 RGB8 -> 8-bit 4:2:0 BT.709", width=8192, height=8192, depth=8, planes=3, bit_depth=8, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=P.MATRIX_BT709)
     bench_write("W8 8192^2 RGBA8 -> 8-bit 4:2:0 BT.601 + alpha", width=8192, height=8192, depth=8, planes=4, bit_depth=8, alpha_state=1, output=1, chroma=P.CHROMA_420, matrix_coefficients=6)
+    bench_write("W8 8192^2 RGB8 -> 8-bit 4:2:2 BT.601 nearest (the plug-in's default save: 8-bit, 4:2:2, AvifFormat.cpp:89)", width=8192, height=8192, depth=8, planes=3, bit_depth=8, alpha_state=0, output=1, chroma=P.CHROMA_422, matrix_coefficients=6, chroma_downsampling=P.DOWNSAMPLE_NEAREST)
     bench_write("W8 8192^2 RGB8 -> 8-bit 4:4:4 BT.601", width=8192, height=8192, depth=8, planes=3, bit_depth=8, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=6)
     bench_write("W8 8192^2 RGB8 -> 10-bit 4:2:0 BT.601", width=8192, height=8192, depth=8, planes=3, bit_depth=10, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=6)
     bench_write("W16 8192^2 RGBA16 premult -> 8-bit 4:2:0 BT.601 + alpha", width=8192, height=8192, depth=16, planes=4, bit_depth=8, alpha_state=2, output=1, chroma=P.CHROMA_420, matrix_coefficients=6)
@@ -176,6 +177,7 @@ if __name__ == "__main__":
         bench_write("16-bit doc + ICC, photograph-like input (smooth + noise) 8192^2 RGB16 -> 12-bit 4:4:4", icc=gpu.icc_prepare_clut16(buf.raw[:n]), smooth=True, width=8192, height=8192, depth=16, planes=3, bit_depth=12, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=6, color_primaries=1)
         bench_write("8-bit doc + ICC (AdobeRGB -> sRGB, matrix-shaper) 8192^2 RGB8 -> 8-bit 4:2:0", icc=gpu.icc_prepare_shaper8(buf.raw[:n]), width=8192, height=8192, depth=8, planes=3, bit_depth=8, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=6, color_primaries=1)
     bench_read("R8 8192^2 8-bit 4:2:0 BT.709 -> RGB8", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_420, bit_depth=8, depth=8, alpha_state=0, matrix_coefficients=1)
+    bench_read("R8 8192^2 8-bit 4:2:2 BT.601 -> RGB8 (what the default save decodes to)", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_422, bit_depth=8, depth=8, alpha_state=0, matrix_coefficients=6)
     bench_read("R8 8192^2 8-bit 4:4:4 BT.601 -> RGB8", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_444, bit_depth=8, depth=8, alpha_state=0, matrix_coefficients=6)
     bench_read("R8 8192^2 8-bit 4:2:0 BT.601 + alpha -> RGBA8", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_420, bit_depth=8, depth=8, alpha_state=1, matrix_coefficients=6)
     bench_read("R8 8192^2 8-bit mono -> Gray8", width=8192, height=8192, colorspace=2, chroma=P.CHROMA_MONOCHROME, bit_depth=8, depth=8, alpha_state=0)
