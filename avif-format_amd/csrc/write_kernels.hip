@@ -575,6 +575,14 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
 //            the row are clamped to its last float4, a lane stores 16 B, 8 B (4 pixels: widths are multiples of 4) or nothing.
 // Variants measured and dropped in round 1 (profiles/r01/hot_variant_sweep*.txt): register prefetch of the next span
 // (-5...-25 %: occupancy) and XCD-contiguous span mapping (+-1 %: nothing is shared between spans).
+// Workgroup size of the streaming kernels.  Their waves share nothing (private LDS strips, no barrier), so the workgroup is only a
+// scheduling unit -- and a small one fills the CUs more evenly: C4 8192^2 0.2015 ms with 256 threads, 0.1940 with 128, 0.1936 with
+// 64, 0.2015 / 0.2007 with 512 / 1024 (two runs each, profiles/r02/stream_block_size.txt).  128 halves the number of dispatches of 64.
+#ifndef AG_STREAM_BLOCK
+#define AG_STREAM_BLOCK 128
+#endif
+constexpr int kStreamWaves = AG_STREAM_BLOCK / 64;
+
 typedef float    f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -589,13 +597,14 @@ template <bool NT, typename V> AG_DEV void stream_store(V* p, V v)
 }
 
 template <int TRANSFER, int PXL, bool NT>
-__global__ __launch_bounds__(256) void write_rgb32_ycbcr444_hot(const WriteParams p)
+__global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_ycbcr444_hot(const WriteParams p)
 {
+    constexpr int WPB = kStreamWaves;
     constexpr int K = 3 * PXL / 4;               // float4 per lane per span
     constexpr int SPAN_PX = 64 * PXL;
     constexpr int SPAN_DW = SPAN_PX * 3 / 2;     // packed u16 codes
     constexpr int LDW = 3 * PXL / 2;             // packed dwords per lane after the transpose
-    __shared__ __attribute__((aligned(16))) uint32_t strip[4][SPAN_DW];
+    __shared__ __attribute__((aligned(16))) uint32_t strip[WPB][SPAN_DW];
 
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -604,9 +613,9 @@ __global__ __launch_bounds__(256) void write_rgb32_ycbcr444_hot(const WriteParam
     // span indices fit 32 bits (host checks): 32-bit udiv instead of a 64-bit software divide per trip
     const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;      // host guarantees width % 4 == 0 and alignment
     const uint32_t total = spans_per_row * (uint32_t)p.nrows;
-    const uint32_t step = gridDim.x * 4;
+    const uint32_t step = gridDim.x * WPB;
 
-    for (uint32_t sidx = blockIdx.x * 4 + wave; sidx < total; sidx += step) {
+    for (uint32_t sidx = blockIdx.x * WPB + wave; sidx < total; sidx += step) {
         const uint32_t r = sidx / spans_per_row;
         const uint32_t sx = sidx - r * spans_per_row;
         const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);             // < SPAN_PX only for the last span of a row
@@ -696,11 +705,11 @@ __global__ __launch_bounds__(256) void write_rgb32_ycbcr444_hot(const WriteParam
 // (same operand order as write_px / the oracle) needs no cross-lane traffic.  Stores: 16 B/lane per luma row, 8 B/lane per chroma
 // plane, contiguous across the wave, non-temporal.
 template <int TRANSFER, int XS, int YS>
-__global__ __launch_bounds__(256) void write_rgb32_ycbcr_sub_hot(const WriteParams p)
+__global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot(const WriteParams p)
 {
     static_assert(XS == 1, "4:2:2 or 4:2:0");
     constexpr int PXL = 8, K = 6, SPAN_PX = 512, SPAN_DW = SPAN_PX * 3 / 2, LDW = 12, VR = 1 << YS;
-    __shared__ __attribute__((aligned(16))) uint32_t strip[4][SPAN_DW];
+    __shared__ __attribute__((aligned(16))) uint32_t strip[kStreamWaves][SPAN_DW];
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     uint32_t* my = strip[wave];
@@ -708,7 +717,7 @@ __global__ __launch_bounds__(256) void write_rgb32_ycbcr_sub_hot(const WritePara
     const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;    // host guarantees width % 4 == 0 and alignment
     const uint32_t groups = ((uint32_t)p.nrows + VR - 1) >> YS;
     const uint32_t total = spans_per_row * groups;
-    for (uint32_t sidx = blockIdx.x * 4 + wave; sidx < total; sidx += gridDim.x * 4) {
+    for (uint32_t sidx = blockIdx.x * kStreamWaves + wave; sidx < total; sidx += gridDim.x * kStreamWaves) {
         const uint32_t gy = sidx / spans_per_row;
         const uint32_t sx = sidx - gy * spans_per_row;
         uint32_t dw[VR][LDW];
@@ -799,18 +808,18 @@ __global__ __launch_bounds__(256) void write_rgb32_ycbcr_sub_hot(const WritePara
 #define AG_RGBA_HOT_PXL 4
 #endif
 template <int TRANSFER>
-__global__ __launch_bounds__(256) void write_rgba32_ycbcra444_hot(const WriteParams p)
+__global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba32_ycbcra444_hot(const WriteParams p)
 {
     constexpr int PXL = AG_RGBA_HOT_PXL, SPAN_PX = 64 * PXL;
     constexpr int LSTRIDE = PXL == 4 ? 12 : 20;                        // dwords per lane in the strip (2 * PXL used + 4 pad)
-    __shared__ __attribute__((aligned(16))) uint32_t strip[4][64 * LSTRIDE];
+    __shared__ __attribute__((aligned(16))) uint32_t strip[kStreamWaves][64 * LSTRIDE];
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     uint32_t* my = strip[wave];
 
     const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;    // any width: the last span of a row is masked
     const uint32_t total = spans_per_row * (uint32_t)p.nrows;
-    for (uint32_t sidx = blockIdx.x * 4 + wave; sidx < total; sidx += gridDim.x * 4) {
+    for (uint32_t sidx = blockIdx.x * kStreamWaves + wave; sidx < total; sidx += gridDim.x * kStreamWaves) {
         const uint32_t r = sidx / spans_per_row;
         const uint32_t sx = sidx - r * spans_per_row;
         const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);
@@ -877,7 +886,7 @@ __global__ __launch_bounds__(256) void write_rgba32_ycbcra444_hot(const WritePar
 // Output sample i is a function of input sample i (RGB) or of its own pixel's float4 (RGBA): no transposition at all.  A wave
 // streams 64 x 4 float4 per trip: coalesced non-temporal 16-byte loads, the curve, 8-byte non-temporal stores at the same index.
 template <int TRANSFER, int PLANES>
-__global__ __launch_bounds__(256) void write_f32_ref_stream(const WriteParams p)
+__global__ __launch_bounds__(AG_STREAM_BLOCK) void write_f32_ref_stream(const WriteParams p)
 {
     constexpr int K = 4;
     const int lane = threadIdx.x & 63;
@@ -885,7 +894,7 @@ __global__ __launch_bounds__(256) void write_f32_ref_stream(const WriteParams p)
     const uint32_t n4 = (uint32_t)p.width * PLANES / 4;                // float4 per row (host: width * PLANES % 4 == 0)
     const uint32_t chunks = (n4 + 64 * K - 1) / (64 * K);
     const uint32_t total = chunks * (uint32_t)p.nrows;
-    for (uint32_t widx = blockIdx.x * 4 + wave; widx < total; widx += gridDim.x * 4) {
+    for (uint32_t widx = blockIdx.x * kStreamWaves + wave; widx < total; widx += gridDim.x * kStreamWaves) {
         const uint32_t r = widx / chunks;
         const uint32_t c = widx - r * chunks;
         const f32x4* sp = reinterpret_cast<const f32x4*>(p.src + (long long)r * p.src_row_bytes);
@@ -924,21 +933,21 @@ __global__ __launch_bounds__(256) void write_f32_ref_stream(const WriteParams p)
 // ...SixteenBit), elementwise like write_f32_ref_stream: one 16-byte vector in (16 or 8 samples = whole pixels for RGBA), the
 // rescale "LUT" formula / premultiply per sample or pixel, one vector out at the same position.
 template <int DEPTH, int PLANES, bool DST16>
-__global__ __launch_bounds__(256) void write_int_ref_stream(const WriteParams p)
+__global__ __launch_bounds__(AG_STREAM_BLOCK) void write_int_ref_stream(const WriteParams p)
 {
     constexpr int K = 4;
     constexpr int NS = 16 / (DEPTH / 8);                                // samples per 16-byte input vector
     constexpr int ODW = NS * (DST16 ? 2 : 1) / 4;                       // output dwords per input vector: 2, 4 or 8
     __shared__ uint16_t lut8[DEPTH == 8 ? 256 : 2];                     // 8-bit documents saved at 10/12 bit (:87-112)
     if constexpr (DEPTH == 8) {
-        if (p.maxv > 255) { lut8[threadIdx.x] = (uint16_t)exact_rescale(threadIdx.x, 255.0f, p.maxf, p.maxv); __syncthreads(); }
+        if (p.maxv > 255) { for (int i = threadIdx.x; i < 256; i += AG_STREAM_BLOCK) lut8[i] = (uint16_t)exact_rescale(i, 255.0f, p.maxf, p.maxv); __syncthreads(); }
     }
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t nv = (uint32_t)((long long)p.width * PLANES * (DEPTH / 8) / 16);   // vectors per row (host: exact)
     const uint32_t chunks = (nv + 64 * K - 1) / (64 * K);
     const uint32_t total = chunks * (uint32_t)p.nrows;
-    for (uint32_t widx = blockIdx.x * 4 + wave; widx < total; widx += gridDim.x * 4) {
+    for (uint32_t widx = blockIdx.x * kStreamWaves + wave; widx < total; widx += gridDim.x * kStreamWaves) {
         const uint32_t r = widx / chunks;
         const uint32_t c = widx - r * chunks;
         const u32x4* sp = reinterpret_cast<const u32x4*>(p.src + (long long)r * p.src_row_bytes);
@@ -1145,11 +1154,11 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
         const long long waves = ((nv + 255) / 256) * p.nrows;
         if (waves == 0) return hipSuccess;
         if (waves + 8LL * 65536 * 4 < 0x7fffffffLL) {
-            long long blocks = (waves + 3) / 4;
-            if (blocks > AG_STREAM_BLOCK_CAP) blocks = AG_STREAM_BLOCK_CAP;
+            long long blocks = (waves + kStreamWaves - 1) / kStreamWaves;
+            if (blocks > AG_STREAM_BLOCK_CAP * 4 / kStreamWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kStreamWaves;
             snprintf(label, kLabelBytes, "write_int_ref_stream<depth=%d,planes=%d,dst16=%d>", depth, planes, (int)dst16);
-#define AG_IREF(D, P) do { if (dst16) hipLaunchKernelGGL((write_int_ref_stream<D, P, true>), dim3((int)blocks), dim3(256), 0, st, p); \
-                           else hipLaunchKernelGGL((write_int_ref_stream<D, P, false>), dim3((int)blocks), dim3(256), 0, st, p); } while (0)
+#define AG_IREF(D, P) do { if (dst16) hipLaunchKernelGGL((write_int_ref_stream<D, P, true>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); \
+                           else hipLaunchKernelGGL((write_int_ref_stream<D, P, false>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); } while (0)
             if (planes == 4) AG_IREF(16, 4); else AG_IREF(16, 3);
 #undef AG_IREF
             return hipGetLastError();
@@ -1162,11 +1171,11 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
         const long long waves = ((n4 + 255) / 256) * p.nrows;
         if (waves == 0) return hipSuccess;
         if (waves + 8LL * 65536 * 4 < 0x7fffffffLL) {
-            long long blocks = (waves + 3) / 4;
-            if (blocks > AG_STREAM_BLOCK_CAP) blocks = AG_STREAM_BLOCK_CAP;
+            long long blocks = (waves + kStreamWaves - 1) / kStreamWaves;
+            if (blocks > AG_STREAM_BLOCK_CAP * 4 / kStreamWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kStreamWaves;
             snprintf(label, kLabelBytes, "write_f32_ref_stream<transfer=%d,planes=%d>", p.transfer, planes);
-#define AG_REF(TR) do { if (planes == 4) hipLaunchKernelGGL((write_f32_ref_stream<TR, 4>), dim3((int)blocks), dim3(256), 0, st, p); \
-                        else hipLaunchKernelGGL((write_f32_ref_stream<TR, 3>), dim3((int)blocks), dim3(256), 0, st, p); } while (0)
+#define AG_REF(TR) do { if (planes == 4) hipLaunchKernelGGL((write_f32_ref_stream<TR, 4>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); \
+                        else hipLaunchKernelGGL((write_f32_ref_stream<TR, 3>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); } while (0)
             switch (p.transfer) {
             case AVIFGPU_TRANSFER_PQ:       AG_REF(AVIFGPU_TRANSFER_PQ); break;
             case AVIFGPU_TRANSFER_HLG:      AG_REF(AVIFGPU_TRANSFER_HLG); break;
@@ -1188,14 +1197,14 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
         const long long spans = (long long)((p.width + 64 * AG_RGBA_HOT_PXL - 1) / (64 * AG_RGBA_HOT_PXL)) * p.nrows;
         if (spans == 0) return hipSuccess;
         if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
-            long long blocks = (spans + 3) / 4;
-            if (blocks > AG_RGBA_BLOCK_CAP) blocks = AG_RGBA_BLOCK_CAP;
+            long long blocks = (spans + kStreamWaves - 1) / kStreamWaves;
+            if (blocks > AG_RGBA_BLOCK_CAP * 4 / kStreamWaves) blocks = AG_RGBA_BLOCK_CAP * 4 / kStreamWaves;
             snprintf(label, kLabelBytes, "write_rgba32_ycbcra444_hot<transfer=%d>", p.transfer);
             switch (p.transfer) {
-            case AVIFGPU_TRANSFER_PQ:       hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<AVIFGPU_TRANSFER_PQ>), dim3((int)blocks), dim3(256), 0, st, p); break;
-            case AVIFGPU_TRANSFER_HLG:      hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<AVIFGPU_TRANSFER_HLG>), dim3((int)blocks), dim3(256), 0, st, p); break;
-            case AVIFGPU_TRANSFER_SMPTE428: hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<AVIFGPU_TRANSFER_SMPTE428>), dim3((int)blocks), dim3(256), 0, st, p); break;
-            default:                        hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<AVIFGPU_TRANSFER_CLIP>), dim3((int)blocks), dim3(256), 0, st, p); break;
+            case AVIFGPU_TRANSFER_PQ:       hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<AVIFGPU_TRANSFER_PQ>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); break;
+            case AVIFGPU_TRANSFER_HLG:      hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<AVIFGPU_TRANSFER_HLG>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); break;
+            case AVIFGPU_TRANSFER_SMPTE428: hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<AVIFGPU_TRANSFER_SMPTE428>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); break;
+            default:                        hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<AVIFGPU_TRANSFER_CLIP>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); break;
             }
             return hipGetLastError();
         }
@@ -1207,11 +1216,11 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
         const long long spans = (long long)((p.width + 511) / 512) * ((p.nrows + (1 << ys) - 1) >> ys);
         if (spans == 0) return hipSuccess;
         if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
-            long long blocks = (spans + 3) / 4;
-            if (blocks > AG_STREAM_BLOCK_CAP) blocks = AG_STREAM_BLOCK_CAP;
+            long long blocks = (spans + kStreamWaves - 1) / kStreamWaves;
+            if (blocks > AG_STREAM_BLOCK_CAP * 4 / kStreamWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kStreamWaves;
             snprintf(label, kLabelBytes, "write_rgb32_ycbcr_sub_hot<transfer=%d,xs=1,ys=%d>", p.transfer, ys);
-#define AG_SUB(TR) do { if (ys) hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<TR, 1, 1>), dim3((int)blocks), dim3(256), 0, st, p); \
-                        else hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<TR, 1, 0>), dim3((int)blocks), dim3(256), 0, st, p); } while (0)
+#define AG_SUB(TR) do { if (ys) hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<TR, 1, 1>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); \
+                        else hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<TR, 1, 0>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); } while (0)
             switch (p.transfer) {
             case AVIFGPU_TRANSFER_PQ:       AG_SUB(AVIFGPU_TRANSFER_PQ); break;
             case AVIFGPU_TRANSFER_HLG:      AG_SUB(AVIFGPU_TRANSFER_HLG); break;
@@ -1232,11 +1241,12 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
             const long long spans = (long long)((p.width + span_px - 1) / span_px) * p.nrows;
             if (spans == 0) return hipSuccess;
             if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
-            long long blocks = (spans + 3) / 4;
-            const long long cap = (variant >> 8) ? (variant >> 8) : 256LL * 512;   // 8192^2: one span per wave (32k blocks) measured 5-6 % faster than two (16k)
+            constexpr int WPB = kStreamWaves;
+            long long blocks = (spans + WPB - 1) / WPB;
+            const long long cap = (variant >> 8) ? (variant >> 8) : 256LL * 512 * 4 / WPB;   // 8192^2: one span per wave measured 5-6 % faster than two
             if (blocks > cap) blocks = cap;
             snprintf(label, kLabelBytes, "write_rgb32_ycbcr444_hot<transfer=%d,pxl=%d,nt=%d>", p.transfer, px8 ? 8 : 4, (int)nt);
-#define AG_HOT3(TR, PX, NT_) hipLaunchKernelGGL((write_rgb32_ycbcr444_hot<TR, PX, NT_>), dim3((int)blocks), dim3(256), 0, st, p)
+#define AG_HOT3(TR, PX, NT_) hipLaunchKernelGGL((write_rgb32_ycbcr444_hot<TR, PX, NT_>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p)
 #define AG_HOT2(TR, PX) do { if (nt) AG_HOT3(TR, PX, true); else AG_HOT3(TR, PX, false); } while (0)
 #define AG_HOT1(TR) do { if (px8) AG_HOT2(TR, 8); else AG_HOT2(TR, 4); } while (0)
             switch (p.transfer) {
