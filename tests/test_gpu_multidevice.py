@@ -220,3 +220,37 @@ def test_rebind_and_device_pointers_after_multi(rebind):
     bad = (ctypes.c_int32 * 1)(99)
     assert gpu.lib.avifgpu_init_devices(bad, 1) == pkg.formatBadParameters
     assert gpu.lib.avifgpu_device_count() == 1          # a rejected list leaves the current binding alone
+
+
+def test_fullsize_c4_eight_contexts_equal_one(rebind):
+    """BASELINE.json configs[3] at full size (8192 x 8192 RGB f32 -> 10-bit PQ YCbCr 4:4:4: 805 MB in, 403 MB out) from host memory:
+    the planes produced by 8 contexts (the 8-GPU split of one image; here 8 x 2 workers on the visible device(s)) are
+    byte-identical to the 1-context planes, and a stripe of them matches the oracle."""
+    import torch
+    W = H_ = 8192
+    d = pkg.WriteDesc(width=W, height=H_, depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_PQ, peak_nits=80,
+                      alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444,
+                      matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020)
+    g = torch.Generator().manual_seed(1234)
+    src = torch.rand((H_, W * 3), generator=g, dtype=torch.float32).pin_memory()
+    outs = {}
+    for n in (1, 8):
+        gpu = rebind(n)
+        planes = [torch.zeros((H_, W * 2), dtype=torch.uint8).pin_memory() for _ in range(3)]
+        gpu.write_rows(d, 0, H_, src.data_ptr(), src.stride(0) * 4, [p.data_ptr() for p in planes] + [None],
+                       [p.stride(0) for p in planes] + [0], mem=pkg.MEM_HOST)
+        outs[n] = planes
+    for a, b in zip(outs[1], outs[8]):
+        assert torch.equal(a, b)
+    r0, nr = 4090, 12                                        # a stripe across the cut between contexts 3 and 4 (row 4096)
+    sub = src[r0:r0 + nr].numpy()
+    want = {}
+    bufs = harness._alloc_write_out(d, nr)
+    ptrs = pkg.planes4([bufs[i].ctypes.data if i in bufs else None for i in range(4)])
+    strides = pkg.strides4([bufs[i].strides[0] if i in bufs else 0 for i in range(4)])
+    import oracle_binding
+    assert oracle_binding.load().oracle_write_rows(ctypes.byref(d), r0, nr, sub.ctypes.data, sub.strides[0], ctypes.byref(ptrs), ctypes.byref(strides)) == 0
+    for pl in range(3):
+        got = outs[8][pl][r0:r0 + nr].numpy().view(np.uint16)
+        diff = np.abs(got.astype(np.int64) - bufs[pl][:nr, :W].astype(np.int64))
+        assert diff.max() <= 1 and (diff == 0).mean() > 0.997, (pl, int(diff.max()), float((diff == 0).mean()))
