@@ -569,10 +569,11 @@ int wait_all()
 // ---- whole-range host conversions ---------------------------------------------------------------------------------------
 namespace {
 
-// rows per sub-tile: AVIFGPU_CHUNK_MB of the larger side (rows in / planes out), even, at least 2
+// rows per sub-tile: AVIFGPU_CHUNK_MB (default 8: 49.7 GB/s H2D for C4 from page-locked memory, 45.0 with 16 -- profiles/r02/
+// pcie_tile_and_lane_sweep.txt) of the rows side, even, at least 2
 int chunk_rows_for(size_t bytes_per_row)
 {
-    const size_t budget = (size_t)env_int("AVIFGPU_CHUNK_MB", 16, 1, 4096) << 20;
+    const size_t budget = (size_t)env_int("AVIFGPU_CHUNK_MB", 8, 1, 4096) << 20;
     size_t rows = budget / std::max<size_t>(bytes_per_row, 1);
     rows = std::max<size_t>(rows & ~(size_t)1, 2);
     return (int)std::min<size_t>(rows, 1u << 30);
