@@ -180,6 +180,14 @@ AG_DEV uint32_t exact_premultiply_fast(uint32_t color, uint32_t alpha, float max
     const float v = __builtin_fmaf(__builtin_fmaf(-q0, maxf, x), rcp_maxf, q0);
     return (uint32_t)cxx_min(floorf(v + 0.5f), maxf);
 }
+// the same value as a float, from float operands (integer-valued; the u8 fast path keeps its codes in float)
+AG_DEV float exact_premultiply_fast_f(float color, float alpha, float maxf, float rcp_maxf)
+{
+    const float x = color * alpha;
+    const float q0 = x * rcp_maxf;
+    const float v = __builtin_fmaf(__builtin_fmaf(-q0, maxf, x), rcp_maxf, q0);
+    return cxx_min(floorf(v + 0.5f), maxf);
+}
 AG_DEV uint32_t exact_unpremultiply(uint32_t color, uint32_t alpha, float maxf)
 {
     const float v = cxx_min((float)color * maxf / (float)alpha, maxf);
@@ -364,6 +372,16 @@ AG_DEV void wave_span_store(uint32_t* strip, int lane, bool active, const uint32
         }
     }
     __builtin_amdgcn_wave_barrier();
+}
+
+// Byte `pos` of a lane's packed u8 output <- (uint8_t)clip((long)s, 0, 255) for a float s (s = v + 0.5f at every call site):
+// v_floor_f32, then v_cvt_pk_u8_f32, which saturates to [0, 255], converts an integer-valued float exactly (its round-to-nearest-
+// even never sees a fraction) and inserts the byte in place.  floor == the C truncation for s >= 0, and for s < 0 both ends are 0
+// (truncation gives 0 or a negative that the clip raises to 0; floor gives a negative that saturates to 0).  One instruction
+// replaces convert + clip + shift/or, and the lane never holds its codes unpacked: on the u8 kernels that is 2-5 waves of occupancy.
+AG_DEV void put_u8(uint32_t* pk, int pos, float s)          // pos is a compile-time constant after unrolling
+{
+    pk[pos >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(s), pos & 3, pk[pos >> 2]);
 }
 
 // Store N samples (u8 or u16 containers) starting at `p`; `nvalid` < N only on the right image edge.

@@ -288,6 +288,37 @@ template <bool SRC16> AG_DEV uint32_t sample_of(const uint32_t* d, int j)
     else return (d[j >> 2] >> (8 * (j & 3))) & 0xffu;
 }
 
+// 8-bit YCbCr -> interleaved RGB8 / RGBA8, written straight into the lane's PACKED output dwords (YuvDecode.cpp:312-326,
+// :369-395).  (uint8)(0.5f + c * 255.0f) of the clamped colour == saturate_u8(floor(0.5f + c * 255.0f)) of the UNclamped one:
+// for c < 0 the sum is below 0.5 (floor <= 0 -> 0, like the clamped 0.5 -> 0), for c > 1 it is above 255.5 (-> 255), in
+// between nothing changes.  put_u8 (device_math.h) does floor + saturate + byte insert, so a pixel costs no clamp, no separate
+// pack and -- the point -- no 48 unpacked output registers per lane: that is what held these kernels at 4 waves/SIMD.
+#ifndef AG_R8_PACKED
+#define AG_R8_PACKED 1
+#endif
+template <bool ALPHA, bool LUT>
+AG_DEV void decode_ycc8_packed(const ReadParams& p, const Tables<LUT>& t, int i, uint32_t yv, uint32_t ua, const ChromaTerms& ct, uint32_t* pk)
+{
+    constexpr int NCH = ALPHA ? 4 : 3;
+    const float Y = look_y(p, t, yv);
+    float R = Y + ct.r;                                                                 // :312
+    float B = Y + ct.b;                                                                 // :313
+    float G = Y - ct.g;                                                                 // :314
+    if constexpr (ALPHA) {
+        pk[i] = ua << 24;                                                               // :395 (the pixel's own dword)
+        if (p.premultiplied) {                                                          // :369-388, as decode_pixel
+            R = clamp01(R); G = clamp01(G); B = clamp01(B);
+            const float A = look_a(p, t, ua);
+            const float r = 1.0f / A;
+            const float uR = unpremultiply_one(R, A, r), uG = unpremultiply_one(G, A, r), uB = unpremultiply_one(B, A, r);
+            R = (ua == 0) ? 0.0f : uR; G = (ua == 0) ? 0.0f : uG; B = (ua == 0) ? 0.0f : uB;
+        }
+    }
+    put_u8(pk, NCH * i + 0, 0.5f + (R * 255.0f));                                       // :324-326
+    put_u8(pk, NCH * i + 1, 0.5f + (G * 255.0f));
+    put_u8(pk, NCH * i + 2, 0.5f + (B * 255.0f));
+}
+
 // The table set of one read configuration: its layout and, with fill = true, its contents.  Only the tables the
 // configuration reads, aliased where the reference's formulas coincide (see read_table_count): 12-bit full-range YCbCr needs
 // 16 KiB instead of 48.  Used twice: build_read_tables fills a device buffer ONCE per parameter set (cached by
@@ -390,14 +421,7 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
     extern __shared__ float lut[];
     Tables<LUT> t = { nullptr, nullptr, nullptr, nullptr, 0.0f };
     int lut_floats = 0;
-    if constexpr (LUT) {
-        lut_floats = read_tables<CS, DEPTH, ALPHA, TRANSFER>(p, lut, t, false, 0, 1);          // layout only
-        typedef float f4 __attribute__((ext_vector_type(4)));
-        const f4* src4 = reinterpret_cast<const f4*>(p.tables);
-        f4* dst4 = reinterpret_cast<f4*>(lut);
-        for (int i = threadIdx.x; i < (lut_floats >> 2); i += 256) dst4[i] = src4[i];           // L2-resident, built once
-        __syncthreads();
-    }
+    if constexpr (LUT) lut_floats = read_tables<CS, DEPTH, ALPHA, TRANSFER>(p, lut, t, false, 0, 1);   // layout only; filled below
 
     // ---- work mapping: a WAVE owns 64 consecutive thread-footprints of ONE row group, so its output is one
     // contiguous span of the interleaved host row (needed by the transposed store below) -----------------------
@@ -447,6 +471,13 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
     uint32_t wv = blockIdx.x * 4 + wave;
     Group cur;
     if (AG_READ_PREFETCH && wv < total_waves) load_group(wv, cur);
+    if constexpr (LUT) {            // (issuing the first group's loads before this copy was measured: no difference)
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4* src4 = reinterpret_cast<const f4*>(p.tables);
+        f4* dst4 = reinterpret_cast<f4*>(lut);
+        for (int i = threadIdx.x; i < (lut_floats >> 2); i += 256) dst4[i] = src4[i];           // L2-resident, built once
+        __syncthreads();
+    }
     for (; wv < total_waves; wv += wstep) {
         const int gy = (int)(wv / wpr);
         const int wx = (int)(wv - (uint32_t)gy * wpr);
@@ -460,6 +491,47 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
         if constexpr (AG_READ_PREFETCH) { if (wv + wstep < total_waves) load_group(wv + wstep, nxt); }   // in flight during the decode below
         else load_group(wv, cur);
 
+        constexpr bool PACKED8 = AG_R8_PACKED && DEPTH == 8 && CS == kCsYcc && ALIGNED && ND_OUT > 4;
+        if constexpr (PACKED8) {
+            // chroma-major: the terms of one chroma sample live only while the 1 / 2 / 4 pixels under it are decoded
+            uint32_t pk[VR][ND_OUT];
+            if (active) {
+                if constexpr (!ALPHA) {
+#pragma unroll
+                    for (int vr = 0; vr < VR; ++vr)
+#pragma unroll
+                        for (int j = 0; j < ND_OUT; ++j) pk[vr][j] = 0;
+                }
+#pragma unroll
+                for (int j = 0; j < NC; ++j) {
+                    // pin the order (the empty asm emits nothing): left alone, instruction selection starts all NC chroma samples at
+                    // once and the footprint's temporaries cost 2-3 waves of occupancy
+#pragma unroll
+                    for (int vr = 0; vr < VR; ++vr)
+#pragma unroll
+                        for (int d = 0; d < NDY; ++d) asm volatile("" : "+v"(cur.y[vr][d]));
+                    const ChromaTerms c = chroma_terms<DEPTH, LUT>(p, t, sample_of<SRC16>(cur.c1, j), sample_of<SRC16>(cur.c2, j));
+#pragma unroll
+                    for (int vr = 0; vr < VR; ++vr)
+#pragma unroll
+                        for (int k = 0; k < (1 << XS); ++k) {
+                            const int i = (j << XS) + k;
+                            decode_ycc8_packed<ALPHA, LUT>(p, t, i, sample_of<SRC16>(cur.y[vr], i), ALPHA ? sample_of<SRC16>(cur.a[ALPHA ? vr : 0], i) : 0u, c, pk[vr]);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            const int span_px = min(64 * PXT, p.width - wx * 64 * PXT);          // valid pixels of this wave's span
+#pragma unroll
+            for (int vr = 0; vr < VR; ++vr) {
+                const int r = r0 + vr;
+                if (r >= p.nrows) continue;                     // wave-uniform
+                wave_span_store<ND_OUT>(strip, lane, active, pk[vr], p.dst + (long long)r * p.dst_row_bytes + (long long)wx * (64 * PXT * NCH * OSZ),
+                                        span_px * NCH * OSZ);
+            }
+            if constexpr (AG_READ_PREFETCH) cur = nxt;
+            continue;
+        }
         ChromaTerms ct[NC];
         if constexpr (CS == kCsYcc && XS + YS > 0) {
             // shared by 2 or 4 pixels: evaluate once.  (4:4:4 keeps it in the pixel loop: hoisting there only lengthens

@@ -337,6 +337,9 @@ enum { kOutRefColor = 0, kOutRefGray = 1, kOutYcbcr = 2 };
 #ifndef AG_W8_NC
 #define AG_W8_NC 8
 #endif
+#ifndef AG_W8_PACKED
+#define AG_W8_PACKED 1
+#endif
 #ifndef AG_W8_NC_ALPHA
 #define AG_W8_NC_ALPHA 4
 #endif
@@ -414,6 +417,131 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
         const int nvalid = active ? min(PXT, p.width - x0) : 0;
         const bool full = nvalid == PXT;
         const int span_px = min(64 * PXT, p.width - wx * 64 * PXT);              // valid pixels of this wave's span
+
+        // ---- 8-bit RGB(A) document -> u8 Y, Cb, Cr (, A) planes (the plug-in's default save and BASELINE C2): stage A is the identity
+        // there (WriteHeifImage.cpp:629-806 copies the bytes; 8-bit planes mean maxValue 255, no rescale; RGBA: the integer premultiply
+        // where the alpha state asks for it), so the row bytes AS LOADED are the codes.  They stay packed (12 dwords per 16-pixel row instead of 48 unpacked registers), v_cvt_f32_ubyteN
+        // converts a byte in place, and put_u8 writes each result byte straight into the lane's packed plane vectors: 132 -> ~60
+        // VGPRs on the 4:2:0 footprint (3 -> 8 waves/SIMD).  Chroma-major order: the floats of the 1/2/4 pixels under one chroma
+        // sample live only while that sample is formed.  Same expressions, operand order and rounding as luma_code / the generic
+        // chroma block below.  The one ragged lane of a row assembles its dwords from replicated bytes and stores byte by byte.
+        constexpr bool FAST8 = AG_W8_PACKED && DEPTH == 8 && (PLANES == 3 || PLANES == 4) && OUT == kOutYcbcr && !DST16 && ICC == 0 && ALIGNED;
+        if constexpr (FAST8) {
+            if (active) {
+                constexpr int NC = PXT >> XS;
+                uint32_t raw[VR][ND];
+#pragma unroll
+                for (int vr = 0; vr < VR; ++vr) {
+                    const int r = min(r0 + vr, p.rows_to_end - 1);          // bottom edge: replicate the last IMAGE row
+                    const uint8_t* rowp = p.src + (long long)r * p.src_row_bytes;
+                    if (full) load_dwords<ND, false, true>(rowp + (long long)x0 * PLANES, raw[vr]);
+                    else {
+                        // the one ragged lane of a row (x0 < width < x0 + PXT; its wave's other lanes are full or idle, so the
+                        // wave's strip is this lane's alone): a rolled byte loop replicates the last pixel into LDS -- unrolled,
+                        // its 48 loads per row would all be hoisted and set the VGPR count of the whole kernel
+                        uint8_t* sb = reinterpret_cast<uint8_t*>(strip);
+#pragma clang loop unroll(disable)
+                        for (int i = 0; i < PXT; ++i) {
+                            const uint8_t* pp = rowp + (long long)min(x0 + i, p.width - 1) * PLANES;
+#pragma unroll
+                            for (int k = 0; k < PLANES; ++k) sb[PLANES * i + k] = pp[k];
+                        }
+#pragma unroll
+                        for (int d = 0; d < ND; ++d) raw[vr][d] = strip[d];
+                    }
+                }
+                uint32_t ypk[VR][PXT / 4], cbpk[NC / 4], crpk[NC / 4];
+#pragma unroll
+                for (int vr = 0; vr < VR; ++vr)
+#pragma unroll
+                    for (int j = 0; j < PXT / 4; ++j) ypk[vr][j] = 0;
+#pragma unroll
+                for (int j = 0; j < NC / 4; ++j) { cbpk[j] = 0; crpk[j] = 0; }
+                auto code = [&](int vr, int i, int k) -> float {            // (float)code: v_cvt_f32_ubyteN on the packed dword
+                    const int e = PLANES * i + k;
+                    return (float)((raw[vr][e >> 2] >> (8 * (e & 3))) & 0xffu);
+                };
+                auto convert = [&](auto nearest_c) {                        // one uniform branch per footprint, not one per chroma sample
+#pragma unroll
+                for (int j = 0; j < NC; ++j) {
+                    // Pin the order: nothing of chroma sample j may be computed before sample j - 1 is done.  (Left alone, instruction
+                    // selection hoists the products of all eight samples to the top and the 4:2:0 footprint needs 106-124 VGPRs
+                    // = 4 waves/SIMD instead of 8.  The empty asm emits nothing; it only makes the packed dwords opaque here.)
+#pragma unroll
+                    for (int vr = 0; vr < VR; ++vr)
+#pragma unroll
+                        for (int d = 0; d < ND; ++d) asm volatile("" : "+v"(raw[vr][d]));
+                    float c[VR][1 << XS][3];
+#pragma unroll
+                    for (int vr = 0; vr < VR; ++vr)
+#pragma unroll
+                        for (int k = 0; k < (1 << XS); ++k) {
+                            const int i = (j << XS) + k;
+                            c[vr][k][0] = code(vr, i, 0); c[vr][k][1] = code(vr, i, 1); c[vr][k][2] = code(vr, i, 2);
+                            if constexpr (PLANES == 4) {
+                                if (p.premultiply) {                         // stage_a: exact_premultiply_fast on the three colours (:691-708)
+                                    const float a = code(vr, i, 3);
+#pragma unroll
+                                    for (int ch = 0; ch < 3; ++ch) c[vr][k][ch] = exact_premultiply_fast_f(c[vr][k][ch], a, p.maxf, p.rcp_maxf);
+                                }
+                            }
+                            put_u8(ypk[vr], i, (c[vr][k][0] * p.my[0] + c[vr][k][1] * p.my[1] + c[vr][k][2] * p.my[2]) + 0.5f);   // luma_code
+                        }
+                    float R = c[0][0][0], G = c[0][0][1], B = c[0][0][2];
+                    if constexpr ((XS || YS) && !decltype(nearest_c)::value) {
+                        constexpr int k1 = XS ? 1 : 0, v1 = YS ? 1 : 0;
+                        R = (R + c[0][k1][0] + c[v1][0][0] + c[v1][k1][0]) * 0.25f;
+                        G = (G + c[0][k1][1] + c[v1][0][1] + c[v1][k1][1]) * 0.25f;
+                        B = (B + c[0][k1][2] + c[v1][0][2] + c[v1][k1][2]) * 0.25f;
+                    }
+                    const float cb = R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2];
+                    const float cr = R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2];
+                    put_u8(cbpk, j, (cb + p.half) + 0.5f);                   // clip_round(cb + half, 255)
+                    put_u8(crpk, j, (cr + p.half) + 0.5f);
+                    __builtin_amdgcn_sched_barrier(0);                      // ... and the machine scheduler may not interleave them either
+                }
+                };
+                if ((XS || YS) && p.nearest) convert(std::true_type{}); else convert(std::false_type{});
+                const int ncvalid = (nvalid + (1 << XS) - 1) >> XS;
+                uint8_t* dcb = p.dst[1] + (long long)gy * p.dst_stride[1] + (x0 >> XS);
+                uint8_t* dcr = p.dst[2] + (long long)gy * p.dst_stride[2] + (x0 >> XS);
+#pragma unroll
+                for (int vr = 0; vr < VR; ++vr) {
+                    const int r = r0 + vr;
+                    if (r >= p.nrows) continue;
+                    uint8_t* dy = p.dst[0] + (long long)r * p.dst_stride[0] + x0;
+                    if (full) store_dwords<PXT / 4, true, true>(dy, ypk[vr]);
+                    else {
+#pragma unroll
+                        for (int i = 0; i < PXT; ++i) if (i < nvalid) dy[i] = (uint8_t)(ypk[vr][i >> 2] >> (8 * (i & 3)));
+                    }
+                    if constexpr (PLANES == 4) {                            // the alpha plane: byte 3 of every pixel dword, gathered with v_perm_b32
+                        uint8_t* da = p.dst[3] + (long long)r * p.dst_stride[3] + x0;
+                        uint32_t apk[PXT / 4];
+#pragma unroll
+                        for (int m = 0; m < PXT / 4; ++m) {
+                            const uint32_t t0 = __builtin_amdgcn_perm(raw[vr][4 * m + 1], raw[vr][4 * m], 0x0c0c0703u);
+                            const uint32_t t1 = __builtin_amdgcn_perm(raw[vr][4 * m + 3], raw[vr][4 * m + 2], 0x0c0c0703u);
+                            apk[m] = __builtin_amdgcn_perm(t1, t0, 0x05040100u);
+                        }
+                        if (full) store_dwords<PXT / 4, true, true>(da, apk);
+                        else {
+#pragma unroll
+                            for (int i = 0; i < PXT; ++i) if (i < nvalid) da[i] = (uint8_t)(apk[i >> 2] >> (8 * (i & 3)));
+                        }
+                    }
+                }
+                if (full) {
+                    store_dwords<NC / 4, true, true>(dcb, cbpk);
+                    store_dwords<NC / 4, true, true>(dcr, crpk);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NC; ++j)
+                        if (j < ncvalid) { dcb[j] = (uint8_t)(cbpk[j >> 2] >> (8 * (j & 3))); dcr[j] = (uint8_t)(crpk[j >> 2] >> (8 * (j & 3))); }
+                }
+            }
+            continue;
+        }
 
         // The integer codes of the footprint stay PACKED until they are stored (4 x u8 or 2 x 2 x u16 per pixel): a 4:2:0
         // footprint of 2 x 16 pixels is 32 or 64 VGPRs instead of 128, which is worth 1-2 waves of occupancy on the SDR

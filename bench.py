@@ -81,6 +81,7 @@ def main():
                     help="untimed setup: run the kernel this long before the W warm-up steps so the GPU leaves its idle "
                          "clock state (measured: the first ~50 ms of launches run at up to 2x the steady-state time)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive (host pointers, in-process N-device) figure")
+    ap.add_argument("--no-rotate", action="store_true", help="skip the rotating-buffer (Infinity Cache) cross-check of the kernel time")
     ap.add_argument("--no-c5", action="store_true", help="skip the configs[4] (16384^2 RGBA f32) sub-measurement")
     args = ap.parse_args()
 
@@ -204,6 +205,36 @@ def main():
     kernel_ms = sorted(series)
     kernel_name = gpu.last_kernel()
 
+    # untimed diagnostic: the same K back-to-back launches ROTATING over 4 disjoint (source, planes) buffer sets, so that no byte a
+    # launch reads or writes can still sit in the 256-MB Infinity Cache when its address comes round again.  The timed region above
+    # reuses one set, like every benchmark loop; this figure shows how much of its number that reuse is worth.  (For the all-
+    # non-temporal kernels: nothing.  tools/membench_r02.hip shows what a write-back store policy would have "gained" there.)
+    rotating = None
+    if world == 1 and not args.no_rotate:
+        NSET = 4
+        sets = [(src, ptrs)]
+        keep = []
+        for j in range(1, NSET):
+            f = frame.clone()
+            pl = [torch.empty_like(t) for t in planes]
+            keep.append((f, pl))
+            sets.append((f[row0:row0 + nrows], [t.data_ptr() for t in pl] + [None]))
+        def rot_step(i):
+            sj, pj = sets[i % NSET]
+            gpu.write_rows(desc, row0, nrows, sj.data_ptr(), sj.stride(0) * 4, pj, strides, mem=pkg.MEM_DEVICE, stream=stream.cuda_stream)
+        for i in range(40):
+            rot_step(i)
+        torch.cuda.synchronize(dev)
+        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        r0.record(stream)
+        for i in range(args.steps):
+            rot_step(i)
+        r1.record(stream)
+        torch.cuda.synchronize(dev)
+        rot_ms = r0.elapsed_time(r1) / args.steps
+        rotating = {"sets": NSET, "kernel_ms_mean": round(rot_ms, 5)}
+        del keep, sets
+
     total_rows = H * world if args.scaling == "weak" else H
     total_px = float(W) * total_rows * args.steps
     value = total_px / elapsed / 1e6
@@ -244,6 +275,9 @@ def main():
             "read_only_frac": round((12.0 * W * nrows) / mean_kernel_s / 1e9 / HBM_PEAK_GBPS, 4),
         },
     }
+    if rotating:
+        rotating["frac"] = round(algo_bytes / (rotating["kernel_ms_mean"] / 1e3) / 1e9 / HBM_PEAK_GBPS, 4)
+        out["roofline"]["rotating_buffers"] = rotating
     out["profile_window"] = {"kernel": kernel_name, "launches_before_timed_region": launches_before_timed, "timed_launches": args.steps}
     # PMC-derived HBM traffic per launch: NOT measured in this run (counters need their own rocprofv3 --pmc passes, which the
     # driver's plain run cannot do) -- read from the committed summary of those passes and labelled as such

@@ -1,0 +1,82 @@
+"""The packed 8-bit fast paths (write_px FAST8: RGB8 / RGBA8 -> u8 Y,Cb,Cr(,A) planes; read_px PACKED8: u8 YCbCr(A) -> RGB8 / RGBA8)
+only exist in the ALIGNED instantiations (16-byte aligned pointers and strides), which the small odd-width cases of
+tests/cases.py never reach with their tight rows.  Here the rows are PADDED to 16 bytes the way libheif pads its planes, so odd
+and ragged widths run the aligned kernels: the one ragged lane of a row (replicated last pixel, byte-wise stores), odd heights
+(replicated last row), both chroma down-sampling modes, premultiplied alpha.  Bit-exact against the oracle."""
+import numpy as np
+import pytest
+
+import harness
+
+pkg = harness.pkg
+pytestmark = pytest.mark.gpu
+
+
+def align(v, a):
+    return (v + a - 1) // a * a
+
+
+def gpu_write_padded(gpu, desc, src):
+    """Like harness.gpu_write(mem='device'), but the source rows sit at a 16-byte padded stride on the device."""
+    import torch
+    dev = f"cuda:{gpu.device}"
+    H, rowb = src.shape[0], src.shape[1] * src.itemsize
+    stride = align(rowb, 16)
+    padded = np.full((H, stride), 0x5A, dtype=np.uint8)
+    padded[:, :rowb] = src.view(np.uint8).reshape(H, rowb)
+    d_src = torch.from_numpy(padded.reshape(-1)).to(dev)
+    bufs = harness._alloc_write_out(desc, H)
+    d_out = {pl: torch.from_numpy(b.view(np.uint8).reshape(-1).copy()).to(dev) for pl, b in bufs.items()}
+    ptrs = [d_out[i].data_ptr() if i in d_out else None for i in range(4)]
+    strides = [bufs[i].strides[0] if i in bufs else 0 for i in range(4)]
+    gpu.write_rows(desc, 0, H, d_src.data_ptr(), stride, ptrs, strides, mem=pkg.MEM_DEVICE, stream=torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
+    raw = {pl: d_out[pl].cpu().numpy().view(bufs[pl].dtype).reshape(bufs[pl].shape) for pl in bufs}
+    return harness._trim(desc, raw, H, harness.write_planes), raw
+
+
+WIDTHS = [1040, 1001, 1000, 24, 17, 2050]
+CHROMAS = [pkg.CHROMA_444, pkg.CHROMA_422, pkg.CHROMA_420]
+
+
+@pytest.mark.parametrize("planes,alpha", [(3, pkg.ALPHA_NONE), (4, pkg.ALPHA_STRAIGHT), (4, pkg.ALPHA_PREMULTIPLIED)])
+@pytest.mark.parametrize("chroma", CHROMAS)
+@pytest.mark.parametrize("width", WIDTHS)
+def test_write_u8_fast_path_padded_rows(gpu, planes, alpha, chroma, width):
+    for height, near, matrix in ((7, False, pkg.MATRIX_BT601), (4, True, pkg.MATRIX_BT709)):
+        kw = dict(width=width, height=height, depth=8, planes=planes, bit_depth=8, alpha_state=alpha, output=pkg.OUT_YCBCR,
+                  chroma=chroma, matrix_coefficients=matrix, color_primaries=pkg.PRIMARIES_BT709)
+        if near:
+            kw["chroma_downsampling"] = pkg.DOWNSAMPLE_NEAREST
+        d = pkg.WriteDesc(**kw)
+        src = harness.make_write_source(d, seed=width + height)
+        want = harness.oracle_write(d, src)
+        got, raw = gpu_write_padded(gpu, d, src)
+        assert "aligned=1" in gpu.last_kernel() and "depth=8" in gpu.last_kernel(), gpu.last_kernel()
+        for pl in want:
+            assert np.array_equal(want[pl], got[pl]), (pl, width, height, near, int(np.abs(want[pl].astype(int) - got[pl].astype(int)).max()))
+        # nothing written beyond the valid samples of a row (the guard pattern of the padding survives)
+        for pl, (w, xs, ys) in harness.write_planes(d).items():
+            assert np.all(raw[pl][:, w:] == 0xA5), (pl, width)
+
+
+@pytest.mark.parametrize("alpha", [pkg.ALPHA_NONE, pkg.ALPHA_STRAIGHT, pkg.ALPHA_PREMULTIPLIED])
+@pytest.mark.parametrize("chroma", CHROMAS)
+@pytest.mark.parametrize("width", [1040, 1001, 24, 2050])
+def test_read_u8_fast_path_padded_rows(gpu, alpha, chroma, width):
+    for height, full_range, matrix in ((7, True, pkg.MATRIX_BT601), (4, False, pkg.MATRIX_BT709)):
+        d = pkg.ReadDesc(width=width, height=height, colorspace=pkg.COLORSPACE_YCBCR, chroma=chroma, bit_depth=8, depth=8,
+                         alpha_state=alpha, matrix_coefficients=matrix, color_primaries=pkg.PRIMARIES_BT709,
+                         transfer_characteristics=pkg.TC_SRGB, full_range_flag=1 if full_range else 0)
+        planes = harness.make_read_source(d, seed=width + height)
+        # 16-byte strides (libheif's own padding): re-pad every plane
+        fixed = {}
+        for pl, arr in planes.items():
+            w = arr.shape[1]
+            out = np.zeros((arr.shape[0], align(w, 16)), dtype=arr.dtype)
+            out[:, :w] = arr
+            fixed[pl] = out
+        want = harness.oracle_read(d, fixed)
+        got = harness.gpu_read(gpu, d, fixed, mem="device")
+        assert "aligned=1" in gpu.last_kernel() and "depth=8" in gpu.last_kernel(), gpu.last_kernel()
+        assert np.array_equal(want, got), (width, height, full_range)

@@ -1,0 +1,147 @@
+// membench_r02.hip -- what the memory system of an MI355X gives the streaming write kernels' ACCESS PATTERNS, measured the way
+// bench.py measures (N back-to-back launches between one event pair, after a clock ramp).  The kernels here move exactly the
+// bytes of their namesakes -- coalesced 16-byte loads of an interleaved f32 row, 16- / 8-byte u16 plane stores -- and do no
+// arithmetic beyond a cast, so "library kernel time / time here" is the share of a kernel's duration that is the memory
+// system's.  Three sets (argv[1]):
+//   patterns  the math-free ceiling of each streaming kernel's pattern (4:4:4 / 4:2:2 / 4:2:0 / RGBA, workgroup sizes, tile sizes)
+//   policy    the cache policy of loads and stores (nt / sc0 / sc1 bits per plane) on the C4 pattern
+//   rotate    the policies again with the buffers ROTATING over 4 disjoint sets from launch to launch
+// What "policy" + "rotate" show (profiles/r02/membench_patterns.txt): storing one or two of the three planes write-back instead
+// of non-temporal "reaches" 0.93-0.99 of 8 TB/s -- because a loop that rewrites the same 128-MiB planes every 0.16 ms keeps
+// them dirty in the 256-MB Infinity Cache and never writes them to HBM.  With rotating buffers the gain is gone and all-nt is the
+// best policy (0.81, the same with and without rotation): that is what the library kernels use, and why bench.py reports a
+// rotating-buffers figure next to its timed one.
+//   hipcc --offload-arch=gfx950 -O3 tools/membench_r02.hip -o tools/membench_r02
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+
+// Stores with the cache policy spelled out: POL bit 0 = nt, bit 1 = sc0, bit 2 = sc1.  (Inline asm because clang was seen dropping
+// the nt bit of some __builtin_nontemporal_store calls when others in the same kernel were plain.)
+template <int POL> __device__ __forceinline__ void st16(void* p, u4 v)
+{
+    if constexpr (POL == 0) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(p), "v"(v) : "memory");
+    if constexpr (POL == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(p), "v"(v) : "memory");
+    if constexpr (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0" :: "v"(p), "v"(v) : "memory");
+    if constexpr (POL == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" :: "v"(p), "v"(v) : "memory");
+    if constexpr (POL == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+    if constexpr (POL == 5) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(p), "v"(v) : "memory");
+    if constexpr (POL == 6) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");
+    if constexpr (POL == 7) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(p), "v"(v) : "memory");
+}
+template <int POL> __device__ __forceinline__ void st8(void* p, u2 v)
+{
+    static_assert(POL == 1, "8-byte stores: nt only");
+    asm volatile("global_store_dwordx2 %0, %1, off nt" :: "v"(p), "v"(v) : "memory");
+}
+
+// CH = 3 (RGB) or 4 (RGBA) floats per pixel in; planes out: luma (+ alpha for CH 4) full size, chroma sub-sampled by (XS, YS).
+// A wave owns 64 * PXL pixels on 1 << YS rows, like write_rgb32_ycbcr444_hot / _sub_hot / write_rgba32_ycbcra444_hot.
+// PY / PC: store policy of the luma (+ alpha) / chroma planes; NTL: non-temporal loads.
+template <int CH, int XS, int YS, int BLOCK, int PXL, int PY, int PC, bool NTL>
+__global__ __launch_bounds__(BLOCK) void k(const f4* __restrict__ in, unsigned short* __restrict__ y, unsigned short* __restrict__ cb,
+                                           unsigned short* __restrict__ cr, unsigned short* __restrict__ al, int width, int height)
+{
+    constexpr int K = CH * PXL / 4, SPAN = 64 * PXL, VR = 1 << YS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned spans_per_row = width / SPAN, groups = height >> YS, total = spans_per_row * groups;
+    for (unsigned s = blockIdx.x * (BLOCK / 64) + wave; s < total; s += gridDim.x * (BLOCK / 64)) {
+        const unsigned gy = s / spans_per_row, sx = s - gy * spans_per_row;
+        f4 v[VR][K];
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+            const f4* row = in + ((size_t)(gy * VR + r) * width * CH) / 4 + (size_t)sx * 64 * K;
+#pragma unroll
+            for (int kk = 0; kk < K; ++kk) v[r][kk] = NTL ? __builtin_nontemporal_load(row + 64 * kk + lane) : row[64 * kk + lane];
+        }
+        unsigned acc = 0;
+#pragma unroll
+        for (int r = 0; r < VR; ++r)
+#pragma unroll
+            for (int kk = 0; kk < K; ++kk) acc ^= (unsigned)v[r][kk].x ^ (unsigned)v[r][kk].y ^ (unsigned)v[r][kk].z ^ (unsigned)v[r][kk].w;
+        const size_t x = (size_t)sx * SPAN + (size_t)lane * PXL;
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+            const size_t o = (size_t)(gy * VR + r) * width + x;
+            if constexpr (PXL == 8) { st16<PY>(y + o, u4{ acc, acc + 1, acc + 2, acc + 3 }); if constexpr (CH == 4) st16<PY>(al + o, u4{ acc, acc + 5, acc + 2, acc + 3 }); }
+            else { st8<PY>(y + o, u2{ acc, acc + 1 }); if constexpr (CH == 4) st8<PY>(al + o, u2{ acc + 2, acc + 3 }); }
+        }
+        const size_t cw = width >> XS, co = (size_t)gy * cw + (x >> XS);
+        if constexpr (PXL == 8 && XS == 0) { st16<PC>(cb + co, u4{ acc, acc, acc, acc }); st16<PC>(cr + co, u4{ acc, acc, acc, 1 }); }
+        else { st8<PC>(cb + co, u2{ acc, acc }); st8<PC>(cr + co, u2{ acc, 1 }); }
+    }
+}
+
+static f4* g_in; static unsigned short* g_p[4];
+
+// nset > 1: launch i uses buffer set i % nset (disjoint inputs and planes)
+template <int CH, int XS, int YS, int BLOCK, int PXL = (CH == 3 ? 8 : 4), int PY = 1, int PC = 1, bool NTL = true>
+void run(const char* name, int W, int H, int launches, int nset = 1)
+{
+    const long long spans = (long long)(W / (64 * PXL)) * (H >> YS);
+    const int blocks = (int)((spans + BLOCK / 64 - 1) / (BLOCK / 64));
+    const size_t plane = (size_t)W * H, inset = (size_t)W * H * CH / 4;          // elements
+    auto launch = [&](int i) {
+        const int j = i % nset;
+        hipLaunchKernelGGL((k<CH, XS, YS, BLOCK, PXL, PY, PC, NTL>), dim3(blocks), dim3(BLOCK), 0, 0, g_in + inset * j, g_p[0] + plane * j, g_p[1] + plane * j,
+                           g_p[2] + plane * j, g_p[3] + plane * j, W, H);
+    };
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 300; ++i) launch(i);                                     // clock ramp
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    for (int i = 0; i < launches; ++i) launch(i);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= launches;
+    const double px = (double)W * H;
+    const double bytes = px * CH * 4 + px * 2 * (CH == 4 ? 2 : 1) + 2.0 * px * 2 / ((1 << XS) * (1 << YS));
+    printf("%-58s wg %4d  %8.4f ms  %7.1f GB/s  %.3f of 8 TB/s  (%.0f B/px)\n", name, BLOCK, ms, bytes / ms / 1e6, bytes / ms / 1e6 / 8000, bytes / px);
+    fflush(stdout);
+}
+
+int main(int argc, char** argv)
+{
+    const char* mode = argc > 1 ? argv[1] : "patterns";
+    CK(hipMalloc(&g_in, (size_t)16384 * 16384 * 16));
+    for (auto& q : g_p) CK(hipMalloc(&q, (size_t)16384 * 16384 * 2));
+    CK(hipMemset(g_in, 0x3c, (size_t)16384 * 16384 * 16));
+    const int W = 8192, H = 8192;
+    for (int rep = 0; rep < 2; ++rep) {
+        if (!strcmp(mode, "patterns")) {
+            run<3, 0, 0, 256>("RGB f32 -> Y,Cb,Cr 4:4:4 (C4) 8192^2", W, H, 200);
+            run<3, 0, 0, 128>("RGB f32 -> Y,Cb,Cr 4:4:4 (C4) 8192^2", W, H, 200);
+            run<3, 0, 0, 64>("RGB f32 -> Y,Cb,Cr 4:4:4 (C4) 8192^2", W, H, 200);
+            run<3, 0, 0, 128, 4>("RGB f32 -> 4:4:4, 4 px / lane, 8192^2", W, H, 200);
+            run<3, 1, 0, 128>("RGB f32 -> 4:2:2 8192^2", W, H, 200);
+            run<3, 1, 1, 128>("RGB f32 -> 4:2:0 8192^2", W, H, 200);
+            run<3, 0, 0, 128>("RGB f32 -> 4:4:4 16384^2", 16384, 16384, 40);
+            run<3, 0, 0, 128>("RGB f32 -> 4:4:4 8192 x 1024 (the N = 8 row tile)", W, 1024, 400);
+            run<4, 0, 0, 128>("RGBA f32 -> Y,Cb,Cr,A (C5) 16384^2", 16384, 16384, 40);
+            run<4, 0, 0, 256>("RGBA f32 -> Y,Cb,Cr,A (C5) 16384^2", 16384, 16384, 40);
+            run<4, 0, 0, 128, 8>("RGBA f32 -> Y,Cb,Cr,A, 8 px / lane, 16384^2", 16384, 16384, 40);
+            run<4, 0, 0, 128>("RGBA f32 -> Y,Cb,Cr,A 8192^2", W, H, 100);
+        } else {
+            const int nset = !strcmp(mode, "rotate") ? 4 : 1;
+            printf("C4 pattern (RGB f32 8192^2 -> three u16 planes), buffer sets: %d.  policy bits: 1 nt, 2 sc0, 4 sc1\n", nset);
+            run<3, 0, 0, 128, 8, 1, 1, true>("nt loads; stores y nt, cb/cr nt   (the library's choice)", W, H, 120, nset);
+            run<3, 0, 0, 128, 8, 1, 1, false>("plain loads; stores all nt", W, H, 120, nset);
+            run<3, 0, 0, 128, 8, 0, 0, true>("nt loads; stores all write-back", W, H, 120, nset);
+            run<3, 0, 0, 128, 8, 0, 0, false>("plain loads; stores all write-back", W, H, 120, nset);
+            run<3, 0, 0, 128, 8, 1, 0, true>("nt loads; stores y nt, cb/cr write-back", W, H, 120, nset);
+            run<3, 0, 0, 128, 8, 0, 1, true>("nt loads; stores y write-back, cb/cr nt", W, H, 120, nset);
+            run<3, 0, 0, 128, 8, 1, 4, true>("nt loads; stores y nt, cb/cr sc1", W, H, 120, nset);
+            run<3, 0, 0, 128, 8, 2, 2, true>("nt loads; stores all sc0", W, H, 120, nset);
+            run<3, 0, 0, 128, 8, 4, 4, true>("nt loads; stores all sc1", W, H, 120, nset);
+            run<3, 0, 0, 128, 8, 6, 6, true>("nt loads; stores all sc0 sc1", W, H, 120, nset);
+            run<3, 0, 0, 128, 8, 3, 3, true>("nt loads; stores all sc0 nt", W, H, 120, nset);
+            run<3, 0, 0, 128, 8, 5, 5, true>("nt loads; stores all sc1 nt", W, H, 120, nset);
+            run<3, 0, 0, 128, 8, 7, 7, true>("nt loads; stores all sc0 sc1 nt", W, H, 120, nset);
+        }
+    }
+    return 0;
+}
