@@ -1010,6 +1010,90 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba32_ycbcra444_hot(co
     }
 }
 
+// ---- RGB16 -> Y, Cb, Cr u16 planes (4:4:4, BASELINE config C3): the streaming structure with 16-bit samples ---------------------
+// A wave owns 512 consecutive pixels of a row = 3 KiB of source: three coalesced non-temporal 16-byte loads per lane (8 samples
+// each).  The rescale LUT expression (WriteHeifImage.cpp:141-166) is per sample, so it runs on the samples as loaded; the rescaled
+// codes leave the lane in the same packed form they arrived in (two u16 per dword), i.e. exactly the strip layout of
+// write_rgb32_ycbcr444_hot<.., 8, ..>: ds_write_b128 at (64k + lane), read back pixel-major with 3 x ds_read_b128 at the
+// conflict-free 12-dword lane stride, 3x3 matrix, three 16-byte plane stores.  width % 8 == 0 keeps every row 16-byte aligned and
+// every lane either whole or idle.
+#ifndef AG_RGB16_NS
+#define AG_RGB16_NS 1      /* 2 and 4 measured 2-9 % slower on every geometry (profiles/r02/rgb16_streaming_geometry.txt) */
+#endif
+template <int NS>      // spans per wave trip: all NS x 3 loads are issued before the first is consumed
+__global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr444_hot(const WriteParams p)
+{
+    constexpr int PXL = 8, K = 3, SPAN_PX = 512, SPAN_DW = SPAN_PX * 3 / 2, LDW = 12;
+    __shared__ __attribute__((aligned(16))) uint32_t strip[kStreamWaves][SPAN_DW];
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    uint32_t* my = strip[wave];
+    const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;
+    const uint32_t total = spans_per_row * (uint32_t)p.nrows;
+    for (uint32_t s0 = (blockIdx.x * kStreamWaves + wave) * NS; s0 < total; s0 += gridDim.x * kStreamWaves * NS) {
+        u32x4 cur[NS][K];
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+            const uint32_t sidx = min(s0 + n, total - 1);                              // a trip's second span may not exist: reload the last one
+            const uint32_t r = sidx / spans_per_row;
+            const uint32_t sx = sidx - r * spans_per_row;
+            const int span_v = min(SPAN_PX, p.width - (int)sx * SPAN_PX) * 3 / 8;      // 16-byte vectors in this span (span_px is a multiple of 8)
+            const u32x4* sp = reinterpret_cast<const u32x4*>(p.src + (long long)r * p.src_row_bytes) + (long long)sx * (64 * K);
+#pragma unroll
+            for (int k = 0; k < K; ++k) cur[n][k] = __builtin_nontemporal_load(sp + min(64 * k + lane, span_v - 1));   // branch-free mask, as in the f32 kernel
+        }
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+            const uint32_t sidx = s0 + n;
+            if (sidx >= total) break;                                                  // wave-uniform
+            const uint32_t r = sidx / spans_per_row;
+            const uint32_t sx = sidx - r * spans_per_row;
+            const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                uint32_t o[4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const uint32_t w = h == 0 ? cur[n][k].x : h == 1 ? cur[n][k].y : h == 2 ? cur[n][k].z : cur[n][k].w;
+                    const uint32_t lo = min(w & 0xffffu, 32768u), hi = min(w >> 16, 32768u);   // the reference reads past its LUT beyond 32768 (stage_a)
+                    o[h] = exact_rescale(lo, 32768.0f, p.maxf, p.maxv) | (exact_rescale(hi, 32768.0f, p.maxf, p.maxv) << 16);
+                }
+                reinterpret_cast<u32x4*>(my)[64 * k + lane] = u32x4{ o[0], o[1], o[2], o[3] };
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint32_t dw[LDW];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const u32x4 v = reinterpret_cast<const u32x4*>(my)[3 * lane + j];
+                dw[4 * j] = v.x; dw[4 * j + 1] = v.y; dw[4 * j + 2] = v.z; dw[4 * j + 3] = v.w;
+            }
+            __builtin_amdgcn_wave_barrier();
+            auto code = [&](int i, int c) -> uint32_t {
+                const int e = 3 * i + c;
+                return (e & 1) ? (dw[e >> 1] >> 16) : (dw[e >> 1] & 0xffffu);
+            };
+            uint32_t yv[PXL], cbv[PXL], crv[PXL];
+#pragma unroll
+            for (int i = 0; i < PXL; ++i) {
+                const uint32_t q0 = code(i, 0), q1 = code(i, 1), q2 = code(i, 2);
+                yv[i] = luma_code(p, q0, q1, q2);
+                const float R = (float)q0, G = (float)q1, B = (float)q2;
+                cbv[i] = clip_round(R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2] + p.half, p.maxv);
+                crv[i] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
+            }
+            if (PXL * lane < span_px) {
+                const long long xoff = ((long long)sx * SPAN_PX + (long long)PXL * lane) * 2;
+                u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
+                u32x4 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16), cbv[4] | (cbv[5] << 16), cbv[6] | (cbv[7] << 16) };
+                u32x4 c = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16), crv[4] | (crv[5] << 16), crv[6] | (crv[7] << 16) };
+                __builtin_nontemporal_store(a, reinterpret_cast<u32x4*>(p.dst[0] + (long long)r * p.dst_stride[0] + xoff));
+                __builtin_nontemporal_store(b, reinterpret_cast<u32x4*>(p.dst[1] + (long long)r * p.dst_stride[1] + xoff));
+                __builtin_nontemporal_store(c, reinterpret_cast<u32x4*>(p.dst[2] + (long long)r * p.dst_stride[2] + xoff));
+            }
+        }
+    }
+}
+
 // ---- RGB(A) f32 -> interleaved RRGGBB(AA) u16: the reference's own hand-off (CreateHeifImageRGBThirtyTwoBit) ------------------
 // Output sample i is a function of input sample i (RGB) or of its own pixel's float4 (RGBA): no transposition at all.  A wave
 // streams 64 x 4 float4 per trip: coalesced non-temporal 16-byte loads, the curve, 8-byte non-temporal stores at the same index.
@@ -1273,7 +1357,8 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
                         int variant, hipStream_t st, char* label)
 {
     // hot path: RGB f32 (no alpha) -> YCbCr 4:4:4 u16 with aligned rows; `variant` is a tuning word:
-    //   bit0 enable, bit1 PXL=8 (else 4), bit2 non-temporal; bits 8.. = blocks (0 = default).
+    //   bit0 enable, bit1 PXL=8 (else 4), bit2 non-temporal, bit3 take the size-gated streaming kernels at any size (tests);
+    //   bits 8.. = blocks (0 = default).
     // (8-bit documents stay on write_px: measured 0.057 vs 0.069 ms for the RGB8 copy, 0.090 vs 0.095 ms for RGBA8 premultiplied)
     if ((variant & 1) && p.icc16_clut == nullptr && depth == 16 && planes >= 3 && output == AVIFGPU_OUT_REFERENCE &&
         ((long long)p.width * planes * (depth / 8)) % 16 == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
@@ -1311,6 +1396,27 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
             default:                        AG_REF(AVIFGPU_TRANSFER_CLIP); break;
             }
 #undef AG_REF
+            return hipGetLastError();
+        }
+    }
+    // RGB16 -> u16 Y, Cb, Cr 4:4:4 (BASELINE C3).  Only for large launches: the generic kernel holds 0.76-0.80 of 8 TB/s up to ~45 Mpx
+    // and falls to 0.70-0.72 at 8192^2 / 16384^2, the streaming one holds 0.74-0.80 everywhere (+10-14 % at 8192^2, -0...4 % at
+    // 6000 x 4000; profiles/r02/rgb16_streaming_geometry.txt).  Both produce the same bytes (tests/test_gpu_kernel_equivalence.py).
+#ifndef AG_RGB16_MIN_PX
+#define AG_RGB16_MIN_PX (40LL << 20)
+#endif
+    if ((variant & 1) && p.icc16_clut == nullptr && depth == 16 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 0 && ys == 0 &&
+        ((long long)p.width * p.nrows >= AG_RGB16_MIN_PX || (variant & 8)) &&
+        (p.width % 8) == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
+        ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |
+          (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2]) & 15) == 0) {
+        const long long spans = (long long)((p.width + 511) / 512) * p.nrows;
+        if (spans == 0) return hipSuccess;
+        if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
+            long long blocks = (spans + kStreamWaves * AG_RGB16_NS - 1) / (kStreamWaves * AG_RGB16_NS);
+            if (blocks > AG_STREAM_BLOCK_CAP * 4 / kStreamWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kStreamWaves;
+            snprintf(label, kLabelBytes, "write_rgb16_ycbcr444_hot<ns=%d>", AG_RGB16_NS);
+            hipLaunchKernelGGL((write_rgb16_ycbcr444_hot<AG_RGB16_NS>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p);
             return hipGetLastError();
         }
     }

@@ -36,6 +36,11 @@ CASES = [
                                   output=pkg.OUT_REFERENCE)),
     ("write_f32_ref_stream", dict(width=333, height=4, depth=32, planes=4, bit_depth=12, transfer=pkg.TRANSFER_CLIP,
                                   alpha_state=pkg.ALPHA_PREMULTIPLIED, output=pkg.OUT_REFERENCE)),
+    ("write_rgb16_ycbcr444_hot", dict(width=1024, height=5, depth=16, planes=3, bit_depth=12, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444, **BT2020)),
+    ("write_rgb16_ycbcr444_hot", dict(width=1000, height=4, depth=16, planes=3, bit_depth=10, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444,
+                                      matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)),
+    ("write_rgb16_ycbcr444_hot", dict(width=8, height=3, depth=16, planes=3, bit_depth=12, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444,
+                                      matrix_coefficients=pkg.MATRIX_RGB_GBR)),
     ("write_int_ref_stream", dict(width=1000, height=5, depth=16, planes=3, bit_depth=12, output=pkg.OUT_REFERENCE)),
     ("write_int_ref_stream", dict(width=502, height=3, depth=16, planes=4, bit_depth=8, alpha_state=pkg.ALPHA_PREMULTIPLIED,
                                   output=pkg.OUT_REFERENCE)),
@@ -47,6 +52,7 @@ def test_specialised_kernel_equals_generic(gpu, kernel, kw):
     d = pkg.WriteDesc(**kw)
     src = harness.make_write_source(d, seed=31)
     try:
+        gpu.lib.avifgpu_set_hot_variant(1 | 2 | 4 | 8)          # bit 3: streaming kernels that the default only takes for large frames
         fast = harness.gpu_write(gpu, d, src, mem="device")
         assert kernel in gpu.last_kernel(), gpu.last_kernel()
         gpu.lib.avifgpu_set_hot_variant(0)
