@@ -304,6 +304,18 @@ AG_DEV void store_dwords(uint8_t* p, const uint32_t (&d)[ND])
 template <int NDW> struct WaveSpan {
     static constexpr int VW = (NDW % 4 == 0) ? 4 : ((NDW % 2 == 0) ? 2 : 1);   // dwords per transfer
     static constexpr int NTR = NDW / VW;                                        // transfers per lane
+    // Lane stride of the lane-major side, in dwords.  A lane-major access of VW dwords is conflict-free when consecutive lanes land in
+    // distinct VW-dword bank slots, i.e. when STRIDE / VW is odd.  NDW = 16 and 32 (the RGBA16 and RGBA f32 4:2:0 footprints) put
+    // every fourth / eighth lane on the same banks and are padded by one slot: RGBA16 4:2:0 0.165 -> 0.160 ms, RGBA f32 4:2:0
+    // 0.266 -> 0.253 ms at 8192^2.  NDW = 8 and 24 (two-way at worst) measured slower / no different with the pad and keep the
+    // dense layout (profiles/r02/read_variants_ab.txt).
+#ifndef AG_SPAN_PAD
+#define AG_SPAN_PAD 1
+#endif
+    static constexpr int STRIDE = (AG_SPAN_PAD && (NTR % 4 == 0)) ? NDW + VW : NDW;
+    static constexpr int STRIP_DW = 64 * STRIDE;                                // dwords of LDS per wave
+    // physical dword of logical dword e of the span (e = lane * NDW + k in lane-major terms)
+    static __device__ __forceinline__ int phys(int e) { return STRIDE == NDW ? e : (e / NDW) * STRIDE + (e % NDW); }
 };
 
 // `w` / `r` are VW*4-byte aligned by construction; tell the compiler so it emits ds_*_b64 / b128, not dword pairs.
@@ -337,11 +349,11 @@ AG_DEV void wave_span_load(uint32_t* strip, int lane, const uint8_t* span, int s
 #pragma clang loop vectorize(disable) unroll(disable)
             for (int k = 0; k < span_bytes - off; ++k) v[k >> 2] |= (uint32_t)span[off + k] << (8 * (k & 3));
         }
-        lds_put<VW>(strip + (j * 64 + lane) * VW, v);
+        lds_put<VW>(strip + WaveSpan<NDW>::phys((j * 64 + lane) * VW), v);
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int j = 0; j < NTR; ++j) lds_get<VW>(strip + lane * NDW + j * VW, &out[j * VW]);
+    for (int j = 0; j < NTR; ++j) lds_get<VW>(strip + lane * WaveSpan<NDW>::STRIDE + j * VW, &out[j * VW]);
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -352,13 +364,13 @@ AG_DEV void wave_span_store(uint32_t* strip, int lane, bool active, const uint32
     constexpr int VW = WaveSpan<NDW>::VW, NTR = WaveSpan<NDW>::NTR;
     if (active) {
 #pragma unroll
-        for (int j = 0; j < NTR; ++j) lds_put<VW>(strip + lane * NDW + j * VW, &in[j * VW]);
+        for (int j = 0; j < NTR; ++j) lds_put<VW>(strip + lane * WaveSpan<NDW>::STRIDE + j * VW, &in[j * VW]);
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int j = 0; j < NTR; ++j) {
         const int off = (j * 64 + lane) * (VW * 4);
-        const uint32_t* rd = strip + (j * 64 + lane) * VW;
+        const uint32_t* rd = strip + WaveSpan<NDW>::phys((j * 64 + lane) * VW);
         if (off + VW * 4 <= span_bytes) {
             uint32_t v[4];
             lds_get<VW>(rd, v);

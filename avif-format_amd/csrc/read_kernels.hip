@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint32_t* strip = nullptr;
-    if constexpr (ALIGNED && ND_OUT > 4) strip = reinterpret_cast<uint32_t*>(lut) + lut_floats + wave * (64 * ND_OUT);
+    if constexpr (ALIGNED && ND_OUT > 4) strip = reinterpret_cast<uint32_t*>(lut) + lut_floats + wave * WaveSpan<ND_OUT>::STRIP_DW;
 
     const int gxn = (p.width + PXT - 1) / PXT;
     const int gyn = (p.nrows + VR - 1) >> YS;
@@ -470,8 +470,15 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
     const uint32_t wstep = gridDim.x * 4;
     uint32_t wv = blockIdx.x * 4 + wave;
     Group cur;
-    if (AG_READ_PREFETCH && wv < total_waves) load_group(wv, cur);
-    if constexpr (LUT) {            // (issuing the first group's loads before this copy was measured: no difference)
+    // Gray kernels issue their first group's plane loads BEFORE the table copy and its barrier (a workgroup lives for one or a few
+    // groups, so the copy otherwise sits in front of every group's HBM latency): -3 % on the three mono rows.  The colour kernels
+    // measured 3-8 % SLOWER that way (their footprints are larger; the early loads cost registers across the copy) and load after it.
+    // Forcing occupancy with amdgpu_waves_per_eu was measured too: 5 or 6 waves spill the 4:2:0 kernels to 2-3.5x their time.
+    // (profiles/r02/read_variants_ab.txt)
+    constexpr bool EARLY = CS == kCsMono;
+    if ((AG_READ_PREFETCH || EARLY) && wv < total_waves) load_group(wv, cur);
+    bool loaded = EARLY;
+    if constexpr (LUT) {
         typedef float f4 __attribute__((ext_vector_type(4)));
         const f4* src4 = reinterpret_cast<const f4*>(p.tables);
         f4* dst4 = reinterpret_cast<f4*>(lut);
@@ -489,7 +496,7 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
 
         Group nxt;
         if constexpr (AG_READ_PREFETCH) { if (wv + wstep < total_waves) load_group(wv + wstep, nxt); }   // in flight during the decode below
-        else load_group(wv, cur);
+        else { if (!loaded) load_group(wv, cur); loaded = false; }
 
         constexpr bool PACKED8 = AG_R8_PACKED && DEPTH == 8 && CS == kCsYcc && ALIGNED && ND_OUT > 4;
         if constexpr (PACKED8) {
@@ -704,7 +711,7 @@ static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, char* lab
     uintptr_t bits = reinterpret_cast<uintptr_t>(p.dst) | (uintptr_t)p.dst_row_bytes;
     for (int pl = 0; pl < 4; ++pl) if (p.src[pl]) bits |= reinterpret_cast<uintptr_t>(p.src[pl]) | (uintptr_t)p.src_stride[pl];
     const bool aligned = (bits & 15) == 0;      // => branch-free vector loads + LDS-transposed coalesced stores
-    const size_t lds = lut_bytes + ((aligned && ND_OUT > 4) ? (size_t)4 * 64 * ND_OUT * sizeof(uint32_t) : 0);
+    const size_t lds = lut_bytes + ((aligned && ND_OUT > 4) ? (size_t)4 * WaveSpan<ND_OUT>::STRIP_DW * sizeof(uint32_t) : 0);
     snprintf(label, kLabelBytes, "read_px<cs=%d,depth=%d,alpha=%d,xs=%d,ys=%d,transfer=%d,aligned=%d>", CS, DEPTH, (int)ALPHA, XS, YS,
              TRANSFER, (int)aligned);
     ReadParams q = p;

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
     // through a wave-private LDS strip (ALIGNED instantiation; the unaligned one keeps per-lane accesses). ----------
     constexpr int NDO = (OUT == kOutRefColor) ? PXT * PLANES * DSZ / 4 : 1;     // interleaved-output dwords per lane per row
     constexpr int NDS = NDO;
-    __shared__ __attribute__((aligned(16))) uint32_t strips[ALIGNED ? 4 : 1][ALIGNED ? 64 * NDS : 1];
+    __shared__ __attribute__((aligned(16))) uint32_t strips[ALIGNED ? 4 : 1][ALIGNED ? WaveSpan<NDS>::STRIP_DW : 1];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint32_t* strip = strips[ALIGNED ? wave : 0];
