@@ -935,19 +935,24 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot(con
 #ifndef AG_RGBA_HOT_PXL
 #define AG_RGBA_HOT_PXL 4
 #endif
+// 256-thread workgroups for this one: 16384^2 0.997 -> 0.977 ms (the three-plane kernels prefer 128, profiles/r02/stream_block_size.txt)
+#ifndef AG_RGBA_STREAM_BLOCK
+#define AG_RGBA_STREAM_BLOCK 256
+#endif
+constexpr int kRgbaWaves = AG_RGBA_STREAM_BLOCK / 64;
 template <int TRANSFER>
-__global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba32_ycbcra444_hot(const WriteParams p)
+__global__ __launch_bounds__(AG_RGBA_STREAM_BLOCK) void write_rgba32_ycbcra444_hot(const WriteParams p)
 {
     constexpr int PXL = AG_RGBA_HOT_PXL, SPAN_PX = 64 * PXL;
     constexpr int LSTRIDE = PXL == 4 ? 12 : 20;                        // dwords per lane in the strip (2 * PXL used + 4 pad)
-    __shared__ __attribute__((aligned(16))) uint32_t strip[kStreamWaves][64 * LSTRIDE];
+    __shared__ __attribute__((aligned(16))) uint32_t strip[kRgbaWaves][64 * LSTRIDE];
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     uint32_t* my = strip[wave];
 
     const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;    // any width: the last span of a row is masked
     const uint32_t total = spans_per_row * (uint32_t)p.nrows;
-    for (uint32_t sidx = blockIdx.x * kStreamWaves + wave; sidx < total; sidx += gridDim.x * kStreamWaves) {
+    for (uint32_t sidx = blockIdx.x * kRgbaWaves + wave; sidx < total; sidx += gridDim.x * kRgbaWaves) {
         const uint32_t r = sidx / spans_per_row;
         const uint32_t sx = sidx - r * spans_per_row;
         const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);
@@ -1431,14 +1436,14 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
         const long long spans = (long long)((p.width + 64 * AG_RGBA_HOT_PXL - 1) / (64 * AG_RGBA_HOT_PXL)) * p.nrows;
         if (spans == 0) return hipSuccess;
         if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
-            long long blocks = (spans + kStreamWaves - 1) / kStreamWaves;
-            if (blocks > AG_RGBA_BLOCK_CAP * 4 / kStreamWaves) blocks = AG_RGBA_BLOCK_CAP * 4 / kStreamWaves;
+            long long blocks = (spans + kRgbaWaves - 1) / kRgbaWaves;
+            if (blocks > AG_RGBA_BLOCK_CAP * 4 / kRgbaWaves) blocks = AG_RGBA_BLOCK_CAP * 4 / kRgbaWaves;
             snprintf(label, kLabelBytes, "write_rgba32_ycbcra444_hot<transfer=%d>", p.transfer);
             switch (p.transfer) {
-            case AVIFGPU_TRANSFER_PQ:       hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<AVIFGPU_TRANSFER_PQ>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); break;
-            case AVIFGPU_TRANSFER_HLG:      hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<AVIFGPU_TRANSFER_HLG>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); break;
-            case AVIFGPU_TRANSFER_SMPTE428: hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<AVIFGPU_TRANSFER_SMPTE428>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); break;
-            default:                        hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<AVIFGPU_TRANSFER_CLIP>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); break;
+            case AVIFGPU_TRANSFER_PQ:       hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<AVIFGPU_TRANSFER_PQ>), dim3((int)blocks), dim3(AG_RGBA_STREAM_BLOCK), 0, st, p); break;
+            case AVIFGPU_TRANSFER_HLG:      hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<AVIFGPU_TRANSFER_HLG>), dim3((int)blocks), dim3(AG_RGBA_STREAM_BLOCK), 0, st, p); break;
+            case AVIFGPU_TRANSFER_SMPTE428: hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<AVIFGPU_TRANSFER_SMPTE428>), dim3((int)blocks), dim3(AG_RGBA_STREAM_BLOCK), 0, st, p); break;
+            default:                        hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<AVIFGPU_TRANSFER_CLIP>), dim3((int)blocks), dim3(AG_RGBA_STREAM_BLOCK), 0, st, p); break;
             }
             return hipGetLastError();
         }

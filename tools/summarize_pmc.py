@@ -2,7 +2,7 @@
 """Turn rocprofv3 outputs of `tools/bench_configs.py` runs into one table per configuration.
 
 bench_configs.py launches every configuration's kernel exactly LAUNCHES times back to back, so the dispatches that match
-write_px|read_px|write_rgb32 (in dispatch order) split into consecutive chunks of LAUNCHES, one per printed configuration.
+write_px|read_px|write_rgb32|write_rgb16|... (in dispatch order) split into consecutive chunks of LAUNCHES, one per printed configuration.
 Inputs: the kernel-trace CSV and the two counter-collection CSVs (FETCH_SIZE, WRITE_SIZE: separate passes, as the MI355X guide
 prescribes) plus the JSON lines bench_configs.py printed in the kernel-trace run.
 gfx950 correction: FETCH_SIZE counts 64-byte units in KiB/2 -> doubled; WRITE_SIZE is KiB as is (MI355X_MICROARCH.md, HBM section)."""
@@ -13,7 +13,7 @@ import re
 import sys
 
 LAUNCHES = 210
-PAT = re.compile(r"write_px|read_px|write_rgb32|write_rgba32|write_f32_ref|write_int_ref")
+PAT = re.compile(r"write_px|read_px|write_rgb32|write_rgb16|write_rgba32|write_f32_ref|write_int_ref")
 
 
 def rows(path_glob):
