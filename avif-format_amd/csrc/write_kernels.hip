@@ -1099,6 +1099,96 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr444_hot(cons
     }
 }
 
+// ... and its 4:2:2 / 4:2:0 sibling (a 16-bit photograph saved as 10/12-bit 4:2:0 AVIF): write_rgb32_ycbcr_sub_hot's structure with the
+// 16-bit front end.  A wave owns 512 pixels on 1 or 2 rows; both rows' loads are in flight before any arithmetic.
+template <int YS>
+__global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr_sub_hot(const WriteParams p)
+{
+    constexpr int PXL = 8, K = 3, SPAN_PX = 512, SPAN_DW = SPAN_PX * 3 / 2, LDW = 12, VR = 1 << YS;
+    __shared__ __attribute__((aligned(16))) uint32_t strip[kStreamWaves][SPAN_DW];
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    uint32_t* my = strip[wave];
+    const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;
+    const uint32_t groups = ((uint32_t)p.nrows + VR - 1) >> YS;
+    const uint32_t total = spans_per_row * groups;
+    for (uint32_t sidx = blockIdx.x * kStreamWaves + wave; sidx < total; sidx += gridDim.x * kStreamWaves) {
+        const uint32_t gy = sidx / spans_per_row;
+        const uint32_t sx = sidx - gy * spans_per_row;
+        const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);             // a multiple of 8
+        const int span_v = span_px * 3 / 8;
+        u32x4 v[VR][K];
+#pragma unroll
+        for (int vr = 0; vr < VR; ++vr) {
+            const int r = min((int)(gy * VR) + vr, p.rows_to_end - 1);             // bottom edge: replicate the last IMAGE row
+            const u32x4* sp = reinterpret_cast<const u32x4*>(p.src + (long long)r * p.src_row_bytes) + (long long)sx * (64 * K);
+#pragma unroll
+            for (int k = 0; k < K; ++k) v[vr][k] = __builtin_nontemporal_load(sp + min(64 * k + lane, span_v - 1));
+        }
+        uint32_t dw[VR][LDW];
+#pragma unroll
+        for (int vr = 0; vr < VR; ++vr) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                uint32_t o[4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const uint32_t w = h == 0 ? v[vr][k].x : h == 1 ? v[vr][k].y : h == 2 ? v[vr][k].z : v[vr][k].w;
+                    const uint32_t lo = min(w & 0xffffu, 32768u), hi = min(w >> 16, 32768u);
+                    o[h] = exact_rescale(lo, 32768.0f, p.maxf, p.maxv) | (exact_rescale(hi, 32768.0f, p.maxf, p.maxv) << 16);
+                }
+                reinterpret_cast<u32x4*>(my)[64 * k + lane] = u32x4{ o[0], o[1], o[2], o[3] };
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const u32x4 t = reinterpret_cast<const u32x4*>(my)[3 * lane + j];
+                dw[vr][4 * j] = t.x; dw[vr][4 * j + 1] = t.y; dw[vr][4 * j + 2] = t.z; dw[vr][4 * j + 3] = t.w;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        auto code = [&](int vr, int i, int c) -> uint32_t {
+            const int e = 3 * i + c;
+            return (e & 1) ? (dw[vr][e >> 1] >> 16) : (dw[vr][e >> 1] & 0xffffu);
+        };
+        const bool mine = PXL * lane < span_px;                                    // whole lane or idle (width % 8 == 0)
+        const long long xoff = ((long long)sx * SPAN_PX + (long long)PXL * lane) * 2;
+#pragma unroll
+        for (int vr = 0; vr < VR; ++vr) {
+            const int r = (int)(gy * VR) + vr;
+            if (r >= p.nrows) continue;                                            // odd last row of the tile: replicated for chroma only
+            uint32_t yv[PXL];
+#pragma unroll
+            for (int i = 0; i < PXL; ++i) yv[i] = luma_code(p, code(vr, i, 0), code(vr, i, 1), code(vr, i, 2));
+            if (mine) {
+                u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
+                __builtin_nontemporal_store(a, reinterpret_cast<u32x4*>(p.dst[0] + (long long)r * p.dst_stride[0] + xoff));
+            }
+        }
+        uint32_t cbv[4], crv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i0 = 2 * j;
+            constexpr int v1 = YS ? 1 : 0;
+            float R = (float)code(0, i0, 0), G = (float)code(0, i0, 1), B = (float)code(0, i0, 2);
+            if (!p.nearest) {
+                R = (R + (float)code(0, i0 + 1, 0) + (float)code(v1, i0, 0) + (float)code(v1, i0 + 1, 0)) * 0.25f;
+                G = (G + (float)code(0, i0 + 1, 1) + (float)code(v1, i0, 1) + (float)code(v1, i0 + 1, 1)) * 0.25f;
+                B = (B + (float)code(0, i0 + 1, 2) + (float)code(v1, i0, 2) + (float)code(v1, i0 + 1, 2)) * 0.25f;
+            }
+            cbv[j] = clip_round(R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2] + p.half, p.maxv);
+            crv[j] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
+        }
+        if (mine) {
+            const long long coff = ((long long)sx * (SPAN_PX / 2) + 4LL * lane) * 2;
+            u32x2 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16) };
+            u32x2 c = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16) };
+            __builtin_nontemporal_store(b, reinterpret_cast<u32x2*>(p.dst[1] + (long long)gy * p.dst_stride[1] + coff));
+            __builtin_nontemporal_store(c, reinterpret_cast<u32x2*>(p.dst[2] + (long long)gy * p.dst_stride[2] + coff));
+        }
+    }
+}
+
 // ---- RGB(A) f32 -> interleaved RRGGBB(AA) u16: the reference's own hand-off (CreateHeifImageRGBThirtyTwoBit) ------------------
 // Output sample i is a function of input sample i (RGB) or of its own pixel's float4 (RGBA): no transposition at all.  A wave
 // streams 64 x 4 float4 per trip: coalesced non-temporal 16-byte loads, the curve, 8-byte non-temporal stores at the same index.
@@ -1422,6 +1512,25 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
             if (blocks > AG_STREAM_BLOCK_CAP * 4 / kStreamWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kStreamWaves;
             snprintf(label, kLabelBytes, "write_rgb16_ycbcr444_hot<ns=%d>", AG_RGB16_NS);
             hipLaunchKernelGGL((write_rgb16_ycbcr444_hot<AG_RGB16_NS>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p);
+            return hipGetLastError();
+        }
+    }
+    // RGB16 -> u16 Y, Cb, Cr 4:2:2 / 4:2:0.  Taken where it wins (profiles/r02/rgb16_streaming_geometry.txt): rows of whole spans
+    // (8192: +9 %, 4096: +5 %, 6144 / 6656: +2-3 %); a ragged last span per row costs it 4-6 % against the generic kernel
+    // (6000, 7952 wide), so those stay generic.  Same bytes either way.
+    if ((variant & 1) && p.icc16_clut == nullptr && depth == 16 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 1 &&
+        ((p.width % 512) == 0 || (variant & 8)) &&
+        (p.width % 8) == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
+        ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |
+          (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2]) & 15) == 0) {
+        const long long spans = (long long)((p.width + 511) / 512) * ((p.nrows + (1 << ys) - 1) >> ys);
+        if (spans == 0) return hipSuccess;
+        if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
+            long long blocks = (spans + kStreamWaves - 1) / kStreamWaves;
+            if (blocks > AG_STREAM_BLOCK_CAP * 4 / kStreamWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kStreamWaves;
+            snprintf(label, kLabelBytes, "write_rgb16_ycbcr_sub_hot<ys=%d>", ys);
+            if (ys) hipLaunchKernelGGL((write_rgb16_ycbcr_sub_hot<1>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p);
+            else hipLaunchKernelGGL((write_rgb16_ycbcr_sub_hot<0>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p);
             return hipGetLastError();
         }
     }
