@@ -6,8 +6,9 @@
 namespace avifgpu {
 
 // Tuning word of the dominant kernel (RGB f32 -> curve -> YCbCr 4:4:4 u16), see launch_write():
-//   bit0 enable the streaming kernels, bit1 8 px/lane (else 4), bit2 non-temporal loads+stores, bits 8.. = block cap (0 = default).
-//   (bits 3 and 4 selected a register-prefetch and an XCD-contiguous variant in round 1; both lost and were removed.)
+//   bit0 enable the streaming kernels, bit1 8 px/lane (else 4), bit2 non-temporal loads+stores, bit3 take the geometry-gated
+//   streaming kernels (RGB16) whatever the frame size (tests use it to reach them on small frames), bits 8.. = block cap
+//   (0 = default).  (Bits 3 and 4 selected a register-prefetch and an XCD-contiguous variant in round 1; both lost and were removed.)
 enum : int { kHotDefault = 1 | 2 | 4 };
 
 struct WriteParams {
