@@ -352,8 +352,13 @@ template <bool DST16, int PLANES, int XS, int ICC = 0> struct WriteShape {
     static constexpr int PXT = NC << XS;
 };
 
+// Workgroup size of the generic write kernel (its waves share only the per-workgroup tables).
+#ifndef AG_WPX_BLOCK
+#define AG_WPX_BLOCK 256
+#endif
+constexpr int kWpxWaves = AG_WPX_BLOCK / 64;
 template <int DEPTH, int PLANES, int OUT, bool DST16, int XS, int YS, int TRANSFER, bool ALIGNED, int ICC = 0>
-__global__ __launch_bounds__(256) void write_px(const WriteParams p)
+__global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
 {
     constexpr int PXT = WriteShape<DST16, PLANES, XS, ICC>::PXT;
     constexpr int VR = 1 << YS;
@@ -367,7 +372,7 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
     // through a wave-private LDS strip (ALIGNED instantiation; the unaligned one keeps per-lane accesses). ----------
     constexpr int NDO = (OUT == kOutRefColor) ? PXT * PLANES * DSZ / 4 : 1;     // interleaved-output dwords per lane per row
     constexpr int NDS = NDO;
-    __shared__ __attribute__((aligned(16))) uint32_t strips[ALIGNED ? 4 : 1][ALIGNED ? WaveSpan<NDS>::STRIP_DW : 1];
+    __shared__ __attribute__((aligned(16))) uint32_t strips[ALIGNED ? kWpxWaves : 1][ALIGNED ? WaveSpan<NDS>::STRIP_DW : 1];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint32_t* strip = strips[ALIGNED ? wave : 0];
@@ -377,8 +382,8 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
     __shared__ int32_t icc8_s1[ICC8 ? 768 : 1];
     __shared__ __attribute__((aligned(16))) uint8_t icc8_s2[ICC8 ? 16400 : 16];
     if constexpr (ICC8) {
-        for (int i = threadIdx.x; i < 768; i += 256) icc8_s1[i] = p.icc8_s1[i];
-        for (int i = threadIdx.x; i < 16388 / 4; i += 256)
+        for (int i = threadIdx.x; i < 768; i += AG_WPX_BLOCK) icc8_s1[i] = p.icc8_s1[i];
+        for (int i = threadIdx.x; i < 16388 / 4; i += AG_WPX_BLOCK)
             reinterpret_cast<uint32_t*>(icc8_s2)[i] = reinterpret_cast<const uint32_t*>(p.icc8_s2)[i];
         __syncthreads();
     }
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
     __shared__ uint16_t lut8[DEPTH == 8 ? 256 : 2];
     if constexpr (DEPTH == 8) {
         if (p.maxv > 255) {
-            lut8[threadIdx.x] = (uint16_t)exact_rescale(threadIdx.x, 255.0f, p.maxf, p.maxv);
+            for (int i = threadIdx.x; i < 256; i += AG_WPX_BLOCK) lut8[i] = (uint16_t)exact_rescale(i, 255.0f, p.maxf, p.maxv);
             __syncthreads();
         }
     }
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(256) void write_px(const WriteParams p)
     const uint32_t wpr = (uint32_t)(gxn + 63) >> 6;        // waves per row group
     const uint32_t total_waves = wpr * (uint32_t)gyn;      // < 2^31 (host checks)
 
-    for (uint32_t wv = blockIdx.x * 4 + wave; wv < total_waves; wv += gridDim.x * 4) {
+    for (uint32_t wv = blockIdx.x * kWpxWaves + wave; wv < total_waves; wv += gridDim.x * kWpxWaves) {
         const int gy = (int)(wv / wpr);
         const int wx = (int)(wv - (uint32_t)gy * wpr);
         const int gx = wx * 64 + lane;
@@ -1316,7 +1321,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_int_ref_stream(const Wr
 #endif
 static inline int grid_for(long long threads_needed)
 {
-    long long blocks = (threads_needed + 255) / 256;
+    long long blocks = (threads_needed + AG_WPX_BLOCK - 1) / AG_WPX_BLOCK;
 #ifndef AG_WRITE_BLOCK_CAP
 #define AG_WRITE_BLOCK_CAP (256LL * 512)
 #endif
@@ -1354,8 +1359,8 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, char* label)
             snprintf(label, kLabelBytes, "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=3>",
                      DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned);
             const int blocks = grid_for(groups) > 2048 ? 2048 : grid_for(groups);     // tables are copied per block
-            if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 3>), dim3(blocks), dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 3>), dim3(blocks), dim3(256), 0, st, p);
+            if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 3>), dim3(blocks), dim3(AG_WPX_BLOCK), 0, st, p);
+            else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 3>), dim3(blocks), dim3(AG_WPX_BLOCK), 0, st, p);
             return hipGetLastError();
         }
     }
@@ -1363,8 +1368,8 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, char* label)
         if (p.icc16_clut != nullptr) {              // 16-bit CLUT ICC transform requested
             snprintf(label, kLabelBytes, "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=5>",
                      DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned);
-            if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 5>), dim3(grid_for(groups)), dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 5>), dim3(grid_for(groups)), dim3(256), 0, st, p);
+            if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 5>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
+            else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 5>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
             return hipGetLastError();
         }
     }
@@ -1376,8 +1381,8 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, char* label)
                 if constexpr (TRANSFER == 3) {
                     snprintf(label, kLabelBytes, "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=4>",
                              DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned);
-                    if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 4>), dim3(grid_for(groups)), dim3(256), 0, st, p);
-                    else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 4>), dim3(grid_for(groups)), dim3(256), 0, st, p);
+                    if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 4>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
+                    else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 4>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
                     return hipGetLastError();
                 } else {
                     return hipErrorInvalidValue;    // rejected earlier by fill_write_params
@@ -1386,17 +1391,17 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, char* label)
             snprintf(label, kLabelBytes, "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=%d>",
                      DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned, linear ? 1 : 2);
             if (linear) {
-                if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 1>), dim3(grid_for(groups)), dim3(256), 0, st, p);
-                else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 1>), dim3(grid_for(groups)), dim3(256), 0, st, p);
+                if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 1>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
+                else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 1>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
             } else {
-                if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 2>), dim3(grid_for(groups)), dim3(256), 0, st, p);
-                else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 2>), dim3(grid_for(groups)), dim3(256), 0, st, p);
+                if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 2>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
+                else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 2>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
             }
             return hipGetLastError();
         }
     }
-    if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true>), dim3(grid_for(groups)), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false>), dim3(grid_for(groups)), dim3(256), 0, st, p);
+    if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
+    else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
     return hipGetLastError();
 }
 
