@@ -291,8 +291,11 @@ int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const Wr
             p.icc_trc_type[c] = g_icc->trc_type[c];
             p.icc_trc_linear[c] = g_icc->trc_type[c] == 1 && g_icc->trc_params[c][0] == 1.0;
             normalise_trc(g_icc->trc_type[c], g_icc->trc_params[c], p.icc_trc[c]);
+            const float gh = (float)p.icc_trc[c][0];
+            p.icc_trc_f[c][0] = gh; p.icc_trc_f[c][1] = (float)(p.icc_trc[c][0] - (double)gh);
+            for (int k = 1; k < 8; ++k) p.icc_trc_f[c][k + 1] = (float)p.icc_trc[c][k];
         }
-        for (int k = 0; k < 9; ++k) p.icc_m[k] = g_icc->matrix[k];
+        for (int k = 0; k < 9; ++k) { p.icc_m[k] = g_icc->matrix[k]; p.icc_m_f[k] = (float)g_icc->matrix[k]; }
         if (g_icc->out_curve != 0) {
             if (g_icc->out_curve != 4) return fail(AVIFGPU_formatBadParameters, "bad ICC output curve");
             // the reference converts to sRGB only for the SDR save of a 32-bit document (ColorProfileConversion.cpp:118-123)
@@ -301,6 +304,15 @@ int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const Wr
             for (int k = 0; k < 8; ++k) p.icc_out_p[k] = g_icc->out_params[k];
             p.icc_out_rcp[0] = std::fabs(g_icc->out_params[1]) < 0.0001 ? 0.0 : 1.0 / g_icc->out_params[1];
             p.icc_out_rcp[1] = std::fabs(g_icc->out_params[3]) < 0.0001 ? 0.0 : 1.0 / g_icc->out_params[3];
+            const double ig = p.icc_out_p[6];                  // 1/g
+            const float ih = (float)ig;
+            p.icc_out_f[0] = ih; p.icc_out_f[1] = (float)(ig - (double)ih);
+            p.icc_out_f[2] = (float)p.icc_out_p[2];
+            p.icc_out_f[3] = (float)p.icc_out_rcp[0];
+            p.icc_out_f[4] = (float)p.icc_out_rcp[1];
+            p.icc_out_f[5] = (float)p.icc_out_p[5];
+            p.icc_out_f[6] = (std::fabs(p.icc_out_p[0]) < 0.0001 || std::fabs(p.icc_out_p[1]) < 0.0001) ? 0.0f : 1.0f;
+            p.icc_out_f[7] = std::fabs(p.icc_out_p[3]) < 0.0001 ? 0.0f : 1.0f;
         }
     }
     if (g_icc16) {

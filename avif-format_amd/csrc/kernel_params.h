@@ -40,6 +40,11 @@ struct WriteParams {
     double  icc_m[9];
     double  icc_out_p[8];
     double  icc_out_rcp[2];      // 1/a, 1/c of the output curve (0 where the coefficient is ~0)
+    // the same curves for the single-precision evaluation (icc_trc_f / icc_inv4_f): exponents as float pairs (hi + lo), the rest rounded
+    float   icc_trc_f[3][9];     // gh, gl, a, b, thr, c, f, add, nonpos
+    float   icc_out_f[9];        // (1/g)h, (1/g)l, b, 1/a, 1/c, break point, [g,a usable], [c usable], 0
+    float   icc_m_f[9];          // the matrix rounded to float (single-precision variant 2)
+    float   icc_pad_f[1];
     // 8-bit matrix-shaper transform (avifgpu_icc_shaper8): tables live in device memory, matrix in kernarg
     const int32_t* icc8_s1;      // [3][256] 1.14 fixed
     const uint8_t* icc8_s2;      // [16385] 8-bit output curve (identical for R,G,B: the destination is sRGB)

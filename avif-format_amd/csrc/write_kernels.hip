@@ -24,6 +24,22 @@
 
 namespace avifgpu {
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#ifndef AG_ICC_F32
+#define AG_ICC_F32 1
+#endif
+#ifndef AG_ICC4_F32
+#define AG_ICC4_F32 0
+#endif
+#ifndef AG_ICC1_HOT
+#define AG_ICC1_HOT 1
+#endif
+#ifndef AG_ICC_MATRIX_F32
+#define AG_ICC_MATRIX_F32 1      /* with the single-precision curves: the 3x3 in fp32 FMAs as well (-6 %, same exact-match rate) */
+#endif
+// which parametric ICC variants evaluate their curves in single precision (icc_pow32) instead of FP64 (icc_pow_pos)
+template <int ICC> struct IccF32 { static constexpr bool value = (ICC == 2 && AG_ICC_F32) || (ICC == 4 && AG_ICC4_F32); };
+
 // One linear-light sample -> integer code: transfer curve, scale by maxValue, clamp, TRUNCATE
 // (reference WriteHeifImage.cpp:1072-1095).
 template <int TRANSFER>
@@ -85,6 +101,90 @@ AG_DEV void icc_pow_table_fill(double* L, float* c, int tid)
         c[tid] = cf;
         L[tid] = -log2((double)cf);
     }
+}
+
+// ---- the same pow in single precision with a double-float exponent (AG_ICC_F32) ------------------------------------------------
+// The FP64 version above is ~25 instructions on paper and ~85 in the ISA: every double is a register pair (v_mov pairs, two
+// v_cndmask per select), and each float <-> double crossing is a conversion.  What needs more than 24 bits is only the product
+// t = g * log2(x) (|t| up to ~50 while 2^t must be good to 1e-7), so that alone is carried as an unevaluated float pair:
+//     log2(x) = s + lo,   s = RN(e + Lh) with its rounding error recovered (Fast2Sum: |e| >= 1 > |Lh|, or e == 0 and the sum is
+//                          exact),  lo = Ll + log2(1 + r) + that error           (Lh + Ll = -log2(c) to 2^-48)
+//     t       = th + tl,  th = RN(gh * s),  tl = fma(gh, s, -th) + gh * lo + gl * s      (gh + gl = the exponent to 2^-48)
+//     x^g     = ldexp(v_exp_f32((th - rint(th)) + tl), rint(th))                          (th - rint(th) is exact)
+// 28 fp32 instructions, one 16-byte LDS read, one transcendental; same accuracy class as the FP64 form (the error is v_exp_f32's ulp
+// and the polynomial's 3e-10).  Arguments are floats: a*R + b is rounded to float first (6e-8 relative, x g on the result).
+struct IccPowTableF { const f32x4_t* t; };          // LDS, 128 entries of {c, Lh, Ll, 0}
+AG_DEV float icc_pow32(const IccPowTableF& T, float x, float gh, float gl)
+{
+    const float xf = fmaxf(x, 1e-37f);                         // x <= 1e-37 (incl. <= 0 and NaN) evaluates on 1e-37 and is zeroed at the end
+    const float m = __builtin_amdgcn_frexp_mantf(xf);          // [0.5, 1)
+    const float ef = (float)__builtin_amdgcn_frexp_expf(xf);
+    const f32x4_t e4 = T.t[(__float_as_uint(m) >> 16) & (kIccPowBins - 1)];
+    const float r = __builtin_fmaf(m, e4.x, -1.0f);
+    float p = __builtin_fmaf(r, 0.2885390081777927f, -0.36067376022224085f);
+    p = __builtin_fmaf(r, p, 0.4808983469629878f);
+    p = __builtin_fmaf(r, p, -0.7213475204444817f);
+    p = __builtin_fmaf(r, p, 1.4426950408889634f);
+    p = r * p;                                                 // log2(1 + r)
+    const float s = ef + e4.y;
+    const float lo = (e4.z + p) + (e4.y - (s - ef));
+    const float th = gh * s;
+    const float tl = __builtin_fmaf(gl, s, __builtin_fmaf(gh, lo, __builtin_fmaf(gh, s, -th)));
+    const float n = __builtin_rintf(th);
+    const float v = __builtin_amdgcn_ldexpf(nat_exp2((th - n) + tl), (int)n);
+    return x > 1e-37f ? v : 0.0f;
+}
+AG_DEV void icc_pow_table_fill_f(f32x4_t* t, int tid)
+{
+    if (tid < kIccPowBins) {
+        const double centre = 0.5 + ((double)tid + 0.5) * (1.0 / 256.0);
+        const float cf = (float)(1.0 / centre);
+        const double L = -log2((double)cf);
+        const float Lh = (float)L;
+        t[tid] = f32x4_t{ cf, Lh, (float)(L - (double)Lh), 0.0f };
+    }
+}
+// float copies of the normalised curve parameters (see icc_trc): g as a float pair, the rest rounded
+struct IccRegsF {
+    float trc[3][9];             // gh, gl, a, b, thr, c, f, add, nonpos
+    float out[9];                // ICC == 4: 1/g as a pair, b, 1/a, 1/c, break point, and the two "coefficient ~ 0" guards as 0/1
+    float m[9];                  // AG_ICC_MATRIX_F32 only
+};
+AG_DEV float icc_f_to_vgpr(float x)
+{
+    float v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x));
+    return v;
+}
+template <int ICC>
+AG_DEV void icc_regs_load_f(const WriteParams& p, IccRegsF& r)      // host-rounded floats (fill_write_params), parked in VGPRs like IccRegs
+{
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) r.trc[c][k] = icc_f_to_vgpr(p.icc_trc_f[c][k]);
+    if constexpr (ICC == 4) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) r.out[k] = icc_f_to_vgpr(p.icc_out_f[k]);
+    }
+#if AG_ICC_MATRIX_F32
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r.m[k] = icc_f_to_vgpr(p.icc_m_f[k]);
+#endif
+}
+AG_DEV float icc_trc_f(const IccPowTableF& T, const float* Q, float R)
+{
+    const float lin = __builtin_fmaf(Q[2], R, Q[3]);
+    const float pw = icc_pow32(T, lin, Q[0], Q[1]);
+    const float hi = lin > 0.0f ? pw + Q[7] : Q[8];
+    const float lo = __builtin_fmaf(Q[5], R, Q[6]);
+    return R >= Q[4] ? hi : lo;
+}
+AG_DEV float icc_inv4_f(const IccPowTableF& T, const float* P, float R)
+{
+    const float hi = (icc_pow32(T, R, P[0], P[1]) - P[2]) * P[3] * P[6];
+    const float lo = R * P[4] * P[7];
+    return R >= P[5] ? hi : lo;
 }
 
 // The parametric variants read up to 43 double parameters per pixel.  As kernel arguments they live in SGPRs, more than the
@@ -157,6 +257,28 @@ AG_DEV float icc_inv4(const IccPowTable& T, const double* P, const double* Q, fl
 // ICC = 1: all three curves are gamma 1 (identity on every float: the "Linear RGB Profile" Photoshop embeds in 32-bit
 // documents) -> matrix only, no call in the kernel.  ICC = 2: general parametric curves (double pow, out of line).
 // ICC = 4: as 2 (linear curves skipped at run time) plus the destination's inverse curve after the matrix (-> sRGB).
+template <int ICC>
+AG_DEV void icc_apply_f(const WriteParams& p, const IccRegs& q, const IccRegsF& qf, const IccPowTableF& T, float (&c)[3])
+{
+    float t[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[k] = p.icc_trc_linear[k] ? c[k] : icc_trc_f(T, qf.trc[k], c[k]);
+#if AG_ICC_MATRIX_F32
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        c[i] = __builtin_fmaf(t[2], qf.m[3 * i + 2], __builtin_fmaf(t[1], qf.m[3 * i + 1], t[0] * qf.m[3 * i + 0]));
+        if constexpr (ICC == 4) c[i] = icc_inv4_f(T, qf.out, c[i]);
+    }
+#else
+    const double t0 = (double)t[0], t1 = (double)t[1], t2 = (double)t[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {                   // the matrix stage stays as it was: double accumulation, one rounding to float
+        const double acc = __builtin_fma(t2, q.m[3 * i + 2], __builtin_fma(t1, q.m[3 * i + 1], t0 * q.m[3 * i + 0]));
+        c[i] = (float)acc;
+        if constexpr (ICC == 4) c[i] = icc_inv4_f(T, qf.out, c[i]);
+    }
+#endif
+}
 template <int ICC>
 AG_DEV void icc_apply(const WriteParams& p, const IccRegs& q, const IccPowTable& T, float (&c)[3])
 {
@@ -239,7 +361,8 @@ AG_DEV void icc16_tetrahedral(const uint16_t* __restrict__ clut, const uint32_t 
 template <int DEPTH, int PLANES, int TRANSFER, int ICC = 0, int RESCALE8 = 2, bool TO8 = false>   // RESCALE8: 0 no, 1 yes, 2 decide per sample (p.maxv); TO8: u8 planes
 AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t (&q)[4],
                     const int32_t* icc8_lds_s1 = nullptr, const uint8_t* icc8_lds_s2 = nullptr, const uint16_t* lut8 = nullptr,
-                    const IccPowTable& powT = IccPowTable{ nullptr, nullptr }, const IccRegs* iccRegs = nullptr)
+                    const IccPowTable& powT = IccPowTable{ nullptr, nullptr }, const IccRegs* iccRegs = nullptr,
+                    const IccPowTableF& powTf = IccPowTableF{ nullptr }, const IccRegsF* iccRegsF = nullptr)
 {
     constexpr bool COLOR = PLANES >= 3;
     constexpr bool ALPHA = (PLANES == 2 || PLANES == 4);
@@ -249,7 +372,10 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
         float col[NCOL];
 #pragma unroll
         for (int k = 0; k < NCOL; ++k) col[k] = __uint_as_float(s[k]);
-        if constexpr (ICC != 0 && COLOR) icc_apply<ICC>(p, *iccRegs, powT, col);                  // ConvertRow runs before the pixel loop: WriteHeifImage.cpp:1031-1034
+        if constexpr (ICC != 0 && COLOR) {                                                        // ConvertRow runs before the pixel loop: WriteHeifImage.cpp:1031-1034
+            if constexpr (IccF32<ICC>::value) icc_apply_f<ICC>(p, *iccRegs, *iccRegsF, powTf, col);
+            else icc_apply<ICC>(p, *iccRegs, powT, col);
+        }
         float a = 1.0f;
         if constexpr (ALPHA) {
             a = cxx_clamp(__uint_as_float(s[PLANES - 1]), 0.0f, 1.0f);          // :558, :1047
@@ -390,12 +516,20 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
 
     // parametric-curve ICC variants: the pow() table (1.5 KiB), filled once per workgroup
     constexpr bool ICCPOW = (ICC == 2 || ICC == 4);
-    __shared__ double icc_pow_L[ICCPOW ? kIccPowBins : 1];
-    __shared__ float icc_pow_c[ICCPOW ? kIccPowBins : 1];
-    if constexpr (ICCPOW) { icc_pow_table_fill(icc_pow_L, icc_pow_c, threadIdx.x); __syncthreads(); }
+    constexpr bool ICCF = IccF32<ICC>::value;
+    __shared__ double icc_pow_L[(ICCPOW && !ICCF) ? kIccPowBins : 1];
+    __shared__ float icc_pow_c[(ICCPOW && !ICCF) ? kIccPowBins : 1];
+    __shared__ __attribute__((aligned(16))) f32x4_t icc_pow_tf[ICCF ? kIccPowBins : 1];
+    if constexpr (ICCPOW) {
+        if constexpr (ICCF) icc_pow_table_fill_f(icc_pow_tf, threadIdx.x); else icc_pow_table_fill(icc_pow_L, icc_pow_c, threadIdx.x);
+        __syncthreads();
+    }
     const IccPowTable powT = { icc_pow_L, icc_pow_c };
+    const IccPowTableF powTf = { icc_pow_tf };
     IccRegs iccRegs;
-    if constexpr (DEPTH == 32 && (ICC == 1 || ICC == 2 || ICC == 4)) icc_regs_load<ICC>(p, iccRegs);
+    IccRegsF iccRegsF;
+    if constexpr (DEPTH == 32 && (ICC == 1 || ICC == 2 || ICC == 4)) icc_regs_load<ICCF ? 1 : ICC>(p, iccRegs);   // float path: the matrix only
+    if constexpr (DEPTH == 32 && ICCF) icc_regs_load_f<ICC>(p, iccRegsF);
 
     // 8-bit documents saved at 10/12 bit: the reference's 256-entry rescale LUT (WriteHeifImage.cpp:87-112), rebuilt per
     // workgroup with the same IEEE expression -- one ds_read per sample instead of a division sequence in the pixel loop
@@ -603,7 +737,7 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
 #pragma unroll
                 for (int i = 0; i < PXT; ++i) {
                     uint32_t q[4] = { 0, 0, 0, 0 };        // gray fills [0] and [3] only
-                    stage_a<DEPTH, PLANES, TRANSFER, ICC, decltype(rescale8)::value, !DST16>(p, s[i], q, icc8_s1, icc8_s2, lut8, powT, &iccRegs);
+                    stage_a<DEPTH, PLANES, TRANSFER, ICC, decltype(rescale8)::value, !DST16>(p, s[i], q, icc8_s1, icc8_s2, lut8, powT, &iccRegs, powTf, &iccRegsF);
                     if constexpr (!PACK) { qp[vr][i][0] = q[0]; qp[vr][i][1] = q[1]; qp[vr][i][2] = q[2]; qp[vr][i][3] = q[3]; }
                     else if constexpr (DST16) { qp[vr][i][0] = q[0] | (q[1] << 16); qp[vr][i][1] = q[2] | (q[3] << 16); }
                     else qp[vr][i][0] = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
@@ -831,18 +965,94 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_ycbcr444_hot(cons
     }
 }
 
+// ---- ... with the ICC matrix in front (icc = 1: a 32-bit document in linear sRGB / Display P3 / ProPhoto primaries saved as Rec.2100
+// PQ -- Photoshop's 32-bit documents carry linear profiles, so this is the usual HDR save) -------------------------------------------
+// The 3x3 needs whole pixels BEFORE the curve, so here the FLOATS cross the wave's strip (6 KiB instead of 3): coalesced loads as
+// above, ds_write_b128 transfer-major, read back pixel-major (lane l: pixels [8l, 8l+8) = 24 floats, 6 x ds_read_b128), matrix,
+// curve, stage B, and the codes are already where the stores want them -- no second transpose.  The matrix runs in fp32 FMAs on the
+// host-rounded coefficients: lcms2 accumulates in double and rounds once to float, this differs from it by an ulp now and then,
+// which moves the exact-match rate of the codes by nothing measurable (profiles/r02/icc_f32_ab.txt; bar of tests/test_gpu_icc.py).
+template <int TRANSFER>
+__global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444_hot(const WriteParams p)
+{
+    constexpr int PXL = 8, K = 6, SPAN_PX = 512, SPAN_DW = SPAN_PX * 3;
+    __shared__ __attribute__((aligned(16))) uint32_t strip[kStreamWaves][SPAN_DW];
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    f32x4* my = reinterpret_cast<f32x4*>(strip[wave]);
+    const float m0 = p.icc_m_f[0], m1 = p.icc_m_f[1], m2 = p.icc_m_f[2], m3 = p.icc_m_f[3], m4 = p.icc_m_f[4], m5 = p.icc_m_f[5],
+                m6 = p.icc_m_f[6], m7 = p.icc_m_f[7], m8 = p.icc_m_f[8];
+    const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;      // width % 4 == 0 (host)
+    const uint32_t total = spans_per_row * (uint32_t)p.nrows;
+    for (uint32_t sidx = blockIdx.x * kStreamWaves + wave; sidx < total; sidx += gridDim.x * kStreamWaves) {
+        const uint32_t r = sidx / spans_per_row;
+        const uint32_t sx = sidx - r * spans_per_row;
+        const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);
+        const int span_f4 = span_px * 3 / 4;
+        const f32x4* sp = reinterpret_cast<const f32x4*>(p.src + (long long)r * p.src_row_bytes) + (long long)sx * (64 * K);
+        f32x4 cur[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) cur[k] = __builtin_nontemporal_load(sp + min(64 * k + lane, span_f4 - 1));
+#pragma unroll
+        for (int k = 0; k < K; ++k) my[64 * k + lane] = cur[k];
+        __builtin_amdgcn_wave_barrier();
+        float c[PXL * 3];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const f32x4 v = my[K * lane + j];
+            c[4 * j] = v.x; c[4 * j + 1] = v.y; c[4 * j + 2] = v.z; c[4 * j + 3] = v.w;
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t yv[PXL], cbv[PXL], crv[PXL];
+#pragma unroll
+        for (int i = 0; i < PXL; ++i) {
+            const float R0 = c[3 * i], G0 = c[3 * i + 1], B0 = c[3 * i + 2];
+            const float R1 = __builtin_fmaf(B0, m2, __builtin_fmaf(G0, m1, R0 * m0));
+            const float G1 = __builtin_fmaf(B0, m5, __builtin_fmaf(G0, m4, R0 * m3));
+            const float B1 = __builtin_fmaf(B0, m8, __builtin_fmaf(G0, m7, R0 * m6));
+            const uint32_t q0 = oetf_code<TRANSFER>(p, R1), q1 = oetf_code<TRANSFER>(p, G1), q2 = oetf_code<TRANSFER>(p, B1);
+            yv[i] = luma_code(p, q0, q1, q2);
+            const float R = (float)q0, G = (float)q1, B = (float)q2;
+            cbv[i] = clip_round(R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2] + p.half, p.maxv);
+            crv[i] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
+        }
+        const long long xoff = ((long long)sx * SPAN_PX + (long long)PXL * lane) * 2;
+        uint8_t* d0 = p.dst[0] + (long long)r * p.dst_stride[0] + xoff;
+        uint8_t* d1 = p.dst[1] + (long long)r * p.dst_stride[1] + xoff;
+        uint8_t* d2 = p.dst[2] + (long long)r * p.dst_stride[2] + xoff;
+        const int nv = span_px - PXL * lane;                                       // >= 8, 4 or <= 0
+        if (nv >= 8) {
+            u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
+            u32x4 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16), cbv[4] | (cbv[5] << 16), cbv[6] | (cbv[7] << 16) };
+            u32x4 cc = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16), crv[4] | (crv[5] << 16), crv[6] | (crv[7] << 16) };
+            __builtin_nontemporal_store(a, reinterpret_cast<u32x4*>(d0));
+            __builtin_nontemporal_store(b, reinterpret_cast<u32x4*>(d1));
+            __builtin_nontemporal_store(cc, reinterpret_cast<u32x4*>(d2));
+        } else if (nv >= 4) {
+            u32x2 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16) };
+            u32x2 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16) };
+            u32x2 cc = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16) };
+            __builtin_nontemporal_store(a, reinterpret_cast<u32x2*>(d0));
+            __builtin_nontemporal_store(b, reinterpret_cast<u32x2*>(d1));
+            __builtin_nontemporal_store(cc, reinterpret_cast<u32x2*>(d2));
+        }
+    }
+}
+
 // ---- the same streaming structure for 4:2:2 / 4:2:0 (the AVIF default) -----------------------------------------------------
 // A wave owns a span of 512 pixels on 1 (4:2:2) or 2 (4:2:0) consecutive rows.  Per row: coalesced non-temporal float4 loads,
 // curve on the samples as loaded, packed codes through the wave-private LDS strip (reused for the second row), read back
 // pixel-major: lane l then holds pixels [8l, 8l+8) of both rows = the footprint of 4 chroma samples, so the box filter
 // (same operand order as write_px / the oracle) needs no cross-lane traffic.  Stores: 16 B/lane per luma row, 8 B/lane per chroma
 // plane, contiguous across the wave, non-temporal.
-template <int TRANSFER, int XS, int YS>
+// ICC1: the linear-profile matrix in front, as in write_rgb32_icc1_ycbcr444_hot -- the floats cross the strip, the codes are packed
+// into the same dw[][] layout the rest of the kernel reads.
+template <int TRANSFER, int XS, int YS, bool ICC1 = false>
 __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot(const WriteParams p)
 {
     static_assert(XS == 1, "4:2:2 or 4:2:0");
     constexpr int PXL = 8, K = 6, SPAN_PX = 512, SPAN_DW = SPAN_PX * 3 / 2, LDW = 12, VR = 1 << YS;
-    __shared__ __attribute__((aligned(16))) uint32_t strip[kStreamWaves][SPAN_DW];
+    __shared__ __attribute__((aligned(16))) uint32_t strip[kStreamWaves][ICC1 ? 2 * SPAN_DW : SPAN_DW];
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     uint32_t* my = strip[wave];
@@ -866,6 +1076,29 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot(con
         }
 #pragma unroll
         for (int vr = 0; vr < VR; ++vr) {
+            if constexpr (ICC1) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) reinterpret_cast<f32x4*>(my)[64 * k + lane] = v[vr][k];
+                __builtin_amdgcn_wave_barrier();
+                float c[PXL * 3];
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const f32x4 t = reinterpret_cast<const f32x4*>(my)[K * lane + j];
+                    c[4 * j] = t.x; c[4 * j + 1] = t.y; c[4 * j + 2] = t.z; c[4 * j + 3] = t.w;
+                }
+                __builtin_amdgcn_wave_barrier();
+                uint32_t q[PXL * 3];
+#pragma unroll
+                for (int i = 0; i < PXL; ++i) {
+                    const float R0 = c[3 * i], G0 = c[3 * i + 1], B0 = c[3 * i + 2];
+                    q[3 * i] = oetf_code<TRANSFER>(p, __builtin_fmaf(B0, p.icc_m_f[2], __builtin_fmaf(G0, p.icc_m_f[1], R0 * p.icc_m_f[0])));
+                    q[3 * i + 1] = oetf_code<TRANSFER>(p, __builtin_fmaf(B0, p.icc_m_f[5], __builtin_fmaf(G0, p.icc_m_f[4], R0 * p.icc_m_f[3])));
+                    q[3 * i + 2] = oetf_code<TRANSFER>(p, __builtin_fmaf(B0, p.icc_m_f[8], __builtin_fmaf(G0, p.icc_m_f[7], R0 * p.icc_m_f[6])));
+                }
+#pragma unroll
+                for (int e = 0; e < LDW; ++e) dw[vr][e] = q[2 * e] | (q[2 * e + 1] << 16);
+                continue;
+            }
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const uint32_t c0 = oetf_code<TRANSFER>(p, v[vr][k].x), c1 = oetf_code<TRANSFER>(p, v[vr][k].y);
@@ -1333,6 +1566,17 @@ static inline int grid_for(long long threads_needed)
     return (int)blocks;
 }
 
+// The parametric ICC variants set up ~60 wave-uniform parameters (and their pow table) per workgroup: a capped grid lets a wave
+// run several groups per set-up.
+#ifndef AG_ICC_BLOCK_CAP
+#define AG_ICC_BLOCK_CAP (256LL * 32)      /* 8192^2: 0.405 ms uncapped, 0.390 at 16k, 0.371 at 8k / 4k, 0.388 at 2k, 0.416 at 1k blocks (variant 2) */
+#endif
+static inline int grid_icc(long long threads_needed)
+{
+    const long long b = grid_for(threads_needed);
+    return (int)(b > AG_ICC_BLOCK_CAP ? AG_ICC_BLOCK_CAP : b);
+}
+
 template <int DEPTH, int PLANES, int OUT, bool DST16, int XS, int YS, int TRANSFER>
 static hipError_t launch_one(const WriteParams& p, hipStream_t st, char* label)
 {
@@ -1381,8 +1625,8 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, char* label)
                 if constexpr (TRANSFER == 3) {
                     snprintf(label, kLabelBytes, "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=4>",
                              DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned);
-                    if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 4>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
-                    else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 4>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
+                    if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 4>), dim3(grid_icc(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
+                    else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 4>), dim3(grid_icc(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
                     return hipGetLastError();
                 } else {
                     return hipErrorInvalidValue;    // rejected earlier by fill_write_params
@@ -1394,8 +1638,8 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, char* label)
                 if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 1>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
                 else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 1>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
             } else {
-                if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 2>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
-                else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 2>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
+                if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 2>), dim3(grid_icc(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
+                else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 2>), dim3(grid_icc(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
             }
             return hipGetLastError();
         }
@@ -1562,7 +1806,8 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
             return hipGetLastError();
         }
     }
-    if ((variant & 1) && p.icc_trc_type[0] == 0 && depth == 32 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 1 &&
+    const bool icc1 = AG_ICC1_HOT && p.icc_trc_type[0] != 0 && p.icc_out == 0 && p.icc_trc_linear[0] && p.icc_trc_linear[1] && p.icc_trc_linear[2];
+    if ((variant & 1) && (p.icc_trc_type[0] == 0 || icc1) && depth == 32 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 1 &&
         (p.width % 4) == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |
           (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2]) & 15) == 0) {
@@ -1571,9 +1816,10 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
         if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
             long long blocks = (spans + kStreamWaves - 1) / kStreamWaves;
             if (blocks > AG_STREAM_BLOCK_CAP * 4 / kStreamWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kStreamWaves;
-            snprintf(label, kLabelBytes, "write_rgb32_ycbcr_sub_hot<transfer=%d,xs=1,ys=%d>", p.transfer, ys);
-#define AG_SUB(TR) do { if (ys) hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<TR, 1, 1>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); \
-                        else hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<TR, 1, 0>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); } while (0)
+            snprintf(label, kLabelBytes, "write_rgb32_ycbcr_sub_hot<transfer=%d,xs=1,ys=%d>%s", p.transfer, ys, icc1 ? " icc=1" : "");
+#define AG_SUB2(TR, YS_) do { if (icc1) hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<TR, 1, YS_, true>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); \
+                              else hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<TR, 1, YS_, false>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); } while (0)
+#define AG_SUB(TR) do { if (ys) AG_SUB2(TR, 1); else AG_SUB2(TR, 0); } while (0)
             switch (p.transfer) {
             case AVIFGPU_TRANSFER_PQ:       AG_SUB(AVIFGPU_TRANSFER_PQ); break;
             case AVIFGPU_TRANSFER_HLG:      AG_SUB(AVIFGPU_TRANSFER_HLG); break;
@@ -1581,6 +1827,28 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
             default:                        AG_SUB(AVIFGPU_TRANSFER_CLIP); break;
             }
 #undef AG_SUB
+#undef AG_SUB2
+            return hipGetLastError();
+        }
+    }
+    // ... and with a linear document profile in front (icc = 1)
+    if ((variant & 1) && AG_ICC1_HOT && p.icc_trc_type[0] != 0 && p.icc_out == 0 && p.icc_trc_linear[0] && p.icc_trc_linear[1] && p.icc_trc_linear[2] &&
+        depth == 32 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 0 && ys == 0 && (p.width % 4) == 0 &&
+        (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
+        ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |
+          (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2]) & 15) == 0) {
+        const long long spans = (long long)((p.width + 511) / 512) * p.nrows;
+        if (spans == 0) return hipSuccess;
+        if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
+            long long blocks = (spans + kStreamWaves - 1) / kStreamWaves;
+            if (blocks > AG_STREAM_BLOCK_CAP * 4 / kStreamWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kStreamWaves;
+            snprintf(label, kLabelBytes, "write_rgb32_icc1_ycbcr444_hot<transfer=%d> icc=1", p.transfer);
+            switch (p.transfer) {
+            case AVIFGPU_TRANSFER_PQ:       hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<AVIFGPU_TRANSFER_PQ>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); break;
+            case AVIFGPU_TRANSFER_HLG:      hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<AVIFGPU_TRANSFER_HLG>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); break;
+            case AVIFGPU_TRANSFER_SMPTE428: hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<AVIFGPU_TRANSFER_SMPTE428>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); break;
+            default:                        hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<AVIFGPU_TRANSFER_CLIP>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); break;
+            }
             return hipGetLastError();
         }
     }

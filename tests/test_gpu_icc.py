@@ -68,9 +68,37 @@ def test_icc_then_pq_matches_lcms2(gpu, lcms, name, kind, trc, g, planes):
         # GPU: one fused launch on the ORIGINAL rows
         got = _gpu_write_icc(gpu, d, src, xf)
         st = harness.compare_write(d, want, got)
+        print(f"icc->rec2020 {name} planes {planes} out {output} {bits}-bit transfer {transfer}: exact {st['exact_frac']:.5f} max {st['max_abs']}")
         assert st["max_abs"] <= 1, (name, output, st)
         assert st["exact_frac"] >= (0.99 if transfer == pkg.TRANSFER_PQ else 0.985), (name, output, st)
         assert ("icc=1" if (trc == 0 and g == 1.0) else "icc=2") in gpu.last_kernel()
+
+
+@pytest.mark.parametrize("name,kind,trc,g", [p for p in PROFILES if p[2] == 0 and p[3] == 1.0])
+@pytest.mark.parametrize("width", [1024, 516, 8])
+def test_icc1_streaming_kernel_matches_lcms2(gpu, lcms, name, kind, trc, g, width):
+    """The usual HDR save: a 32-bit document with a LINEAR profile (sRGB / Display P3 / ProPhoto primaries) -> Rec.2020 -> PQ ->
+    4:4:4 planes takes the streaming kernel with the matrix in front (fp32 FMAs; lcms2: double accumulation).  Same bars."""
+    icc = _profile(lcms, kind, trc, g)
+    xf = gpu.icc_prepare(icc)
+    for bits, transfer, peak, chroma in ((10, pkg.TRANSFER_PQ, 80, pkg.CHROMA_444), (12, pkg.TRANSFER_PQ, 1000, pkg.CHROMA_444),
+                                         (12, pkg.TRANSFER_CLIP, 80, pkg.CHROMA_444), (10, pkg.TRANSFER_HLG, 80, pkg.CHROMA_444),
+                                         (10, pkg.TRANSFER_PQ, 80, pkg.CHROMA_420), (12, pkg.TRANSFER_PQ, 1000, pkg.CHROMA_422),
+                                         (12, pkg.TRANSFER_CLIP, 80, pkg.CHROMA_420)):
+        d = pkg.WriteDesc(width=width, height=9, depth=32, planes=3, bit_depth=bits, transfer=transfer, peak_nits=peak,
+                          alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR, chroma=chroma,
+                          matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020)
+        src = harness.make_write_source(d, seed=width + bits)
+        conv = src.copy()
+        assert lcms.oracle_icc_convert_rows_to_rec2020(icc, len(icc), 0, conv.ctypes.data, d.width, d.height, conv.strides[0]) == 0
+        want = harness.oracle_write(d, conv)
+        got = _gpu_write_icc(gpu, d, src, xf)
+        k = gpu.last_kernel()
+        assert ("write_rgb32_icc1_ycbcr444_hot" in k) if chroma == pkg.CHROMA_444 else ("write_rgb32_ycbcr_sub_hot" in k and "icc=1" in k), k
+        st = harness.compare_write(d, want, got)
+        print(f"icc1-streaming {name} width {width} {bits}-bit transfer {transfer} chroma {chroma}: exact {st['exact_frac']:.5f} max {st['max_abs']}")
+        assert st["max_abs"] <= 1, (name, st)
+        assert st["exact_frac"] >= (0.99 if transfer != pkg.TRANSFER_CLIP else 0.985) or d.width * d.height < 1000, (name, st)
 
 
 @pytest.mark.parametrize("name,kind,trc,g", PROFILES)
@@ -97,6 +125,7 @@ def test_icc_to_srgb_then_clip_matches_lcms2(gpu, lcms, name, kind, trc, g, plan
         want = harness.oracle_write(d, conv)
         got = _gpu_write_icc(gpu, d, src, xf)
         st = harness.compare_write(d, want, got)
+        print(f"icc->srgb {name} planes {planes} out {output} {bits}-bit: exact {st['exact_frac']:.5f} max {st['max_abs']}")
         assert st["max_abs"] <= 1, (name, output, st)
         worst = min(worst, st["exact_frac"])
         assert "icc=4" in gpu.last_kernel()
