@@ -162,9 +162,37 @@ int check_write(const avifgpu_write_desc* d, int row0, int nrows, WriteGeom& g)
 struct IccDeviceTables {
     void* icc8 = nullptr;  std::vector<uint8_t> icc8_host;     // [3][256] int32 followed by 16388 bytes of shaper2
     void* icc16 = nullptr; std::vector<uint8_t> icc16_host;    // 33^3 x 4 u16
+    void* pow_tab = nullptr;                                    // 128 x float4, constant
 };
 static std::mutex g_icc_mu;
 static std::map<int, IccDeviceTables> g_icc_tables;            // keyed by HIP device ordinal
+
+// The bins of icc_pow32 (write_kernels.hip): c = RN_float(1 / bin centre) and -log2(c) as a float pair.  Constants -- evaluated
+// once per device here instead of once per workgroup on the device (a double log2 there costs ~200 instructions per thread, a
+// quarter of what a streaming workgroup does in its whole life).
+int upload_icc_pow_table(WriteParams& p)
+{
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDevice", AVIFGPU_writErr);
+    std::lock_guard<std::mutex> lk(g_icc_mu);
+    IccDeviceTables& c = g_icc_tables[dev];
+    if (!c.pow_tab) {
+        float t[128][4];
+        for (int i = 0; i < 128; ++i) {
+            const double centre = 0.5 + ((double)i + 0.5) * (1.0 / 256.0);
+            const float cf = (float)(1.0 / centre);
+            const double L = -std::log2((double)cf);
+            const float Lh = (float)L;
+            t[i][0] = cf; t[i][1] = Lh; t[i][2] = (float)(L - (double)Lh); t[i][3] = 0.0f;
+        }
+        e = hipMalloc(&c.pow_tab, sizeof(t));
+        if (e == hipSuccess) e = hipMemcpy(c.pow_tab, t, sizeof(t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { if (c.pow_tab) (void)hipFree(c.pow_tab); c.pow_tab = nullptr; return hip_fail(e, "upload of the pow table", AVIFGPU_memFullErr); }
+    }
+    p.icc_pow_tab = static_cast<const float*>(c.pow_tab);
+    return 0;
+}
 
 int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p)
 {
@@ -244,6 +272,7 @@ void release_device_caches()
         (void)hipSetDevice(kv.first);
         if (kv.second.icc8) (void)hipFree(kv.second.icc8);
         if (kv.second.icc16) (void)hipFree(kv.second.icc16);
+        if (kv.second.pow_tab) (void)hipFree(kv.second.pow_tab);
     }
     g_icc_tables.clear();
     if (cur >= 0) (void)hipSetDevice(cur);
@@ -296,6 +325,7 @@ int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const Wr
             for (int k = 1; k < 8; ++k) p.icc_trc_f[c][k + 1] = (float)p.icc_trc[c][k];
         }
         for (int k = 0; k < 9; ++k) { p.icc_m[k] = g_icc->matrix[k]; p.icc_m_f[k] = (float)g_icc->matrix[k]; }
+        { const int rc = upload_icc_pow_table(p); if (rc) return rc; }
         if (g_icc->out_curve != 0) {
             if (g_icc->out_curve != 4) return fail(AVIFGPU_formatBadParameters, "bad ICC output curve");
             // the reference converts to sRGB only for the SDR save of a 32-bit document (ColorProfileConversion.cpp:118-123)

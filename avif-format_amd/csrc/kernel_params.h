@@ -45,6 +45,7 @@ struct WriteParams {
     float   icc_out_f[9];        // (1/g)h, (1/g)l, b, 1/a, 1/c, break point, [g,a usable], [c usable], 0
     float   icc_m_f[9];          // the matrix rounded to float (single-precision variant 2)
     float   icc_pad_f[1];
+    const float* icc_pow_tab;    // 128 x {c, Lh, Ll, 0}: the bins of icc_pow32, built once per device on the host (upload_icc_pow_table)
     // 8-bit matrix-shaper transform (avifgpu_icc_shaper8): tables live in device memory, matrix in kernarg
     const int32_t* icc8_s1;      // [3][256] 1.14 fixed
     const uint8_t* icc8_s2;      // [16385] 8-bit output curve (identical for R,G,B: the destination is sRGB)

@@ -134,15 +134,10 @@ AG_DEV float icc_pow32(const IccPowTableF& T, float x, float gh, float gl)
     const float v = __builtin_amdgcn_ldexpf(nat_exp2((th - n) + tl), (int)n);
     return x > 1e-37f ? v : 0.0f;
 }
-AG_DEV void icc_pow_table_fill_f(f32x4_t* t, int tid)
+// the 2-KiB table is a constant, built once per device on the host (upload_icc_pow_table): a workgroup copies it from L2
+AG_DEV void icc_pow_table_fill_f(f32x4_t* t, const float* dev_table, int tid)
 {
-    if (tid < kIccPowBins) {
-        const double centre = 0.5 + ((double)tid + 0.5) * (1.0 / 256.0);
-        const float cf = (float)(1.0 / centre);
-        const double L = -log2((double)cf);
-        const float Lh = (float)L;
-        t[tid] = f32x4_t{ cf, Lh, (float)(L - (double)Lh), 0.0f };
-    }
+    if (tid < kIccPowBins) t[tid] = reinterpret_cast<const f32x4_t*>(dev_table)[tid];
 }
 // float copies of the normalised curve parameters (see icc_trc): g as a float pair, the rest rounded
 struct IccRegsF {
@@ -521,7 +516,7 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
     __shared__ float icc_pow_c[(ICCPOW && !ICCF) ? kIccPowBins : 1];
     __shared__ __attribute__((aligned(16))) f32x4_t icc_pow_tf[ICCF ? kIccPowBins : 1];
     if constexpr (ICCPOW) {
-        if constexpr (ICCF) icc_pow_table_fill_f(icc_pow_tf, threadIdx.x); else icc_pow_table_fill(icc_pow_L, icc_pow_c, threadIdx.x);
+        if constexpr (ICCF) icc_pow_table_fill_f(icc_pow_tf, p.icc_pow_tab, threadIdx.x); else icc_pow_table_fill(icc_pow_L, icc_pow_c, threadIdx.x);
         __syncthreads();
     }
     const IccPowTable powT = { icc_pow_L, icc_pow_c };
@@ -972,11 +967,20 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_ycbcr444_hot(cons
 // curve, stage B, and the codes are already where the stores want them -- no second transpose.  The matrix runs in fp32 FMAs on the
 // host-rounded coefficients: lcms2 accumulates in double and rounds once to float, this differs from it by an ulp now and then,
 // which moves the exact-match rate of the codes by nothing measurable (profiles/r02/icc_f32_ab.txt; bar of tests/test_gpu_icc.py).
-template <int TRANSFER>
+// ICCV = 4: the sRGB destination of the SDR (Clip) save of a 32-bit document -- the inverse sRGB curve after the matrix, in single
+// precision (icc_inv4_f: exact-match rate 0.99992 against lcms2 instead of 0.99999 with FP64 curves, profiles/r02/icc_f32_ab.txt).
+template <int TRANSFER, int ICCV>
 __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444_hot(const WriteParams p)
 {
     constexpr int PXL = 8, K = 6, SPAN_PX = 512, SPAN_DW = SPAN_PX * 3;
     __shared__ __attribute__((aligned(16))) uint32_t strip[kStreamWaves][SPAN_DW];
+    __shared__ __attribute__((aligned(16))) f32x4_t pow_t[ICCV == 4 ? kIccPowBins : 1];
+    if constexpr (ICCV == 4) {
+        static_assert(AG_STREAM_BLOCK >= kIccPowBins, "one table entry per thread");
+        icc_pow_table_fill_f(pow_t, p.icc_pow_tab, threadIdx.x);
+        __syncthreads();
+    }
+    const IccPowTableF powT = { pow_t };
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     f32x4* my = reinterpret_cast<f32x4*>(strip[wave]);
@@ -1007,9 +1011,10 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444_hot
 #pragma unroll
         for (int i = 0; i < PXL; ++i) {
             const float R0 = c[3 * i], G0 = c[3 * i + 1], B0 = c[3 * i + 2];
-            const float R1 = __builtin_fmaf(B0, m2, __builtin_fmaf(G0, m1, R0 * m0));
-            const float G1 = __builtin_fmaf(B0, m5, __builtin_fmaf(G0, m4, R0 * m3));
-            const float B1 = __builtin_fmaf(B0, m8, __builtin_fmaf(G0, m7, R0 * m6));
+            float R1 = __builtin_fmaf(B0, m2, __builtin_fmaf(G0, m1, R0 * m0));
+            float G1 = __builtin_fmaf(B0, m5, __builtin_fmaf(G0, m4, R0 * m3));
+            float B1 = __builtin_fmaf(B0, m8, __builtin_fmaf(G0, m7, R0 * m6));
+            if constexpr (ICCV == 4) { R1 = icc_inv4_f(powT, p.icc_out_f, R1); G1 = icc_inv4_f(powT, p.icc_out_f, G1); B1 = icc_inv4_f(powT, p.icc_out_f, B1); }
             const uint32_t q0 = oetf_code<TRANSFER>(p, R1), q1 = oetf_code<TRANSFER>(p, G1), q2 = oetf_code<TRANSFER>(p, B1);
             yv[i] = luma_code(p, q0, q1, q2);
             const float R = (float)q0, G = (float)q1, B = (float)q2;
@@ -1047,12 +1052,19 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444_hot
 // plane, contiguous across the wave, non-temporal.
 // ICC1: the linear-profile matrix in front, as in write_rgb32_icc1_ycbcr444_hot -- the floats cross the strip, the codes are packed
 // into the same dw[][] layout the rest of the kernel reads.
-template <int TRANSFER, int XS, int YS, bool ICC1 = false>
+template <int TRANSFER, int XS, int YS, int ICCV = 0>       // ICCV: 0 none, 1 linear-profile matrix, 4 matrix + inverse sRGB curve
 __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot(const WriteParams p)
 {
     static_assert(XS == 1, "4:2:2 or 4:2:0");
     constexpr int PXL = 8, K = 6, SPAN_PX = 512, SPAN_DW = SPAN_PX * 3 / 2, LDW = 12, VR = 1 << YS;
+    constexpr bool ICC1 = ICCV != 0;
     __shared__ __attribute__((aligned(16))) uint32_t strip[kStreamWaves][ICC1 ? 2 * SPAN_DW : SPAN_DW];
+    __shared__ __attribute__((aligned(16))) f32x4_t pow_t[ICCV == 4 ? kIccPowBins : 1];
+    if constexpr (ICCV == 4) {
+        icc_pow_table_fill_f(pow_t, p.icc_pow_tab, threadIdx.x);
+        __syncthreads();
+    }
+    const IccPowTableF powT = { pow_t };
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     uint32_t* my = strip[wave];
@@ -1091,9 +1103,12 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot(con
 #pragma unroll
                 for (int i = 0; i < PXL; ++i) {
                     const float R0 = c[3 * i], G0 = c[3 * i + 1], B0 = c[3 * i + 2];
-                    q[3 * i] = oetf_code<TRANSFER>(p, __builtin_fmaf(B0, p.icc_m_f[2], __builtin_fmaf(G0, p.icc_m_f[1], R0 * p.icc_m_f[0])));
-                    q[3 * i + 1] = oetf_code<TRANSFER>(p, __builtin_fmaf(B0, p.icc_m_f[5], __builtin_fmaf(G0, p.icc_m_f[4], R0 * p.icc_m_f[3])));
-                    q[3 * i + 2] = oetf_code<TRANSFER>(p, __builtin_fmaf(B0, p.icc_m_f[8], __builtin_fmaf(G0, p.icc_m_f[7], R0 * p.icc_m_f[6])));
+                    float R1 = __builtin_fmaf(B0, p.icc_m_f[2], __builtin_fmaf(G0, p.icc_m_f[1], R0 * p.icc_m_f[0]));
+                    float G1 = __builtin_fmaf(B0, p.icc_m_f[5], __builtin_fmaf(G0, p.icc_m_f[4], R0 * p.icc_m_f[3]));
+                    float B1 = __builtin_fmaf(B0, p.icc_m_f[8], __builtin_fmaf(G0, p.icc_m_f[7], R0 * p.icc_m_f[6]));
+                    if constexpr (ICCV == 4) { R1 = icc_inv4_f(powT, p.icc_out_f, R1); G1 = icc_inv4_f(powT, p.icc_out_f, G1); B1 = icc_inv4_f(powT, p.icc_out_f, B1); }
+                    q[3 * i] = oetf_code<TRANSFER>(p, R1); q[3 * i + 1] = oetf_code<TRANSFER>(p, G1); q[3 * i + 2] = oetf_code<TRANSFER>(p, B1);
+                    if constexpr (ICCV == 4) __builtin_amdgcn_sched_barrier(0);     // one pixel's three pows at a time (interleaving all 24 of a row: 224 VGPRs)
                 }
 #pragma unroll
                 for (int e = 0; e < LDW; ++e) dw[vr][e] = q[2 * e] | (q[2 * e + 1] << 16);
@@ -1806,8 +1821,10 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
             return hipGetLastError();
         }
     }
-    const bool icc1 = AG_ICC1_HOT && p.icc_trc_type[0] != 0 && p.icc_out == 0 && p.icc_trc_linear[0] && p.icc_trc_linear[1] && p.icc_trc_linear[2];
-    if ((variant & 1) && (p.icc_trc_type[0] == 0 || icc1) && depth == 32 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 1 &&
+    const bool icc_lin = AG_ICC1_HOT && p.icc_trc_type[0] != 0 && p.icc_trc_linear[0] && p.icc_trc_linear[1] && p.icc_trc_linear[2];
+    const bool icc1 = icc_lin && p.icc_out == 0;
+    const bool icc4 = icc_lin && p.icc_out == 4 && p.transfer == AVIFGPU_TRANSFER_CLIP;
+    if ((variant & 1) && (p.icc_trc_type[0] == 0 || icc1 || icc4) && depth == 32 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 1 &&
         (p.width % 4) == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |
           (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2]) & 15) == 0) {
@@ -1816,10 +1833,15 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
         if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
             long long blocks = (spans + kStreamWaves - 1) / kStreamWaves;
             if (blocks > AG_STREAM_BLOCK_CAP * 4 / kStreamWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kStreamWaves;
-            snprintf(label, kLabelBytes, "write_rgb32_ycbcr_sub_hot<transfer=%d,xs=1,ys=%d>%s", p.transfer, ys, icc1 ? " icc=1" : "");
-#define AG_SUB2(TR, YS_) do { if (icc1) hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<TR, 1, YS_, true>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); \
-                              else hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<TR, 1, YS_, false>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); } while (0)
+            snprintf(label, kLabelBytes, "write_rgb32_ycbcr_sub_hot<transfer=%d,xs=1,ys=%d>%s", p.transfer, ys, icc1 ? " icc=1" : icc4 ? " icc=4" : "");
+#define AG_SUB2(TR, YS_) do { if (icc1) hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<TR, 1, YS_, 1>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); \
+                              else hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<TR, 1, YS_, 0>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); } while (0)
 #define AG_SUB(TR) do { if (ys) AG_SUB2(TR, 1); else AG_SUB2(TR, 0); } while (0)
+            if (icc4) {
+                if (ys) hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<AVIFGPU_TRANSFER_CLIP, 1, 1, 4>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p);
+                else hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<AVIFGPU_TRANSFER_CLIP, 1, 0, 4>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p);
+                return hipGetLastError();
+            }
             switch (p.transfer) {
             case AVIFGPU_TRANSFER_PQ:       AG_SUB(AVIFGPU_TRANSFER_PQ); break;
             case AVIFGPU_TRANSFER_HLG:      AG_SUB(AVIFGPU_TRANSFER_HLG); break;
@@ -1832,7 +1854,7 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
         }
     }
     // ... and with a linear document profile in front (icc = 1)
-    if ((variant & 1) && AG_ICC1_HOT && p.icc_trc_type[0] != 0 && p.icc_out == 0 && p.icc_trc_linear[0] && p.icc_trc_linear[1] && p.icc_trc_linear[2] &&
+    if ((variant & 1) && (icc1 || icc4) &&
         depth == 32 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 0 && ys == 0 && (p.width % 4) == 0 &&
         (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |
@@ -1842,12 +1864,13 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
         if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
             long long blocks = (spans + kStreamWaves - 1) / kStreamWaves;
             if (blocks > AG_STREAM_BLOCK_CAP * 4 / kStreamWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kStreamWaves;
-            snprintf(label, kLabelBytes, "write_rgb32_icc1_ycbcr444_hot<transfer=%d> icc=1", p.transfer);
+            snprintf(label, kLabelBytes, "write_rgb32_icc1_ycbcr444_hot<transfer=%d> icc=%d", p.transfer, icc4 ? 4 : 1);
+            if (icc4) { hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<AVIFGPU_TRANSFER_CLIP, 4>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); return hipGetLastError(); }
             switch (p.transfer) {
-            case AVIFGPU_TRANSFER_PQ:       hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<AVIFGPU_TRANSFER_PQ>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); break;
-            case AVIFGPU_TRANSFER_HLG:      hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<AVIFGPU_TRANSFER_HLG>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); break;
-            case AVIFGPU_TRANSFER_SMPTE428: hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<AVIFGPU_TRANSFER_SMPTE428>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); break;
-            default:                        hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<AVIFGPU_TRANSFER_CLIP>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); break;
+            case AVIFGPU_TRANSFER_PQ:       hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<AVIFGPU_TRANSFER_PQ, 1>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); break;
+            case AVIFGPU_TRANSFER_HLG:      hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<AVIFGPU_TRANSFER_HLG, 1>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); break;
+            case AVIFGPU_TRANSFER_SMPTE428: hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<AVIFGPU_TRANSFER_SMPTE428, 1>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); break;
+            default:                        hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<AVIFGPU_TRANSFER_CLIP, 1>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); break;
             }
             return hipGetLastError();
         }

@@ -101,6 +101,32 @@ def test_icc1_streaming_kernel_matches_lcms2(gpu, lcms, name, kind, trc, g, widt
         assert st["exact_frac"] >= (0.99 if transfer != pkg.TRANSFER_CLIP else 0.985) or d.width * d.height < 1000, (name, st)
 
 
+@pytest.mark.parametrize("name,kind,trc,g", [p for p in PROFILES if p[2] == 0 and p[3] == 1.0])
+@pytest.mark.parametrize("width", [1024, 516])
+def test_icc4_streaming_kernel_matches_lcms2(gpu, lcms, name, kind, trc, g, width):
+    """The SDR save of a 32-bit document with a linear profile (always converted to sRGB, ColorProfileConversion.cpp:118-123):
+    matrix + inverse sRGB curve in front of the Clip quantiser, on the streaming kernels (single-precision curve)."""
+    icc = _profile(lcms, kind, trc, g)
+    xf = gpu.icc_prepare(icc, pkg.ICC_TARGET_SRGB_FLOAT)
+    worst = 1.0
+    for bits, chroma in ((12, pkg.CHROMA_444), (10, pkg.CHROMA_420), (12, pkg.CHROMA_422)):
+        d = pkg.WriteDesc(width=width, height=9, depth=32, planes=3, bit_depth=bits, transfer=pkg.TRANSFER_CLIP,
+                          alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR, chroma=chroma, matrix_coefficients=pkg.MATRIX_BT601,
+                          color_primaries=pkg.PRIMARIES_BT709)
+        src = harness.make_write_source(d, seed=width + bits)
+        conv = src.copy()
+        assert lcms.oracle_icc_convert_rows_to_srgb_float(icc, len(icc), 0, conv.ctypes.data, d.width, d.height, conv.strides[0]) == 0
+        want = harness.oracle_write(d, conv)
+        got = _gpu_write_icc(gpu, d, src, xf)
+        k = gpu.last_kernel()
+        assert "icc=4" in k and ("write_rgb32_icc1_ycbcr444_hot" in k if chroma == pkg.CHROMA_444 else "write_rgb32_ycbcr_sub_hot" in k), k
+        st = harness.compare_write(d, want, got)
+        print(f"icc4-streaming {name} width {width} {bits}-bit chroma {chroma}: exact {st['exact_frac']:.5f} max {st['max_abs']}")
+        assert st["max_abs"] <= 1, (name, st)
+        worst = min(worst, st["exact_frac"])
+    assert worst >= 0.985, (name, worst)
+
+
 @pytest.mark.parametrize("name,kind,trc,g", PROFILES)
 @pytest.mark.parametrize("planes", [3, 4])
 def test_icc_to_srgb_then_clip_matches_lcms2(gpu, lcms, name, kind, trc, g, planes):
