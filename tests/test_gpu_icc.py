@@ -102,6 +102,29 @@ def test_icc1_streaming_kernel_matches_lcms2(gpu, lcms, name, kind, trc, g, widt
 
 
 @pytest.mark.parametrize("name,kind,trc,g", [p for p in PROFILES if p[2] == 0 and p[3] == 1.0])
+@pytest.mark.parametrize("width,alpha", [(1024, pkg.ALPHA_STRAIGHT), (515, pkg.ALPHA_PREMULTIPLIED), (7, pkg.ALPHA_STRAIGHT)])
+def test_icc1_rgba_streaming_kernel_matches_lcms2(gpu, lcms, name, kind, trc, g, width, alpha):
+    """RGBA f32 with a linear profile -> Rec.2020 PQ -> Y,Cb,Cr,A: the C5 kernel with the matrix on R,G,B in front (alpha copied)."""
+    icc = _profile(lcms, kind, trc, g)
+    xf = gpu.icc_prepare(icc)
+    for bits, transfer in ((12, pkg.TRANSFER_PQ), (10, pkg.TRANSFER_CLIP)):
+        d = pkg.WriteDesc(width=width, height=9, depth=32, planes=4, bit_depth=bits, transfer=transfer, peak_nits=80,
+                          alpha_state=alpha, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444,
+                          matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020)
+        src = harness.make_write_source(d, seed=width + bits)
+        conv = src.copy()
+        assert lcms.oracle_icc_convert_rows_to_rec2020(icc, len(icc), 1, conv.ctypes.data, d.width, d.height, conv.strides[0]) == 0
+        want = harness.oracle_write(d, conv)
+        got = _gpu_write_icc(gpu, d, src, xf)
+        k = gpu.last_kernel()
+        assert "write_rgba32_ycbcra444_hot" in k and "icc=1" in k, k
+        st = harness.compare_write(d, want, got)
+        print(f"icc1-rgba-streaming {name} width {width} {bits}-bit transfer {transfer}: exact {st['exact_frac']:.5f} max {st['max_abs']}")
+        assert st["max_abs"] <= 1, (name, st)
+        assert st["exact_frac"] >= 0.99 or d.width * d.height < 1000, (name, st)
+
+
+@pytest.mark.parametrize("name,kind,trc,g", [p for p in PROFILES if p[2] == 0 and p[3] == 1.0])
 @pytest.mark.parametrize("width", [1024, 516])
 def test_icc4_streaming_kernel_matches_lcms2(gpu, lcms, name, kind, trc, g, width):
     """The SDR save of a 32-bit document with a linear profile (always converted to sRGB, ColorProfileConversion.cpp:118-123):
