@@ -269,7 +269,9 @@ int32_t avifgpu_read_rows(const avifgpu_read_desc* desc,
  * carries a non-Rec.2020 profile (ColorProfileConversion::ConvertRow, src/common/ColorProfileConversion.cpp:159-187,
  * transform built at :235-266 against CreateRec2020LinearRGBProfile, ColorProfileGeneration.cpp:141-178).  For
  * matrix/TRC RGB profiles that lcms2 pipeline is [per-channel TRC] -> [one 3x3 matrix in double] -> float, which the
- * write kernels can apply in place of the CPU call.  LUT-based profiles (A2B tags), sampled `curv` tables (on this
+ * write kernels can apply in place of the CPU call.  (Tier 2, like every float path: the kernels evaluate the curves and --
+ * on the streaming kernels -- the matrix in single precision; the bar is on the integer codes behind the transfer curve,
+ * |delta code| <= 1 and >= 99 % exact against the real lcms2, measured 99.7-100 %: tests/test_gpu_icc.py.)  LUT-based profiles (A2B tags), sampled `curv` tables (on this
  * 32-bit path only; Photoshop's 32-bit documents carry linear profiles) are NOT covered: avifgpu_icc_prepare returns AVIFGPU_formatCannotRead and the caller keeps
  * its lcms2 path. */
 typedef struct avifgpu_icc_transform {
