@@ -1448,6 +1448,80 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr_sub_hot(con
     }
 }
 
+// ---- RGBA16 -> Y, Cb, Cr, A u16 planes (4:4:4): the streaming structure for 16-bit documents with transparency -------------------
+// A wave owns 512 pixels of a row = 4 KiB: four coalesced non-temporal 16-byte loads per lane, each holding two whole RGBA pixels.
+// Rescale (per sample) and the integer premultiply (per pixel) run on the vector as loaded; the codes go back into the same two
+// dwords per pixel and cross the strip as one ds_write_b128 (lane stride padded 16 -> 20 dwords: conflict-free b128 read-back);
+// lane l then holds pixels [8l, 8l+8) and writes 16 bytes per plane.  width % 8 == 0 (whole lanes).
+__global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra444_hot(const WriteParams p)
+{
+    constexpr int PXL = 8, K = 4, SPAN_PX = 512, LSTRIDE = 20;
+    __shared__ __attribute__((aligned(16))) uint32_t strip[kStreamWaves][64 * LSTRIDE];
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    uint32_t* my = strip[wave];
+    const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;
+    const uint32_t total = spans_per_row * (uint32_t)p.nrows;
+    for (uint32_t sidx = blockIdx.x * kStreamWaves + wave; sidx < total; sidx += gridDim.x * kStreamWaves) {
+        const uint32_t r = sidx / spans_per_row;
+        const uint32_t sx = sidx - r * spans_per_row;
+        const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);             // a multiple of 8
+        const int span_v = span_px / 2;                                            // 16-byte vectors (2 pixels each)
+        const u32x4* sp = reinterpret_cast<const u32x4*>(p.src + (long long)r * p.src_row_bytes) + (long long)sx * (64 * K);
+        u32x4 cur[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) cur[k] = __builtin_nontemporal_load(sp + min(64 * k + lane, span_v - 1));
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            uint32_t o[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                                          // the vector's two pixels
+                const uint32_t w0 = h == 0 ? cur[k].x : cur[k].z, w1 = h == 0 ? cur[k].y : cur[k].w;
+                uint32_t c0 = exact_rescale(min(w0 & 0xffffu, 32768u), 32768.0f, p.maxf, p.maxv);
+                uint32_t c1 = exact_rescale(min(w0 >> 16, 32768u), 32768.0f, p.maxf, p.maxv);
+                uint32_t c2 = exact_rescale(min(w1 & 0xffffu, 32768u), 32768.0f, p.maxf, p.maxv);
+                const uint32_t a = exact_rescale(min(w1 >> 16, 32768u), 32768.0f, p.maxf, p.maxv);
+                if (p.premultiply) {                                               // stage_a: after the rescale, in the plane's code domain
+                    c0 = exact_premultiply_fast(c0, a, p.maxf, p.rcp_maxf);
+                    c1 = exact_premultiply_fast(c1, a, p.maxf, p.rcp_maxf);
+                    c2 = exact_premultiply_fast(c2, a, p.maxf, p.rcp_maxf);
+                }
+                o[2 * h] = c0 | (c1 << 16); o[2 * h + 1] = c2 | (a << 16);
+            }
+            const int v = 64 * k + lane;                                           // vector index in the span: pixels 2v, 2v + 1
+            *reinterpret_cast<u32x4*>(my + (v >> 2) * LSTRIDE + (v & 3) * 4) = u32x4{ o[0], o[1], o[2], o[3] };
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t dw[2 * PXL];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32x4 t = *reinterpret_cast<const u32x4*>(my + lane * LSTRIDE + 4 * j);
+            dw[4 * j] = t.x; dw[4 * j + 1] = t.y; dw[4 * j + 2] = t.z; dw[4 * j + 3] = t.w;
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t yv[PXL], cbv[PXL], crv[PXL], av[PXL];
+#pragma unroll
+        for (int i = 0; i < PXL; ++i) {
+            const uint32_t q0 = dw[2 * i] & 0xffffu, q1 = dw[2 * i] >> 16, q2 = dw[2 * i + 1] & 0xffffu;
+            av[i] = dw[2 * i + 1] >> 16;
+            yv[i] = luma_code(p, q0, q1, q2);
+            const float R = (float)q0, G = (float)q1, B = (float)q2;
+            cbv[i] = clip_round(R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2] + p.half, p.maxv);
+            crv[i] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
+        }
+        if (PXL * lane < span_px) {
+            const long long xoff = ((long long)sx * SPAN_PX + (long long)PXL * lane) * 2;
+            const uint32_t* pl[4] = { yv, cbv, crv, av };
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t* q = pl[c];
+                u32x4 o = { q[0] | (q[1] << 16), q[2] | (q[3] << 16), q[4] | (q[5] << 16), q[6] | (q[7] << 16) };
+                __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(p.dst[c] + (long long)r * p.dst_stride[c] + xoff));
+            }
+        }
+    }
+}
+
 // ---- RGB(A) f32 -> interleaved RRGGBB(AA) u16: the reference's own hand-off (CreateHeifImageRGBThirtyTwoBit) ------------------
 // Output sample i is a function of input sample i (RGB) or of its own pixel's float4 (RGBA): no transposition at all.  A wave
 // streams 64 x 4 float4 per trip: coalesced non-temporal 16-byte loads, the curve, 8-byte non-temporal stores at the same index.
@@ -1782,6 +1856,25 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
             if (blocks > AG_STREAM_BLOCK_CAP * 4 / kStreamWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kStreamWaves;
             snprintf(label, kLabelBytes, "write_rgb16_ycbcr444_hot<ns=%d>", AG_RGB16_NS);
             hipLaunchKernelGGL((write_rgb16_ycbcr444_hot<AG_RGB16_NS>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p);
+            return hipGetLastError();
+        }
+    }
+#ifndef AG_RGBA16_MIN_PX
+#define AG_RGBA16_MIN_PX 0
+#endif
+    // RGBA16 -> u16 Y, Cb, Cr, A 4:4:4
+    if ((variant & 1) && p.icc16_clut == nullptr && depth == 16 && planes == 4 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 0 && ys == 0 &&
+        ((long long)p.width * p.nrows >= AG_RGBA16_MIN_PX || (variant & 8)) && p.dst[3] != nullptr &&
+        (p.width % 8) == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
+        ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) | reinterpret_cast<uintptr_t>(p.dst[3]) |
+          (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2] | (uintptr_t)p.dst_stride[3]) & 15) == 0) {
+        const long long spans = (long long)((p.width + 511) / 512) * p.nrows;
+        if (spans == 0) return hipSuccess;
+        if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
+            long long blocks = (spans + kStreamWaves - 1) / kStreamWaves;
+            if (blocks > AG_STREAM_BLOCK_CAP * 4 / kStreamWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kStreamWaves;
+            snprintf(label, kLabelBytes, "write_rgba16_ycbcra444_hot");
+            hipLaunchKernelGGL(write_rgba16_ycbcra444_hot, dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p);
             return hipGetLastError();
         }
     }

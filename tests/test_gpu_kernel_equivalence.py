@@ -47,6 +47,12 @@ CASES = [
     ("write_rgb16_ycbcr_sub_hot", dict(width=520, height=5, depth=16, planes=3, bit_depth=10, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_422,
                                        matrix_coefficients=pkg.MATRIX_BT709, color_primaries=pkg.PRIMARIES_BT709)),
     ("write_rgb16_ycbcr_sub_hot", dict(width=8, height=1, depth=16, planes=3, bit_depth=12, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420, **BT2020)),
+    ("write_rgba16_ycbcra444_hot", dict(width=1024, height=5, depth=16, planes=4, bit_depth=12, alpha_state=pkg.ALPHA_PREMULTIPLIED,
+                                        output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444, **BT2020)),
+    ("write_rgba16_ycbcra444_hot", dict(width=1000, height=4, depth=16, planes=4, bit_depth=10, alpha_state=pkg.ALPHA_STRAIGHT,
+                                        output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444, matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)),
+    ("write_rgba16_ycbcra444_hot", dict(width=8, height=2, depth=16, planes=4, bit_depth=12, alpha_state=pkg.ALPHA_PREMULTIPLIED,
+                                        output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444, **BT2020)),
     ("write_int_ref_stream", dict(width=1000, height=5, depth=16, planes=3, bit_depth=12, output=pkg.OUT_REFERENCE)),
     ("write_int_ref_stream", dict(width=502, height=3, depth=16, planes=4, bit_depth=8, alpha_state=pkg.ALPHA_PREMULTIPLIED,
                                   output=pkg.OUT_REFERENCE)),
