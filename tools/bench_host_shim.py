@@ -28,7 +28,7 @@ class NoFillHost(FakeHost):
         return 0
 
 
-def run(width, height, max_data, output, chroma=pkg.CHROMA_444, reps=3, nofill=False, planes="pinned", contexts=1):
+def run(width, height, max_data, output, chroma=pkg.CHROMA_444, reps=3, nofill=False, planes="pinned", contexts=1, depth=32, bits=10):
     """planes: "pinned"   = avifgpu_image_alloc'ed once, outside the timed call (page-locked: DMA target),
                "pageable" = ordinary heap memory with libheif-like 16-byte strides (what heif_image_add_plane gives the plug-in):
                             the library bounces every tile through its pinned staging,
@@ -37,12 +37,13 @@ def run(width, height, max_data, output, chroma=pkg.CHROMA_444, reps=3, nofill=F
     ndev = max(torch.cuda.device_count(), 1)
     gpu = pkg.AvifGpu(devices=[i % ndev for i in range(contexts)])
     rng = np.random.default_rng(1234)
-    src = rng.random((height, width * 3), dtype=np.float32)
+    src = rng.random((height, width * 3), dtype=np.float32) if depth == 32 else rng.integers(0, 256 if depth == 8 else 32769, (height, width * 3)).astype(np.uint8 if depth == 8 else np.uint16)
+    ssz = 2 if bits > 8 else 1
     best = None
     keep = []
     pre = H.Image()
     if planes != "inside":
-        pre.width, pre.height, pre.bit_depth = width, height, 10
+        pre.width, pre.height, pre.bit_depth = width, height, bits
         if output == pkg.OUT_YCBCR:
             pre.colorspace, pre.chroma = pkg.COLORSPACE_YCBCR, chroma
         else:
@@ -52,19 +53,19 @@ def run(width, height, max_data, output, chroma=pkg.CHROMA_444, reps=3, nofill=F
         else:
             xs, ys = harness.chroma_shift(chroma)
             for pl in range(3 if output == pkg.OUT_YCBCR else 1):
-                w = (width * 3 if output != pkg.OUT_YCBCR else (width if pl == 0 else (width + xs) >> xs)) * 2
+                w = (width * 3 if output != pkg.OUT_YCBCR else (width if pl == 0 else (width + xs) >> xs)) * ssz
                 h = height if (pl == 0 or output != pkg.OUT_YCBCR) else (height + ys) >> ys
                 a = np.zeros((h, (w + 15) // 16 * 16), dtype=np.uint8)
                 keep.append(a)
                 pre.plane[pl] = a.ctypes.data
                 pre.stride[pl] = a.strides[0]
     for _ in range(reps):
-        host = (NoFillHost if nofill else FakeHost)(width, height, 32, 3, max_data=max_data, image=src)
-        opts = H.SaveUIOptions(imageBitDepth=10, hdrTransferFunction=pkg.TRANSFER_PQ, pq=H.PQOptions(80), chromaSubsampling=chroma, lossless=0)
+        host = (NoFillHost if nofill else FakeHost)(width, height, depth, 3, max_data=max_data, image=src)
+        opts = H.SaveUIOptions(imageBitDepth=bits, hdrTransferFunction=pkg.TRANSFER_PQ, pq=H.PQOptions(80), chromaSubsampling=chroma, lossless=0)
         img = H.Image() if planes == "inside" else pre
         t0 = time.perf_counter()
         code = gpu.lib.avifgpu_host_create_heif_image(ctypes.byref(host.fr), pkg.ALPHA_NONE, ctypes.byref(opts), output,
-                                                      pkg.MATRIX_BT2020_NCL, pkg.PRIMARIES_BT2020, ctypes.byref(img))
+                                                      pkg.MATRIX_BT2020_NCL if depth == 32 else pkg.MATRIX_BT601, pkg.PRIMARIES_BT2020 if depth == 32 else pkg.PRIMARIES_BT709, ctypes.byref(img))
         dt = time.perf_counter() - t0
         assert code == 0, gpu.lib.avifgpu_last_error()
         if planes == "inside":
@@ -75,12 +76,12 @@ def run(width, height, max_data, output, chroma=pkg.CHROMA_444, reps=3, nofill=F
         gpu.lib.avifgpu_image_free(ctypes.byref(pre))
     # the host's own fill cost (numpy memcpy of every tile into the pinned buffer) for reference
     t0 = time.perf_counter(); tmp = src.copy(); fill = time.perf_counter() - t0
-    print(json.dumps({"config": f"{width}x{height} RGB f32 -> 10-bit PQ, output={'YCbCr' + {3: '444', 2: '422', 1: '420'}[chroma] if output else 'interleaved'}"
+    print(json.dumps({"config": f"{width}x{height} RGB {'f32' if depth == 32 else 'u%d' % depth} -> {bits}-bit{' PQ' if depth == 32 else ''}, output={'YCbCr' + {3: '444', 2: '422', 1: '420'}[chroma] if output else 'interleaved'}"
                                 + (" (host fill skipped: pipeline floor)" if nofill else ""),
                       "planes": planes, "contexts": contexts, "lanes": int(os.environ.get("AVIFGPU_LANES", "2")),
                       "maxData_MiB": max_data / 2**20, "tiles": tiles, "seconds": round(best, 4),
                       "Mpx_s": round(width * height / best / 1e6, 1), "host_fill_memcpy_s": round(fill, 4),
-                      "H2D_GB_s_equiv": round(width * height * 12 / best / 1e9, 1)}), flush=True)
+                      "H2D_GB_s_equiv": round(width * height * 3 * (depth // 8) / best / 1e9, 1)}), flush=True)
 
 
 def run_read(width, height, max_data, bits, depth, chroma, tc, reps=3):
@@ -127,6 +128,11 @@ if __name__ == "__main__":
         run(8192, 8192, 64 << 20, pkg.OUT_REFERENCE)
         run(8192, 8192, 64 << 20, pkg.OUT_YCBCR, planes="pageable")
         run(8192, 8192, 64 << 20, pkg.OUT_YCBCR, planes="inside")
+    if mode in ("all", "write", "sdr"):
+        # the plug-in's default save (8-bit document, 8-bit 4:2:2, AvifFormat.cpp:89) and a 16-bit photograph saved as 12-bit 4:2:0
+        run(8192, 8192, 64 << 20, pkg.OUT_YCBCR, chroma=pkg.CHROMA_422, depth=8, bits=8)
+        run(8192, 8192, 64 << 20, pkg.OUT_YCBCR, chroma=pkg.CHROMA_422, depth=8, bits=8, planes="pageable")
+        run(8192, 8192, 64 << 20, pkg.OUT_YCBCR, chroma=pkg.CHROMA_420, depth=16, bits=12)
     if mode in ("all", "write", "floor"):
         for md in (16 << 20, 64 << 20):
             run(8192, 8192, md, pkg.OUT_YCBCR, nofill=True)
