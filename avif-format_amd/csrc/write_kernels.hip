@@ -1068,6 +1068,17 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot(con
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     uint32_t* my = strip[wave];
+    // ICCV = 4 reads 18 more wave-uniform floats per pixel than the scalar file holds next to the rest of WriteParams (182
+    // v_writelane / v_readlane spills in the first build): parked in VGPRs once, like IccRegsF.  (The 24 inlined pows of a row
+    // still interleave to 185-231 VGPRs = 2 waves/SIMD; amdgpu_waves_per_eu(3|4) turns that into scratch spills and 1.6-2.3x the time.)
+    float icm[9], ico[9];
+    if constexpr (ICCV == 4) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { icm[k] = icc_f_to_vgpr(p.icc_m_f[k]); ico[k] = icc_f_to_vgpr(p.icc_out_f[k]); }
+    } else if constexpr (ICCV == 1) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { icm[k] = p.icc_m_f[k]; ico[k] = 0.0f; }
+    }
 
     const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;    // host guarantees width % 4 == 0 and alignment
     const uint32_t groups = ((uint32_t)p.nrows + VR - 1) >> YS;
@@ -1103,10 +1114,10 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot(con
 #pragma unroll
                 for (int i = 0; i < PXL; ++i) {
                     const float R0 = c[3 * i], G0 = c[3 * i + 1], B0 = c[3 * i + 2];
-                    float R1 = __builtin_fmaf(B0, p.icc_m_f[2], __builtin_fmaf(G0, p.icc_m_f[1], R0 * p.icc_m_f[0]));
-                    float G1 = __builtin_fmaf(B0, p.icc_m_f[5], __builtin_fmaf(G0, p.icc_m_f[4], R0 * p.icc_m_f[3]));
-                    float B1 = __builtin_fmaf(B0, p.icc_m_f[8], __builtin_fmaf(G0, p.icc_m_f[7], R0 * p.icc_m_f[6]));
-                    if constexpr (ICCV == 4) { R1 = icc_inv4_f(powT, p.icc_out_f, R1); G1 = icc_inv4_f(powT, p.icc_out_f, G1); B1 = icc_inv4_f(powT, p.icc_out_f, B1); }
+                    float R1 = __builtin_fmaf(B0, icm[2], __builtin_fmaf(G0, icm[1], R0 * icm[0]));
+                    float G1 = __builtin_fmaf(B0, icm[5], __builtin_fmaf(G0, icm[4], R0 * icm[3]));
+                    float B1 = __builtin_fmaf(B0, icm[8], __builtin_fmaf(G0, icm[7], R0 * icm[6]));
+                    if constexpr (ICCV == 4) { R1 = icc_inv4_f(powT, ico, R1); G1 = icc_inv4_f(powT, ico, G1); B1 = icc_inv4_f(powT, ico, B1); }
                     q[3 * i] = oetf_code<TRANSFER>(p, R1); q[3 * i + 1] = oetf_code<TRANSFER>(p, G1); q[3 * i + 2] = oetf_code<TRANSFER>(p, B1);
                     if constexpr (ICCV == 4) __builtin_amdgcn_sched_barrier(0);     // one pixel's three pows at a time (interleaving all 24 of a row: 224 VGPRs)
                 }
