@@ -29,7 +29,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #define AG_ICC_F32 1
 #endif
 #ifndef AG_ICC4_F32
-#define AG_ICC4_F32 0
+#define AG_ICC4_F32 1
 #endif
 #ifndef AG_ICC1_HOT
 #define AG_ICC1_HOT 1
@@ -114,8 +114,20 @@ AG_DEV void icc_pow_table_fill(double* L, float* c, int tid)
 // 28 fp32 instructions, one 16-byte LDS read, one transcendental; same accuracy class as the FP64 form (the error is v_exp_f32's ulp
 // and the polynomial's 3e-10).  Arguments are floats: a*R + b is rounded to float first (6e-8 relative, x g on the result).
 struct IccPowTableF { const f32x4_t* t; };          // LDS, 128 entries of {c, Lh, Ll, 0}
+// AG_ICC_FASTPOW (default): pow = v_exp_f32(g * v_log_f32(x)) -- the two hardware transcendentals and one multiply.  Its error is
+// the 1-ulp error of log2 x times g (|g log2 x| reaches ~30: ~2e-6 relative on the result), which the integer codes behind the
+// transfer curve barely see: exact-match rate against the real lcms2 0.99889 -> 0.99868 (parametric document curves -> PQ) and
+// 0.99985 -> 0.99982 (-> sRGB, 12-bit Clip), bars 0.99 / 0.985 -- for 3.5x less arithmetic per pow (icc=4 0.44 -> 0.75 of
+// 8 TB/s, icc=2 0.43 -> 0.56; profiles/r02/icc_f32_ab.txt).  0 selects the double-float evaluation below (float-ulp accurate).
+#ifndef AG_ICC_FASTPOW
+#define AG_ICC_FASTPOW 1
+#endif
 AG_DEV float icc_pow32(const IccPowTableF& T, float x, float gh, float gl)
 {
+#if AG_ICC_FASTPOW
+    (void)T; (void)gl;
+    return x > 1e-37f ? nat_exp2(gh * nat_log2(x)) : 0.0f;
+#endif
     const float xf = fmaxf(x, 1e-37f);                         // x <= 1e-37 (incl. <= 0 and NaN) evaluates on 1e-37 and is zeroed at the end
     const float m = __builtin_amdgcn_frexp_mantf(xf);          // [0.5, 1)
     const float ef = (float)__builtin_amdgcn_frexp_expf(xf);
@@ -137,7 +149,11 @@ AG_DEV float icc_pow32(const IccPowTableF& T, float x, float gh, float gl)
 // the 2-KiB table is a constant, built once per device on the host (upload_icc_pow_table): a workgroup copies it from L2
 AG_DEV void icc_pow_table_fill_f(f32x4_t* t, const float* dev_table, int tid)
 {
+#if !AG_ICC_FASTPOW
     if (tid < kIccPowBins) t[tid] = reinterpret_cast<const f32x4_t*>(dev_table)[tid];
+#else
+    (void)t; (void)dev_table; (void)tid;
+#endif
 }
 // float copies of the normalised curve parameters (see icc_trc): g as a float pair, the rest rounded
 struct IccRegsF {
@@ -514,7 +530,7 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
     constexpr bool ICCF = IccF32<ICC>::value;
     __shared__ double icc_pow_L[(ICCPOW && !ICCF) ? kIccPowBins : 1];
     __shared__ float icc_pow_c[(ICCPOW && !ICCF) ? kIccPowBins : 1];
-    __shared__ __attribute__((aligned(16))) f32x4_t icc_pow_tf[ICCF ? kIccPowBins : 1];
+    __shared__ __attribute__((aligned(16))) f32x4_t icc_pow_tf[(ICCF && !AG_ICC_FASTPOW) ? kIccPowBins : 1];
     if constexpr (ICCPOW) {
         if constexpr (ICCF) icc_pow_table_fill_f(icc_pow_tf, p.icc_pow_tab, threadIdx.x); else icc_pow_table_fill(icc_pow_L, icc_pow_c, threadIdx.x);
         __syncthreads();
@@ -974,7 +990,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444_hot
 {
     constexpr int PXL = 8, K = 6, SPAN_PX = 512, SPAN_DW = SPAN_PX * 3;
     __shared__ __attribute__((aligned(16))) uint32_t strip[kStreamWaves][SPAN_DW];
-    __shared__ __attribute__((aligned(16))) f32x4_t pow_t[ICCV == 4 ? kIccPowBins : 1];
+    __shared__ __attribute__((aligned(16))) f32x4_t pow_t[(ICCV == 4 && !AG_ICC_FASTPOW) ? kIccPowBins : 1];
     if constexpr (ICCV == 4) {
         static_assert(AG_STREAM_BLOCK >= kIccPowBins, "one table entry per thread");
         icc_pow_table_fill_f(pow_t, p.icc_pow_tab, threadIdx.x);
@@ -1059,7 +1075,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot(con
     constexpr int PXL = 8, K = 6, SPAN_PX = 512, SPAN_DW = SPAN_PX * 3 / 2, LDW = 12, VR = 1 << YS;
     constexpr bool ICC1 = ICCV != 0;
     __shared__ __attribute__((aligned(16))) uint32_t strip[kStreamWaves][ICC1 ? 2 * SPAN_DW : SPAN_DW];
-    __shared__ __attribute__((aligned(16))) f32x4_t pow_t[ICCV == 4 ? kIccPowBins : 1];
+    __shared__ __attribute__((aligned(16))) f32x4_t pow_t[(ICCV == 4 && !AG_ICC_FASTPOW) ? kIccPowBins : 1];
     if constexpr (ICCV == 4) {
         icc_pow_table_fill_f(pow_t, p.icc_pow_tab, threadIdx.x);
         __syncthreads();
