@@ -1220,7 +1220,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot(con
 #define AG_RGBA_STREAM_BLOCK 256
 #endif
 constexpr int kRgbaWaves = AG_RGBA_STREAM_BLOCK / 64;
-template <int TRANSFER, bool ICC1 = false>       // ICC1: the linear-profile matrix on R, G, B first (ConvertRow runs before the pixel loop and copies alpha)
+template <int TRANSFER, int ICCV = 0>            // ICCV 1: the linear-profile matrix on R, G, B first (ConvertRow runs before the pixel loop and copies alpha); 4: + inverse sRGB curve
 __global__ __launch_bounds__(AG_RGBA_STREAM_BLOCK) void write_rgba32_ycbcra444_hot(const WriteParams p)
 {
     constexpr int PXL = AG_RGBA_HOT_PXL, SPAN_PX = 64 * PXL;
@@ -1243,11 +1243,17 @@ __global__ __launch_bounds__(AG_RGBA_STREAM_BLOCK) void write_rgba32_ycbcra444_h
 #pragma unroll
         for (int k = 0; k < PXL; ++k) {
             float col[3] = { v[k].x, v[k].y, v[k].z };
-            if constexpr (ICC1) {                                                   // a pixel is one float4 here: no transpose needed in front
+            if constexpr (ICCV != 0) {                                              // a pixel is one float4 here: no transpose needed in front
                 const float R0 = col[0], G0 = col[1], B0 = col[2];
                 col[0] = __builtin_fmaf(B0, p.icc_m_f[2], __builtin_fmaf(G0, p.icc_m_f[1], R0 * p.icc_m_f[0]));
                 col[1] = __builtin_fmaf(B0, p.icc_m_f[5], __builtin_fmaf(G0, p.icc_m_f[4], R0 * p.icc_m_f[3]));
                 col[2] = __builtin_fmaf(B0, p.icc_m_f[8], __builtin_fmaf(G0, p.icc_m_f[7], R0 * p.icc_m_f[6]));
+                if constexpr (ICCV == 4) {
+                    static_assert(AG_ICC_FASTPOW, "the RGBA kernel carries no pow table");
+                    const IccPowTableF noT = { nullptr };
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) col[c] = icc_inv4_f(noT, p.icc_out_f, col[c]);
+                }
             }
             const float a = cxx_clamp(v[k].w, 0.0f, 1.0f);                          // WriteHeifImage.cpp:1047
             if (p.premultiply && a < 1.0f) {                                        // :1049-1066
@@ -1927,8 +1933,10 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
 #ifndef AG_RGBA_HOT_ENABLE
 #define AG_RGBA_HOT_ENABLE 1
 #endif
-    const bool rgba_icc1 = AG_ICC1_HOT && p.icc_trc_type[0] != 0 && p.icc_out == 0 && p.icc_trc_linear[0] && p.icc_trc_linear[1] && p.icc_trc_linear[2];
-    if (AG_RGBA_HOT_ENABLE && (variant & 1) && (p.icc_trc_type[0] == 0 || rgba_icc1) && depth == 32 && planes == 4 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 0 && ys == 0 &&
+    const bool rgba_lin = AG_ICC1_HOT && p.icc_trc_type[0] != 0 && p.icc_trc_linear[0] && p.icc_trc_linear[1] && p.icc_trc_linear[2];
+    const bool rgba_icc1 = rgba_lin && p.icc_out == 0;
+    const bool rgba_icc4 = rgba_lin && p.icc_out == 4 && p.transfer == AVIFGPU_TRANSFER_CLIP && AG_ICC_FASTPOW;
+    if (AG_RGBA_HOT_ENABLE && (variant & 1) && (p.icc_trc_type[0] == 0 || rgba_icc1 || rgba_icc4) && depth == 32 && planes == 4 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 0 && ys == 0 &&
         (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 && p.dst[3] != nullptr &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |
           reinterpret_cast<uintptr_t>(p.dst[3]) | (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2] |
@@ -1938,9 +1946,10 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
         if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
             long long blocks = (spans + kRgbaWaves - 1) / kRgbaWaves;
             if (blocks > AG_RGBA_BLOCK_CAP * 4 / kRgbaWaves) blocks = AG_RGBA_BLOCK_CAP * 4 / kRgbaWaves;
-            snprintf(label, kLabelBytes, "write_rgba32_ycbcra444_hot<transfer=%d>%s", p.transfer, rgba_icc1 ? " icc=1" : "");
-#define AG_RGBA(TR) do { if (rgba_icc1) hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<TR, true>), dim3((int)blocks), dim3(AG_RGBA_STREAM_BLOCK), 0, st, p); \
-                         else hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<TR, false>), dim3((int)blocks), dim3(AG_RGBA_STREAM_BLOCK), 0, st, p); } while (0)
+            snprintf(label, kLabelBytes, "write_rgba32_ycbcra444_hot<transfer=%d>%s", p.transfer, rgba_icc1 ? " icc=1" : rgba_icc4 ? " icc=4" : "");
+            if (rgba_icc4) { hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<AVIFGPU_TRANSFER_CLIP, 4>), dim3((int)blocks), dim3(AG_RGBA_STREAM_BLOCK), 0, st, p); return hipGetLastError(); }
+#define AG_RGBA(TR) do { if (rgba_icc1) hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<TR, 1>), dim3((int)blocks), dim3(AG_RGBA_STREAM_BLOCK), 0, st, p); \
+                         else hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<TR, 0>), dim3((int)blocks), dim3(AG_RGBA_STREAM_BLOCK), 0, st, p); } while (0)
             switch (p.transfer) {
             case AVIFGPU_TRANSFER_PQ:       AG_RGBA(AVIFGPU_TRANSFER_PQ); break;
             case AVIFGPU_TRANSFER_HLG:      AG_RGBA(AVIFGPU_TRANSFER_HLG); break;

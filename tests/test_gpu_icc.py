@@ -125,6 +125,28 @@ def test_icc1_rgba_streaming_kernel_matches_lcms2(gpu, lcms, name, kind, trc, g,
 
 
 @pytest.mark.parametrize("name,kind,trc,g", [p for p in PROFILES if p[2] == 0 and p[3] == 1.0])
+@pytest.mark.parametrize("width,alpha", [(1024, pkg.ALPHA_PREMULTIPLIED), (515, pkg.ALPHA_STRAIGHT)])
+def test_icc4_rgba_streaming_kernel_matches_lcms2(gpu, lcms, name, kind, trc, g, width, alpha):
+    """RGBA f32 with a linear profile saved as SDR: -> sRGB (matrix + inverse curve) -> Clip -> Y,Cb,Cr,A on the RGBA streaming kernel."""
+    icc = _profile(lcms, kind, trc, g)
+    xf = gpu.icc_prepare(icc, pkg.ICC_TARGET_SRGB_FLOAT)
+    for bits in (10, 12):
+        d = pkg.WriteDesc(width=width, height=9, depth=32, planes=4, bit_depth=bits, transfer=pkg.TRANSFER_CLIP,
+                          alpha_state=alpha, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444, matrix_coefficients=pkg.MATRIX_BT601,
+                          color_primaries=pkg.PRIMARIES_BT709)
+        src = harness.make_write_source(d, seed=width + bits)
+        conv = src.copy()
+        assert lcms.oracle_icc_convert_rows_to_srgb_float(icc, len(icc), 1, conv.ctypes.data, d.width, d.height, conv.strides[0]) == 0
+        want = harness.oracle_write(d, conv)
+        got = _gpu_write_icc(gpu, d, src, xf)
+        k = gpu.last_kernel()
+        assert "write_rgba32_ycbcra444_hot" in k and "icc=4" in k, k
+        st = harness.compare_write(d, want, got)
+        print(f"icc4-rgba-streaming {name} width {width} {bits}-bit: exact {st['exact_frac']:.5f} max {st['max_abs']}")
+        assert st["max_abs"] <= 1 and st["exact_frac"] >= 0.985, (name, st)
+
+
+@pytest.mark.parametrize("name,kind,trc,g", [p for p in PROFILES if p[2] == 0 and p[3] == 1.0])
 @pytest.mark.parametrize("width", [1024, 516])
 def test_icc4_streaming_kernel_matches_lcms2(gpu, lcms, name, kind, trc, g, width):
     """The SDR save of a 32-bit document with a linear profile (always converted to sRGB, ColorProfileConversion.cpp:118-123):
