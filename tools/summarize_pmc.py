@@ -13,7 +13,7 @@ import re
 import sys
 
 LAUNCHES = 210
-PAT = re.compile(r"write_px|read_px|write_rgb32|write_rgb16|write_rgba32|write_f32_ref|write_int_ref")
+PAT = re.compile(r"avifgpu::(write_|read_px)")     # every conversion kernel of the library (build_read_tables is not one)
 
 
 def rows(path_glob):
