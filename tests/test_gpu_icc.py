@@ -225,6 +225,29 @@ def _gpu_write_icc(gpu, d, src, xf):
     return harness._trim(d, bufs, d.height, harness.write_planes)
 
 
+def test_icc_streaming_and_generic_kernels_agree_within_tier2(gpu, lcms):
+    """with an ICC transform the streaming kernels (single-precision 3x3) and the generic kernel (FP64 3x3) are
+    identical within tier 2, not byte for byte."""
+    icc = _profile(lcms, 1, 0, 1.0)                                  # linear Display P3
+    for target, transfer, bits in ((None, pkg.TRANSFER_PQ, 12), (pkg.ICC_TARGET_SRGB_FLOAT, pkg.TRANSFER_CLIP, 12)):
+        xf = gpu.icc_prepare(icc) if target is None else gpu.icc_prepare(icc, target)
+        for planes, chroma in ((3, pkg.CHROMA_444), (3, pkg.CHROMA_420), (4, pkg.CHROMA_444)):
+            d = pkg.WriteDesc(width=1024, height=16, depth=32, planes=planes, bit_depth=bits, transfer=transfer, peak_nits=80,
+                              alpha_state=pkg.ALPHA_STRAIGHT if planes == 4 else pkg.ALPHA_NONE, output=pkg.OUT_YCBCR, chroma=chroma,
+                              matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020)
+            src = harness.make_write_source(d, seed=77)
+            try:
+                fast = _gpu_write_icc(gpu, d, src, xf)
+                assert "hot" in gpu.last_kernel(), gpu.last_kernel()
+                gpu.lib.avifgpu_set_hot_variant(0)
+                slow = _gpu_write_icc(gpu, d, src, xf)
+                assert "write_px" in gpu.last_kernel(), gpu.last_kernel()
+            finally:
+                gpu.lib.avifgpu_set_hot_variant(1 | 2 | 4)
+            st = harness.compare_write(d, slow, fast)
+            assert st["max_abs"] <= 1 and st["exact_frac"] >= 0.995, (target, planes, chroma, st)
+
+
 def test_icc_matrix_agrees_with_lcms2(gpu, lcms):
     """The prepared 3x3 reproduces lcms2 on the unit vectors to float rounding, for every test profile."""
     for name, kind, trc, g in PROFILES:
