@@ -79,3 +79,42 @@ def test_write_fuzz_wide_aligned(gpu, i):
                 assert st["max_abs"] == 0, (kw, row0, nrows, gpu.last_kernel(), st)
     finally:
         gpu.lib.avifgpu_set_hot_variant(1 | 2 | 4)
+
+
+def _read_case(i):
+    rng = np.random.default_rng(9191 + i)
+    bits, depth = [(8, 8), (8, 8), (10, 16), (12, 16), (10, 32), (12, 32)][int(rng.integers(0, 6))]
+    cs = int(rng.choice([pkg.COLORSPACE_YCBCR, pkg.COLORSPACE_YCBCR, pkg.COLORSPACE_YCBCR, pkg.COLORSPACE_RGB, pkg.COLORSPACE_MONOCHROME]))
+    chroma = {pkg.COLORSPACE_YCBCR: int(rng.choice([pkg.CHROMA_444, pkg.CHROMA_422, pkg.CHROMA_420])),
+              pkg.COLORSPACE_RGB: pkg.CHROMA_444, pkg.COLORSPACE_MONOCHROME: pkg.CHROMA_MONOCHROME}[cs]
+    w = max(8, int(rng.integers(40, 3000)) // int(rng.choice([1, 2, 8, 16])) * int(rng.choice([1, 2, 8, 16])))
+    kw = dict(width=w, height=int(rng.integers(1, 10)), colorspace=cs, chroma=chroma, bit_depth=bits, depth=depth,
+              alpha_state=int(rng.choice([pkg.ALPHA_NONE, pkg.ALPHA_STRAIGHT, pkg.ALPHA_PREMULTIPLIED])),
+              matrix_coefficients=pkg.MATRIX_RGB_GBR if cs == pkg.COLORSPACE_RGB else int(rng.choice([pkg.MATRIX_BT601, pkg.MATRIX_BT709, pkg.MATRIX_BT2020_NCL])),
+              color_primaries=pkg.PRIMARIES_BT709, full_range_flag=int(rng.random() < 0.7) if cs != pkg.COLORSPACE_RGB else 1)
+    if depth == 32:
+        kw.update(transfer_characteristics=pkg.TC_PQ if cs == pkg.COLORSPACE_MONOCHROME else int(rng.choice([pkg.TC_PQ, pkg.TC_HLG, pkg.TC_SMPTE428])),
+                  pq_peak_nits=int(rng.choice([80, 1000])))
+    return kw
+
+
+@pytest.mark.parametrize("i", range(160))
+def test_read_fuzz_wide_aligned(gpu, i):
+    import cases
+    from test_gpu_read import _check
+    kw = _read_case(i)
+    d = pkg.ReadDesc(**kw)
+    planes = harness.make_read_source(d, seed=i)
+    fixed = {}
+    for pl, arr in planes.items():                                 # 16-byte strides, as libheif pads its planes
+        out = np.zeros((arr.shape[0], align(arr.shape[1] * arr.itemsize, 16) // arr.itemsize), dtype=arr.dtype)
+        out[:, :arr.shape[1]] = arr
+        fixed[pl] = out
+    cut = 2 * int(np.random.default_rng(i).integers(0, d.height // 2 + 1))
+    for row0, nrows in ((0, cut), (cut, d.height - cut)):
+        if nrows == 0:
+            continue
+        want = harness.oracle_read(d, fixed, row0, nrows)
+        got = harness.gpu_read(gpu, d, fixed, row0, nrows, mem="device")
+        assert "aligned=1" in gpu.last_kernel(), gpu.last_kernel()
+        _check(f"read-fuzz-wide-{i}", kw, got, want)
