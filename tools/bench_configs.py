@@ -143,6 +143,7 @@ if __name__ == "__main__":
     bench_write("BIG 16384^2 RGB16 -> 12-bit 4:4:4 BT.2020", width=16384, height=16384, depth=16, planes=3, bit_depth=12, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=P.MATRIX_BT2020_NCL, color_primaries=9)
     bench_write("BIG 16384^2 RGB8 -> 8-bit 4:2:0 BT.709", width=16384, height=16384, depth=8, planes=3, bit_depth=8, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=P.MATRIX_BT709)
     bench_write("BIG 16384^2 RGB f32 -> 10-bit PQ interleaved (reference hand-off)", width=16384, height=16384, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=0)
+    bench_write("W32 8192^2 RGBA f32 -> 10-bit PQ 4:2:0 + alpha", width=8192, height=8192, depth=32, planes=4, bit_depth=10, transfer=0, peak_nits=80, alpha_state=1, output=1, chroma=P.CHROMA_420, matrix_coefficients=9, color_primaries=9)
     bench_write("C5 16384^2 RGBA f32 -> 12-bit PQ 4:4:4 + alpha", width=16384, height=16384, depth=32, planes=4, bit_depth=12, transfer=0, peak_nits=80, alpha_state=1, output=1, chroma=P.CHROMA_444, matrix_coefficients=9, color_primaries=9)
     bench_write("RGBA8 premultiplied -> 8-bit interleaved (reference hand-off) 8192^2", width=8192, height=8192, depth=8, planes=4, bit_depth=8, alpha_state=2, output=0)
     bench_write("REF RGB16 -> 12-bit interleaved (reference hand-off) 8192^2", width=8192, height=8192, depth=16, planes=3, bit_depth=12, alpha_state=0, output=0)
