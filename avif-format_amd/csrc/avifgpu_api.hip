@@ -198,23 +198,34 @@ int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p)
 {
     if (t->grid_points != AVIFGPU_ICC_CLUT_GRID) return fail(AVIFGPU_formatBadParameters, "16-bit ICC table: grid_points must be 33");
     const size_t n = sizeof(t->table);
-    // one plane + one row + one node of zero padding behind the table: the kernel steps past the last node of an axis whose
-    // input is 0xffff (with weight 0, see icc16_tetrahedral)
+    // Device layout: one 64-byte RECORD per cell holding its eight corner nodes (corner j = 4*dr + 2*dg + db, 8 bytes each), so the
+    // four nodes a pixel's tetrahedron needs sit in ONE cache line instead of up to four lines 8.7 KiB / 264 B apart in the node-major
+    // table.  Cells exist for index 32 on every axis too (input 0xffff lands there with fraction 0): corners beyond the grid are
+    // zero, which is what the library's zeroed strides amount to (the node they reach is multiplied by 0).  33^3 x 64 B = 2.3 MB.
     constexpr size_t G = AVIFGPU_ICC_CLUT_GRID;
-    const size_t pad = (G * G + G + 1) * sizeof(t->table[0]);
+    const size_t rec_bytes = G * G * G * 64;
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return hip_fail(e, "hipGetDevice", AVIFGPU_writErr);
     std::lock_guard<std::mutex> lk(g_icc_mu);
     IccDeviceTables& c = g_icc_tables[dev];
     if (!c.icc16) {
-        e = hipMalloc(&c.icc16, n + pad);
-        if (e == hipSuccess) e = hipMemset(static_cast<uint8_t*>(c.icc16) + n, 0, pad);
-        if (e != hipSuccess) { if (c.icc16) (void)hipFree(c.icc16); c.icc16 = nullptr; return hip_fail(e, "hipMalloc(icc16 table)", AVIFGPU_memFullErr); }
+        e = hipMalloc(&c.icc16, rec_bytes);
+        if (e != hipSuccess) { c.icc16 = nullptr; return hip_fail(e, "hipMalloc(icc16 table)", AVIFGPU_memFullErr); }
     }
     if (c.icc16_host.size() != n || memcmp(c.icc16_host.data(), t->table, n) != 0) {
+        std::vector<uint16_t> rec(rec_bytes / 2, 0);
+        for (size_t r = 0; r < G; ++r)
+            for (size_t g = 0; g < G; ++g)
+                for (size_t b = 0; b < G; ++b) {
+                    uint16_t* dst = rec.data() + ((r * G + g) * G + b) * 32;
+                    for (int j = 0; j < 8; ++j) {
+                        const size_t rr = r + ((j >> 2) & 1), gg = g + ((j >> 1) & 1), bb = b + (j & 1);
+                        if (rr < G && gg < G && bb < G) memcpy(dst + 4 * j, t->table[(rr * G + gg) * G + bb], 8);
+                    }
+                }
         e = hipDeviceSynchronize();                             // a launch may still be reading the previous table
-        if (e == hipSuccess) e = hipMemcpy(c.icc16, t->table, n, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(c.icc16, rec.data(), rec_bytes, hipMemcpyHostToDevice);
         if (e != hipSuccess) return hip_fail(e, "upload of the ICC table", AVIFGPU_writErr);
         c.icc16_host.assign(reinterpret_cast<const uint8_t*>(t->table), reinterpret_cast<const uint8_t*>(t->table) + n);
     }

@@ -338,20 +338,18 @@ AG_DEV void icc16_tetrahedral(const uint16_t* __restrict__ clut, const uint32_t 
         c0i[k] = f >> 16;
         r[k] = f & 0xffffu;
     }
-    // Node index strides (table is [r][g][b][4]).  The library zeroes the stride of an axis whose input is 0xffff (cell index 32,
-    // the last node); its fraction is then 0, so whatever node the full stride reaches is multiplied by 0 -- the device copy of the
-    // table is padded by one plane + one row + one node of zeros (upload_icc16) and the three compare/select pairs disappear.
-    constexpr uint32_t s0 = (uint32_t)(G * G), s1 = (uint32_t)G, s2 = 1u;
-    const uint32_t base = (c0i[0] * G + c0i[1]) * G + c0i[2];
+    // The device table holds one 64-byte record per CELL: its eight corner nodes, corner j = 4*dr + 2*dg + db (upload_icc16), so the
+    // four nodes of the tetrahedron come from one cache line.  The library zeroes the stride of an axis whose input is 0xffff (cell
+    // index 32); its fraction is then 0, and the records of those cells hold zeros for the corners beyond the grid.
+    const uint32_t cell = (c0i[0] * G + c0i[1]) * G + c0i[2];
     const uint32_t mx = max(max(r[0], r[1]), r[2]), mn = min(min(r[0], r[1]), r[2]);
     const uint32_t md = r[0] + r[1] + r[2] - mx - mn;
-    const uint32_t smax = r[0] == mx ? s0 : (r[1] == mx ? s1 : s2);  // first axis holding the maximum ...
-    const uint32_t smin = r[2] == mn ? s2 : (r[1] == mn ? s1 : s0);  // ... last axis holding the minimum: distinct axes even when all tie
-    const uint32_t n1 = base + smax, n3 = base + s0 + s1 + s2, n2 = n3 - smin;
+    const uint32_t jmax = r[0] == mx ? 4u : (r[1] == mx ? 2u : 1u);  // first axis holding the maximum ...
+    const uint32_t jmin = r[2] == mn ? 1u : (r[1] == mn ? 2u : 4u);  // ... last axis holding the minimum: distinct axes even when all tie
     const uint32_t ra = mx, rb = md, rc = mn;
     typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-    const u2 v0 = *reinterpret_cast<const u2*>(clut + 4 * base), v1 = *reinterpret_cast<const u2*>(clut + 4 * n1);
-    const u2 v2 = *reinterpret_cast<const u2*>(clut + 4 * n2),   v3 = *reinterpret_cast<const u2*>(clut + 4 * n3);
+    const u2* rec = reinterpret_cast<const u2*>(clut + 32 * cell);
+    const u2 v0 = rec[0], v1 = rec[jmax], v2 = rec[7u - jmin], v3 = rec[7];
     const uint32_t p0[3] = { v0.x & 0xffffu, v0.x >> 16, v0.y & 0xffffu }, p1[3] = { v1.x & 0xffffu, v1.x >> 16, v1.y & 0xffffu };
     const uint32_t p2[3] = { v2.x & 0xffffu, v2.x >> 16, v2.y & 0xffffu }, p3[3] = { v3.x & 0xffffu, v3.x >> 16, v3.y & 0xffffu };
 #pragma unroll
