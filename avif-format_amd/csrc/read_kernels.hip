@@ -408,8 +408,13 @@ template <int CS, int DEPTH, bool ALPHA, int XS> struct ReadShape {
     static constexpr int PXT = NC << XS;
 };
 
+// Workgroup size of the read kernel (its waves share only the table copy).
+#ifndef AG_RPX_BLOCK
+#define AG_RPX_BLOCK 256
+#endif
+constexpr int kRpxWaves = AG_RPX_BLOCK / 64;
 template <int CS, int DEPTH, bool ALPHA, int XS, int YS, int TRANSFER, bool LUT, bool ALIGNED>
-__global__ __launch_bounds__(256) void read_px(const ReadParams p)
+__global__ __launch_bounds__(AG_RPX_BLOCK) void read_px(const ReadParams p)
 {
     constexpr bool SRC16 = DEPTH != 8;
     constexpr int NC = ReadShape<CS, DEPTH, ALPHA, XS>::NC;
@@ -467,8 +472,8 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
         }
     };
 
-    const uint32_t wstep = gridDim.x * 4;
-    uint32_t wv = blockIdx.x * 4 + wave;
+    const uint32_t wstep = gridDim.x * kRpxWaves;
+    uint32_t wv = blockIdx.x * kRpxWaves + wave;
     Group cur;
     // Gray kernels issue their first group's plane loads BEFORE the table copy and its barrier (a workgroup lives for one or a few
     // groups, so the copy otherwise sits in front of every group's HBM latency): -3 % on the three mono rows.  The colour kernels
@@ -482,7 +487,7 @@ __global__ __launch_bounds__(256) void read_px(const ReadParams p)
         typedef float f4 __attribute__((ext_vector_type(4)));
         const f4* src4 = reinterpret_cast<const f4*>(p.tables);
         f4* dst4 = reinterpret_cast<f4*>(lut);
-        for (int i = threadIdx.x; i < (lut_floats >> 2); i += 256) dst4[i] = src4[i];           // L2-resident, built once
+        for (int i = threadIdx.x; i < (lut_floats >> 2); i += AG_RPX_BLOCK) dst4[i] = src4[i];           // L2-resident, built once
         __syncthreads();
     }
     for (; wv < total_waves; wv += wstep) {
@@ -699,7 +704,7 @@ static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, char* lab
     constexpr int NCHL = (CS == kCsMono ? 1 : 3) + (ALPHA ? 1 : 0);
     constexpr int ND_OUT = PXT * NCHL * (DEPTH / 8) / 4;
     const long long waves = (long long)(((p.width + PXT - 1) / PXT + 63) / 64) * ((p.nrows + (1 << YS) - 1) >> YS);
-    long long blocks = (waves + 3) / 4;
+    long long blocks = (waves + kRpxWaves - 1) / kRpxWaves;
     // Grid cap, measured (profiles/r01/ab_read_variants.txt, second table): with the tables copied from the device cache
     // instead of rebuilt per workgroup, a 16k-block grid beats 2k by 5-10 % on the f32 and 10-bit kernels.
 #ifndef AG_READ_BLOCK_CAP
@@ -711,7 +716,7 @@ static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, char* lab
     uintptr_t bits = reinterpret_cast<uintptr_t>(p.dst) | (uintptr_t)p.dst_row_bytes;
     for (int pl = 0; pl < 4; ++pl) if (p.src[pl]) bits |= reinterpret_cast<uintptr_t>(p.src[pl]) | (uintptr_t)p.src_stride[pl];
     const bool aligned = (bits & 15) == 0;      // => branch-free vector loads + LDS-transposed coalesced stores
-    const size_t lds = lut_bytes + ((aligned && ND_OUT > 4) ? (size_t)4 * WaveSpan<ND_OUT>::STRIP_DW * sizeof(uint32_t) : 0);
+    const size_t lds = lut_bytes + ((aligned && ND_OUT > 4) ? (size_t)kRpxWaves * WaveSpan<ND_OUT>::STRIP_DW * sizeof(uint32_t) : 0);
     snprintf(label, kLabelBytes, "read_px<cs=%d,depth=%d,alpha=%d,xs=%d,ys=%d,transfer=%d,aligned=%d>", CS, DEPTH, (int)ALPHA, XS, YS,
              TRANSFER, (int)aligned);
     ReadParams q = p;
@@ -719,7 +724,7 @@ static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, char* lab
         const hipError_t e = cached_tables<CS, DEPTH, ALPHA, TRANSFER>(p, st, &q.tables);
         if (e != hipSuccess) return e;
     }
-#define AG_READ_LAUNCH(LUT_, AL_) hipLaunchKernelGGL((read_px<CS, DEPTH, ALPHA, XS, YS, TRANSFER, LUT_, AL_>), dim3((int)blocks), dim3(256), lds, st, q)
+#define AG_READ_LAUNCH(LUT_, AL_) hipLaunchKernelGGL((read_px<CS, DEPTH, ALPHA, XS, YS, TRANSFER, LUT_, AL_>), dim3((int)blocks), dim3(AG_RPX_BLOCK), lds, st, q)
     if constexpr (DEPTH == 8) {
         if (aligned) AG_READ_LAUNCH(true, true); else AG_READ_LAUNCH(true, false);
     } else {
