@@ -27,6 +27,23 @@ class Ranks:
                     print(f"[distrib] nccl init failed ({exc}); using gloo for barrier/MAX", file=sys.stderr)
                     dist.init_process_group(backend="gloo")
             self.dist = dist
+            # a CPU-side (gloo) group next to RCCL: ranks that only WAIT (rank 0's single-process sections of bench.py) then block
+            # on a socket instead of spinning in a collective kernel on their GPU
+            self.cpu_group = None
+            if dist.get_backend() == "nccl":
+                try:
+                    self.cpu_group = dist.new_group(backend="gloo")
+                except Exception:                # noqa: BLE001 -- fall back to the device barrier
+                    self.cpu_group = None
+
+    def host_barrier(self):
+        """Barrier that keeps the GPUs idle while ranks wait (falls back to barrier())."""
+        if self.dist is None:
+            return
+        if getattr(self, "cpu_group", None) is not None:
+            self.dist.barrier(group=self.cpu_group)
+        else:
+            self.barrier()
 
     def barrier(self):
         if self.dist is not None:

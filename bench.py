@@ -348,7 +348,7 @@ def main():
                 out["pcie_inclusive"] = {"value": None, "note": f"skipped: {exc}"}
         else:
             out["pcie_inclusive"] = {"value": None, "note": f"skipped: {ndev} device(s) visible to rank 0, {world} needed"}
-    ranks.barrier()
+    ranks.host_barrier()          # the other ranks waited here on the CPU: their GPUs were rank 0's to use
 
     if rank == 0 and world == 1:
         if not args.no_cpu_baseline:
