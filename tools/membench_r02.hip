@@ -104,6 +104,97 @@ void run(const char* name, int W, int H, int launches, int nset = 1)
     fflush(stdout);
 }
 
+
+// The u8 READ pattern (8-bit 4:2:0 YCbCr planes -> interleaved RGB8, 4.5 B/px, two thirds of it WRITES): a wave owns 1024 pixels on
+// two rows -- 16-byte loads of the two luma rows, 8-byte loads of the two chroma rows, three 16-byte stores per output row.
+__global__ __launch_bounds__(256) void k_read8(const unsigned char* __restrict__ y, const unsigned char* __restrict__ cb, const unsigned char* __restrict__ cr,
+                                               unsigned char* __restrict__ out, int width, int height)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned spans_per_row = width / 1024, total = spans_per_row * (height / 2);
+    for (unsigned s = blockIdx.x * 4 + wave; s < total; s += gridDim.x * 4) {
+        const unsigned gy = s / spans_per_row, sx = s - gy * spans_per_row;
+        const size_t x = (size_t)sx * 1024 + lane * 16;
+        const u4 y0 = __builtin_nontemporal_load((const u4*)(y + (size_t)(2 * gy) * width + x));
+        const u4 y1 = __builtin_nontemporal_load((const u4*)(y + (size_t)(2 * gy + 1) * width + x));
+        const u2 c0 = __builtin_nontemporal_load((const u2*)(cb + (size_t)gy * (width / 2) + x / 2));
+        const u2 c1 = __builtin_nontemporal_load((const u2*)(cr + (size_t)gy * (width / 2) + x / 2));
+        const unsigned acc = y0.x ^ y0.y ^ y0.z ^ y0.w ^ y1.x ^ y1.y ^ y1.z ^ y1.w ^ c0.x ^ c0.y ^ c1.x ^ c1.y;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            u4* o = (u4*)(out + ((size_t)(2 * gy + r) * width + (size_t)sx * 1024) * 3) + lane;     // 3 x 1 KiB per row, transfer-major
+            st16<1>(o, u4{ acc, acc + 1, acc + 2, acc + 3 });
+            st16<1>(o + 64, u4{ acc, acc + 1, acc + 2, acc + 4 });
+            st16<1>(o + 128, u4{ acc, acc + 1, acc + 2, acc + 5 });
+        }
+    }
+}
+static void run_read8(int W, int H, int launches)
+{
+    unsigned char* y = (unsigned char*)g_p[1]; unsigned char* cb = (unsigned char*)g_p[2]; unsigned char* cr = cb + (size_t)W * H / 4;
+    unsigned char* out = (unsigned char*)g_in;                 // 3 B/px: the 4-GiB buffer
+    const int blocks = (W / 1024) * (H / 2) / 4;
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 300; ++i) hipLaunchKernelGGL(k_read8, dim3(blocks), dim3(256), 0, 0, y, cb, cr, out, W, H);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    for (int i = 0; i < launches; ++i) hipLaunchKernelGGL(k_read8, dim3(blocks), dim3(256), 0, 0, y, cb, cr, out, W, H);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= launches;
+    const double bytes = (double)W * H * 4.5;
+    printf("%-58s wg  256  %8.4f ms  %7.1f GB/s  %.3f of 8 TB/s  (4.5 B/px)\n", W == 8192 ? "8-bit 4:2:0 planes -> RGB8 (read direction) 8192^2" : "8-bit 4:2:0 planes -> RGB8 (read direction) 16384^2", ms, bytes / ms / 1e6, bytes / ms / 1e6 / 8000);
+}
+
+
+// u16 planes -> interleaved RGB f32 (the HDR open): 4:4:4 (18 B/px, 2/3 writes) and 4:2:0 (15 B/px, 4/5 writes).  A wave owns 512
+// pixels on 1 << YS rows; 16-byte luma loads, 16- or 8-byte chroma loads, six 16-byte stores per output row.
+template <int YS>
+__global__ __launch_bounds__(256) void k_read32(const unsigned short* __restrict__ y, const unsigned short* __restrict__ cb, const unsigned short* __restrict__ cr,
+                                                float* __restrict__ out, int width, int height)
+{
+    constexpr int VR = 1 << YS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned spans_per_row = width / 512, total = spans_per_row * (height >> YS);
+    for (unsigned s = blockIdx.x * 4 + wave; s < total; s += gridDim.x * 4) {
+        const unsigned gy = s / spans_per_row, sx = s - gy * spans_per_row;
+        const size_t x = (size_t)sx * 512 + lane * 8;
+        unsigned acc = 0;
+#pragma unroll
+        for (int r = 0; r < VR; ++r) { const u4 t = __builtin_nontemporal_load((const u4*)(y + (size_t)(gy * VR + r) * width + x)); acc ^= t.x ^ t.y ^ t.z ^ t.w; }
+        if constexpr (YS) {
+            const u2 c0 = __builtin_nontemporal_load((const u2*)(cb + (size_t)gy * (width / 2) + x / 2));
+            const u2 c1 = __builtin_nontemporal_load((const u2*)(cr + (size_t)gy * (width / 2) + x / 2));
+            acc ^= c0.x ^ c0.y ^ c1.x ^ c1.y;
+        } else {
+            const u4 c0 = __builtin_nontemporal_load((const u4*)(cb + (size_t)gy * width + x));
+            const u4 c1 = __builtin_nontemporal_load((const u4*)(cr + (size_t)gy * width + x));
+            acc ^= c0.x ^ c0.y ^ c0.z ^ c0.w ^ c1.x ^ c1.y ^ c1.z ^ c1.w;
+        }
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+            u4* o = (u4*)(out + ((size_t)(gy * VR + r) * width + (size_t)sx * 512) * 3) + lane;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) st16<1>(o + 64 * k, u4{ acc, acc + 1, acc + 2, acc + 3 + (unsigned)k });
+        }
+    }
+}
+template <int YS>
+static void run_read32(int W, int H, int launches)
+{
+    unsigned short* y = g_p[1]; unsigned short* cb = g_p[2]; unsigned short* cr = g_p[3];
+    float* out = (float*)g_in;
+    const int blocks = (W / 512) * (H >> YS) / 4;
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 300; ++i) hipLaunchKernelGGL(k_read32<YS>, dim3(blocks), dim3(256), 0, 0, y, cb, cr, out, W, H);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    for (int i = 0; i < launches; ++i) hipLaunchKernelGGL(k_read32<YS>, dim3(blocks), dim3(256), 0, 0, y, cb, cr, out, W, H);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= launches;
+    const double bpp = YS ? 15.0 : 18.0, bytes = (double)W * H * bpp;
+    printf("%-58s wg  256  %8.4f ms  %7.1f GB/s  %.3f of 8 TB/s  (%.0f B/px)\n", YS ? "u16 4:2:0 planes -> RGB f32 (read direction) 8192^2" : "u16 4:4:4 planes -> RGB f32 (read direction) 8192^2", ms, bytes / ms / 1e6, bytes / ms / 1e6 / 8000, bpp);
+}
+
 int main(int argc, char** argv)
 {
     const char* mode = argc > 1 ? argv[1] : "patterns";
@@ -125,6 +216,10 @@ int main(int argc, char** argv)
             run<4, 0, 0, 256>("RGBA f32 -> Y,Cb,Cr,A (C5) 16384^2", 16384, 16384, 40);
             run<4, 0, 0, 128, 8>("RGBA f32 -> Y,Cb,Cr,A, 8 px / lane, 16384^2", 16384, 16384, 40);
             run<4, 0, 0, 128>("RGBA f32 -> Y,Cb,Cr,A 8192^2", W, H, 100);
+            run_read8(8192, 8192, 300);
+            run_read8(16384, 16384, 100);
+            run_read32<0>(8192, 8192, 200);
+            run_read32<1>(8192, 8192, 200);
         } else {
             const int nset = !strcmp(mode, "rotate") ? 4 : 1;
             printf("C4 pattern (RGB f32 8192^2 -> three u16 planes), buffer sets: %d.  policy bits: 1 nt, 2 sc0, 4 sc1\n", nset);
