@@ -107,6 +107,7 @@ void run(const char* name, int W, int H, int launches, int nset = 1)
 
 // The u8 READ pattern (8-bit 4:2:0 YCbCr planes -> interleaved RGB8, 4.5 B/px, two thirds of it WRITES): a wave owns 1024 pixels on
 // two rows -- 16-byte loads of the two luma rows, 8-byte loads of the two chroma rows, three 16-byte stores per output row.
+template <int POL>
 __global__ __launch_bounds__(256) void k_read8(const unsigned char* __restrict__ y, const unsigned char* __restrict__ cb, const unsigned char* __restrict__ cr,
                                                unsigned char* __restrict__ out, int width, int height)
 {
@@ -123,28 +124,30 @@ __global__ __launch_bounds__(256) void k_read8(const unsigned char* __restrict__
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             u4* o = (u4*)(out + ((size_t)(2 * gy + r) * width + (size_t)sx * 1024) * 3) + lane;     // 3 x 1 KiB per row, transfer-major
-            st16<1>(o, u4{ acc, acc + 1, acc + 2, acc + 3 });
-            st16<1>(o + 64, u4{ acc, acc + 1, acc + 2, acc + 4 });
-            st16<1>(o + 128, u4{ acc, acc + 1, acc + 2, acc + 5 });
+            st16<POL>(o, u4{ acc, acc + 1, acc + 2, acc + 3 });
+            st16<POL>(o + 64, u4{ acc, acc + 1, acc + 2, acc + 4 });
+            st16<POL>(o + 128, u4{ acc, acc + 1, acc + 2, acc + 5 });
         }
     }
 }
-static void run_read8(int W, int H, int launches)
+template <int POL = 1>
+static void run_read8(int W, int H, int launches, int nset = 1)
 {
     unsigned char* y = (unsigned char*)g_p[1]; unsigned char* cb = (unsigned char*)g_p[2]; unsigned char* cr = cb + (size_t)W * H / 4;
-    unsigned char* out = (unsigned char*)g_in;                 // 3 B/px: the 4-GiB buffer
+    unsigned char* out = (unsigned char*)g_in;                 // 3 B/px: the 4-GiB buffer (nset disjoint outputs when rotating)
+    const size_t oset = (size_t)W * H * 3;
     const int blocks = (W / 1024) * (H / 2) / 4;
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    for (int i = 0; i < 300; ++i) hipLaunchKernelGGL(k_read8, dim3(blocks), dim3(256), 0, 0, y, cb, cr, out, W, H);
+    for (int i = 0; i < 300; ++i) hipLaunchKernelGGL(k_read8<POL>, dim3(blocks), dim3(256), 0, 0, y, cb, cr, out + oset * (i % nset), W, H);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(a));
-    for (int i = 0; i < launches; ++i) hipLaunchKernelGGL(k_read8, dim3(blocks), dim3(256), 0, 0, y, cb, cr, out, W, H);
+    for (int i = 0; i < launches; ++i) hipLaunchKernelGGL(k_read8<POL>, dim3(blocks), dim3(256), 0, 0, y, cb, cr, out + oset * (i % nset), W, H);
     CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= launches;
     const double bytes = (double)W * H * 4.5;
-    printf("%-58s wg  256  %8.4f ms  %7.1f GB/s  %.3f of 8 TB/s  (4.5 B/px)\n", W == 8192 ? "8-bit 4:2:0 planes -> RGB8 (read direction) 8192^2" : "8-bit 4:2:0 planes -> RGB8 (read direction) 16384^2", ms, bytes / ms / 1e6, bytes / ms / 1e6 / 8000);
+    char name[128]; snprintf(name, sizeof name, "8-bit 4:2:0 planes -> RGB8 (read direction) %d^2, stores %d, %d set(s)", W, POL, nset);
+    printf("%-58s wg  256  %8.4f ms  %7.1f GB/s  %.3f of 8 TB/s  (4.5 B/px)\n", name, ms, bytes / ms / 1e6, bytes / ms / 1e6 / 8000);
 }
-
 
 // u16 planes -> interleaved RGB f32 (the HDR open): 4:4:4 (18 B/px, 2/3 writes) and 4:2:0 (15 B/px, 4/5 writes).  A wave owns 512
 // pixels on 1 << YS rows; 16-byte luma loads, 16- or 8-byte chroma loads, six 16-byte stores per output row.
@@ -220,6 +223,15 @@ int main(int argc, char** argv)
             run_read8(16384, 16384, 100);
             run_read32<0>(8192, 8192, 200);
             run_read32<1>(8192, 8192, 200);
+        } else if (!strcmp(mode, "readpolicy")) {                 // store policies on the write-heavy read pattern, rotating outputs
+            run_read8<1>(8192, 8192, 300, 4);
+            run_read8<0>(8192, 8192, 300, 4);
+            run_read8<2>(8192, 8192, 300, 4);
+            run_read8<4>(8192, 8192, 300, 4);
+            run_read8<6>(8192, 8192, 300, 4);
+            run_read8<5>(8192, 8192, 300, 4);
+            run_read8<3>(8192, 8192, 300, 4);
+            run_read8<7>(8192, 8192, 300, 4);
         } else {
             const int nset = !strcmp(mode, "rotate") ? 4 : 1;
             printf("C4 pattern (RGB f32 8192^2 -> three u16 planes), buffer sets: %d.  policy bits: 1 nt, 2 sc0, 4 sc1\n", nset);
