@@ -78,6 +78,7 @@ __global__ __launch_bounds__(BLOCK) void k(const f4* __restrict__ in, unsigned s
 }
 
 static f4* g_in; static unsigned short* g_p[4];
+static long long g_pitch = -1, g_skew = 0;      // "skew" mode: plane k at g_p[0] + k * (g_pitch + g_skew) elements (g_pitch < 0: separate allocations)
 
 // nset > 1: launch i uses buffer set i % nset (disjoint inputs and planes)
 template <int CH, int XS, int YS, int BLOCK, int PXL = (CH == 3 ? 8 : 4), int PY = 1, int PC = 1, bool NTL = true>
@@ -88,6 +89,11 @@ void run(const char* name, int W, int H, int launches, int nset = 1)
     const size_t plane = (size_t)W * H, inset = (size_t)W * H * CH / 4;          // elements
     auto launch = [&](int i) {
         const int j = i % nset;
+        if (g_pitch >= 0) {
+            const size_t d = (size_t)(g_pitch + g_skew);
+            hipLaunchKernelGGL((k<CH, XS, YS, BLOCK, PXL, PY, PC, NTL>), dim3(blocks), dim3(BLOCK), 0, 0, g_in, g_p[0], g_p[0] + d, g_p[0] + 2 * d, g_p[0] + 3 * d, W, H);
+            return;
+        }
         hipLaunchKernelGGL((k<CH, XS, YS, BLOCK, PXL, PY, PC, NTL>), dim3(blocks), dim3(BLOCK), 0, 0, g_in + inset * j, g_p[0] + plane * j, g_p[1] + plane * j,
                            g_p[2] + plane * j, g_p[3] + plane * j, W, H);
     };
@@ -223,6 +229,20 @@ int main(int argc, char** argv)
             run_read8(16384, 16384, 100);
             run_read32<0>(8192, 8192, 200);
             run_read32<1>(8192, 8192, 200);
+        } else if (!strcmp(mode, "skew")) {                       // do the distances between the three output planes matter?
+            printf("separate allocations: %p %p %p\n", (void*)g_p[0], (void*)g_p[1], (void*)g_p[2]);
+            run<3, 0, 0, 128>("C4, planes in separate allocations", W, H, 200);
+            unsigned short* keep = g_p[0];
+            unsigned short* pool; CK(hipMalloc(&pool, (size_t)3300 << 20)); g_p[0] = pool;
+            printf("pool %p, input %p\n", (void*)pool, (void*)g_in);
+            const long long mib[] = { 128, 129, 130, 132, 136, 144, 160, 192, 256, 258, 384, 512, 514, 640, 768, 1024, 1026, 1536 };
+            for (long long m : mib) {
+                g_pitch = m << 19; g_skew = 0;                     // elements of 2 B
+                char nm[96]; snprintf(nm, sizeof nm, "C4, planes %lld MiB apart", m);
+                run<3, 0, 0, 128>(nm, W, H, 200);
+            }
+            CK(hipFree(pool)); g_p[0] = keep;
+            g_pitch = -1;
         } else if (!strcmp(mode, "readpolicy")) {                 // store policies on the write-heavy read pattern, rotating outputs
             run_read8<1>(8192, 8192, 300, 4);
             run_read8<0>(8192, 8192, 300, 4);
