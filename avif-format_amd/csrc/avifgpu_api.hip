@@ -198,12 +198,16 @@ int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p)
 {
     if (t->grid_points != AVIFGPU_ICC_CLUT_GRID) return fail(AVIFGPU_formatBadParameters, "16-bit ICC table: grid_points must be 33");
     const size_t n = sizeof(t->table);
-    // Device layout: one 64-byte RECORD per cell holding its eight corner nodes (corner j = 4*dr + 2*dg + db, 8 bytes each), so the
-    // four nodes a pixel's tetrahedron needs sit in ONE cache line instead of up to four lines 8.7 KiB / 264 B apart in the node-major
-    // table.  Cells exist for index 32 on every axis too (input 0xffff lands there with fraction 0): corners beyond the grid are
-    // zero, which is what the library's zeroed strides amount to (the node they reach is multiplied by 0).  33^3 x 64 B = 2.3 MB.
+    // Device layout: one 128-byte RECORD (a cache line) per cell, seven 16-byte units of two nodes each (8 bytes per node; corner
+    // j = 4*dr + 2*dg + db): unit 0 = {corner 0, corner 7}, which every tetrahedron uses, and unit 1 + k = {corner 4 >> amax,
+    // corner 7 - (4 >> amin)} for the six orders of (axis of the largest fraction, axis of the smallest), k = 2*amax + amin -
+    // (amin > amax) -- so the four nodes of a pixel's tetrahedron arrive in TWO 16-byte gathers from ONE line, instead of four
+    // 8-byte gathers (or, in lcms2's node-major table, up to four lines 8.7 KiB / 264 B apart).  Cells exist for index 32 on every
+    // axis too (input 0xffff lands there with fraction 0): corners beyond the grid are zero, which is what the library's zeroed
+    // strides amount to (the node they reach is multiplied by 0).  33^3 x 128 B = 4.6 MB.
     constexpr size_t G = AVIFGPU_ICC_CLUT_GRID;
-    const size_t rec_bytes = G * G * G * 64;
+    constexpr size_t kRecU16 = kIcc16RecBytes / 2;
+    const size_t rec_bytes = G * G * G * kIcc16RecBytes;
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return hip_fail(e, "hipGetDevice", AVIFGPU_writErr);
@@ -218,11 +222,18 @@ int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p)
         for (size_t r = 0; r < G; ++r)
             for (size_t g = 0; g < G; ++g)
                 for (size_t b = 0; b < G; ++b) {
-                    uint16_t* dst = rec.data() + ((r * G + g) * G + b) * 32;
-                    for (int j = 0; j < 8; ++j) {
+                    uint16_t* dst = rec.data() + ((r * G + g) * G + b) * kRecU16;
+                    auto put = [&](int unit, int half, int j) {            // node of corner j -> 8 bytes at unit * 16 + half * 8
                         const size_t rr = r + ((j >> 2) & 1), gg = g + ((j >> 1) & 1), bb = b + (j & 1);
-                        if (rr < G && gg < G && bb < G) memcpy(dst + 4 * j, t->table[(rr * G + gg) * G + bb], 8);
-                    }
+                        if (rr < G && gg < G && bb < G) memcpy(dst + 8 * unit + 4 * half, t->table[(rr * G + gg) * G + bb], 8);
+                    };
+                    put(0, 0, 0); put(0, 1, 7);
+                    for (int amax = 0; amax < 3; ++amax)
+                        for (int amin = 0; amin < 3; ++amin) {
+                            if (amin == amax) continue;
+                            const int k = 2 * amax + amin - (amin > amax ? 1 : 0);
+                            put(1 + k, 0, 4 >> amax); put(1 + k, 1, 7 - (4 >> amin));
+                        }
                 }
         e = hipDeviceSynchronize();                             // a launch may still be reading the previous table
         if (e == hipSuccess) e = hipMemcpy(c.icc16, rec.data(), rec_bytes, hipMemcpyHostToDevice);

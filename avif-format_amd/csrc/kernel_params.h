@@ -11,6 +11,9 @@ namespace avifgpu {
 //   (0 = default).  (Bits 3 and 4 selected a register-prefetch and an XCD-contiguous variant in round 1; both lost and were removed.)
 enum : int { kHotDefault = 1 | 2 | 4 };
 
+// 16-bit ICC table on the device: bytes per cell record (upload_icc16 builds it, icc16_tetrahedral reads it)
+enum : int { kIcc16RecBytes = 128 };
+
 struct WriteParams {
     const uint8_t* src;          // row `row0`, interleaved
     int64_t        src_row_bytes;
@@ -51,7 +54,7 @@ struct WriteParams {
     const uint8_t* icc8_s2;      // [16385] 8-bit output curve (identical for R,G,B: the destination is sRGB)
     int32_t icc8_m[9];
     int32_t icc8_off[3];
-    // 16-bit CLUT transform (avifgpu_icc_clut16): 33^3 nodes x 4 u16 in device memory (L2-resident, 281 KiB)
+    // 16-bit CLUT transform (avifgpu_icc_clut16): 33^3 cell records of kIcc16RecBytes in device memory (4.6 MB)
     const uint16_t* icc16_clut;
 };
 

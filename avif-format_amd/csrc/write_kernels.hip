@@ -338,18 +338,21 @@ AG_DEV void icc16_tetrahedral(const uint16_t* __restrict__ clut, const uint32_t 
         c0i[k] = f >> 16;
         r[k] = f & 0xffffu;
     }
-    // The device table holds one 64-byte record per CELL: its eight corner nodes, corner j = 4*dr + 2*dg + db (upload_icc16), so the
-    // four nodes of the tetrahedron come from one cache line.  The library zeroes the stride of an axis whose input is 0xffff (cell
-    // index 32); its fraction is then 0, and the records of those cells hold zeros for the corners beyond the grid.
+    // The device table holds one 128-byte record (one cache line) per CELL, laid out for the FOUR nodes a tetrahedron needs to arrive
+    // in TWO 16-byte gathers (upload_icc16): unit 0 = {corner 0, corner 7} (every tetrahedron), unit 1 + k = {corner jmax, corner
+    // 7 - jmin} for the six (max axis, min axis) orders, corner j = 4*dr + 2*dg + db.  The library zeroes the stride of an axis whose
+    // input is 0xffff (cell index 32); its fraction is then 0, and the records of those cells hold zeros for the corners beyond the grid.
     const uint32_t cell = (c0i[0] * G + c0i[1]) * G + c0i[2];
     const uint32_t mx = max(max(r[0], r[1]), r[2]), mn = min(min(r[0], r[1]), r[2]);
     const uint32_t md = r[0] + r[1] + r[2] - mx - mn;
-    const uint32_t jmax = r[0] == mx ? 4u : (r[1] == mx ? 2u : 1u);  // first axis holding the maximum ...
-    const uint32_t jmin = r[2] == mn ? 1u : (r[1] == mn ? 2u : 4u);  // ... last axis holding the minimum: distinct axes even when all tie
+    const uint32_t amax = r[0] == mx ? 0u : (r[1] == mx ? 1u : 2u);  // first axis holding the maximum ...
+    const uint32_t amin = r[2] == mn ? 2u : (r[1] == mn ? 1u : 0u);  // ... last axis holding the minimum: distinct axes even when all tie
+    const uint32_t k = 2u * amax + amin - (amin > amax ? 1u : 0u);   // 0..5
     const uint32_t ra = mx, rb = md, rc = mn;
-    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-    const u2* rec = reinterpret_cast<const u2*>(clut + 32 * cell);
-    const u2 v0 = rec[0], v1 = rec[jmax], v2 = rec[7u - jmin], v3 = rec[7];
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4* rec = reinterpret_cast<const u4*>(clut + (kIcc16RecBytes / 2) * cell);
+    const u4 v07 = rec[0], v12 = rec[1u + k];
+    struct { uint32_t x, y; } v0{ v07.x, v07.y }, v3{ v07.z, v07.w }, v1{ v12.x, v12.y }, v2{ v12.z, v12.w };
     const uint32_t p0[3] = { v0.x & 0xffffu, v0.x >> 16, v0.y & 0xffffu }, p1[3] = { v1.x & 0xffffu, v1.x >> 16, v1.y & 0xffffu };
     const uint32_t p2[3] = { v2.x & 0xffffu, v2.x >> 16, v2.y & 0xffffu }, p3[3] = { v3.x & 0xffffu, v3.x >> 16, v3.y & 0xffffu };
 #pragma unroll
