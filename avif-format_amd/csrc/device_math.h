@@ -77,6 +77,37 @@ AG_DEV float fast_linear_to_pq_scaled(float value, float log2_mult_m1, float log
     const float d = 1.0f + kPqC3 * x;
     return nat_exp2(__builtin_fmaf(kPqM2, nat_log2(near_ieee_div(n, d)), log2_max));
 }
+// The same function on TWO samples: the twelve full-rate operations of a sample, minus the clamp and the truncation, become six
+// packed ones (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 do two IEEE single operations per lane per issue slot on gfx950: 2.98 vs
+// 2.74 cycles per wave instruction, tools/alubench.hip), element for element the operations above -- so the results are
+// the same bits.  The transcendentals stay one per sample.  AG_PQ_MAX0=0 also drops the max(value, 0): v_log_f32 of a negative
+// number is NaN, NaN flows through every later operation, and the caller's v_med3_f32(NaN, 0, max) returns 0 -- the code the
+// reference stores for a negative sample (the same route +NaN input has always taken).
+#ifndef AG_PQ_PACKED
+#define AG_PQ_PACKED 1
+#endif
+#ifndef AG_PQ_MAX0
+#define AG_PQ_MAX0 0
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+AG_DEV f32x2 fast_linear_to_pq_scaled2(f32x2 value, float log2_mult_m1, float log2_max)
+{
+#if AG_PQ_MAX0
+    const f32x2 l = { nat_log2(max0(value.x)), nat_log2(max0(value.y)) };
+#else
+    const f32x2 l = { nat_log2(value.x), nat_log2(value.y) };
+#endif
+    const f32x2 e1 = __builtin_elementwise_fma((f32x2)kPqM1, l, (f32x2)log2_mult_m1);
+    const f32x2 x = { nat_exp2(e1.x), nat_exp2(e1.y) };
+    const f32x2 n = kPqC1 + kPqC2 * x;                   // -ffp-contract=off: v_pk_mul_f32 + v_pk_add_f32
+    const f32x2 d = 1.0f + kPqC3 * x;
+    const f32x2 r = { nat_rcp(d.x), nat_rcp(d.y) };
+    const f32x2 q0 = n * r;
+    const f32x2 q = __builtin_elementwise_fma(__builtin_elementwise_fma(-q0, d, n), r, q0);   // near_ieee_div, two at a time
+    const f32x2 lq = { nat_log2(q.x), nat_log2(q.y) };
+    const f32x2 e2 = __builtin_elementwise_fma((f32x2)kPqM2, lq, (f32x2)log2_max);
+    return f32x2{ nat_exp2(e2.x), nat_exp2(e2.y) };
+}
 AG_DEV float fast_linear_to_pq(float value, float mult)
 {
     return fast_linear_to_pq_scaled(value, kPqM1 * nat_log2(mult), 0.0f);

@@ -53,6 +53,28 @@ AG_DEV uint32_t oetf_code(const WriteParams& p, float f)
     return (uint32_t)__builtin_amdgcn_fmed3f(scaled, 0.0f, p.maxf);
 }
 
+// two samples at once: the PQ curve in packed arithmetic (device_math.h), every other curve sample by sample
+template <int TRANSFER>
+AG_DEV void oetf_code2(const WriteParams& p, float f0, float f1, uint32_t& c0, uint32_t& c1)
+{
+    if constexpr (TRANSFER == AVIFGPU_TRANSFER_PQ && AG_PQ_PACKED) {
+        const f32x2 s = fast_linear_to_pq_scaled2(f32x2{ f0, f1 }, p.pq_log2_mult_m1, p.log2_maxf);
+        c0 = (uint32_t)__builtin_amdgcn_fmed3f(s.x, 0.0f, p.maxf);
+        c1 = (uint32_t)__builtin_amdgcn_fmed3f(s.y, 0.0f, p.maxf);
+    } else {
+        c0 = oetf_code<TRANSFER>(p, f0);
+        c1 = oetf_code<TRANSFER>(p, f1);
+    }
+}
+
+template <int TRANSFER, int N>
+AG_DEV void oetf_codes(const WriteParams& p, const float (&f)[N], uint32_t (&c)[N])
+{
+#pragma unroll
+    for (int i = 0; i + 1 < N; i += 2) oetf_code2<TRANSFER>(p, f[i], f[i + 1], c[i], c[i + 1]);
+    if constexpr (N & 1) c[N - 1] = oetf_code<TRANSFER>(p, f[N - 1]);
+}
+
 // ---- pow(x, g) for the ICC curves --------------------------------------------------------------------------------------
 // lcms2 evaluates its parametric curves with libm's pow in double and hands the result to the next stage as a FLOAT; the tier-2
 // bar is on the integer code behind that.  So what the kernel needs is pow to ~1 ulp of float -- not of double.  Built for the
@@ -908,8 +930,9 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_ycbcr444_hot(cons
 
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const uint32_t c0 = oetf_code<TRANSFER>(p, cur[k].x), c1 = oetf_code<TRANSFER>(p, cur[k].y);
-            const uint32_t c2 = oetf_code<TRANSFER>(p, cur[k].z), c3 = oetf_code<TRANSFER>(p, cur[k].w);
+            uint32_t c0, c1, c2, c3;
+            oetf_code2<TRANSFER>(p, cur[k].x, cur[k].y, c0, c1);
+            oetf_code2<TRANSFER>(p, cur[k].z, cur[k].w, c2, c3);
             u32x2 pk = { c0 | (c1 << 16), c2 | (c3 << 16) };
             reinterpret_cast<u32x2*>(my)[64 * k + lane] = pk;
         }
@@ -1026,17 +1049,29 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444_hot
         __builtin_amdgcn_wave_barrier();
         uint32_t yv[PXL], cbv[PXL], crv[PXL];
 #pragma unroll
-        for (int i = 0; i < PXL; ++i) {
-            const float R0 = c[3 * i], G0 = c[3 * i + 1], B0 = c[3 * i + 2];
-            float R1 = __builtin_fmaf(B0, m2, __builtin_fmaf(G0, m1, R0 * m0));
-            float G1 = __builtin_fmaf(B0, m5, __builtin_fmaf(G0, m4, R0 * m3));
-            float B1 = __builtin_fmaf(B0, m8, __builtin_fmaf(G0, m7, R0 * m6));
-            if constexpr (ICCV == 4) { R1 = icc_inv4_f(powT, p.icc_out_f, R1); G1 = icc_inv4_f(powT, p.icc_out_f, G1); B1 = icc_inv4_f(powT, p.icc_out_f, B1); }
-            const uint32_t q0 = oetf_code<TRANSFER>(p, R1), q1 = oetf_code<TRANSFER>(p, G1), q2 = oetf_code<TRANSFER>(p, B1);
-            yv[i] = luma_code(p, q0, q1, q2);
-            const float R = (float)q0, G = (float)q1, B = (float)q2;
-            cbv[i] = clip_round(R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2] + p.half, p.maxv);
-            crv[i] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
+        for (int i = 0; i < PXL; i += 2) {                                         // two pixels = three sample pairs for the packed curve
+            float t[6];
+            uint32_t q[6];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float R0 = c[3 * (i + h)], G0 = c[3 * (i + h) + 1], B0 = c[3 * (i + h) + 2];
+                t[3 * h] = __builtin_fmaf(B0, m2, __builtin_fmaf(G0, m1, R0 * m0));
+                t[3 * h + 1] = __builtin_fmaf(B0, m5, __builtin_fmaf(G0, m4, R0 * m3));
+                t[3 * h + 2] = __builtin_fmaf(B0, m8, __builtin_fmaf(G0, m7, R0 * m6));
+                if constexpr (ICCV == 4) {
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) t[3 * h + e] = icc_inv4_f(powT, p.icc_out_f, t[3 * h + e]);
+                }
+            }
+            oetf_codes<TRANSFER>(p, t, q);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t q0 = q[3 * h], q1 = q[3 * h + 1], q2 = q[3 * h + 2];
+                yv[i + h] = luma_code(p, q0, q1, q2);
+                const float R = (float)q0, G = (float)q1, B = (float)q2;
+                cbv[i + h] = clip_round(R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2] + p.half, p.maxv);
+                crv[i + h] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
+            }
         }
         const long long xoff = ((long long)sx * SPAN_PX + (long long)PXL * lane) * 2;
         uint8_t* d0 = p.dst[0] + (long long)r * p.dst_stride[0] + xoff;
@@ -1129,14 +1164,24 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot(con
                 __builtin_amdgcn_wave_barrier();
                 uint32_t q[PXL * 3];
 #pragma unroll
-                for (int i = 0; i < PXL; ++i) {
-                    const float R0 = c[3 * i], G0 = c[3 * i + 1], B0 = c[3 * i + 2];
-                    float R1 = __builtin_fmaf(B0, icm[2], __builtin_fmaf(G0, icm[1], R0 * icm[0]));
-                    float G1 = __builtin_fmaf(B0, icm[5], __builtin_fmaf(G0, icm[4], R0 * icm[3]));
-                    float B1 = __builtin_fmaf(B0, icm[8], __builtin_fmaf(G0, icm[7], R0 * icm[6]));
-                    if constexpr (ICCV == 4) { R1 = icc_inv4_f(powT, ico, R1); G1 = icc_inv4_f(powT, ico, G1); B1 = icc_inv4_f(powT, ico, B1); }
-                    q[3 * i] = oetf_code<TRANSFER>(p, R1); q[3 * i + 1] = oetf_code<TRANSFER>(p, G1); q[3 * i + 2] = oetf_code<TRANSFER>(p, B1);
-                    if constexpr (ICCV == 4) __builtin_amdgcn_sched_barrier(0);     // one pixel's three pows at a time (interleaving all 24 of a row: 224 VGPRs)
+                for (int i = 0; i < PXL; i += 2) {                                 // two pixels = three sample pairs for the packed curve
+                    float t[6];
+                    uint32_t qq[6];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float R0 = c[3 * (i + h)], G0 = c[3 * (i + h) + 1], B0 = c[3 * (i + h) + 2];
+                        t[3 * h] = __builtin_fmaf(B0, icm[2], __builtin_fmaf(G0, icm[1], R0 * icm[0]));
+                        t[3 * h + 1] = __builtin_fmaf(B0, icm[5], __builtin_fmaf(G0, icm[4], R0 * icm[3]));
+                        t[3 * h + 2] = __builtin_fmaf(B0, icm[8], __builtin_fmaf(G0, icm[7], R0 * icm[6]));
+                        if constexpr (ICCV == 4) {
+#pragma unroll
+                            for (int e = 0; e < 3; ++e) t[3 * h + e] = icc_inv4_f(powT, ico, t[3 * h + e]);
+                            __builtin_amdgcn_sched_barrier(0);                      // one pixel's three pows at a time (interleaving all 24 of a row: 224 VGPRs)
+                        }
+                    }
+                    oetf_codes<TRANSFER>(p, t, qq);
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) q[3 * i + e] = qq[e];
                 }
 #pragma unroll
                 for (int e = 0; e < LDW; ++e) dw[vr][e] = q[2 * e] | (q[2 * e + 1] << 16);
@@ -1144,8 +1189,9 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot(con
             }
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const uint32_t c0 = oetf_code<TRANSFER>(p, v[vr][k].x), c1 = oetf_code<TRANSFER>(p, v[vr][k].y);
-                const uint32_t c2 = oetf_code<TRANSFER>(p, v[vr][k].z), c3 = oetf_code<TRANSFER>(p, v[vr][k].w);
+                uint32_t c0, c1, c2, c3;
+                oetf_code2<TRANSFER>(p, v[vr][k].x, v[vr][k].y, c0, c1);
+                oetf_code2<TRANSFER>(p, v[vr][k].z, v[vr][k].w, c2, c3);
                 u32x2 pk = { c0 | (c1 << 16), c2 | (c3 << 16) };
                 reinterpret_cast<u32x2*>(my)[64 * k + lane] = pk;
             }
@@ -1242,30 +1288,41 @@ __global__ __launch_bounds__(AG_RGBA_STREAM_BLOCK) void write_rgba32_ycbcra444_h
 #pragma unroll
         for (int k = 0; k < PXL; ++k) v[k] = stream_load<true>(sp + min(64 * k + lane, span_px - 1));       // branch-free mask: see the RGB kernel
 #pragma unroll
-        for (int k = 0; k < PXL; ++k) {
-            float col[3] = { v[k].x, v[k].y, v[k].z };
-            if constexpr (ICCV != 0) {                                              // a pixel is one float4 here: no transpose needed in front
-                const float R0 = col[0], G0 = col[1], B0 = col[2];
-                col[0] = __builtin_fmaf(B0, p.icc_m_f[2], __builtin_fmaf(G0, p.icc_m_f[1], R0 * p.icc_m_f[0]));
-                col[1] = __builtin_fmaf(B0, p.icc_m_f[5], __builtin_fmaf(G0, p.icc_m_f[4], R0 * p.icc_m_f[3]));
-                col[2] = __builtin_fmaf(B0, p.icc_m_f[8], __builtin_fmaf(G0, p.icc_m_f[7], R0 * p.icc_m_f[6]));
-                if constexpr (ICCV == 4) {
-                    static_assert(AG_ICC_FASTPOW, "the RGBA kernel carries no pow table");
-                    const IccPowTableF noT = { nullptr };
+        for (int k = 0; k < PXL; k += 2) {                                         // two pixels = three colour-sample pairs for the packed curve
+            float t[6], al[2];
+            uint32_t q[6];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) col[c] = icc_inv4_f(noT, p.icc_out_f, col[c]);
+            for (int h = 0; h < 2; ++h) {
+                float col[3] = { v[k + h].x, v[k + h].y, v[k + h].z };
+                if constexpr (ICCV != 0) {                                          // a pixel is one float4 here: no transpose needed in front
+                    const float R0 = col[0], G0 = col[1], B0 = col[2];
+                    col[0] = __builtin_fmaf(B0, p.icc_m_f[2], __builtin_fmaf(G0, p.icc_m_f[1], R0 * p.icc_m_f[0]));
+                    col[1] = __builtin_fmaf(B0, p.icc_m_f[5], __builtin_fmaf(G0, p.icc_m_f[4], R0 * p.icc_m_f[3]));
+                    col[2] = __builtin_fmaf(B0, p.icc_m_f[8], __builtin_fmaf(G0, p.icc_m_f[7], R0 * p.icc_m_f[6]));
+                    if constexpr (ICCV == 4) {
+                        static_assert(AG_ICC_FASTPOW, "the RGBA kernel carries no pow table");
+                        const IccPowTableF noT = { nullptr };
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) col[c] = icc_inv4_f(noT, p.icc_out_f, col[c]);
+                    }
                 }
-            }
-            const float a = cxx_clamp(v[k].w, 0.0f, 1.0f);                          // WriteHeifImage.cpp:1047
-            if (p.premultiply && a < 1.0f) {                                        // :1049-1066
+                const float a = cxx_clamp(v[k + h].w, 0.0f, 1.0f);                  // WriteHeifImage.cpp:1047
+                if (p.premultiply && a < 1.0f) {                                    // :1049-1066
 #pragma unroll
-                for (int c = 0; c < 3; ++c) col[c] = (a == 0.0f) ? 0.0f : cxx_clamp(col[c], 0.0f, 1.0f) * a;
+                    for (int c = 0; c < 3; ++c) col[c] = (a == 0.0f) ? 0.0f : cxx_clamp(col[c], 0.0f, 1.0f) * a;
+                }
+                al[h] = a;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) t[3 * h + c] = col[c];
             }
-            const uint32_t c0 = oetf_code<TRANSFER>(p, col[0]), c1 = oetf_code<TRANSFER>(p, col[1]), c2 = oetf_code<TRANSFER>(p, col[2]);
-            const uint32_t c3 = (uint32_t)__builtin_amdgcn_fmed3f(a * p.maxf, 0.0f, p.maxf);   // :1096
-            const int pidx = 64 * k + lane;
-            u32x2 pk = { c0 | (c1 << 16), c2 | (c3 << 16) };
-            *reinterpret_cast<u32x2*>(my + (pidx / PXL) * LSTRIDE + (pidx % PXL) * 2) = pk;
+            oetf_codes<TRANSFER>(p, t, q);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t c3 = (uint32_t)__builtin_amdgcn_fmed3f(al[h] * p.maxf, 0.0f, p.maxf);   // :1096
+                const int pidx = 64 * (k + h) + lane;
+                u32x2 pk = { q[3 * h] | (q[3 * h + 1] << 16), q[3 * h + 2] | (c3 << 16) };
+                *reinterpret_cast<u32x2*>(my + (pidx / PXL) * LSTRIDE + (pidx % PXL) * 2) = pk;
+            }
         }
         __builtin_amdgcn_wave_barrier();
         uint32_t dw[2 * PXL];
@@ -1578,27 +1635,41 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_f32_ref_stream(const Wr
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             idx[k] = c * (64 * K) + 64 * k + lane;
+            v[k] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };                                // beyond the row: nothing loaded, nothing stored, arithmetic defined
             if (idx[k] < n4) v[k] = stream_load<true>(sp + idx[k]);
         }
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            if (idx[k] >= n4) continue;
-            float s0 = v[k].x, s1 = v[k].y, s2 = v[k].z, s3 = v[k].w;
-            uint32_t c0, c1, c2, c3;
-            if constexpr (PLANES == 4) {
-                const float a = cxx_clamp(s3, 0.0f, 1.0f);                          // WriteHeifImage.cpp:1047
-                if (p.premultiply && a < 1.0f) {                                    // :1049-1066
-                    s0 = (a == 0.0f) ? 0.0f : cxx_clamp(s0, 0.0f, 1.0f) * a;
-                    s1 = (a == 0.0f) ? 0.0f : cxx_clamp(s1, 0.0f, 1.0f) * a;
-                    s2 = (a == 0.0f) ? 0.0f : cxx_clamp(s2, 0.0f, 1.0f) * a;
+        for (int k = 0; k < K; k += 2) {                                           // two float4 at a time: sample pairs for the packed curve
+            float t[8];
+            uint32_t q[8], ca[2] = { 0, 0 };
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float s0 = v[k + h].x, s1 = v[k + h].y, s2 = v[k + h].z, s3 = v[k + h].w;
+                if constexpr (PLANES == 4) {
+                    const float a = cxx_clamp(s3, 0.0f, 1.0f);                      // WriteHeifImage.cpp:1047
+                    if (p.premultiply && a < 1.0f) {                                // :1049-1066
+                        s0 = (a == 0.0f) ? 0.0f : cxx_clamp(s0, 0.0f, 1.0f) * a;
+                        s1 = (a == 0.0f) ? 0.0f : cxx_clamp(s1, 0.0f, 1.0f) * a;
+                        s2 = (a == 0.0f) ? 0.0f : cxx_clamp(s2, 0.0f, 1.0f) * a;
+                    }
+                    ca[h] = (uint32_t)__builtin_amdgcn_fmed3f(a * p.maxf, 0.0f, p.maxf);   // :1096
                 }
-                c3 = (uint32_t)__builtin_amdgcn_fmed3f(a * p.maxf, 0.0f, p.maxf);   // :1096
-            } else {
-                c3 = oetf_code<TRANSFER>(p, s3);
+                t[4 * h] = s0; t[4 * h + 1] = s1; t[4 * h + 2] = s2; t[4 * h + 3] = s3;
             }
-            c0 = oetf_code<TRANSFER>(p, s0); c1 = oetf_code<TRANSFER>(p, s1); c2 = oetf_code<TRANSFER>(p, s2);
-            u32x2 o = { c0 | (c1 << 16), c2 | (c3 << 16) };
-            stream_store<true>(dp + idx[k], o);
+            if constexpr (PLANES == 4) {
+                const float tc[6] = { t[0], t[1], t[2], t[4], t[5], t[6] };
+                uint32_t qc[6];
+                oetf_codes<TRANSFER>(p, tc, qc);
+                q[0] = qc[0]; q[1] = qc[1]; q[2] = qc[2]; q[3] = ca[0]; q[4] = qc[3]; q[5] = qc[4]; q[6] = qc[5]; q[7] = ca[1];
+            } else {
+                oetf_codes<TRANSFER>(p, t, q);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (idx[k + h] >= n4) continue;
+                u32x2 o = { q[4 * h] | (q[4 * h + 1] << 16), q[4 * h + 2] | (q[4 * h + 3] << 16) };
+                stream_store<true>(dp + idx[k + h], o);
+            }
         }
     }
 }
