@@ -184,9 +184,21 @@ AG_DEV uint32_t trunc_u(float v) { return (uint32_t)__builtin_amdgcn_fmed3f(v, 0
 // rescale LUT entry, reference WriteHeifImage.cpp:97,124,151: (int)((i / srcMax) * dstMax + 0.5f), clamped.
 AG_DEV uint32_t exact_rescale(uint32_t i, float src_max, float dst_max, int dst_max_i)
 {
-    int v = (int)((((float)i / src_max) * dst_max) + 0.5f);
-    v = v < 0 ? 0 : (v > dst_max_i ? dst_max_i : v);
-    return (uint32_t)v;
+    const uint32_t v = (uint32_t)((((float)i / src_max) * dst_max) + 0.5f);      // i >= 0: the reference's "< 0" clamp never fires
+    return v > (uint32_t)dst_max_i ? (uint32_t)dst_max_i : v;
+}
+
+// The 16-bit table (src_max = 32768) for the TWO samples of a dword, packed result.  i / 32768 is an exact scaling, so
+// RN(RN(i / 32768) * dst_max) = RN(i * (dst_max / 32768)) -- the constant is exact too -- and one multiply does for two; both
+// samples take it and the "+ 0.5f" in packed single precision (v_pk_mul_f32, v_pk_add_f32: separately rounded, like the reference).
+// Inputs are clamped to 32768 first (the reference reads past its table beyond that), which makes the result <= dst_max: the
+// upper clamp never fires.  scale = dst_max / 32768.
+typedef float dm_f32x2 __attribute__((ext_vector_type(2)));
+AG_DEV uint32_t exact_rescale16_pair(uint32_t w, float scale)
+{
+    const uint32_t lo = min(w & 0xffffu, 32768u), hi = min(w >> 16, 32768u);
+    const dm_f32x2 t = dm_f32x2{ (float)lo, (float)hi } * scale + 0.5f;
+    return (uint32_t)t.x | ((uint32_t)t.y << 16);
 }
 
 // BuildSixteenBitToEightBitLookup entry (WriteHeifImage.cpp:114-139): (int)(i / 32768f * 255f + 0.5f) for i in [0, 32768] is, for

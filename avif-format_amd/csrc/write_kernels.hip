@@ -421,10 +421,10 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
         } else if constexpr (!COLOR) {
             col[0] = cxx_clamp(col[0], 0.0f, 1.0f);                             // gray, no alpha: :602
         }
+        uint32_t qc[NCOL];
+        oetf_codes<TRANSFER>(p, col, qc);
 #pragma unroll
-        for (int k = 0; k < NCOL; ++k) {
-            q[k] = oetf_code<TRANSFER>(p, col[k]);
-        }
+        for (int k = 0; k < NCOL; ++k) q[k] = qc[k];
         q[3] = ALPHA ? (uint32_t)__builtin_amdgcn_fmed3f(a * p.maxf, 0.0f, p.maxf) : (uint32_t)p.maxv;
         return;
     } else {
@@ -1410,8 +1410,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr444_hot(cons
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
                     const uint32_t w = h == 0 ? cur[n][k].x : h == 1 ? cur[n][k].y : h == 2 ? cur[n][k].z : cur[n][k].w;
-                    const uint32_t lo = min(w & 0xffffu, 32768u), hi = min(w >> 16, 32768u);   // the reference reads past its LUT beyond 32768 (stage_a)
-                    o[h] = exact_rescale(lo, 32768.0f, p.maxf, p.maxv) | (exact_rescale(hi, 32768.0f, p.maxf, p.maxv) << 16);
+                    o[h] = exact_rescale16_pair(w, p.maxf * (1.0f / 32768.0f));
                 }
                 reinterpret_cast<u32x4*>(my)[64 * k + lane] = u32x4{ o[0], o[1], o[2], o[3] };
             }
@@ -1484,8 +1483,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr_sub_hot(con
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
                     const uint32_t w = h == 0 ? v[vr][k].x : h == 1 ? v[vr][k].y : h == 2 ? v[vr][k].z : v[vr][k].w;
-                    const uint32_t lo = min(w & 0xffffu, 32768u), hi = min(w >> 16, 32768u);
-                    o[h] = exact_rescale(lo, 32768.0f, p.maxf, p.maxv) | (exact_rescale(hi, 32768.0f, p.maxf, p.maxv) << 16);
+                    o[h] = exact_rescale16_pair(w, p.maxf * (1.0f / 32768.0f));
                 }
                 reinterpret_cast<u32x4*>(my)[64 * k + lane] = u32x4{ o[0], o[1], o[2], o[3] };
             }
@@ -1568,10 +1566,9 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra444_hot(co
 #pragma unroll
             for (int h = 0; h < 2; ++h) {                                          // the vector's two pixels
                 const uint32_t w0 = h == 0 ? cur[k].x : cur[k].z, w1 = h == 0 ? cur[k].y : cur[k].w;
-                uint32_t c0 = exact_rescale(min(w0 & 0xffffu, 32768u), 32768.0f, p.maxf, p.maxv);
-                uint32_t c1 = exact_rescale(min(w0 >> 16, 32768u), 32768.0f, p.maxf, p.maxv);
-                uint32_t c2 = exact_rescale(min(w1 & 0xffffu, 32768u), 32768.0f, p.maxf, p.maxv);
-                const uint32_t a = exact_rescale(min(w1 >> 16, 32768u), 32768.0f, p.maxf, p.maxv);
+                const uint32_t q01 = exact_rescale16_pair(w0, p.maxf * (1.0f / 32768.0f)), q2a = exact_rescale16_pair(w1, p.maxf * (1.0f / 32768.0f));
+                uint32_t c0 = q01 & 0xffffu, c1 = q01 >> 16, c2 = q2a & 0xffffu;
+                const uint32_t a = q2a >> 16;
                 if (p.premultiply) {                                               // stage_a: after the rescale, in the plane's code domain
                     c0 = exact_premultiply_fast(c0, a, p.maxf, p.rcp_maxf);
                     c1 = exact_premultiply_fast(c1, a, p.maxf, p.rcp_maxf);
