@@ -184,8 +184,9 @@ AG_DEV uint32_t trunc_u(float v) { return (uint32_t)__builtin_amdgcn_fmed3f(v, 0
 // rescale LUT entry, reference WriteHeifImage.cpp:97,124,151: (int)((i / srcMax) * dstMax + 0.5f), clamped.
 AG_DEV uint32_t exact_rescale(uint32_t i, float src_max, float dst_max, int dst_max_i)
 {
-    const uint32_t v = (uint32_t)((((float)i / src_max) * dst_max) + 0.5f);      // i >= 0: the reference's "< 0" clamp never fires
-    return v > (uint32_t)dst_max_i ? (uint32_t)dst_max_i : v;
+    int v = (int)((((float)i / src_max) * dst_max) + 0.5f);
+    v = v < 0 ? 0 : (v > dst_max_i ? dst_max_i : v);
+    return (uint32_t)v;
 }
 
 // The 16-bit table (src_max = 32768) for the TWO samples of a dword, packed result.  i / 32768 is an exact scaling, so

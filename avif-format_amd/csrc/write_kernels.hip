@@ -421,10 +421,10 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
         } else if constexpr (!COLOR) {
             col[0] = cxx_clamp(col[0], 0.0f, 1.0f);                             // gray, no alpha: :602
         }
-        uint32_t qc[NCOL];
-        oetf_codes<TRANSFER>(p, col, qc);
 #pragma unroll
-        for (int k = 0; k < NCOL; ++k) q[k] = qc[k];
+        for (int k = 0; k < NCOL; ++k) {
+            q[k] = oetf_code<TRANSFER>(p, col[k]);       // sample by sample here: the packed pair form costs the generic kernel registers (-5 %, profiles/r02/packed_pq_ab.txt)
+        }
         q[3] = ALPHA ? (uint32_t)__builtin_amdgcn_fmed3f(a * p.maxf, 0.0f, p.maxf) : (uint32_t)p.maxv;
         return;
     } else {
