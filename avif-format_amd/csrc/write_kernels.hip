@@ -497,6 +497,9 @@ enum { kOutRefColor = 0, kOutRefGray = 1, kOutYcbcr = 2 };
 #ifndef AG_W8_NC
 #define AG_W8_NC 8
 #endif
+#ifndef AG_ICC8_FAST
+#define AG_ICC8_FAST 1
+#endif
 #ifndef AG_W8_PACKED
 #define AG_W8_PACKED 1
 #endif
@@ -598,7 +601,10 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
         // VGPRs on the 4:2:0 footprint (3 -> 8 waves/SIMD).  Chroma-major order: the floats of the 1/2/4 pixels under one chroma
         // sample live only while that sample is formed.  Same expressions, operand order and rounding as luma_code / the generic
         // chroma block below.  The one ragged lane of a row assembles its dwords from replicated bytes and stores byte by byte.
-        constexpr bool FAST8 = AG_W8_PACKED && DEPTH == 8 && (PLANES == 3 || PLANES == 4) && OUT == kOutYcbcr && !DST16 && ICC == 0 && ALIGNED;
+        // ICC == 3 (the 8-bit matrix-shaper transform, ConvertRow in front of the pixel loop) rides the same structure: the three colour
+        // bytes go through lcms2's integer evaluation -- two LDS tables and a 1.14 matrix, the expressions of stage_a -- on their way
+        // from the packed dword to the float, alpha untouched.
+        constexpr bool FAST8 = AG_W8_PACKED && DEPTH == 8 && (PLANES == 3 || PLANES == 4) && OUT == kOutYcbcr && !DST16 && (ICC == 0 || (ICC == 3 && AG_ICC8_FAST)) && ALIGNED;
         if constexpr (FAST8) {
             if (active) {
                 constexpr int NC = PXT >> XS;
@@ -650,7 +656,21 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
 #pragma unroll
                         for (int k = 0; k < (1 << XS); ++k) {
                             const int i = (j << XS) + k;
-                            c[vr][k][0] = code(vr, i, 0); c[vr][k][1] = code(vr, i, 1); c[vr][k][2] = code(vr, i, 2);
+                            if constexpr (ICC == 3) {
+                                // lcms2's 8-bit matrix-shaper evaluation (MatShaperEval16), bit for bit: see stage_a
+                                const int e0 = PLANES * i;
+                                const int r = icc8_s1[(raw[vr][e0 >> 2] >> (8 * (e0 & 3))) & 0xffu];
+                                const int g = icc8_s1[256 + ((raw[vr][(e0 + 1) >> 2] >> (8 * ((e0 + 1) & 3))) & 0xffu)];
+                                const int b = icc8_s1[512 + ((raw[vr][(e0 + 2) >> 2] >> (8 * ((e0 + 2) & 3))) & 0xffu)];
+#pragma unroll
+                                for (int ch = 0; ch < 3; ++ch) {
+                                    int l = (__mul24(p.icc8_m[3 * ch], r) + __mul24(p.icc8_m[3 * ch + 1], g) + __mul24(p.icc8_m[3 * ch + 2], b) + p.icc8_off[ch] + 0x2000) >> 14;
+                                    l = l < 0 ? 0 : (l > 16384 ? 16384 : l);
+                                    c[vr][k][ch] = (float)icc8_s2[l];
+                                }
+                            } else {
+                                c[vr][k][0] = code(vr, i, 0); c[vr][k][1] = code(vr, i, 1); c[vr][k][2] = code(vr, i, 2);
+                            }
                             if constexpr (PLANES == 4) {
                                 if (p.premultiply) {                         // stage_a: exact_premultiply_fast on the three colours (:691-708)
                                     const float a = code(vr, i, 3);

@@ -80,11 +80,18 @@ def test_prepare_rejects_non_profiles():
     assert pkg.load().avifgpu_icc_prepare_shaper8(bytes(300), 300, ctypes.byref(t)) == pkg.formatCannotRead
 
 
-def _gpu(gpu, d, src, sh):
+def _gpu(gpu, d, src, sh, pad=False):
     import torch
     dev = f"cuda:{gpu.device}"
     bufs = harness._alloc_write_out(d, d.height)
-    d_src = torch.from_numpy(src.reshape(-1)).to(dev)
+    if pad:                                        # rows padded to a 16-byte multiple (+16): aligned rows whatever the width
+        stride = (src.shape[1] + 15) // 16 * 16 + 16
+        wide = np.full((src.shape[0], stride), 0xA5, dtype=src.dtype)
+        wide[:, :src.shape[1]] = src
+        src = wide[:, :src.shape[1]]
+        d_src = torch.from_numpy(wide.reshape(-1)).to(dev)
+    else:
+        d_src = torch.from_numpy(src.reshape(-1)).to(dev)
     d_out = {pl: torch.from_numpy(b.view(np.uint8).reshape(-1).copy()).to(dev) for pl, b in bufs.items()}
     ptrs = [d_out[i].data_ptr() if i in d_out else None for i in range(4)]
     strides = [bufs[i].strides[0] if i in bufs else 0 for i in range(4)]
@@ -130,6 +137,32 @@ def test_gpu_icc8_then_every_output_kind(gpu, lcms):
         got = _gpu(gpu, d, src, sh)
         for pl in want:
             assert np.array_equal(got[pl], want[pl]), (kw, pl)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("width", [1024, 1000, 336, 20])
+@pytest.mark.parametrize("chroma", ["444", "422", "420"])
+@pytest.mark.parametrize("planes,alpha_state", [(3, "NONE"), (4, "STRAIGHT"), (4, "PREMULTIPLIED")])
+def test_gpu_icc8_packed_u8_plane_path(gpu, lcms, width, chroma, planes, alpha_state):
+    """The default kind of save (8-bit document -> u8 Y, Cb, Cr(, A) planes) with the ICC stage in front runs on the packed
+    16-pixel footprint kernel (aligned rows): every chroma format, both down-sampling modes, alpha copied / premultiplied
+    after the transform, widths with and without a ragged last footprint, odd heights -- bit-exact against lcms2 + the oracle."""
+    icc = _profile(lcms, 3, 0, 2.19921875)
+    sh = gpu.icc_prepare_shaper8(icc)
+    for ds in (pkg.DOWNSAMPLE_AVERAGE, pkg.DOWNSAMPLE_NEAREST):
+        d = pkg.WriteDesc(width=width, height=37, depth=8, planes=planes, bit_depth=8, alpha_state=getattr(pkg, "ALPHA_" + alpha_state),
+                          output=pkg.OUT_YCBCR, chroma=getattr(pkg, "CHROMA_" + chroma), chroma_downsampling=ds,
+                          matrix_coefficients=pkg.MATRIX_BT601)
+        src = harness.make_write_source(d, seed=width + planes)
+        conv = src.copy()
+        assert lcms.oracle_icc_convert_rows_to_srgb8(icc, len(icc), int(planes == 4), conv.ctypes.data, d.width, d.height,
+                                                     conv.strides[0]) == 0
+        want = harness.oracle_write(d, conv)
+        got = _gpu(gpu, d, src, sh, pad=True)
+        name = gpu.last_kernel()
+        assert "icc=3" in name and "aligned=1" in name, name
+        for pl in want:
+            assert np.array_equal(got[pl], want[pl]), (ds, pl, name)
 
 
 @pytest.mark.gpu
