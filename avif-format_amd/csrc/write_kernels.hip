@@ -497,6 +497,9 @@ enum { kOutRefColor = 0, kOutRefGray = 1, kOutYcbcr = 2 };
 #ifndef AG_W8_NC
 #define AG_W8_NC 8
 #endif
+#ifndef AG_W16TO8_FAST
+#define AG_W16TO8_FAST 1
+#endif
 #ifndef AG_ICC8_FAST
 #define AG_ICC8_FAST 1
 #endif
@@ -601,32 +604,52 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
         // VGPRs on the 4:2:0 footprint (3 -> 8 waves/SIMD).  Chroma-major order: the floats of the 1/2/4 pixels under one chroma
         // sample live only while that sample is formed.  Same expressions, operand order and rounding as luma_code / the generic
         // chroma block below.  The one ragged lane of a row assembles its dwords from replicated bytes and stores byte by byte.
+        // 16-bit RGBA documents saved at 8 bit take it too (samples rescaled and packed as the row arrives: 0.62 -> 0.67; for RGB16 the generic
+        // path measures 3 % faster and keeps it, profiles/r02/w16to8_packed_ab.txt).
         // ICC == 3 (the 8-bit matrix-shaper transform, ConvertRow in front of the pixel loop) rides the same structure: the three colour
         // bytes go through lcms2's integer evaluation -- two LDS tables and a 1.14 matrix, the expressions of stage_a -- on their way
         // from the packed dword to the float, alpha untouched.
-        constexpr bool FAST8 = AG_W8_PACKED && DEPTH == 8 && (PLANES == 3 || PLANES == 4) && OUT == kOutYcbcr && !DST16 && (ICC == 0 || (ICC == 3 && AG_ICC8_FAST)) && ALIGNED;
+        constexpr bool FAST8 = AG_W8_PACKED && (DEPTH == 8 || (DEPTH == 16 && PLANES == 4 && AG_W16TO8_FAST && ICC == 0)) && (PLANES == 3 || PLANES == 4) && OUT == kOutYcbcr && !DST16 &&
+                               (ICC == 0 || (ICC == 3 && AG_ICC8_FAST)) && ALIGNED;
         if constexpr (FAST8) {
             if (active) {
                 constexpr int NC = PXT >> XS;
-                uint32_t raw[VR][ND];
+                constexpr int NDB = PXT * PLANES / 4;                       // dwords of a footprint row as 8-bit codes
+                uint32_t raw[VR][NDB];
 #pragma unroll
                 for (int vr = 0; vr < VR; ++vr) {
                     const int r = min(r0 + vr, p.rows_to_end - 1);          // bottom edge: replicate the last IMAGE row
                     const uint8_t* rowp = p.src + (long long)r * p.src_row_bytes;
-                    if (full) load_dwords<ND, false, true>(rowp + (long long)x0 * PLANES, raw[vr]);
-                    else {
+                    if (full) {
+                        if constexpr (DEPTH == 8) load_dwords<NDB, false, true>(rowp + (long long)x0 * PLANES, raw[vr]);
+                        else {
+                            // 16-bit document saved at 8 bit: BuildSixteenBitToEightBitLookup's entry (rescale16_to_8, exact integer form) per
+                            // sample as the row arrives, packed to the byte layout an 8-bit document has -- from here on the two are the same
+                            uint32_t w[2 * NDB];
+                            load_dwords<2 * NDB, false, true>(rowp + (long long)x0 * PLANES * 2, w);
+#pragma unroll
+                            for (int d = 0; d < NDB; ++d) {
+                                const uint32_t b0 = rescale16_to_8(min(w[2 * d] & 0xffffu, 32768u)), b1 = rescale16_to_8(min(w[2 * d] >> 16, 32768u));
+                                const uint32_t b2 = rescale16_to_8(min(w[2 * d + 1] & 0xffffu, 32768u)), b3 = rescale16_to_8(min(w[2 * d + 1] >> 16, 32768u));
+                                raw[vr][d] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+                            }
+                        }
+                    } else {
                         // the one ragged lane of a row (x0 < width < x0 + PXT; its wave's other lanes are full or idle, so the
                         // wave's strip is this lane's alone): a rolled byte loop replicates the last pixel into LDS -- unrolled,
                         // its 48 loads per row would all be hoisted and set the VGPR count of the whole kernel
                         uint8_t* sb = reinterpret_cast<uint8_t*>(strip);
 #pragma clang loop unroll(disable)
                         for (int i = 0; i < PXT; ++i) {
-                            const uint8_t* pp = rowp + (long long)min(x0 + i, p.width - 1) * PLANES;
+                            const uint8_t* pp = rowp + (long long)min(x0 + i, p.width - 1) * BPP;
 #pragma unroll
-                            for (int k = 0; k < PLANES; ++k) sb[PLANES * i + k] = pp[k];
+                            for (int k = 0; k < PLANES; ++k) {
+                                if constexpr (DEPTH == 8) sb[PLANES * i + k] = pp[k];
+                                else sb[PLANES * i + k] = (uint8_t)rescale16_to_8(min(ld_u16(pp + 2 * k), 32768u));
+                            }
                         }
 #pragma unroll
-                        for (int d = 0; d < ND; ++d) raw[vr][d] = strip[d];
+                        for (int d = 0; d < NDB; ++d) raw[vr][d] = strip[d];
                     }
                 }
                 uint32_t ypk[VR][PXT / 4], cbpk[NC / 4], crpk[NC / 4];
@@ -649,7 +672,7 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
 #pragma unroll
                     for (int vr = 0; vr < VR; ++vr)
 #pragma unroll
-                        for (int d = 0; d < ND; ++d) asm volatile("" : "+v"(raw[vr][d]));
+                        for (int d = 0; d < NDB; ++d) asm volatile("" : "+v"(raw[vr][d]));
                     float c[VR][1 << XS][3];
 #pragma unroll
                     for (int vr = 0; vr < VR; ++vr)
