@@ -60,6 +60,29 @@ def test_write_u8_fast_path_padded_rows(gpu, planes, alpha, chroma, width):
             assert np.all(raw[pl][:, w:] == 0xA5), (pl, width)
 
 
+@pytest.mark.parametrize("planes,alpha", [(4, pkg.ALPHA_STRAIGHT), (4, pkg.ALPHA_PREMULTIPLIED), (3, pkg.ALPHA_NONE)])
+@pytest.mark.parametrize("chroma", CHROMAS)
+@pytest.mark.parametrize("width", [1040, 1001, 24, 17, 2050])
+def test_write_16bit_document_to_u8_planes_padded_rows(gpu, planes, alpha, chroma, width):
+    """A 16-bit document saved at 8 bit: RGBA16 takes the packed footprint too (samples rescaled with the reference's 16 -> 8 table
+    expression and packed as the row arrives), RGB16 the generic kernel -- same cases either way, incl. samples beyond 32768."""
+    for height, near in ((7, False), (4, True)):
+        kw = dict(width=width, height=height, depth=16, planes=planes, bit_depth=8, alpha_state=alpha, output=pkg.OUT_YCBCR,
+                  chroma=chroma, matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)
+        if near:
+            kw["chroma_downsampling"] = pkg.DOWNSAMPLE_NEAREST
+        d = pkg.WriteDesc(**kw)
+        src = harness.make_write_source(d, seed=width + height + planes)
+        src.reshape(-1)[5::97] = 40000                     # beyond Photoshop's range: clamped like the reference's table index
+        want = harness.oracle_write(d, src)
+        got, raw = gpu_write_padded(gpu, d, src)
+        assert "aligned=1" in gpu.last_kernel() and "depth=16" in gpu.last_kernel(), gpu.last_kernel()
+        for pl in want:
+            assert np.array_equal(want[pl], got[pl]), (pl, width, height, near, int(np.abs(want[pl].astype(int) - got[pl].astype(int)).max()))
+        for pl, (w, xs, ys) in harness.write_planes(d).items():
+            assert np.all(raw[pl][:, w:] == 0xA5), (pl, width)
+
+
 @pytest.mark.parametrize("alpha", [pkg.ALPHA_NONE, pkg.ALPHA_STRAIGHT, pkg.ALPHA_PREMULTIPLIED])
 @pytest.mark.parametrize("chroma", CHROMAS)
 @pytest.mark.parametrize("width", [1040, 1001, 24, 2050])
