@@ -331,6 +331,9 @@ AG_DEV void icc_apply(const WriteParams& p, const IccRegs& q, const IccPowTable&
     }
 }
 
+#ifndef AG_ICC16_LEAN
+#define AG_ICC16_LEAN 1
+#endif
 // ---- 16-bit ICC stage: lcms2's resampled pipeline (include/avifgpu.h, "16-bit SDR save path") --------------------------------
 // BuildHostToLcmsLookup / BuildLcmsToHostLookup entries (ColorProfileConversion.cpp:37-95), evaluated instead of tabulated.
 // The reference's float expressions -- (int)(i / 32768f * 65535f + .5f) and (int)(i / 65535f * 32768f + .5f) with IEEE single
@@ -460,9 +463,16 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
             if constexpr (DEPTH == 8) {
                 v[k] = (RESCALE8 == 1 || (RESCALE8 == 2 && p.maxv > 255)) ? (uint32_t)lut8[sx[k]] : sx[k];   // the reference's 256-entry LUT, :87-112
             } else {
+                if constexpr (ICC == 5 && !TO8 && AG_ICC16_LEAN) {
+                    // behind the ICC stage every sample is icc16_lcms_to_host(..) <= 32768: no input clamp, and then neither end of the
+                    // table expression's clamp can fire; i / 32768 * max with ONE multiply by the exact constant max / 32768
+                    // (exact_rescale16_pair, device_math.h).  This kernel is instruction-bound: 9 -> 4 per sample.
+                    v[k] = (uint32_t)((float)sx[k] * (p.maxf * (1.0f / 32768.0f)) + 0.5f);
+                } else {
                 const uint32_t i = sx[k] > 32768u ? 32768u : sx[k];  // reference reads past its LUT here
                 if constexpr (TO8) v[k] = rescale16_to_8(i);                                         // :114-139, exact integer form
                 else v[k] = exact_rescale(i, 32768.0f, p.maxf, p.maxv);                              // :141-166
+                }
             }
         }
         const uint32_t a = ALPHA ? v[PLANES - 1] : (uint32_t)p.maxv;
