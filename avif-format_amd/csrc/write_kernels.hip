@@ -469,9 +469,9 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
                     // (exact_rescale16_pair, device_math.h).  This kernel is instruction-bound: 9 -> 4 per sample.
                     v[k] = (uint32_t)((float)sx[k] * (p.maxf * (1.0f / 32768.0f)) + 0.5f);
                 } else {
-                const uint32_t i = sx[k] > 32768u ? 32768u : sx[k];  // reference reads past its LUT here
-                if constexpr (TO8) v[k] = rescale16_to_8(i);                                         // :114-139, exact integer form
-                else v[k] = exact_rescale(i, 32768.0f, p.maxf, p.maxv);                              // :141-166
+                    const uint32_t i = sx[k] > 32768u ? 32768u : sx[k];  // reference reads past its LUT here
+                    if constexpr (TO8) v[k] = rescale16_to_8(i);                                     // :114-139, exact integer form
+                    else v[k] = exact_rescale(i, 32768.0f, p.maxf, p.maxv);                          // :141-166
                 }
             }
         }
