@@ -1,5 +1,6 @@
-# repeat the GPU suite to catch intermittent crashes; prints the python stack of a crash (faulthandler)
-for i in 1 2 3 4 5 6 7 8 9 10 11 12; do
+# repeat the GPU suite N times (default 12) to catch intermittent crashes; prints the python stack of a crash (faulthandler)
+#   bash tools/gpu/stress.sh [N]
+for i in $(seq 1 ${1:-12}); do
   timeout 600 python -X faulthandler -m pytest tests -m gpu -q -x -p no:cacheprovider $STRESS_ARGS > gpurun_out/stress_$i.log 2>&1
   rc=$?
   echo "run $i rc=$rc $(tail -1 gpurun_out/stress_$i.log | cut -c1-80)"
