@@ -40,7 +40,7 @@ struct Args {
     int width = 0, height = 0, depth = 8, planes = 3, bits = 8, transfer = AVIFGPU_TRANSFER_CLIP, peak = 1000;
     int alpha = AVIFGPU_ALPHA_NONE, output = AVIFGPU_OUT_REFERENCE, chroma = AVIFGPU_CHROMA_444;
     int matrix = AVIFGPU_MATRIX_BT601, primaries = AVIFGPU_PRIMARIES_BT709, tc = 2, limited = 0, colorspace = AVIFGPU_COLORSPACE_YCBCR;
-    int lossless = 0, maxdata = 0, device = 0, hlg_ootf = 0, nclx = 0;
+    int lossless = 0, maxdata = 0, device = 0, hlg_ootf = 0, nclx = 0, keep_profile = 0;
     float gamma = 1.2f;
 };
 
@@ -50,7 +50,7 @@ struct Args {
     fprintf(stderr,
         "usage: avifgpu_cli write --width W --height H --depth 8|16|32 --planes 1..4 --bits 8|10|12 [--transfer clip|pq|smpte428]\n"
         "                         [--peak NITS] [--alpha none|straight|premultiplied] [--ycbcr 444|422|420] [--matrix N] [--primaries N]\n"
-        "                         [--lossless] [--icc PROFILE] [--maxdata BYTES] [--device N] IN.raw OUT.planes\n"
+        "                         [--lossless] [--icc PROFILE [--keep-profile]] [--maxdata BYTES] [--device N] IN.raw OUT.planes\n"
         "       avifgpu_cli read  --width W --height H --depth 8|16|32 --bits 8|10|12 --colorspace ycbcr|rgb|mono [--chroma 444|422|420]\n"
         "                         [--alpha none|straight|premultiplied] [--matrix N --primaries N --tc N [--limited]] [--peak NITS]\n"
         "                         [--hlg-ootf --gamma G] [--maxdata BYTES] [--device N] IN.planes OUT.raw\n");
@@ -88,6 +88,7 @@ Args parse(int argc, char** argv)
         else if (o == "--gamma") a.gamma = (float)atof(val());
         else if (o == "--hlg-ootf") a.hlg_ootf = 1;
         else if (o == "--lossless") a.lossless = 1;
+        else if (o == "--keep-profile") a.keep_profile = 1;
         else if (o == "--icc") a.icc = val();
         else if (o == "--transfer") a.transfer = pick(val(), {{"clip", AVIFGPU_TRANSFER_CLIP}, {"pq", AVIFGPU_TRANSFER_PQ}, {"smpte428", AVIFGPU_TRANSFER_SMPTE428}}, "--transfer");
         else if (o == "--alpha") a.alpha = pick(val(), {{"none", AVIFGPU_ALPHA_NONE}, {"straight", AVIFGPU_ALPHA_STRAIGHT}, {"premultiplied", AVIFGPU_ALPHA_PREMULTIPLIED}}, "--alpha");
@@ -160,16 +161,16 @@ int do_write(const Args& a)
     avifgpu_SaveUIOptions o{};
     o.imageBitDepth = a.bits; o.hdrTransferFunction = a.transfer; o.pq.nominalPeakBrightness = a.peak;
     o.chromaSubsampling = a.chroma; o.lossless = (uint8_t)a.lossless;
+    o.keepColorProfile = (uint8_t)a.keep_profile;
+    o.iccDecision = AVIFGPU_ICC_LIKE_PLUGIN;
     if (!a.icc.empty()) {
-        // the plug-in's own gate (ColorProfileConversion.cpp:107-131,:143-156): HDR saves convert to Rec.2020 unless the
-        // document already is Rec.2020; everything else converts to sRGB unless it already is sRGB (32-bit Clip: always)
-        const int32_t is = avifgpu_icc_detect(profile.data(), (uint32_t)profile.size());
-        if (is < 0) return fail("avifgpu_icc_detect", is);
-        const bool hdr = a.depth == 32 && a.transfer != AVIFGPU_TRANSFER_CLIP;
-        o.convertToRec2020 = hdr && !(is & AVIFGPU_ICC_IS_REC2020);
-        o.convertToSRGB = !hdr && (a.depth == 32 || !(is & AVIFGPU_ICC_IS_SRGB));
-        fprintf(stderr, "icc: document profile is%s Rec.2020,%s sRGB -> %s\n", (is & AVIFGPU_ICC_IS_REC2020) ? "" : " not",
-                (is & AVIFGPU_ICC_IS_SRGB) ? "" : " not", o.convertToRec2020 ? "convert to Rec.2020" : o.convertToSRGB ? "convert to sRGB" : "no conversion");
+        // the plug-in's own gate (ColorProfileConversion.cpp:98-157), taken inside the library: HDR saves convert to Rec.2020
+        // unless the document already is Rec.2020; 8/16-bit saves convert to sRGB unless it already is sRGB or the profile is
+        // kept; 32-bit Clip saves convert to sRGB unless the profile is kept.  Printed here, decided there.
+        const int32_t conversion = avifgpu_host_required_conversion_for_record(&g_host.fr, &o);
+        if (conversion < 0) return fail("avifgpu_host_required_conversion_for_record", conversion);
+        fprintf(stderr, "icc: %s\n", conversion == AVIFGPU_CONVERT_TO_REC2020 ? "convert to Rec.2020"
+                                    : conversion == AVIFGPU_CONVERT_TO_SRGB ? "convert to sRGB" : "no conversion");
     }
     avifgpu_image img{};
     const int rc = avifgpu_host_create_heif_image(&g_host.fr, a.alpha, &o, a.output, a.lossless ? AVIFGPU_MATRIX_RGB_GBR : a.matrix,

@@ -114,10 +114,19 @@ struct WritePlan { avifgpu_write_desc desc; int output; };
 // Shared body of the six CreateHeifImage* functions: FormatRecord set-up as DoWriteStart (Write.cpp:279-295), then
 // the tile loop that replaces WriteHeifImage.cpp:1017-1135 (and its five siblings).
 void CreateHeifImageInto(FormatRecordPtr formatRecord, AlphaState alphaState, const VPoint& imageSize,
-                         const SaveUIOptions& saveOptions, int output, int matrix, int primaries, avifgpu_image* img)
+                         const SaveUIOptions& callerOptions, int output, int matrix, int primaries, avifgpu_image* img)
 {
     const bool hasAlpha = alphaState != AlphaState::None;
     const bool mono = IsMonochromeImage(formatRecord);
+    SaveUIOptions saveOptions = callerOptions;
+    if (saveOptions.iccDecision == AVIFGPU_ICC_LIKE_PLUGIN) {
+        // what ColorProfileConversion's constructors decide (ColorProfileConversion.cpp:98-157): host_decisions.cpp
+        const int32_t conversion = avifgpu_host_required_conversion_for_record(formatRecord, &saveOptions);
+        if (conversion == AVIFGPU_writErr) throw std::runtime_error(avifgpu::last_error());   // "Unable to load the document color profile."
+        if (conversion < 0) throw OSErrException((OSErr)conversion);
+        saveOptions.convertToRec2020 = conversion == AVIFGPU_CONVERT_TO_REC2020;
+        saveOptions.convertToSRGB = conversion == AVIFGPU_CONVERT_TO_SRGB;
+    }
     if (hasAlpha != HasAlphaChannel(formatRecord)) throw OSErrException(AVIFGPU_formatBadParameters);
     // The plug-in cannot save HLG: every 32-bit branch throws for it (WriteHeifImage.cpp:581-582,:1088-1089,:1123-1124).  The
     // C-ABI below offers LinearToHLG (ColorTransfer.cpp:141-164, defined but unreachable in the reference) as an extension;

@@ -47,7 +47,19 @@ class HLGOptions(ctypes.Structure):
 class SaveUIOptions(ctypes.Structure):
     _fields_ = [("imageBitDepth", c_int32), ("hdrTransferFunction", c_int32), ("pq", PQOptions),
                 ("chromaSubsampling", c_int32), ("lossless", c_uint8), ("convertToRec2020", c_uint8),
-                ("convertToSRGB", c_uint8), ("chromaDownsampling", c_uint8)]
+                ("convertToSRGB", c_uint8), ("chromaDownsampling", c_uint8), ("keepColorProfile", c_uint8),
+                ("premultipliedAlpha", c_uint8), ("iccDecision", c_uint8), ("reserved", c_uint8)]
+
+
+ICC_EXPLICIT, ICC_LIKE_PLUGIN = 0, 1
+CONVERT_NONE, CONVERT_TO_REC2020, CONVERT_TO_SRGB = 0, 1, 2
+THROW_NOTHING, THROW_BAD_ALLOC, THROW_RUNTIME_ERROR, THROW_OSERR = 0, 1, 2, 3
+DIRECTION_SAVE, DIRECTION_OPEN = 0, 1
+
+
+class ReadPlan(ctypes.Structure):
+    _fields_ = [("colorspace", c_int32), ("chroma", c_int32), ("plane_count", c_int32), ("channels", c_int32 * 4),
+                ("required_bits", c_int32), ("assume_luma_bits", c_int32)]
 
 
 class LoadUIOptions(ctypes.Structure):
@@ -73,4 +85,15 @@ HOST_ABI = [
                                                  c_int32, POINTER(Image)]),
     ("avifgpu_host_read_heif_image", c_int16, [POINTER(Image), c_int32, POINTER(Nclx), POINTER(LoadUIOptions),
                                                POINTER(FormatRecord)]),
+    # decisions of the reference-named adapters (csrc/host_decisions.cpp)
+    ("avifgpu_host_image_bit_depth", c_int32, [c_int32]),
+    ("avifgpu_host_chroma_subsampling", c_int32, [c_int32, c_int32]),
+    ("avifgpu_host_interleaved_chroma", c_int32, [c_int32, c_int32]),
+    ("avifgpu_host_normalize_save_options", c_int16, [POINTER(FormatRecord), POINTER(SaveUIOptions)]),
+    ("avifgpu_host_alpha_state", c_int32, [POINTER(FormatRecord), POINTER(SaveUIOptions)]),
+    ("avifgpu_host_required_conversion", c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
+    ("avifgpu_host_required_conversion_for_record", c_int32, [POINTER(FormatRecord), POINTER(SaveUIOptions)]),
+    ("avifgpu_host_exception_class", c_int32, [c_int32, c_int32]),
+    ("avifgpu_host_plan_read", c_int16, [c_int32, c_int32, c_int32, c_int32, POINTER(ReadPlan)]),
+    ("avifgpu_host_check_read_depths", c_int16, [POINTER(ReadPlan), POINTER(c_int32 * 4), c_int32, POINTER(c_int32)]),
 ]

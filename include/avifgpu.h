@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AVIFGPU_ABI_VERSION 2
+#define AVIFGPU_ABI_VERSION 3
 
 /* ---- OSErr codes used by the hot path (Photoshop SDK values) ------------------------------- */
 #define AVIFGPU_noErr                0
@@ -284,8 +284,9 @@ typedef struct avifgpu_icc_transform {
 } avifgpu_icc_transform;
 
 /* REC2020_LINEAR: HDR saves (transfer PQ / SMPTE 428), ColorProfileConversion.cpp:235-266.
- * SRGB_FLOAT: 32-bit documents saved as SDR (transfer Clip) are ALWAYS converted to sRGB, "because the 32-bit mode uses
- * linear gamma" (ColorProfileConversion.cpp:118-123, :268-331 with TYPE_RGB[A]_FLT): lcms2's float pipeline is then
+ * SRGB_FLOAT: 32-bit documents saved as SDR (transfer Clip) are converted to sRGB whenever keepColorProfile is off -- even
+ * from an sRGB profile, "because the 32-bit mode uses linear gamma" (ColorProfileConversion.cpp:105,:118-123, :268-331 with
+ * TYPE_RGB[A]_FLT; with keepColorProfile on, NO transform is installed): lcms2's float pipeline is then
  * [TRC] -> [3x3 in double] -> [inverse sRGB parametric curve in double] -> float. */
 enum { AVIFGPU_ICC_TARGET_REC2020_LINEAR = 0, AVIFGPU_ICC_TARGET_SRGB_FLOAT = 2 };
 

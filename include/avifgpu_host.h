@@ -86,14 +86,25 @@ typedef struct avifgpu_SaveUIOptions {
     /* 1 = convert the RGB document from formatRecord->iCCprofileData to sRGB on the GPU.  depth 8: the case in which the
      * 8-bit constructor installs a transform (ColorProfileConversion.cpp:134-157: profile present, keepColorProfile off,
      * !IsSRGBColorProfile) -- lcms2's 8-bit matrix-shaper pipeline, bit-exact.  depth 32 with transfer Clip: the SDR save
-     * of a 32-bit document, always converted (:118-123) -- lcms2's float pipeline.  formatCannotRead for profiles that are
+     * of a 32-bit document, converted whenever keepColorProfile is off, even from sRGB (:105,:118-123; with keepColorProfile
+     * the reference installs NO transform and embeds the profile) -- lcms2's float pipeline.  formatCannotRead for profiles that are
      * not matrix/TRC.  depth 16: lcms2's resampled 33^3 table + tetrahedral interpolation, bit-exact. */
     uint8_t convertToSRGB;
     /* Chroma down-sampling of the fused 4:2:0 / 4:2:2 output: 0 = what libheif 1.14.0's own conversion does for the plug-in's
      * interleaved hand-off (the co-sited top-left sample) -- the drop-in default; 1 = box average of the
      * 2x1 / 2x2 footprint (AVIFGPU_DOWNSAMPLE_AVERAGE), which later libheif versions made their default. */
     uint8_t chromaDownsampling;
+    /* ---- ABI 3 ---- */
+    uint8_t keepColorProfile;                 /* SaveUIOptions::keepColorProfile (AvifFormat.h:97) */
+    uint8_t premultipliedAlpha;               /* SaveUIOptions::premultipliedAlpha (AvifFormat.h:100); read by
+                                                 avifgpu_host_alpha_state / avifgpu_host_normalize_save_options only */
+    /* AVIFGPU_ICC_EXPLICIT (0): convertToRec2020 / convertToSRGB are taken as given.  AVIFGPU_ICC_LIKE_PLUGIN (1): they are
+     * ignored and avifgpu_host_create_heif_image decides like ColorProfileConversion's constructors do
+     * (avifgpu_host_required_conversion_for_record below) from formatRecord->iCCprofileData and keepColorProfile. */
+    uint8_t iccDecision;
+    uint8_t reserved;
 } avifgpu_SaveUIOptions;
+enum { AVIFGPU_ICC_EXPLICIT = 0, AVIFGPU_ICC_LIKE_PLUGIN = 1 };
 typedef struct avifgpu_LoadUIOptions {
     avifgpu_HLGOptions hlg;
     avifgpu_PQOptions  pq;
@@ -153,6 +164,87 @@ avifgpu_OSErr avifgpu_host_create_heif_image(avifgpu_FormatRecord* formatRecord,
 avifgpu_OSErr avifgpu_host_read_heif_image(const avifgpu_image* image, int32_t alphaState,
                                            const avifgpu_nclx* nclxProfile, const avifgpu_LoadUIOptions* loadOptions,
                                            avifgpu_FormatRecord* formatRecord);
+
+/* ==== Decisions of the reference-named adapters, as C-ABI helpers =====================================================
+ * Everything integration/WriteHeifImage_gpu.cpp / ReadHeifImage_gpu.cpp (the twelve reference-named functions, compiled only
+ * against the real Photoshop SDK + libheif headers) has to DECIDE lives here, where it is compiled and tested without those
+ * headers (tests/test_host_decisions.py enumerates every input against a restatement of the reference lines cited); the
+ * adapter files themselves only copy fields and call.  Enum arguments are the reference's own enumerator ORDINALS. */
+
+/* GetHeifImageBitDepth (WriteHeifImage.cpp:41-61): ImageBitDepth::{Eight, Ten, Twelve} (AvifFormat.h:42-47, ordinals 0,1,2)
+ * -> 8 | 10 | 12; AVIFGPU_formatCannotRead for anything else. */
+int32_t avifgpu_host_image_bit_depth(int32_t imageBitDepth);
+
+/* The "chroma" encoder parameter (EncodeAndSaveImage, Write.cpp:96-123): ChromaSubsampling::{Yuv420, Yuv422, Yuv444}
+ * (AvifFormat.h:28-33, ordinals 0,1,2) -> AVIFGPU_CHROMA_420|422|444; lossless forces 4:4:4 (:98-102) before the value is
+ * looked at; AVIFGPU_formatBadParameters for anything else (:121-122). */
+int32_t avifgpu_host_chroma_subsampling(int32_t chromaSubsampling, int32_t lossless);
+
+/* GetRGBImageChroma (WriteHeifImage.cpp:63-85): the heif_chroma of the interleaved hand-off as libheif's enumerator value
+ * (10 interleaved_RGB, 11 RGBA, 14 RRGGBB_LE, 15 RRGGBBAA_LE); bit_depth is 8 | 10 | 12, else AVIFGPU_formatCannotRead. */
+int32_t avifgpu_host_interleaved_chroma(int32_t bit_depth, int32_t has_alpha);
+
+/* What DoWriteStart does to the options before it calls CreateHeifImage* (Write.cpp:231-258), in place:  32-bit mono ->
+ * transfer Clip; 32-bit colour with SMPTE 428 -> 12 bit; premultipliedAlpha off for 32-bit HDR (transfer != Clip after the
+ * first rule).  imageBitDepth is the NUMBER (8|10|12) here, as everywhere in avifgpu_SaveUIOptions. */
+avifgpu_OSErr avifgpu_host_normalize_save_options(const avifgpu_FormatRecord* formatRecord, avifgpu_SaveUIOptions* saveOptions);
+
+/* GetAlphaState (Write.cpp:189-208): AVIFGPU_ALPHA_NONE without an alpha plane (HasAlphaChannel, Utilities.cpp:418-432),
+ * PREMULTIPLIED when premultipliedAlpha && !lossless, else STRAIGHT. */
+int32_t avifgpu_host_alpha_state(const avifgpu_FormatRecord* formatRecord, const avifgpu_SaveUIOptions* saveOptions);
+
+/* Which transform ColorProfileConversion's constructors install (ColorProfileConversion.cpp:98-157) -- the three call sites
+ * WriteHeifImage.cpp:651 (8), :830 (16), :1015 (32); the gray functions never build one:
+ *   depth 32:  mayRequireConversion = transfer != Clip || !keepColorProfile (:105).  With a profile and that flag:
+ *              Clip -> ALWAYS to sRGB (:118-123), otherwise to linear Rec.2020 unless the profile IS Rec.2020 (:126-129).
+ *              Clip + keepColorProfile -> NO transform: the pixels stay, the profile is embedded (WriteMetadata.cpp:133-136).
+ *   depth 8/16: with a profile and !keepColorProfile (:143): to sRGB unless the profile IS sRGB (:152-155).
+ * has_profile = HasColorProfileMetadata(formatRecord) (HostMetadata.cpp:63-69); detect_mask = avifgpu_icc_detect() of the
+ * profile bytes, consulted only where the reference opens the profile -- a negative mask there is the reference's
+ * "Unable to load the document color profile." (:111-114,:147-150): returns AVIFGPU_writErr with that message.
+ * Returns AVIFGPU_CONVERT_* (>= 0) or a negative OSErr. */
+enum { AVIFGPU_CONVERT_NONE = 0, AVIFGPU_CONVERT_TO_REC2020 = 1, AVIFGPU_CONVERT_TO_SRGB = 2 };
+int32_t avifgpu_host_required_conversion(int32_t depth, int32_t monochrome, int32_t transfer, int32_t keepColorProfile,
+                                         int32_t has_profile, int32_t detect_mask);
+/* The same from a record + options: has_profile = iCCprofileData != NULL && iCCprofileSize > 0 (the adapter fills them only
+ * when HasColorProfileMetadata holds); runs avifgpu_icc_detect only when the decision needs it. */
+int32_t avifgpu_host_required_conversion_for_record(const avifgpu_FormatRecord* formatRecord,
+                                                    const avifgpu_SaveUIOptions* saveOptions);
+
+/* Which C++ exception an adapter re-throws for a shim result so that DoWriteStart / DoReadContinue map it back as before
+ * (Write.cpp:345-364, Read.cpp:659-678): memFullErr -> std::bad_alloc; the direction's own fallback code (writErr on save,
+ * readErr on open) -> std::runtime_error(avifgpu_last_error()) -- that is what the shim returned for the reference's
+ * runtime_error messages; any other non-zero code -> OSErrException(code) (userCanceledErr, the host's advanceState error,
+ * formatBadParameters, formatCannotRead ...). */
+enum { AVIFGPU_THROW_NOTHING = 0, AVIFGPU_THROW_BAD_ALLOC = 1, AVIFGPU_THROW_RUNTIME_ERROR = 2, AVIFGPU_THROW_OSERR = 3 };
+enum { AVIFGPU_DIRECTION_SAVE = 0, AVIFGPU_DIRECTION_OPEN = 1 };
+int32_t avifgpu_host_exception_class(int32_t err, int32_t direction);
+
+/* Which planes an open takes from the decoded heif_image and what it checks first, per entry point:
+ *   gray entries (ReadHeifImageGray*, ReadHeifImage.cpp:418,489,863): heif_channel_Y (+Alpha) whatever the colour space says;
+ *     the 8-bit entry ASSUMES 8-bit luma (:430) -- required_bits = 8 applies to alpha only there.
+ *   RGB entries (:561,:714,:949): YCbCr -> Y,Cb,Cr with the chroma format's shifts (GetChromaShift, :52-81: anything that is
+ *     not 4:2:0 / 4:2:2 counts as 4:4:4), the 8-bit driver ASSUMES 8-bit luma (:91) and checks chroma / alpha against it; RGB -> R,G,B planes, 8-bit host depth requires 8-bit planes (:585-588); any other
+ *     colour space: "Unsupported image color space, expected RGB." (:575-578,:728-731,:971-974).
+ * heif_colorspace / heif_chroma are libheif's enumerator values (YCbCr 0, RGB 1, monochrome 2; 4:2:0 1, 4:2:2 2, 4:4:4 3);
+ * channels[] are heif_channel values (Y 0, Cb 1, Cr 2, R 3, G 4, B 5, Alpha 6), channels[3] is always Alpha. */
+typedef struct avifgpu_read_plan {
+    int32_t colorspace;              /* AVIFGPU_COLORSPACE_* for avifgpu_image.colorspace */
+    int32_t chroma;                  /* AVIFGPU_CHROMA_*     for avifgpu_image.chroma */
+    int32_t plane_count;             /* colour planes to fetch: 1 or 3 */
+    int32_t channels[4];
+    int32_t required_bits;           /* 0 = whatever plane 0 has; 8 = the 8-bit planar-RGB / gray entry's fixed depth */
+    int32_t assume_luma_bits;        /* != 0: do not query plane 0's depth, use this (ReadHeifImageGrayEightBit, :430) */
+} avifgpu_read_plan;
+avifgpu_OSErr avifgpu_host_plan_read(int32_t gray_entry, int32_t host_depth, int32_t heif_colorspace, int32_t heif_chroma,
+                                     avifgpu_read_plan* out);
+/* The depth checks of those drivers: bits[i] = heif_image_get_bits_per_pixel_range(channels[i]) for the planes fetched
+ * (bits[3] = alpha when has_alpha).  readErr + the reference's message ("The chroma channel bit depth does not match the
+ * main image." :96, "The color channel bit depths do not match." :593, "Unsupported RGB channel bit depth, expected 8
+ * bits-per-channel." :587, "The alpha channel bit depth does not match the main image channels." :134) or noErr; *bit_depth
+ * receives the value for avifgpu_image.bit_depth. */
+avifgpu_OSErr avifgpu_host_check_read_depths(const avifgpu_read_plan* plan, const int32_t bits[4], int32_t has_alpha,
+                                             int32_t* bit_depth);
 
 #ifdef __cplusplus
 }

@@ -40,60 +40,49 @@ namespace
         return bridge.real->abortProc() ? 1 : 0;
     }
 
+    // Decisions (which planes, which checks, which exception) are the library's tested helpers (include/avifgpu_host.h,
+    // csrc/host_decisions.cpp, tests/test_host_decisions.py); this file converts types, queries libheif and re-throws.
+    [[noreturn]] void ThrowFor(int32_t err)
+    {
+        switch (avifgpu_host_exception_class(err, AVIFGPU_DIRECTION_OPEN))         // Read.cpp:659-678 run backwards
+        {
+        case AVIFGPU_THROW_BAD_ALLOC: throw std::bad_alloc();
+        case AVIFGPU_THROW_RUNTIME_ERROR: throw std::runtime_error(avifgpu_last_error());   // the reference's runtime_error messages
+        default: throw OSErrException(static_cast<OSErr>(err));
+        }
+    }
+
     void ReadOnGpu(const heif_image* image, AlphaState alphaState, const heif_color_profile_nclx* nclxProfile,
-                   const LoadUIOptions* loadOptions, FormatRecordPtr formatRecord)
+                   const LoadUIOptions* loadOptions, FormatRecordPtr formatRecord, bool grayEntry)
     {
         const VPoint imageSize = GetImageSize(formatRecord);
         const bool hasAlpha = alphaState != AlphaState::None;
 
         // ---- the heif_image as the conversion layer sees it (ReadHeifImage.cpp:89-111, :567-579) ----
+        avifgpu_read_plan plan{};
+        avifgpu_OSErr planErr = avifgpu_host_plan_read(grayEntry, formatRecord->depth, static_cast<int32_t>(heif_image_get_colorspace(image)),
+                                                       static_cast<int32_t>(heif_image_get_chroma_format(image)), &plan);
+        if (planErr != noErr) ThrowFor(planErr);
+        int32_t bits[4] = { 0, 0, 0, 0 };
+        for (int i = 0; i < plan.plane_count; i++)
+        {
+            bits[i] = heif_image_get_bits_per_pixel_range(image, static_cast<heif_channel>(plan.channels[i]));
+        }
+        if (hasAlpha) bits[3] = heif_image_get_bits_per_pixel_range(image, heif_channel_Alpha);
+
         avifgpu_image in{};
         in.width = imageSize.h; in.height = imageSize.v;
-        const heif_colorspace colorspace = heif_image_get_colorspace(image);
-        heif_channel channels[4] = { heif_channel_Y, heif_channel_Cb, heif_channel_Cr, heif_channel_Alpha };
-        int planeCount = 3;
-        switch (colorspace)
-        {
-        case heif_colorspace_YCbCr:
-            in.colorspace = AVIFGPU_COLORSPACE_YCBCR;
-            switch (heif_image_get_chroma_format(image))                                             // GetChromaShift, :52-81
-            {
-            case heif_chroma_420: in.chroma = AVIFGPU_CHROMA_420; break;
-            case heif_chroma_422: in.chroma = AVIFGPU_CHROMA_422; break;
-            default: in.chroma = AVIFGPU_CHROMA_444; break;
-            }
-            break;
-        case heif_colorspace_RGB:
-            in.colorspace = AVIFGPU_COLORSPACE_RGB; in.chroma = AVIFGPU_CHROMA_444;
-            channels[0] = heif_channel_R; channels[1] = heif_channel_G; channels[2] = heif_channel_B;
-            break;
-        case heif_colorspace_monochrome:
-            in.colorspace = AVIFGPU_COLORSPACE_MONOCHROME; in.chroma = AVIFGPU_CHROMA_MONOCHROME;
-            planeCount = 1;
-            break;
-        default:
-            throw std::runtime_error("Unsupported image color space, expected RGB.");                // :575-578
-        }
-        in.bit_depth = heif_image_get_bits_per_pixel_range(image, channels[0]);
-        for (int i = 1; i < planeCount; i++)
-        {
-            if (heif_image_get_bits_per_pixel_range(image, channels[i]) != in.bit_depth)
-            {
-                throw std::runtime_error("The chroma channel bit depth does not match the main image.");   // :96-100
-            }
-        }
-        for (int i = 0; i < planeCount; i++)
+        in.colorspace = plan.colorspace; in.chroma = plan.chroma;
+        planErr = avifgpu_host_check_read_depths(&plan, bits, hasAlpha, &in.bit_depth);
+        if (planErr != noErr) ThrowFor(planErr);
+        for (int i = 0; i < plan.plane_count; i++)
         {
             int stride = 0;
-            in.plane[i] = const_cast<uint8_t*>(heif_image_get_plane_readonly(image, channels[i], &stride));
+            in.plane[i] = const_cast<uint8_t*>(heif_image_get_plane_readonly(image, static_cast<heif_channel>(plan.channels[i]), &stride));
             in.stride[i] = stride;
         }
         if (hasAlpha)
         {
-            if (heif_image_get_bits_per_pixel_range(image, heif_channel_Alpha) != in.bit_depth)
-            {
-                throw std::runtime_error("The alpha channel bit depth does not match the main image.");   // :337-340 etc.
-            }
             int stride = 0;
             in.plane[3] = const_cast<uint8_t*>(heif_image_get_plane_readonly(image, heif_channel_Alpha, &stride));
             in.stride[3] = stride;
@@ -139,40 +128,38 @@ namespace
         if (formatRecord->depth == 16) formatRecord->maxValue = shim.maxValue;
         formatRecord->data = nullptr;
 
-        if (err == memFullErr) throw std::bad_alloc();
-        if (err == readErr) throw std::runtime_error(avifgpu_last_error());        // the reference's runtime_error messages
-        OSErrException::ThrowIfError(err);
+        if (err != noErr) ThrowFor(err);
     }
 }
 
 void ReadHeifImageGrayEightBit(const heif_image* image, AlphaState alphaState, const heif_color_profile_nclx* nclxProfile, FormatRecordPtr formatRecord)
 {
-    ReadOnGpu(image, alphaState, nclxProfile, nullptr, formatRecord);
+    ReadOnGpu(image, alphaState, nclxProfile, nullptr, formatRecord, true);
 }
 
 void ReadHeifImageRGBEightBit(const heif_image* image, AlphaState alphaState, const heif_color_profile_nclx* nclxProfile, FormatRecordPtr formatRecord)
 {
-    ReadOnGpu(image, alphaState, nclxProfile, nullptr, formatRecord);
+    ReadOnGpu(image, alphaState, nclxProfile, nullptr, formatRecord, false);
 }
 
 void ReadHeifImageGraySixteenBit(const heif_image* image, AlphaState alphaState, const heif_color_profile_nclx* nclxProfile, FormatRecordPtr formatRecord)
 {
-    ReadOnGpu(image, alphaState, nclxProfile, nullptr, formatRecord);
+    ReadOnGpu(image, alphaState, nclxProfile, nullptr, formatRecord, true);
 }
 
 void ReadHeifImageRGBSixteenBit(const heif_image* image, AlphaState alphaState, const heif_color_profile_nclx* nclxProfile, FormatRecordPtr formatRecord)
 {
-    ReadOnGpu(image, alphaState, nclxProfile, nullptr, formatRecord);
+    ReadOnGpu(image, alphaState, nclxProfile, nullptr, formatRecord, false);
 }
 
 void ReadHeifImageGrayThirtyTwoBit(const heif_image* image, AlphaState alphaState, const heif_color_profile_nclx* nclxProfile,
                                    const LoadUIOptions& loadOptions, FormatRecordPtr formatRecord)
 {
-    ReadOnGpu(image, alphaState, nclxProfile, &loadOptions, formatRecord);
+    ReadOnGpu(image, alphaState, nclxProfile, &loadOptions, formatRecord, true);
 }
 
 void ReadHeifImageRGBThirtyTwoBit(const heif_image* image, AlphaState alphaState, const heif_color_profile_nclx* nclxProfile,
                                   const LoadUIOptions& loadOptions, FormatRecordPtr formatRecord)
 {
-    ReadOnGpu(image, alphaState, nclxProfile, &loadOptions, formatRecord);
+    ReadOnGpu(image, alphaState, nclxProfile, &loadOptions, formatRecord, false);
 }

@@ -65,15 +65,23 @@ namespace
         return bridge.real->abortProc() ? 1 : 0;
     }
 
-    int GetHeifImageBitDepth(ImageBitDepth bitDepth)
+    // Every decision below is taken by libavifgpu's tested helpers (include/avifgpu_host.h, "Decisions of the reference-named
+    // adapters"; csrc/host_decisions.cpp, tests/test_host_decisions.py); this file only converts types and re-throws.
+
+    [[noreturn]] void ThrowFor(int32_t err, int32_t direction)
     {
-        switch (bitDepth)
+        switch (avifgpu_host_exception_class(err, direction))                      // Write.cpp:345-364 run backwards
         {
-        case ImageBitDepth::Eight: return 8;
-        case ImageBitDepth::Ten: return 10;
-        case ImageBitDepth::Twelve: return 12;
-        default: throw OSErrException(formatCannotRead);                       // WriteHeifImage.cpp:57
+        case AVIFGPU_THROW_BAD_ALLOC: throw std::bad_alloc();
+        case AVIFGPU_THROW_RUNTIME_ERROR: throw std::runtime_error(avifgpu_last_error());   // e.g. "Unsupported color transfer function."
+        default: throw OSErrException(static_cast<OSErr>(err));
         }
+    }
+
+    int32_t Checked(int32_t valueOrErr)                                             // helpers return a value >= 0 or a negative OSErr
+    {
+        if (valueOrErr < 0) ThrowFor(valueOrErr, AVIFGPU_DIRECTION_SAVE);
+        return valueOrErr;
     }
 
     ScopedHeifImage CreateHeifImage(int width, int height, heif_colorspace colorspace, heif_chroma chroma)
@@ -83,44 +91,30 @@ namespace
         return ScopedHeifImage(tempImage);
     }
 
-    int32_t ToAvifgpuChroma(ChromaSubsampling value)
-    {
-        switch (value)
-        {
-        case ChromaSubsampling::Yuv420: return AVIFGPU_CHROMA_420;
-        case ChromaSubsampling::Yuv422: return AVIFGPU_CHROMA_422;
-        case ChromaSubsampling::Yuv444: return AVIFGPU_CHROMA_444;
-        default: throw OSErrException(formatBadParameters);                     // Write.cpp:122
-        }
-    }
-
-    // What ColorProfileConversion's constructors decide (ColorProfileConversion.cpp:98-157), restated on the profile bytes:
-    // 0 = no transform, 1 = to linear Rec.2020 (HDR), 2 = to sRGB (SDR).
-    int RequiredConversion(const FormatRecordPtr formatRecord, const SaveUIOptions& saveOptions, const void* profile, int32 size)
-    {
-        if (!HasColorProfileMetadata(formatRecord)) return 0;                   // HostMetadata.cpp:63-69
-        const int32_t is = avifgpu_icc_detect(profile, static_cast<uint32_t>(size));    // IsRec2020ColorProfile / IsSRGBColorProfile
-        if (formatRecord->depth == 32)
-        {
-            if (saveOptions.hdrTransferFunction == ColorTransferFunction::Clip) return 2;   // always: ":118-123"
-            return (is >= 0 && (is & AVIFGPU_ICC_IS_REC2020)) ? 0 : 1;
-        }
-        if (saveOptions.keepColorProfile) return 0;
-        return (is >= 0 && (is & AVIFGPU_ICC_IS_SRGB)) ? 0 : 2;
-    }
-
     // Shared body of the six functions.
     ScopedHeifImage CreateOnGpu(FormatRecordPtr formatRecord, AlphaState alphaState, const VPoint& imageSize,
                                 const SaveUIOptions& saveOptions, bool monochrome)
     {
         const bool hasAlpha = alphaState != AlphaState::None;
-        const int bits = GetHeifImageBitDepth(saveOptions.imageBitDepth);
+        const int bits = Checked(avifgpu_host_image_bit_depth(static_cast<int32_t>(saveOptions.imageBitDepth)));   // WriteHeifImage.cpp:41-61
 
 #ifdef AVIFGPU_FUSED_YCBCR
         const bool fused = !monochrome;
 #else
         const bool fused = false;
 #endif
+        avifgpu_SaveUIOptions o{};
+        o.imageBitDepth = bits;
+        o.hdrTransferFunction = static_cast<int32_t>(saveOptions.hdrTransferFunction);    // same order, ColorTransfer.h:28-34
+        o.pq.nominalPeakBrightness = saveOptions.pq.nominalPeakBrightness;
+        o.lossless = saveOptions.lossless;
+        o.chromaSubsampling = monochrome ? AVIFGPU_CHROMA_444
+                                         : Checked(avifgpu_host_chroma_subsampling(static_cast<int32_t>(saveOptions.chromaSubsampling), saveOptions.lossless));
+        o.chromaDownsampling = 0;                                                         // libheif 1.14.0's own (co-sited)
+        o.keepColorProfile = saveOptions.keepColorProfile;
+        o.premultipliedAlpha = saveOptions.premultipliedAlpha;
+        o.iccDecision = AVIFGPU_ICC_LIKE_PLUGIN;                                          // ColorProfileConversion.cpp:98-157, decided in the library
+
         // ---- the heif_image, created the way the reference creates it (or as YCbCr planes for the fused hand-off) ----
         ScopedHeifImage image;
         avifgpu_image out{};
@@ -133,13 +127,6 @@ namespace
             out.plane[index] = heif_image_get_plane(image.get(), channel, &stride);      // libheif's stride is respected
             out.stride[index] = stride;
         };
-        avifgpu_SaveUIOptions o{};
-        o.imageBitDepth = bits;
-        o.hdrTransferFunction = static_cast<int32_t>(saveOptions.hdrTransferFunction);    // same order, ColorTransfer.h:28-34
-        o.pq.nominalPeakBrightness = saveOptions.pq.nominalPeakBrightness;
-        o.lossless = saveOptions.lossless;
-        o.chromaSubsampling = monochrome ? AVIFGPU_CHROMA_444 : ToAvifgpuChroma(saveOptions.chromaSubsampling);
-        o.chromaDownsampling = 0;                                                         // libheif 1.14.0's own (co-sited)
         if (monochrome)
         {
             image = CreateHeifImage(imageSize.h, imageSize.v, heif_colorspace_monochrome, heif_chroma_monochrome);   // :179
@@ -149,22 +136,25 @@ namespace
         }
         else if (fused)
         {
-            const int32_t c = saveOptions.lossless ? AVIFGPU_CHROMA_444 : o.chromaSubsampling;                       // Write.cpp:98-127
-            const heif_chroma hc = c == AVIFGPU_CHROMA_420 ? heif_chroma_420 : (c == AVIFGPU_CHROMA_422 ? heif_chroma_422 : heif_chroma_444);
-            image = CreateHeifImage(imageSize.h, imageSize.v, heif_colorspace_YCbCr, hc);
+            const int32_t c = o.chromaSubsampling;                                        // Write.cpp:98-127 (lossless: 4:4:4)
+            image = CreateHeifImage(imageSize.h, imageSize.v, heif_colorspace_YCbCr, static_cast<heif_chroma>(c));   // AVIFGPU_CHROMA_* == heif_chroma_4xx
             out.colorspace = AVIFGPU_COLORSPACE_YCBCR; out.chroma = c;
-            const int cw = c == AVIFGPU_CHROMA_444 ? imageSize.h : (imageSize.h + 1) / 2;
-            const int ch = c == AVIFGPU_CHROMA_420 ? (imageSize.v + 1) / 2 : imageSize.v;
-            bind(0, heif_channel_Y, imageSize.h, imageSize.v);
-            bind(1, heif_channel_Cb, cw, ch);
-            bind(2, heif_channel_Cr, cw, ch);
-            if (hasAlpha) bind(3, heif_channel_Alpha, imageSize.h, imageSize.v);
+            // plane sizes from the library (avifgpu_write_plane_geometry): chroma planes are (W+1)/2 wide, (H+1)/2 tall for 4:2:0
+            avifgpu_write_desc geometry{};
+            geometry.width = imageSize.h; geometry.height = imageSize.v; geometry.depth = formatRecord->depth; geometry.planes = formatRecord->planes;
+            geometry.bit_depth = bits; geometry.alpha_state = static_cast<int32_t>(alphaState); geometry.output = AVIFGPU_OUT_YCBCR;
+            geometry.chroma = c; geometry.full_range = 1; geometry.transfer = o.hdrTransferFunction; geometry.peak_nits = o.pq.nominalPeakBrightness;
+            const heif_channel channels[4] = { heif_channel_Y, heif_channel_Cb, heif_channel_Cr, heif_channel_Alpha };
+            for (int i = 0; i < (hasAlpha ? 4 : 3); i++)
+            {
+                int32_t w = 0, h = 0, bytesPerSample = 0, samplesPerPixel = 0;
+                Checked(avifgpu_write_plane_geometry(&geometry, i, &w, &h, &bytesPerSample, &samplesPerPixel));
+                bind(i, channels[i], w, h);
+            }
         }
         else
         {
-            heif_chroma chroma;                                                                                      // :63-85
-            if (bits == 8) chroma = hasAlpha ? heif_chroma_interleaved_RGBA : heif_chroma_interleaved_RGB;
-            else chroma = hasAlpha ? heif_chroma_interleaved_RRGGBBAA_LE : heif_chroma_interleaved_RRGGBB_LE;
+            const heif_chroma chroma = static_cast<heif_chroma>(Checked(avifgpu_host_interleaved_chroma(bits, hasAlpha)));   // :63-85
             image = CreateHeifImage(imageSize.h, imageSize.v, heif_colorspace_RGB, chroma);
             out.colorspace = AVIFGPU_COLORSPACE_RGB; out.chroma = static_cast<int32_t>(chroma);
             bind(0, heif_channel_interleaved, imageSize.h, imageSize.v);
@@ -181,38 +171,33 @@ namespace
         shim.HostSupports32BitCoordinates = 1; shim.PluginUsing32BitCoordinates = 1;   // the shim always fills theRect32; the trampoline
                                                                                         // converts through the reference's own SetRect
 
-        // ---- ICC: on the GPU for matrix/TRC profiles, the reference's lcms2 ConvertRow (from the trampoline) for the rest ----
+        // ---- ICC: the profile bytes go to the library, which decides like ColorProfileConversion's constructors and converts
+        //      matrix/TRC profiles on the GPU; the reference's lcms2 ConvertRow (from the trampoline) takes the rest ----
         std::unique_ptr<ScopedHandleSuiteLock> profileLock;
-        int conversion = 0;
-        if (!monochrome && HasColorProfileMetadata(formatRecord))
+        if (!monochrome && HasColorProfileMetadata(formatRecord))                         // HostMetadata.cpp:63-69
         {
             profileLock.reset(new ScopedHandleSuiteLock(formatRecord->handleProcs, formatRecord->iCCprofileData));
             shim.iCCprofileData = profileLock->data();
             shim.iCCprofileSize = formatRecord->iCCprofileSize;
-            conversion = RequiredConversion(formatRecord, saveOptions, shim.iCCprofileData, shim.iCCprofileSize);
         }
-        o.convertToRec2020 = conversion == 1;
-        o.convertToSRGB = conversion == 2;
 
         bridge.real = formatRecord; bridge.shim = &shim; bridge.converter = nullptr; bridge.width = imageSize.h;
         const int32_t output = fused ? AVIFGPU_OUT_YCBCR : AVIFGPU_OUT_REFERENCE;
         avifgpu_OSErr err = avifgpu_host_create_heif_image(&shim, static_cast<int32_t>(alphaState), &o, output, -1, -1, &out);
-        if (err == formatCannotRead && conversion != 0)
+        if (err == formatCannotRead && avifgpu_host_required_conversion_for_record(&shim, &o) > 0)
         {
-            // LUT-based profile or sampled curves in a 32-bit document: keep the reference's CPU transform, convert the rest on the GPU
+            // LUT-based profile (or one the GPU stage does not take): keep the reference's CPU transform, convert the rest on the GPU
             std::unique_ptr<ColorProfileConversion> converter(formatRecord->depth == 32
                 ? new ColorProfileConversion(formatRecord, hasAlpha, saveOptions.hdrTransferFunction, saveOptions.keepColorProfile)
                 : new ColorProfileConversion(formatRecord, hasAlpha, formatRecord->depth, saveOptions.keepColorProfile));
-            o.convertToRec2020 = 0; o.convertToSRGB = 0;
+            o.iccDecision = AVIFGPU_ICC_EXPLICIT; o.convertToRec2020 = 0; o.convertToSRGB = 0;
             bridge.converter = converter.get();
             err = avifgpu_host_create_heif_image(&shim, static_cast<int32_t>(alphaState), &o, output, -1, -1, &out);
             bridge.converter = nullptr;
         }
         bridge.real = nullptr; bridge.shim = nullptr;
         // loPlane / hiPlane / colBytes / planeBytes / rowBytes were set by DoWriteStart before this call (Write.cpp:279-295)
-        if (err == memFullErr) throw std::bad_alloc();
-        if (err == writErr) throw std::runtime_error(avifgpu_last_error());              // e.g. "Unsupported color transfer function."
-        OSErrException::ThrowIfError(err);
+        if (err != noErr) ThrowFor(err, AVIFGPU_DIRECTION_SAVE);
         return image;
     }
 }

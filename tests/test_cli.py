@@ -148,3 +148,9 @@ def test_cli_write_with_document_profile(tmp_path):
         assert ("convert to sRGB" in r.stderr) == expect_convert, r.stderr
         got = np.frombuffer((tmp_path / "out.planes").read_bytes(), dtype=np.uint16).reshape(d.height, d.width * 3)
         assert np.array_equal(got, want[0]), desc
+        # keepColorProfile: no transform is installed whatever the profile is (ColorProfileConversion.cpp:143)
+        r = _run("write", "--width", d.width, "--height", d.height, "--depth", 16, "--planes", 3, "--bits", 10,
+                 "--icc", tmp_path / "doc.icc", "--keep-profile", tmp_path / "in.raw", tmp_path / "out.planes")
+        assert r.returncode == 0 and "no conversion" in r.stderr, r.stderr
+        got = np.frombuffer((tmp_path / "out.planes").read_bytes(), dtype=np.uint16).reshape(d.height, d.width * 3)
+        assert np.array_equal(got, harness.oracle_write(d, src)[0]), desc

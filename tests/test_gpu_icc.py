@@ -349,3 +349,52 @@ def test_host_shim_sdr_save_of_32bit_document(gpu, lcms):
     st = harness.compare_write(d, want, got)
     assert st["max_abs"] <= 1 and st["exact_frac"] >= 0.985, st
     gpu.lib.avifgpu_image_free(ctypes.byref(img))
+
+
+@pytest.mark.parametrize("keep", [1, 0])
+def test_host_shim_decides_like_the_plugin_clip_and_kept_profile(gpu, lcms, keep):
+    """iccDecision = LIKE_PLUGIN: the shim takes ColorProfileConversion's decision itself (ColorProfileConversion.cpp:98-157).
+    A 32-bit Clip save with keepColorProfile installs NO transform (:105) -- the planes equal the oracle's conversion of the
+    UNTOUCHED document -- and without it the document is converted to sRGB first (:118-123), profile bytes identical."""
+    from fake_host import FakeHost
+    H = pkg.host
+    icc = _profile(lcms, 3, 0, 1.0)                       # AdobeRGB primaries, linear
+    d = pkg.WriteDesc(width=300, height=40, depth=32, planes=3, bit_depth=12, transfer=pkg.TRANSFER_CLIP,
+                      alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_REFERENCE)
+    src = harness.make_write_source(d, seed=29)
+    conv = src.copy()
+    if not keep:
+        assert lcms.oracle_icc_convert_rows_to_srgb_float(icc, len(icc), 0, conv.ctypes.data, d.width, d.height, conv.strides[0]) == 0
+    want = harness.oracle_write(d, conv)
+    host = FakeHost(d.width, d.height, 32, 3, max_data=300 * 12 * 10, image=src)
+    blob = ctypes.create_string_buffer(icc, len(icc))
+    host.fr.iCCprofileData = ctypes.cast(blob, ctypes.c_void_p)
+    host.fr.iCCprofileSize = len(icc)
+    # convertToSRGB = 1 is deliberately left set: LIKE_PLUGIN must override the explicit flags
+    opts = H.SaveUIOptions(imageBitDepth=12, hdrTransferFunction=pkg.TRANSFER_CLIP, pq=H.PQOptions(1000), chromaSubsampling=pkg.CHROMA_444,
+                           convertToSRGB=1, keepColorProfile=keep, iccDecision=H.ICC_LIKE_PLUGIN)
+    assert gpu.lib.avifgpu_host_required_conversion_for_record(ctypes.byref(host.fr), ctypes.byref(opts)) == (H.CONVERT_NONE if keep else H.CONVERT_TO_SRGB)
+    img = H.Image()
+    code = gpu.lib.avifgpu_host_create_heif_image(ctypes.byref(host.fr), pkg.ALPHA_NONE, ctypes.byref(opts), pkg.OUT_REFERENCE,
+                                                  -1, -1, ctypes.byref(img))
+    assert code == 0, gpu.lib.avifgpu_last_error()
+    raw = (ctypes.c_uint8 * (img.stride[0] * d.height)).from_address(img.plane[0])
+    got = {0: np.frombuffer(raw, dtype=np.uint8).reshape(d.height, img.stride[0])[:, :d.width * 3 * 2].view(np.uint16).copy()}
+    st = harness.compare_write(d, want, got)
+    if keep:
+        assert st["max_abs"] == 0, st                     # no ICC arithmetic at all: the plain Clip path, bit-exact
+    else:
+        assert st["max_abs"] <= 1 and st["exact_frac"] >= 0.985, st
+    gpu.lib.avifgpu_image_free(ctypes.byref(img))
+    # a profile that cannot be opened where the reference opens it: runtime_error -> writErr + the reference's message
+    junk = ctypes.create_string_buffer(b"\0" * 256)
+    host2 = FakeHost(d.width, d.height, 32, 3, image=src)
+    host2.fr.iCCprofileData = ctypes.cast(junk, ctypes.c_void_p)
+    host2.fr.iCCprofileSize = 256
+    img2 = H.Image()
+    code = gpu.lib.avifgpu_host_create_heif_image(ctypes.byref(host2.fr), pkg.ALPHA_NONE, ctypes.byref(opts), pkg.OUT_REFERENCE, -1, -1, ctypes.byref(img2))
+    if keep:
+        assert code == 0                                   # never opened (:107)
+        gpu.lib.avifgpu_image_free(ctypes.byref(img2))
+    else:
+        assert code == pkg.writErr and b"Unable to load the document color profile." in gpu.lib.avifgpu_last_error()
