@@ -1,0 +1,167 @@
+// pq_variants -- exact-match rate of candidate LinearToPQ evaluations against the reference's float formula with glibc powf
+// (ColorTransfer.cpp:69-92 followed by the truncating store of WriteHeifImage.cpp:1093-1096), per bit depth and peak, on the
+// sweep of tests/test_gpu_t2_truth.py and on a C4-like sample.  Development tool for DESIGN.md section 4 (12-bit T2 gap):
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o tools/pq_variants tools/pq_variants.hip && tools/pq_variants
+// Also prints the absolute / relative error of v_log_f32 on the range of q, which is what variant choice hinges on.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+constexpr float kM1 = 2610.0f / 16384.0f, kM2 = 2523.0f / 4096.0f * 128.0f;
+constexpr float kC1 = 3424.0f / 4096.0f, kC2 = 2413.0f / 4096.0f * 32.0f, kC3 = 2392.0f / 4096.0f * 32.0f;
+
+__device__ __forceinline__ float nlog2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float nexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float nrcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+__device__ __forceinline__ float near_div(float n, float d)
+{
+    const float r = nrcp(d), q = n * r;
+    return fma_(fma_(-q, d, n), r, q);
+}
+
+// log2(q) * m2 for q in [0.83, 1.01] without v_log_f32: t = q - 1 (exact), s = t / (q + 1), 2 atanh(s) = ln q.
+// Coefficients carry m2 * 2 / ln 2.
+__device__ __forceinline__ float m2log2_series(float q, int terms)
+{
+    const float t = q - 1.0f, u = q + 1.0f;
+    const float s = t * nrcp(u), z = s * s;
+    const float K = kM2 * 2.8853900817779268f;                     // m2 * 2 / ln 2
+    float p;
+    if (terms == 4) { p = fma_(z, K / 7.0f, K / 5.0f); p = fma_(p, z, K / 3.0f); p = fma_(p, z, K); }
+    else if (terms == 3) { p = fma_(z, K / 5.0f, K / 3.0f); p = fma_(p, z, K); }
+    else { p = fma_(z, K / 9.0f, K / 7.0f); p = fma_(p, z, K / 5.0f); p = fma_(p, z, K / 3.0f); p = fma_(p, z, K); }
+    return s * p;
+}
+
+// x = (value * mult)^m1 candidates
+template <int XV> __device__ __forceinline__ float pq_x(float value, float mult, float log2_mult_m1)
+{
+    if (XV == 0) return nexp2(fma_(kM1, nlog2(value), log2_mult_m1));                 // library today
+    if (XV == 1) return nexp2(kM1 * nlog2(value * mult));                             // multiply first, like the reference
+    // XV == 2: split off the exponent so v_log_f32 sees [1, 2) (no -1 + log2(m) cancellation inside the unit)
+    const float t = value * mult;
+    const int e = __builtin_amdgcn_frexp_expf(t);
+    const float m = __builtin_amdgcn_frexp_mantf(t) * 2.0f;                            // [1, 2)
+    const float l = nlog2(m);                                                         // [0, 1)
+    return nexp2(fma_(kM1, l, kM1 * (float)(e - 1)));
+}
+
+// variant = XV * 10 + QV;  QV: 0 = library today (v_log, log2(max) folded), 1 = v_log, multiply by max at the end,
+// 2/3/4 = series with 3/4/5 terms, multiply at the end
+template <int XV, int QV> __device__ __forceinline__ float pq_scaled(float value, float mult, float log2_mult_m1, float maxv, float log2_max)
+{
+    const float x = pq_x<XV>(value, mult, log2_mult_m1);
+    const float n = kC1 + kC2 * x, d = 1.0f + kC3 * x;
+    const float q = near_div(n, d);
+    if (QV == 0) return nexp2(fma_(kM2, nlog2(q), log2_max));
+    if (QV == 1) return nexp2(kM2 * nlog2(q)) * maxv;
+    return nexp2(m2log2_series(q, QV + 1)) * maxv;
+}
+
+template <int XV, int QV> __global__ void run(const float* in, uint16_t* out, int n, float mult, float log2_mult_m1, float maxv, float log2_max)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = pq_scaled<XV, QV>(in[i], mult, log2_mult_m1, maxv, log2_max);
+    out[i] = (uint16_t)(uint32_t)__builtin_amdgcn_fmed3f(v, 0.0f, maxv);
+}
+
+__global__ void log_probe(const float* in, float* out, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[i] = nlog2(in[i]); }
+
+static float host_pq(float value, float peak)                      // ColorTransfer.cpp:69-92
+{
+    if (value < 0.0f) return 0.0f;
+    const float mult = peak / 10000.0f;
+    const float x = powf(value * mult, kM1);
+    return powf((kC1 + kC2 * x) / (1.0f + kC3 * x), kM2);
+}
+
+template <int XV, int QV> static void launch(const float* din, uint16_t* dout, int n, float peak, int bits)
+{
+    const float mult = peak / 10000.0f, maxv = (float)((1 << bits) - 1);
+    run<XV, QV><<<(n + 255) / 256, 256>>>(din, dout, n, mult, kM1 * log2f(mult), maxv, log2f(maxv));
+}
+
+int main()
+{
+    // ---- samples: the sweep of tests/test_gpu_t2_truth.py + a C4-like distribution ----
+    std::vector<float> sweep, c4;
+    for (int i = 0; i < 400000; ++i) sweep.push_back((float)((double)i / 399999.0));
+    for (int i = 0; i < 400000; ++i) sweep.push_back((float)exp(log(1e-9) + (log(12.5) - log(1e-9)) * (double)i / 399999.0));
+    for (int i = 0; i < 100000; ++i) sweep.push_back((float)(1.0 + 129.0 * (double)i / 99999.0));
+    uint64_t s = 1234;
+    auto rnd = [&]() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (double)(s >> 11) / 9007199254740992.0; };
+    for (int i = 0; i < 1000000; ++i) { const double u = rnd(); c4.push_back((float)(u < 0.9 ? rnd() : (u < 0.999 ? 1.0 + 11.5 * rnd() : -0.01 * rnd()))); }
+
+    for (int set = 0; set < 2; ++set) {
+        const std::vector<float>& x = set ? c4 : sweep;
+        const int n = (int)x.size();
+        float* din; uint16_t* dout;
+        CHECK(hipMalloc(&din, n * sizeof(float))); CHECK(hipMalloc(&dout, n * sizeof(uint16_t)));
+        CHECK(hipMemcpy(din, x.data(), n * sizeof(float), hipMemcpyHostToDevice));
+        std::vector<uint16_t> got(n), want(n);
+        printf("== %s (%d samples): fraction of codes that differ from the glibc-powf reference\n", set ? "C4-like" : "t2 sweep", n);
+        printf("%-8s %-6s", "bits", "peak");
+        const char* names[] = { "x0q0(lib)", "x0q1", "x0q2", "x0q3", "x0q4", "x1q1", "x1q3", "x2q1", "x2q3" };
+        for (const char* nm : names) printf(" %10s", nm);
+        printf("\n");
+        for (int bits : { 10, 12 }) for (float peak : { 80.0f, 1000.0f, 10000.0f }) {
+            const float maxv = (float)((1 << bits) - 1);
+            for (int i = 0; i < n; ++i) { const float v = host_pq(x[i], peak) * maxv; want[i] = (uint16_t)std::min(std::max(v, 0.0f), maxv); }
+            printf("%-8d %-6.0f", bits, peak);
+            for (int k = 0; k < 9; ++k) {
+                switch (k) {
+                case 0: launch<0, 0>(din, dout, n, peak, bits); break;
+                case 1: launch<0, 1>(din, dout, n, peak, bits); break;
+                case 2: launch<0, 2>(din, dout, n, peak, bits); break;
+                case 3: launch<0, 3>(din, dout, n, peak, bits); break;
+                case 4: launch<0, 4>(din, dout, n, peak, bits); break;
+                case 5: launch<1, 1>(din, dout, n, peak, bits); break;
+                case 6: launch<1, 3>(din, dout, n, peak, bits); break;
+                case 7: launch<2, 1>(din, dout, n, peak, bits); break;
+                case 8: launch<2, 3>(din, dout, n, peak, bits); break;
+                }
+                CHECK(hipMemcpy(got.data(), dout, n * sizeof(uint16_t), hipMemcpyDeviceToHost));
+                int bad = 0, worst = 0;
+                for (int i = 0; i < n; ++i) { const int dlt = abs((int)got[i] - (int)want[i]); bad += dlt != 0; worst = std::max(worst, dlt); }
+                printf(" %8.4f%%%s", 100.0 * bad / n, worst > 1 ? "!" : " ");
+            }
+            printf("\n");
+        }
+        CHECK(hipFree(din)); CHECK(hipFree(dout));
+    }
+
+    // ---- v_log_f32 on the range of q: absolute and relative error against double ----
+    {
+        std::vector<float> q;
+        for (float v = 0.83f; v < 1.012f; v = nextafterf(v, 2.0f)) q.push_back(v);
+        const int n = (int)q.size();
+        float *din, *dout;
+        CHECK(hipMalloc(&din, n * sizeof(float))); CHECK(hipMalloc(&dout, n * sizeof(float)));
+        CHECK(hipMemcpy(din, q.data(), n * sizeof(float), hipMemcpyHostToDevice));
+        log_probe<<<(n + 255) / 256, 256>>>(din, dout, n);
+        std::vector<float> l(n);
+        CHECK(hipMemcpy(l.data(), dout, n * sizeof(float), hipMemcpyDeviceToHost));
+        const double edges[] = { 0.83, 0.9, 0.95, 0.98, 0.99, 0.999, 1.0, 1.001, 1.012 };
+        printf("== v_log_f32 on q (every float in [0.83, 1.012), %d values): max |err| absolute, relative, in ulps of the result\n", n);
+        for (int b = 0; b + 1 < 9; ++b) {
+            double ea = 0, er = 0, eu = 0;
+            for (int i = 0; i < n; ++i) {
+                if (q[i] < edges[b] || q[i] >= edges[b + 1] || q[i] == 1.0f) continue;
+                const double t = log2((double)q[i]), e = fabs((double)l[i] - t);
+                ea = std::max(ea, e); er = std::max(er, e / fabs(t));
+                eu = std::max(eu, e / (double)(nextafterf(fabsf((float)t), 4.0f) - fabsf((float)t)));
+            }
+            printf("  q in [%.3f, %.3f): abs %.3e  rel %.3e  %.1f ulp\n", edges[b], edges[b + 1], ea, er, eu);
+        }
+    }
+    return 0;
+}
