@@ -103,6 +103,11 @@ class IccShaper8(ctypes.Structure):
                 ("shaper2", (ctypes.c_uint8 * 16388) * 3)]
 
 
+class DeviceInfo(ctypes.Structure):
+    _fields_ = [("device", c_int32), ("numa_node", c_int32), ("workers", c_int32), ("workers_pinned", c_int32),
+                ("pci_bus_id", ctypes.c_char * 32), ("cpulist", ctypes.c_char * 256)]
+
+
 _PLANES4 = c_void_p * 4
 _STRIDES4 = c_int64 * 4
 
@@ -113,6 +118,8 @@ ABI = [
     ("avifgpu_init_devices", c_int32, [POINTER(c_int32), c_int32]),
     ("avifgpu_device_count", c_int32, []),
     ("avifgpu_shutdown", None, []),
+    ("avifgpu_device_topology", c_int32, [c_int32, POINTER(DeviceInfo)]),
+    ("avifgpu_topology_probe", c_int32, [c_char_p, c_char_p, POINTER(c_int32), ctypes.c_char_p, c_int32]),
     ("avifgpu_last_error", c_char_p, []),
     ("avifgpu_write_rows", c_int32, [POINTER(WriteDesc), c_int32, c_int32, c_void_p, c_int64,
                                      POINTER(_PLANES4), POINTER(_STRIDES4), c_int32, c_void_p]),
@@ -137,6 +144,7 @@ ABI = [
     ("avifgpu_read_algorithmic_bytes", c_int64, [POINTER(ReadDesc), c_int32]),
     ("avifgpu_last_kernel_name", c_char_p, []),
     ("avifgpu_set_hot_variant", None, [c_int32]),
+    ("avifgpu_probe_pattern_rgb32_444", c_int32, [c_void_p, c_int64, POINTER(c_void_p * 3), POINTER(c_int64 * 3), c_int32, c_int32, c_void_p]),
 ]
 
 
@@ -251,6 +259,17 @@ class AvifGpu:
         self._check(self.lib.avifgpu_read_rows(ctypes.byref(desc), row0, nrows,
                                                ctypes.byref(planes4(src_ptrs)), ctypes.byref(strides4(src_strides)),
                                                dst_ptr, dst_row_bytes, mem, stream or None))
+
+    def topology(self):
+        """[{device, pci_bus_id, numa_node, cpulist, workers, workers_pinned}] of the bound devices (avifgpu_device_topology)."""
+        out = []
+        for i in range(64):
+            info = DeviceInfo()
+            if self.lib.avifgpu_device_topology(i, ctypes.byref(info)) != 0:
+                break
+            out.append({"device": info.device, "pci_bus_id": info.pci_bus_id.decode(), "numa_node": info.numa_node,
+                        "cpulist": info.cpulist.decode(), "workers": info.workers, "workers_pinned": bool(info.workers_pinned)})
+        return out
 
     def last_kernel(self) -> str:
         return self.lib.avifgpu_last_kernel_name().decode()

@@ -346,6 +346,19 @@ int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const Wr
             p.icc_trc_f[c][0] = gh; p.icc_trc_f[c][1] = (float)(p.icc_trc[c][0] - (double)gh);
             for (int k = 1; k < 8; ++k) p.icc_trc_f[c][k + 1] = (float)p.icc_trc[c][k];
         }
+        // One curve for R, G and B (what every matrix/TRC display profile with a parametric or gamma curve has) whose general form
+        //     y = R >= thr ? (a R + b > 0 ? pow(a R + b, g) + add : nonpos) : c R + f
+        // never takes the "a R + b <= 0" side with a value other than what pow(0, g) + add gives: a > 0, a thr + b >= 0 and
+        // nonpos == add, g > 0.  Then exp2(g log2(a R + b)) + add is the whole upper branch (log2 0 = -inf -> 0), and the streaming
+        // kernels evaluate the curve on the samples exactly as loaded (icc = 2 on write_rgb32_icc1_ycbcr444_hot and its siblings).
+        {
+            bool same = true;
+            for (int c = 1; c < 3; ++c)
+                for (int k = 0; k < 8; ++k) same = same && p.icc_trc[c][k] == p.icc_trc[0][k];
+            const double* Q = p.icc_trc[0];                    // g, a, b, thr, c, f, add, nonpos
+            const bool linear = p.icc_trc_linear[0] && p.icc_trc_linear[1] && p.icc_trc_linear[2];
+            p.icc_same_simple = same && !linear && Q[0] > 0.0 && Q[1] > 0.0 && std::isfinite(Q[3]) && Q[1] * Q[3] + Q[2] >= 0.0 && Q[7] == Q[6];
+        }
         for (int k = 0; k < 9; ++k) { p.icc_m[k] = g_icc->matrix[k]; p.icc_m_f[k] = (float)g_icc->matrix[k]; }
         { const int rc = upload_icc_pow_table(p); if (rc) return rc; }
         if (g_icc->out_curve != 0) {
@@ -490,6 +503,8 @@ int fill_read_params(const avifgpu_read_desc* d, int nrows, const ReadGeom& g, R
     for (uint32_t v : kVerifiedKg) if (v == kg_bits) p.fast_div = 1;
     if (getenv("AVIFGPU_FORCE_IEEE_DIV")) p.fast_div = 0;        // test hook: exercise the fallback
     p.rcp_kg = 1.0f / p.kg;
+    p.maxcf = (float)p.maxc;
+    p.rcp_maxc = 1.0f / p.maxcf;
     if (d->depth == 32) {
         p.pq_mult = 10000.0f / (float)(d->pq_peak_nits > 0 ? d->pq_peak_nits : 1);                                 // ColorTransfer.cpp:114
         p.pq_log2_mult = (float)std::log2((double)p.pq_mult);
@@ -611,6 +626,12 @@ int32_t avifgpu_init_devices(const int32_t* device_indices, int32_t count)
 int32_t avifgpu_init(int32_t device_index) { return avifgpu_init_devices(&device_index, 1); }
 
 int32_t avifgpu_device_count(void) { return bound_device_count(); }
+
+int32_t avifgpu_device_topology(int32_t index, avifgpu_device_info* out) { return device_topology(index, out); }
+int32_t avifgpu_topology_probe(const char* sysfs_root, const char* pci_bus_id, int32_t* numa_node, char* cpulist, int32_t cpulist_len)
+{
+    return topology_probe_c(sysfs_root, pci_bus_id, numa_node, cpulist, cpulist_len);
+}
 
 void avifgpu_shutdown(void)
 {

@@ -113,6 +113,58 @@ AG_DEV float fast_linear_to_pq(float value, float mult)
     return fast_linear_to_pq_scaled(value, kPqM1 * nat_log2(mult), 0.0f);
 }
 
+// ---- the same curve, closer to the reference's bits (round 3; tools/pq_variants.hip, profiles/r03/pq_variants.txt) -----------
+// Where the codes of the form above differ from the reference's it is almost never the last factor: v_log_f32 is accurate to an
+// ulp of its RESULT on the whole range of q (measured: <= 1.0 ulp for every float in [0.83, 1.012)).  It is x.  The reference
+// rounds q = N(x) / D(x) to float, so an x that is a few 1e-7 away from the reference's powf moves q across a rounding boundary in
+// ~10 % of the samples, and every such flip is 4.7e-6 relative on q^m2 -- 0.8 % of a code at 12 bit.  x = 2^(m1 log2 t) loses its
+// accuracy in the exponent: |m1 log2 t| reaches 4, where a float resolves 2.4e-7, and folding log2(mult) in adds a second rounding.
+// Here
+//     t = value * mult = m 2^e  (v_frexp_*),   A = m1 e = n + f  (n = floor A),   x = 2^n * 2^(m1 log2 m + f)
+// m1 e is EXACT in float (m1 = 2610 / 2^14 has 12 significant bits, |e| < 2^8), so are n and f; the one rounded number the exponent
+// sees is below 1.2 in magnitude, v_log_f32 gets an argument in [0.5, 1), and 2^n is a v_ldexp_f32.  The scale by maxValue is a
+// multiply at the end, like the reference's, instead of an addend of the last exponent (log2 4095 = 12: half an ulp of [8, 16) is
+// 4.8e-7).  Mismatching codes on the 900 k-sample sweep at 12 bit, 80 nits: 0.258 % (compact form) -> 0.234 % (multiply at the
+// end) -> 0.109 % (exact m1 e) -> 0.068 % (this).  +8 issue slots per sample, about half of them packed for two.  Same specials as
+// above: negative -> NaN in v_log_f32 -> code 0; 0 -> x = 0; +inf -> NaN -> code 0; NaN -> code 0.
+#ifndef AG_PQ_HI_SPLIT
+#define AG_PQ_HI_SPLIT 1         /* 0: 2^(m1 log2 m + A) in one v_exp_f32 (no floor / ldexp): the 0.109 % form, for A/B */
+#endif
+AG_DEV float fast_linear_to_pq_scaled_hi(float value, float mult, float maxf)
+{
+    const float t = value * mult;
+    const float A = kPqM1 * (float)__builtin_amdgcn_frexp_expf(t);                     // exact
+    const float nA = AG_PQ_HI_SPLIT ? __builtin_floorf(A) : 0.0f;
+    const float e1 = __builtin_fmaf(kPqM1, nat_log2(__builtin_amdgcn_frexp_mantf(t)), A - nA);
+    const float x = __builtin_amdgcn_ldexpf(nat_exp2(e1), (int)nA);
+    const float n = kPqC1 + kPqC2 * x;
+    const float d = 1.0f + kPqC3 * x;
+    return nat_exp2(kPqM2 * nat_log2(near_ieee_div(n, d))) * maxf;
+}
+AG_DEV f32x2 fast_linear_to_pq_scaled2_hi(f32x2 value, float mult, float maxf)
+{
+    const f32x2 t = value * mult;
+    const f32x2 A = kPqM1 * f32x2{ (float)__builtin_amdgcn_frexp_expf(t.x), (float)__builtin_amdgcn_frexp_expf(t.y) };
+    const f32x2 nA = AG_PQ_HI_SPLIT ? f32x2{ __builtin_floorf(A.x), __builtin_floorf(A.y) } : f32x2{ 0.0f, 0.0f };
+    const f32x2 l = { nat_log2(__builtin_amdgcn_frexp_mantf(t.x)), nat_log2(__builtin_amdgcn_frexp_mantf(t.y)) };
+    const f32x2 e1 = __builtin_elementwise_fma((f32x2)kPqM1, l, A - nA);
+    const f32x2 x = { __builtin_amdgcn_ldexpf(nat_exp2(e1.x), (int)nA.x), __builtin_amdgcn_ldexpf(nat_exp2(e1.y), (int)nA.y) };
+    const f32x2 n = kPqC1 + kPqC2 * x;
+    const f32x2 d = 1.0f + kPqC3 * x;
+    const f32x2 r = { nat_rcp(d.x), nat_rcp(d.y) };
+    const f32x2 q0 = n * r;
+    const f32x2 q = __builtin_elementwise_fma(__builtin_elementwise_fma(-q0, d, n), r, q0);
+    const f32x2 e2 = kPqM2 * f32x2{ nat_log2(q.x), nat_log2(q.y) };
+    return f32x2{ nat_exp2(e2.x), nat_exp2(e2.y) } * maxf;
+}
+// Which evaluation the write kernels use: 0 = the compact one everywhere, 2 = the closer one everywhere, 1 = the closer one for
+// 12-bit output only (a code is 4x finer there: exact-match rate 99.74 % -> 99.93 % on the sweep of tests/test_gpu_t2_truth.py;
+// the 12-bit kernels -- RGBA above all, BASELINE C5 -- have the issue slots to spare, the 10-bit RGB kernel does not: 0.777 -> 0.70
+// of 8 TB/s with the exact-m1e form everywhere, profiles/r03/pq_hi_library_ab.txt), decided per launch.
+#ifndef AG_PQ_HI
+#define AG_PQ_HI 1
+#endif
+
 // PQToLinear, reference ColorTransfer.cpp:94-117.  mult = 10000 / peak.
 //
 //   x = v^(1/m2);  out = (max(x - c1, 0) / (c2 - c3 x))^(1/m1) * mult

@@ -426,6 +426,7 @@ avifgpu_OSErr avifgpu_host_create_heif_image(avifgpu_FormatRecord* formatRecord,
         matrix_coefficients = nclx.matrix_coefficients; color_primaries = nclx.color_primaries;
     }
     return guarded([&] {
+        avifgpu::HostCallGuard serial;                      // one save / open at a time per process (pipeline.hip)
         const VPoint imageSize = GetImageSize(formatRecord);
         switch (formatRecord->depth) {                                                      // Write.cpp:303-336
         case 8: case 16: case 32: break;
@@ -440,7 +441,10 @@ avifgpu_OSErr avifgpu_host_read_heif_image(const avifgpu_image* image, int32_t a
                                            const avifgpu_LoadUIOptions* loadOptions, avifgpu_FormatRecord* formatRecord)
 {
     if (!image || !formatRecord || !formatRecord->advanceState) return AVIFGPU_formatBadParameters;
-    return guarded([&] { ReadHeifImageCommon(image, (AlphaState)alphaState, nclxProfile, loadOptions, formatRecord); }, AVIFGPU_readErr);
+    return guarded([&] {
+        avifgpu::HostCallGuard serial;
+        ReadHeifImageCommon(image, (AlphaState)alphaState, nclxProfile, loadOptions, formatRecord);
+    }, AVIFGPU_readErr);
 }
 
 } // extern "C"

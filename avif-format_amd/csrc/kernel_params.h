@@ -38,7 +38,8 @@ struct WriteParams {
     int32_t icc_trc_type[3];     // lcms2 parametric type per channel (0 = no ICC stage)
     int32_t icc_out;             // 0 | 4: output curve after the matrix (avifgpu_icc_transform::out_curve)
     int32_t icc_trc_linear[3];   // channel curve is gamma 1 (identity on every float)
-    int32_t icc_pad;
+    int32_t icc_same_simple;     // all three channel curves are the SAME parametric curve in its "simple" form (fill_write_params): the
+                                 // streaming kernels evaluate it per sample as loaded, R >= thr ? exp2(g log2(a R + b)) + add : c R + f
     double  icc_trc[3][8];       // normalised: g, a, b, thr, c, f, add, nonpos (see icc_trc in write_kernels.hip)
     double  icc_m[9];
     double  icc_out_p[8];
@@ -67,6 +68,8 @@ struct ReadParams {
     int32_t nrows;
     int32_t bits;                // 8 | 10 | 12 | 16
     int32_t maxc;                // 2^bits - 1
+    float   maxcf;               // (float)maxc
+    float   rcp_maxc;            // RN(1 / maxcf): unorm_to_float in read_kernels.hip
     int32_t full_range;          // effective (nclx ? flag : 1)
     int32_t identity_lut;        // colour image with GBR matrix: T_UV = T_Y (YuvLookupTables.cpp:177-180)
     int32_t premultiplied;

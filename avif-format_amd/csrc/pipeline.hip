@@ -27,8 +27,12 @@
 #include <cstring>
 #include <deque>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
+
+#include <pthread.h>
+#include <sched.h>
 
 #include "staging.h"
 
@@ -83,7 +87,65 @@ struct Ctx {
     int init_err = 0; char init_msg[256] = "";
     int err = 0; char err_msg[512] = "";                   // first failure of any tile since the last wait_all
     char last_label[kLabelBytes] = "";
+    // a pinned tile buffer the calling thread asked for: allocated by the WORKER, whose affinity is the device's NUMA node, so the
+    // pages are first touched (and page-locked) on the socket the GPU's x16 link hangs off
+    bool alloc_pending = false; int alloc_slot = 0; size_t alloc_bytes = 0; int alloc_rc = 0;
+    bool pinned_to_node = false;
 };
+
+// Where a bound device sits in the host: PCI bus id, NUMA node, the node's CPUs ("report which GPUs hang off which
+// root complex").  Read once per binding from sysfs; AVIFGPU_SYSFS_ROOT redirects the reads (tests use a fake tree).
+struct DeviceTopo { int device = -1; int numa_node = -1; std::string bdf, cpulist; int workers = 0; bool pinned = false; };
+std::vector<DeviceTopo> g_topo;
+
+bool read_small_file(const std::string& path, std::string& out)
+{
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return false;
+    char buf[512];
+    const size_t n = fread(buf, 1, sizeof(buf) - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    out = buf;
+    while (!out.empty() && (out.back() == '\n' || out.back() == ' ' || out.back() == '\r')) out.pop_back();
+    return true;
+}
+
+// "0-63,128-191" -> cpu_set_t; false for an empty or malformed list
+bool parse_cpulist(const std::string& list, cpu_set_t& set)
+{
+    CPU_ZERO(&set);
+    int count = 0;
+    const char* p = list.c_str();
+    while (*p) {
+        char* e = nullptr;
+        const long a = strtol(p, &e, 10);
+        if (e == p || a < 0) return false;
+        long b = a;
+        p = e;
+        if (*p == '-') { b = strtol(p + 1, &e, 10); if (e == p + 1 || b < a) return false; p = e; }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) { CPU_SET((int)c, &set); ++count; }
+        if (*p == ',') ++p; else if (*p) return false;
+    }
+    return count > 0;
+}
+
+int topology_probe(const char* sysfs_root, const char* bdf_in, int& numa_node, std::string& cpulist)
+{
+    numa_node = -1; cpulist.clear();
+    if (!bdf_in || !*bdf_in) return AVIFGPU_formatBadParameters;
+    std::string bdf(bdf_in);
+    for (char& ch : bdf) if (ch >= 'A' && ch <= 'F') ch = (char)(ch - 'A' + 'a');          // sysfs names are lower case
+    const std::string root = (sysfs_root && *sysfs_root) ? sysfs_root : "/sys";
+    const std::string dev = root + "/bus/pci/devices/" + bdf;
+    std::string txt;
+    if (!read_small_file(dev + "/numa_node", txt)) return AVIFGPU_readErr;                 // no such device in this tree
+    numa_node = atoi(txt.c_str());
+    // the node's CPUs; a single-node host (or a VM) reports node -1 and the device's own local_cpulist, if any, is used
+    if (numa_node >= 0 && read_small_file(root + "/devices/system/node/node" + std::to_string(numa_node) + "/cpulist", txt)) cpulist = txt;
+    else if (read_small_file(dev + "/local_cpulist", txt)) cpulist = txt;
+    return 0;
+}
 
 std::mutex g_ctx_mu;                                       // init / shutdown
 std::vector<Ctx*>* g_ctxs = nullptr;                       // heap-held on purpose: a process that never calls avifgpu_shutdown
@@ -107,7 +169,10 @@ int env_int(const char* name, int dflt, int lo, int hi)
     return (int)std::min<long>(std::max<long>(x, lo), hi);
 }
 
-// Is [p, p + bytes) page-locked memory HIP can DMA to directly?
+// Is [p, p + bytes) page-locked memory HIP can DMA to directly?  The whole span has to lie inside ONE page-locked range: the
+// runtime reports the range its first byte belongs to (start + size) and the last byte must fall inside it -- two ends that are
+// each page-locked say nothing about what lies between them.  A runtime that does not report ranges for host memory degrades to
+// the probe of both ends.
 bool is_pinned(const void* p, size_t bytes)
 {
     auto one = [](const void* q) {
@@ -116,8 +181,16 @@ bool is_pinned(const void* p, size_t bytes)
         if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
         return a.type == hipMemoryTypeHost;
     };
-    if (!p) return false;
-    return one(p) && (bytes <= 1 || one(static_cast<const uint8_t*>(p) + bytes - 1));
+    if (!p || !one(p)) return false;
+    if (bytes <= 1) return true;
+    void* start = nullptr; size_t size = 0;
+    if (hipPointerGetAttribute(&start, HIP_POINTER_ATTRIBUTE_RANGE_START_ADDR, const_cast<void*>(p)) == hipSuccess &&
+        hipPointerGetAttribute(&size, HIP_POINTER_ATTRIBUTE_RANGE_SIZE, const_cast<void*>(p)) == hipSuccess && start && size) {
+        const uintptr_t lo = reinterpret_cast<uintptr_t>(start), a = reinterpret_cast<uintptr_t>(p);
+        return a >= lo && a + bytes <= lo + size;
+    }
+    (void)hipGetLastError();
+    return one(static_cast<const uint8_t*>(p) + bytes - 1);
 }
 
 int grow_device(void** p, size_t* cap, size_t need)
@@ -328,6 +401,13 @@ void release_slot(Ctx& c, const Job& j)
 void worker_main(Ctx* cp)
 {
     Ctx& c = *cp;
+    // run on the CPUs of the device's NUMA node (when the host says which they are): the bounce memcpy of pageable caller memory,
+    // the first touch of every pinned staging buffer and the driver's submission path then stay on the socket the GPU hangs off
+    for (const DeviceTopo& t : g_topo) {
+        cpu_set_t set;
+        if (t.device == c.device && env_int("AVIFGPU_PIN_WORKERS", 1, 0, 1) && parse_cpulist(t.cpulist, set))
+            c.pinned_to_node = pthread_setaffinity_np(pthread_self(), sizeof(set), &set) == 0;
+    }
     hipError_t e = hipSetDevice(c.device);
     for (int s = 0; e == hipSuccess && s < c.nslots; ++s) {
         e = hipStreamCreateWithFlags(&c.slot[s].stream, hipStreamNonBlocking);
@@ -348,12 +428,21 @@ void worker_main(Ctx* cp)
     std::deque<Job> inflight;
     for (;;) {
         Job j;
-        bool have = false;
+        bool have = false, alloc = false;
         {
             std::unique_lock<std::mutex> lk(c.mu);
-            if (inflight.empty()) c.cv_work.wait(lk, [&] { return c.stop || !c.queue.empty(); });
-            if (!c.queue.empty()) { j = c.queue.front(); c.queue.pop_front(); have = true; }
+            if (inflight.empty()) c.cv_work.wait(lk, [&] { return c.stop || !c.queue.empty() || c.alloc_pending; });
+            if (c.alloc_pending) alloc = true;
+            else if (!c.queue.empty()) { j = c.queue.front(); c.queue.pop_front(); have = true; }
             else if (c.stop && inflight.empty()) break;
+        }
+        if (alloc) {
+            // the slot is idle (its producer is the one waiting for this buffer)
+            Slot& sl = c.slot[c.alloc_slot];
+            const int rc = grow_pinned(&sl.h_rows, &sl.h_rows_cap, c.alloc_bytes);
+            { std::lock_guard<std::mutex> lk(c.mu); c.alloc_rc = rc; c.alloc_pending = false; }
+            c.cv_done.notify_all();
+            continue;
         }
         if (have) {
             // a slot never holds two tiles: the producer waited for it before queueing
@@ -367,8 +456,10 @@ void worker_main(Ctx* cp)
         const hipError_t q = hipEventQuery(c.slot[inflight.front().slot].done);
         if (q == hipErrorNotReady) {
             (void)hipGetLastError();
+            // nap until a tile (or a buffer request) arrives.  `stop` is NOT part of the predicate: a shutdown with tiles in flight
+            // would turn this into a busy spin on hipEventQuery; it is looked at when the last tile has landed
             std::unique_lock<std::mutex> lk(c.mu);
-            c.cv_work.wait_for(lk, std::chrono::microseconds(30), [&] { return c.stop || !c.queue.empty(); });
+            c.cv_work.wait_for(lk, std::chrono::microseconds(30), [&] { return !c.queue.empty() || c.alloc_pending; });
             continue;
         }
         Job done = inflight.front();
@@ -444,6 +535,7 @@ void contexts_shutdown()
     delete g_ctxs;
     g_ctxs = nullptr;
     g_bound.clear();
+    g_topo.clear();
 }
 
 int contexts_init(const int32_t* devices, int count)
@@ -456,19 +548,37 @@ int contexts_init(const int32_t* devices, int count)
                     e == hipSuccess ? "device count 0" : hipGetErrorString(e));
     for (int i = 0; i < count; ++i)
         if (devices[i] < 0 || devices[i] >= n) return fail(AVIFGPU_formatBadParameters, "device %d out of range [0,%d)", devices[i], n);
+    const int nslots = env_int("AVIFGPU_SLOTS", 4, 2, kMaxSlots);
+    // Lanes: contexts per bound device.  One worker keeps one copy queue per direction busy; a second lane on the same device
+    // overlaps its submissions with the first one's (measured: see profiles/r02/pcie_host_pointer_path.jsonl).
+    const int lanes = env_int("AVIFGPU_LANES", kDefaultLanes, 1, 4);
+    const bool trace = env_int("AVIFGPU_TRACE", 0, 0, 1) != 0;
     {
+        // same binding AND same knobs: nothing to do (a changed AVIFGPU_LANES / AVIFGPU_SLOTS / AVIFGPU_TRACE re-binds)
         std::lock_guard<std::mutex> lk(g_ctx_mu);
-        if (g_ctxs && g_bound == std::vector<int>(devices, devices + count)) return 0;     // same binding: nothing to do
+        if (g_ctxs && g_bound == std::vector<int>(devices, devices + count) && (int)g_ctxs->size() == count * lanes &&
+            (*g_ctxs)[0]->nslots == nslots && g_trace == trace) return 0;
     }
     contexts_shutdown();                                   // re-binding releases every stream, event and buffer of the old devices
     release_device_caches();                               // ... and their table caches (never reused on another device)
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     auto* v = new std::vector<Ctx*>();
-    const int nslots = env_int("AVIFGPU_SLOTS", 4, 2, kMaxSlots);
-    // Lanes: contexts per bound device.  One worker keeps one copy queue per direction busy; a second lane on the same device
-    // overlaps its submissions with the first one's (measured: see profiles/r02/pcie_host_pointer_path.jsonl).
-    const int lanes = env_int("AVIFGPU_LANES", kDefaultLanes, 1, 4);
-    g_trace = env_int("AVIFGPU_TRACE", 0, 0, 1) != 0;
+    g_trace = trace;
+    // where each bound device sits: PCI bus id -> NUMA node -> that node's CPUs (sysfs); the workers pin themselves to them
+    g_topo.clear();
+    for (int i = 0; i < count; ++i) {
+        bool seen = false;
+        for (const DeviceTopo& t : g_topo) seen = seen || t.device == devices[i];
+        if (seen) continue;
+        DeviceTopo t;
+        t.device = devices[i];
+        char bdf[64] = "";
+        if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), devices[i]) == hipSuccess) {
+            t.bdf = bdf;
+            (void)topology_probe(getenv("AVIFGPU_SYSFS_ROOT"), bdf, t.numa_node, t.cpulist);
+        } else (void)hipGetLastError();
+        g_topo.push_back(t);
+    }
     int rc = 0;
     for (int i = 0; i < count * lanes && !rc; ++i) {
         Ctx* c = new Ctx();
@@ -482,6 +592,11 @@ int contexts_init(const int32_t* devices, int count)
     }
     g_ctxs = v;
     g_bound.assign(devices, devices + count);
+    for (DeviceTopo& t : g_topo) {
+        t.workers = 0; t.pinned = true;
+        for (Ctx* c : *v) if (c->device == t.device) { ++t.workers; t.pinned = t.pinned && c->pinned_to_node; }
+        t.pinned = t.pinned && t.workers > 0;
+    }
     if (rc) {
         // unwind outside the lock-free helpers: same steps as contexts_shutdown
         for (Ctx* c : *g_ctxs) {
@@ -490,9 +605,32 @@ int contexts_init(const int32_t* devices, int count)
             if (c->worker.joinable()) c->worker.join();
             delete c;
         }
-        delete g_ctxs; g_ctxs = nullptr; g_bound.clear();
+        delete g_ctxs; g_ctxs = nullptr; g_bound.clear(); g_topo.clear();
     }
     return rc;
+}
+
+int device_topology(int index, avifgpu_device_info* out)
+{
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    if (!out || index < 0 || index >= (int)g_topo.size()) return AVIFGPU_formatBadParameters;
+    const DeviceTopo& t = g_topo[index];
+    std::memset(out, 0, sizeof(*out));
+    out->device = t.device; out->numa_node = t.numa_node; out->workers = t.workers; out->workers_pinned = t.pinned ? 1 : 0;
+    snprintf(out->pci_bus_id, sizeof(out->pci_bus_id), "%s", t.bdf.c_str());
+    snprintf(out->cpulist, sizeof(out->cpulist), "%s", t.cpulist.c_str());
+    return 0;
+}
+
+int topology_probe_c(const char* sysfs_root, const char* bdf, int32_t* numa_node, char* cpulist, int32_t cpulist_len)
+{
+    int node = -1; std::string list;
+    const int rc = topology_probe(sysfs_root, bdf, node, list);
+    if (numa_node) *numa_node = node;
+    if (cpulist && cpulist_len > 0) snprintf(cpulist, (size_t)cpulist_len, "%s", list.c_str());
+    if (rc) return rc;
+    cpu_set_t set;
+    return list.empty() ? 0 : (parse_cpulist(list, set) ? CPU_COUNT(&set) : AVIFGPU_readErr);
 }
 
 void* tile_buffer(int ctx, int slot, size_t bytes)
@@ -500,7 +638,14 @@ void* tile_buffer(int ctx, int slot, size_t bytes)
     Ctx* c = ctx_at(ctx);
     if (!c || slot < 0 || slot >= c->nslots) return nullptr;
     Slot& sl = c->slot[slot];                              // the slot is idle (the producer owns it between wait_slot and enqueue)
-    if (grow_pinned(&sl.h_rows, &sl.h_rows_cap, bytes ? bytes : 64)) return nullptr;
+    const size_t need = bytes ? bytes : 64;
+    if (need <= sl.h_rows_cap) return sl.h_rows;
+    // (re)allocated by the context's worker: first touched and page-locked on the NUMA node of the device it feeds
+    std::unique_lock<std::mutex> lk(c->mu);
+    c->alloc_slot = slot; c->alloc_bytes = need; c->alloc_rc = 0; c->alloc_pending = true;
+    c->cv_work.notify_one();
+    c->cv_done.wait(lk, [&] { return !c->alloc_pending; });
+    if (c->alloc_rc) { set_error("hipHostMalloc of a pinned tile buffer failed"); return nullptr; }
     return sl.h_rows;
 }
 
@@ -581,9 +726,16 @@ int chunk_rows_for(size_t bytes_per_row)
 
 } // namespace
 
+// Host-pointer conversions share the contexts' slots and their sticky error state: ONE at a time per process.  Photoshop calls a
+// plug-in serially (AvifFormat.cpp:104-199); any other caller's threads are serialised here instead of corrupting each other.
+std::recursive_mutex g_host_call_mu;
+void host_call_lock() { g_host_call_mu.lock(); }
+void host_call_unlock() { g_host_call_mu.unlock(); }
+
 int write_rows_host(const avifgpu_write_desc* d, int row0, int nrows, const void* src, int64_t src_row_bytes,
                     void* const dst[4], const int64_t dst_stride[4], const IccArgs& icc)
 {
+    std::lock_guard<std::recursive_mutex> serial(g_host_call_mu);
     const int n = context_count();
     if (n == 0) return fail(AVIFGPU_formatBadParameters, "avifgpu_init has not succeeded: no HIP device bound (no CPU fallback)");
     WriteGeom g;
@@ -623,6 +775,7 @@ int write_rows_host(const avifgpu_write_desc* d, int row0, int nrows, const void
 int read_rows_host(const avifgpu_read_desc* d, int row0, int nrows, const void* const src[4], const int64_t src_stride[4],
                    void* dst, int64_t dst_row_bytes)
 {
+    std::lock_guard<std::recursive_mutex> serial(g_host_call_mu);
     const int n = context_count();
     if (n == 0) return fail(AVIFGPU_formatBadParameters, "avifgpu_init has not succeeded: no HIP device bound (no CPU fallback)");
     ReadGeom g;

@@ -51,22 +51,35 @@ AG_DEV int lim2full_uv(int bits, int v)
     }
 }
 
+// (float)u / (float)maxc -- the one division every table entry is made of (YuvLookupTables.cpp:171,182,188) -- in three FMAs:
+// q0 = u * RN(1/max), q = fma(fma(-q0, max, u), RN(1/max), q0).  For max = 255, 1023, 4095 and 65535 (the only values there are)
+// this equals the IEEE quotient for EVERY u in [0, max]: tests/test_oracle_properties.py::test_unorm_division_is_exact runs the
+// same C expression over all 70 914 inputs.  It is what lets a full-range image be decoded with no table at all (below).
+AG_DEV float unorm_to_float(const ReadParams& p, int u)
+{
+    const float x = (float)u;
+    const float q0 = x * p.rcp_maxc;
+    return __builtin_fmaf(__builtin_fmaf(-q0, p.maxcf, x), p.rcp_maxc, q0);
+}
 // Table formulas, reference YuvLookupTables.cpp:157-190 (and ReadHeifImage.cpp:402-415 for the alpha form).
 AG_DEV float table_y(const ReadParams& p, int i)
 {
     const int u = p.full_range ? i : lim2full_y(p.bits, i);
-    return (float)u / (float)p.maxc;
+    return unorm_to_float(p, u);
 }
 AG_DEV float table_uv(const ReadParams& p, int i)
 {
     if (p.identity_lut) return table_y(p, i);
     const int u = p.full_range ? i : lim2full_uv(p.bits, i);
-    return (float)u / (float)p.maxc - 0.5f;
+    return unorm_to_float(p, u) - 0.5f;
 }
-AG_DEV float table_a(const ReadParams& p, int i) { return (float)i / (float)p.maxc; }
+AG_DEV float table_a(const ReadParams& p, int i) { return unorm_to_float(p, i); }
 
 // LUT = true : tables live in LDS (bits <= 12), a lookup is one ds_read_b32 -- no branch in the pixel loop.
-// LUT = false: 16-bit samples, the table formula is evaluated per sample (3 x 65536 floats would not fit LDS).
+// LUT = false: the table formula is evaluated per sample: 16-bit samples (3 x 65536 floats would not fit LDS) and, since round 3,
+//              FULL-RANGE images of every depth up to AG_READ_ARITH_BITS: an entry is then unorm_to_float(code) -- three FMAs -- and
+//              a workgroup that has no table to copy has no barrier and no dead time in front of its first plane load.  (A table
+//              workgroup spends ~1.5 us on the copy + barrier out of the ~10 us it lives: the "launch-size" gap of the u8 rows.)
 template <bool LUT> struct Tables {
     const float* ty; const float* tuv; const float* ta;
     const float* te;      // planar RGB -> f32: EOTF(T_A[i]) per code
@@ -319,6 +332,26 @@ AG_DEV void decode_ycc8_packed(const ReadParams& p, const Tables<LUT>& t, int i,
     put_u8(pk, NCH * i + 2, 0.5f + (B * 255.0f));
 }
 
+// Two pixels at once (AG_R8_PKMATH): the nine full-rate float operations per pixel above -- three adds, three multiplies by 255, three
+// adds of 0.5 -- become v_pk_add_f32 / v_pk_mul_f32 on pixel PAIRS (two IEEE single operations per lane per issue slot on gfx950,
+// element for element the scalar sequence: same bits).  ct0 / ct1 are the chroma terms of the two pixels: the same for a 4:2:x pair,
+// which is where this is used (pairing 4:4:4 pixels keeps two sets of chroma terms alive: 64 -> 70 VGPRs and a scratch spill).
+#ifndef AG_R8_PKMATH
+#define AG_R8_PKMATH 1
+#endif
+template <bool LUT>
+AG_DEV void decode_ycc8_packed_pair(const ReadParams& p, const Tables<LUT>& t, int i, uint32_t yv0, uint32_t yv1, const ChromaTerms& ct0,
+                                    const ChromaTerms& ct1, uint32_t* pk)
+{
+    const f32x2 Y = { look_y(p, t, yv0), look_y(p, t, yv1) };
+    const f32x2 R = Y + f32x2{ ct0.r, ct1.r };                                           // :312
+    const f32x2 B = Y + f32x2{ ct0.b, ct1.b };                                           // :313
+    const f32x2 G = Y - f32x2{ ct0.g, ct1.g };                                           // :314
+    const f32x2 sR = 0.5f + (R * 255.0f), sG = 0.5f + (G * 255.0f), sB = 0.5f + (B * 255.0f);   // :324-326
+    put_u8(pk, 3 * i + 0, sR.x); put_u8(pk, 3 * i + 1, sG.x); put_u8(pk, 3 * i + 2, sB.x);
+    put_u8(pk, 3 * i + 3, sR.y); put_u8(pk, 3 * i + 4, sG.y); put_u8(pk, 3 * i + 5, sB.y);
+}
+
 // The table set of one read configuration: its layout and, with fill = true, its contents.  Only the tables the
 // configuration reads, aliased where the reference's formulas coincide (see read_table_count): 12-bit full-range YCbCr needs
 // 16 KiB instead of 48.  Used twice: build_read_tables fills a device buffer ONCE per parameter set (cached by
@@ -375,6 +408,10 @@ __global__ __launch_bounds__(256) void build_read_tables(const ReadParams p, flo
 
 #ifndef AG_READ_PREFETCH
 #define AG_READ_PREFETCH 0
+#endif
+// deepest full-range image that is decoded without tables (0 = never): see launch_read_one
+#ifndef AG_READ_ARITH_BITS
+#define AG_READ_ARITH_BITS 8
 #endif
 #ifndef AG_R8_NC
 #define AG_R8_NC 8
@@ -524,12 +561,19 @@ __global__ __launch_bounds__(AG_RPX_BLOCK) void read_px(const ReadParams p)
                         for (int d = 0; d < NDY; ++d) asm volatile("" : "+v"(cur.y[vr][d]));
                     const ChromaTerms c = chroma_terms<DEPTH, LUT>(p, t, sample_of<SRC16>(cur.c1, j), sample_of<SRC16>(cur.c2, j));
 #pragma unroll
-                    for (int vr = 0; vr < VR; ++vr)
+                    for (int vr = 0; vr < VR; ++vr) {
+                        if constexpr (AG_R8_PKMATH && !ALPHA && XS == 1) {
+                            // 4:2:x: the two pixels under this chroma sample on row vr
+                            const int i = j << 1;
+                            decode_ycc8_packed_pair<LUT>(p, t, i, sample_of<SRC16>(cur.y[vr], i), sample_of<SRC16>(cur.y[vr], i + 1), c, c, pk[vr]);
+                        } else {
 #pragma unroll
-                        for (int k = 0; k < (1 << XS); ++k) {
-                            const int i = (j << XS) + k;
-                            decode_ycc8_packed<ALPHA, LUT>(p, t, i, sample_of<SRC16>(cur.y[vr], i), ALPHA ? sample_of<SRC16>(cur.a[ALPHA ? vr : 0], i) : 0u, c, pk[vr]);
+                            for (int k = 0; k < (1 << XS); ++k) {
+                                const int i = (j << XS) + k;
+                                decode_ycc8_packed<ALPHA, LUT>(p, t, i, sample_of<SRC16>(cur.y[vr], i), ALPHA ? sample_of<SRC16>(cur.a[ALPHA ? vr : 0], i) : 0u, c, pk[vr]);
+                            }
                         }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -720,15 +764,20 @@ static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, char* lab
     snprintf(label, kLabelBytes, "read_px<cs=%d,depth=%d,alpha=%d,xs=%d,ys=%d,transfer=%d,aligned=%d>", CS, DEPTH, (int)ALPHA, XS, YS,
              TRANSFER, (int)aligned);
     ReadParams q = p;
-    if (lut_bytes) {
+    if (lut_bytes && !(p.full_range && p.bits <= AG_READ_ARITH_BITS && !(CS == kCsRgb && DEPTH == 32))) {
         const hipError_t e = cached_tables<CS, DEPTH, ALPHA, TRANSFER>(p, st, &q.tables);
         if (e != hipSuccess) return e;
     }
-#define AG_READ_LAUNCH(LUT_, AL_) hipLaunchKernelGGL((read_px<CS, DEPTH, ALPHA, XS, YS, TRANSFER, LUT_, AL_>), dim3((int)blocks), dim3(AG_RPX_BLOCK), lds, st, q)
+#define AG_READ_LAUNCH(LUT_, AL_) hipLaunchKernelGGL((read_px<CS, DEPTH, ALPHA, XS, YS, TRANSFER, LUT_, AL_>), dim3((int)blocks), dim3(AG_RPX_BLOCK), LUT_ ? lds : lds - lut_bytes, st, q)
+    // table-free decode: full range (an entry is one exact division) up to AG_READ_ARITH_BITS; planar RGB -> f32 keeps its table
+    // (EOTF per code instead of per sample), limited range keeps its tables (an integer division per entry)
+    const bool arith = p.full_range && p.bits <= AG_READ_ARITH_BITS && !(CS == kCsRgb && DEPTH == 32);
+    if (arith) snprintf(label + strlen(label), kLabelBytes - strlen(label), " tables=none");
     if constexpr (DEPTH == 8) {
-        if (aligned) AG_READ_LAUNCH(true, true); else AG_READ_LAUNCH(true, false);
+        if (arith) { if (aligned) AG_READ_LAUNCH(false, true); else AG_READ_LAUNCH(false, false); }
+        else { if (aligned) AG_READ_LAUNCH(true, true); else AG_READ_LAUNCH(true, false); }
     } else {
-        if (p.bits <= 12) { if (aligned) AG_READ_LAUNCH(true, true); else AG_READ_LAUNCH(true, false); }
+        if (p.bits <= 12 && !arith) { if (aligned) AG_READ_LAUNCH(true, true); else AG_READ_LAUNCH(true, false); }
         else { if (aligned) AG_READ_LAUNCH(false, true); else AG_READ_LAUNCH(false, false); }
     }
 #undef AG_READ_LAUNCH

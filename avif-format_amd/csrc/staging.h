@@ -85,6 +85,13 @@ int  read_tile_enqueue(int ctx, int slot, const avifgpu_read_desc* d, int row0, 
                        const int64_t src_stride[4], void* dst, int64_t dst_row_bytes);
 int  wait_slot(int ctx, int slot);                   // the tile last queued on (ctx, slot) has fully landed in host memory
 int  wait_all();                                     // every context idle; returns the first error any tile produced
+// One host-pointer conversion (whole-range call or a shim save / open) at a time per process: they share slots and error state.
+void host_call_lock();
+void host_call_unlock();
+struct HostCallGuard { HostCallGuard() { host_call_lock(); } ~HostCallGuard() { host_call_unlock(); } };
+// Topology of the bound devices (avifgpu_device_topology / avifgpu_topology_probe, include/avifgpu.h)
+int  device_topology(int index, avifgpu_device_info* out);
+int  topology_probe_c(const char* sysfs_root, const char* bdf, int32_t* numa_node, char* cpulist, int32_t cpulist_len);
 
 // Whole-range host conversions: rows [row0, row0 + nrows) are cut into one contiguous row tile per context (even cuts) and
 // each tile is pipelined through that context's slots in sub-tiles.  Output bytes do not depend on the number of contexts.

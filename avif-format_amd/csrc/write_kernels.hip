@@ -42,11 +42,17 @@ template <int ICC> struct IccF32 { static constexpr bool value = (ICC == 2 && AG
 
 // One linear-light sample -> integer code: transfer curve, scale by maxValue, clamp, TRUNCATE
 // (reference WriteHeifImage.cpp:1072-1095).
+// kTransferPqHi: the PQ evaluation that reproduces more of the reference's bits (device_math.h, fast_linear_to_pq_scaled_hi) as a
+// kernel-side transfer id of its own, so that the two forms never share a register allocation.  The launchers pick it once per launch
+// from the output depth (AG_PQ_HI): 10-bit saves -- the headline configuration -- keep the compact form.
+constexpr int kTransferPqHi = 4;
+static inline bool pq_hi_launch(const WriteParams& p) { return AG_PQ_HI == 2 || (AG_PQ_HI == 1 && p.maxv > 1023); }
 template <int TRANSFER>
 AG_DEV uint32_t oetf_code(const WriteParams& p, float f)
 {
     float scaled;
-    if constexpr (TRANSFER == AVIFGPU_TRANSFER_PQ) scaled = fast_linear_to_pq_scaled(f, p.pq_log2_mult_m1, p.log2_maxf);
+    if constexpr (TRANSFER == kTransferPqHi) scaled = fast_linear_to_pq_scaled_hi(f, p.pq_mult, p.maxf);
+    else if constexpr (TRANSFER == AVIFGPU_TRANSFER_PQ) scaled = fast_linear_to_pq_scaled(f, p.pq_log2_mult_m1, p.log2_maxf);
     else if constexpr (TRANSFER == AVIFGPU_TRANSFER_SMPTE428) scaled = fast_linear_to_smpte428(f) * p.maxf;
     else if constexpr (TRANSFER == AVIFGPU_TRANSFER_HLG) scaled = fast_linear_to_hlg(f) * p.maxf;
     else scaled = f * p.maxf;                                                   // Clip: exact
@@ -57,8 +63,9 @@ AG_DEV uint32_t oetf_code(const WriteParams& p, float f)
 template <int TRANSFER>
 AG_DEV void oetf_code2(const WriteParams& p, float f0, float f1, uint32_t& c0, uint32_t& c1)
 {
-    if constexpr (TRANSFER == AVIFGPU_TRANSFER_PQ && AG_PQ_PACKED) {
-        const f32x2 s = fast_linear_to_pq_scaled2(f32x2{ f0, f1 }, p.pq_log2_mult_m1, p.log2_maxf);
+    if constexpr ((TRANSFER == AVIFGPU_TRANSFER_PQ || TRANSFER == kTransferPqHi) && AG_PQ_PACKED) {
+        const f32x2 s = TRANSFER == kTransferPqHi ? fast_linear_to_pq_scaled2_hi(f32x2{ f0, f1 }, p.pq_mult, p.maxf)
+                                                  : fast_linear_to_pq_scaled2(f32x2{ f0, f1 }, p.pq_log2_mult_m1, p.log2_maxf);
         c0 = (uint32_t)__builtin_amdgcn_fmed3f(s.x, 0.0f, p.maxf);
         c1 = (uint32_t)__builtin_amdgcn_fmed3f(s.y, 0.0f, p.maxf);
     } else {
@@ -219,6 +226,25 @@ AG_DEV float icc_inv4_f(const IccPowTableF& T, const float* P, float R)
     const float lo = R * P[4] * P[7];
     return R >= P[5] ? hi : lo;
 }
+
+// The "simple" curve of fill_write_params (icc_same_simple): one parametric curve for R, G and B whose upper branch is a pure power
+// law.  Two transcendentals and six full-rate operations per sample, no table; evaluated by the streaming kernels on the samples
+// as loaded.  Q = gh, gl, a, b, thr, c, f, add, nonpos (WriteParams::icc_trc_f[0]).  A NaN sample fails R >= thr, takes c R + f and
+// stays NaN; the unselected side may be NaN (log2 of a negative a R + b below thr) and is dropped by the select.
+struct IccSimple { float g, a, b, thr, c, f, add; };
+AG_DEV IccSimple icc_simple_load(const WriteParams& p)
+{
+    return IccSimple{ p.icc_trc_f[0][0], p.icc_trc_f[0][2], p.icc_trc_f[0][3], p.icc_trc_f[0][4], p.icc_trc_f[0][5], p.icc_trc_f[0][6], p.icc_trc_f[0][7] };
+}
+AG_DEV float icc_trc_simple(const IccSimple& q, float R)
+{
+    const float hi = nat_exp2(q.g * nat_log2(__builtin_fmaf(q.a, R, q.b))) + q.add;
+    const float lo = __builtin_fmaf(q.c, R, q.f);
+    return R >= q.thr ? hi : lo;
+}
+#ifndef AG_ICC2_HOT
+#define AG_ICC2_HOT 1
+#endif
 
 // The parametric variants read up to 43 double parameters per pixel.  As kernel arguments they live in SGPRs, more than the
 // scalar file holds next to everything else: the compiler spills them to VGPR lanes and reads them back with v_readlane_b32
@@ -1090,6 +1116,14 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444_hot
         f32x4 cur[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) cur[k] = __builtin_nontemporal_load(sp + min(64 * k + lane, span_f4 - 1));
+        if constexpr (ICCV == 2) {                                                 // the document's curve: per sample, the same for R, G, B
+            const IccSimple q = icc_simple_load(p);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                cur[k].x = icc_trc_simple(q, cur[k].x); cur[k].y = icc_trc_simple(q, cur[k].y);
+                cur[k].z = icc_trc_simple(q, cur[k].z); cur[k].w = icc_trc_simple(q, cur[k].w);
+            }
+        }
 #pragma unroll
         for (int k = 0; k < K; ++k) my[64 * k + lane] = cur[k];
         __builtin_amdgcn_wave_barrier();
@@ -1180,7 +1214,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot(con
     if constexpr (ICCV == 4) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) { icm[k] = icc_f_to_vgpr(p.icc_m_f[k]); ico[k] = icc_f_to_vgpr(p.icc_out_f[k]); }
-    } else if constexpr (ICCV == 1) {
+    } else if constexpr (ICCV == 1 || ICCV == 2) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) { icm[k] = p.icc_m_f[k]; ico[k] = 0.0f; }
     }
@@ -1205,6 +1239,14 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot(con
 #pragma unroll
         for (int vr = 0; vr < VR; ++vr) {
             if constexpr (ICC1) {
+                if constexpr (ICCV == 2) {                                         // the document's curve: per sample, the same for R, G, B
+                    const IccSimple q = icc_simple_load(p);
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        v[vr][k].x = icc_trc_simple(q, v[vr][k].x); v[vr][k].y = icc_trc_simple(q, v[vr][k].y);
+                        v[vr][k].z = icc_trc_simple(q, v[vr][k].z); v[vr][k].w = icc_trc_simple(q, v[vr][k].w);
+                    }
+                }
 #pragma unroll
                 for (int k = 0; k < K; ++k) reinterpret_cast<f32x4*>(my)[64 * k + lane] = v[vr][k];
                 __builtin_amdgcn_wave_barrier();
@@ -1347,6 +1389,11 @@ __global__ __launch_bounds__(AG_RGBA_STREAM_BLOCK) void write_rgba32_ycbcra444_h
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 float col[3] = { v[k + h].x, v[k + h].y, v[k + h].z };
+                if constexpr (ICCV == 2) {                                          // the document's curve on R, G, B (alpha is copied)
+                    const IccSimple q = icc_simple_load(p);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) col[c] = icc_trc_simple(q, col[c]);
+                }
                 if constexpr (ICCV != 0) {                                          // a pixel is one float4 here: no transpose needed in front
                     const float R0 = col[0], G0 = col[1], B0 = col[2];
                     col[0] = __builtin_fmaf(B0, p.icc_m_f[2], __builtin_fmaf(G0, p.icc_m_f[1], R0 * p.icc_m_f[0]));
@@ -1907,7 +1954,7 @@ static hipError_t launch_tr(const WriteParams& p, hipStream_t st, char* label)
 {
     if constexpr (DEPTH == 32) {
         switch (p.transfer) {
-        case AVIFGPU_TRANSFER_PQ:       AG_LAUNCH(DEPTH, PLANES, OUT, DST16, XS, YS, 0);
+        case AVIFGPU_TRANSFER_PQ:       if (pq_hi_launch(p)) AG_LAUNCH(DEPTH, PLANES, OUT, DST16, XS, YS, kTransferPqHi); AG_LAUNCH(DEPTH, PLANES, OUT, DST16, XS, YS, 0);
         case AVIFGPU_TRANSFER_HLG:      AG_LAUNCH(DEPTH, PLANES, OUT, DST16, XS, YS, 1);
         case AVIFGPU_TRANSFER_SMPTE428: AG_LAUNCH(DEPTH, PLANES, OUT, DST16, XS, YS, 2);
         default:                        AG_LAUNCH(DEPTH, PLANES, OUT, DST16, XS, YS, 3);
@@ -1984,7 +2031,7 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
 #define AG_REF(TR) do { if (planes == 4) hipLaunchKernelGGL((write_f32_ref_stream<TR, 4>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); \
                         else hipLaunchKernelGGL((write_f32_ref_stream<TR, 3>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); } while (0)
             switch (p.transfer) {
-            case AVIFGPU_TRANSFER_PQ:       AG_REF(AVIFGPU_TRANSFER_PQ); break;
+            case AVIFGPU_TRANSFER_PQ:       if (pq_hi_launch(p)) AG_REF(kTransferPqHi); else AG_REF(AVIFGPU_TRANSFER_PQ); break;
             case AVIFGPU_TRANSFER_HLG:      AG_REF(AVIFGPU_TRANSFER_HLG); break;
             case AVIFGPU_TRANSFER_SMPTE428: AG_REF(AVIFGPU_TRANSFER_SMPTE428); break;
             default:                        AG_REF(AVIFGPU_TRANSFER_CLIP); break;
@@ -2058,7 +2105,8 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
     const bool rgba_lin = AG_ICC1_HOT && p.icc_trc_type[0] != 0 && p.icc_trc_linear[0] && p.icc_trc_linear[1] && p.icc_trc_linear[2];
     const bool rgba_icc1 = rgba_lin && p.icc_out == 0;
     const bool rgba_icc4 = rgba_lin && p.icc_out == 4 && p.transfer == AVIFGPU_TRANSFER_CLIP && AG_ICC_FASTPOW;
-    if (AG_RGBA_HOT_ENABLE && (variant & 1) && (p.icc_trc_type[0] == 0 || rgba_icc1 || rgba_icc4) && depth == 32 && planes == 4 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 0 && ys == 0 &&
+    const bool rgba_icc2 = AG_ICC2_HOT && p.icc_trc_type[0] != 0 && p.icc_same_simple && p.icc_out == 0;
+    if (AG_RGBA_HOT_ENABLE && (variant & 1) && (p.icc_trc_type[0] == 0 || rgba_icc1 || rgba_icc4 || rgba_icc2) && depth == 32 && planes == 4 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 0 && ys == 0 &&
         (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 && p.dst[3] != nullptr &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |
           reinterpret_cast<uintptr_t>(p.dst[3]) | (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2] |
@@ -2068,12 +2116,13 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
         if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
             long long blocks = (spans + kRgbaWaves - 1) / kRgbaWaves;
             if (blocks > AG_RGBA_BLOCK_CAP * 4 / kRgbaWaves) blocks = AG_RGBA_BLOCK_CAP * 4 / kRgbaWaves;
-            snprintf(label, kLabelBytes, "write_rgba32_ycbcra444_hot<transfer=%d>%s", p.transfer, rgba_icc1 ? " icc=1" : rgba_icc4 ? " icc=4" : "");
+            snprintf(label, kLabelBytes, "write_rgba32_ycbcra444_hot<transfer=%d>%s", p.transfer, rgba_icc1 ? " icc=1" : rgba_icc4 ? " icc=4" : rgba_icc2 ? " icc=2" : "");
             if (rgba_icc4) { hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<AVIFGPU_TRANSFER_CLIP, 4>), dim3((int)blocks), dim3(AG_RGBA_STREAM_BLOCK), 0, st, p); return hipGetLastError(); }
 #define AG_RGBA(TR) do { if (rgba_icc1) hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<TR, 1>), dim3((int)blocks), dim3(AG_RGBA_STREAM_BLOCK), 0, st, p); \
+                         else if (rgba_icc2) hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<TR, 2>), dim3((int)blocks), dim3(AG_RGBA_STREAM_BLOCK), 0, st, p); \
                          else hipLaunchKernelGGL((write_rgba32_ycbcra444_hot<TR, 0>), dim3((int)blocks), dim3(AG_RGBA_STREAM_BLOCK), 0, st, p); } while (0)
             switch (p.transfer) {
-            case AVIFGPU_TRANSFER_PQ:       AG_RGBA(AVIFGPU_TRANSFER_PQ); break;
+            case AVIFGPU_TRANSFER_PQ:       if (pq_hi_launch(p)) AG_RGBA(kTransferPqHi); else AG_RGBA(AVIFGPU_TRANSFER_PQ); break;
             case AVIFGPU_TRANSFER_HLG:      AG_RGBA(AVIFGPU_TRANSFER_HLG); break;
             case AVIFGPU_TRANSFER_SMPTE428: AG_RGBA(AVIFGPU_TRANSFER_SMPTE428); break;
             default:                        AG_RGBA(AVIFGPU_TRANSFER_CLIP); break;
@@ -2085,7 +2134,8 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
     const bool icc_lin = AG_ICC1_HOT && p.icc_trc_type[0] != 0 && p.icc_trc_linear[0] && p.icc_trc_linear[1] && p.icc_trc_linear[2];
     const bool icc1 = icc_lin && p.icc_out == 0;
     const bool icc4 = icc_lin && p.icc_out == 4 && p.transfer == AVIFGPU_TRANSFER_CLIP;
-    if ((variant & 1) && (p.icc_trc_type[0] == 0 || icc1 || icc4) && depth == 32 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 1 &&
+    const bool icc2 = AG_ICC2_HOT && p.icc_trc_type[0] != 0 && p.icc_same_simple && p.icc_out == 0;
+    if ((variant & 1) && (p.icc_trc_type[0] == 0 || icc1 || icc4 || icc2) && depth == 32 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 1 &&
         (p.width % 4) == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |
           (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2]) & 15) == 0) {
@@ -2094,8 +2144,9 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
         if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
             long long blocks = (spans + kStreamWaves - 1) / kStreamWaves;
             if (blocks > AG_STREAM_BLOCK_CAP * 4 / kStreamWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kStreamWaves;
-            snprintf(label, kLabelBytes, "write_rgb32_ycbcr_sub_hot<transfer=%d,xs=1,ys=%d>%s", p.transfer, ys, icc1 ? " icc=1" : icc4 ? " icc=4" : "");
+            snprintf(label, kLabelBytes, "write_rgb32_ycbcr_sub_hot<transfer=%d,xs=1,ys=%d>%s", p.transfer, ys, icc1 ? " icc=1" : icc4 ? " icc=4" : icc2 ? " icc=2" : "");
 #define AG_SUB2(TR, YS_) do { if (icc1) hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<TR, 1, YS_, 1>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); \
+                              else if (icc2) hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<TR, 1, YS_, 2>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); \
                               else hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<TR, 1, YS_, 0>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); } while (0)
 #define AG_SUB(TR) do { if (ys) AG_SUB2(TR, 1); else AG_SUB2(TR, 0); } while (0)
             if (icc4) {
@@ -2104,7 +2155,7 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
                 return hipGetLastError();
             }
             switch (p.transfer) {
-            case AVIFGPU_TRANSFER_PQ:       AG_SUB(AVIFGPU_TRANSFER_PQ); break;
+            case AVIFGPU_TRANSFER_PQ:       if (pq_hi_launch(p)) AG_SUB(kTransferPqHi); else AG_SUB(AVIFGPU_TRANSFER_PQ); break;
             case AVIFGPU_TRANSFER_HLG:      AG_SUB(AVIFGPU_TRANSFER_HLG); break;
             case AVIFGPU_TRANSFER_SMPTE428: AG_SUB(AVIFGPU_TRANSFER_SMPTE428); break;
             default:                        AG_SUB(AVIFGPU_TRANSFER_CLIP); break;
@@ -2115,7 +2166,7 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
         }
     }
     // ... and with a linear document profile in front (icc = 1)
-    if ((variant & 1) && (icc1 || icc4) &&
+    if ((variant & 1) && (icc1 || icc4 || icc2) &&
         depth == 32 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 0 && ys == 0 && (p.width % 4) == 0 &&
         (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |
@@ -2125,14 +2176,17 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
         if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
             long long blocks = (spans + kStreamWaves - 1) / kStreamWaves;
             if (blocks > AG_STREAM_BLOCK_CAP * 4 / kStreamWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kStreamWaves;
-            snprintf(label, kLabelBytes, "write_rgb32_icc1_ycbcr444_hot<transfer=%d> icc=%d", p.transfer, icc4 ? 4 : 1);
+            snprintf(label, kLabelBytes, "write_rgb32_icc1_ycbcr444_hot<transfer=%d> icc=%d", p.transfer, icc4 ? 4 : icc2 ? 2 : 1);
             if (icc4) { hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<AVIFGPU_TRANSFER_CLIP, 4>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); return hipGetLastError(); }
+#define AG_I444(TR) do { if (icc2) hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<TR, 2>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); \
+                         else hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<TR, 1>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); } while (0)
             switch (p.transfer) {
-            case AVIFGPU_TRANSFER_PQ:       hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<AVIFGPU_TRANSFER_PQ, 1>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); break;
-            case AVIFGPU_TRANSFER_HLG:      hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<AVIFGPU_TRANSFER_HLG, 1>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); break;
-            case AVIFGPU_TRANSFER_SMPTE428: hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<AVIFGPU_TRANSFER_SMPTE428, 1>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); break;
-            default:                        hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<AVIFGPU_TRANSFER_CLIP, 1>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); break;
+            case AVIFGPU_TRANSFER_PQ:       if (pq_hi_launch(p)) AG_I444(kTransferPqHi); else AG_I444(AVIFGPU_TRANSFER_PQ); break;
+            case AVIFGPU_TRANSFER_HLG:      AG_I444(AVIFGPU_TRANSFER_HLG); break;
+            case AVIFGPU_TRANSFER_SMPTE428: AG_I444(AVIFGPU_TRANSFER_SMPTE428); break;
+            default:                        AG_I444(AVIFGPU_TRANSFER_CLIP); break;
             }
+#undef AG_I444
             return hipGetLastError();
         }
     }
@@ -2155,7 +2209,7 @@ hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16,
 #define AG_HOT2(TR, PX) do { if (nt) AG_HOT3(TR, PX, true); else AG_HOT3(TR, PX, false); } while (0)
 #define AG_HOT1(TR) do { if (px8) AG_HOT2(TR, 8); else AG_HOT2(TR, 4); } while (0)
             switch (p.transfer) {
-            case AVIFGPU_TRANSFER_PQ:       AG_HOT1(AVIFGPU_TRANSFER_PQ); break;
+            case AVIFGPU_TRANSFER_PQ:       if (pq_hi_launch(p)) AG_HOT1(kTransferPqHi); else AG_HOT1(AVIFGPU_TRANSFER_PQ); break;
             case AVIFGPU_TRANSFER_HLG:      AG_HOT1(AVIFGPU_TRANSFER_HLG); break;
             case AVIFGPU_TRANSFER_SMPTE428: AG_HOT1(AVIFGPU_TRANSFER_SMPTE428); break;
             default:                        AG_HOT1(AVIFGPU_TRANSFER_CLIP); break;

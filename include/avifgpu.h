@@ -22,6 +22,10 @@
  *
  * Return values are Photoshop OSErr codes (reference error convention: src/common/Write.cpp:345-364,
  * src/common/Read.cpp:531-550): 0 = noErr.
+ *
+ * Threading: AVIFGPU_MEM_DEVICE calls may come from any thread (they only enqueue a kernel).  AVIFGPU_MEM_HOST calls and the
+ * FormatRecord shim of avifgpu_host.h share the bound contexts' staging slots: the library serialises them (one conversion at a time
+ * per process, later callers wait) -- the plug-in itself is called serially on Photoshop's main thread (AvifFormat.cpp:104-199).
  */
 #ifndef AVIFGPU_H
 #define AVIFGPU_H
@@ -230,6 +234,29 @@ int32_t avifgpu_init_devices(const int32_t* device_indices, int32_t count);
 int32_t avifgpu_device_count(void);            /* contexts currently bound (0 before avifgpu_init*) */
 void    avifgpu_shutdown(void);
 
+/* Where bound device `index` (0 .. distinct devices of the binding - 1) sits in the host: SURVEY.md 8(e), "report which GPUs hang
+ * off which root complex".  avifgpu_init_devices reads each device's PCI bus id (hipDeviceGetPCIBusId) and, from sysfs,
+ * /sys/bus/pci/devices/<bdf>/numa_node and that node's CPU list; the device's worker threads pin themselves to those CPUs
+ * (AVIFGPU_PIN_WORKERS=0 turns that off), and they -- not the calling thread -- allocate the context's pinned staging and tile
+ * buffers, so the pages are first touched and page-locked on the socket the GPU's x16 link is attached to.  On an 8-GPU MI355X
+ * node (4 GPUs per socket) that keeps every H2D / D2H stream off the inter-socket fabric.  numa_node is -1 and cpulist empty when
+ * the host does not say (single-node machines, containers without sysfs): nothing is pinned then.
+ * AVIFGPU_formatBadParameters for an index outside the binding. */
+typedef struct avifgpu_device_info {
+    int32_t device;              /* HIP ordinal */
+    int32_t numa_node;           /* -1 = unknown */
+    int32_t workers;             /* worker threads (lanes) feeding this device */
+    int32_t workers_pinned;      /* 1 = their CPU affinity is `cpulist` */
+    char    pci_bus_id[32];      /* "0000:c1:00.0" */
+    char    cpulist[256];        /* "0-63,128-191" */
+} avifgpu_device_info;
+int32_t avifgpu_device_topology(int32_t index, avifgpu_device_info* out);
+
+/* The sysfs part of the above on its own (no device needed): NUMA node and CPU list of PCI device `pci_bus_id` under
+ * `sysfs_root` (NULL = "/sys").  Returns the number of CPUs in the list (0 = none known), AVIFGPU_readErr when the tree has no
+ * such device or the list does not parse, AVIFGPU_formatBadParameters for a null bus id. */
+int32_t avifgpu_topology_probe(const char* sysfs_root, const char* pci_bus_id, int32_t* numa_node, char* cpulist, int32_t cpulist_len);
+
 /* Message for the last non-zero return on this thread (what LibHeifException / runtime_error carry
  * in the reference, UIWin.cpp:1827-1843). */
 const char* avifgpu_last_error(void);
@@ -358,6 +385,14 @@ int64_t avifgpu_read_algorithmic_bytes(const avifgpu_read_desc* desc, int32_t nr
  * dominant kernel; see avif-format_amd/csrc/kernel_params.h.  Results are byte-identical for every value (with an ICC transform of
  * a 32-bit document: identical within tier 2 -- the streaming kernels run the 3x3 in single precision). */
 void avifgpu_set_hot_variant(int32_t variant);
+
+/* Measurement hook (not part of the reference mapping): launches the MATH-FREE twin of the dominant kernel -- the memory accesses
+ * of RGB f32 -> Y, Cb, Cr u16 4:4:4 (six coalesced non-temporal 16-byte loads and three non-temporal 16-byte plane stores per lane,
+ * one 512-pixel span per wave) with no conversion -- on device pointers, on `stream`.  bench.py times it next to the real kernel:
+ * what this box's memory system gives this access pattern is the measured ceiling `roofline.peak_measured`.  width % 512 == 0,
+ * 16-byte aligned pointers and strides; the planes receive a checksum, not pixels. */
+int32_t avifgpu_probe_pattern_rgb32_444(const void* src, int64_t src_row_bytes, void* const dst[3], const int64_t dst_stride[3],
+                                        int32_t width, int32_t nrows, void* stream);
 
 /* Name + last launch geometry of the kernel the previous *_rows call dispatched (for bench/profiles). */
 const char* avifgpu_last_kernel_name(void);

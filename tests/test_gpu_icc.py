@@ -101,6 +101,42 @@ def test_icc1_streaming_kernel_matches_lcms2(gpu, lcms, name, kind, trc, g, widt
         assert st["exact_frac"] >= (0.99 if transfer != pkg.TRANSFER_CLIP else 0.985) or d.width * d.height < 1000, (name, st)
 
 
+@pytest.mark.parametrize("name,kind,trc,g", [p for p in PROFILES if not (p[2] == 0 and p[3] == 1.0)])
+@pytest.mark.parametrize("width", [1024, 516])
+def test_icc2_streaming_kernels_match_lcms2(gpu, lcms, name, kind, trc, g, width):
+    """A 32-bit document whose profile has ONE parametric / gamma curve for R, G and B (gamma 2.2, the sRGB curve, gamma 1.8 as `para`)
+    saved as Rec.2100 PQ: the curve runs on the streaming kernels, per sample as loaded, as exp2(g log2(a R + b)) -- the same
+    arithmetic the generic icc = 2 kernel uses (AG_ICC_FASTPOW), so the same bars against the real lcms2."""
+    icc = _profile(lcms, kind, trc, g)
+    xf = gpu.icc_prepare(icc)
+    for planes, bits, transfer, peak, chroma in ((3, 10, pkg.TRANSFER_PQ, 80, pkg.CHROMA_444), (3, 12, pkg.TRANSFER_PQ, 1000, pkg.CHROMA_444),
+                                                 (3, 10, pkg.TRANSFER_PQ, 80, pkg.CHROMA_420), (3, 12, pkg.TRANSFER_SMPTE428, 80, pkg.CHROMA_422),
+                                                 (4, 12, pkg.TRANSFER_PQ, 80, pkg.CHROMA_444)):
+        d = pkg.WriteDesc(width=width, height=10, depth=32, planes=planes, bit_depth=bits, transfer=transfer, peak_nits=peak,
+                          alpha_state=pkg.ALPHA_STRAIGHT if planes == 4 else pkg.ALPHA_NONE, output=pkg.OUT_YCBCR, chroma=chroma,
+                          matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020)
+        src = np.abs(harness.make_write_source(d, seed=width + bits))      # non-linear curves: no negative inputs (see above)
+        conv = src.copy()
+        assert lcms.oracle_icc_convert_rows_to_rec2020(icc, len(icc), int(planes == 4), conv.ctypes.data, d.width, d.height, conv.strides[0]) == 0
+        want = harness.oracle_write(d, conv)
+        got = _gpu_write_icc(gpu, d, src, xf)
+        k = gpu.last_kernel()
+        assert "hot" in k and "icc=2" in k, k
+        st = harness.compare_write(d, want, got)
+        print(f"icc2-streaming {name} width {width} planes {planes} {bits}-bit transfer {transfer} chroma {chroma}: exact {st['exact_frac']:.5f} max {st['max_abs']}")
+        assert st["max_abs"] <= 1, (name, st)
+        assert st["exact_frac"] >= 0.99, (name, st)
+        # ... and within tier 2 of the generic kernel (FP64-free there too: same curve arithmetic, matrix in fp32 on both)
+        try:
+            gpu.lib.avifgpu_set_hot_variant(0)
+            slow = _gpu_write_icc(gpu, d, src, xf)
+            assert "write_px" in gpu.last_kernel() and "icc=2" in gpu.last_kernel(), gpu.last_kernel()
+        finally:
+            gpu.lib.avifgpu_set_hot_variant(1 | 2 | 4)
+        st2 = harness.compare_write(d, slow, got)
+        assert st2["max_abs"] <= 1 and st2["exact_frac"] >= 0.995, (name, st2)
+
+
 @pytest.mark.parametrize("name,kind,trc,g", [p for p in PROFILES if p[2] == 0 and p[3] == 1.0])
 @pytest.mark.parametrize("width,alpha", [(1024, pkg.ALPHA_STRAIGHT), (515, pkg.ALPHA_PREMULTIPLIED), (7, pkg.ALPHA_STRAIGHT)])
 def test_icc1_rgba_streaming_kernel_matches_lcms2(gpu, lcms, name, kind, trc, g, width, alpha):

@@ -256,3 +256,32 @@ def test_cpu_baseline_structures_equal_whole_frame(oracle, chroma, down):
         assert rc == 0
         for pl in want:
             assert np.array_equal(bufs[pl], want[pl]), (which, pl)
+
+
+def test_unorm_division_is_exact(tmp_path):
+    """read_kernels.hip::unorm_to_float: (float)u / (float)max as q0 = u * RN(1/max), q = fma(fma(-q0, max, u), RN(1/max), q0) equals the
+    IEEE quotient for every u in [0, max] and max in {255, 1023, 4095, 65535} -- every entry of every table of
+    YuvLookupTables.cpp:157-190 / ReadHeifImage.cpp:402-415.  The same C expression (fmaf is exact), all 70 914 inputs."""
+    import subprocess
+    src = tmp_path / "unorm.c"
+    src.write_text(r"""
+#include <math.h>
+#include <stdio.h>
+int main(void) {
+    const int maxes[4] = { 255, 1023, 4095, 65535 };
+    int bad = 0, n = 0;
+    for (int m = 0; m < 4; ++m) {
+        const float mx = (float)maxes[m], r = 1.0f / mx;
+        for (int i = 0; i <= maxes[m]; ++i, ++n) {
+            const float x = (float)i, q0 = x * r, q = fmaf(fmaf(-q0, mx, x), r, q0);
+            if (q != x / mx) ++bad;
+        }
+    }
+    printf("%d %d\n", n, bad);
+    return 0;
+}
+""")
+    exe = tmp_path / "unorm"
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", str(exe), str(src), "-lm"], check=True)
+    n, bad = map(int, subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split())
+    assert (n, bad) == (256 + 1024 + 4096 + 65536, 0)

@@ -15,7 +15,7 @@ wait
 for o in variants/$unit.*.o; do
   name=$(basename $o .o); name=${name#$unit.}
   objs=""
-  for f in avifgpu_api.hip pipeline.hip write_kernels.hip read_kernels.hip host_shim.cpp icc_profile.cpp; do
+  for f in avifgpu_api.hip pipeline.hip write_kernels.hip read_kernels.hip pattern_probe.hip host_shim.cpp host_decisions.cpp icc_profile.cpp; do
     if [ "$f" = "$unit.hip" ]; then objs="$objs $o"; else objs="$objs build/$f.o"; fi
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libavifgpu_$name.so $objs

@@ -2,7 +2,8 @@
 // (ColorTransfer.cpp:69-92 followed by the truncating store of WriteHeifImage.cpp:1093-1096), per bit depth and peak, on the
 // sweep of tests/test_gpu_t2_truth.py and on a C4-like sample.  Development tool for DESIGN.md section 4 (12-bit T2 gap):
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o tools/pq_variants tools/pq_variants.hip && tools/pq_variants
-// Also prints the absolute / relative error of v_log_f32 on the range of q, which is what variant choice hinges on.
+// Columns: x<how x = t^m1 is formed> q<how the last exponent is scaled> d<which quotient>.  Also prints the error of v_log_f32 on
+// the range of q (it IS 1 ulp of the result there: the series that avoided it gained nothing and was dropped from this table).
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -27,51 +28,60 @@ __device__ __forceinline__ float near_div(float n, float d)
     return fma_(fma_(-q, d, n), r, q);
 }
 
-// log2(q) * m2 for q in [0.83, 1.01] without v_log_f32: t = q - 1 (exact), s = t / (q + 1), 2 atanh(s) = ln q.
-// Coefficients carry m2 * 2 / ln 2.
-__device__ __forceinline__ float m2log2_series(float q, int terms)
-{
-    const float t = q - 1.0f, u = q + 1.0f;
-    const float s = t * nrcp(u), z = s * s;
-    const float K = kM2 * 2.8853900817779268f;                     // m2 * 2 / ln 2
-    float p;
-    if (terms == 4) { p = fma_(z, K / 7.0f, K / 5.0f); p = fma_(p, z, K / 3.0f); p = fma_(p, z, K); }
-    else if (terms == 3) { p = fma_(z, K / 5.0f, K / 3.0f); p = fma_(p, z, K); }
-    else { p = fma_(z, K / 9.0f, K / 7.0f); p = fma_(p, z, K / 5.0f); p = fma_(p, z, K / 3.0f); p = fma_(p, z, K); }
-    return s * p;
-}
-
 // x = (value * mult)^m1 candidates
 template <int XV> __device__ __forceinline__ float pq_x(float value, float mult, float log2_mult_m1)
 {
     if (XV == 0) return nexp2(fma_(kM1, nlog2(value), log2_mult_m1));                 // library today
     if (XV == 1) return nexp2(kM1 * nlog2(value * mult));                             // multiply first, like the reference
-    // XV == 2: split off the exponent so v_log_f32 sees [1, 2) (no -1 + log2(m) cancellation inside the unit)
     const float t = value * mult;
-    const int e = __builtin_amdgcn_frexp_expf(t);
-    const float m = __builtin_amdgcn_frexp_mantf(t) * 2.0f;                            // [1, 2)
-    const float l = nlog2(m);                                                         // [0, 1)
-    return nexp2(fma_(kM1, l, kM1 * (float)(e - 1)));
+    const float ef = (float)__builtin_amdgcn_frexp_expf(t);                           // t = m * 2^e, m in [0.5, 1)
+    const float m = __builtin_amdgcn_frexp_mantf(t);
+    const float l = nlog2(m);                                                         // [-1, 0)
+    const float A = kM1 * ef;                                                         // EXACT: 12-bit x 5-bit integers
+    if (XV == 2) return nexp2(fma_(kM1, l, A));
+    // XV == 3: integer part of the exponent applied by ldexp, so that the FMA rounds a number below 2 in magnitude
+    const float n = __builtin_floorf(A), f = A - n;                                   // both exact
+    return __builtin_amdgcn_ldexpf(nexp2(fma_(kM1, l, f)), (int)n);
 }
 
-// variant = XV * 10 + QV;  QV: 0 = library today (v_log, log2(max) folded), 1 = v_log, multiply by max at the end,
-// 2/3/4 = series with 3/4/5 terms, multiply at the end
-template <int XV, int QV> __device__ __forceinline__ float pq_scaled(float value, float mult, float log2_mult_m1, float maxv, float log2_max)
+template <int DV> __device__ __forceinline__ float pq_div(float n, float d)
+{
+    if (DV == 0) return near_div(n, d);                                               // library today
+    if (DV == 2) return n / d;                                                        // IEEE (v_div_scale / fmas / fixup)
+    float r = nrcp(d);
+    r = fma_(fma_(-d, r, 1.0f), r, r);                                                // one Newton step on the reciprocal first
+    const float q = n * r;
+    return fma_(fma_(-q, d, n), r, q);
+}
+
+// QV: 0 = library today (log2(max) folded into the last exponent), 1 = multiply by max at the end
+template <int XV, int QV, int DV> __device__ __forceinline__ float pq_scaled(float value, float mult, float log2_mult_m1, float maxv, float log2_max)
 {
     const float x = pq_x<XV>(value, mult, log2_mult_m1);
     const float n = kC1 + kC2 * x, d = 1.0f + kC3 * x;
-    const float q = near_div(n, d);
+    const float q = pq_div<DV>(n, d);
     if (QV == 0) return nexp2(fma_(kM2, nlog2(q), log2_max));
-    if (QV == 1) return nexp2(kM2 * nlog2(q)) * maxv;
-    return nexp2(m2log2_series(q, QV + 1)) * maxv;
+    return nexp2(kM2 * nlog2(q)) * maxv;
 }
 
-template <int XV, int QV> __global__ void run(const float* in, uint16_t* out, int n, float mult, float log2_mult_m1, float maxv, float log2_max)
+template <int XV, int QV, int DV> __global__ void run(const float* in, uint16_t* out, int n, float mult, float log2_mult_m1, float maxv, float log2_max)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float v = pq_scaled<XV, QV>(in[i], mult, log2_mult_m1, maxv, log2_max);
+    const float v = pq_scaled<XV, QV, DV>(in[i], mult, log2_mult_m1, maxv, log2_max);
     out[i] = (uint16_t)(uint32_t)__builtin_amdgcn_fmed3f(v, 0.0f, maxv);
+}
+
+// how often the two cheap quotients differ from the IEEE quotient on the (n, d) pairs the curve produces
+__global__ void div_probe(const float* in, int n, float mult, unsigned* bad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = pq_x<2>(in[i], mult, 0.0f);
+    const float nn = kC1 + kC2 * x, dd = 1.0f + kC3 * x;
+    const float q = nn / dd;
+    if (pq_div<0>(nn, dd) != q) atomicAdd(&bad[0], 1u);
+    if (pq_div<1>(nn, dd) != q) atomicAdd(&bad[1], 1u);
 }
 
 __global__ void log_probe(const float* in, float* out, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[i] = nlog2(in[i]); }
@@ -84,10 +94,10 @@ static float host_pq(float value, float peak)                      // ColorTrans
     return powf((kC1 + kC2 * x) / (1.0f + kC3 * x), kM2);
 }
 
-template <int XV, int QV> static void launch(const float* din, uint16_t* dout, int n, float peak, int bits)
+template <int XV, int QV, int DV> static void launch(const float* din, uint16_t* dout, int n, float peak, int bits)
 {
     const float mult = peak / 10000.0f, maxv = (float)((1 << bits) - 1);
-    run<XV, QV><<<(n + 255) / 256, 256>>>(din, dout, n, mult, kM1 * log2f(mult), maxv, log2f(maxv));
+    run<XV, QV, DV><<<(n + 255) / 256, 256>>>(din, dout, n, mult, kM1 * log2f(mult), maxv, log2f(maxv));
 }
 
 int main()
@@ -110,8 +120,8 @@ int main()
         std::vector<uint16_t> got(n), want(n);
         printf("== %s (%d samples): fraction of codes that differ from the glibc-powf reference\n", set ? "C4-like" : "t2 sweep", n);
         printf("%-8s %-6s", "bits", "peak");
-        const char* names[] = { "x0q0(lib)", "x0q1", "x0q2", "x0q3", "x0q4", "x1q1", "x1q3", "x2q1", "x2q3" };
-        for (const char* nm : names) printf(" %10s", nm);
+        const char* names[] = { "x0q0d0(lib)", "x0q1d0", "x2q0d0", "x2q1d0", "x2q1d1", "x2q1d2", "x3q1d0", "x3q1d1", "x3q1d2" };
+        for (const char* nm : names) printf(" %11s", nm);
         printf("\n");
         for (int bits : { 10, 12 }) for (float peak : { 80.0f, 1000.0f, 10000.0f }) {
             const float maxv = (float)((1 << bits) - 1);
@@ -119,22 +129,31 @@ int main()
             printf("%-8d %-6.0f", bits, peak);
             for (int k = 0; k < 9; ++k) {
                 switch (k) {
-                case 0: launch<0, 0>(din, dout, n, peak, bits); break;
-                case 1: launch<0, 1>(din, dout, n, peak, bits); break;
-                case 2: launch<0, 2>(din, dout, n, peak, bits); break;
-                case 3: launch<0, 3>(din, dout, n, peak, bits); break;
-                case 4: launch<0, 4>(din, dout, n, peak, bits); break;
-                case 5: launch<1, 1>(din, dout, n, peak, bits); break;
-                case 6: launch<1, 3>(din, dout, n, peak, bits); break;
-                case 7: launch<2, 1>(din, dout, n, peak, bits); break;
-                case 8: launch<2, 3>(din, dout, n, peak, bits); break;
+                case 0: launch<0, 0, 0>(din, dout, n, peak, bits); break;
+                case 1: launch<0, 1, 0>(din, dout, n, peak, bits); break;
+                case 2: launch<2, 0, 0>(din, dout, n, peak, bits); break;
+                case 3: launch<2, 1, 0>(din, dout, n, peak, bits); break;
+                case 4: launch<2, 1, 1>(din, dout, n, peak, bits); break;
+                case 5: launch<2, 1, 2>(din, dout, n, peak, bits); break;
+                case 6: launch<3, 1, 0>(din, dout, n, peak, bits); break;
+                case 7: launch<3, 1, 1>(din, dout, n, peak, bits); break;
+                case 8: launch<3, 1, 2>(din, dout, n, peak, bits); break;
                 }
                 CHECK(hipMemcpy(got.data(), dout, n * sizeof(uint16_t), hipMemcpyDeviceToHost));
                 int bad = 0, worst = 0;
                 for (int i = 0; i < n; ++i) { const int dlt = abs((int)got[i] - (int)want[i]); bad += dlt != 0; worst = std::max(worst, dlt); }
-                printf(" %8.4f%%%s", 100.0 * bad / n, worst > 1 ? "!" : " ");
+                printf(" %9.4f%%%s", 100.0 * bad / n, worst > 1 ? "!" : " ");
             }
             printf("\n");
+        }
+        {
+            unsigned* dbad; unsigned hbad[2] = { 0, 0 };
+            CHECK(hipMalloc(&dbad, sizeof hbad)); CHECK(hipMemset(dbad, 0, sizeof hbad));
+            div_probe<<<(n + 255) / 256, 256>>>(din, n, 80.0f / 10000.0f, dbad);
+            CHECK(hipMemcpy(hbad, dbad, sizeof hbad, hipMemcpyDeviceToHost));
+            printf("   quotient != IEEE n/d (peak 80): rcp + residual step %.4f%%, with a Newton step on the reciprocal first %.4f%%\n",
+                   100.0 * hbad[0] / n, 100.0 * hbad[1] / n);
+            CHECK(hipFree(dbad));
         }
         CHECK(hipFree(din)); CHECK(hipFree(dout));
     }
