@@ -34,6 +34,7 @@ TC_SRGB, TC_PQ, TC_SMPTE428, TC_HLG = 13, 16, 17, 18
 OUT_REFERENCE, OUT_YCBCR = 0, 1
 DOWNSAMPLE_AVERAGE, DOWNSAMPLE_NEAREST = 0, 1
 CHROMA_ZERO_LIBHEIF, CHROMA_ZERO_DECODER = 0, 1
+PQ_AUTO, PQ_COMPACT, PQ_CLOSE = 0, 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1
 
 noErr, userCanceledErr, readErr, writErr, memFullErr = 0, -128, -19, -20, -108
@@ -44,7 +45,7 @@ class WriteDesc(ctypes.Structure):
     _fields_ = [(n, c_int32) for n in (
         "width", "height", "depth", "planes", "bit_depth", "transfer", "peak_nits", "alpha_state",
         "output", "chroma", "matrix_coefficients", "color_primaries", "full_range", "chroma_downsampling",
-        "chroma_zero_point", "reserved")]
+        "chroma_zero_point", "pq_evaluation")]
 
     def __init__(self, **kw):
         super().__init__()

@@ -157,10 +157,10 @@ AG_DEV f32x2 fast_linear_to_pq_scaled2_hi(f32x2 value, float mult, float maxf)
     const f32x2 e2 = kPqM2 * f32x2{ nat_log2(q.x), nat_log2(q.y) };
     return f32x2{ nat_exp2(e2.x), nat_exp2(e2.y) } * maxf;
 }
-// Which evaluation the write kernels use: 0 = the compact one everywhere, 2 = the closer one everywhere, 1 = the closer one for
-// 12-bit output only (a code is 4x finer there: exact-match rate 99.74 % -> 99.93 % on the sweep of tests/test_gpu_t2_truth.py;
-// the 12-bit kernels -- RGBA above all, BASELINE C5 -- have the issue slots to spare, the 10-bit RGB kernel does not: 0.777 -> 0.70
-// of 8 TB/s with the exact-m1e form everywhere, profiles/r03/pq_hi_library_ab.txt), decided per launch.
+// Build-time override of the per-launch choice (WriteParams::pq_close): 0 = the compact form everywhere, 2 = the close form
+// everywhere, 1 = as the descriptor says.  (AUTO picks the close form for 12-bit output: a code is 4x finer there -- exact-match rate
+// 99.74 % -> 99.93 % on the sweep of tests/test_gpu_t2_truth.py -- and the 12-bit kernels, RGBA above all, have issue slots to spare
+// on most boxes; the 10-bit RGB kernel does not: 0.777 -> 0.70 of 8 TB/s, profiles/r03/pq_hi_library_ab.txt.)
 #ifndef AG_PQ_HI
 #define AG_PQ_HI 1
 #endif

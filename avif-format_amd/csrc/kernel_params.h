@@ -32,6 +32,7 @@ struct WriteParams {
     float   pq_mult;             // peak_nits / 10000 (ColorTransfer.cpp:86)
     float   pq_log2_mult_m1;     // m1 * log2(pq_mult): the multiply by pq_mult folded into the first exponent
     float   log2_maxf;           // log2(maxf): the multiply by maxValue folded into the second exponent
+    int32_t pq_close;            // evaluate LinearToPQ in its "close" form (avifgpu_write_desc::pq_evaluation, resolved per launch)
     float   my[3], mcb[3], mcr[3];
     float   half;                // 1 << (bits-1)
     // ICC row transform in front of stage A (include/avifgpu.h); used only by the ICC instantiations

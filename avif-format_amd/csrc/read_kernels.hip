@@ -77,9 +77,8 @@ AG_DEV float table_a(const ReadParams& p, int i) { return unorm_to_float(p, i); 
 
 // LUT = true : tables live in LDS (bits <= 12), a lookup is one ds_read_b32 -- no branch in the pixel loop.
 // LUT = false: the table formula is evaluated per sample: 16-bit samples (3 x 65536 floats would not fit LDS) and, since round 3,
-//              FULL-RANGE images of every depth up to AG_READ_ARITH_BITS: an entry is then unorm_to_float(code) -- three FMAs -- and
-//              a workgroup that has no table to copy has no barrier and no dead time in front of its first plane load.  (A table
-//              workgroup spends ~1.5 us on the copy + barrier out of the ~10 us it lives: the "launch-size" gap of the u8 rows.)
+//              the FULL-RANGE configurations of read_arith_policy(): an entry is then unorm_to_float(code) -- three FMAs -- and the
+//              workgroup has no table to copy and no barrier in front of its first plane load.
 template <bool LUT> struct Tables {
     const float* ty; const float* tuv; const float* ta;
     const float* te;      // planar RGB -> f32: EOTF(T_A[i]) per code
@@ -409,10 +408,24 @@ __global__ __launch_bounds__(256) void build_read_tables(const ReadParams p, flo
 #ifndef AG_READ_PREFETCH
 #define AG_READ_PREFETCH 0
 #endif
-// deepest full-range image that is decoded without tables (0 = never): see launch_read_one
-#ifndef AG_READ_ARITH_BITS
-#define AG_READ_ARITH_BITS 8
+// Which full-range configurations are decoded WITHOUT tables (an entry is unorm_to_float(code), three FMAs): measured per row
+// (profiles/r03/read_table_free_ab.txt, two interleaved passes on one box).  It pays where the lookups were a large share of a small
+// kernel or the table was large: 10/12-bit -> 16-bit hosts, gray (12-bit 0.651 -> 0.805 of 8 TB/s) and 4:4:4 (+6 % at 12 bit), and
+// 8-bit 4:2:0 with alpha (+4 %).  It loses where registers are tight: the 8-bit colour kernels without alpha (-5...-8 %: 94 -> 104
+// VGPRs on the 4:2:0 footprint) and every f32 host (-4...-9 %), which keep their LDS tables.  AG_READ_ARITH: 0 never, 1 this policy,
+// 2 every full-range configuration up to 12 bit (the A/B).
+#ifndef AG_READ_ARITH
+#define AG_READ_ARITH 1
 #endif
+template <int CS, int DEPTH, bool ALPHA, int XS> constexpr bool read_arith_policy()
+{
+    if (AG_READ_ARITH == 0) return false;
+    if (CS == kCsRgb && DEPTH == 32) return false;          // EOTF per code lives in its table
+    if (AG_READ_ARITH == 2) return true;
+    if (DEPTH == 16) return CS == kCsMono || (CS == kCsYcc && XS == 0 && !ALPHA);
+    if (DEPTH == 8) return CS == kCsYcc && ALPHA && XS == 1;
+    return false;
+}
 #ifndef AG_R8_NC
 #define AG_R8_NC 8
 #endif
@@ -764,18 +777,19 @@ static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, char* lab
     snprintf(label, kLabelBytes, "read_px<cs=%d,depth=%d,alpha=%d,xs=%d,ys=%d,transfer=%d,aligned=%d>", CS, DEPTH, (int)ALPHA, XS, YS,
              TRANSFER, (int)aligned);
     ReadParams q = p;
-    if (lut_bytes && !(p.full_range && p.bits <= AG_READ_ARITH_BITS && !(CS == kCsRgb && DEPTH == 32))) {
+    const bool arith = p.full_range && p.bits <= 12 && read_arith_policy<CS, DEPTH, ALPHA, XS>();
+    if (lut_bytes && !arith) {
         const hipError_t e = cached_tables<CS, DEPTH, ALPHA, TRANSFER>(p, st, &q.tables);
         if (e != hipSuccess) return e;
     }
 #define AG_READ_LAUNCH(LUT_, AL_) hipLaunchKernelGGL((read_px<CS, DEPTH, ALPHA, XS, YS, TRANSFER, LUT_, AL_>), dim3((int)blocks), dim3(AG_RPX_BLOCK), LUT_ ? lds : lds - lut_bytes, st, q)
-    // table-free decode: full range (an entry is one exact division) up to AG_READ_ARITH_BITS; planar RGB -> f32 keeps its table
-    // (EOTF per code instead of per sample), limited range keeps its tables (an integer division per entry)
-    const bool arith = p.full_range && p.bits <= AG_READ_ARITH_BITS && !(CS == kCsRgb && DEPTH == 32);
+    // table-free decode (read_arith_policy): full range only -- limited range keeps its tables (an integer division per entry)
     if (arith) snprintf(label + strlen(label), kLabelBytes - strlen(label), " tables=none");
     if constexpr (DEPTH == 8) {
-        if (arith) { if (aligned) AG_READ_LAUNCH(false, true); else AG_READ_LAUNCH(false, false); }
-        else { if (aligned) AG_READ_LAUNCH(true, true); else AG_READ_LAUNCH(true, false); }
+        if constexpr (read_arith_policy<CS, DEPTH, ALPHA, XS>()) {            // (instantiated only where the policy can choose it)
+            if (arith) { if (aligned) AG_READ_LAUNCH(false, true); else AG_READ_LAUNCH(false, false); return hipGetLastError(); }
+        }
+        if (aligned) AG_READ_LAUNCH(true, true); else AG_READ_LAUNCH(true, false);
     } else {
         if (p.bits <= 12 && !arith) { if (aligned) AG_READ_LAUNCH(true, true); else AG_READ_LAUNCH(true, false); }
         else { if (aligned) AG_READ_LAUNCH(false, true); else AG_READ_LAUNCH(false, false); }

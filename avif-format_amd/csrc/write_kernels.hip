@@ -44,9 +44,10 @@ template <int ICC> struct IccF32 { static constexpr bool value = (ICC == 2 && AG
 // (reference WriteHeifImage.cpp:1072-1095).
 // kTransferPqHi: the PQ evaluation that reproduces more of the reference's bits (device_math.h, fast_linear_to_pq_scaled_hi) as a
 // kernel-side transfer id of its own, so that the two forms never share a register allocation.  The launchers pick it once per launch
-// from the output depth (AG_PQ_HI): 10-bit saves -- the headline configuration -- keep the compact form.
+// from WriteParams::pq_close (avifgpu_write_desc::pq_evaluation; AUTO: 12-bit output only -- 10-bit saves, the headline configuration,
+// keep the compact form).  AG_PQ_HI = 0 / 2 forces one form at build time for A/B.
 constexpr int kTransferPqHi = 4;
-static inline bool pq_hi_launch(const WriteParams& p) { return AG_PQ_HI == 2 || (AG_PQ_HI == 1 && p.maxv > 1023); }
+static inline bool pq_hi_launch(const WriteParams& p) { return AG_PQ_HI == 2 || (AG_PQ_HI == 1 && p.pq_close); }
 template <int TRANSFER>
 AG_DEV uint32_t oetf_code(const WriteParams& p, float f)
 {
@@ -241,6 +242,20 @@ AG_DEV float icc_trc_simple(const IccSimple& q, float R)
     const float hi = nat_exp2(q.g * nat_log2(__builtin_fmaf(q.a, R, q.b))) + q.add;
     const float lo = __builtin_fmaf(q.c, R, q.f);
     return R >= q.thr ? hi : lo;
+}
+// two samples: the four packable operations as v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (same bits, element for element)
+AG_DEV f32x2 icc_trc_simple2(const IccSimple& q, f32x2 R)
+{
+    const f32x2 lin = __builtin_elementwise_fma((f32x2)q.a, R, (f32x2)q.b);
+    const f32x2 e = q.g * f32x2{ nat_log2(lin.x), nat_log2(lin.y) };
+    const f32x2 hi = f32x2{ nat_exp2(e.x), nat_exp2(e.y) } + q.add;
+    const f32x2 lo = __builtin_elementwise_fma((f32x2)q.c, R, (f32x2)q.f);
+    return f32x2{ R.x >= q.thr ? hi.x : lo.x, R.y >= q.thr ? hi.y : lo.y };
+}
+AG_DEV void icc_trc_simple4(const IccSimple& q, f32x4_t& v)
+{
+    const f32x2 a = icc_trc_simple2(q, f32x2{ v.x, v.y }), b = icc_trc_simple2(q, f32x2{ v.z, v.w });
+    v.x = a.x; v.y = a.y; v.z = b.x; v.w = b.y;
 }
 #ifndef AG_ICC2_HOT
 #define AG_ICC2_HOT 1
@@ -550,7 +565,10 @@ enum { kOutRefColor = 0, kOutRefGray = 1, kOutYcbcr = 2 };
 // 2 chroma samples per lane keep a 4:2:0 footprint at 8 pixels (16: 197 VGPRs, 2 waves/SIMD, 6.9 k instructions; measured
 // 0.412 -> 0.370 ms).  4:4:4 keeps 4 pixels per lane (2 measured slower: 0.487 -> 0.507 ms, narrower loads and stores).
 template <bool DST16, int PLANES, int XS, int ICC = 0> struct WriteShape {
-    static constexpr int NC = ((ICC == 2 || ICC == 4) && XS == 1) ? 2 : (DST16 ? 4 : ((PLANES == 2 || PLANES == 4) ? AG_W8_NC_ALPHA : AG_W8_NC));
+    // ICC == 5 (the 16-bit table transform) saved to u8 planes: 4 chroma samples per lane like the u16 layouts.  With 8, a 4:2:0 footprint
+    // is 32 pixels x two 16-byte gathers each, all hoisted: 315 VGPRs = ONE wave per SIMD (profiles/r02/isa/resources.tsv); with 4 it is
+    // 16 pixels and the kernel fits 3-4 waves.
+    static constexpr int NC = ((ICC == 2 || ICC == 4) && XS == 1) ? 2 : ((DST16 || ICC == 5) ? 4 : ((PLANES == 2 || PLANES == 4) ? AG_W8_NC_ALPHA : AG_W8_NC));
     static constexpr int PXT = NC << XS;
 };
 
@@ -1119,10 +1137,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444_hot
         if constexpr (ICCV == 2) {                                                 // the document's curve: per sample, the same for R, G, B
             const IccSimple q = icc_simple_load(p);
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                cur[k].x = icc_trc_simple(q, cur[k].x); cur[k].y = icc_trc_simple(q, cur[k].y);
-                cur[k].z = icc_trc_simple(q, cur[k].z); cur[k].w = icc_trc_simple(q, cur[k].w);
-            }
+            for (int k = 0; k < K; ++k) icc_trc_simple4(q, cur[k]);
         }
 #pragma unroll
         for (int k = 0; k < K; ++k) my[64 * k + lane] = cur[k];
@@ -1242,10 +1257,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot(con
                 if constexpr (ICCV == 2) {                                         // the document's curve: per sample, the same for R, G, B
                     const IccSimple q = icc_simple_load(p);
 #pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        v[vr][k].x = icc_trc_simple(q, v[vr][k].x); v[vr][k].y = icc_trc_simple(q, v[vr][k].y);
-                        v[vr][k].z = icc_trc_simple(q, v[vr][k].z); v[vr][k].w = icc_trc_simple(q, v[vr][k].w);
-                    }
+                    for (int k = 0; k < K; ++k) icc_trc_simple4(q, v[vr][k]);
                 }
 #pragma unroll
                 for (int k = 0; k < K; ++k) reinterpret_cast<f32x4*>(my)[64 * k + lane] = v[vr][k];
@@ -1391,8 +1403,8 @@ __global__ __launch_bounds__(AG_RGBA_STREAM_BLOCK) void write_rgba32_ycbcra444_h
                 float col[3] = { v[k + h].x, v[k + h].y, v[k + h].z };
                 if constexpr (ICCV == 2) {                                          // the document's curve on R, G, B (alpha is copied)
                     const IccSimple q = icc_simple_load(p);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) col[c] = icc_trc_simple(q, col[c]);
+                    const f32x2 rg = icc_trc_simple2(q, f32x2{ col[0], col[1] });
+                    col[0] = rg.x; col[1] = rg.y; col[2] = icc_trc_simple(q, col[2]);
                 }
                 if constexpr (ICCV != 0) {                                          // a pixel is one float4 here: no transpose needed in front
                     const float R0 = col[0], G0 = col[1], B0 = col[2];
@@ -1907,6 +1919,8 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, char* label)
     }
     if constexpr (DEPTH == 16 && PLANES >= 3) {
         if (p.icc16_clut != nullptr) {              // 16-bit CLUT ICC transform requested
+            constexpr int PXT5 = WriteShape<DST16, PLANES, XS, 5>::PXT;
+            groups = (long long)((p.width + PXT5 - 1) / PXT5) * ((p.nrows + (1 << YS) - 1) >> YS);
             snprintf(label, kLabelBytes, "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=5>",
                      DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned);
             if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 5>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);

@@ -153,6 +153,19 @@ enum {
     AVIFGPU_CHROMA_ZERO_DECODER = 1
 };
 
+/* How LinearToPQ (ColorTransfer.cpp:69-92) is evaluated -- tier 2 either way (|delta code| <= 1 against the reference's powf): what
+ * differs is the share of codes that are EXACTLY the reference's, and the cost (1 M-sample sweep at 80 nits):
+ *   COMPACT  5 transcendentals + 12 full-rate operations per sample:   99.93 % exact at 10 bit, 99.74 % at 12 bit
+ *   CLOSE    + 8 issue slots (exact m1 * exponent, split 2^n * 2^f):   99.97 % exact at 10 bit, 99.93 % at 12 bit
+ * AUTO = COMPACT for 10-bit output (the HBM-bound RGB kernel has no issue slots to spare: 0.78 -> 0.70 of 8 TB/s with CLOSE) and
+ * CLOSE for 12-bit output (a code is 4x finer there; the RGBA kernel of BASELINE C5 goes 0.83 -> 0.75 on the fastest box seen, nothing
+ * on the others).  A caller that wants the throughput at 12 bit or the exact-match rate at 10 bit says so here. */
+enum {
+    AVIFGPU_PQ_AUTO    = 0,
+    AVIFGPU_PQ_COMPACT = 1,
+    AVIFGPU_PQ_CLOSE   = 2
+};
+
 enum {
     AVIFGPU_MEM_HOST   = 0,
     AVIFGPU_MEM_DEVICE = 1
@@ -182,7 +195,7 @@ typedef struct avifgpu_write_desc {
     int32_t full_range;          /* reference always writes 1 (WriteMetadata.cpp:46); 0 is rejected */
     int32_t chroma_downsampling; /* AVIFGPU_DOWNSAMPLE_* */
     int32_t chroma_zero_point;   /* AVIFGPU_CHROMA_ZERO_* */
-    int32_t reserved;
+    int32_t pq_evaluation;       /* AVIFGPU_PQ_* (transfer PQ only); 0 = the default */
 } avifgpu_write_desc;
 
 /*

@@ -9,8 +9,9 @@ they are, including its float-rounded exponents 1/m1, 1/m2 and multipliers) eval
    SMPTE 428) and, code by code, is no larger than the oracle's own error plus that epsilon -- the 1e-4 bar of
    tests/test_gpu_read.py exists because the REFERENCE formula's float32 evaluation (c2 - c3*x cancels) is up to ~5e-5 off
    the truth, not because the kernel is;
- * write direction (OETF -> integer code, truncating): the exact-match rate is asserted per bit depth at the measured level
-   (>= 99.9 % at 10 bit, >= 99.6 % at 12 bit: the same relative error meets four times as many code boundaries), and every
+ * write direction (OETF -> integer code, truncating): the exact-match rate is asserted at the measured level (>= 99.9 % at 10 and
+   at 12 bit with the default evaluation; the compact form, which 12-bit output no longer takes by default, keeps its >= 99.6 % there:
+   the same relative error meets four times as many code boundaries), and every
    mismatching sample is shown to sit within 2e-5 relative of a code boundary of the exact function.  2e-5 is the float32
    evaluation noise of the reference formula itself: q = (c1 + c2 x) / (1 + c3 x) carries 2-3 roundings of 6e-8 and q^78.84
    multiplies them by 78.84 (measured: up to 1.3e-5).  A mismatch is therefore a truncation artefact of two evaluations that
@@ -82,21 +83,24 @@ def test_eotf_error_against_float64_truth(gpu, bits, curve):
     assert np.all(e_gpu <= e_orc + eps_rel * np.abs(truth) + 1e-12)                               # never worse than the oracle + eps
 
 
-@pytest.mark.parametrize("bits,peak,min_exact", [(10, 80, 0.999), (10, 1000, 0.999), (10, 10000, 0.999),
-                                                 (12, 80, 0.996), (12, 1000, 0.996)])
-def test_pq_write_mismatches_are_code_boundary_cases(gpu, bits, peak, min_exact):
+# Round 3: 12-bit output takes the "close" evaluation by default (avifgpu_write_desc.pq_evaluation = AUTO): >= 99.9 % exact, the bar
+# SURVEY 8(a) proposed, at every depth.  COMPACT / CLOSE can be asked for explicitly; their own measured levels are asserted too.
+@pytest.mark.parametrize("bits,peak,mode,min_exact", [(10, 80, 0, 0.999), (10, 1000, 0, 0.999), (10, 10000, 0, 0.999),
+                                                      (12, 80, 0, 0.999), (12, 1000, 0, 0.999),
+                                                      (12, 80, 1, 0.996), (10, 80, 2, 0.9995), (12, 10000, 2, 0.999)])
+def test_pq_write_mismatches_are_code_boundary_cases(gpu, bits, peak, mode, min_exact):
     x = np.concatenate([np.linspace(0, 1, 400_000, dtype=np.float32),
                         np.geomspace(1e-9, 12.5, 400_000).astype(np.float32),
                         np.linspace(1, 130, 100_000, dtype=np.float32)])
     n = (x.size // 3) * 3
     src = x[:n].reshape(1, n)
     d = pkg.WriteDesc(width=n // 3, height=1, depth=32, planes=3, bit_depth=bits, transfer=pkg.TRANSFER_PQ, peak_nits=peak,
-                      alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_REFERENCE)
+                      alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_REFERENCE, pq_evaluation=mode)
     want = harness.oracle_write(d, src)[0].reshape(-1).astype(np.int64)
     got = harness.gpu_write(gpu, d, src)[0].reshape(-1).astype(np.int64)
     maxv = (1 << bits) - 1
     exact = float(np.mean(want == got))
-    print(f"PQ OETF {bits}-bit peak {peak}: exact {exact:.6f}, max |dcode| {int(np.max(np.abs(want - got)))}")
+    print(f"PQ OETF {bits}-bit peak {peak} pq_evaluation {('auto', 'compact', 'close')[mode]}: exact {exact:.6f}, max |dcode| {int(np.max(np.abs(want - got)))}")
     assert np.max(np.abs(want - got)) <= 1
     assert exact >= min_exact, exact
     bad = np.nonzero(want != got)[0]

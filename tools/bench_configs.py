@@ -183,6 +183,7 @@ if __name__ == "__main__":
         n = L.oracle_icc_make_profile(3, 0, 2.19921875, buf, len(buf))
         bench_write("16-bit doc + ICC (AdobeRGB -> sRGB, 33^3 table) 8192^2 RGB16 -> 12-bit 4:4:4", icc=gpu.icc_prepare_clut16(buf.raw[:n]), width=8192, height=8192, depth=16, planes=3, bit_depth=12, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=6, color_primaries=1)
         bench_write("16-bit doc + ICC, photograph-like input (smooth + noise) 8192^2 RGB16 -> 12-bit 4:4:4", icc=gpu.icc_prepare_clut16(buf.raw[:n]), smooth=True, width=8192, height=8192, depth=16, planes=3, bit_depth=12, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=6, color_primaries=1)
+        bench_write("16-bit doc + ICC, photograph-like input, saved as 8-bit 8192^2 RGB16 -> 8-bit 4:2:0", icc=gpu.icc_prepare_clut16(buf.raw[:n]), smooth=True, width=8192, height=8192, depth=16, planes=3, bit_depth=8, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=6, color_primaries=1)
         bench_write("8-bit doc + ICC (AdobeRGB -> sRGB, matrix-shaper) 8192^2 RGB8 -> 8-bit 4:2:0", icc=gpu.icc_prepare_shaper8(buf.raw[:n]), width=8192, height=8192, depth=8, planes=3, bit_depth=8, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=6, color_primaries=1)
         bench_write("8-bit doc + ICC, photograph-like input (smooth + noise) 8192^2 RGB8 -> 8-bit 4:2:0", icc=gpu.icc_prepare_shaper8(buf.raw[:n]), smooth=True, width=8192, height=8192, depth=8, planes=3, bit_depth=8, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=6, color_primaries=1)
     bench_read("R8 8192^2 8-bit 4:2:0 BT.709 -> RGB8", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_420, bit_depth=8, depth=8, alpha_state=0, matrix_coefficients=1)
