@@ -18,7 +18,10 @@ converts rows [k*H/N, (k+1)*H/N) -- BASELINE.json configs[3] ("row-tiled across 
 image.  --scaling weak: every rank converts one full frame per step (a batch of N frames).
 
 Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per launch (18 B/px: 12 in + 6 out,
-SURVEY.md 8d) / mean kernel time from HIP events recorded on the launch stream.  Extra objects on the same line:
+SURVEY.md 8d) / mean kernel time from HIP events recorded on the launch stream; `roofline.peak` = the 8 TB/s spec,
+`roofline.peak_measured` = what the kernel's MATH-FREE twin (same loads and stores, no conversion) reaches on the same buffers in
+the same process, `frac_of_measured` = achieved / that; `read_only_frac` is the north-star's literal "HBM-read" figure (input bytes
+only), bounded by 12/18 for 4:4:4 output -- `frac` is the one that is claimed.  Extra objects on the same line:
   c5              BASELINE.json configs[4] (16384 x 16384 RGBA f32 -> 12-bit PQ Y,Cb,Cr,A), the same N-way row split, device-resident
   pcie_inclusive  rank 0 alone, ONE process, the library's in-process row-tile scheduler on the N GPUs of the run
                   (avifgpu_init_devices): page-locked host rows in, host planes out -- what N x16 links buy this path

@@ -1,13 +1,17 @@
 #!/usr/bin/env python3
-"""Regenerate the measured tables of DESIGN.md (between the BEGIN/END markers) from profiles/r02/bench_configs.jsonl and
-profiles/r02/configs_traffic.json, so the document cannot drift from the committed measurements."""
+"""Regenerate the measured tables of DESIGN.md (between the BEGIN/END markers) from profiles/<round>/bench_configs.jsonl and
+profiles/<round>/configs_traffic.json, so the document cannot drift from the committed measurements.
+    python tools/make_design_tables.py [round directory, default r03]"""
 import json
 import os
 import re
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rows = [json.loads(l) for l in open(os.path.join(ROOT, "profiles/r02/bench_configs.jsonl")) if l.startswith("{")]
-traffic = {e["config"]: e for e in json.load(open(os.path.join(ROOT, "profiles/r02/configs_traffic.json")))}
+RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+rows = [json.loads(l) for l in open(os.path.join(ROOT, "profiles", RND, "bench_configs.jsonl")) if l.startswith("{")]
+tpath = os.path.join(ROOT, "profiles", RND, "configs_traffic.json")
+traffic = {e["config"]: e for e in json.load(open(tpath))} if os.path.exists(tpath) else {}
 
 
 def table(pred):
@@ -19,7 +23,8 @@ def table(pred):
         m = re.match(r"(\w+)<(.*)>", k)
         short = m.group(1) + " " + re.sub(r"(depth|planes|out|dst16|transfer|aligned|pxl|nt|prefetch|xcdmap|cs|alpha)=", lambda x: x.group(1)[0] + "", m.group(2)) if m else k
         t = traffic.get(r["config"], {}).get("traffic_over_algorithmic")
-        out.append("| %s | `%s` | %g | %.4f | %.0f | %.2f | %s |" % (r["config"], k.split("<")[0] + ("" if "icc=" not in k else " icc=" + k.split("icc=")[1].rstrip(">")),
+        tag = ("" if "icc=" not in k else " icc=" + k.split("icc=")[1].rstrip(">").split()[0]) + (" tables=none" if "tables=none" in k else "")
+        out.append("| %s | `%s` | %g | %.4f | %.0f | %.2f | %s |" % (r["config"], k.split("<")[0] + tag,
                                                                     r["bytes_per_px"], r["ms_mean"], r["GB_s"], r["frac_of_8TBs"], ("%.4f" % t) if t else "—"))
     return "\n".join(out)
 
