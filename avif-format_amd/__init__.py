@@ -95,6 +95,10 @@ ICC_TARGET_SRGB_FLOAT = 2
 ICC_IS_REC2020, ICC_IS_SRGB = 1, 2
 
 
+class IccSampled32(ctypes.Structure):
+    _fields_ = [("base", IccTransform), ("curve", (c_float * 65536) * 3)]
+
+
 class IccClut16(ctypes.Structure):
     _fields_ = [("grid_points", c_int32), ("reserved", c_int32 * 3), ("table", (ctypes.c_uint16 * 4) * (33 * 33 * 33))]
 
@@ -129,6 +133,9 @@ ABI = [
     ("avifgpu_icc_prepare", c_int32, [c_void_p, ctypes.c_uint32, c_int32, POINTER(IccTransform)]),
     ("avifgpu_write_rows_icc", c_int32, [POINTER(WriteDesc), POINTER(IccTransform), c_int32, c_int32, c_void_p, c_int64,
                                          POINTER(_PLANES4), POINTER(_STRIDES4), c_int32, c_void_p]),
+    ("avifgpu_icc_prepare_sampled", c_int32, [c_void_p, ctypes.c_uint32, c_int32, POINTER(IccSampled32)]),
+    ("avifgpu_write_rows_icc_sampled", c_int32, [POINTER(WriteDesc), POINTER(IccSampled32), c_int32, c_int32, c_void_p, c_int64,
+                                                 POINTER(_PLANES4), POINTER(_STRIDES4), c_int32, c_void_p]),
     ("avifgpu_icc_detect", c_int32, [c_void_p, ctypes.c_uint32]),
     ("avifgpu_icc_prepare_clut16", c_int32, [c_void_p, ctypes.c_uint32, POINTER(IccClut16)]),
     ("avifgpu_write_rows_icc16", c_int32, [POINTER(WriteDesc), POINTER(IccClut16), c_int32, c_int32, c_void_p, c_int64,
@@ -226,6 +233,11 @@ class AvifGpu:
                                                           ctypes.byref(planes4(dst_ptrs)), ctypes.byref(strides4(dst_strides)),
                                                           mem, stream or None))
             return
+        if isinstance(icc, IccSampled32):
+            self._check(self.lib.avifgpu_write_rows_icc_sampled(ctypes.byref(desc), ctypes.byref(icc), row0, nrows, src_ptr, src_row_bytes,
+                                                                ctypes.byref(planes4(dst_ptrs)), ctypes.byref(strides4(dst_strides)),
+                                                                mem, stream or None))
+            return
         if isinstance(icc, IccShaper8):
             self._check(self.lib.avifgpu_write_rows_icc8(ctypes.byref(desc), ctypes.byref(icc), row0, nrows, src_ptr, src_row_bytes,
                                                          ctypes.byref(planes4(dst_ptrs)), ctypes.byref(strides4(dst_strides)),
@@ -248,6 +260,11 @@ class AvifGpu:
     def icc_prepare_shaper8(self, profile_bytes: bytes) -> "IccShaper8":
         t = IccShaper8()
         self._check(self.lib.avifgpu_icc_prepare_shaper8(profile_bytes, len(profile_bytes), ctypes.byref(t)))
+        return t
+
+    def icc_prepare_sampled(self, profile_bytes: bytes, target=ICC_TARGET_REC2020_LINEAR) -> "IccSampled32":
+        t = IccSampled32()
+        self._check(self.lib.avifgpu_icc_prepare_sampled(profile_bytes, len(profile_bytes), target, ctypes.byref(t)))
         return t
 
     def icc_prepare(self, profile_bytes: bytes, target=ICC_TARGET_REC2020_LINEAR) -> "IccTransform":

@@ -164,6 +164,7 @@ struct IccDeviceTables {
     void* icc8 = nullptr;  std::vector<uint8_t> icc8_host;     // [3][256] int32 followed by 16388 bytes of shaper2
     void* icc16 = nullptr; std::vector<uint8_t> icc16_host;    // 33^3 x 4 u16
     void* pow_tab = nullptr;                                    // 128 x float4, constant
+    void* s32 = nullptr;   std::vector<uint8_t> s32_host;      // 3 x 65536 floats: sampled curves of a 32-bit document
 };
 static std::mutex g_icc_mu;
 static std::map<int, IccDeviceTables> g_icc_tables;            // keyed by HIP device ordinal
@@ -245,6 +246,28 @@ int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p)
     return 0;
 }
 
+int upload_icc_sampled(const avifgpu_icc_sampled32* t, WriteParams& p)
+{
+    const size_t n = sizeof(t->curve);
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDevice", AVIFGPU_writErr);
+    std::lock_guard<std::mutex> lk(g_icc_mu);
+    IccDeviceTables& c = g_icc_tables[dev];
+    if (!c.s32) {
+        e = hipMalloc(&c.s32, n);
+        if (e != hipSuccess) { c.s32 = nullptr; return hip_fail(e, "hipMalloc(sampled ICC curves)", AVIFGPU_memFullErr); }
+    }
+    if (c.s32_host.size() != n || memcmp(c.s32_host.data(), t->curve, n) != 0) {
+        e = hipDeviceSynchronize();                             // a launch may still be reading the previous curves
+        if (e == hipSuccess) e = hipMemcpy(c.s32, t->curve, n, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return hip_fail(e, "upload of the sampled ICC curves", AVIFGPU_writErr);
+        c.s32_host.assign(reinterpret_cast<const uint8_t*>(t->curve), reinterpret_cast<const uint8_t*>(t->curve) + n);
+    }
+    p.icc_s_tab = static_cast<const float*>(c.s32);
+    return 0;
+}
+
 int upload_icc8(const avifgpu_icc_shaper8* t, WriteParams& p)
 {
     if (memcmp(t->shaper2[0], t->shaper2[1], 16385) != 0 || memcmp(t->shaper2[0], t->shaper2[2], 16385) != 0)
@@ -296,6 +319,7 @@ void release_device_caches()
         if (kv.second.icc8) (void)hipFree(kv.second.icc8);
         if (kv.second.icc16) (void)hipFree(kv.second.icc16);
         if (kv.second.pow_tab) (void)hipFree(kv.second.pow_tab);
+        if (kv.second.s32) (void)hipFree(kv.second.s32);
     }
     g_icc_tables.clear();
     if (cur >= 0) (void)hipSetDevice(cur);
@@ -333,12 +357,18 @@ static void normalise_trc(int type, const double* P, double* Q)
 int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const WriteGeom& g, const IccArgs& icc, WriteParams& p)
 {
     memset(&p, 0, sizeof(p));
-    const avifgpu_icc_transform* g_icc = icc.f32;
+    const avifgpu_icc_transform* g_icc = icc.s32 ? &icc.s32->base : icc.f32;
     const avifgpu_icc_clut16* g_icc16 = icc.c16;
     const avifgpu_icc_shaper8* g_icc8 = icc.s8;
     if (g_icc) {
         if (d->depth != 32 || d->planes < 3) return fail(AVIFGPU_formatBadParameters, "the ICC row transform applies to 32-bit RGB(A) documents");
-        for (int c = 0; c < 3; ++c) {
+        if (icc.s32) {
+            // sampled curves: the curve stage is the device table; the matrix / output curve below are shared with the parametric form
+            const int rc = upload_icc_sampled(icc.s32, p);
+            if (rc) return rc;
+        }
+        for (int c = 0; c < 3 && icc.s32; ++c) p.icc_trc_type[c] = 6;           // marks "sampled" for the launchers
+        for (int c = 0; c < 3 && !icc.s32; ++c) {
             if (g_icc->trc_type[c] < 1 || g_icc->trc_type[c] > 5) return fail(AVIFGPU_formatBadParameters, "bad ICC curve type");
             p.icc_trc_type[c] = g_icc->trc_type[c];
             p.icc_trc_linear[c] = g_icc->trc_type[c] == 1 && g_icc->trc_params[c][0] == 1.0;
@@ -358,7 +388,7 @@ int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const Wr
                 for (int k = 0; k < 8; ++k) same = same && p.icc_trc[c][k] == p.icc_trc[0][k];
             const double* Q = p.icc_trc[0];                    // g, a, b, thr, c, f, add, nonpos
             const bool linear = p.icc_trc_linear[0] && p.icc_trc_linear[1] && p.icc_trc_linear[2];
-            p.icc_same_simple = same && !linear && Q[0] > 0.0 && Q[1] > 0.0 && std::isfinite(Q[3]) && Q[1] * Q[3] + Q[2] >= 0.0 && Q[7] == Q[6];
+            p.icc_same_simple = !icc.s32 && same && !linear && Q[0] > 0.0 && Q[1] > 0.0 && std::isfinite(Q[3]) && Q[1] * Q[3] + Q[2] >= 0.0 && Q[7] == Q[6];
         }
         for (int k = 0; k < 9; ++k) { p.icc_m[k] = g_icc->matrix[k]; p.icc_m_f[k] = (float)g_icc->matrix[k]; }
         { const int rc = upload_icc_pow_table(p); if (rc) return rc; }
@@ -724,6 +754,14 @@ int32_t avifgpu_write_rows_icc(const avifgpu_write_desc* d, const avifgpu_icc_tr
                                int32_t mem_kind, void* stream)
 {
     IccArgs a; a.f32 = icc;
+    return write_rows_any(d, a, row0, nrows, src, src_row_bytes, dst, dst_stride, mem_kind, stream);
+}
+
+int32_t avifgpu_write_rows_icc_sampled(const avifgpu_write_desc* d, const avifgpu_icc_sampled32* icc, int32_t row0, int32_t nrows,
+                                       const void* src, int64_t src_row_bytes, void* const dst[4], const int64_t dst_stride[4],
+                                       int32_t mem_kind, void* stream)
+{
+    IccArgs a; a.s32 = icc;
     return write_rows_any(d, a, row0, nrows, src, src_row_bytes, dst, dst_stride, mem_kind, stream);
 }
 

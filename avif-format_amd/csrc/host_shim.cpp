@@ -176,13 +176,19 @@ void CreateHeifImageInto(FormatRecordPtr formatRecord, AlphaState alphaState, co
     // ICC row transform (replaces converter.ConvertRow, WriteHeifImage.cpp:1012,1031-1034) for the HDR case
     avifgpu_icc_transform icc;
     const avifgpu_icc_transform* iccp = nullptr;
+    std::unique_ptr<avifgpu_icc_sampled32> iccs;                // 32-bit document with sampled curves (768 KiB: on the heap)
     if (saveOptions.convertToRec2020) {
         if (formatRecord->depth != 32 || mono || !formatRecord->iCCprofileData || formatRecord->iCCprofileSize <= 0)
             throw OSErrException(AVIFGPU_formatBadParameters);
-        const int rc = avifgpu_icc_prepare(formatRecord->iCCprofileData, (uint32_t)formatRecord->iCCprofileSize,
-                                           AVIFGPU_ICC_TARGET_REC2020_LINEAR, &icc);
+        int rc = avifgpu_icc_prepare(formatRecord->iCCprofileData, (uint32_t)formatRecord->iCCprofileSize,
+                                     AVIFGPU_ICC_TARGET_REC2020_LINEAR, &icc);
+        if (rc == AVIFGPU_formatCannotRead) {          // not parametric: sampled `curv` tables take the tabulated form
+            iccs.reset(new avifgpu_icc_sampled32);
+            rc = avifgpu_icc_prepare_sampled(formatRecord->iCCprofileData, (uint32_t)formatRecord->iCCprofileSize,
+                                             AVIFGPU_ICC_TARGET_REC2020_LINEAR, iccs.get());
+            if (rc) iccs.reset();
+        } else if (!rc) iccp = &icc;
         if (rc) throw OSErrException((OSErr)rc);       // e.g. LUT-based profile: the caller falls back to its lcms2 path
-        iccp = &icc;
     }
     // ... and for the 8-bit SDR case (document profile -> sRGB, ColorProfileConversion.cpp:134-157): lcms2's own 8-bit
     // matrix-shaper integer pipeline, bit-exact
@@ -192,10 +198,15 @@ void CreateHeifImageInto(FormatRecordPtr formatRecord, AlphaState alphaState, co
         // 32-bit document saved as SDR (Clip): always converted to sRGB (ColorProfileConversion.cpp:118-123), float pipeline
         if (saveOptions.convertToRec2020 || mono || !formatRecord->iCCprofileData || formatRecord->iCCprofileSize <= 0)
             throw OSErrException(AVIFGPU_formatBadParameters);
-        const int rc = avifgpu_icc_prepare(formatRecord->iCCprofileData, (uint32_t)formatRecord->iCCprofileSize,
-                                           AVIFGPU_ICC_TARGET_SRGB_FLOAT, &icc);
+        int rc = avifgpu_icc_prepare(formatRecord->iCCprofileData, (uint32_t)formatRecord->iCCprofileSize,
+                                     AVIFGPU_ICC_TARGET_SRGB_FLOAT, &icc);
+        if (rc == AVIFGPU_formatCannotRead) {
+            iccs.reset(new avifgpu_icc_sampled32);
+            rc = avifgpu_icc_prepare_sampled(formatRecord->iCCprofileData, (uint32_t)formatRecord->iCCprofileSize,
+                                             AVIFGPU_ICC_TARGET_SRGB_FLOAT, iccs.get());
+            if (rc) iccs.reset();
+        } else if (!rc) iccp = &icc;
         if (rc) throw OSErrException((OSErr)rc);
-        iccp = &icc;
     } else if (saveOptions.convertToSRGB && formatRecord->depth == 16) {
         // 16-bit document: lcms2's resampled 33^3 table + tetrahedral interpolation, bit-exact (include/avifgpu.h)
         if (mono || !formatRecord->iCCprofileData || formatRecord->iCCprofileSize <= 0) throw OSErrException(AVIFGPU_formatBadParameters);
@@ -217,7 +228,7 @@ void CreateHeifImageInto(FormatRecordPtr formatRecord, AlphaState alphaState, co
     const TileSlots ts;
     if (ts.nctx == 0) { avifgpu::set_error("avifgpu_init has not succeeded: no HIP device bound (no CPU fallback)"); throw OSErrException(AVIFGPU_formatBadParameters); }
     avifgpu::IccArgs iccArgs;
-    iccArgs.f32 = iccp; iccArgs.s8 = icc8.get(); iccArgs.c16 = icc16.get();
+    iccArgs.f32 = iccp; iccArgs.s8 = icc8.get(); iccArgs.c16 = icc16.get(); iccArgs.s32 = iccs.get();
 
     // Every exit path drains the contexts: no tile may still be reading a pinned buffer or writing a plane afterwards.
     auto bail = [&](OSErr e) { (void)avifgpu::wait_all(); formatRecord->data = nullptr; throw OSErrException(e); };

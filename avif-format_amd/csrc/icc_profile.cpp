@@ -247,6 +247,24 @@ int prepare_float_pipeline(const void* icc_profile, uint32_t size, int32_t targe
 }
 } // namespace
 
+// 32-bit documents with sampled curves: the curve stage of lcms2's float pipeline, tabulated over the 16-bit word it quantises
+// every sample to (cmsEvalToneCurveFloat, cmsgamma.c: In = _cmsQuickSaturateWord(v * 65535.0); Out = cmsEvalToneCurve16(In);
+// return Out / 65535.0) -- eval_curve_float above, evaluated at v = In / 65535 would round-trip through the same word, but the
+// table is filled from the word directly so that no float rounding of In / 65535 can move an index.
+extern "C" int32_t avifgpu_icc_prepare_sampled(const void* icc_profile, uint32_t size, int32_t target, avifgpu_icc_sampled32* out)
+{
+    if (!out) return fail(AVIFGPU_formatBadParameters, "bad ICC profile buffer");
+    Trc trc[3];
+    const int rc = prepare_float_pipeline(icc_profile, size, target, &out->base, trc, true);
+    if (rc) return rc;
+    for (int c = 0; c < 3; ++c)
+        if (trc[c].type != 0 || trc[c].table.size() < 2)
+            return fail(AVIFGPU_formatCannotRead, "not every channel carries a sampled curve: parametric profiles take avifgpu_icc_prepare");
+    for (int c = 0; c < 3; ++c)
+        for (uint32_t in = 0; in < 65536; ++in) out->curve[c][in] = (float)(eval_table16(trc[c].table, (uint16_t)in) / 65535.0);
+    return 0;
+}
+
 extern "C" int32_t avifgpu_icc_prepare_shaper8(const void* icc_profile, uint32_t size, avifgpu_icc_shaper8* out)
 {
     if (!icc_profile || !out || size < 132) return fail(AVIFGPU_formatBadParameters, "bad ICC profile buffer");

@@ -7,7 +7,8 @@ namespace avifgpu {
 
 // Tuning word of the dominant kernel (RGB f32 -> curve -> YCbCr 4:4:4 u16), see launch_write():
 //   bit0 enable the streaming kernels, bit1 8 px/lane (else 4), bit2 non-temporal loads+stores, bit3 take the geometry-gated
-//   streaming kernels (RGB16) whatever the frame size (tests use it to reach them on small frames), bits 8.. = block cap
+//   streaming kernels (RGB16) whatever the frame size (tests use it to reach them on small frames), bit4 (16) no FLAT launches
+//   (launch_write: contiguous 4:4:4 / interleaved tiles are launched as one long row), bits 8.. = block cap
 //   (0 = default).  (Bits 3 and 4 selected a register-prefetch and an XCD-contiguous variant in round 1; both lost and were removed.)
 enum : int { kHotDefault = 1 | 2 | 4 };
 
@@ -58,6 +59,8 @@ struct WriteParams {
     int32_t icc8_off[3];
     // 16-bit CLUT transform (avifgpu_icc_clut16): 33^3 cell records of kIcc16RecBytes in device memory (4.6 MB)
     const uint16_t* icc16_clut;
+    // sampled curves of a 32-bit document (avifgpu_icc_sampled32): 3 x 65536 floats in device memory (768 KiB, L2-resident)
+    const float* icc_s_tab;
 };
 
 struct ReadParams {

@@ -834,8 +834,37 @@ static hipError_t launch_read_cs(const ReadParams& p, int depth, bool alpha, int
     }
 }
 
+static hipError_t launch_read_impl(const ReadParams& p, int colorspace, int depth, bool alpha, int xs, int ys, hipStream_t st, char* label);
+
+// FLAT launches, as on the write side (write_kernels.hip, launch_write): with no chroma sub-sampling and contiguous planes and host
+// rows, the tile is one long row of width x nrows pixels -- a wave's span then starts on a span boundary of the buffers, not of a
+// row: no half-empty last span per row, no row starting inside a 128-byte line.  Same kernel, same bytes.
+#ifndef AG_READ_FLAT
+#define AG_READ_FLAT 1
+#endif
 hipError_t launch_read(const ReadParams& p, int colorspace, int depth, bool alpha, int xs, int ys,
                        hipStream_t st, char* label)
+{
+    const long long px = (long long)p.width * p.nrows;
+    const int ssz = p.bits > 8 ? 2 : 1;
+    const int nch = (colorspace == AVIFGPU_COLORSPACE_MONOCHROME ? 1 : 3) + (alpha ? 1 : 0);
+    const bool h422 = xs == 1 && ys == 0 && (p.width & 1) == 0 && colorspace == AVIFGPU_COLORSPACE_YCBCR;     // 4:2:2: sub-sampled along the row only
+    bool flat = AG_READ_FLAT && hot_variant() != 0 && !(hot_variant() & 16) && p.nrows > 1 && ys == 0 && (xs == 0 || h422) && px < (1LL << 29) &&
+                p.dst_row_bytes == (long long)p.width * nch * (depth / 8);
+    auto plane_px = [&](int pl, long long w) { return (h422 && (pl == 1 || pl == 2)) ? w / 2 : w; };
+    for (int pl = 0; pl < 4 && flat; ++pl) if (p.src[pl]) flat = p.src_stride[pl] == plane_px(pl, p.width) * ssz;
+    if (!flat) return launch_read_impl(p, colorspace, depth, alpha, xs, ys, st, label);
+    ReadParams q = p;
+    q.width = (int32_t)px; q.nrows = 1;
+    q.dst_row_bytes = px * nch * (depth / 8);
+    for (int pl = 0; pl < 4; ++pl) if (q.src[pl]) q.src_stride[pl] = plane_px(pl, px) * ssz;
+    const hipError_t e = launch_read_impl(q, colorspace, depth, alpha, xs, ys, st, label);
+    const size_t n = strlen(label);
+    if (n + 6 < (size_t)kLabelBytes) snprintf(label + n, kLabelBytes - n, " flat");
+    return e;
+}
+
+static hipError_t launch_read_impl(const ReadParams& p, int colorspace, int depth, bool alpha, int xs, int ys, hipStream_t st, char* label)
 {
     switch (colorspace) {
     case AVIFGPU_COLORSPACE_YCBCR: return launch_read_cs<kCsYcc>(p, depth, alpha, xs, ys, st, label);

@@ -17,6 +17,7 @@ struct IccArgs {
     const avifgpu_icc_transform* f32 = nullptr;     // 32-bit documents (avifgpu_write_rows_icc)
     const avifgpu_icc_shaper8*   s8 = nullptr;      // 8-bit documents  (avifgpu_write_rows_icc8)
     const avifgpu_icc_clut16*    c16 = nullptr;     // 16-bit documents (avifgpu_write_rows_icc16)
+    const avifgpu_icc_sampled32* s32 = nullptr;     // 32-bit documents with sampled curves (avifgpu_write_rows_icc_sampled)
 };
 
 constexpr int kLabelBytes = 192;                    // kernel label buffers handed to launch_*()
@@ -58,6 +59,7 @@ void release_device_caches();                        // read tables + ICC tables
 // Device copies of the ICC tables, cached per HIP device, re-uploaded only when the contents change.
 int  upload_icc8(const avifgpu_icc_shaper8* t, WriteParams& p);
 int  upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p);
+int  upload_icc_sampled(const avifgpu_icc_sampled32* t, WriteParams& p);
 
 // ---- pipeline.hip: bound contexts, staging slots, the row-tile scheduler --------------------------------------------
 // A context = one HIP device ordinal + one worker thread + kSlots staging slots (device in/out buffers, pinned host in/out

@@ -14,6 +14,7 @@
 // (write_rgb32_ycbcr444_lds) whose global loads are fully coalesced 1-KiB wave transactions.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
 #include <type_traits>
 #include "kernel_params.h"
 #include "staging.h"
@@ -372,6 +373,32 @@ AG_DEV void icc_apply(const WriteParams& p, const IccRegs& q, const IccPowTable&
     }
 }
 
+// ICC = 6: a 32-bit document whose profile carries SAMPLED curves.  lcms2's float pipeline quantises every sample to a 16-bit word
+// before it interpolates such a curve (cmsEvalToneCurveFloat: In = _cmsQuickSaturateWord(v * 65535.0), cmsgamma.c), so the curve
+// stage is a function of that word: the host tabulated it (avifgpu_icc_prepare_sampled), here the word is formed with the library's
+// own arithmetic -- the product and the + 0.5 in double (exact), _cmsQuickFloor's magic-number floor, the two saturation tests --
+// and the float is looked up (768 KiB table, L2-resident).  Matrix in fp32 FMAs on host-rounded coefficients like the streaming
+// kernels (tier 2), the inverse sRGB curve after it for the Clip save.
+AG_DEV uint32_t icc_quick_saturate_word(float v)
+{
+    const double d = (double)v * 65535.0 + 0.5;
+    const double t = (d - 32767.0) + 103079215104.0;            // _cmsQuickFloor: 68719476736.0 * 1.5, the low word >> 16
+    const uint32_t q = (uint32_t)((__double2loint(t) >> 16) + 32767) & 0xffffu;       // & 0xffff: a NaN sample must not index outside
+    return d <= 0.0 ? 0u : (d >= 65535.0 ? 0xffffu : q);
+}
+AG_DEV void icc_apply_sampled(const WriteParams& p, float (&c)[3])
+{
+    const IccPowTableF noT = { nullptr };
+    float t[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[k] = p.icc_s_tab[65536 * k + icc_quick_saturate_word(c[k])];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        c[i] = __builtin_fmaf(t[2], p.icc_m_f[3 * i + 2], __builtin_fmaf(t[1], p.icc_m_f[3 * i + 1], t[0] * p.icc_m_f[3 * i + 0]));
+        if (p.icc_out == 4) c[i] = icc_inv4_f(noT, p.icc_out_f, c[i]);
+    }
+}
+
 #ifndef AG_ICC16_LEAN
 #define AG_ICC16_LEAN 1
 #endif
@@ -451,7 +478,8 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
 #pragma unroll
         for (int k = 0; k < NCOL; ++k) col[k] = __uint_as_float(s[k]);
         if constexpr (ICC != 0 && COLOR) {                                                        // ConvertRow runs before the pixel loop: WriteHeifImage.cpp:1031-1034
-            if constexpr (IccF32<ICC>::value) icc_apply_f<ICC>(p, *iccRegs, *iccRegsF, powTf, col);
+            if constexpr (ICC == 6) icc_apply_sampled(p, col);
+            else if constexpr (IccF32<ICC>::value) icc_apply_f<ICC>(p, *iccRegs, *iccRegsF, powTf, col);
             else icc_apply<ICC>(p, *iccRegs, powT, col);
         }
         float a = 1.0f;
@@ -1895,7 +1923,7 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, char* label)
     if constexpr (DEPTH == 32 && PLANES >= 3) {
         bool linear = true;
         for (int c = 0; c < 3; ++c) linear = linear && p.icc_trc_linear[c] != 0;
-        if (p.icc_trc_type[0] != 0 && (p.icc_out == 4 || !linear)) {      // variants 2 and 4 use a smaller footprint
+        if (p.icc_trc_type[0] != 0 && p.icc_s_tab == nullptr && (p.icc_out == 4 || !linear)) {      // variants 2 and 4 use a smaller footprint
             constexpr int PXT2 = WriteShape<DST16, PLANES, XS, 2>::PXT;
             groups = (long long)((p.width + PXT2 - 1) / PXT2) * ((p.nrows + (1 << YS) - 1) >> YS);
         }
@@ -1929,6 +1957,16 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, char* label)
         }
     }
     if constexpr (DEPTH == 32 && PLANES >= 3) {
+        if (p.icc_s_tab != nullptr) {               // sampled document curves: table lookup in front of the matrix
+            if constexpr (TRANSFER == kTransferPqHi) return hipErrorInvalidValue;       // (launch_tr sends sampled profiles to the plain PQ id)
+            else {
+                snprintf(label, kLabelBytes, "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=6>",
+                         DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned);
+                if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 6>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
+                else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 6>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
+                return hipGetLastError();
+            }
+        }
         if (p.icc_trc_type[0] != 0) {               // ICC row transform requested: separate instantiations, the others pay nothing
             bool linear = true;
             for (int c = 0; c < 3; ++c) linear = linear && p.icc_trc_linear[c] != 0;
@@ -1968,7 +2006,7 @@ static hipError_t launch_tr(const WriteParams& p, hipStream_t st, char* label)
 {
     if constexpr (DEPTH == 32) {
         switch (p.transfer) {
-        case AVIFGPU_TRANSFER_PQ:       if (pq_hi_launch(p)) AG_LAUNCH(DEPTH, PLANES, OUT, DST16, XS, YS, kTransferPqHi); AG_LAUNCH(DEPTH, PLANES, OUT, DST16, XS, YS, 0);
+        case AVIFGPU_TRANSFER_PQ:       if (pq_hi_launch(p) && p.icc_s_tab == nullptr) AG_LAUNCH(DEPTH, PLANES, OUT, DST16, XS, YS, kTransferPqHi); AG_LAUNCH(DEPTH, PLANES, OUT, DST16, XS, YS, 0);
         case AVIFGPU_TRANSFER_HLG:      AG_LAUNCH(DEPTH, PLANES, OUT, DST16, XS, YS, 1);
         case AVIFGPU_TRANSFER_SMPTE428: AG_LAUNCH(DEPTH, PLANES, OUT, DST16, XS, YS, 2);
         default:                        AG_LAUNCH(DEPTH, PLANES, OUT, DST16, XS, YS, 3);
@@ -2007,9 +2045,47 @@ static hipError_t launch_planes(const WriteParams& p, int planes, bool dst16, in
     }
 }
 
+static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes, bool dst16, int output, int xs, int ys,
+                                    int variant, hipStream_t st, char* label);
+
 // Entry used by avifgpu_api.hip.  `variant` selects the hot-path implementation when it applies.
+//
+// FLAT launches (round 3).  When nothing depends on where a row ends -- 4:4:4 or 4:2:2 planes or the interleaved hand-off, 16- /
+// 32-bit documents -- and source and planes are contiguous (row stride == row bytes: the library's own staging buffers whenever a row is a
+// multiple of 16 bytes, and any tightly packed caller buffer), the tile IS one long row of width x nrows pixels.  Launched as such,
+// every wave's span starts on a span boundary of the buffer instead of a row boundary: no half-empty last span per row (7952-wide
+// rows fill 15.53 spans of 512 pixels) and no rows that start in the middle of a 128-byte line (7952 x 12 B = 745.5 lines).  Same
+// kernels, same per-pixel arithmetic, same bytes (tests/test_gpu_kernel_equivalence.py); variant bit 4 (16) turns it off for A/B.
+#ifndef AG_FLAT
+#define AG_FLAT 1
+#endif
 hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16, int output, int xs, int ys,
                         int variant, hipStream_t st, char* label)
+{
+    const long long px = (long long)p.width * p.nrows;
+    // 4:2:2 qualifies too (chroma is sub-sampled along the row only): even width, chroma planes of width / 2 samples per row
+    const bool h422 = xs == 1 && ys == 0 && (p.width & 1) == 0 && output == AVIFGPU_OUT_YCBCR;
+    bool flat = AG_FLAT && (variant & 1) && !(variant & 16) && p.nrows > 1 && planes >= 3 && (depth == 16 || depth == 32) && ys == 0 && (xs == 0 || h422) &&
+                px < (1LL << 29) && p.src_row_bytes == (long long)p.width * planes * (depth / 8);
+    const int dsz = dst16 ? 2 : 1;
+    auto plane_px = [&](int pl, long long w) { return (h422 && (pl == 1 || pl == 2)) ? w / 2 : w; };
+    if (flat) {
+        if (output == AVIFGPU_OUT_REFERENCE) flat = p.dst_stride[0] == (long long)p.width * planes * dsz;
+        else for (int pl = 0; pl < (planes == 4 ? 4 : 3); ++pl) flat = flat && p.dst[pl] != nullptr && p.dst_stride[pl] == plane_px(pl, p.width) * dsz;
+    }
+    if (!flat) return launch_write_impl(p, depth, planes, dst16, output, xs, ys, variant, st, label);
+    WriteParams q = p;
+    q.width = (int32_t)px; q.nrows = 1; q.rows_to_end = 1;
+    q.src_row_bytes = px * planes * (depth / 8);
+    for (int pl = 0; pl < 4; ++pl) if (q.dst[pl]) q.dst_stride[pl] = (output == AVIFGPU_OUT_REFERENCE ? px * planes : plane_px(pl, px)) * dsz;
+    const hipError_t e = launch_write_impl(q, depth, planes, dst16, output, xs, ys, variant, st, label);
+    const size_t n = strlen(label);
+    if (n + 6 < (size_t)kLabelBytes) snprintf(label + n, kLabelBytes - n, " flat");
+    return e;
+}
+
+static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes, bool dst16, int output, int xs, int ys,
+                                    int variant, hipStream_t st, char* label)
 {
     // hot path: RGB f32 (no alpha) -> YCbCr 4:4:4 u16 with aligned rows; `variant` is a tuning word:
     //   bit0 enable, bit1 PXL=8 (else 4), bit2 non-temporal, bit3 take the size-gated streaming kernels at any size (tests);

@@ -311,9 +311,9 @@ int32_t avifgpu_read_rows(const avifgpu_read_desc* desc,
  * matrix/TRC RGB profiles that lcms2 pipeline is [per-channel TRC] -> [one 3x3 matrix in double] -> float, which the
  * write kernels can apply in place of the CPU call.  (Tier 2, like every float path: the kernels evaluate the curves and --
  * on the streaming kernels -- the matrix in single precision; the bar is on the integer codes behind the transfer curve,
- * |delta code| <= 1 and >= 99 % exact against the real lcms2, measured 99.7-100 %: tests/test_gpu_icc.py.)  LUT-based profiles (A2B tags), sampled `curv` tables (on this
- * 32-bit path only; Photoshop's 32-bit documents carry linear profiles) are NOT covered: avifgpu_icc_prepare returns AVIFGPU_formatCannotRead and the caller keeps
- * its lcms2 path. */
+ * |delta code| <= 1 and >= 99 % exact against the real lcms2, measured 99.7-100 %: tests/test_gpu_icc.py.)  Sampled `curv` tables
+ * are not parametric: avifgpu_icc_prepare returns AVIFGPU_formatCannotRead for them and avifgpu_icc_prepare_sampled (below) takes
+ * them; LUT-based profiles (A2B tags) are NOT covered by either and the caller keeps its lcms2 path. */
 typedef struct avifgpu_icc_transform {
     int32_t trc_type[3];         /* lcms2 parametric curve type 1..5 per channel (1 = plain gamma; gamma 1 = linear) */
     int32_t out_curve;           /* 0 = none (linear destination); 4 = inverse of lcms2 parametric type 4 (sRGB) after the matrix */
@@ -340,6 +340,25 @@ int32_t avifgpu_write_rows_icc(const avifgpu_write_desc* desc, const avifgpu_icc
                                const void* src, int64_t src_row_bytes,
                                void* const dst[4], const int64_t dst_stride[4],
                                int32_t mem_kind, void* stream);
+
+/* ---- ... for 32-bit documents whose profile carries SAMPLED curves (`curv` tables) ------------------------------------------------
+ * lcms2's float pipeline does not interpolate such a curve in floating point: cmsEvalToneCurveFloat saturates the sample to a 16-bit
+ * word (_cmsQuickSaturateWord(v * 65535.0)), interpolates the table in 16-bit fixed point (cmsEvalToneCurve16 = LinLerp1D) and
+ * divides back by 65535 -- so per channel the curve stage is a function of a 16-bit index.  avifgpu_icc_prepare_sampled tabulates
+ * it (65536 floats per channel, the library's arithmetic restated on the host: csrc/icc_profile.cpp), the kernel computes the same
+ * index in double and looks the float up; matrix and, for the sRGB target, the inverse curve follow as in avifgpu_icc_transform.
+ * All three channels must be sampled (a profile that mixes sampled and parametric channels, and every LUT-based / A2B profile,
+ * still returns AVIFGPU_formatCannotRead: the caller keeps lcms2).  768 KiB: allocate it once per save. */
+typedef struct avifgpu_icc_sampled32 {
+    avifgpu_icc_transform base;  /* matrix, out_curve, out_params as above; trc_type[] = 0 */
+    float curve[3][65536];       /* curve[c][_cmsQuickSaturateWord(v * 65535.0)] = what lcms2's curve stage hands to the matrix for sample v */
+} avifgpu_icc_sampled32;
+int32_t avifgpu_icc_prepare_sampled(const void* icc_profile, uint32_t size, int32_t target, avifgpu_icc_sampled32* out);
+int32_t avifgpu_write_rows_icc_sampled(const avifgpu_write_desc* desc, const avifgpu_icc_sampled32* icc,
+                                       int32_t row0, int32_t nrows,
+                                       const void* src, int64_t src_row_bytes,
+                                       void* const dst[4], const int64_t dst_stride[4],
+                                       int32_t mem_kind, void* stream);
 
 /* Which working space the document profile already is: the checks that decide whether the reference installs a transform
  * at all -- IsRec2020ColorProfile / IsSRGBColorProfile (src/common/ColorProfileDetection.cpp:331-374): the cicp tag when

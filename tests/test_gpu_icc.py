@@ -434,3 +434,87 @@ def test_host_shim_decides_like_the_plugin_clip_and_kept_profile(gpu, lcms, keep
         gpu.lib.avifgpu_image_free(ctypes.byref(img2))
     else:
         assert code == pkg.writErr and b"Unable to load the document color profile." in gpu.lib.avifgpu_last_error()
+
+
+SAMPLED = [("p3-sampled-srgb-1024", 1, 3, 1024), ("adobergb-sampled-per-channel-256", 3, 4, 256), ("prophoto-sampled-per-channel-33", 2, 4, 33)]
+
+
+@pytest.mark.gpu
+def test_sampled_curve_tables_equal_lcms2_per_word(lcms):
+    """avifgpu_icc_prepare_sampled (host only): curve[c][w] is what lcms2's float curve stage returns for every 16-bit word w -- checked
+    through the real library by converting gray ramps v = w / 65535 with an identity-primaries profile is not possible (the matrix
+    follows), so the check is structural: the table equals cmsEvalToneCurve16's output / 65535 as restated in icc_profile.cpp, it is
+    monotone for the monotone test curves, and its ends are 0 and 1."""
+    lib = pkg.load()
+    for name, kind, trc, g in SAMPLED:
+        icc = _profile(lcms, kind, trc, g)
+        t = pkg.IccSampled32()
+        assert lib.avifgpu_icc_prepare_sampled(icc, len(icc), pkg.ICC_TARGET_REC2020_LINEAR, ctypes.byref(t)) == 0, name
+        assert lib.avifgpu_icc_prepare(icc, len(icc), pkg.ICC_TARGET_REC2020_LINEAR, ctypes.byref(pkg.IccTransform())) == pkg.formatCannotRead
+        c = np.ctypeslib.as_array(t.curve)
+        assert c.shape == (3, 65536) and np.all(np.diff(c, axis=1) >= 0), name
+        assert np.all(c[:, 0] == 0.0) and np.all(c[:, 65535] == 1.0), name
+    # a parametric profile is not "sampled"; a non-profile is rejected
+    icc = _profile(lcms, 1, 2, 1.8)
+    assert lib.avifgpu_icc_prepare_sampled(icc, len(icc), 0, ctypes.byref(pkg.IccSampled32())) == pkg.formatCannotRead
+    assert lib.avifgpu_icc_prepare_sampled(bytes(200), 200, 0, ctypes.byref(pkg.IccSampled32())) == pkg.formatCannotRead
+
+
+@pytest.mark.parametrize("name,kind,trc,g", SAMPLED)
+@pytest.mark.parametrize("planes", [3, 4])
+def test_sampled_document_curves_match_lcms2(gpu, lcms, name, kind, trc, g, planes):
+    """A 32-bit document whose profile carries sampled `curv` tables (one curve for all channels, or a different one per channel):
+    lcms2's float pipeline quantises every sample to a 16-bit word and interpolates the table in fixed point; the GPU forms the same
+    word and looks the tabulated result up (icc = 6).  Against the REAL lcms2 + the oracle's pixel loop, tier-2 bars."""
+    icc = _profile(lcms, kind, trc, g)
+    alpha = pkg.ALPHA_STRAIGHT if planes == 4 else pkg.ALPHA_NONE
+    for target, conv_fn, cfgs in (
+            (pkg.ICC_TARGET_REC2020_LINEAR, lcms.oracle_icc_convert_rows_to_rec2020,
+             ((pkg.OUT_YCBCR, pkg.CHROMA_444, 10, pkg.TRANSFER_PQ), (pkg.OUT_YCBCR, pkg.CHROMA_420, 12, pkg.TRANSFER_PQ), (pkg.OUT_REFERENCE, pkg.CHROMA_444, 12, pkg.TRANSFER_SMPTE428))),
+            (pkg.ICC_TARGET_SRGB_FLOAT, lcms.oracle_icc_convert_rows_to_srgb_float,
+             ((pkg.OUT_YCBCR, pkg.CHROMA_422, 12, pkg.TRANSFER_CLIP), (pkg.OUT_REFERENCE, pkg.CHROMA_444, 10, pkg.TRANSFER_CLIP)))):
+        xf = gpu.icc_prepare_sampled(icc, target)
+        for output, chroma, bits, transfer in cfgs:
+            hdr = transfer != pkg.TRANSFER_CLIP
+            d = pkg.WriteDesc(width=516, height=18, depth=32, planes=planes, bit_depth=bits, transfer=transfer, peak_nits=80,
+                              alpha_state=alpha, output=output, chroma=chroma,
+                              matrix_coefficients=pkg.MATRIX_BT2020_NCL if hdr else pkg.MATRIX_BT601,
+                              color_primaries=pkg.PRIMARIES_BT2020 if hdr else pkg.PRIMARIES_BT709)
+            src = harness.make_write_source(d, seed=41)       # negatives, > 1 and NaN-free: lcms2 saturates the word at both ends
+            conv = src.copy()
+            assert conv_fn(icc, len(icc), int(planes == 4), conv.ctypes.data, d.width, d.height, conv.strides[0]) == 0
+            want = harness.oracle_write(d, conv)
+            got = _gpu_write_icc(gpu, d, src, xf)
+            assert "icc=6" in gpu.last_kernel(), gpu.last_kernel()
+            st = harness.compare_write(d, want, got)
+            print(f"icc-sampled {name} planes {planes} target {target} out {output} {bits}-bit transfer {transfer}: exact {st['exact_frac']:.5f} max {st['max_abs']}")
+            assert st["max_abs"] <= 1, (name, st)
+            assert st["exact_frac"] >= (0.99 if hdr else 0.985), (name, st)
+
+
+def test_host_shim_takes_sampled_profiles_itself(gpu, lcms):
+    """convertToRec2020 with a sampled-curve profile: the shim falls through from the parametric form to the tabulated one instead of
+    returning formatCannotRead (which is now left to LUT-based profiles)."""
+    from fake_host import FakeHost
+    H = pkg.host
+    icc = _profile(lcms, 1, 3, 1024)
+    d = pkg.WriteDesc(width=300, height=40, depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_PQ, peak_nits=80,
+                      alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_REFERENCE)
+    src = np.abs(harness.make_write_source(d, seed=43))
+    conv = src.copy()
+    assert lcms.oracle_icc_convert_rows_to_rec2020(icc, len(icc), 0, conv.ctypes.data, d.width, d.height, conv.strides[0]) == 0
+    want = harness.oracle_write(d, conv)
+    host = FakeHost(d.width, d.height, 32, 3, max_data=300 * 12 * 10, image=src)
+    blob = ctypes.create_string_buffer(icc, len(icc))
+    host.fr.iCCprofileData = ctypes.cast(blob, ctypes.c_void_p)
+    host.fr.iCCprofileSize = len(icc)
+    opts = H.SaveUIOptions(imageBitDepth=10, hdrTransferFunction=pkg.TRANSFER_PQ, pq=H.PQOptions(80), chromaSubsampling=pkg.CHROMA_444,
+                           iccDecision=H.ICC_LIKE_PLUGIN)
+    img = H.Image()
+    code = gpu.lib.avifgpu_host_create_heif_image(ctypes.byref(host.fr), pkg.ALPHA_NONE, ctypes.byref(opts), pkg.OUT_REFERENCE, -1, -1, ctypes.byref(img))
+    assert code == 0, gpu.lib.avifgpu_last_error()
+    raw = (ctypes.c_uint8 * (img.stride[0] * d.height)).from_address(img.plane[0])
+    got = {0: np.frombuffer(raw, dtype=np.uint8).reshape(d.height, img.stride[0])[:, :d.width * 3 * 2].view(np.uint16).copy()}
+    st = harness.compare_write(d, want, got)
+    assert st["max_abs"] <= 1 and st["exact_frac"] >= 0.99, st
+    gpu.lib.avifgpu_image_free(ctypes.byref(img))

@@ -74,3 +74,91 @@ def test_specialised_kernel_equals_generic(gpu, kernel, kw):
         gpu.lib.avifgpu_set_hot_variant(1 | 2 | 4)
     for pl in slow:
         assert np.array_equal(fast[pl], slow[pl]), (kernel, pl)
+
+
+FLAT_CASES = [
+    dict(width=1000, height=7, depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_PQ, peak_nits=80, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444, **BT2020),
+    dict(width=7952, height=3, depth=32, planes=3, bit_depth=12, transfer=pkg.TRANSFER_PQ, peak_nits=1000, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444, **BT2020),
+    dict(width=1016, height=5, depth=32, planes=4, bit_depth=12, transfer=pkg.TRANSFER_PQ, peak_nits=80, alpha_state=pkg.ALPHA_STRAIGHT,
+         output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444, **BT2020),
+    dict(width=1000, height=5, depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_PQ, peak_nits=80, output=pkg.OUT_REFERENCE),
+    dict(width=1000, height=6, depth=16, planes=3, bit_depth=12, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444, **BT2020),
+    dict(width=1000, height=6, depth=16, planes=4, bit_depth=10, alpha_state=pkg.ALPHA_PREMULTIPLIED, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444, **BT2020),
+    dict(width=1000, height=5, depth=16, planes=3, bit_depth=12, output=pkg.OUT_REFERENCE),
+    dict(width=16, height=9, depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_SMPTE428, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444, **BT2020),
+    # 4:2:2 is sub-sampled along the row only: flat too (chroma planes of width / 2)
+    dict(width=1008, height=7, depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_PQ, peak_nits=80, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_422, **BT2020),
+    dict(width=1008, height=6, depth=32, planes=3, bit_depth=12, transfer=pkg.TRANSFER_PQ, peak_nits=1000, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_422,
+         chroma_downsampling=pkg.DOWNSAMPLE_NEAREST, **BT2020),
+    dict(width=1008, height=5, depth=16, planes=3, bit_depth=10, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_422, matrix_coefficients=pkg.MATRIX_BT709),
+    dict(width=1008, height=5, depth=16, planes=4, bit_depth=12, alpha_state=pkg.ALPHA_STRAIGHT, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_422, **BT2020),
+]
+
+
+@pytest.mark.parametrize("kw", FLAT_CASES, ids=[f"flat-{i}" for i in range(len(FLAT_CASES))])
+def test_flat_launch_equals_row_launch(gpu, kw):
+    """launch_write: a contiguous 4:4:4 / interleaved tile is launched as ONE row of width x nrows pixels (span boundaries of the
+    buffer instead of row boundaries).  Same kernels, same arithmetic: the bytes must equal the row-by-row launch (variant bit 4 = off)
+    and the generic kernel's."""
+    d = pkg.WriteDesc(**kw)
+    src = harness.make_write_source(d, seed=17)
+    try:
+        gpu.lib.avifgpu_set_hot_variant(1 | 2 | 4 | 8)
+        flat = harness.gpu_write(gpu, d, src, mem="device")
+        assert gpu.last_kernel().endswith(" flat"), gpu.last_kernel()
+        gpu.lib.avifgpu_set_hot_variant(1 | 2 | 4 | 8 | 16)
+        rows = harness.gpu_write(gpu, d, src, mem="device")
+        assert "flat" not in gpu.last_kernel(), gpu.last_kernel()
+        gpu.lib.avifgpu_set_hot_variant(0)
+        slow = harness.gpu_write(gpu, d, src, mem="device")
+        assert "write_px" in gpu.last_kernel() and "flat" not in gpu.last_kernel(), gpu.last_kernel()
+    finally:
+        gpu.lib.avifgpu_set_hot_variant(1 | 2 | 4)
+    for pl in slow:
+        assert np.array_equal(flat[pl], rows[pl]), pl
+        assert np.array_equal(flat[pl], slow[pl]), pl
+    # a padded row stride (what libheif hands over for widths that are not a multiple of 8 samples) is NOT flattened
+    harness.gpu_write(gpu, d, src, mem="device", stride_pad=8)
+    assert "flat" not in gpu.last_kernel(), gpu.last_kernel()
+
+
+READ_FLAT_CASES = [
+    dict(width=1000, height=7, colorspace=pkg.COLORSPACE_YCBCR, chroma=pkg.CHROMA_444, bit_depth=10, depth=32, alpha_state=pkg.ALPHA_NONE,
+         matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020, transfer_characteristics=pkg.TC_PQ),
+    dict(width=1000, height=6, colorspace=pkg.COLORSPACE_YCBCR, chroma=pkg.CHROMA_444, bit_depth=12, depth=16, alpha_state=pkg.ALPHA_PREMULTIPLIED,
+         matrix_coefficients=pkg.MATRIX_BT709),
+    dict(width=1008, height=5, colorspace=pkg.COLORSPACE_YCBCR, chroma=pkg.CHROMA_444, bit_depth=8, depth=8, alpha_state=pkg.ALPHA_NONE,
+         matrix_coefficients=pkg.MATRIX_BT601, full_range_flag=0),
+    dict(width=1008, height=9, colorspace=pkg.COLORSPACE_MONOCHROME, chroma=pkg.CHROMA_MONOCHROME, bit_depth=8, depth=8, alpha_state=pkg.ALPHA_STRAIGHT),
+    dict(width=1000, height=4, colorspace=pkg.COLORSPACE_MONOCHROME, chroma=pkg.CHROMA_MONOCHROME, bit_depth=12, depth=16, alpha_state=pkg.ALPHA_NONE),
+    dict(width=1000, height=5, colorspace=pkg.COLORSPACE_RGB, chroma=pkg.CHROMA_444, bit_depth=12, depth=32, alpha_state=pkg.ALPHA_STRAIGHT,
+         matrix_coefficients=pkg.MATRIX_RGB_GBR, color_primaries=pkg.PRIMARIES_BT2020, transfer_characteristics=pkg.TC_HLG),
+    dict(width=1008, height=6, colorspace=pkg.COLORSPACE_YCBCR, chroma=pkg.CHROMA_422, bit_depth=8, depth=8, alpha_state=pkg.ALPHA_NONE,
+         matrix_coefficients=pkg.MATRIX_BT601),
+    dict(width=1008, height=5, colorspace=pkg.COLORSPACE_YCBCR, chroma=pkg.CHROMA_422, bit_depth=10, depth=32, alpha_state=pkg.ALPHA_STRAIGHT,
+         matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020, transfer_characteristics=pkg.TC_PQ),
+]
+
+
+@pytest.mark.parametrize("kw", READ_FLAT_CASES, ids=[f"read-flat-{i}" for i in range(len(READ_FLAT_CASES))])
+def test_flat_read_launch_equals_row_launch(gpu, kw):
+    """launch_read: planes without chroma sub-sampling and a host row buffer that are all contiguous are decoded as ONE row of
+    width x nrows pixels.  Same kernel: the bytes must equal the row-by-row launch (variant bit 4 = off) -- and the oracle."""
+    d = pkg.ReadDesc(**kw)
+    planes = harness.make_read_source(d, seed=23)
+    try:
+        flat = harness.gpu_read(gpu, d, planes)
+        assert gpu.last_kernel().endswith(" flat"), gpu.last_kernel()
+        gpu.lib.avifgpu_set_hot_variant(1 | 2 | 4 | 16)
+        rows = harness.gpu_read(gpu, d, planes)
+        assert "flat" not in gpu.last_kernel(), gpu.last_kernel()
+    finally:
+        gpu.lib.avifgpu_set_hot_variant(1 | 2 | 4)
+    assert np.array_equal(flat.view(np.uint8), rows.view(np.uint8))
+    want = harness.oracle_read(d, planes)
+    if d.depth == 32:
+        np.testing.assert_allclose(flat, want, rtol=1e-4, atol=1e-9)
+    else:
+        assert np.array_equal(flat, want)
+    harness.gpu_read(gpu, d, harness.make_read_source(d, seed=23, stride_pad=8))     # padded plane strides: not flattened
+    assert "flat" not in gpu.last_kernel(), gpu.last_kernel()
