@@ -20,10 +20,25 @@ gpu = pkg.AvifGpu(0)
 stream = torch.cuda.Stream(dev)
 
 
-def time_launch(fn, iters=60, warm=150, batch=10):   # warm: clock ramp of an idle MI355X takes ~50 ms
-    """Mean / median ms per launch.  Launches are timed in back-to-back batches between one pair of HIP events (as bench.py
-    does): an event pair around every single launch adds ~5 us of record/launch gap, which is 10-25 % of the small kernels
-    (kernel-trace durations in profiles/r01/configs_traffic.json are the cross-check)."""
+WARM = int(os.environ.get("BENCH_WARM", "0"))         # 0: from the row's size (below); > 0: exactly this many warm-up launches
+RAMP_S = float(os.environ.get("BENCH_RAMP_S", "0.15"))
+LAST = {"launches": 0}
+
+
+def warm_launches(algorithmic_bytes):
+    """Warm-up launches of a row: at least 150, and enough for ~0.15 s of back-to-back launches of THIS kernel.  An MI355X that sat
+    idle during a row's host-side set-up needs that long to return to its steady state, and 150 launches are 30 ms of a 0.2 ms kernel
+    but 2.4 ms of a 16 us one -- the short rows (C2 at 4096^2, the u8 reads) were being timed 5-10 % low
+    (profiles/r03/warmup_clock_ramp_ab.txt: 150 vs 3000 warm-up launches; a torch kernel as the ramp did NOT close the gap, the
+    library kernel itself does).  The count is a function of the row's algorithmic bytes only, so every profiling pass launches the
+    same number of kernels per row (tools/summarize_pmc.py cuts the dispatch stream by the 'launches' each row prints)."""
+    if WARM > 0:
+        return WARM
+    est_s = algorithmic_bytes / 5.0e12
+    return max(150, min(20000, int(RAMP_S / max(est_s, 1e-7))))
+
+
+def time_launch(fn, iters=60, warm=150, batch=10):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize(dev)
@@ -35,6 +50,7 @@ def time_launch(fn, iters=60, warm=150, batch=10):   # warm: clock ramp of an id
         b.record(stream)
     torch.cuda.synchronize(dev)
     ts = sorted(a.elapsed_time(b) / batch for a, b in evs)
+    LAST["launches"] = warm + (iters // batch) * batch
     return sum(ts) / len(ts), ts[len(ts) // 2]
 
 
@@ -76,11 +92,12 @@ def bench_write(name, icc=None, smooth=False, **kw):
         ptrs[pl], strides[pl] = bufs[pl].data_ptr(), bufs[pl].stride(0)
     fn = lambda: gpu.write_rows(d, 0, d.height, src.data_ptr(), src.stride(0) * src.element_size(), ptrs, strides,
                                 mem=pkg.MEM_DEVICE, stream=stream.cuda_stream, icc=icc)
-    mean, p50 = time_launch(fn)
     ab = gpu.write_algorithmic_bytes(d, d.height)
+    mean, p50 = time_launch(fn, warm=warm_launches(ab))
     print(json.dumps({"config": name, "kernel": gpu.last_kernel(), "ms_mean": round(mean, 4), "ms_p50": round(p50, 4),
                       "Mpx_s": round(d.width * d.height / mean / 1e3, 0), "GB_s": round(ab / mean / 1e6, 1),
-                      "frac_of_8TBs": round(ab / mean / 1e6 / 8000, 3), "bytes_per_px": ab / (d.width * d.height)}), flush=True)
+                      "frac_of_8TBs": round(ab / mean / 1e6 / 8000, 3), "bytes_per_px": ab / (d.width * d.height),
+                      "launches": LAST["launches"]}), flush=True)
 
 
 def bench_read(name, **kw):
@@ -99,11 +116,12 @@ def bench_read(name, **kw):
     out = torch.empty((d.height, d.width * nch * (d.depth // 8)), dtype=torch.uint8, device=dev)
     fn = lambda: gpu.read_rows(d, 0, d.height, ptrs, strides, out.data_ptr(), out.stride(0), mem=pkg.MEM_DEVICE,
                                stream=stream.cuda_stream)
-    mean, p50 = time_launch(fn)
     ab = gpu.read_algorithmic_bytes(d, d.height)
+    mean, p50 = time_launch(fn, warm=warm_launches(ab))
     print(json.dumps({"config": name, "kernel": gpu.last_kernel(), "ms_mean": round(mean, 4), "ms_p50": round(p50, 4),
                       "Mpx_s": round(d.width * d.height / mean / 1e3, 0), "GB_s": round(ab / mean / 1e6, 1),
-                      "frac_of_8TBs": round(ab / mean / 1e6 / 8000, 3), "bytes_per_px": ab / (d.width * d.height)}), flush=True)
+                      "frac_of_8TBs": round(ab / mean / 1e6 / 8000, 3), "bytes_per_px": ab / (d.width * d.height),
+                      "launches": LAST["launches"]}), flush=True)
 
 
 ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]      # optional substrings: run matching configurations only

@@ -52,8 +52,11 @@ def main():
         for name in g:
             vals = sorted(((int(x["Dispatch_Id"]), float(x["Counter_Value"])) for x in recs if x["Counter_Name"] == name))
             vals = [v for _, v in vals]
+            start = 0
             for i, c in enumerate(cfgs):
-                chunk = vals[i * LAUNCHES:(i + 1) * LAUNCHES][-60:]
+                n = c.get("launches", LAUNCHES)
+                chunk = vals[start:start + n][-60:]
+                start += n
                 if chunk:
                     e = table.setdefault(c["config"], {"kernel": c["kernel"], "algorithmic_bytes": round(c["bytes_per_px"] * c["Mpx_s"] * c["ms_mean"] * 1e3)})
                     e[name] = sum(chunk) / len(chunk)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 outputs of `tools/bench_configs.py` runs into one table per configuration.
 
-bench_configs.py launches every configuration's kernel exactly LAUNCHES times back to back, so the dispatches that match
+bench_configs.py launches every configuration's kernel a known number of times back to back (each row prints its 'launches': a
+size-dependent warm-up + 60 timed; rows of older runs: LAUNCHES), so the dispatches that match
 write_px|read_px|write_rgb32|write_rgb16|... (in dispatch order) split into consecutive chunks of LAUNCHES, one per printed configuration.
 Inputs: the kernel-trace CSV and the two counter-collection CSVs (FETCH_SIZE, WRITE_SIZE: separate passes, as the MI355X guide
 prescribes) plus the JSON lines bench_configs.py printed in the kernel-trace run.
@@ -27,8 +28,17 @@ def rows(path_glob):
     return out
 
 
-def chunks(seq):
-    return [seq[i:i + LAUNCHES] for i in range(0, len(seq) - LAUNCHES + 1, LAUNCHES)]
+def chunks(seq, counts=None):
+    """The dispatch stream cut into one chunk per configuration: by the 'launches' each row printed, else LAUNCHES each."""
+    if not counts:
+        return [seq[i:i + LAUNCHES] for i in range(0, len(seq) - LAUNCHES + 1, LAUNCHES)]
+    out, i = [], 0
+    for n in counts:
+        if i + n > len(seq):
+            break
+        out.append(seq[i:i + n])
+        i += n
+    return out
 
 
 def main(prof_dir, configs_jsonl, out_json):
@@ -42,8 +52,9 @@ def main(prof_dir, configs_jsonl, out_json):
         rs.sort(key=lambda r: int(r["Dispatch_Id"]))
         per_counter[name] = [float(r["Counter_Value"]) for r in rs]
     table = []
-    dch = chunks(dur)
-    fch, wch = chunks(per_counter["FETCH_SIZE"]), chunks(per_counter["WRITE_SIZE"])
+    counts = [c["launches"] for c in cfgs] if all("launches" in c for c in cfgs) else None
+    dch = chunks(dur, counts)
+    fch, wch = chunks(per_counter["FETCH_SIZE"], counts), chunks(per_counter["WRITE_SIZE"], counts)
     for i, c in enumerate(cfgs):
         e = {"config": c["config"], "kernel": c["kernel"], "algorithmic_bytes": c["bytes_per_px"] * c["Mpx_s"] * c["ms_mean"] * 1e3}
         if i < len(dch):
