@@ -113,6 +113,9 @@ class DeviceInfo(ctypes.Structure):
                 ("pci_bus_id", ctypes.c_char * 32), ("cpulist", ctypes.c_char * 256)]
 
 
+Transform16Fn = ctypes.CFUNCTYPE(None, c_void_p, POINTER(ctypes.c_uint16), POINTER(ctypes.c_uint16), ctypes.c_uint32)
+TransformF32Fn = ctypes.CFUNCTYPE(None, c_void_p, POINTER(ctypes.c_float), POINTER(ctypes.c_float), ctypes.c_uint32)
+
 _PLANES4 = c_void_p * 4
 _STRIDES4 = c_int64 * 4
 
@@ -138,6 +141,7 @@ ABI = [
                                                  POINTER(_PLANES4), POINTER(_STRIDES4), c_int32, c_void_p]),
     ("avifgpu_icc_detect", c_int32, [c_void_p, ctypes.c_uint32]),
     ("avifgpu_icc_prepare_clut16", c_int32, [c_void_p, ctypes.c_uint32, POINTER(IccClut16)]),
+    ("avifgpu_icc_clut16_from_transforms", c_int32, [c_void_p, c_void_p, c_void_p, POINTER(IccClut16)]),
     ("avifgpu_write_rows_icc16", c_int32, [POINTER(WriteDesc), POINTER(IccClut16), c_int32, c_int32, c_void_p, c_int64,
                                            POINTER(_PLANES4), POINTER(_STRIDES4), c_int32, c_void_p]),
     ("avifgpu_icc_prepare_shaper8", c_int32, [c_void_p, ctypes.c_uint32, POINTER(IccShaper8)]),

@@ -114,7 +114,8 @@ struct WritePlan { avifgpu_write_desc desc; int output; };
 // Shared body of the six CreateHeifImage* functions: FormatRecord set-up as DoWriteStart (Write.cpp:279-295), then
 // the tile loop that replaces WriteHeifImage.cpp:1017-1135 (and its five siblings).
 void CreateHeifImageInto(FormatRecordPtr formatRecord, AlphaState alphaState, const VPoint& imageSize,
-                         const SaveUIOptions& callerOptions, int output, int matrix, int primaries, avifgpu_image* img)
+                         const SaveUIOptions& callerOptions, int output, int matrix, int primaries, avifgpu_image* img,
+                         const avifgpu_icc_clut16* documentToSRGB16 = nullptr)
 {
     const bool hasAlpha = alphaState != AlphaState::None;
     const bool mono = IsMonochromeImage(formatRecord);
@@ -210,9 +211,11 @@ void CreateHeifImageInto(FormatRecordPtr formatRecord, AlphaState alphaState, co
     } else if (saveOptions.convertToSRGB && formatRecord->depth == 16) {
         // 16-bit document: lcms2's resampled 33^3 table + tetrahedral interpolation, bit-exact (include/avifgpu.h)
         if (mono || !formatRecord->iCCprofileData || formatRecord->iCCprofileSize <= 0) throw OSErrException(AVIFGPU_formatBadParameters);
-        icc16.reset(new avifgpu_icc_clut16);
-        const int rc = avifgpu_icc_prepare_clut16(formatRecord->iCCprofileData, (uint32_t)formatRecord->iCCprofileSize, icc16.get());
-        if (rc) throw OSErrException((OSErr)rc);
+        if (!documentToSRGB16) {                       // else: the caller's own table (avifgpu_icc_clut16_from_transforms), any profile
+            icc16.reset(new avifgpu_icc_clut16);
+            const int rc = avifgpu_icc_prepare_clut16(formatRecord->iCCprofileData, (uint32_t)formatRecord->iCCprofileSize, icc16.get());
+            if (rc) throw OSErrException((OSErr)rc);
+        }
     } else if (saveOptions.convertToSRGB) {
         if (formatRecord->depth != 8 || mono || !formatRecord->iCCprofileData || formatRecord->iCCprofileSize <= 0)
             throw OSErrException(AVIFGPU_formatBadParameters);
@@ -228,7 +231,7 @@ void CreateHeifImageInto(FormatRecordPtr formatRecord, AlphaState alphaState, co
     const TileSlots ts;
     if (ts.nctx == 0) { avifgpu::set_error("avifgpu_init has not succeeded: no HIP device bound (no CPU fallback)"); throw OSErrException(AVIFGPU_formatBadParameters); }
     avifgpu::IccArgs iccArgs;
-    iccArgs.f32 = iccp; iccArgs.s8 = icc8.get(); iccArgs.c16 = icc16.get(); iccArgs.s32 = iccs.get();
+    iccArgs.f32 = iccp; iccArgs.s8 = icc8.get(); iccArgs.c16 = icc16 ? icc16.get() : (saveOptions.convertToSRGB && formatRecord->depth == 16 ? documentToSRGB16 : nullptr); iccArgs.s32 = iccs.get();
 
     // Every exit path drains the contexts: no tile may still be reading a pinned buffer or writing a plane afterwards.
     auto bail = [&](OSErr e) { (void)avifgpu::wait_all(); formatRecord->data = nullptr; throw OSErrException(e); };
@@ -429,6 +432,15 @@ avifgpu_OSErr avifgpu_host_create_heif_image(avifgpu_FormatRecord* formatRecord,
                                              const avifgpu_SaveUIOptions* saveOptions, int32_t output,
                                              int32_t matrix_coefficients, int32_t color_primaries, avifgpu_image* img)
 {
+    return avifgpu_host_create_heif_image_with_table(formatRecord, alphaState, saveOptions, output, matrix_coefficients, color_primaries,
+                                                     nullptr, img);
+}
+
+avifgpu_OSErr avifgpu_host_create_heif_image_with_table(avifgpu_FormatRecord* formatRecord, int32_t alphaState,
+                                                        const avifgpu_SaveUIOptions* saveOptions, int32_t output,
+                                                        int32_t matrix_coefficients, int32_t color_primaries,
+                                                        const avifgpu_icc_clut16* documentToSRGB16, avifgpu_image* img)
+{
     if (!formatRecord || !saveOptions || !img || !formatRecord->advanceState) return AVIFGPU_formatBadParameters;
     if (matrix_coefficients < 0) {                          // "what the plug-in will attach"
         avifgpu_nclx nclx;
@@ -444,7 +456,7 @@ avifgpu_OSErr avifgpu_host_create_heif_image(avifgpu_FormatRecord* formatRecord,
         default: throw OSErrException(AVIFGPU_formatBadParameters);
         }
         CreateHeifImageInto(formatRecord, (AlphaState)alphaState, imageSize, *saveOptions, output, matrix_coefficients,
-                            color_primaries, img);
+                            color_primaries, img, documentToSRGB16);
     }, AVIFGPU_writErr);
 }
 

@@ -5,8 +5,10 @@
 // 1/MAX_ENCODEABLE_XYZ, destination = inverse of the Bradford-adapted primaries matrix scaled by MAX_ENCODEABLE_XYZ,
 // adjacent matrices multiplied in double) so the result agrees with lcms2 2.12 to float rounding
 // (tests/test_gpu_icc.py checks it against the real library).
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -265,6 +267,120 @@ extern "C" int32_t avifgpu_icc_prepare_sampled(const void* icc_profile, uint32_t
     return 0;
 }
 
+// ---- 16-bit path, ANY profile: the table read out of the caller's own transform -------------------------------------------
+// lcms2's TetrahedralInterp16 on an R-major 33^3 table of {R, G, B, 0} nodes -- the host twin of icc16_tetrahedral in
+// write_kernels.hip (same fixed-point position, same tetrahedron choice through the largest / smallest fraction, same rounding in
+// wrapping 32-bit arithmetic).  Used only to VERIFY a table that was read out of a transform.
+static void tetra16_host(const avifgpu_icc_clut16& t, const uint16_t in[3], uint16_t out[3])
+{
+    constexpr int G = AVIFGPU_ICC_CLUT_GRID;
+    uint32_t c0[3], r[3];
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t a = (uint32_t)in[k] * 32u;
+        const uint32_t f = a + (a + 0x7fffu) / 0xffffu;                                   // _cmsToFixedDomain
+        c0[k] = f >> 16; r[k] = f & 0xffffu;
+    }
+    auto node = [&](uint32_t dr, uint32_t dg, uint32_t db, int ch) -> int32_t {
+        const uint32_t R = c0[0] + dr, Gn = c0[1] + dg, B = c0[2] + db;
+        if (R >= (uint32_t)G || Gn >= (uint32_t)G || B >= (uint32_t)G) return 0;            // beyond the grid: its fraction is 0
+        return t.table[(R * G + Gn) * G + B][ch];
+    };
+    // the tetrahedron: corner 0, the corner one step along the axis of the LARGEST fraction, the corner all but one step along the
+    // axis of the SMALLEST, corner 7.  On ties the candidates give the same sum (equal fractions merge their two differences), so
+    // any consistent choice equals the library's if-tree.
+    const uint32_t mx = std::max({ r[0], r[1], r[2] }), mn = std::min({ r[0], r[1], r[2] });
+    const int amax = r[0] == mx ? 0 : (r[1] == mx ? 1 : 2);
+    const int amin = r[2] == mn ? 2 : (r[1] == mn ? 1 : 0);
+    uint32_t p1[3] = { 0, 0, 0 }, p2[3] = { 1, 1, 1 };
+    p1[amax] = 1; p2[amin] = 0;
+    const uint32_t frac[3] = { mx, r[0] + r[1] + r[2] - mx - mn, mn };
+    for (int ch = 0; ch < 3; ++ch) {
+        const int32_t v0 = node(0, 0, 0, ch), v1 = node(p1[0], p1[1], p1[2], ch), v2 = node(p2[0], p2[1], p2[2], ch), v3 = node(1, 1, 1, ch);
+        const uint32_t rest = (uint32_t)(v1 - v0) * frac[0] + (uint32_t)(v2 - v1) * frac[1] + (uint32_t)(v3 - v2) * frac[2] + 0x8001u;
+        const int32_t tt = (int32_t)rest;
+        out[ch] = (uint16_t)(v0 + ((tt + (tt >> 16)) >> 16));
+    }
+}
+
+// FixWhiteMisalignment (cmsopt.c), the last step of OptimizeByResampling: unless the obtained white is wildly off (WhitesAreEqual's
+// 0xf000 guard, evaluated channel by channel in order), the white node is patched to the exact white of the output space.
+static void fix_white_misalignment(avifgpu_icc_clut16& t)
+{
+    constexpr int G = AVIFGPU_ICC_CLUT_GRID;
+    uint16_t* white = t.table[G * G * G - 1];
+    bool patch = false;
+    for (int i = 0; i < 3; ++i) {
+        if (std::abs((int)white[i] - 0xffff) > 0xf000) break;
+        if (white[i] != 0xffff) { patch = true; break; }
+    }
+    if (patch) white[0] = white[1] = white[2] = 0xffff;
+}
+
+// For 16-bit data lcms2 turns EVERY profile pair -- matrix/TRC or LUT-based (A2B) -- into a 33^3 table + tetrahedral interpolation
+// when the transform is created (OptimizeByResampling: the last resort of _cmsOptimizePipeline, taken for 16-bit formatters with the
+// reference's flags, ColorProfileConversion.cpp:268-331).  The table is not readable THROUGH that transform (only inputs 0 and
+// 0xffff land on a node with a zero fraction: _cmsToFixedDomain(32 * in) has a non-zero low half for every other word), but lcms2
+// fills it by evaluating the linked FLOAT pipeline at the node colours (XFormSampler16: word / 65535.0 as float in,
+// _cmsQuickSaturateWord(out * 65535.0) back), and a TYPE_RGB_FLT transform of the same profiles, intent and flags evaluates exactly
+// that pipeline (none of the lossy optimisations applies to float formatters).  So a caller that links lcms2 hands over two
+// callbacks: the float transform, from which the nodes are computed the way lcms2 computes them, and the 16-bit transform it would
+// have used, against which the result is PROVEN: 4096 pseudo-random colours (uniform, neutrals with tied fractions, words around
+// the nodes) go through the 16-bit callback and through the library's own interpolation of the table; one differing sample (another
+// CMM, cmsFLAGS_NOOPTIMIZE, a different grid, a different lcms2) fails the call with AVIFGPU_formatCannotRead and the caller keeps its CPU path.
+extern "C" int32_t avifgpu_icc_clut16_from_transforms(avifgpu_transform_f32_fn float_fn, avifgpu_transform16_fn word_fn, void* user,
+                                                      avifgpu_icc_clut16* out)
+{
+    if (!float_fn || !word_fn || !out) return fail(AVIFGPU_formatBadParameters, "null transform callback / table");
+    constexpr int G = AVIFGPU_ICC_CLUT_GRID;
+    std::memset(out, 0, sizeof(*out));
+    out->grid_points = G;
+    uint16_t node[G];
+    float fnode[G];
+    for (int i = 0; i < G; ++i) {
+        node[i] = quick_saturate_word((double)i * 65535.0 / (double)(G - 1));             // _cmsQuantizeVal
+        fnode[i] = (float)(node[i] / 65535.0);                                            // XFormSampler16's input
+    }
+    {
+        std::vector<float> in((size_t)G * G * G * 3), res((size_t)G * G * G * 3);
+        for (int r = 0; r < G; ++r) for (int g = 0; g < G; ++g) for (int b = 0; b < G; ++b) {
+            float* p = &in[((size_t)(r * G + g) * G + b) * 3];
+            p[0] = fnode[r]; p[1] = fnode[g]; p[2] = fnode[b];
+        }
+        float_fn(user, in.data(), res.data(), (uint32_t)(G * G * G));
+        for (size_t i = 0; i < (size_t)G * G * G; ++i) {
+            for (int c = 0; c < 3; ++c) out->table[i][c] = quick_saturate_word((double)res[3 * i + c] * 65535.0);
+            out->table[i][3] = 0;
+        }
+    }
+    fix_white_misalignment(*out);
+    constexpr uint32_t N = 4096;
+    std::vector<uint16_t> pin(N * 3), pwant(N * 3);
+    uint64_t st = 0x9e3779b97f4a7c15ull;
+    auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(st >> 33); };
+    for (uint32_t i = 0; i < N; ++i) {
+        uint16_t* p = &pin[3 * i];
+        const uint32_t kind = i & 7;
+        if (kind == 0) { p[0] = p[1] = p[2] = (uint16_t)rnd(); }
+        else if (kind == 1) { for (int c = 0; c < 3; ++c) p[c] = (uint16_t)(node[rnd() % G] + (int)(rnd() % 3) - 1); }
+        else { for (int c = 0; c < 3; ++c) p[c] = (uint16_t)rnd(); }
+    }
+    pin[0] = pin[1] = pin[2] = 0;                                                          // both ends of the neutral axis
+    pin[3] = pin[4] = pin[5] = 0xffff;
+    word_fn(user, pin.data(), pwant.data(), N);
+    uint32_t bad = 0;
+    for (uint32_t i = 0; i < N; ++i) {
+        uint16_t got[3];
+        tetra16_host(*out, &pin[3 * i], got);
+        if (got[0] != pwant[3 * i] || got[1] != pwant[3 * i + 1] || got[2] != pwant[3 * i + 2]) ++bad;
+    }
+    if (bad) {
+        char msg[200];
+        std::snprintf(msg, sizeof(msg), "the 16-bit transform is not the 33^3 tetrahedral table of the float one (%u of %u probe colours differ): keep the CPU path", bad, N);
+        return fail(AVIFGPU_formatCannotRead, msg);
+    }
+    return 0;
+}
+
 extern "C" int32_t avifgpu_icc_prepare_shaper8(const void* icc_profile, uint32_t size, avifgpu_icc_shaper8* out)
 {
     if (!icc_profile || !out || size < 132) return fail(AVIFGPU_formatBadParameters, "bad ICC profile buffer");
@@ -335,15 +451,7 @@ extern "C" int32_t avifgpu_icc_prepare_clut16(const void* icc_profile, uint32_t 
             dst[i] = quick_saturate_word((double)o * 65535.0);
         }
     }
-    // FixWhiteMisalignment (cmsopt.c): unless the obtained white is wildly off (WhitesAreEqual's 0xf000 guard, evaluated
-    // channel by channel in order), the white node is patched to the exact white of the output space.
-    uint16_t* white = out->table[G * G * G - 1];
-    bool patch = false;
-    for (int i = 0; i < 3; ++i) {
-        if (std::abs((int)white[i] - 0xffff) > 0xf000) break;
-        if (white[i] != 0xffff) { patch = true; break; }
-    }
-    if (patch) white[0] = white[1] = white[2] = 0xffff;
+    fix_white_misalignment(*out);
     return 0;
 }
 

@@ -83,6 +83,8 @@ HOST_ABI = [
     ("avifgpu_host_save_nclx", c_int16, [POINTER(FormatRecord), POINTER(SaveUIOptions), POINTER(Nclx)]),
     ("avifgpu_host_create_heif_image", c_int16, [POINTER(FormatRecord), c_int32, POINTER(SaveUIOptions), c_int32, c_int32,
                                                  c_int32, POINTER(Image)]),
+    ("avifgpu_host_create_heif_image_with_table", c_int16, [POINTER(FormatRecord), c_int32, POINTER(SaveUIOptions), c_int32, c_int32,
+                                                            c_int32, c_void_p, POINTER(Image)]),
     ("avifgpu_host_read_heif_image", c_int16, [POINTER(Image), c_int32, POINTER(Nclx), POINTER(LoadUIOptions),
                                                POINTER(FormatRecord)]),
     # decisions of the reference-named adapters (csrc/host_decisions.cpp)

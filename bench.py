@@ -366,7 +366,9 @@ def main():
         def step5(i=0):
             gpu.write_rows(d5, r5, n5, f5.data_ptr(), f5.stride(0) * 4, [p.data_ptr() for p in p5], [p.stride(0) for p in p5],
                            mem=pkg.MEM_DEVICE, stream=stream.cuda_stream)
-        for _ in range(5):
+        # warm-up: generating the 4.3 GB frame kept the GPU busy with other kernels; ~60 ms of THIS kernel in front of the timed
+        # steps, like the clock ramp of the headline (a 5-launch warm-up read 3-8 % low, cf. profiles/r03/warmup_clock_ramp_ab.txt)
+        for _ in range(max(5, int(60 * world / 1.0))):
             step5()
         torch.cuda.synchronize(dev)
         e5 = ranks.timed(step5, k5, sync=lambda: torch.cuda.synchronize(dev))

@@ -447,6 +447,21 @@ typedef struct avifgpu_icc_clut16 {
  * `curv` tables (AVIFGPU_formatCannotRead otherwise: the caller keeps lcms2). */
 int32_t avifgpu_icc_prepare_clut16(const void* icc_profile, uint32_t size, avifgpu_icc_clut16* out);
 
+/* The same table for ANY profile -- LUT-based (A2B) ones included -- computed from transforms the CALLER owns.  For 16-bit formatters
+ * lcms2 resamples every profile pair into a 33^3 table + tetrahedral interpolation when the transform is created (the reference's
+ * flags, ColorProfileConversion.cpp:268-331), filling it from the linked float pipeline -- which is what a TYPE_RGB_FLT transform of
+ * the same profiles, intent and flags evaluates.  The plug-in, which links lcms2, passes
+ *   float_fn: cmsDoTransform on that float transform (interleaved RGB floats, 1.0 = white), used to compute the 35937 nodes the way
+ *             lcms2 computes them, and
+ *   word_fn:  cmsDoTransform on the TYPE_RGB_16 transform it would have used per row (interleaved RGB words in [0, 65535]), used to
+ *             PROVE the table: 4096 probe colours must come out of the library's interpolation exactly as out of word_fn.
+ * AVIFGPU_formatCannotRead (keep the CPU path) if they do not -- another CMM, cmsFLAGS_NOOPTIMIZE, another grid.  Host-only: no device
+ * needed; both callbacks are called on the calling thread, before the function returns. */
+typedef void (*avifgpu_transform_f32_fn)(void* user, const float* rgb_in, float* rgb_out, uint32_t pixel_count);
+typedef void (*avifgpu_transform16_fn)(void* user, const uint16_t* rgb_in, uint16_t* rgb_out, uint32_t pixel_count);
+int32_t avifgpu_icc_clut16_from_transforms(avifgpu_transform_f32_fn float_fn, avifgpu_transform16_fn word_fn, void* user,
+                                           avifgpu_icc_clut16* out);
+
 /* avifgpu_write_rows for 16-bit RGB(A) documents with that transform applied first; alpha takes the reference's
  * [0,32768] -> [0,65535] -> [0,32768] round trip (cmsFLAGS_COPY_ALPHA in between). */
 int32_t avifgpu_write_rows_icc16(const avifgpu_write_desc* desc, const avifgpu_icc_clut16* icc,

@@ -155,6 +155,15 @@ avifgpu_OSErr avifgpu_host_create_heif_image(avifgpu_FormatRecord* formatRecord,
                                              int32_t matrix_coefficients, int32_t color_primaries,
                                              avifgpu_image* img);
 
+/* The same with the document -> sRGB table of a 16-bit RGB document supplied by the caller (avifgpu_icc_clut16_from_transforms:
+ * LUT-based and any other profile lcms2 opens; integration/LcmsTableBridge.cpp builds it).  The table is used exactly where the
+ * plain entry would have parsed the profile itself -- depth 16 and the decision (explicit or LIKE_PLUGIN) says "to sRGB" -- and is
+ * ignored everywhere else; NULL = the plain entry. */
+avifgpu_OSErr avifgpu_host_create_heif_image_with_table(avifgpu_FormatRecord* formatRecord, int32_t alphaState,
+                                                        const avifgpu_SaveUIOptions* saveOptions, int32_t output,
+                                                        int32_t matrix_coefficients, int32_t color_primaries,
+                                                        const avifgpu_icc_clut16* documentToSRGB16, avifgpu_image* img);
+
 /*
  * Read direction: one entry for the six ReadHeifImage{Gray,RGB}{Eight,Sixteen,ThirtyTwo}Bit functions
  * (dispatch as DoReadContinue, Read.cpp:587-630; host depth from formatRecord->depth).  Sets loPlane/hiPlane/

@@ -15,6 +15,7 @@
 #include <lcms2.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <wchar.h>
 
@@ -311,4 +312,107 @@ int32_t oracle_icc_convert_rows_to_srgb16(const void* icc, uint32_t icc_size, in
     if (out) cmsCloseProfile(out);
     cmsDeleteContext(ctx);
     return rc;
+}
+
+/* ---- LUT-based (A2B) document profiles + a transform handle whose callback has avifgpu_transform16_fn's shape ----------------
+ * Test material for avifgpu_icc_clut16_from_transforms: the plug-in would pass cmsDoTransform on its own 16-bit transform
+ * (ColorProfileConversion.cpp:268-331) and on a float twin of it; the tests pass oracle_icc_transform16_run[_float] on transforms
+ * created the same way. */
+
+typedef struct { int variant; } a2b_cargo;
+static cmsInt32Number a2b_sampler(const cmsUInt16Number in[], cmsUInt16Number out[], void* cargo)
+{
+    /* a display-like device with a non-separable twist (so no matrix/TRC model could stand in for the table): gamma 2.2,
+     * Display-P3-ish primaries adapted to D50, a cross-channel saturation term, encoded as ICC v4 Lab */
+    const a2b_cargo* c = (const a2b_cargo*)cargo;
+    double rgb[3], lin[3];
+    for (int k = 0; k < 3; ++k) { rgb[k] = in[k] / 65535.0; lin[k] = pow(rgb[k], 2.2); }
+    const double twist = c->variant ? 0.12 : 0.05;
+    const double mean = (lin[0] + lin[1] + lin[2]) / 3.0;
+    for (int k = 0; k < 3; ++k) lin[k] = lin[k] + twist * (lin[k] - mean) * (1.0 - mean) + (c->variant ? 0.02 * lin[(k + 1) % 3] * lin[(k + 2) % 3] : 0.0);
+    static const double M[3][3] = { { 0.5151, 0.2920, 0.1571 }, { 0.2412, 0.6922, 0.0666 }, { -0.0011, 0.0419, 0.7841 } };
+    cmsCIEXYZ xyz = { M[0][0] * lin[0] + M[0][1] * lin[1] + M[0][2] * lin[2],
+                      M[1][0] * lin[0] + M[1][1] * lin[1] + M[1][2] * lin[2],
+                      M[2][0] * lin[0] + M[2][1] * lin[1] + M[2][2] * lin[2] };
+    if (xyz.X < 0) xyz.X = 0; if (xyz.Y < 0) xyz.Y = 0; if (xyz.Z < 0) xyz.Z = 0;
+    cmsCIELab lab;
+    cmsXYZ2Lab(cmsD50_XYZ(), &lab, &xyz);
+    cmsFloat2LabEncoded(out, &lab);
+    return 1;
+}
+
+/* variant 0 / 1: v4 RGB display profile holding ONLY an AToB0 tag (curves -> 17^3 CLUT -> curves, PCS Lab); returns its size. */
+int32_t oracle_icc_make_a2b_profile(int32_t variant, void* out, uint32_t cap)
+{
+    cmsContext ctx = cmsCreateContext(NULL, NULL);
+    cmsHPROFILE h = cmsCreateProfilePlaceholder(ctx);
+    int32_t rc = -1;
+    if (!h) { cmsDeleteContext(ctx); return -1; }
+    cmsSetProfileVersion(h, 4.3);
+    cmsSetDeviceClass(h, cmsSigDisplayClass);
+    cmsSetColorSpace(h, cmsSigRgbData);
+    cmsSetPCS(h, cmsSigLabData);
+    cmsSetHeaderRenderingIntent(h, INTENT_PERCEPTUAL);
+    cmsPipeline* p = cmsPipelineAlloc(ctx, 3, 3);
+    cmsToneCurve* pre = cmsBuildGamma(ctx, variant ? 1.1 : 1.0);
+    cmsToneCurve* pre3[3] = { pre, pre, pre };
+    cmsStage* clut = cmsStageAllocCLut16bit(ctx, 17, 3, 3, NULL);
+    a2b_cargo cargo = { variant };
+    int ok = p && pre && clut && cmsStageSampleCLut16bit(clut, a2b_sampler, &cargo, 0);
+    if (ok) {
+        cmsPipelineInsertStage(p, cmsAT_END, cmsStageAllocToneCurves(ctx, 3, pre3));
+        cmsPipelineInsertStage(p, cmsAT_END, clut);
+        cmsPipelineInsertStage(p, cmsAT_END, cmsStageAllocToneCurves(ctx, 3, NULL));
+        cmsMLU* d = cmsMLUalloc(ctx, 1);
+        cmsMLUsetASCII(d, "en", "US", variant ? "avifgpu test A2B profile (1)" : "avifgpu test A2B profile (0)");
+        ok = cmsWriteTag(h, cmsSigAToB0Tag, p) && cmsWriteTag(h, cmsSigMediaWhitePointTag, cmsD50_XYZ()) &&
+             cmsWriteTag(h, cmsSigProfileDescriptionTag, d);
+        cmsMLUfree(d);
+        cmsUInt32Number n = 0;
+        if (ok && cmsSaveProfileToMem(h, NULL, &n) && n <= cap && cmsSaveProfileToMem(h, out, &n)) rc = (int32_t)n;
+    }
+    if (pre) cmsFreeToneCurve(pre);
+    if (p) cmsPipelineFree(p);
+    cmsCloseProfile(h);
+    cmsDeleteContext(ctx);
+    return rc;
+}
+
+typedef struct { cmsContext ctx; cmsHTRANSFORM t, tf; } transform16_handle;
+
+/* document profile -> sRGB, TYPE_RGB_16 both sides, the reference's intent and flags (ColorProfileConversion.cpp:268-331);
+ * extra_flags lets a test ask for what the plug-in never does (cmsFLAGS_NOOPTIMIZE = 0x0100) to see the read-out refuse it. */
+void* oracle_icc_transform16_open(const void* icc, uint32_t icc_size, uint32_t extra_flags)
+{
+    transform16_handle* h = (transform16_handle*)calloc(1, sizeof(*h));
+    if (!h) return NULL;
+    h->ctx = cmsCreateContext(NULL, NULL);
+    cmsHPROFILE doc = cmsOpenProfileFromMemTHR(h->ctx, icc, icc_size);
+    cmsHPROFILE out = cmsCreate_sRGBProfileTHR(h->ctx);
+    if (doc && out)
+    {
+        h->t = cmsCreateTransformTHR(h->ctx, doc, TYPE_RGB_16, out, TYPE_RGB_16, INTENT_PERCEPTUAL, cmsFLAGS_BLACKPOINTCOMPENSATION | extra_flags);
+        h->tf = cmsCreateTransformTHR(h->ctx, doc, TYPE_RGB_FLT, out, TYPE_RGB_FLT, INTENT_PERCEPTUAL, cmsFLAGS_BLACKPOINTCOMPENSATION);
+    }
+    if (doc) cmsCloseProfile(doc);
+    if (out) cmsCloseProfile(out);
+    if (!h->t || !h->tf) { if (h->t) cmsDeleteTransform(h->t); if (h->tf) cmsDeleteTransform(h->tf); cmsDeleteContext(h->ctx); free(h); return NULL; }
+    return h;
+}
+void oracle_icc_transform16_run(void* user, const uint16_t* in, uint16_t* out, uint32_t pixel_count)
+{
+    cmsDoTransform(((transform16_handle*)user)->t, in, out, pixel_count);
+}
+void oracle_icc_transform16_run_float(void* user, const float* in, float* out, uint32_t pixel_count)
+{
+    cmsDoTransform(((transform16_handle*)user)->tf, in, out, pixel_count);
+}
+void oracle_icc_transform16_close(void* user)
+{
+    transform16_handle* h = (transform16_handle*)user;
+    if (!h) return;
+    cmsDeleteTransform(h->t);
+    cmsDeleteTransform(h->tf);
+    cmsDeleteContext(h->ctx);
+    free(h);
 }

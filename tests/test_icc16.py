@@ -30,7 +30,30 @@ def lcms():
     L.oracle_icc_convert_rows_to_srgb16.restype = ctypes.c_int32
     L.oracle_icc_convert_rows_to_srgb16.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
                                                      ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+    L.oracle_icc_make_a2b_profile.restype = ctypes.c_int32
+    L.oracle_icc_make_a2b_profile.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_uint32]
+    L.oracle_icc_transform16_open.restype = ctypes.c_void_p
+    L.oracle_icc_transform16_open.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
+    L.oracle_icc_transform16_close.argtypes = [ctypes.c_void_p]
     return L
+
+
+def _a2b_profile(L, variant):
+    buf = ctypes.create_string_buffer(1 << 18)
+    n = L.oracle_icc_make_a2b_profile(variant, buf, len(buf))
+    assert n > 0
+    return buf.raw[:n]
+
+
+def _clut_from_transform(L, icc, extra_flags=0):
+    """What the plug-in would do: cmsDoTransform on the 16-bit transform it already owns and on a float twin, as callbacks."""
+    h = L.oracle_icc_transform16_open(icc, len(icc), extra_flags)
+    assert h
+    t = pkg.IccClut16()
+    rc = pkg.load().avifgpu_icc_clut16_from_transforms(ctypes.cast(L.oracle_icc_transform16_run_float, ctypes.c_void_p),
+                                                       ctypes.cast(L.oracle_icc_transform16_run, ctypes.c_void_p), h, ctypes.byref(t))
+    L.oracle_icc_transform16_close(h)
+    return rc, t
 
 
 def _profile(L, kind, trc, g):
@@ -99,6 +122,86 @@ def test_table_and_interpolation_reproduce_lcms2(lcms, name, kind, trc, g):
     assert np.array_equal(got, want.astype(np.int64)), name
 
 
+@pytest.mark.parametrize("name,kind,trc,g", PROFILES)
+def test_table_read_out_of_a_transform_equals_the_built_one(lcms, name, kind, trc, g):
+    """avifgpu_icc_clut16_from_transforms on lcms2's own transforms returns the table avifgpu_icc_prepare_clut16 builds from
+    the profile bytes: two routes to the same 35937 nodes."""
+    icc = _profile(lcms, kind, trc, g)
+    rc, t = _clut_from_transform(lcms, icc)
+    assert rc == 0, pkg.load().avifgpu_last_error()
+    assert t.grid_points == 33
+    assert np.array_equal(np.ctypeslib.as_array(t.table), np.ctypeslib.as_array(_clut(icc).table)), name
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_table_read_out_of_an_a2b_transform(lcms, variant):
+    """LUT-based document profile (AToB0 only: curves, 17^3 CLUT, curves, PCS Lab) -- nothing the profile parser accepts, but the
+    caller's transform is still a 33^3 table: the read-out succeeds, proves itself, and interpolating it (numpy restatement)
+    reproduces lcms2 on 200k colours."""
+    icc = _a2b_profile(lcms, variant)
+    t0 = pkg.IccClut16()
+    assert pkg.load().avifgpu_icc_prepare_clut16(icc, len(icc), ctypes.byref(t0)) == pkg.formatCannotRead
+    rc, t = _clut_from_transform(lcms, icc)
+    assert rc == 0, pkg.load().avifgpu_last_error()
+    table = np.ctypeslib.as_array(t.table).reshape(33, 33, 33, 4)
+    assert not table[..., 3].any()
+    inp = _samples(200_000, 65535, 3 + variant)
+    want = inp.astype(np.uint16).reshape(1, -1).copy()
+    assert lcms.oracle_icc_convert_rows_to_srgb16(icc, len(icc), 0, 1, want.ctypes.data, inp.shape[0], 1, want.strides[0]) == 0
+    assert np.array_equal(_tetrahedral(table[..., :3], inp), want.reshape(-1, 3).astype(np.int64))
+    # the twist is really there: no neutral-preserving matrix/TRC model gives these greens from these neutrals
+    assert len(np.unique(table[:, :, :, 1])) > 1000
+
+
+BRIDGE = os.path.join(os.path.dirname(ICC_LIB), "..", "avif-format_amd", "libavifgpu_lcms_bridge.so")
+
+
+def _bridge():
+    """integration/LcmsTableBridge.cpp, the glue the plug-in's adapter compiles: built next to the library where lcms2.h exists."""
+    if not os.path.exists(BRIDGE):
+        pytest.skip("libavifgpu_lcms_bridge.so not built (lcms2 absent)")
+    pkg.load()                                                  # the bridge resolves avifgpu_* against the already loaded library
+    B = ctypes.CDLL(BRIDGE)
+    B.avifgpu_lcms_document_to_srgb_clut16.restype = ctypes.c_int32
+    B.avifgpu_lcms_document_to_srgb_clut16.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(pkg.IccClut16)]
+    return B
+
+
+def _bridge_table(icc):
+    t = pkg.IccClut16()
+    rc = _bridge().avifgpu_lcms_document_to_srgb_clut16(icc, len(icc), ctypes.byref(t))
+    return rc, t
+
+
+def test_adapter_bridge_builds_the_same_tables(lcms):
+    """The adapter-side helper (its own lcms2 context, transforms created as InitializeForSRGBConversion creates them) returns
+    the tables of the two routes above: the parser's for a matrix/TRC profile, the test handle's for the LUT-based ones."""
+    icc = _profile(lcms, 2, 0, 1.8)
+    rc, t = _bridge_table(icc)
+    assert rc == 0, pkg.load().avifgpu_last_error()
+    assert np.array_equal(np.ctypeslib.as_array(t.table), np.ctypeslib.as_array(_clut(icc).table))
+    for variant in (0, 1):
+        icc = _a2b_profile(lcms, variant)
+        rc, t = _bridge_table(icc)
+        assert rc == 0, pkg.load().avifgpu_last_error()
+        assert np.array_equal(np.ctypeslib.as_array(t.table), np.ctypeslib.as_array(_clut_from_transform(lcms, icc)[1].table))
+    assert _bridge_table(bytes(400))[0] == pkg.formatCannotRead                       # not a profile
+    gray = bytearray(_profile(lcms, 0, 0, 2.2)); gray[16:20] = b"GRAY"
+    assert _bridge_table(bytes(gray))[0] == pkg.formatCannotRead                      # not an RGB profile
+    assert _bridge().avifgpu_lcms_document_to_srgb_clut16(None, 0, None) == pkg.formatBadParameters
+
+
+def test_read_out_refuses_a_transform_that_is_not_a_table(lcms):
+    """cmsFLAGS_NOOPTIMIZE keeps the 16-bit transform on the float pipeline (curves + matrix evaluated per pixel): its results are
+    not the interpolation of the node values, the proof notices, the caller keeps the CPU path.  Null arguments are caller errors."""
+    icc = _profile(lcms, 2, 0, 1.8)
+    rc, _ = _clut_from_transform(lcms, icc, extra_flags=0x0100)
+    assert rc == pkg.formatCannotRead
+    assert b"is not the 33^3" in pkg.load().avifgpu_last_error()
+    t = pkg.IccClut16()
+    assert pkg.load().avifgpu_icc_clut16_from_transforms(None, None, None, ctypes.byref(t)) == pkg.formatBadParameters
+
+
 def test_prepare_clut16_rejects_what_it_cannot_do(lcms):
     t = pkg.IccClut16()
     assert pkg.load().avifgpu_icc_prepare_clut16(bytes(300), 300, ctypes.byref(t)) == pkg.formatCannotRead
@@ -159,6 +262,27 @@ def test_gpu_16bit_rows_bit_exact(gpu, lcms, name, kind, trc, g):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 1])
+def test_gpu_16bit_rows_bit_exact_for_an_a2b_profile(gpu, lcms, variant):
+    """The same 4 M pixel sweep for a LUT-based document profile, its table read out of the caller's transform."""
+    icc = _a2b_profile(lcms, variant)
+    rc, clut = _clut_from_transform(lcms, icc)
+    assert rc == 0
+    w, h = 2048, 2048
+    src = _samples(w * h, 32768, 17).astype(np.uint16).reshape(h, w * 3).copy()
+    conv = src.copy()
+    assert lcms.oracle_icc_convert_rows_to_srgb16(icc, len(icc), 0, 0, conv.ctypes.data, w, h, conv.strides[0]) == 0
+    for kw in (dict(bit_depth=12, output=pkg.OUT_REFERENCE),
+               dict(bit_depth=8, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_422, matrix_coefficients=pkg.MATRIX_BT601)):
+        d = pkg.WriteDesc(width=w, height=h, depth=16, planes=3, alpha_state=pkg.ALPHA_NONE, **kw)
+        want = harness.oracle_write(d, conv)
+        got = _gpu(gpu, d, src, clut)
+        for pl in want:
+            assert np.array_equal(got[pl], want[pl]), (variant, kw, pl)
+        assert "icc=5" in gpu.last_kernel()
+
+
+@pytest.mark.gpu
 def test_gpu_icc16_then_every_output_kind(gpu, lcms):
     """RGBA (alpha takes the two range maps), premultiply, 8/10-bit rescale, fused YCbCr 4:2:0 / 4:2:2, ragged size."""
     icc = _profile(lcms, 2, 0, 1.8)
@@ -206,6 +330,55 @@ def test_host_shim_converts_16bit_document_to_srgb(gpu, lcms):
     raw = (ctypes.c_uint8 * (img.stride[0] * d.height)).from_address(img.plane[0])
     got = np.frombuffer(raw, dtype=np.uint8).reshape(d.height, img.stride[0])[:, :d.width * 6].view(np.uint16)
     assert np.array_equal(got, want[0])
+    gpu.lib.avifgpu_image_free(ctypes.byref(img))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("planes", [3, 4])
+def test_host_shim_converts_a_lut_based_16bit_document_with_the_callers_table(gpu, lcms, planes):
+    """The adapter's flow for an A2B profile: the plain entry refuses the profile (formatCannotRead), the bridge computes the
+    table from lcms2, avifgpu_host_create_heif_image_with_table converts with it -- decisions still made like the plug-in's."""
+    from fake_host import FakeHost
+    H = pkg.host
+    icc = _a2b_profile(lcms, 1)
+    alpha = pkg.ALPHA_STRAIGHT if planes == 4 else pkg.ALPHA_NONE
+    d = pkg.WriteDesc(width=389, height=53, depth=16, planes=planes, bit_depth=10, alpha_state=alpha, output=pkg.OUT_REFERENCE)
+    src = np.minimum(harness.make_write_source(d, seed=9), 32768)
+    conv = src.copy()
+    assert lcms.oracle_icc_convert_rows_to_srgb16(icc, len(icc), int(planes == 4), 0, conv.ctypes.data, d.width, d.height, conv.strides[0]) == 0
+    want = harness.oracle_write(d, conv)
+    keep = ctypes.create_string_buffer(icc, len(icc))
+    opts = H.SaveUIOptions(imageBitDepth=10, hdrTransferFunction=pkg.TRANSFER_CLIP, pq=H.PQOptions(1000), chromaSubsampling=pkg.CHROMA_420,
+                           lossless=0, keepColorProfile=0, iccDecision=H.ICC_LIKE_PLUGIN)
+
+    def save(table):
+        host = FakeHost(d.width, d.height, 16, planes, max_data=d.width * 2 * planes * 9, image=src)
+        host.fr.iCCprofileData = ctypes.cast(keep, ctypes.c_void_p)
+        host.fr.iCCprofileSize = len(icc)
+        img = H.Image()
+        code = gpu.lib.avifgpu_host_create_heif_image_with_table(ctypes.byref(host.fr), alpha, ctypes.byref(opts), pkg.OUT_REFERENCE,
+                                                                 pkg.MATRIX_BT601, pkg.PRIMARIES_BT709,
+                                                                 ctypes.byref(table) if table is not None else None, ctypes.byref(img))
+        return code, img
+
+    code, img = save(None)
+    assert code == pkg.formatCannotRead
+    gpu.lib.avifgpu_image_free(ctypes.byref(img))
+    rc, table = _bridge_table(icc)
+    assert rc == 0, gpu.lib.avifgpu_last_error()
+    code, img = save(table)
+    assert code == 0, gpu.lib.avifgpu_last_error()
+    raw = (ctypes.c_uint8 * (img.stride[0] * d.height)).from_address(img.plane[0])
+    got = np.frombuffer(raw, dtype=np.uint8).reshape(d.height, img.stride[0])[:, :d.width * 2 * planes].view(np.uint16)
+    assert np.array_equal(got, want[0])
+    gpu.lib.avifgpu_image_free(ctypes.byref(img))
+    # keepColorProfile: the decision says "no conversion" and the table is ignored
+    opts.keepColorProfile = 1
+    code, img = save(table)
+    assert code == 0
+    raw = (ctypes.c_uint8 * (img.stride[0] * d.height)).from_address(img.plane[0])
+    got = np.frombuffer(raw, dtype=np.uint8).reshape(d.height, img.stride[0])[:, :d.width * 2 * planes].view(np.uint16)
+    assert np.array_equal(got, harness.oracle_write(d, src)[0])
     gpu.lib.avifgpu_image_free(ctypes.byref(img))
 
 

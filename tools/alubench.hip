@@ -40,6 +40,56 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed)
     if (s == 123.25f) out[0] = s;
 }
 
+// integer probes for the 16-bit ICC stage (lcms2's tetrahedral interpolation): which forms are full rate
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+template <int OP>
+__global__ __launch_bounds__(256) void ki(float* out, int iters, float seed)
+{
+    unsigned a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (unsigned)(seed * 1000.0f) + 977u * (threadIdx.x + i);
+    const unsigned w = (unsigned)(seed * 77.0f) | 0x10001u;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if constexpr (OP == 0) a[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a[i]), __builtin_bit_cast(us2, w), a[i], false);
+            if constexpr (OP == 1) a[i] = (unsigned)__mul24((int)a[i], (int)w) + 3u;                                     // v_mad_i32_i24
+            if constexpr (OP == 2) a[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(us2, a[i] + 0x10001u), __builtin_bit_cast(us2, 0x80008000u))) + 1u;   // pk_min_u16 + add
+            if constexpr (OP == 3) a[i] = __builtin_amdgcn_perm(a[i], w, 0x05040100u) + 1u;                              // v_perm_b32 + add
+            if constexpr (OP == 4) a[i] = __builtin_amdgcn_ubfe(a[i], 10, 16) + w;                                       // v_bfe_u32 + add
+            if constexpr (OP == 5) a[i] = max(min(a[i], w), min(max(a[i], w), a[(i + 1) & 7]));                               // v_med3_u32
+            if constexpr (OP == 6) a[i] = a[i] * w;                                                                      // v_mul_lo_u32
+            if constexpr (OP == 7) a[i] = (a[i] << 5) + w;                                                               // v_lshl_add_u32
+        }
+    }
+    unsigned s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += a[i];
+    if (s == 123u) out[0] = (float)s;
+}
+
+template <int OP> void runi(const char* name, double ops_per_iter_per_lane)
+{
+    float* d; CK(hipMalloc(&d, 64));
+    const int blocks = 256 * 8, iters = 2000;
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    hipLaunchKernelGGL((ki<OP>), dim3(blocks), dim3(256), 0, 0, d, iters, 1.5f);
+    CK(hipDeviceSynchronize());
+    std::vector<float> ts;
+    for (int r = 0; r < 5; ++r) {
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL((ki<OP>), dim3(blocks), dim3(256), 0, 0, d, iters, 1.5f);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b)); ts.push_back(ms);
+    }
+    std::sort(ts.begin(), ts.end());
+    const double lane_ops = (double)blocks * 256 * iters * ops_per_iter_per_lane;
+    const double per_simd_wave_instr = lane_ops / 64.0 / 1024.0;
+    printf("%-28s %8.3f ms  %8.2f Tlane-op/s   %6.2f cycles/wave-instr @2.4GHz-equivalent\n", name, ts[2],
+           lane_ops / ts[2] / 1e9, ts[2] * 1e-3 * 2.4e9 / per_simd_wave_instr);
+    CK(hipFree(d));
+}
+
 template <int OP> void run(const char* name, double ops_per_iter_per_lane)
 {
     float* d; CK(hipMalloc(&d, 64));
@@ -72,5 +122,13 @@ int main()
     run<7>("v_sqrt_f32", 8);
     run<5>("exp + 1 fma (per pair)", 8);
     run<6>("exp + 3 fma (per quad)", 8);
+    runi<0>("v_dot2_u32_u16", 8);
+    runi<1>("v_mad_i32_i24", 8);
+    runi<2>("v_pk_min_u16 + v_pk_add", 16);
+    runi<3>("v_perm_b32 + v_add", 16);
+    runi<4>("v_bfe_u32 + v_add", 16);
+    runi<5>("v_med3_u32", 8);
+    runi<6>("v_mul_lo_u32", 8);
+    runi<7>("v_lshl_add_u32", 8);
     return 0;
 }
