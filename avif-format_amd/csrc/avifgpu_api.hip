@@ -200,8 +200,8 @@ int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p)
 {
     if (t->grid_points != AVIFGPU_ICC_CLUT_GRID) return fail(AVIFGPU_formatBadParameters, "16-bit ICC table: grid_points must be 33");
     const size_t n = sizeof(t->table);
-    // Device layout: one 128-byte RECORD (a cache line) per cell, seven 16-byte units of two nodes each (8 bytes per node; corner
-    // j = 4*dr + 2*dg + db): unit 0 = {corner 0, corner 7}, which every tetrahedron uses, and unit 1 + k = {corner 4 >> amax,
+    // Device layout: one 128-byte RECORD (a cache line) per cell, seven 16-byte units of two nodes each (stored channel by channel
+    // as node pairs, the operand form of v_dot2_u32_u16 -- kernel_params.h; corner j = 4*dr + 2*dg + db): unit 0 = {corner 0, corner 7}, which every tetrahedron uses, and unit 1 + k = {corner 4 >> amax,
     // corner 7 - (4 >> amin)} for the six orders of (axis of the largest fraction, axis of the smallest), k = 2*amax + amin -
     // (amin > amax) -- so the four nodes of a pixel's tetrahedron arrive in TWO 16-byte gathers from ONE line, instead of four
     // 8-byte gathers (or, in lcms2's node-major table, up to four lines 8.7 KiB / 264 B apart).  Cells exist for index 32 on every
@@ -225,10 +225,24 @@ int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p)
             for (size_t g = 0; g < G; ++g)
                 for (size_t b = 0; b < G; ++b) {
                     uint16_t* dst = rec.data() + ((r * G + g) * G + b) * kRecU16;
-                    auto put = [&](int unit, int half, int j) {            // node of corner j -> 8 bytes at unit * 16 + half * 8
+                    auto put = [&](int unit, int half, int j) {            // node of corner j -> its place in the unit
                         const size_t rr = r + ((j >> 2) & 1), gg = g + ((j >> 1) & 1), bb = b + (j & 1);
-                        if (rr < G && gg < G && bb < G) memcpy(dst + 8 * unit + 4 * half, t->table[(rr * G + gg) * G + bb], 8);
+                        if (!(rr < G && gg < G && bb < G)) return;
+                        const uint16_t* node = t->table[(rr * G + gg) * G + bb];
+#if AG_ICC16_DOT2
+                        for (int ch = 0; ch < 3; ++ch) dst[8 * unit + 2 * ch + half] = node[ch];      // {a.R, b.R, a.G, b.G, a.B, b.B, 0, 0}
+#else
+                        memcpy(dst + 8 * unit + 4 * half, node, 8);                                     // {a.R, a.G, a.B, 0, b.R, b.G, b.B, 0}
+#endif
                     };
+#if AG_ICC16_DOT2
+                    put(kIcc16BaseUnit, 0, 0); put(kIcc16BaseUnit, 1, 7);
+                    for (int idx = 0; idx < 8; ++idx) {
+                        const int amax = kIcc16AxesOfIdx[idx][0], amin = kIcc16AxesOfIdx[idx][1];
+                        if (amax < 0) continue;
+                        put(idx, 0, 4 >> amax); put(idx, 1, 7 - (4 >> amin));
+                    }
+#else
                     put(0, 0, 0); put(0, 1, 7);
                     for (int amax = 0; amax < 3; ++amax)
                         for (int amin = 0; amin < 3; ++amin) {
@@ -236,6 +250,7 @@ int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p)
                             const int k = 2 * amax + amin - (amin > amax ? 1 : 0);
                             put(1 + k, 0, 4 >> amax); put(1 + k, 1, 7 - (4 >> amin));
                         }
+#endif
                 }
         e = hipDeviceSynchronize();                             // a launch may still be reading the previous table
         if (e == hipSuccess) e = hipMemcpy(c.icc16, rec.data(), rec_bytes, hipMemcpyHostToDevice);

@@ -14,6 +14,17 @@ enum : int { kHotDefault = 1 | 2 | 4 };
 
 // 16-bit ICC table on the device: bytes per cell record (upload_icc16 builds it, icc16_tetrahedral reads it)
 enum : int { kIcc16RecBytes = 128 };
+// Record layout / interpolation form: 1 = node PAIRS per channel ({a.R|b.R<<16, a.G|b.G<<16, a.B|b.B<<16, 0} per 16-byte unit) feeding
+// v_dot2_u32_u16 on weights, 0 = two whole nodes per unit and differences x fractions (round 2).  Shared by the uploader and the kernel.
+#ifndef AG_ICC16_DOT2
+#define AG_ICC16_DOT2 1
+#endif
+// ... and in that layout the unit of a cell record is picked by the three compares of the fractions,
+// idx = (r0 >= r1) + 2 (r1 >= r2) + 4 (r0 >= r2): unit idx holds {corner 4 >> amax, corner 7 - (4 >> amin)} of the order idx stands
+// for, as (amax, amin) below; idx 3 and 4 are contradictions, unit 3 holds {corner 0, corner 7}, unit 4 is empty.
+enum : int { kIcc16BaseUnit = 3 };
+//                                         idx:      0        1        2      3 (base)   4 (none)    5        6        7
+constexpr int kIcc16AxesOfIdx[8][2] = { { 2, 0 }, { 2, 1 }, { 1, 0 }, { -1, -1 }, { -1, -1 }, { 0, 1 }, { 1, 2 }, { 0, 2 } };
 
 struct WriteParams {
     const uint8_t* src;          // row `row0`, interleaved

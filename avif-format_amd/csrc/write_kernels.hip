@@ -460,10 +460,76 @@ AG_DEV void icc16_tetrahedral(const uint16_t* __restrict__ clut, const uint32_t 
     }
 }
 
+#if AG_ICC16_DOT2
+// The same transform in the form this kernel's bound asks for (it is VALU-issue bound: profiles/r03/pmc_icc16_random_vs_photo.json):
+//  * host sample -> 16.16 grid position in one expression.  With j = icc16_host_to_lcms(i) the library's position is
+//    32 j + ((32 j + 0x7fff) / 0xffff) = (j << 5) + ((j + 1024) >> 11); for i <= 32768 that equals
+//    (65537 i + 512 - (i > 16448 ? 32769 : 0)) >> 10 (tests/test_icc16.py checks all 32769 inputs): 5 operations instead of 9.
+//  * the tetrahedron from three compares: idx = (r0 >= r1) + 2 (r1 >= r2) + 4 (r0 >= r2) picks the record unit from a packed constant.
+//  * Rest = (p1-p0) ra + (p2-p1) rb + (p3-p2) rc + 0x8001 regrouped by NODE: p0 (0xffff - ra) + p1 (ra - rb) + p2 (rb - rc) + p3 rc
+//    + (0x8001 + p0 - (p0 << 16)) -- the same value modulo 2^32, which is all the library's int32 arithmetic keeps -- so that two
+//    v_dot2_u32_u16 on node pairs (the record stores them paired per channel) replace three subtractions and three multiplies.
+AG_DEV uint32_t icc16_host_to_fixed(uint32_t i)                // i <= 32768
+{
+    // both factors fit 24 bits, the sum 32.  Spelled out: left to itself instruction selection takes v_mad_u64_u32 (quarter rate) for two of three
+    uint32_t t;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t) : "v"(i), "s"(65537u), "v"(i > 16448u ? 512u - 32769u : 512u));
+    return t >> 10;
+}
+AG_DEV uint32_t umax3(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_max3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+AG_DEV uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_min3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+AG_DEV uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_med3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+// host[] <= 32768 (the caller clamps: packed, as the row arrives)
+AG_DEV void icc16_tetrahedral_host(const uint16_t* __restrict__ clut, const uint32_t (&host)[3], uint32_t (&out)[3])
+{
+    constexpr uint32_t G = AVIFGPU_ICC_CLUT_GRID;
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    uint32_t c0i[3], r[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t f = icc16_host_to_fixed(host[k]);
+        c0i[k] = f >> 16;
+        r[k] = f & 0xffffu;
+    }
+    const uint32_t cell_off = ((c0i[0] * G + c0i[1]) * G + c0i[2]) * (uint32_t)kIcc16RecBytes;      // < 2^23: 32-bit offsets from the table base
+    const uint32_t mx = umax3(r[0], r[1], r[2]), mn = umin3(r[0], r[1], r[2]), md = umed3(r[0], r[1], r[2]);
+    // the record is addressed by the outcome of the three compares, idx = (r0 >= r1) + 2 (r1 >= r2) + 4 (r0 >= r2): unit idx holds the
+    // middle node pair of that order (upload_icc16, kIcc16UnitOfIdx); idx 3 and 4 cannot occur -- unit 3 holds {corner 0, corner 7}.
+    // Ties resolve to ANY order holding a maximal and a minimal axis: the sum is the same.  (v_cmp + v_addc_co: idx = 2 idx + carry.)
+    // Spelled out (6 instructions; instruction selection makes 9 of the C form, whatever its shape): the compare results are consumed as
+    // carry-ins.  Each mask is read two or more VALU instructions after its compare (the VALU-writes-SGPR wait states of gfx950).
+    uint32_t idx;
+    uint64_t m02, m12, m01;
+    asm("v_cmp_ge_u32_e64 %1, %4, %6\n\t"
+        "v_cmp_ge_u32_e64 %2, %5, %6\n\t"
+        "v_cmp_ge_u32_e64 %3, %4, %5\n\t"
+        "v_cndmask_b32_e64 %0, 0, 1, %1\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %2\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %3"
+        : "=&v"(idx), "=&s"(m02), "=&s"(m12), "=&s"(m01) : "v"(r[0]), "v"(r[1]), "v"(r[2]) : "vcc");
+    const uint32_t unit_off = cell_off + (idx << 4);
+    const uint32_t w12 = (mx - md) | ((md - mn) << 16), w03 = (mx ^ 0xffffu) | (mn << 16);
+    typedef uint32_t u3 __attribute__((ext_vector_type(3)));     // 12 of the unit's 16 bytes: a fourth register would only be waited for
+    const char* base = reinterpret_cast<const char*>(clut);
+    const u3 u03 = *reinterpret_cast<const u3*>(base + cell_off + 16 * kIcc16BaseUnit), u12 = *reinterpret_cast<const u3*>(base + unit_off);
+    const uint32_t a03[3] = { u03.x, u03.y, u03.z }, a12[3] = { u12.x, u12.y, u12.z };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t p0 = a03[k] & 0xffffu;
+        uint32_t acc = (uint32_t)(__mul24((int)p0, -65535) + 0x8001);                                 // v_mad_i32_i24
+        acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a12[k]), __builtin_bit_cast(us2, w12), acc, false);
+        acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a03[k]), __builtin_bit_cast(us2, w03), acc, false);
+        const int32_t t = (int32_t)acc;
+        out[k] = (p0 + (uint32_t)((t + (t >> 16)) >> 16)) & 0xffffu;
+    }
+}
+#endif
+
 // ---- stage A: one source pixel -> integer codes (reference WriteHeifImage.cpp inner loops) --------
 // s[] holds the PLANES raw samples (u8/u16 values, or f32 bit patterns).  q[0..NCOL-1] colour, q[3] alpha.
 // RESCALE8: an 8-bit document saved at 10/12 bit -- decided once per row by the caller where that pays (no alpha), else here.
-template <int DEPTH, int PLANES, int TRANSFER, int ICC = 0, int RESCALE8 = 2, bool TO8 = false>   // RESCALE8: 0 no, 1 yes, 2 decide per sample (p.maxv); TO8: u8 planes
+// QF (the 16-bit table transform into u16 planes): q[0..2] are the colour codes AS FLOATS (bit patterns) -- stage B multiplies them next
+template <int DEPTH, int PLANES, int TRANSFER, int ICC = 0, int RESCALE8 = 2, bool TO8 = false, bool QF = false>   // RESCALE8: 0 no, 1 yes, 2 decide per sample (p.maxv); TO8: u8 planes
 AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t (&q)[4],
                     const int32_t* icc8_lds_s1 = nullptr, const uint8_t* icc8_lds_s2 = nullptr, const uint16_t* lut8 = nullptr,
                     const IccPowTable& powT = IccPowTable{ nullptr, nullptr }, const IccRegs* iccRegs = nullptr,
@@ -507,10 +573,29 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
         if constexpr (ICC == 5 && DEPTH == 16 && COLOR) {
             // ConvertRow for 16-bit rows (ColorProfileConversion.cpp:159-187): range map, lcms2 transform, range map back --
             // all PLANES samples take the two maps, the three colours also the table
+#if AG_ICC16_DOT2
+            uint32_t cin[3] = { sx[0], sx[1], sx[2] }, cout[3];                 // <= 32768: clamped by write_px as the row arrives (packed)
+            icc16_tetrahedral_host(p.icc16_clut, cin, cout);
+            if constexpr (QF) {
+                // icc16_lcms_to_host and the rescale to the output depth on floats, where this kernel's instruction mix is cheapest:
+                // (j + 1 + (j >= 65408)) >> 1 = floor(j / 2 + (j >= 65408 ? 1 : 1/2)), every term exact in fp32; then the lean rescale
+                // below with floor() for the truncating conversion -- the same values, and stage B takes them without converting back
+                static_assert(PLANES == 3 && !TO8, "QF: RGB into u16 planes");
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float hf = __builtin_floorf(__builtin_fmaf((float)cout[k], 0.5f, cout[k] >= 65408u ? 1.0f : 0.5f));
+                    q[k] = __float_as_uint(__builtin_floorf(hf * (p.maxf * (1.0f / 32768.0f)) + 0.5f));
+                }
+                q[3] = (uint32_t)p.maxv;
+                return;
+            }
+            if constexpr (PLANES == 4) sx[3] = icc16_host_to_lcms(sx[3]);
+#else
 #pragma unroll
             for (int k = 0; k < PLANES; ++k) sx[k] = icc16_host_to_lcms(sx[k] > 32768u ? 32768u : sx[k]);
             uint32_t cin[3] = { sx[0], sx[1], sx[2] }, cout[3];
             icc16_tetrahedral(p.icc16_clut, cin, cout);
+#endif
             sx[0] = cout[0]; sx[1] = cout[1]; sx[2] = cout[2];
 #pragma unroll
             for (int k = 0; k < PLANES; ++k) sx[k] = icc16_lcms_to_host(sx[k]);
@@ -562,9 +647,13 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
 // ---- stage B on integer codes (libheif restatement) --------------------------------
 // Stage B has no special case for the identity (GBR, lossless) matrix: the host passes my = (0,1,0), mcb = (0,0,1),
 // mcr = (1,0,0), half = 0, and 0*R + 1*G + 0*B (+ 0.5, truncate) returns the integer code G exactly.
+AG_DEV uint32_t luma_code_f(const WriteParams& p, float r, float g, float b)
+{
+    return clip_round(r * p.my[0] + g * p.my[1] + b * p.my[2], p.maxv);
+}
 AG_DEV uint32_t luma_code(const WriteParams& p, uint32_t r, uint32_t g, uint32_t b)
 {
-    return clip_round((float)r * p.my[0] + (float)g * p.my[1] + (float)b * p.my[2], p.maxv);
+    return luma_code_f(p, (float)r, (float)g, (float)b);
 }
 
 // ---- generic kernel ----------------------------------------------------------------------------
@@ -852,6 +941,11 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
             else if constexpr (DST16) return (qp[vr][i][k >> 1] >> (16 * (k & 1))) & 0xffffu;
             else return (qp[vr][i][0] >> (8 * k)) & 0xffu;
         };
+        // the 16-bit table transform into u16 Y, Cb, Cr planes hands its colour codes over as floats (stage_a, QF)
+        constexpr bool QF = AG_ICC16_DOT2 && ICC == 5 && DEPTH == 16 && PLANES == 3 && DST16 && OUT == kOutYcbcr && !PACK;
+        auto qflt = [&](int vr, int i, int k) -> float {
+            if constexpr (QF) return __uint_as_float(qp[vr][i][k]); else return (float)qget(vr, i, k);
+        };
 
 #pragma unroll
         for (int vr = 0; vr < VR; ++vr) {
@@ -865,6 +959,14 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
                 // occupancy: C4 4:2:0 0.69 -> 0.47 of peak, profiles/r01/transposed_load_experiment.txt).
                 uint32_t raw[ND];
                 load_dwords<ND, false, ALIGNED>(rowp + (long long)x0 * BPP, raw);
+                if constexpr (ICC == 5 && DEPTH == 16 && AG_ICC16_DOT2) {
+                    // the ICC stage's input clamp (Photoshop's 16-bit white is 32768; the table position is defined up to there), two
+                    // samples per v_pk_min_u16 while they are still packed
+                    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                    for (int d = 0; d < ND; ++d)
+                        raw[d] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2, raw[d]), us2{ 32768, 32768 }));
+                }
 #pragma unroll
                 for (int i = 0; i < PXT; ++i)
 #pragma unroll
@@ -882,7 +984,7 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
 #pragma unroll
                     for (int k = 0; k < PLANES; ++k) {
                         if constexpr (DEPTH == 8) s[i][k] = ld_u8(pp + k);
-                        else if constexpr (DEPTH == 16) s[i][k] = ld_u16(pp + 2 * k);
+                        else if constexpr (DEPTH == 16) s[i][k] = (ICC == 5 && AG_ICC16_DOT2) ? min(ld_u16(pp + 2 * k), 32768u) : ld_u16(pp + 2 * k);
                         else s[i][k] = ld_u32(pp + 4 * k);
                     }
                 }
@@ -896,7 +998,7 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
 #pragma unroll
                 for (int i = 0; i < PXT; ++i) {
                     uint32_t q[4] = { 0, 0, 0, 0 };        // gray fills [0] and [3] only
-                    stage_a<DEPTH, PLANES, TRANSFER, ICC, decltype(rescale8)::value, !DST16>(p, s[i], q, icc8_s1, icc8_s2, lut8, powT, &iccRegs, powTf, &iccRegsF);
+                    stage_a<DEPTH, PLANES, TRANSFER, ICC, decltype(rescale8)::value, !DST16, QF>(p, s[i], q, icc8_s1, icc8_s2, lut8, powT, &iccRegs, powTf, &iccRegsF);
                     if constexpr (!PACK) { qp[vr][i][0] = q[0]; qp[vr][i][1] = q[1]; qp[vr][i][2] = q[2]; qp[vr][i][3] = q[3]; }
                     else if constexpr (DST16) { qp[vr][i][0] = q[0] | (q[1] << 16); qp[vr][i][1] = q[2] | (q[3] << 16); }
                     else qp[vr][i][0] = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
@@ -943,7 +1045,7 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
 #pragma unroll
                 for (int i = 0; i < PXT; ++i) {
                     if constexpr (OUT == kOutRefGray) yv[i] = qget(vr, i, 0);   // planar Y(+A): :247-252
-                    else yv[i] = luma_code(p, qget(vr, i, 0), qget(vr, i, 1), qget(vr, i, 2));
+                    else yv[i] = luma_code_f(p, qflt(vr, i, 0), qflt(vr, i, 1), qflt(vr, i, 2));
                 }
 #pragma unroll
                 for (int i = 0; i < PXT; ++i) av[i] = qget(vr, i, 3);
@@ -959,15 +1061,15 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
                 const int i0 = j << XS;
-                float R = (float)qget(0, i0, 0), G = (float)qget(0, i0, 1), B = (float)qget(0, i0, 2);
+                float R = qflt(0, i0, 0), G = qflt(0, i0, 1), B = qflt(0, i0, 2);
                 if constexpr (XS || YS) {
                     if (!p.nearest) {
                         constexpr int i1o = XS ? 1 : 0;
                         constexpr int v1 = YS ? 1 : 0;
                         // (x2, r2) replication at the image edges already happened in the loads above
-                        R = (R + (float)qget(0, i0 + i1o, 0) + (float)qget(v1, i0, 0) + (float)qget(v1, i0 + i1o, 0)) * 0.25f;
-                        G = (G + (float)qget(0, i0 + i1o, 1) + (float)qget(v1, i0, 1) + (float)qget(v1, i0 + i1o, 1)) * 0.25f;
-                        B = (B + (float)qget(0, i0 + i1o, 2) + (float)qget(v1, i0, 2) + (float)qget(v1, i0 + i1o, 2)) * 0.25f;
+                        R = (R + qflt(0, i0 + i1o, 0) + qflt(v1, i0, 0) + qflt(v1, i0 + i1o, 0)) * 0.25f;
+                        G = (G + qflt(0, i0 + i1o, 1) + qflt(v1, i0, 1) + qflt(v1, i0 + i1o, 1)) * 0.25f;
+                        B = (B + qflt(0, i0 + i1o, 2) + qflt(v1, i0, 2) + qflt(v1, i0 + i1o, 2)) * 0.25f;
                     }
                 }
                 const float cb = R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2];

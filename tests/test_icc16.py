@@ -153,6 +153,32 @@ def test_table_read_out_of_an_a2b_transform(lcms, variant):
     assert len(np.unique(table[:, :, :, 1])) > 1000
 
 
+def test_kernel_forms_of_position_and_interpolation():
+    """The two rewrites the device kernel relies on (write_kernels.hip, AG_ICC16_DOT2), checked where they are cheap to check
+    exhaustively: (1) range map + _cmsToFixedDomain in one expression, all 32769 host samples; (2) the interpolation sum regrouped
+    by node -- the operand form of v_dot2_u32_u16 -- equals the library's differences-times-fractions modulo 2^32, including
+    where its int32 arithmetic wraps (random 16-bit nodes do that; real tables never)."""
+    i = np.arange(0, 32769, dtype=np.int64)
+    j = 2 * i - (i > 16448)                                                     # icc16_host_to_lcms
+    a = 32 * j
+    assert np.array_equal(a + (a + 0x7fff) // 0xffff, (65537 * i + 512 - (i > 16448) * 32769) >> 10)
+    rng = np.random.default_rng(5)
+    n = 1_000_000
+    v = rng.integers(0, 65536, size=(n, 4)).astype(np.int64)
+    r = np.sort(rng.integers(0, 65536, size=(n, 3)), axis=1)[:, ::-1].astype(np.int64)      # ra >= rb >= rc
+    v[:2000] = rng.choice([0, 1, 32768, 65534, 65535], size=(2000, 4))
+    r[2000:4000] = np.sort(rng.choice([0, 1, 65534, 65535], size=(2000, 3)), axis=1)[:, ::-1]
+    ra, rb, rc = r[:, 0], r[:, 1], r[:, 2]
+
+    def wrap(x):
+        return ((x + 2 ** 31) % 2 ** 32) - 2 ** 31
+    rest = wrap((v[:, 1] - v[:, 0]) * ra + (v[:, 2] - v[:, 1]) * rb + (v[:, 3] - v[:, 2]) * rc + 0x8001)
+    want = (v[:, 0] + ((rest + (rest >> 16)) >> 16)) & 0xffff
+    acc = wrap(0x8001 - 65535 * v[:, 0] + v[:, 1] * (ra - rb) + v[:, 2] * (rb - rc) + v[:, 0] * (ra ^ 0xffff) + v[:, 3] * rc)
+    assert np.array_equal(acc, rest)
+    assert np.array_equal((v[:, 0] + ((acc + (acc >> 16)) >> 16)) & 0xffff, want)
+
+
 BRIDGE = os.path.join(os.path.dirname(ICC_LIB), "..", "avif-format_amd", "libavifgpu_lcms_bridge.so")
 
 

@@ -25,7 +25,10 @@ CANDIDATES = [["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"], [
 
 
 def main():
+    global CANDIDATES
     out_json, rows = sys.argv[1], sys.argv[2:]
+    if os.environ.get("PMC_GROUPS"):                            # "A,B;C,D": other counters than the memory-hierarchy set, one pass per group
+        CANDIDATES = [g.split(",") for g in os.environ["PMC_GROUPS"].split(";") if g]
     env = dict(os.environ, TMPDIR="/tmp")
     listing = subprocess.run(["rocprofv3", "-L"], capture_output=True, text=True, env=env, cwd="/tmp").stdout
     have = set(re.findall(r"\b([A-Z][A-Za-z0-9_]{3,})\b", listing))
