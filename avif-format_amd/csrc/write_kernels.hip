@@ -677,6 +677,16 @@ enum { kOutRefColor = 0, kOutRefGray = 1, kOutYcbcr = 2 };
 #ifndef AG_W8_NC_ALPHA
 #define AG_W8_NC_ALPHA 4
 #endif
+// Packed f32 (v_pk_mul_f32 / v_pk_add_f32) in the u8 kernels' stage B: 0 never, 1 behind an ICC stage, 2 always.  Measured: nothing.
+// A wave64 v_fma_f32 issues in ~2.7 cycles on gfx950 and a v_pk_fma_f32 in ~5.8 (tools/alubench, profiles/r03/alubench_int.txt) --
+// two plain instructions cost what one packed one does -- so the 17 % fewer instructions of the 8-bit ICC kernel (2779 -> 2297 static
+// VALU with the mad chain below) bought only what the integer part of it bought (0.0759 -> 0.0704 ms, all three settings within 1 %;
+// profiles/r03/w8_pkf32_ab.txt), at 76 -> 85 VGPRs for the plain 4:2:0 kernel.  Kept as an A/B switch.
+#ifndef AG_W8_PKF32
+#define AG_W8_PKF32 0
+#endif
+typedef f32x2 f2;
+AG_DEV int mad24_sv(int s_coef, int v, int acc) { int d; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "s"(s_coef), "v"(v), "v"(acc)); return d; }
 // chroma samples per lane: 4 for u16 planes, AG_W8_NC for u8 planes (every plane store >= 8 / 4 bytes per lane)
 // The parametric ICC variants (2, 4) carry ~300 instructions and up to 86 parameter VGPRs per pixel stream: with sub-sampled chroma
 // 2 chroma samples per lane keep a 4:2:0 footprint at 8 pixels (16: 197 VGPRs, 2 waves/SIMD, 6.9 k instructions; measured
@@ -782,6 +792,7 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
         // from the packed dword to the float, alpha untouched.
         constexpr bool FAST8 = AG_W8_PACKED && (DEPTH == 8 || (DEPTH == 16 && PLANES == 4 && AG_W16TO8_FAST && ICC == 0)) && (PLANES == 3 || PLANES == 4) && OUT == kOutYcbcr && !DST16 &&
                                (ICC == 0 || (ICC == 3 && AG_ICC8_FAST)) && ALIGNED;
+        constexpr bool PKF32 = AG_W8_PKF32 == 2 || (AG_W8_PKF32 == 1 && ICC != 0);
         if constexpr (FAST8) {
             if (active) {
                 constexpr int NC = PXT >> XS;
@@ -858,7 +869,10 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
                                 const int b = icc8_s1[512 + ((raw[vr][(e0 + 2) >> 2] >> (8 * ((e0 + 2) & 3))) & 0xffu)];
 #pragma unroll
                                 for (int ch = 0; ch < 3; ++ch) {
-                                    int l = (__mul24(p.icc8_m[3 * ch], r) + __mul24(p.icc8_m[3 * ch + 1], g) + __mul24(p.icc8_m[3 * ch + 2], b) + p.icc8_off[ch] + 0x2000) >> 14;
+                                    // three v_mad_i32_i24 in a chain (wrapping int32 sums are associative: any order is the library's value).
+                                    // Spelled out -- left alone the sum becomes mul, mul, mad, add3; the rounding constant rides in a VGPR
+                                    // because a VOP3 reads one scalar operand, and that is the coefficient.
+                                    int l = mad24_sv(p.icc8_m[3 * ch + 2], b, mad24_sv(p.icc8_m[3 * ch + 1], g, mad24_sv(p.icc8_m[3 * ch], r, p.icc8_off[ch] + 0x2000))) >> 14;
                                     l = l < 0 ? 0 : (l > 16384 ? 16384 : l);
                                     c[vr][k][ch] = (float)icc8_s2[l];
                                 }
@@ -872,19 +886,43 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
                                     for (int ch = 0; ch < 3; ++ch) c[vr][k][ch] = exact_premultiply_fast_f(c[vr][k][ch], a, p.maxf, p.rcp_maxf);
                                 }
                             }
-                            put_u8(ypk[vr], i, (c[vr][k][0] * p.my[0] + c[vr][k][1] * p.my[1] + c[vr][k][2] * p.my[2]) + 0.5f);   // luma_code
+                            if constexpr (!(PKF32 && XS == 1))
+                                put_u8(ypk[vr], i, (c[vr][k][0] * p.my[0] + c[vr][k][1] * p.my[1] + c[vr][k][2] * p.my[2]) + 0.5f);   // luma_code
                         }
+                    if constexpr (PKF32 && XS == 1) {
+                        // the same single-precision operations, two at a time: the two pixels of a chroma sample for luma, (Cb, Cr) for chroma
+#pragma unroll
+                        for (int vr = 0; vr < VR; ++vr) {
+                            const f2 c0 = { c[vr][0][0], c[vr][1][0] }, c1 = { c[vr][0][1], c[vr][1][1] }, c2 = { c[vr][0][2], c[vr][1][2] };
+                            const f2 y = ((c0 * p.my[0] + c1 * p.my[1]) + c2 * p.my[2]) + 0.5f;
+                            put_u8(ypk[vr], (j << 1), y.x);
+                            put_u8(ypk[vr], (j << 1) + 1, y.y);
+                        }
+                    }
                     float R = c[0][0][0], G = c[0][0][1], B = c[0][0][2];
                     if constexpr ((XS || YS) && !decltype(nearest_c)::value) {
                         constexpr int k1 = XS ? 1 : 0, v1 = YS ? 1 : 0;
-                        R = (R + c[0][k1][0] + c[v1][0][0] + c[v1][k1][0]) * 0.25f;
-                        G = (G + c[0][k1][1] + c[v1][0][1] + c[v1][k1][1]) * 0.25f;
+                        if constexpr (PKF32) {
+                            f2 rg = { R, G };
+                            rg = (((rg + f2{ c[0][k1][0], c[0][k1][1] }) + f2{ c[v1][0][0], c[v1][0][1] }) + f2{ c[v1][k1][0], c[v1][k1][1] }) * 0.25f;
+                            R = rg.x; G = rg.y;
+                        } else {
+                            R = (R + c[0][k1][0] + c[v1][0][0] + c[v1][k1][0]) * 0.25f;
+                            G = (G + c[0][k1][1] + c[v1][0][1] + c[v1][k1][1]) * 0.25f;
+                        }
                         B = (B + c[0][k1][2] + c[v1][0][2] + c[v1][k1][2]) * 0.25f;
                     }
+                    if constexpr (PKF32) {
+                        const f2 cc = ((R * f2{ p.mcb[0], p.mcr[0] } + G * f2{ p.mcb[1], p.mcr[1] }) + B * f2{ p.mcb[2], p.mcr[2] });
+                        const f2 co = (cc + p.half) + 0.5f;
+                        put_u8(cbpk, j, co.x);                               // clip_round(cb + half, 255)
+                        put_u8(crpk, j, co.y);
+                    } else {
                     const float cb = R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2];
                     const float cr = R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2];
                     put_u8(cbpk, j, (cb + p.half) + 0.5f);                   // clip_round(cb + half, 255)
                     put_u8(crpk, j, (cr + p.half) + 0.5f);
+                    }
                     __builtin_amdgcn_sched_barrier(0);                      // ... and the machine scheduler may not interleave them either
                 }
                 };
