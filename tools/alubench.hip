@@ -60,6 +60,19 @@ __global__ __launch_bounds__(256) void ki(float* out, int iters, float seed)
             if constexpr (OP == 5) a[i] = max(min(a[i], w), min(max(a[i], w), a[(i + 1) & 7]));                               // v_med3_u32
             if constexpr (OP == 6) a[i] = a[i] * w;                                                                      // v_mul_lo_u32
             if constexpr (OP == 7) a[i] = (a[i] << 5) + w;                                                               // v_lshl_add_u32
+            if constexpr (OP == 8) a[i] = a[i] + a[(i + 1) & 7];                                                                    // v_add_u32 (VOP2)
+            if constexpr (OP == 9) a[i] = a[i] ^ (a[(i + 3) & 7] | 1u);   // v_xor + v_or                                                                    // v_xor_b32
+            if constexpr (OP == 10) a[i] = (a[i] >> 3) | 0x80000000u;                                                    // v_lshrrev + v_or
+            if constexpr (OP == 11) a[i] = min(a[i], w) + 0x1000u;                                                       // v_min_u32 + v_add
+            if constexpr (OP == 12) a[i] = __float_as_uint((float)a[i]);                                                 // v_cvt_f32_u32
+            if constexpr (OP == 13) a[i] = (uint32_t)__uint_as_float(a[i] | 0x40000000u);                                // v_or + v_cvt_u32_f32
+            if constexpr (OP == 14) a[i] = __float_as_uint((float)(a[i] & 0xffu)) + w;                                   // v_cvt_f32_ubyte0 + v_add
+            if constexpr (OP == 15) a[i] = __float_as_uint(__builtin_floorf(__uint_as_float(a[i]) * 1.5f));              // v_mul_f32 + v_floor_f32
+            if constexpr (OP == 16) a[i] = __float_as_uint(__uint_as_float(a[i]) * 1.0001f);                             // v_mul_f32
+            if constexpr (OP == 17) a[i] = __float_as_uint(__uint_as_float(a[i]) + 1.0001f);                             // v_add_f32
+            if constexpr (OP == 18) a[i] = __float_as_uint(__builtin_amdgcn_fmed3f(__uint_as_float(a[i]), 0.0f, 1.5f) + 0.25f);   // v_med3_f32 + v_add_f32
+            if constexpr (OP == 19) a[i] = (a[i] > w ? a[i] : w + 3u) + 1u;                                              // v_cmp + v_cndmask + adds
+            if constexpr (OP == 20) a[i] = (uint32_t)__mul24((int)a[i], (int)w);                                         // v_mul_i32_i24 (VOP2)
         }
     }
     unsigned s = 0;
@@ -130,5 +143,18 @@ int main()
     runi<5>("v_med3_u32", 8);
     runi<6>("v_mul_lo_u32", 8);
     runi<7>("v_lshl_add_u32", 8);
+    runi<8>("v_add_u32", 8);
+    runi<9>("v_xor_b32 + v_or", 16);
+    runi<10>("v_lshrrev + v_or", 16);
+    runi<11>("v_min_u32 + v_add", 16);
+    runi<12>("v_cvt_f32_u32", 8);
+    runi<13>("v_or + v_cvt_u32_f32", 16);
+    runi<14>("v_cvt_f32_ubyte0 + v_add", 16);
+    runi<15>("v_mul_f32 + v_floor_f32", 16);
+    runi<16>("v_mul_f32", 8);
+    runi<17>("v_add_f32", 8);
+    runi<18>("v_med3_f32 + v_add_f32", 16);
+    runi<19>("cmp+cndmask+2 add (4)", 32);
+    runi<20>("v_mul_i32_i24", 8);
     return 0;
 }

@@ -12,6 +12,7 @@ import glob
 import json
 import os
 import re
+import shlex
 import subprocess
 import sys
 
@@ -42,7 +43,7 @@ def main():
         d = "/tmp/pmc_" + g[0]
         subprocess.run(["rm", "-rf", d])
         cmd = ["rocprofv3", "--pmc", *g, "-d", d, "-o", "p", "--output-format", "csv", "--", "bash", "-c",
-               "cd %s && python tools/bench_configs.py %s > %s/cfg.jsonl 2>/dev/null" % (ROOT, " ".join("'%s'" % r for r in rows), d)]
+               "cd %s && python tools/bench_configs.py %s > %s/cfg.jsonl 2>/dev/null" % (ROOT, " ".join(shlex.quote(r) for r in rows), d)]
         os.makedirs(d, exist_ok=True)
         r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd="/tmp", timeout=900)
         if r.returncode != 0:
