@@ -86,10 +86,11 @@ bool HasAlphaChannel(const FormatRecordPtr formatRecord)
 // made whatever maxData says; every larger tile stays within the budget.
 int rows_per_tile(int32_t max_data, int64_t row_bytes, int height, bool even)
 {
-    // Large tiles only coarsen the pipeline (8192^2 f32 save, host fill skipped: 15.6-16.2 ms with 8 MiB tiles, 17.3-19.0 with
-    // 16 MiB, 23 with 64 MiB -- the last tiles of each context drain alone; profiles/r02/host_shim_end_to_end.jsonl,
-    // profiles/r02/pcie_tile_and_lane_sweep.txt), so a generous maxData is not used up.  AVIFGPU_TILE_MB overrides the cap.
-    int64_t cap = 8;
+    // Large tiles only coarsen the pipeline -- the last tiles drain alone, and the host fills a tile while nothing of it can travel --
+    // so a generous maxData is not used up: 16 MiB (8192^2 f32 save with the host fill skipped: 17.6 ms with 8 MiB tiles, 16.5 with 16,
+    // profiles/r03/host_shim_after_upload_order.txt; before the uploads were ordered 8 MiB was the better of the two,
+    // profiles/r02/host_shim_end_to_end.jsonl).  AVIFGPU_TILE_MB overrides the cap.
+    int64_t cap = 16;
     if (const char* v = getenv("AVIFGPU_TILE_MB")) { const long x = strtol(v, nullptr, 0); if (x >= 1 && x <= 2047) cap = x; }
     int64_t budget = max_data > 0 ? std::min<int64_t>(max_data, cap << 20) : (cap << 20);
     budget = std::min<int64_t>(budget, std::numeric_limits<int32_t>::max());

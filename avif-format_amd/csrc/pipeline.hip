@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -63,11 +64,13 @@ struct Job {
     int nbounce = 0;
     char label[kLabelBytes] = "";
     double t_queued = 0, t_start = 0, t_issued = 0;        // AVIFGPU_TRACE
+    uint64_t upload_seq = 0;                               // position in its device's upload order (enqueue())
 };
 
 struct Slot {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
+    hipEvent_t up_done = nullptr;                          // this tile's host-to-device copies (UploadOrder)
     void* d_in = nullptr;  size_t d_in_cap = 0;
     void* d_out = nullptr; size_t d_out_cap = 0;
     void* h_rows = nullptr;   size_t h_rows_cap = 0;      // pinned: the shim's tile buffer / bounce of pageable rows
@@ -227,12 +230,87 @@ void host_copy_rows(uint8_t* dst, size_t dst_pitch, const uint8_t* src, size_t s
     for (size_t r = 0; r < rows; ++r) std::memcpy(dst + r * dst_pitch, src + r * src_pitch, bytes);
 }
 
+// ---- upload order ------------------------------------------------------------------------------------------------------
+// Every slot has its own stream, so the copies of up to lanes x slots tiles are in flight at once -- and left alone they march in
+// step: all uploads share the link and finish together, then all kernels, then all downloads, during which the upward direction of
+// the link idles (25 % of a C4 save in the copy trace of round 3, profiles/r03/pcie_copy_trace_summary.txt).  The uploads of one
+// DEVICE are therefore chained in issue order, at most AVIFGPU_UPLOAD_DEPTH (default 1) of them running at a time: tile t+DEPTH's
+// upload waits for tile t's, and tile t's planes travel down while it runs -- the link is busy both ways, as a classic three-stage
+// pipeline has it, with the per-slot streams still giving every tile its own kernel and download order.  0 = no chaining.
+// The order is the order in which the caller QUEUED the tiles (a ticket per tile, taken in enqueue()), whichever lane a tile went
+// to: the caller waits for staging slots in that same order, so tiles must also complete in it -- two lanes taking the chain in the
+// order their threads happened to arrive cost a third of the throughput (27 ms instead of 16 for C4, profiles/r03/upload_order_sweep.jsonl).
+constexpr int kMaxUploadDepth = 4;
+struct UploadOrder {
+    std::mutex mu;
+    std::condition_variable turn;
+    uint64_t next_ticket = 0;                              // handed out by enqueue()
+    uint64_t serving = 0;                                  // the ticket whose uploads may be issued now
+    hipEvent_t ring[kMaxUploadDepth] = {};                 // upload-done events of the last DEPTH tiles issued on this device
+    int head = 0;
+};
+std::mutex g_upload_mu;
+std::vector<std::unique_ptr<UploadOrder>> g_upload;       // by device index
+int g_upload_depth = 1;
+
+UploadOrder& upload_order(int device)
+{
+    std::lock_guard<std::mutex> lk(g_upload_mu);
+    if ((int)g_upload.size() <= device) g_upload.resize((size_t)device + 1);
+    if (!g_upload[device]) g_upload[device].reset(new UploadOrder);
+    return *g_upload[device];
+}
+
+// Taken around the host-to-device copies of one tile: construct -> the stream waits for the upload DEPTH tiles back; finish() ->
+// this tile's upload is recorded as the newest.  Holding the device's mutex in between keeps two lanes from interleaving.
+// A started tile's place in the order.  EVERY started tile passes its turn on -- from issue() when it gets that far, from the
+// destructor when it fails earlier -- or the tiles behind it would wait for ever.
+class UploadTurn {
+public:
+    UploadTurn(int device, uint64_t ticket) : order_(upload_order(device)), ticket_(ticket) {}
+    ~UploadTurn() { if (!passed_) { std::unique_lock<std::mutex> lk(order_.mu); wait(lk); pass(); } }
+    // issue the host-to-device copies of the tile through `copies` (returns hipError_t) in this tile's turn
+    template <typename F> hipError_t issue(Slot& sl, F&& copies)
+    {
+        std::unique_lock<std::mutex> lk(order_.mu);
+        wait(lk);
+        hipError_t e = hipSuccess;
+        if (g_upload_depth > 0) {
+            hipEvent_t prev = order_.ring[order_.head];     // the oldest of the last DEPTH uploads
+            if (prev && prev != sl.up_done) e = hipStreamWaitEvent(sl.stream, prev, 0);
+        }
+        if (e == hipSuccess) e = copies();
+        if (e == hipSuccess && g_upload_depth > 0) {
+            e = hipEventRecord(sl.up_done, sl.stream);
+            if (e == hipSuccess) { order_.ring[order_.head] = sl.up_done; order_.head = (order_.head + 1) % g_upload_depth; }
+        }
+        pass();
+        return e;
+    }
+private:
+    void wait(std::unique_lock<std::mutex>& lk) { order_.turn.wait(lk, [&] { return order_.serving == ticket_; }); }
+    void pass() { ++order_.serving; passed_ = true; order_.turn.notify_all(); }
+    UploadOrder& order_;
+    const uint64_t ticket_;
+    bool passed_ = false;
+};
+
+// a slot's events are about to be destroyed: nothing may wait on them afterwards
+void forget_uploads_of(int device, const Slot& sl)
+{
+    if (!sl.up_done) return;
+    UploadOrder& o = upload_order(device);
+    std::lock_guard<std::mutex> lk(o.mu);
+    for (hipEvent_t& e : o.ring) if (e == sl.up_done) e = nullptr;
+}
+
 // ---- worker side -------------------------------------------------------------------------------------------------------
 // Issue the copies and the launch of one tile on its slot's stream.  Returns an OSErr; the message is in this thread's
 // last_error().  After the first asynchronous operation any failure drains the stream before returning, so no DMA is left
 // running into (or out of) caller memory behind an error return.
 int start_write(Ctx& c, Job& j)
 {
+    UploadTurn turn(c.device, j.upload_seq);
     Slot& sl = c.slot[j.slot];
     const avifgpu_write_desc* d = &j.wd;
     WriteGeom g;
@@ -259,13 +337,15 @@ int start_write(Ctx& c, Job& j)
     hipError_t e;
     const size_t src_span = (size_t)j.rows_in_stride * (size_t)(j.nrows - 1) + row_bytes;
     const bool own_tile = j.rows_in == sl.h_rows;            // the shim's pinned tile buffer
-    if (own_tile || is_pinned(j.rows_in, src_span)) {
-        e = copy_rows(sl.d_in, in_pitch, j.rows_in, (size_t)j.rows_in_stride, row_bytes, (size_t)j.nrows, hipMemcpyHostToDevice, st);
-    } else {
+    const bool direct = own_tile || is_pinned(j.rows_in, src_span);
+    if (!direct) {                                           // the CPU copy of pageable rows: before the device's upload order is taken
         if ((err = grow_pinned(&sl.h_rows, &sl.h_rows_cap, in_pitch * (size_t)j.nrows))) return err;
         host_copy_rows(static_cast<uint8_t*>(sl.h_rows), in_pitch, static_cast<const uint8_t*>(j.rows_in), (size_t)j.rows_in_stride, row_bytes, (size_t)j.nrows);
-        e = hipMemcpyAsync(sl.d_in, sl.h_rows, in_pitch * (size_t)j.nrows, hipMemcpyHostToDevice, st);
     }
+    e = turn.issue(sl, [&] {
+        if (direct) return copy_rows(sl.d_in, in_pitch, j.rows_in, (size_t)j.rows_in_stride, row_bytes, (size_t)j.nrows, hipMemcpyHostToDevice, st);
+        return hipMemcpyAsync(sl.d_in, sl.h_rows, in_pitch * (size_t)j.nrows, hipMemcpyHostToDevice, st);
+    });
     if (e != hipSuccess) { (void)hipStreamSynchronize(st); return hip_fail(e, "H2D copy", AVIFGPU_writErr); }
 
     p.src = static_cast<const uint8_t*>(sl.d_in); p.src_row_bytes = (int64_t)in_pitch;
@@ -304,6 +384,7 @@ int start_write(Ctx& c, Job& j)
 
 int start_read(Ctx& c, Job& j)
 {
+    UploadTurn turn(c.device, j.upload_seq);
     Slot& sl = c.slot[j.slot];
     const avifgpu_read_desc* d = &j.rd;
     ReadGeom g;
@@ -336,20 +417,24 @@ int start_read(Ctx& c, Job& j)
         any_pageable = any_pageable || !pinned_src[pl];
     }
     if (any_pageable && (err = grow_pinned(&sl.h_planes, &sl.h_planes_cap, in_total))) return err;
-    for (int pl = 0; pl < 4; ++pl) {
-        if (!read_plane_used(d, g, pl)) continue;
-        uint8_t* dev = static_cast<uint8_t*>(sl.d_in) + off[pl];
-        p.src[pl] = dev; p.src_stride[pl] = (int64_t)pitch[pl];
-        if (prow[pl] == 0) continue;
-        if (pinned_src[pl]) {
-            e = copy_rows(dev, pitch[pl], j.planes_in[pl], (size_t)j.planes_in_stride[pl], (size_t)pbytes[pl], (size_t)prow[pl], hipMemcpyHostToDevice, st);
-        } else {
-            uint8_t* hb = static_cast<uint8_t*>(sl.h_planes) + off[pl];
-            host_copy_rows(hb, pitch[pl], static_cast<const uint8_t*>(j.planes_in[pl]), (size_t)j.planes_in_stride[pl], (size_t)pbytes[pl], (size_t)prow[pl]);
-            e = hipMemcpyAsync(dev, hb, pitch[pl] * (size_t)prow[pl], hipMemcpyHostToDevice, st);
-        }
-        if (e != hipSuccess) { (void)hipStreamSynchronize(st); return hip_fail(e, "H2D copy", AVIFGPU_readErr); }
+    for (int pl = 0; pl < 4; ++pl) {                         // the CPU copies of pageable planes: before the device's upload order is taken
+        if (!read_plane_used(d, g, pl) || prow[pl] == 0 || pinned_src[pl]) continue;
+        host_copy_rows(static_cast<uint8_t*>(sl.h_planes) + off[pl], pitch[pl], static_cast<const uint8_t*>(j.planes_in[pl]),
+                       (size_t)j.planes_in_stride[pl], (size_t)pbytes[pl], (size_t)prow[pl]);
     }
+    e = turn.issue(sl, [&] {
+        hipError_t ce = hipSuccess;
+        for (int pl = 0; pl < 4 && ce == hipSuccess; ++pl) {
+            if (!read_plane_used(d, g, pl)) continue;
+            uint8_t* dev = static_cast<uint8_t*>(sl.d_in) + off[pl];
+            p.src[pl] = dev; p.src_stride[pl] = (int64_t)pitch[pl];
+            if (prow[pl] == 0) continue;
+            if (pinned_src[pl]) ce = copy_rows(dev, pitch[pl], j.planes_in[pl], (size_t)j.planes_in_stride[pl], (size_t)pbytes[pl], (size_t)prow[pl], hipMemcpyHostToDevice, st);
+            else ce = hipMemcpyAsync(dev, static_cast<uint8_t*>(sl.h_planes) + off[pl], pitch[pl] * (size_t)prow[pl], hipMemcpyHostToDevice, st);
+        }
+        return ce;
+    });
+    if (e != hipSuccess) { (void)hipStreamSynchronize(st); return hip_fail(e, "H2D copy", AVIFGPU_readErr); }
     p.dst = static_cast<uint8_t*>(sl.d_out); p.dst_row_bytes = (int64_t)out_pitch;
     e = launch_read(p, d->colorspace, d->depth, g.alpha, g.xs, g.ys, st, j.label);
     if (e != hipSuccess) { (void)hipStreamSynchronize(st); return hip_fail(e, "kernel launch", AVIFGPU_readErr); }
@@ -412,6 +497,7 @@ void worker_main(Ctx* cp)
     for (int s = 0; e == hipSuccess && s < c.nslots; ++s) {
         e = hipStreamCreateWithFlags(&c.slot[s].stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c.slot[s].done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c.slot[s].up_done, hipEventDisableTiming);
     }
     {
         std::lock_guard<std::mutex> lk(c.mu);
@@ -479,7 +565,9 @@ void worker_main(Ctx* cp)
         if (sl.d_out) (void)hipFree(sl.d_out);
         if (sl.h_rows) (void)hipHostFree(sl.h_rows);
         if (sl.h_planes) (void)hipHostFree(sl.h_planes);
+        forget_uploads_of(c.device, sl);
         if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.up_done) (void)hipEventDestroy(sl.up_done);
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
         sl = Slot();
     }
@@ -500,6 +588,11 @@ int enqueue(int ctx, Job& j)
         if (c->slot[j.slot].busy) return fail(AVIFGPU_formatBadParameters, "staging slot (%d, %d) is still busy", ctx, j.slot);
         c->slot[j.slot].busy = true;
         if (g_trace) j.t_queued = now_us();
+        {
+            UploadOrder& o = upload_order(c->device);
+            std::lock_guard<std::mutex> l2(o.mu);
+            j.upload_seq = o.next_ticket++;
+        }
         c->queue.push_back(j);
     }
     c->cv_work.notify_one();
@@ -548,11 +641,16 @@ int contexts_init(const int32_t* devices, int count)
                     e == hipSuccess ? "device count 0" : hipGetErrorString(e));
     for (int i = 0; i < count; ++i)
         if (devices[i] < 0 || devices[i] >= n) return fail(AVIFGPU_formatBadParameters, "device %d out of range [0,%d)", devices[i], n);
-    const int nslots = env_int("AVIFGPU_SLOTS", 4, 2, kMaxSlots);
     // Lanes: contexts per bound device.  One worker keeps one copy queue per direction busy; a second lane on the same device
-    // overlaps its submissions with the first one's (measured: see profiles/r02/pcie_host_pointer_path.jsonl).
+    // overlaps its submissions -- and its CPU copies of pageable caller memory -- with the first one's.
     const int lanes = env_int("AVIFGPU_LANES", kDefaultLanes, 1, 4);
+    // Slots: tiles in flight per lane, each with a stream of its own.  Default lanes x slots = 4 streams per device: the runtime
+    // multiplexes a process's streams onto 4 hardware queues per device, and the barrier that orders a tile's upload behind the
+    // previous one's then also holds up whatever OTHER stream shares its queue -- 2 x 3, 1 x 6 or 2 x 4 streams measured 19-27 ms for
+    // the C4 job against 15.5-16 ms for 2 x 2 or 1 x 4 (profiles/r03/upload_order_sweep.jsonl).
+    const int nslots = env_int("AVIFGPU_SLOTS", std::max(2, 4 / lanes), 2, kMaxSlots);
     const bool trace = env_int("AVIFGPU_TRACE", 0, 0, 1) != 0;
+    g_upload_depth = env_int("AVIFGPU_UPLOAD_DEPTH", 1, 0, kMaxUploadDepth);
     {
         // same binding AND same knobs: nothing to do (a changed AVIFGPU_LANES / AVIFGPU_SLOTS / AVIFGPU_TRACE re-binds)
         std::lock_guard<std::mutex> lk(g_ctx_mu);
@@ -714,11 +812,12 @@ int wait_all()
 // ---- whole-range host conversions ---------------------------------------------------------------------------------------
 namespace {
 
-// rows per sub-tile: AVIFGPU_CHUNK_MB (default 8: 49.7 GB/s H2D for C4 from page-locked memory, 45.0 with 16 -- profiles/r02/
-// pcie_tile_and_lane_sweep.txt) of the rows side, even, at least 2
+// rows per sub-tile: AVIFGPU_CHUNK_MB of the rows side (default 16: with the uploads in order a tile only has to be long enough to
+// hide its own launch and copy set-up -- C4 from page-locked memory 17.0 ms with 8 MiB tiles, 16.0 with 16, 15.5 with 32, profiles/r03/
+// upload_order_sweep.jsonl -- and short enough that small frames still pipeline), even, at least 2
 int chunk_rows_for(size_t bytes_per_row)
 {
-    const size_t budget = (size_t)env_int("AVIFGPU_CHUNK_MB", 8, 1, 4096) << 20;
+    const size_t budget = (size_t)env_int("AVIFGPU_CHUNK_MB", 16, 1, 4096) << 20;
     size_t rows = budget / std::max<size_t>(bytes_per_row, 1);
     rows = std::max<size_t>(rows & ~(size_t)1, 2);
     return (int)std::min<size_t>(rows, 1u << 30);
