@@ -650,18 +650,19 @@ int contexts_init(const int32_t* devices, int count)
     // the C4 job against 15.5-16 ms for 2 x 2 or 1 x 4 (profiles/r03/upload_order_sweep.jsonl).
     const int nslots = env_int("AVIFGPU_SLOTS", std::max(2, 4 / lanes), 2, kMaxSlots);
     const bool trace = env_int("AVIFGPU_TRACE", 0, 0, 1) != 0;
-    g_upload_depth = env_int("AVIFGPU_UPLOAD_DEPTH", 1, 0, kMaxUploadDepth);
+    const int upload_depth = env_int("AVIFGPU_UPLOAD_DEPTH", 1, 0, kMaxUploadDepth);
     {
-        // same binding AND same knobs: nothing to do (a changed AVIFGPU_LANES / AVIFGPU_SLOTS / AVIFGPU_TRACE re-binds)
+        // same binding AND same knobs: nothing to do (a changed AVIFGPU_LANES / AVIFGPU_SLOTS / AVIFGPU_TRACE / AVIFGPU_UPLOAD_DEPTH re-binds)
         std::lock_guard<std::mutex> lk(g_ctx_mu);
         if (g_ctxs && g_bound == std::vector<int>(devices, devices + count) && (int)g_ctxs->size() == count * lanes &&
-            (*g_ctxs)[0]->nslots == nslots && g_trace == trace) return 0;
+            (*g_ctxs)[0]->nslots == nslots && g_trace == trace && g_upload_depth == upload_depth) return 0;
     }
     contexts_shutdown();                                   // re-binding releases every stream, event and buffer of the old devices
     release_device_caches();                               // ... and their table caches (never reused on another device)
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     auto* v = new std::vector<Ctx*>();
     g_trace = trace;
+    g_upload_depth = upload_depth;                         // no tile is in flight here: the old contexts are gone
     // where each bound device sits: PCI bus id -> NUMA node -> that node's CPUs (sysfs); the workers pin themselves to them
     g_topo.clear();
     for (int i = 0; i < count; ++i) {

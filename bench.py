@@ -402,7 +402,7 @@ def main():
                     best = dt if best is None else min(best, dt)
                 # the link's own ceiling for this job, same process, same page-locked buffers: the frame up and the planes down as
                 # plain asynchronous copies on two streams at once, no kernel, no tiling (GPU 0's link only)
-                ceiling = None
+                ceiling = up_only = None
                 try:
                     d_in = torch.empty((H, W * 3), dtype=torch.float32, device=dev)
                     d_o = [torch.empty((H, W * 2), dtype=torch.uint8, device=dev) for _ in range(3)]
@@ -418,6 +418,14 @@ def main():
                         torch.cuda.synchronize(dev)
                         dt = time.perf_counter() - t1
                         ceiling = dt if ceiling is None else min(ceiling, dt)
+                    for _ in range(3):                # ... and the frame alone going up, one copy: the direction that carries 2/3 of the bytes
+                        torch.cuda.synchronize(dev)
+                        t1 = time.perf_counter()
+                        with torch.cuda.stream(s_up):
+                            d_in.copy_(h_src, non_blocking=True)
+                        torch.cuda.synchronize(dev)
+                        dt = time.perf_counter() - t1
+                        up_only = dt if up_only is None else min(up_only, dt)
                     del d_in, d_o
                 except Exception:                     # noqa: BLE001 -- a diagnostic of a diagnostic
                     ceiling = None
@@ -425,6 +433,8 @@ def main():
                                          "gpus": world, "H2D_GB_s": round(W * H * 12 / best / 1e9, 1), "D2H_GB_s": round(W * H * 6 / best / 1e9, 1),
                                          "plain_copies_seconds": None if ceiling is None else round(ceiling, 5),
                                          "frac_of_plain_copies": None if ceiling is None or world != 1 else round(ceiling / best, 3),
+                                         "upload_only_seconds": None if up_only is None else round(up_only, 5),
+                                         "frac_of_upload_only": None if up_only is None or world != 1 else round(up_only / best, 3),
                                          "topology": multi.topology(),
                                          "note": "one process, one calling thread: avifgpu_init_devices + avifgpu_write_rows(MEM_HOST); whole "
                                                  f"{W}x{H} frame, page-locked rows in / planes out, row tiles dealt across the GPUs, best of 5"}

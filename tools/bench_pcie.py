@@ -49,6 +49,30 @@ def run(W, H, ncontexts, chunk_mb, pinned, reps=4, slots=None):
                       "total_GB_s": round(W * H * 18 / best / 1e9, 1)}), flush=True)
 
 
+def run_read(W, H, chunk_mb, pinned, reps=4):
+    """The open direction of the same frame: 10-bit YCbCr 4:4:4 planes (403 MB) up, RGB f32 rows (805 MB) down."""
+    os.environ["AVIFGPU_CHUNK_MB"] = str(chunk_mb)
+    gpu = pkg.AvifGpu(devices=[0])
+    d = pkg.ReadDesc(width=W, height=H, colorspace=pkg.COLORSPACE_YCBCR, chroma=pkg.CHROMA_444, bit_depth=10, depth=32,
+                     alpha_state=pkg.ALPHA_NONE, color_primaries=pkg.PRIMARIES_BT2020, transfer_characteristics=pkg.TC_PQ,
+                     matrix_coefficients=pkg.MATRIX_BT2020_NCL, full_range_flag=1, pq_peak_nits=80)
+    planes = [(torch.rand((H, W)) * 1023).to(torch.int16) for _ in range(3)]
+    dst = torch.empty((H, W * 3), dtype=torch.float32)
+    if pinned:
+        planes = [p.pin_memory() for p in planes]
+        dst = dst.pin_memory()
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        gpu.read_rows(d, 0, H, [p.data_ptr() for p in planes] + [None], [p.stride(0) * 2 for p in planes] + [0], dst.data_ptr(),
+                      dst.stride(0) * 4, mem=pkg.MEM_HOST)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    print(json.dumps({"config": f"{W}x{H} 10-bit PQ YCbCr 4:4:4 -> RGB f32, host pointers", "memory": "pinned" if pinned else "pageable",
+                      "chunk_MiB": chunk_mb, "seconds": round(best, 4), "Mpx_s": round(W * H / best / 1e6, 1),
+                      "D2H_GB_s": round(W * H * 12 / best / 1e9, 1), "H2D_GB_s": round(W * H * 6 / best / 1e9, 1)}), flush=True)
+
+
 if __name__ == "__main__":
     W = H = 8192
     for chunk in (8, 32, 128):
