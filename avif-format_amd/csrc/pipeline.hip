@@ -813,12 +813,15 @@ int wait_all()
 // ---- whole-range host conversions ---------------------------------------------------------------------------------------
 namespace {
 
-// rows per sub-tile: AVIFGPU_CHUNK_MB of the rows side (default 16: with the uploads in order a tile only has to be long enough to
-// hide its own launch and copy set-up -- C4 from page-locked memory 17.0 ms with 8 MiB tiles, 16.0 with 16, 15.5 with 32, profiles/r03/
-// upload_order_sweep.jsonl -- and short enough that small frames still pipeline), even, at least 2
-int chunk_rows_for(size_t bytes_per_row)
+// rows per sub-tile, even, at least 2.  With the uploads in order a tile only has to be long enough to hide its own launch and the
+// ~27 us between two uploads, and short enough that the job still has a dozen tiles per worker to pipeline: a twelfth of the worker's
+// share, between 4 and 32 MiB of the rows side (C4 from page-locked memory: 17.0 ms with 8 MiB tiles, 16.0 with 16, 15.5 with 32,
+// profiles/r03/upload_order_sweep.jsonl).  AVIFGPU_CHUNK_MB fixes it.
+int chunk_rows_for(size_t bytes_per_row, int rows_per_worker)
 {
-    const size_t budget = (size_t)env_int("AVIFGPU_CHUNK_MB", 16, 1, 4096) << 20;
+    size_t budget;
+    if (getenv("AVIFGPU_CHUNK_MB")) budget = (size_t)env_int("AVIFGPU_CHUNK_MB", 16, 1, 4096) << 20;
+    else budget = std::min<size_t>(std::max<size_t>(bytes_per_row * (size_t)std::max(rows_per_worker, 1) / 12, (size_t)4 << 20), (size_t)32 << 20);
     size_t rows = budget / std::max<size_t>(bytes_per_row, 1);
     rows = std::max<size_t>(rows & ~(size_t)1, 2);
     return (int)std::min<size_t>(rows, 1u << 30);
@@ -843,7 +846,7 @@ int write_rows_host(const avifgpu_write_desc* d, int row0, int nrows, const void
     if (err) return err;
     const int nslots = slots_per_context();
     const size_t row_bytes = (size_t)d->width * d->planes * (d->depth / 8);
-    const int chunk = chunk_rows_for(row_bytes);
+    const int chunk = chunk_rows_for(row_bytes, (nrows + n - 1) / n);
     const bool ycc = d->output == AVIFGPU_OUT_YCBCR;
     std::vector<int> next(n), end(n);
     for (int c = 0; c < n; ++c) { next[c] = row0 + row_cut(nrows, n, c, true); end[c] = row0 + row_cut(nrows, n, c + 1, true); }
@@ -883,7 +886,7 @@ int read_rows_host(const avifgpu_read_desc* d, int row0, int nrows, const void* 
     if (err) return err;
     const int nslots = slots_per_context();
     const size_t row_bytes = (size_t)d->width * g.nch * (d->depth / 8);
-    const int chunk = chunk_rows_for(row_bytes);
+    const int chunk = chunk_rows_for(row_bytes, (nrows + n - 1) / n);
     const bool ycc = d->colorspace == AVIFGPU_COLORSPACE_YCBCR;
     std::vector<int> next(n), end(n);
     for (int c = 0; c < n; ++c) { next[c] = row0 + row_cut(nrows, n, c, true); end[c] = row0 + row_cut(nrows, n, c + 1, true); }
