@@ -230,7 +230,7 @@ int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p)
                         if (!(rr < G && gg < G && bb < G)) return;
                         const uint16_t* node = t->table[(rr * G + gg) * G + bb];
 #if AG_ICC16_DOT2
-                        for (int ch = 0; ch < 3; ++ch) dst[8 * unit + 2 * ch + half] = node[ch];      // {a.R, b.R, a.G, b.G, a.B, b.B, 0, 0}
+                        for (int ch = 0; ch < 3; ++ch) dst[(kIcc16UnitBytes / 2) * unit + 2 * ch + half] = node[ch];      // {a.R, b.R, a.G, b.G, a.B, b.B, 0, 0}
 #else
                         memcpy(dst + 8 * unit + 4 * half, node, 8);                                     // {a.R, a.G, a.B, 0, b.R, b.G, b.B, 0}
 #endif

@@ -13,7 +13,12 @@ namespace avifgpu {
 enum : int { kHotDefault = 1 | 2 | 4 };
 
 // 16-bit ICC table on the device: bytes per cell record (upload_icc16 builds it, icc16_tetrahedral reads it)
-enum : int { kIcc16RecBytes = 128 };
+#ifndef AG_ICC16_REC96
+#define AG_ICC16_REC96 0        // 1: 12-byte units, 96-byte records, a 3.45 MB table instead of 4.6.  Measured: uniformly random input 0.672 ->
+                                // 0.606 ms (still not L2-resident), photograph-like 0.201 -> 0.206 (records straddle lines): left off
+                                // (profiles/r03/icc16_rec96_ab.txt)
+#endif
+enum : int { kIcc16RecBytes = AG_ICC16_REC96 ? 96 : 128, kIcc16UnitBytes = AG_ICC16_REC96 ? 12 : 16 };
 // Record layout / interpolation form: 1 = node PAIRS per channel ({a.R|b.R<<16, a.G|b.G<<16, a.B|b.B<<16, 0} per 16-byte unit) feeding
 // v_dot2_u32_u16 on weights, 0 = two whole nodes per unit and differences x fractions (round 2).  Shared by the uploader and the kernel.
 #ifndef AG_ICC16_DOT2

@@ -507,11 +507,11 @@ AG_DEV void icc16_tetrahedral_host(const uint16_t* __restrict__ clut, const uint
         "v_addc_co_u32_e64 %0, vcc, %0, %0, %2\n\t"
         "v_addc_co_u32_e64 %0, vcc, %0, %0, %3"
         : "=&v"(idx), "=&s"(m02), "=&s"(m12), "=&s"(m01) : "v"(r[0]), "v"(r[1]), "v"(r[2]) : "vcc");
-    const uint32_t unit_off = cell_off + (idx << 4);
+    const uint32_t unit_off = cell_off + idx * (uint32_t)kIcc16UnitBytes;
     const uint32_t w12 = (mx - md) | ((md - mn) << 16), w03 = (mx ^ 0xffffu) | (mn << 16);
     typedef uint32_t u3 __attribute__((ext_vector_type(3)));     // 12 of the unit's 16 bytes: a fourth register would only be waited for
     const char* base = reinterpret_cast<const char*>(clut);
-    const u3 u03 = *reinterpret_cast<const u3*>(base + cell_off + 16 * kIcc16BaseUnit), u12 = *reinterpret_cast<const u3*>(base + unit_off);
+    const u3 u03 = *reinterpret_cast<const u3*>(base + cell_off + kIcc16UnitBytes * kIcc16BaseUnit), u12 = *reinterpret_cast<const u3*>(base + unit_off);
     const uint32_t a03[3] = { u03.x, u03.y, u03.z }, a12[3] = { u12.x, u12.y, u12.z };
 #pragma unroll
     for (int k = 0; k < 3; ++k) {

@@ -71,6 +71,35 @@ def test_write_rows_host_n_contexts_equal_one(rebind, monkeypatch, name):
             assert np.array_equal(got[pl], ref[pl]), (name, n, pl)       # byte-identical for every N, padding included
 
 
+@pytest.mark.parametrize("depth,lanes,slots", [(0, 2, 4), (1, 1, 4), (1, 2, 2), (1, 4, 3), (2, 2, 2), (4, 3, 8)])
+def test_upload_order_settings_give_the_same_bytes(rebind, monkeypatch, depth, lanes, slots):
+    """The scheduler's knobs -- uploads of a device unordered / in queue order, 1..4 at a time, lanes x slots below and above the
+    4 hardware queues -- change when copies run, never what they carry: many small sub-tiles on 1 and 3 contexts, both
+    directions, equal to the defaults' bytes; and a changed AVIFGPU_UPLOAD_DEPTH re-binds like the other knobs."""
+    wd = pkg.WriteDesc(**WRITE["c5-420-near"])
+    src = harness.make_write_source(wd, seed=21)
+    rd = pkg.ReadDesc(width=264, height=151, colorspace=pkg.COLORSPACE_YCBCR, chroma=pkg.CHROMA_420, bit_depth=10, depth=16,
+                      alpha_state=pkg.ALPHA_PREMULTIPLIED, matrix_coefficients=pkg.MATRIX_BT709)
+    planes = harness.make_read_source(rd, seed=5, stride_pad=8)
+    monkeypatch.setenv("AVIFGPU_CHUNK_MB", "1")
+    gpu = rebind(1)
+    want_w = harness.gpu_write(gpu, wd, src, mem="host", stride_pad=8, return_raw=True)
+    want_r = harness.gpu_read(gpu, rd, planes, mem="host")
+    monkeypatch.setenv("AVIFGPU_UPLOAD_DEPTH", str(depth))
+    monkeypatch.setenv("AVIFGPU_LANES", str(lanes))
+    monkeypatch.setenv("AVIFGPU_SLOTS", str(slots))
+    for n in (1, 3):
+        gpu = rebind(n)
+        for _ in range(2):                                     # twice: the second pass starts from the first one's event ring
+            got = harness.gpu_write(gpu, wd, src, mem="host", stride_pad=8, return_raw=True)
+            for pl in want_w:
+                assert np.array_equal(got[pl], want_w[pl]), (depth, lanes, slots, n, pl)
+            assert np.array_equal(harness.gpu_read(gpu, rd, planes, mem="host").view(np.uint8), want_r.view(np.uint8))
+    import torch
+    ndev = max(torch.cuda.device_count(), 1)
+    assert gpu.topology()[0]["workers"] == lanes * len([i for i in range(3) if i % ndev == 0])     # the knob took effect
+
+
 def test_read_rows_host_n_contexts_equal_one(rebind, monkeypatch):
     for kw in (dict(width=264, height=151, colorspace=pkg.COLORSPACE_YCBCR, chroma=pkg.CHROMA_420, bit_depth=10, depth=16,
                     alpha_state=pkg.ALPHA_PREMULTIPLIED, matrix_coefficients=pkg.MATRIX_BT709),
