@@ -20,6 +20,7 @@
 //     no peer traffic: a tile's output bytes depend on its own rows only, so the planes are byte-identical for any N.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -224,10 +225,93 @@ hipError_t copy_rows(void* dst, size_t dst_pitch, const void* src, size_t src_pi
     return hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, bytes, rows, kind, st);
 }
 
-void host_copy_rows(uint8_t* dst, size_t dst_pitch, const uint8_t* src, size_t src_pitch, size_t bytes, size_t rows)
+void copy_rows_here(uint8_t* dst, size_t dst_pitch, const uint8_t* src, size_t src_pitch, size_t bytes, size_t rows)
 {
     if (dst_pitch == bytes && src_pitch == bytes) { std::memcpy(dst, src, bytes * rows); return; }
     for (size_t r = 0; r < rows; ++r) std::memcpy(dst + r * dst_pitch, src + r * src_pitch, bytes);
+}
+
+// ---- CPU copies of pageable caller memory ------------------------------------------------------------------------------
+// A tile of pageable rows (or planes) goes through a pinned bounce buffer: a memcpy of 16-32 MiB that one thread does at 10-20 GB/s,
+// a third of what the link takes.  The workers share a few helper threads that split such a copy by rows (AVIFGPU_COPY_THREADS,
+// default 3 helpers beside the worker itself; 0 = the worker alone, round 2's behaviour).  Helpers are created on first use by the
+// worker that needs them and inherit its CPU affinity -- the NUMA node of that worker's GPU.  Page-locked caller memory never gets here.
+class CopyHelpers {
+public:
+    struct Piece { uint8_t* dst; const uint8_t* src; size_t dst_pitch, src_pitch, bytes, rows; std::atomic<int>* left; };
+    void copy(uint8_t* dst, size_t dst_pitch, const uint8_t* src, size_t src_pitch, size_t bytes, size_t rows)
+    {
+        const int helpers = want();
+        if (helpers == 0 || bytes * rows < ((size_t)2 << 20) || rows < 2) { copy_rows_here(dst, dst_pitch, src, src_pitch, bytes, rows); return; }
+        ensure(helpers);
+        const size_t parts = std::min<size_t>((size_t)helpers + 1, rows);
+        std::atomic<int> left((int)parts - 1);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (size_t k = 1; k < parts; ++k) {
+                const size_t r0 = rows * k / parts, r1 = rows * (k + 1) / parts;
+                queue_.push_back({ dst + r0 * dst_pitch, src + r0 * src_pitch, dst_pitch, src_pitch, bytes, r1 - r0, &left });
+            }
+        }
+        cv_.notify_all();
+        copy_rows_here(dst, dst_pitch, src, src_pitch, bytes, rows / parts);                 // the caller's own share: rows [0, rows/parts)
+        // help with whatever is still queued (this copy's pieces or another worker's), then wait for the pieces others took
+        for (;;) {
+            Piece p;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (queue_.empty()) break;
+                p = queue_.front(); queue_.pop_front();
+            }
+            run(p);
+        }
+        while (left.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+    }
+    void shutdown()
+    {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (std::thread& t : threads_) if (t.joinable()) t.join();
+        threads_.clear();
+        stop_ = false;
+    }
+private:
+    static int want() { return env_int("AVIFGPU_COPY_THREADS", 3, 0, 15); }
+    static void run(const Piece& p)
+    {
+        copy_rows_here(p.dst, p.dst_pitch, p.src, p.src_pitch, p.bytes, p.rows);
+        p.left->fetch_sub(1, std::memory_order_release);
+    }
+    void ensure(int n)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        while ((int)threads_.size() < n) threads_.emplace_back([this] { loop(); });
+    }
+    void loop()
+    {
+        for (;;) {
+            Piece p;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+                if (queue_.empty()) return;                     // stop
+                p = queue_.front(); queue_.pop_front();
+            }
+            run(p);
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<Piece> queue_;
+    std::vector<std::thread> threads_;
+    bool stop_ = false;
+};
+// never destroyed (like the contexts: their threads may outlive static destruction at process exit); contexts_shutdown() joins the helpers
+CopyHelpers& copy_helpers() { static CopyHelpers* p = new CopyHelpers; return *p; }
+
+void host_copy_rows(uint8_t* dst, size_t dst_pitch, const uint8_t* src, size_t src_pitch, size_t bytes, size_t rows)
+{
+    copy_helpers().copy(dst, dst_pitch, src, src_pitch, bytes, rows);
 }
 
 // ---- upload order ------------------------------------------------------------------------------------------------------
@@ -629,6 +713,7 @@ void contexts_shutdown()
     g_ctxs = nullptr;
     g_bound.clear();
     g_topo.clear();
+    copy_helpers().shutdown();                             // the next binding's workers make their own (affinity of THEIR node)
 }
 
 int contexts_init(const int32_t* devices, int count)
