@@ -228,6 +228,29 @@ def test_read_out_refuses_a_transform_that_is_not_a_table(lcms):
     assert pkg.load().avifgpu_icc_clut16_from_transforms(None, None, None, ctypes.byref(t)) == pkg.formatBadParameters
 
 
+def test_read_out_survives_hostile_callbacks():
+    """Callbacks that answer NaN, infinity, nonsense or the plain identity (which lcms2 never resamples) are refused by the proof --
+    no crash, no table.  Needs no lcms2: the callbacks are Python functions."""
+    lib = pkg.load()
+
+    def const_float(v):
+        def f(user, pin, pout, n):
+            np.ctypeslib.as_array(pout, (n * 3,))[:] = v
+        return pkg.TransformF32Fn(f)
+
+    def copy_words(user, pin, pout, n):
+        np.ctypeslib.as_array(pout, (n * 3,))[:] = np.ctypeslib.as_array(pin, (n * 3,))
+
+    def copy_floats(user, pin, pout, n):
+        np.ctypeslib.as_array(pout, (n * 3,))[:] = np.ctypeslib.as_array(pin, (n * 3,))
+    words = pkg.Transform16Fn(copy_words)
+    t = pkg.IccClut16()
+    for ff in (const_float(float("nan")), const_float(float("inf")), const_float(-1e30), const_float(0.5), pkg.TransformF32Fn(copy_floats)):
+        rc = lib.avifgpu_icc_clut16_from_transforms(ctypes.cast(ff, ctypes.c_void_p), ctypes.cast(words, ctypes.c_void_p), None, ctypes.byref(t))
+        assert rc == pkg.formatCannotRead
+        assert b"probe colours differ" in lib.avifgpu_last_error()
+
+
 def test_prepare_clut16_rejects_what_it_cannot_do(lcms):
     t = pkg.IccClut16()
     assert pkg.load().avifgpu_icc_prepare_clut16(bytes(300), 300, ctypes.byref(t)) == pkg.formatCannotRead
