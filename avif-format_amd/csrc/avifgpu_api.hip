@@ -200,16 +200,15 @@ int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p)
 {
     if (t->grid_points != AVIFGPU_ICC_CLUT_GRID) return fail(AVIFGPU_formatBadParameters, "16-bit ICC table: grid_points must be 33");
     const size_t n = sizeof(t->table);
-    // Device layout: one 128-byte RECORD (a cache line) per cell, seven 16-byte units of two nodes each (stored channel by channel
-    // as node pairs, the operand form of v_dot2_u32_u16 -- kernel_params.h; corner j = 4*dr + 2*dg + db): unit 0 = {corner 0, corner 7}, which every tetrahedron uses, and unit 1 + k = {corner 4 >> amax,
-    // corner 7 - (4 >> amin)} for the six orders of (axis of the largest fraction, axis of the smallest), k = 2*amax + amin -
-    // (amin > amax) -- so the four nodes of a pixel's tetrahedron arrive in TWO 16-byte gathers from ONE line, instead of four
-    // 8-byte gathers (or, in lcms2's node-major table, up to four lines 8.7 KiB / 264 B apart).  Cells exist for index 32 on every
-    // axis too (input 0xffff lands there with fraction 0): corners beyond the grid are zero, which is what the library's zeroed
-    // strides amount to (the node they reach is multiplied by 0).  33^3 x 128 B = 4.6 MB.
+    // Device layout (kernel_params.h, AG_ICC16_DOT2): node-PAIR tables, 1.76 MB -- the four nodes of a pixel's tetrahedron arrive in two
+    // 12-byte gathers, {p0, p3} from table A and {p1, p2} from table B, each pair stored channel by channel (lo | hi << 16), the operand
+    // form of v_dot2_u32_u16.  Nodes beyond the grid are zero: the fraction of an axis at its end is 0 and so is their weight, which is
+    // what the library's zeroed strides amount to.  Round 2 and the first half of round 3 used one 128-byte RECORD per cell (every
+    // node stored up to eight times, 4.6 MB: two gathers from one line, but the table did not stay in the 4 MB L2 next to the streams
+    // and uniformly random input re-fetched it from the Infinity Cache at 2.4 x the algorithmic traffic; layouts 1 and 0 below).
     constexpr size_t G = AVIFGPU_ICC_CLUT_GRID;
     constexpr size_t kRecU16 = kIcc16RecBytes / 2;
-    const size_t rec_bytes = G * G * G * kIcc16RecBytes;
+    const size_t rec_bytes = AG_ICC16_DOT2 == 2 ? (size_t)kIcc16PairTablesBytes : G * G * G * kIcc16RecBytes;
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return hip_fail(e, "hipGetDevice", AVIFGPU_writErr);
@@ -221,6 +220,28 @@ int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p)
     }
     if (c.icc16_host.size() != n || memcmp(c.icc16_host.data(), t->table, n) != 0) {
         std::vector<uint16_t> rec(rec_bytes / 2, 0);
+#if AG_ICC16_DOT2 == 2
+        // node-pair tables (kernel_params.h): A[n] = {node n, node n + (1,1,1)}, B[3 m + k] = {node m, node m + e_k}
+        {
+            auto node_at = [&](size_t r, size_t g, size_t b) -> const uint16_t* {
+                return (r < G && g < G && b < G) ? t->table[(r * G + g) * G + b] : nullptr;
+            };
+            auto put_pair = [&](uint16_t* dst, const uint16_t* lo, const uint16_t* hi) {
+                for (int ch = 0; ch < 3; ++ch) { dst[2 * ch] = lo ? lo[ch] : 0; dst[2 * ch + 1] = hi ? hi[ch] : 0; }
+            };
+            uint16_t* A = rec.data();
+            uint16_t* B = rec.data() + kIcc16TableABytes / 2;
+            for (size_t r = 0; r < G; ++r)
+                for (size_t g = 0; g < G; ++g)
+                    for (size_t b = 0; b < G; ++b) {
+                        const size_t n_ = (r * G + g) * G + b;
+                        put_pair(A + 6 * n_, node_at(r, g, b), node_at(r + 1, g + 1, b + 1));
+                        put_pair(B + 6 * (3 * n_ + 0), node_at(r, g, b), node_at(r + 1, g, b));
+                        put_pair(B + 6 * (3 * n_ + 1), node_at(r, g, b), node_at(r, g + 1, b));
+                        put_pair(B + 6 * (3 * n_ + 2), node_at(r, g, b), node_at(r, g, b + 1));
+                    }
+        }
+#else
         for (size_t r = 0; r < G; ++r)
             for (size_t g = 0; g < G; ++g)
                 for (size_t b = 0; b < G; ++b) {
@@ -229,13 +250,13 @@ int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p)
                         const size_t rr = r + ((j >> 2) & 1), gg = g + ((j >> 1) & 1), bb = b + (j & 1);
                         if (!(rr < G && gg < G && bb < G)) return;
                         const uint16_t* node = t->table[(rr * G + gg) * G + bb];
-#if AG_ICC16_DOT2
+#if AG_ICC16_DOT2 == 1
                         for (int ch = 0; ch < 3; ++ch) dst[(kIcc16UnitBytes / 2) * unit + 2 * ch + half] = node[ch];      // {a.R, b.R, a.G, b.G, a.B, b.B, 0, 0}
 #else
                         memcpy(dst + 8 * unit + 4 * half, node, 8);                                     // {a.R, a.G, a.B, 0, b.R, b.G, b.B, 0}
 #endif
                     };
-#if AG_ICC16_DOT2
+#if AG_ICC16_DOT2 == 1
                     put(kIcc16BaseUnit, 0, 0); put(kIcc16BaseUnit, 1, 7);
                     for (int idx = 0; idx < 8; ++idx) {
                         const int amax = kIcc16AxesOfIdx[idx][0], amin = kIcc16AxesOfIdx[idx][1];
@@ -252,6 +273,7 @@ int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p)
                         }
 #endif
                 }
+#endif
         e = hipDeviceSynchronize();                             // a launch may still be reading the previous table
         if (e == hipSuccess) e = hipMemcpy(c.icc16, rec.data(), rec_bytes, hipMemcpyHostToDevice);
         if (e != hipSuccess) return hip_fail(e, "upload of the ICC table", AVIFGPU_writErr);

@@ -12,7 +12,7 @@ namespace avifgpu {
 //   (0 = default).  (Bits 3 and 4 selected a register-prefetch and an XCD-contiguous variant in round 1; both lost and were removed.)
 enum : int { kHotDefault = 1 | 2 | 4 };
 
-// 16-bit ICC table on the device: bytes per cell record (upload_icc16 builds it, icc16_tetrahedral reads it)
+// 16-bit ICC table on the device (upload_icc16 builds it, icc16_tetrahedral* read it).  Layouts 0 and 1: bytes per cell record
 #ifndef AG_ICC16_REC96
 #define AG_ICC16_REC96 0        // 1: 12-byte units, 96-byte records, a 3.45 MB table instead of 4.6.  Measured: uniformly random input 0.672 ->
                                 // 0.606 ms (still not L2-resident), photograph-like 0.201 -> 0.206 (records straddle lines): left off
@@ -22,9 +22,16 @@ enum : int { kIcc16RecBytes = AG_ICC16_REC96 ? 96 : 128, kIcc16UnitBytes = AG_IC
 // Record layout / interpolation form: 1 = node PAIRS per channel ({a.R|b.R<<16, a.G|b.G<<16, a.B|b.B<<16, 0} per 16-byte unit) feeding
 // v_dot2_u32_u16 on weights, 0 = two whole nodes per unit and differences x fractions (round 2).  Shared by the uploader and the kernel.
 #ifndef AG_ICC16_DOT2
-#define AG_ICC16_DOT2 1
+#define AG_ICC16_DOT2 2
 #endif
-// ... and in that layout the unit of a cell record is picked by the three compares of the fractions,
+// AG_ICC16_DOT2 == 2: no cell records at all but node-PAIR tables, 1.76 MB instead of 4.6 (the L2 of an XCD holds 4 MB): table A,
+// entry n = {node n, node n + (1,1,1)} (the two ends of every tetrahedron of cell n), and table B, entry 3 m + k = {node m, node m + e_k}
+// (the middle pair: m = n + e_amax, k = the axis of the MIDDLE fraction); 12 bytes per entry (lo | hi << 16 per channel).  A pixel
+// still takes two 12-byte gathers.  Nodes beyond the grid are zero and carry weight 0 (lcms2 zeroes the stride of an axis at its end).
+enum : uint32_t { kIcc16Nodes = 33u * 33u * 33u, kIcc16PairBytes = 12u, kIcc16TableABytes = kIcc16Nodes * kIcc16PairBytes,
+                  kIcc16TableBEntries = kIcc16Nodes + 33u * 33u,           // m = n + stride(amax) may pass the last node by one slab
+                  kIcc16PairTablesBytes = kIcc16TableABytes + kIcc16TableBEntries * 3u * kIcc16PairBytes };
+// ... and in layout 1 the unit of a cell record is picked by the three compares of the fractions,
 // idx = (r0 >= r1) + 2 (r1 >= r2) + 4 (r0 >= r2): unit idx holds {corner 4 >> amax, corner 7 - (4 >> amin)} of the order idx stands
 // for, as (amax, amin) below; idx 3 and 4 are contradictions, unit 3 holds {corner 0, corner 7}, unit 4 is empty.
 enum : int { kIcc16BaseUnit = 3 };
@@ -73,7 +80,7 @@ struct WriteParams {
     const uint8_t* icc8_s2;      // [16385] 8-bit output curve (identical for R,G,B: the destination is sRGB)
     int32_t icc8_m[9];
     int32_t icc8_off[3];
-    // 16-bit CLUT transform (avifgpu_icc_clut16): 33^3 cell records of kIcc16RecBytes in device memory (4.6 MB)
+    // 16-bit CLUT transform (avifgpu_icc_clut16): the node-pair tables in device memory (1.76 MB; layouts above)
     const uint16_t* icc16_clut;
     // sampled curves of a 32-bit document (avifgpu_icc_sampled32): 3 x 65536 floats in device memory (768 KiB, L2-resident)
     const float* icc_s_tab;

@@ -476,6 +476,8 @@ AG_DEV uint32_t icc16_host_to_fixed(uint32_t i)                // i <= 32768
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t) : "v"(i), "s"(65537u), "v"(i > 16448u ? 512u - 32769u : 512u));
     return t >> 10;
 }
+// scalar coefficient x vector + vector accumulator, spelled out where instruction selection would otherwise split or widen it
+AG_DEV int mad24_sv(int s_coef, int v, int acc) { int d; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "s"(s_coef), "v"(v), "v"(acc)); return d; }
 AG_DEV uint32_t umax3(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_max3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 AG_DEV uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_min3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 AG_DEV uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_med3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
@@ -491,8 +493,25 @@ AG_DEV void icc16_tetrahedral_host(const uint16_t* __restrict__ clut, const uint
         c0i[k] = f >> 16;
         r[k] = f & 0xffffu;
     }
-    const uint32_t cell_off = ((c0i[0] * G + c0i[1]) * G + c0i[2]) * (uint32_t)kIcc16RecBytes;      // < 2^23: 32-bit offsets from the table base
     const uint32_t mx = umax3(r[0], r[1], r[2]), mn = umin3(r[0], r[1], r[2]), md = umed3(r[0], r[1], r[2]);
+    const uint32_t w12 = (mx - md) | ((md - mn) << 16), w03 = (mx ^ 0xffffu) | (mn << 16);
+    typedef uint32_t u3 __attribute__((ext_vector_type(3)));     // 12 bytes: lo | hi << 16 per channel
+    const char* base = reinterpret_cast<const char*>(clut);
+#if AG_ICC16_DOT2 == 2
+    // node-pair tables (kernel_params.h): {p0, p3} = A[n], {p1, p2} = B[3 (n + stride(amax)) + mid].  The order of the three fractions
+    // picks one of six byte offsets -- 36 stride(amax) + 12 mid, table A's size folded in -- through a tree of selects on the three
+    // compares; ties resolve to ANY order holding a maximal and a minimal axis (the sum is the same).
+    const uint32_t n12 = (uint32_t)mad24_sv(33 * 33 * (int)kIcc16PairBytes, (int)c0i[0], mad24_sv(33 * (int)kIcc16PairBytes, (int)c0i[1], (int)(c0i[2] * kIcc16PairBytes)));
+    constexpr uint32_t S0 = 33u * 33u * 36u, S1 = 33u * 36u, S2 = 36u, TA = kIcc16TableABytes;
+    const bool c01 = r[0] >= r[1], c12 = r[1] >= r[2], c02 = r[0] >= r[2];
+    //                     r0>=r1>=r2: max 0, mid 1      r0>=r2>r1: max 0, mid 2         r2>r0>=r1: max 2, mid 0
+    const uint32_t hi01 = c12 ? TA + S0 + 12u : (c02 ? TA + S0 + 24u : TA + S2 + 0u);
+    //                     r1>r0>=r2 (c02): max 1, mid 0;  r1>=r2>r0: max 1, mid 2        r2>r1>r0: max 2, mid 1
+    const uint32_t lo01 = c12 ? (c02 ? TA + S1 + 0u : TA + S1 + 24u) : TA + S2 + 12u;
+    const uint32_t pair_off = (uint32_t)mad24_sv(3, (int)n12, (int)(c01 ? hi01 : lo01));          // < 2^21
+    const u3 u03 = *reinterpret_cast<const u3*>(base + n12), u12 = *reinterpret_cast<const u3*>(base + pair_off);
+#else
+    const uint32_t cell_off = ((c0i[0] * G + c0i[1]) * G + c0i[2]) * (uint32_t)kIcc16RecBytes;      // < 2^23: 32-bit offsets from the table base
     // the record is addressed by the outcome of the three compares, idx = (r0 >= r1) + 2 (r1 >= r2) + 4 (r0 >= r2): unit idx holds the
     // middle node pair of that order (upload_icc16, kIcc16UnitOfIdx); idx 3 and 4 cannot occur -- unit 3 holds {corner 0, corner 7}.
     // Ties resolve to ANY order holding a maximal and a minimal axis: the sum is the same.  (v_cmp + v_addc_co: idx = 2 idx + carry.)
@@ -508,10 +527,8 @@ AG_DEV void icc16_tetrahedral_host(const uint16_t* __restrict__ clut, const uint
         "v_addc_co_u32_e64 %0, vcc, %0, %0, %3"
         : "=&v"(idx), "=&s"(m02), "=&s"(m12), "=&s"(m01) : "v"(r[0]), "v"(r[1]), "v"(r[2]) : "vcc");
     const uint32_t unit_off = cell_off + idx * (uint32_t)kIcc16UnitBytes;
-    const uint32_t w12 = (mx - md) | ((md - mn) << 16), w03 = (mx ^ 0xffffu) | (mn << 16);
-    typedef uint32_t u3 __attribute__((ext_vector_type(3)));     // 12 of the unit's 16 bytes: a fourth register would only be waited for
-    const char* base = reinterpret_cast<const char*>(clut);
     const u3 u03 = *reinterpret_cast<const u3*>(base + cell_off + kIcc16UnitBytes * kIcc16BaseUnit), u12 = *reinterpret_cast<const u3*>(base + unit_off);
+#endif
     const uint32_t a03[3] = { u03.x, u03.y, u03.z }, a12[3] = { u12.x, u12.y, u12.z };
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -686,7 +703,6 @@ enum { kOutRefColor = 0, kOutRefGray = 1, kOutYcbcr = 2 };
 #define AG_W8_PKF32 0
 #endif
 typedef f32x2 f2;
-AG_DEV int mad24_sv(int s_coef, int v, int acc) { int d; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "s"(s_coef), "v"(v), "v"(acc)); return d; }
 // chroma samples per lane: 4 for u16 planes, AG_W8_NC for u8 planes (every plane store >= 8 / 4 bytes per lane)
 // The parametric ICC variants (2, 4) carry ~300 instructions and up to 86 parameter VGPRs per pixel stream: with sub-sampled chroma
 // 2 chroma samples per lane keep a 4:2:0 footprint at 8 pixels (16: 197 VGPRs, 2 waves/SIMD, 6.9 k instructions; measured
