@@ -341,6 +341,14 @@ int upload_icc8(const avifgpu_icc_shaper8* t, WriteParams& p)
     p.icc8_s1 = static_cast<const int32_t*>(c.icc8);
     p.icc8_s2 = static_cast<const uint8_t*>(c.icc8) + n1;
     for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) p.icc8_m[3 * i + j] = t->matrix[i][j]; p.icc8_off[i] = t->offset[i]; }
+    // the packed u8 kernel can take two of the three products of a matrix row in one v_dot2_i32_i16 when their operands fit 16
+    // signed bits: the G and B columns (a coefficient of 2.0 or more -- 32768 in 1.14 -- sits on the diagonal of a wide-gamut red,
+    // ProPhoto or ACES to sRGB, i.e. in column 0, which keeps its 24-bit multiply) and the G and B shaper tables (<= 16384 for curves into [0, 1])
+    bool fits = true;
+    for (int i = 0; i < 3; ++i) for (int j = 1; j < 3; ++j) fits = fits && t->matrix[i][j] >= -32768 && t->matrix[i][j] <= 32767;
+    for (int c2 = 1; c2 < 3; ++c2) for (int v = 0; v < 256; ++v) fits = fits && t->shaper1[c2][v] >= 0 && t->shaper1[c2][v] <= 32767;
+    p.icc8_dot2 = (fits && !(g_hot_variant & 32)) ? 1 : 0;  // bit 5 of the tuning word: tests take the three-mad form on the same data
+    for (int i = 0; i < 3; ++i) p.icc8_m12[i] = (int32_t)(((uint32_t)t->matrix[i][1] & 0xffffu) | ((uint32_t)t->matrix[i][2] << 16));
     return 0;
 }
 

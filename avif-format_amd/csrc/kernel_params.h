@@ -8,7 +8,7 @@ namespace avifgpu {
 // Tuning word of the dominant kernel (RGB f32 -> curve -> YCbCr 4:4:4 u16), see launch_write():
 //   bit0 enable the streaming kernels, bit1 8 px/lane (else 4), bit2 non-temporal loads+stores, bit3 take the geometry-gated
 //   streaming kernels (RGB16) whatever the frame size (tests use it to reach them on small frames), bit4 (16) no FLAT launches
-//   (launch_write: contiguous 4:4:4 / interleaved tiles are launched as one long row), bits 8.. = block cap
+//   (launch_write: contiguous 4:4:4 / interleaved tiles are launched as one long row), bit5 (32) no v_dot2 in the packed 8-bit ICC stage, bits 8.. = block cap
 //   (0 = default).  (Bits 3 and 4 selected a register-prefetch and an XCD-contiguous variant in round 1; both lost and were removed.)
 enum : int { kHotDefault = 1 | 2 | 4 };
 
@@ -80,6 +80,8 @@ struct WriteParams {
     const uint8_t* icc8_s2;      // [16385] 8-bit output curve (identical for R,G,B: the destination is sRGB)
     int32_t icc8_m[9];
     int32_t icc8_off[3];
+    int32_t icc8_m12[3];         // row i: m[i][1] | m[i][2] << 16, the operand of v_dot2_i32_i16 -- valid when icc8_dot2
+    int32_t icc8_dot2;           // the G and B columns of the 1.14 matrix and the G and B shaper tables fit 16 signed bits
     // 16-bit CLUT transform (avifgpu_icc_clut16): the node-pair tables in device memory (1.76 MB; layouts above)
     const uint16_t* icc16_clut;
     // sampled curves of a 32-bit document (avifgpu_icc_sampled32): 3 x 65536 floats in device memory (768 KiB, L2-resident)

@@ -703,6 +703,15 @@ enum { kOutRefColor = 0, kOutRefGray = 1, kOutYcbcr = 2 };
 #define AG_W8_PKF32 0
 #endif
 typedef f32x2 f2;
+// The 8-bit matrix-shaper on the packed u8 path (FAST8 in write_px) with two of the three products of a row in one v_dot2_i32_i16,
+// where the launch says the operands fit (WriteParams::icc8_dot2): 3 -> 2 multiply instructions per channel.  0 = always three mads.
+#ifndef AG_ICC8_DOT2
+#define AG_ICC8_DOT2 1
+#endif
+template <int DEPTH, int PLANES, int OUT, bool DST16, bool ALIGNED, int ICC> constexpr bool icc8_fast8()
+{
+    return AG_W8_PACKED && AG_ICC8_FAST && ICC == 3 && DEPTH == 8 && (PLANES == 3 || PLANES == 4) && OUT == 2 /* kOutYcbcr */ && !DST16 && ALIGNED;
+}
 // chroma samples per lane: 4 for u16 planes, AG_W8_NC for u8 planes (every plane store >= 8 / 4 bytes per lane)
 // The parametric ICC variants (2, 4) carry ~300 instructions and up to 86 parameter VGPRs per pixel stream: with sub-sampled chroma
 // 2 chroma samples per lane keep a 4:2:0 footprint at 8 pixels (16: 197 VGPRs, 2 waves/SIMD, 6.9 k instructions; measured
@@ -745,7 +754,9 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
     __shared__ int32_t icc8_s1[ICC8 ? 768 : 1];
     __shared__ __attribute__((aligned(16))) uint8_t icc8_s2[ICC8 ? 16400 : 16];
     if constexpr (ICC8) {
-        for (int i = threadIdx.x; i < 768; i += AG_WPX_BLOCK) icc8_s1[i] = p.icc8_s1[i];
+        // dot2 form (FAST8 path below): the B table is kept shifted into the high half, so that G | B is the packed operand
+        const bool hi_b = AG_ICC8_DOT2 && icc8_fast8<DEPTH, PLANES, OUT, DST16, ALIGNED, ICC>() && p.icc8_dot2;
+        for (int i = threadIdx.x; i < 768; i += AG_WPX_BLOCK) icc8_s1[i] = (hi_b && i >= 512) ? (int32_t)((uint32_t)p.icc8_s1[i] << 16) : p.icc8_s1[i];
         for (int i = threadIdx.x; i < 16388 / 4; i += AG_WPX_BLOCK)
             reinterpret_cast<uint32_t*>(icc8_s2)[i] = reinterpret_cast<const uint32_t*>(p.icc8_s2)[i];
         __syncthreads();
@@ -861,7 +872,8 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
                     const int e = PLANES * i + k;
                     return (float)((raw[vr][e >> 2] >> (8 * (e & 3))) & 0xffu);
                 };
-                auto convert = [&](auto nearest_c) {                        // one uniform branch per footprint, not one per chroma sample
+                static_assert(ICC != 3 || icc8_fast8<DEPTH, PLANES, OUT, DST16, ALIGNED, ICC>(), "the LDS fill above decides the B table's form with this");
+                auto convert = [&](auto nearest_c, auto dot2_c) {           // uniform branches per footprint, not per chroma sample
 #pragma unroll
                 for (int j = 0; j < NC; ++j) {
                     // Pin the order: nothing of chroma sample j may be computed before sample j - 1 is done.  (Left alone, instruction
@@ -883,6 +895,19 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
                                 const int r = icc8_s1[(raw[vr][e0 >> 2] >> (8 * (e0 & 3))) & 0xffu];
                                 const int g = icc8_s1[256 + ((raw[vr][(e0 + 1) >> 2] >> (8 * ((e0 + 1) & 3))) & 0xffu)];
                                 const int b = icc8_s1[512 + ((raw[vr][(e0 + 2) >> 2] >> (8 * ((e0 + 2) & 3))) & 0xffu)];
+                                if constexpr (decltype(dot2_c)::value) {
+                                    // m1 g + m2 b in one v_dot2_i32_i16 (the B table entries sit in the high half: g | b is the operand pair),
+                                    // m0 r as a 24-bit mad: the same wrapping int32 sum
+                                    typedef short s2 __attribute__((ext_vector_type(2)));
+                                    const uint32_t gb = (uint32_t)g | (uint32_t)b;
+#pragma unroll
+                                    for (int ch = 0; ch < 3; ++ch) {
+                                        int l = __builtin_amdgcn_sdot2(__builtin_bit_cast(s2, gb), __builtin_bit_cast(s2, p.icc8_m12[ch]),
+                                                                       mad24_sv(p.icc8_m[3 * ch], r, p.icc8_off[ch] + 0x2000), false) >> 14;
+                                        l = l < 0 ? 0 : (l > 16384 ? 16384 : l);
+                                        c[vr][k][ch] = (float)icc8_s2[l];
+                                    }
+                                } else
 #pragma unroll
                                 for (int ch = 0; ch < 3; ++ch) {
                                     // three v_mad_i32_i24 in a chain (wrapping int32 sums are associative: any order is the library's value).
@@ -942,7 +967,13 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
                     __builtin_amdgcn_sched_barrier(0);                      // ... and the machine scheduler may not interleave them either
                 }
                 };
-                if ((XS || YS) && p.nearest) convert(std::true_type{}); else convert(std::false_type{});
+                const bool near = (XS || YS) && p.nearest;
+                if constexpr (ICC == 3 && AG_ICC8_DOT2) {
+                    if (p.icc8_dot2) { if (near) convert(std::true_type{}, std::true_type{}); else convert(std::false_type{}, std::true_type{}); }
+                    else { if (near) convert(std::true_type{}, std::false_type{}); else convert(std::false_type{}, std::false_type{}); }
+                } else {
+                    if (near) convert(std::true_type{}, std::false_type{}); else convert(std::false_type{}, std::false_type{});
+                }
                 const int ncvalid = (nvalid + (1 << XS) - 1) >> XS;
                 uint8_t* dcb = p.dst[1] + (long long)gy * p.dst_stride[1] + (x0 >> XS);
                 uint8_t* dcr = p.dst[2] + (long long)gy * p.dst_stride[2] + (x0 >> XS);

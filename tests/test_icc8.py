@@ -166,6 +166,31 @@ def test_gpu_icc8_packed_u8_plane_path(gpu, lcms, width, chroma, planes, alpha_s
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,kind,trc,g", [PROFILES[0], PROFILES[2], PROFILES[-1]])
+def test_gpu_every_rgb_triple_through_the_packed_path_both_matrix_forms(gpu, lcms, name, kind, trc, g):
+    """All 2^24 RGB8 triples through the packed u8-plane kernel (8-bit YCbCr 4:4:4 behind the ICC stage), once with two products of a
+    matrix row in a v_dot2_i32_i16 (the default where the operands fit 16 bits) and once as three 24-bit mads (tuning bit 32):
+    the same planes, equal to lcms2 ConvertRow + the oracle's pixel loop."""
+    icc = _profile(lcms, kind, trc, g)
+    sh = gpu.icc_prepare_shaper8(icc)
+    src = _all_rgb()
+    conv = src.copy()
+    assert lcms.oracle_icc_convert_rows_to_srgb8(icc, len(icc), 0, conv.ctypes.data, 4096, 4096, conv.strides[0]) == 0
+    d = pkg.WriteDesc(width=4096, height=4096, depth=8, planes=3, bit_depth=8, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR,
+                      chroma=pkg.CHROMA_444, matrix_coefficients=pkg.MATRIX_BT601)
+    want = harness.oracle_write(d, conv)
+    try:
+        for variant in (1 | 2 | 4, (1 | 2 | 4) | 32):
+            gpu.lib.avifgpu_set_hot_variant(variant)
+            got = _gpu(gpu, d, src, sh, pad=True)
+            assert "icc=3" in gpu.last_kernel() and "aligned=1" in gpu.last_kernel()
+            for pl in want:
+                assert np.array_equal(got[pl], want[pl]), (name, variant, pl)
+    finally:
+        gpu.lib.avifgpu_set_hot_variant(1 | 2 | 4)
+
+
+@pytest.mark.gpu
 def test_host_shim_converts_8bit_document_to_srgb(gpu, lcms):
     """FormatRecord shim with saveOptions.convertToSRGB: tiles converted with lcms2's 8-bit pipeline and handed off like
     CreateHeifImageRGBEightBit (interleaved RGBA, heif_chroma_interleaved_RGBA), byte-identical to lcms2 + the pixel loop."""
