@@ -21,7 +21,10 @@ Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per launch
 SURVEY.md 8d) / mean kernel time from HIP events recorded on the launch stream; `roofline.peak` = the 8 TB/s spec,
 `roofline.peak_measured` = what the kernel's MATH-FREE twin (same loads and stores, no conversion) reaches on the same buffers in
 the same process, `frac_of_measured` = achieved / that; `read_only_frac` is the north-star's literal "HBM-read" figure (input bytes
-only), bounded by 12/18 for 4:4:4 output -- `frac` is the one that is claimed.  Extra objects on the same line:
+only), bounded by 12/18 for 4:4:4 output -- `frac` is the one that is claimed.  `roofline.traffic` = HBM bytes per launch from
+the PMC counters, measured in THIS run at N = 1 by two child `rocprofv3 --pmc` passes over the same kernel (measure_traffic_live;
+about 25 s; --no-live-traffic or a missing rocprofv3 falls back to the committed profiles/traffic.json, and the line says which).
+Extra objects on the same line:
   c5              BASELINE.json configs[4] (16384 x 16384 RGBA f32 -> 12-bit PQ Y,Cb,Cr,A), the same N-way row split, device-resident
   pcie_inclusive  rank 0 alone, ONE process, the library's in-process row-tile scheduler on the N GPUs of the run
                   (avifgpu_init_devices): page-locked host rows in, host planes out -- what N x16 links buy this path
@@ -66,6 +69,53 @@ def make_frame(torch, dev, width, height, planes, seed):
     return a.view(height, width * planes).contiguous()
 
 
+def measure_traffic_live(args, kernel_name):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, measured NOW: two child runs of this script's
+    --traffic-child mode (the same frame, the same kernel, 24 launches) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`
+    -- counters in passes of their own, no trace domain beside them -- corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE is
+    in KiB and gfx950 tallies a 128-byte read request as 64: x 2; WRITE_SIZE in KiB as reported).  Returns None where rocprofv3
+    is not installed; a dict with a `note` instead of numbers when a pass fails (the caller then falls back to profiles/traffic.json)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None
+    base = kernel_name.split("<")[0].split()[0]
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--traffic-child", "--width", str(args.width), "--height", str(args.height),
+             "--bits", str(args.bits), "--chroma", args.chroma, "--transfer", args.transfer, "--scaling", args.scaling]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    got = {}
+    t0 = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="avifgpu_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([exe, "--pmc", counter, "--kernel-include-regex", base, "-d", d, "-o", "t", "--output-format", "csv", "--", *child],
+                               cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+            vals = []
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(f, newline="")):
+                    if row.get("Counter_Name") == counter and base in row.get("Kernel_Name", ""):
+                        vals.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or len(vals) < 8:
+                return {"note": f"live {counter} pass gave {len(vals)} samples (rc {r.returncode}): {r.stderr[-200:]!r}"}
+            vals = vals[4:]                                   # the first launches warm the TLBs and caches
+            got[counter] = (sum(vals) / len(vals), len(vals))
+        except Exception as exc:      # noqa: BLE001 -- a diagnostic must not lose the headline line
+            return {"note": f"live {counter} pass failed: {exc}"}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    rd, wr = got["FETCH_SIZE"][0] * 2048.0, got["WRITE_SIZE"][0] * 1024.0
+    return {"hbm_bytes_per_launch": rd + wr, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
+            "source": f"measured in this run: child rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (own passes, no trace domains) over "
+                      f"{got['FETCH_SIZE'][1]} + {got['WRITE_SIZE'][1]} launches of {base}; FETCH_SIZE KiB x 2 (gfx950 counts a 128-B read as 64) "
+                      f"+ WRITE_SIZE KiB; {time.perf_counter() - t0:.0f} s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +137,9 @@ def main():
     ap.add_argument("--no-rotate", action="store_true", help="skip the rotating-buffer (Infinity Cache) cross-check of the kernel time")
     ap.add_argument("--no-c5", action="store_true", help="skip the configs[4] (16384^2 RGBA f32) sub-measurement")
     ap.add_argument("--no-pattern", action="store_true", help="skip the math-free pattern probe (roofline.peak_measured)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two child rocprofv3 --pmc passes); use profiles/traffic.json")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)   # the child of those passes: the kernel alone, 24 launches
     args = ap.parse_args()
 
     import torch
@@ -147,6 +200,12 @@ def main():
         launches[0] += 1
         gpu.write_rows(desc, row0, nrows, src.data_ptr(), src.stride(0) * 4, ptrs, strides,
                        mem=pkg.MEM_DEVICE, stream=stream.cuda_stream)
+
+    if args.traffic_child:                     # under rocprofv3 --pmc (measure_traffic_live): the kernel alone, nothing printed
+        for _ in range(24):
+            step()
+        torch.cuda.synchronize(dev)
+        return
 
     if args.sweep:
         lib = pkg.load()
@@ -341,8 +400,17 @@ def main():
     out["profile_window"] = {"kernel": kernel_name, "launches_before_timed_region": launches_before_timed, "timed_launches": args.steps}
     # PMC-derived HBM traffic per launch: NOT measured in this run (counters need their own rocprofv3 --pmc passes, which the
     # driver's plain run cannot do) -- read from the committed summary of those passes and labelled as such
+    live = None
+    if world == 1 and not args.no_live_traffic:
+        live = measure_traffic_live(args, kernel_name)
+    if live and live.get("hbm_bytes_per_launch"):
+        out["roofline"]["traffic"] = live["hbm_bytes_per_launch"]
+        out["roofline"]["traffic_source"] = live["source"]
+        out["roofline"]["traffic_over_algorithmic"] = round(live["hbm_bytes_per_launch"] / algo_bytes, 5)
+    elif live:
+        out["roofline"]["traffic_live_note"] = live.get("note")
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and world == 1:
+    if os.path.exists(tpath) and world == 1 and not (live and live.get("hbm_bytes_per_launch")):
         try:
             tj = json.load(open(tpath))
             if tj.get("workload") == f"{W}x{H}-{args.chroma}-{args.bits}":
