@@ -90,9 +90,11 @@ int rows_per_tile(int32_t max_data, int64_t row_bytes, int height, bool even)
     // so a generous maxData is not used up: 16 MiB (8192^2 f32 save with the host fill skipped: 17.6 ms with 8 MiB tiles, 16.5 with 16,
     // profiles/r03/host_shim_after_upload_order.txt; before the uploads were ordered 8 MiB was the better of the two,
     // profiles/r02/host_shim_end_to_end.jsonl).  AVIFGPU_TILE_MB overrides the cap.
-    int64_t cap = 16;
-    if (const char* v = getenv("AVIFGPU_TILE_MB")) { const long x = strtol(v, nullptr, 0); if (x >= 1 && x <= 2047) cap = x; }
-    int64_t budget = max_data > 0 ? std::min<int64_t>(max_data, cap << 20) : (cap << 20);
+    // ... and a small document still gets two dozen tiles to pipeline: a 24th of the image, between 4 and 16 MiB (the default 8-bit
+    // 4:2:2 save of an 8192^2 document: 7.4 ms with 8 MiB tiles, 7.7 with 16).
+    int64_t cap_bytes = std::min<int64_t>(std::max<int64_t>(row_bytes * (int64_t)height / 24, (int64_t)4 << 20), (int64_t)16 << 20);
+    if (const char* v = getenv("AVIFGPU_TILE_MB")) { const long x = strtol(v, nullptr, 0); if (x >= 1 && x <= 2047) cap_bytes = (int64_t)x << 20; }
+    int64_t budget = max_data > 0 ? std::min<int64_t>(max_data, cap_bytes) : cap_bytes;
     budget = std::min<int64_t>(budget, std::numeric_limits<int32_t>::max());
     int64_t rows = budget / std::max<int64_t>(row_bytes, 1);
     rows = std::min<int64_t>(rows, height);
