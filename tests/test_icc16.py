@@ -6,6 +6,7 @@ driven like the reference (oracle/icc_oracle.c).  Bar: bit-exact.
 CPU part: the host-built table (avifgpu_icc_prepare_clut16) + a numpy restatement of the interpolation against lcms2's raw
 TYPE_RGB_16 transform.  GPU part: the fused kernel against the whole reference flow."""
 import ctypes
+import functools
 import os
 
 import numpy as np
@@ -329,6 +330,47 @@ def test_gpu_16bit_rows_bit_exact_for_an_a2b_profile(gpu, lcms, variant):
         for pl in want:
             assert np.array_equal(got[pl], want[pl]), (variant, kw, pl)
         assert "icc=5" in gpu.last_kernel()
+
+
+@functools.lru_cache(maxsize=1)
+def _photograph_like(width, height, seed=77):
+    """Large-scale gradients + a few codes of noise (the kind of content tools/bench_configs.py's photograph rows use), Photoshop's
+    16-bit range.  A 1024-row band of the gradient repeated down the frame, fresh noise everywhere: cheap to make at 67 Mpx."""
+    rng = np.random.default_rng(seed)
+    band = min(1024, height)
+    y = np.linspace(0, 1, band, dtype=np.float32).reshape(-1, 1)
+    x = np.linspace(0, 1, width, dtype=np.float32).reshape(-1, 1)
+    ph = np.array([0.0, 2.1, 4.2], dtype=np.float32).reshape(1, 3)
+    a = (6.0 * x + ph).reshape(1, -1)                          # sin(a + b) cos(c - e) by the addition theorems: outer products only
+    b, c, e = 3.0 * y, 2.0 * y, np.repeat(x, 3, axis=1).reshape(1, -1)
+    img = (np.sin(a) * np.cos(b) + np.cos(a) * np.sin(b)) * (np.cos(c) * np.cos(e) + np.sin(c) * np.sin(e))
+    base = ((0.5 + 0.45 * img) * 32000.0 + 300.0).astype(np.int16)
+    frame = np.tile(base, ((height + band - 1) // band, 1))[:height]
+    frame += rng.integers(-96, 97, size=frame.shape, dtype=np.int8)          # a few codes of noise; stays inside [0, 32768]
+    assert frame.min() >= 0
+    return frame.view(np.uint16)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(bit_depth=12, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444, matrix_coefficients=pkg.MATRIX_BT601),
+                                dict(bit_depth=8, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420, matrix_coefficients=pkg.MATRIX_BT601)],
+                         ids=["12bit-444", "8bit-420"])
+def test_gpu_full_frame_photograph_bit_exact(gpu, lcms, kw):
+    """The two measured configurations of the table kernel at their measured size -- 8192 x 8192 RGB16, photograph-like content, an
+    AdobeRGB document saved as 12-bit 4:4:4 and as 8-bit 4:2:0: every sample of every plane equals lcms2's ConvertRow (the real
+    library, 67 Mpx on the CPU) followed by the oracle's pixel loop."""
+    icc = _profile(lcms, 3, 0, 2.19921875)
+    clut = gpu.icc_prepare_clut16(icc)
+    w = h = 8192
+    src = _photograph_like(w, h)
+    conv = src.copy()
+    assert lcms.oracle_icc_convert_rows_to_srgb16(icc, len(icc), 0, 0, conv.ctypes.data, w, h, conv.strides[0]) == 0
+    d = pkg.WriteDesc(width=w, height=h, depth=16, planes=3, alpha_state=pkg.ALPHA_NONE, **kw)
+    want = harness.oracle_write(d, conv)
+    got = _gpu(gpu, d, src, clut)
+    for pl in want:
+        assert np.array_equal(got[pl], want[pl]), (kw, pl)
+    assert "icc=5" in gpu.last_kernel()
 
 
 @pytest.mark.gpu
