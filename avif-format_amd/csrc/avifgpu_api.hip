@@ -205,7 +205,7 @@ int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p)
     // form of v_dot2_u32_u16.  Nodes beyond the grid are zero: the fraction of an axis at its end is 0 and so is their weight, which is
     // what the library's zeroed strides amount to.  Round 2 and the first half of round 3 used one 128-byte RECORD per cell (every
     // node stored up to eight times, 4.6 MB: two gathers from one line, but the table did not stay in the 4 MB L2 next to the streams
-    // and uniformly random input re-fetched it from the Infinity Cache at 2.4 x the algorithmic traffic; layouts 1 and 0 below).
+    // and uniformly random input re-fetched it from the Infinity Cache at 2.4 x the algorithmic traffic; layout 1 below, kept for A/B).
     constexpr size_t G = AVIFGPU_ICC_CLUT_GRID;
     constexpr size_t kRecU16 = kIcc16RecBytes / 2;
     const size_t rec_bytes = AG_ICC16_DOT2 == 2 ? (size_t)kIcc16PairTablesBytes : G * G * G * kIcc16RecBytes;
@@ -250,28 +250,14 @@ int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p)
                         const size_t rr = r + ((j >> 2) & 1), gg = g + ((j >> 1) & 1), bb = b + (j & 1);
                         if (!(rr < G && gg < G && bb < G)) return;
                         const uint16_t* node = t->table[(rr * G + gg) * G + bb];
-#if AG_ICC16_DOT2 == 1
                         for (int ch = 0; ch < 3; ++ch) dst[(kIcc16UnitBytes / 2) * unit + 2 * ch + half] = node[ch];      // {a.R, b.R, a.G, b.G, a.B, b.B, 0, 0}
-#else
-                        memcpy(dst + 8 * unit + 4 * half, node, 8);                                     // {a.R, a.G, a.B, 0, b.R, b.G, b.B, 0}
-#endif
                     };
-#if AG_ICC16_DOT2 == 1
                     put(kIcc16BaseUnit, 0, 0); put(kIcc16BaseUnit, 1, 7);
                     for (int idx = 0; idx < 8; ++idx) {
                         const int amax = kIcc16AxesOfIdx[idx][0], amin = kIcc16AxesOfIdx[idx][1];
                         if (amax < 0) continue;
                         put(idx, 0, 4 >> amax); put(idx, 1, 7 - (4 >> amin));
                     }
-#else
-                    put(0, 0, 0); put(0, 1, 7);
-                    for (int amax = 0; amax < 3; ++amax)
-                        for (int amin = 0; amin < 3; ++amin) {
-                            if (amin == amax) continue;
-                            const int k = 2 * amax + amin - (amin > amax ? 1 : 0);
-                            put(1 + k, 0, 4 >> amax); put(1 + k, 1, 7 - (4 >> amin));
-                        }
-#endif
                 }
 #endif
         e = hipDeviceSynchronize();                             // a launch may still be reading the previous table

@@ -12,29 +12,25 @@ namespace avifgpu {
 //   (0 = default).  (Bits 3 and 4 selected a register-prefetch and an XCD-contiguous variant in round 1; both lost and were removed.)
 enum : int { kHotDefault = 1 | 2 | 4 };
 
-// 16-bit ICC table on the device (upload_icc16 builds it, icc16_tetrahedral* read it).  Layouts 0 and 1: bytes per cell record
-#ifndef AG_ICC16_REC96
-#define AG_ICC16_REC96 0        // 1: 12-byte units, 96-byte records, a 3.45 MB table instead of 4.6.  Measured: uniformly random input 0.672 ->
-                                // 0.606 ms (still not L2-resident), photograph-like 0.201 -> 0.206 (records straddle lines): left off
-                                // (profiles/r03/icc16_rec96_ab.txt)
-#endif
-enum : int { kIcc16RecBytes = AG_ICC16_REC96 ? 96 : 128, kIcc16UnitBytes = AG_ICC16_REC96 ? 12 : 16 };
-// Record layout / interpolation form: 1 = node PAIRS per channel ({a.R|b.R<<16, a.G|b.G<<16, a.B|b.B<<16, 0} per 16-byte unit) feeding
-// v_dot2_u32_u16 on weights, 0 = two whole nodes per unit and differences x fractions (round 2).  Shared by the uploader and the kernel.
+// 16-bit ICC table on the device (upload_icc16 builds it, icc16_tetrahedral_host reads it): AG_ICC16_DOT2 picks the layout.  Both keep
+// node PAIRS per channel (lo | hi << 16), the operand form of v_dot2_u32_u16, and cost a pixel two 12-byte gathers.
+//   2 (default)  node-pair tables, 1.76 MB, L2-resident
+//   1            one 128-byte record per cell (every node stored up to eight times, 4.6 MB): 1 % faster on photograph-like input, but
+//                uniformly random input re-fetches the table from the Infinity Cache at 2.4 x the algorithmic traffic
+//                (profiles/r03/icc16_pair_tables_ab.txt).  A 96-byte record and round 2's whole-node records are in the git history.
 #ifndef AG_ICC16_DOT2
 #define AG_ICC16_DOT2 2
 #endif
-// AG_ICC16_DOT2 == 2: no cell records at all but node-PAIR tables, 1.76 MB instead of 4.6 (the L2 of an XCD holds 4 MB): table A,
-// entry n = {node n, node n + (1,1,1)} (the two ends of every tetrahedron of cell n), and table B, entry 3 m + k = {node m, node m + e_k}
+// Layout 2: table A, entry n = {node n, node n + (1,1,1)} (the two ends of every tetrahedron of cell n), and table B, entry 3 m + k = {node m, node m + e_k}
 // (the middle pair: m = n + e_amax, k = the axis of the MIDDLE fraction); 12 bytes per entry (lo | hi << 16 per channel).  A pixel
 // still takes two 12-byte gathers.  Nodes beyond the grid are zero and carry weight 0 (lcms2 zeroes the stride of an axis at its end).
 enum : uint32_t { kIcc16Nodes = 33u * 33u * 33u, kIcc16PairBytes = 12u, kIcc16TableABytes = kIcc16Nodes * kIcc16PairBytes,
                   kIcc16TableBEntries = kIcc16Nodes + 33u * 33u,           // m = n + stride(amax) may pass the last node by one slab
                   kIcc16PairTablesBytes = kIcc16TableABytes + kIcc16TableBEntries * 3u * kIcc16PairBytes };
-// ... and in layout 1 the unit of a cell record is picked by the three compares of the fractions,
+// Layout 1: 16-byte units of a 128-byte cell record; the unit is picked by the three compares of the fractions,
 // idx = (r0 >= r1) + 2 (r1 >= r2) + 4 (r0 >= r2): unit idx holds {corner 4 >> amax, corner 7 - (4 >> amin)} of the order idx stands
 // for, as (amax, amin) below; idx 3 and 4 are contradictions, unit 3 holds {corner 0, corner 7}, unit 4 is empty.
-enum : int { kIcc16BaseUnit = 3 };
+enum : int { kIcc16RecBytes = 128, kIcc16UnitBytes = 16, kIcc16BaseUnit = 3 };
 //                                         idx:      0        1        2      3 (base)   4 (none)    5        6        7
 constexpr int kIcc16AxesOfIdx[8][2] = { { 2, 0 }, { 2, 1 }, { 1, 0 }, { -1, -1 }, { -1, -1 }, { 0, 1 }, { 1, 2 }, { 0, 2 } };
 

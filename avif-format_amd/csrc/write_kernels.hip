@@ -419,56 +419,15 @@ AG_DEV uint32_t icc16_lcms_to_host(uint32_t j) { return (j + 1u + (j >= 65408u ?
 // fractions the library's if-tree picks one order; any order gives the same sum, because the tied terms (p1-p0)*r + (p2-p1)*r
 // collapse to (p2-p0)*r -- exactly, also modulo 2^32 -- so the intermediate node drops out.  That makes the selection a few
 // compares and selects (v_max3 / v_med3 / v_min3) instead of a divergent six-way branch.
-AG_DEV void icc16_tetrahedral(const uint16_t* __restrict__ clut, const uint32_t (&in)[3], uint32_t (&out)[3])
-{
-    constexpr int G = AVIFGPU_ICC_CLUT_GRID;
-    uint32_t c0i[3], r[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        // _cmsToFixedDomain(in * 32) = a + (a + 0x7fff) / 0xffff with a = 32 * in; for every 16-bit input the quotient equals
-        // (in + 1024) >> 11 (tests/test_icc16.py checks all 65536 values): shift, add, shift-add instead of six operations
-        const uint32_t f = (in[k] << 5) + ((in[k] + 1024u) >> 11);
-        c0i[k] = f >> 16;
-        r[k] = f & 0xffffu;
-    }
-    // The device table holds one 128-byte record (one cache line) per CELL, laid out for the FOUR nodes a tetrahedron needs to arrive
-    // in TWO 16-byte gathers (upload_icc16): unit 0 = {corner 0, corner 7} (every tetrahedron), unit 1 + k = {corner jmax, corner
-    // 7 - jmin} for the six (max axis, min axis) orders, corner j = 4*dr + 2*dg + db.  The library zeroes the stride of an axis whose
-    // input is 0xffff (cell index 32); its fraction is then 0, and the records of those cells hold zeros for the corners beyond the grid.
-    const uint32_t cell = (c0i[0] * G + c0i[1]) * G + c0i[2];
-    const uint32_t mx = max(max(r[0], r[1]), r[2]), mn = min(min(r[0], r[1]), r[2]);
-    const uint32_t md = r[0] + r[1] + r[2] - mx - mn;
-    const uint32_t amax = r[0] == mx ? 0u : (r[1] == mx ? 1u : 2u);  // first axis holding the maximum ...
-    const uint32_t amin = r[2] == mn ? 2u : (r[1] == mn ? 1u : 0u);  // ... last axis holding the minimum: distinct axes even when all tie
-    const uint32_t k = 2u * amax + amin - (amin > amax ? 1u : 0u);   // 0..5
-    const uint32_t ra = mx, rb = md, rc = mn;
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    const u4* rec = reinterpret_cast<const u4*>(clut + (kIcc16RecBytes / 2) * cell);
-    const u4 v07 = rec[0], v12 = rec[1u + k];
-    struct { uint32_t x, y; } v0{ v07.x, v07.y }, v3{ v07.z, v07.w }, v1{ v12.x, v12.y }, v2{ v12.z, v12.w };
-    const uint32_t p0[3] = { v0.x & 0xffffu, v0.x >> 16, v0.y & 0xffffu }, p1[3] = { v1.x & 0xffffu, v1.x >> 16, v1.y & 0xffffu };
-    const uint32_t p2[3] = { v2.x & 0xffffu, v2.x >> 16, v2.y & 0xffffu }, p3[3] = { v3.x & 0xffffu, v3.x >> 16, v3.y & 0xffffu };
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        // 17-bit signed differences x 16-bit fractions: v_mul_i32_i24 (full rate) returns the low 32 bits of the product,
-        // i.e. exactly the wrapping int32 multiply of the library
-        const uint32_t rest = (uint32_t)__mul24((int)(p1[k] - p0[k]), (int)ra) +
-                              (uint32_t)__mul24((int)(p2[k] - p1[k]), (int)rb) +
-                              (uint32_t)__mul24((int)(p3[k] - p2[k]), (int)rc) + 0x8001u;
-        const int32_t t = (int32_t)rest;
-        out[k] = (p0[k] + (uint32_t)((t + (t >> 16)) >> 16)) & 0xffffu;
-    }
-}
-
-#if AG_ICC16_DOT2
-// The same transform in the form this kernel's bound asks for (it is VALU-issue bound: profiles/r03/pmc_icc16_random_vs_photo.json):
+//
+// The kernel is VALU-issue bound (profiles/r03/pmc_icc3_icc5.json), so the arithmetic takes the forms that issue fewest instructions:
 //  * host sample -> 16.16 grid position in one expression.  With j = icc16_host_to_lcms(i) the library's position is
 //    32 j + ((32 j + 0x7fff) / 0xffff) = (j << 5) + ((j + 1024) >> 11); for i <= 32768 that equals
 //    (65537 i + 512 - (i > 16448 ? 32769 : 0)) >> 10 (tests/test_icc16.py checks all 32769 inputs): 5 operations instead of 9.
-//  * the tetrahedron from three compares: idx = (r0 >= r1) + 2 (r1 >= r2) + 4 (r0 >= r2) picks the record unit from a packed constant.
+//  * the tetrahedron from three compares (r0 >= r1, r1 >= r2, r0 >= r2): they pick the byte offset of the middle node pair.
 //  * Rest = (p1-p0) ra + (p2-p1) rb + (p3-p2) rc + 0x8001 regrouped by NODE: p0 (0xffff - ra) + p1 (ra - rb) + p2 (rb - rc) + p3 rc
 //    + (0x8001 + p0 - (p0 << 16)) -- the same value modulo 2^32, which is all the library's int32 arithmetic keeps -- so that two
-//    v_dot2_u32_u16 on node pairs (the record stores them paired per channel) replace three subtractions and three multiplies.
+//    v_dot2_u32_u16 on node pairs (the table stores them paired per channel) replace three subtractions and three multiplies.
 AG_DEV uint32_t icc16_host_to_fixed(uint32_t i)                // i <= 32768
 {
     // both factors fit 24 bits, the sum 32.  Spelled out: left to itself instruction selection takes v_mad_u64_u32 (quarter rate) for two of three
@@ -540,7 +499,6 @@ AG_DEV void icc16_tetrahedral_host(const uint16_t* __restrict__ clut, const uint
         out[k] = (p0 + (uint32_t)((t + (t >> 16)) >> 16)) & 0xffffu;
     }
 }
-#endif
 
 // ---- stage A: one source pixel -> integer codes (reference WriteHeifImage.cpp inner loops) --------
 // s[] holds the PLANES raw samples (u8/u16 values, or f32 bit patterns).  q[0..NCOL-1] colour, q[3] alpha.
@@ -590,7 +548,6 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
         if constexpr (ICC == 5 && DEPTH == 16 && COLOR) {
             // ConvertRow for 16-bit rows (ColorProfileConversion.cpp:159-187): range map, lcms2 transform, range map back --
             // all PLANES samples take the two maps, the three colours also the table
-#if AG_ICC16_DOT2
             uint32_t cin[3] = { sx[0], sx[1], sx[2] }, cout[3];                 // <= 32768: clamped by write_px as the row arrives (packed)
             icc16_tetrahedral_host(p.icc16_clut, cin, cout);
             if constexpr (QF) {
@@ -607,12 +564,6 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
                 return;
             }
             if constexpr (PLANES == 4) sx[3] = icc16_host_to_lcms(sx[3]);
-#else
-#pragma unroll
-            for (int k = 0; k < PLANES; ++k) sx[k] = icc16_host_to_lcms(sx[k] > 32768u ? 32768u : sx[k]);
-            uint32_t cin[3] = { sx[0], sx[1], sx[2] }, cout[3];
-            icc16_tetrahedral(p.icc16_clut, cin, cout);
-#endif
             sx[0] = cout[0]; sx[1] = cout[1]; sx[2] = cout[2];
 #pragma unroll
             for (int k = 0; k < PLANES; ++k) sx[k] = icc16_lcms_to_host(sx[k]);
@@ -1027,7 +978,7 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
             else return (qp[vr][i][0] >> (8 * k)) & 0xffu;
         };
         // the 16-bit table transform into u16 Y, Cb, Cr planes hands its colour codes over as floats (stage_a, QF)
-        constexpr bool QF = AG_ICC16_DOT2 && ICC == 5 && DEPTH == 16 && PLANES == 3 && DST16 && OUT == kOutYcbcr && !PACK;
+        constexpr bool QF = ICC == 5 && DEPTH == 16 && PLANES == 3 && DST16 && OUT == kOutYcbcr && !PACK;
         auto qflt = [&](int vr, int i, int k) -> float {
             if constexpr (QF) return __uint_as_float(qp[vr][i][k]); else return (float)qget(vr, i, k);
         };
@@ -1044,7 +995,7 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
                 // occupancy: C4 4:2:0 0.69 -> 0.47 of peak, profiles/r01/transposed_load_experiment.txt).
                 uint32_t raw[ND];
                 load_dwords<ND, false, ALIGNED>(rowp + (long long)x0 * BPP, raw);
-                if constexpr (ICC == 5 && DEPTH == 16 && AG_ICC16_DOT2) {
+                if constexpr (ICC == 5 && DEPTH == 16) {
                     // the ICC stage's input clamp (Photoshop's 16-bit white is 32768; the table position is defined up to there), two
                     // samples per v_pk_min_u16 while they are still packed
                     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -1069,7 +1020,7 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
 #pragma unroll
                     for (int k = 0; k < PLANES; ++k) {
                         if constexpr (DEPTH == 8) s[i][k] = ld_u8(pp + k);
-                        else if constexpr (DEPTH == 16) s[i][k] = (ICC == 5 && AG_ICC16_DOT2) ? min(ld_u16(pp + 2 * k), 32768u) : ld_u16(pp + 2 * k);
+                        else if constexpr (DEPTH == 16) s[i][k] = ICC == 5 ? min(ld_u16(pp + 2 * k), 32768u) : ld_u16(pp + 2 * k);
                         else s[i][k] = ld_u32(pp + 4 * k);
                     }
                 }
