@@ -19,6 +19,7 @@
 #include "kernel_params.h"
 #include "staging.h"
 #include "device_math.h"
+#include "satword_f32.h"
 #include "../../include/avifgpu.h"
 
 #pragma clang fp contract(off)
@@ -379,19 +380,31 @@ AG_DEV void icc_apply(const WriteParams& p, const IccRegs& q, const IccPowTable&
 // own arithmetic -- the product and the + 0.5 in double (exact), _cmsQuickFloor's magic-number floor, the two saturation tests --
 // and the float is looked up (768 KiB table, L2-resident).  Matrix in fp32 FMAs on host-rounded coefficients like the streaming
 // kernels (tier 2), the inverse sRGB curve after it for the Clip save.
+#ifndef AG_ICC6_F64
+#define AG_ICC6_F64 0
+#endif
 AG_DEV uint32_t icc_quick_saturate_word(float v)
 {
+#if AG_ICC6_F64
     const double d = (double)v * 65535.0 + 0.5;
     const double t = (d - 32767.0) + 103079215104.0;            // _cmsQuickFloor: 68719476736.0 * 1.5, the low word >> 16
     const uint32_t q = (uint32_t)((__double2loint(t) >> 16) + 32767) & 0xffffu;       // & 0xffff: a NaN sample must not index outside
     return d <= 0.0 ? 0u : (d >= 65535.0 ? 0xffffu : q);
+#else
+    return quick_saturate_word_f32(v);                          // the same word for every float (tools/satword_check.hip: all 2^32), no FP64
+#endif
 }
+// The curve stage alone (one table lookup per sample): write_px runs it for ALL pixels of a lane's footprint before any of them goes
+// on, so the lookups of a footprint are in flight together -- pixel by pixel every lookup's latency was exposed (0.63 ms for C4).
+AG_DEV float icc_sampled_curve(const WriteParams& p, int channel, float v)
+{
+    return p.icc_s_tab[65536 * channel + icc_quick_saturate_word(v)];
+}
+// ... and what follows it: the matrix (and the inverse sRGB curve of a Clip save).  t[] = the curve stage's outputs.
 AG_DEV void icc_apply_sampled(const WriteParams& p, float (&c)[3])
 {
     const IccPowTableF noT = { nullptr };
-    float t[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) t[k] = p.icc_s_tab[65536 * k + icc_quick_saturate_word(c[k])];
+    const float t[3] = { c[0], c[1], c[2] };
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         c[i] = __builtin_fmaf(t[2], p.icc_m_f[3 * i + 2], __builtin_fmaf(t[1], p.icc_m_f[3 * i + 1], t[0] * p.icc_m_f[3 * i + 0]));
@@ -1029,6 +1042,13 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
                 for (int i = 0; i < PXT; ++i)
 #pragma unroll
                     for (int k = 0; k < PLANES; ++k) s[i][k] = 0;
+            }
+            if constexpr (ICC == 6 && DEPTH == 32 && (PLANES == 3 || PLANES == 4)) {
+                // sampled document curves: the footprint's lookups first, all in flight at once (icc_sampled_curve); alpha is not looked up
+#pragma unroll
+                for (int i = 0; i < PXT; ++i)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) s[i][k] = __float_as_uint(icc_sampled_curve(p, k, __uint_as_float(s[i][k])));
             }
             auto stage_row = [&](auto rescale8) {
 #pragma unroll

@@ -78,6 +78,8 @@ def smooth_src(d):
     img = (img * 32768.0 + 40.0 * torch.randn(img.shape, generator=g, device=dev)).clamp_(0, 32768)
     if d.depth == 8:
         return (img / 128.5).to(torch.uint8).reshape(d.height, -1)
+    if d.depth == 32:
+        return (img / 32768.0).to(torch.float32).reshape(d.height, -1).contiguous()
     return img.to(torch.int32).to(torch.int16).reshape(d.height, -1)
 
 
@@ -195,6 +197,11 @@ if __name__ == "__main__":
         n = L.oracle_icc_make_profile(0, 1, 0.0, buf, len(buf))
         xf2 = gpu.icc_prepare(buf.raw[:n])
         bench_write("C4 + ICC (sRGB parametric TRC doc -> Rec.2020) 8192^2 RGB f32 -> 10-bit PQ 4:4:4", icc=xf2, width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=9, color_primaries=9)
+        big = ctypes.create_string_buffer(1 << 18)
+        n = L.oracle_icc_make_profile(1, 3, 1024.0, big, len(big))          # Display-P3 primaries, sRGB EOTF as a 1024-entry `curv` table
+        if n > 0:
+            bench_write("C4 + ICC (sampled-curve doc profile -> Rec.2020), photograph-like input 8192^2 RGB f32 -> 10-bit PQ 4:4:4", icc=gpu.icc_prepare_sampled(big.raw[:n]), smooth=True, width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=9, color_primaries=9)
+            bench_write("C4 + ICC (sampled-curve doc profile -> Rec.2020) 8192^2 RGB f32 -> 10-bit PQ 4:4:4", icc=gpu.icc_prepare_sampled(big.raw[:n]), width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=9, color_primaries=9)
         n = L.oracle_icc_make_profile(1, 0, 1.0, buf, len(buf))
         xf3 = gpu.icc_prepare(buf.raw[:n], P.ICC_TARGET_SRGB_FLOAT)
         bench_write("SDR save of a 32-bit doc + ICC (linear Display-P3 -> sRGB) 8192^2 RGB f32 -> 12-bit Clip 4:2:0", icc=xf3, width=8192, height=8192, depth=32, planes=3, bit_depth=12, transfer=P.TRANSFER_CLIP, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=6, color_primaries=1)

@@ -45,7 +45,7 @@ def main():
         cmd = ["rocprofv3", "--pmc", *g, "-d", d, "-o", "p", "--output-format", "csv", "--", "bash", "-c",
                "cd %s && python tools/bench_configs.py %s > %s/cfg.jsonl 2>/dev/null" % (ROOT, " ".join(shlex.quote(r) for r in rows), d)]
         os.makedirs(d, exist_ok=True)
-        r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd="/tmp", timeout=900)
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd="/tmp", timeout=int(os.environ.get("PMC_PASS_TIMEOUT", "180")))
         if r.returncode != 0:
             notes.append("pass failed: " + " ".join(g) + ": " + r.stderr[-300:])
             continue
