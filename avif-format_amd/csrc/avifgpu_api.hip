@@ -5,6 +5,7 @@
 // (one worker thread + staging slots per context, row tiles dealt across contexts); device-pointer calls
 // launch directly on the caller's stream and device.
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -271,7 +272,11 @@ int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p)
 
 int upload_icc_sampled(const avifgpu_icc_sampled32* t, WriteParams& p)
 {
-    const size_t n = sizeof(t->curve);
+    // curve[] (768 KiB) followed by table16[] (24 KiB): one device buffer, one upload when the profile changes
+    const size_t nc = sizeof(t->curve), nt = sizeof(t->table16), n = nc + nt;
+    for (int ch = 0; ch < 3; ++ch)
+        if (t->entries[ch] < 0 || t->entries[ch] > AVIFGPU_ICC_SAMPLED_MAX || t->entries[ch] == 1)
+            return fail(AVIFGPU_formatBadParameters, "sampled ICC curves: entries[] must be 0 or 2..%d", (int)AVIFGPU_ICC_SAMPLED_MAX);
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return hip_fail(e, "hipGetDevice", AVIFGPU_writErr);
@@ -281,13 +286,18 @@ int upload_icc_sampled(const avifgpu_icc_sampled32* t, WriteParams& p)
         e = hipMalloc(&c.s32, n);
         if (e != hipSuccess) { c.s32 = nullptr; return hip_fail(e, "hipMalloc(sampled ICC curves)", AVIFGPU_memFullErr); }
     }
-    if (c.s32_host.size() != n || memcmp(c.s32_host.data(), t->curve, n) != 0) {
+    const uint8_t* host = reinterpret_cast<const uint8_t*>(t->curve);        // curve[] and table16[] are adjacent members
+    static_assert(offsetof(avifgpu_icc_sampled32, table16) == offsetof(avifgpu_icc_sampled32, curve) + sizeof(t->curve), "one span");
+    if (c.s32_host.size() != n || memcmp(c.s32_host.data(), host, n) != 0) {
         e = hipDeviceSynchronize();                             // a launch may still be reading the previous curves
-        if (e == hipSuccess) e = hipMemcpy(c.s32, t->curve, n, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(c.s32, host, n, hipMemcpyHostToDevice);
         if (e != hipSuccess) return hip_fail(e, "upload of the sampled ICC curves", AVIFGPU_writErr);
-        c.s32_host.assign(reinterpret_cast<const uint8_t*>(t->curve), reinterpret_cast<const uint8_t*>(t->curve) + n);
+        c.s32_host.assign(host, host + n);
     }
     p.icc_s_tab = static_cast<const float*>(c.s32);
+    p.icc_s_tab16 = reinterpret_cast<const uint16_t*>(static_cast<const uint8_t*>(c.s32) + nc);
+    const bool lds = t->entries[0] > 0 && t->entries[1] > 0 && t->entries[2] > 0 && !(g_hot_variant & 64);   // bit 6: tests take the memory path
+    for (int ch = 0; ch < 3; ++ch) p.icc_s_n[ch] = lds ? t->entries[ch] : 0;
     return 0;
 }
 

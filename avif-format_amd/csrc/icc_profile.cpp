@@ -264,6 +264,14 @@ extern "C" int32_t avifgpu_icc_prepare_sampled(const void* icc_profile, uint32_t
             return fail(AVIFGPU_formatCannotRead, "not every channel carries a sampled curve: parametric profiles take avifgpu_icc_prepare");
     for (int c = 0; c < 3; ++c)
         for (uint32_t in = 0; in < 65536; ++in) out->curve[c][in] = (float)(eval_table16(trc[c].table, (uint16_t)in) / 65535.0);
+    std::memset(out->table16, 0, sizeof(out->table16));
+    bool small = true;
+    for (int c = 0; c < 3; ++c) small = small && trc[c].table.size() <= (size_t)AVIFGPU_ICC_SAMPLED_MAX;
+    for (int c = 0; c < 3; ++c) {
+        out->entries[c] = small ? (int32_t)trc[c].table.size() : 0;
+        if (small) std::memcpy(out->table16[c], trc[c].table.data(), trc[c].table.size() * sizeof(uint16_t));
+    }
+    out->reserved = 0;
     return 0;
 }
 

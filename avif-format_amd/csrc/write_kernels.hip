@@ -400,6 +400,25 @@ AG_DEV float icc_sampled_curve(const WriteParams& p, int channel, float v)
 {
     return p.icc_s_tab[65536 * channel + icc_quick_saturate_word(v)];
 }
+// The same value computed where a lookup is cheap: the profile's own table sits in LDS (<= 4096 entries per channel, stored as
+// pairs T[i] | T[i+1] << 16 so that one ds_read_b32 fetches both ends of a segment) and the kernel does what cmsEvalToneCurve16 does for
+// a sampled curve -- LinLerp1D (cmsintrp.c): position = _cmsToFixedDomain(domain * word) = x + (x + 0x7fff) / 0xffff, 15.16; the
+// rounded blend y0 + (((y1 - y0) * rest + 0x8000) >> 16) in unsigned 32-bit wrap-around arithmetic -- then divides the word by 65535
+// as a float (three FMAs that equal (float)(w / 65535.0) for every w: tests/test_gpu_icc.py checks all 65536 against curve[]).
+// A wave-wide scattered load from memory costs the texture addresser ~64 cycles whatever its locality (profiles/r03/icc6_input_probe.txt);
+// an LDS read of 64 different words a handful.
+AG_DEV float icc_sampled_curve_lds(const uint32_t* __restrict__ pairs, uint32_t domain, float v)
+{
+    const uint32_t word = icc_quick_saturate_word(v);
+    const uint32_t x = __umul24(domain, word);                                  // < 2^28
+    const uint32_t val3 = x + (uint32_t)(((uint64_t)(x + 0x7fffu) * 0x80008001ull) >> 47);       // (x + 0x7fff) / 0xffff, exact below 2^32
+    const uint32_t pr = pairs[val3 >> 16];
+    const uint32_t y0 = pr & 0xffffu, y1 = pr >> 16;
+    const uint32_t dif = (uint32_t)__mul24((int)(y1 - y0), (int)(val3 & 0xffffu)) + 0x8000u;     // 17 x 16 signed bits: the wrapped product
+    const float w = (float)(((dif >> 16) + y0) & 0xffffu);
+    const float q0 = w * (1.0f / 65535.0f);
+    return __builtin_fmaf(__builtin_fmaf(-q0, 65535.0f, w), 1.0f / 65535.0f, q0);
+}
 // ... and what follows it: the matrix (and the inverse sRGB curve of a Clip save).  t[] = the curve stage's outputs.
 AG_DEV void icc_apply_sampled(const WriteParams& p, float (&c)[3])
 {
@@ -726,6 +745,22 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
         __syncthreads();
     }
 
+    // sampled-curve ICC variant: the profile's tables as (T[i], T[i+1]) pairs in dynamic LDS (4 bytes per entry, sized by the launch)
+    extern __shared__ uint32_t icc6_pairs[];
+    const bool icc6_lds = ICC == 6 && p.icc_s_n[0] > 0;
+    const int icc6_off[3] = { 0, p.icc_s_n[0], p.icc_s_n[0] + p.icc_s_n[1] };
+    if constexpr (ICC == 6) {
+        if (icc6_lds) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const uint16_t* t16 = p.icc_s_tab16 + ch * AVIFGPU_ICC_SAMPLED_MAX;
+                const int n = p.icc_s_n[ch];
+                for (int i = threadIdx.x; i < n; i += AG_WPX_BLOCK) icc6_pairs[icc6_off[ch] + i] = (uint32_t)t16[i] | ((uint32_t)t16[min(i + 1, n - 1)] << 16);
+            }
+            __syncthreads();
+        }
+    }
+
     // parametric-curve ICC variants: the pow() table (1.5 KiB), filled once per workgroup
     constexpr bool ICCPOW = (ICC == 2 || ICC == 4);
     constexpr bool ICCF = IccF32<ICC>::value;
@@ -1044,11 +1079,20 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
                     for (int k = 0; k < PLANES; ++k) s[i][k] = 0;
             }
             if constexpr (ICC == 6 && DEPTH == 32 && (PLANES == 3 || PLANES == 4)) {
-                // sampled document curves: the footprint's lookups first, all in flight at once (icc_sampled_curve); alpha is not looked up
+                // sampled document curves, the whole footprint before any pixel goes on; alpha is not looked up.  In LDS where the
+                // profile's tables are small enough (uniform per launch), else one memory lookup per sample, all of them in flight at once.
+                if (icc6_lds) {
 #pragma unroll
-                for (int i = 0; i < PXT; ++i)
+                    for (int i = 0; i < PXT; ++i)
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) s[i][k] = __float_as_uint(icc_sampled_curve(p, k, __uint_as_float(s[i][k])));
+                        for (int k = 0; k < 3; ++k)
+                            s[i][k] = __float_as_uint(icc_sampled_curve_lds(icc6_pairs + icc6_off[k], (uint32_t)p.icc_s_n[k] - 1u, __uint_as_float(s[i][k])));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < PXT; ++i)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) s[i][k] = __float_as_uint(icc_sampled_curve(p, k, __uint_as_float(s[i][k])));
+                }
             }
             auto stage_row = [&](auto rescale8) {
 #pragma unroll
@@ -2120,8 +2164,10 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, char* label)
             else {
                 snprintf(label, kLabelBytes, "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=6>",
                          DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned);
-                if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 6>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
-                else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 6>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
+                const size_t lds = p.icc_s_n[0] > 0 ? (size_t)(p.icc_s_n[0] + p.icc_s_n[1] + p.icc_s_n[2]) * 4 : 0;      // <= 48 KiB
+                if (lds) snprintf(label + strlen(label), kLabelBytes - strlen(label), " lds");
+                if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 6>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), lds, st, p);
+                else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 6>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), lds, st, p);
                 return hipGetLastError();
             }
         }

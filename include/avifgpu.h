@@ -346,12 +346,18 @@ int32_t avifgpu_write_rows_icc(const avifgpu_write_desc* desc, const avifgpu_icc
  * word (_cmsQuickSaturateWord(v * 65535.0)), interpolates the table in 16-bit fixed point (cmsEvalToneCurve16 = LinLerp1D) and
  * divides back by 65535 -- so per channel the curve stage is a function of a 16-bit index.  avifgpu_icc_prepare_sampled tabulates
  * it (65536 floats per channel, the library's arithmetic restated on the host: csrc/icc_profile.cpp), the kernel computes the same
- * index in double and looks the float up; matrix and, for the sRGB target, the inverse curve follow as in avifgpu_icc_transform.
+ * index and looks the float up (or interpolates the profile's own table in LDS: the same value); matrix and, for the sRGB target, the inverse curve follow as in avifgpu_icc_transform.
  * All three channels must be sampled (a profile that mixes sampled and parametric channels, and every LUT-based / A2B profile,
  * still returns AVIFGPU_formatCannotRead: the caller keeps lcms2).  768 KiB: allocate it once per save. */
+enum { AVIFGPU_ICC_SAMPLED_MAX = 4096 };
 typedef struct avifgpu_icc_sampled32 {
     avifgpu_icc_transform base;  /* matrix, out_curve, out_params as above; trc_type[] = 0 */
     float curve[3][65536];       /* curve[c][_cmsQuickSaturateWord(v * 65535.0)] = what lcms2's curve stage hands to the matrix for sample v */
+    /* The profile's own tables, when none has more than AVIFGPU_ICC_SAMPLED_MAX entries (entries[] = 0 otherwise): the kernel then keeps
+     * them in LDS and performs LinLerp1D itself -- the same words, the same floats as curve[], without a scattered memory load per sample. */
+    uint16_t table16[3][AVIFGPU_ICC_SAMPLED_MAX];
+    int32_t  entries[3];
+    int32_t  reserved;
 } avifgpu_icc_sampled32;
 int32_t avifgpu_icc_prepare_sampled(const void* icc_profile, uint32_t size, int32_t target, avifgpu_icc_sampled32* out);
 int32_t avifgpu_write_rows_icc_sampled(const avifgpu_write_desc* desc, const avifgpu_icc_sampled32* icc,

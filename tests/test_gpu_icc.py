@@ -454,6 +454,27 @@ def test_sampled_curve_tables_equal_lcms2_per_word(lcms):
         c = np.ctypeslib.as_array(t.curve)
         assert c.shape == (3, 65536) and np.all(np.diff(c, axis=1) >= 0), name
         assert np.all(c[:, 0] == 0.0) and np.all(c[:, 65535] == 1.0), name
+        # the profile's own tables ride along, and what the kernel does with them in LDS (icc_sampled_curve_lds: LinLerp1D with the
+        # division by 0xffff as a multiply-shift, then w / 65535 as three single-precision FMAs) returns curve[] bit for bit, every word
+        n = list(t.entries)
+        assert n == [int(g)] * 3, (name, n)
+        w = np.arange(65536, dtype=np.uint64)
+        for ch in range(3):
+            tab = np.ctypeslib.as_array(t.table16)[ch, :n[ch]].astype(np.uint64)
+            pairs = tab | (np.append(tab[1:], tab[-1:]) << np.uint64(16))
+            x = np.uint64(n[ch] - 1) * w
+            val3 = x + (((x + np.uint64(0x7fff)) * np.uint64(0x80008001)) >> np.uint64(47))
+            assert np.array_equal(val3, x + (x + np.uint64(0x7fff)) // np.uint64(0xffff))
+            pr = pairs[(val3 >> np.uint64(16)).astype(np.int64)]
+            y0, y1 = pr & np.uint64(0xffff), pr >> np.uint64(16)
+            dif = ((y1.astype(np.int64) - y0.astype(np.int64)) * (val3 & np.uint64(0xffff)).astype(np.int64) + 0x8000) & 0xffffffff
+            out16 = ((dif >> 16) + y0.astype(np.int64)) & 0xffff
+            wf = out16.astype(np.float32)
+            r = np.float32(1.0) / np.float32(65535.0)
+            q0 = wf * r
+            fma = lambda a, b, cc: (a.astype(np.float64) * b.astype(np.float64) + cc.astype(np.float64)).astype(np.float32)   # exact product + one rounding
+            got = fma(fma(-q0, np.full_like(q0, 65535.0), wf), np.full_like(q0, r), q0)
+            assert np.array_equal(got.view(np.uint32), c[ch].view(np.uint32)), (name, ch)
     # a parametric profile is not "sampled"; a non-profile is rejected
     icc = _profile(lcms, 1, 2, 1.8)
     assert lib.avifgpu_icc_prepare_sampled(icc, len(icc), 0, ctypes.byref(pkg.IccSampled32())) == pkg.formatCannotRead
@@ -485,7 +506,15 @@ def test_sampled_document_curves_match_lcms2(gpu, lcms, name, kind, trc, g, plan
             assert conv_fn(icc, len(icc), int(planes == 4), conv.ctypes.data, d.width, d.height, conv.strides[0]) == 0
             want = harness.oracle_write(d, conv)
             got = _gpu_write_icc(gpu, d, src, xf)
-            assert "icc=6" in gpu.last_kernel(), gpu.last_kernel()
+            assert "icc=6" in gpu.last_kernel() and " lds" in gpu.last_kernel(), gpu.last_kernel()
+            try:                                               # the memory-lookup form of the same kernel (tuning bit 64): the same planes
+                gpu.lib.avifgpu_set_hot_variant(1 | 2 | 4 | 64)
+                mem = _gpu_write_icc(gpu, d, src, xf)
+                assert "icc=6" in gpu.last_kernel() and " lds" not in gpu.last_kernel(), gpu.last_kernel()
+            finally:
+                gpu.lib.avifgpu_set_hot_variant(1 | 2 | 4)
+            for pl in got:
+                assert np.array_equal(got[pl], mem[pl]), (name, pl)
             st = harness.compare_write(d, want, got)
             print(f"icc-sampled {name} planes {planes} target {target} out {output} {bits}-bit transfer {transfer}: exact {st['exact_frac']:.5f} max {st['max_abs']}")
             assert st["max_abs"] <= 1, (name, st)
