@@ -481,6 +481,17 @@ def test_sampled_curve_tables_equal_lcms2_per_word(lcms):
     assert lib.avifgpu_icc_prepare_sampled(bytes(200), 200, 0, ctypes.byref(pkg.IccSampled32())) == pkg.formatCannotRead
 
 
+def test_single_precision_word_equals_the_librarys_for_every_float():
+    """tools/satword_check (built from tools/satword_check.hip with hipcc): the kernel's single-precision form of
+    _cmsQuickSaturateWord(v * 65535.0) against the double-precision one, all 2^32 float bit patterns, on the device."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "satword_check")
+    if not os.path.exists(exe):
+        pytest.skip("tools/satword_check not built (hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o tools/satword_check tools/satword_check.hip)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "differing words: 0" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("name,kind,trc,g", SAMPLED)
 @pytest.mark.parametrize("planes", [3, 4])
 def test_sampled_document_curves_match_lcms2(gpu, lcms, name, kind, trc, g, planes):
