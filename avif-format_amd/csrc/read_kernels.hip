@@ -616,18 +616,29 @@ __global__ __launch_bounds__(AG_RPX_BLOCK) void read_px(const ReadParams p)
             const int r = r0 + vr;
             if (r >= p.nrows) continue;                     // wave-uniform
             uint32_t o[PXT * NCH];
+            // this row's samples, picked by SELECTS on vr: where the loop is unrolled (everywhere but one instantiation) they fold away;
+            // where it stays rolled -- 8-bit 4:2:0 + alpha with unaligned rows, "loop not unrolled" -- indexing cur.y[vr] would put the
+            // whole group into scratch memory (60 bytes per lane in round 2's resources.tsv)
+            uint32_t yrow[NDY], arow[NDY], g1row[NDY], g2row[NDY];
+#pragma unroll
+            for (int d = 0; d < NDY; ++d) {
+                yrow[d] = vr == 0 ? cur.y[0][d] : cur.y[VR - 1][d];
+                arow[d] = ALPHA ? (vr == 0 ? cur.a[0][d] : cur.a[ALPHA ? VR - 1 : 0][d]) : 0u;
+                g1row[d] = CS == kCsRgb ? (vr == 0 ? cur.g1[0][d] : cur.g1[CS == kCsRgb ? VR - 1 : 0][d]) : 0u;
+                g2row[d] = CS == kCsRgb ? (vr == 0 ? cur.g2[0][d] : cur.g2[CS == kCsRgb ? VR - 1 : 0][d]) : 0u;
+            }
             if (active) {
 #pragma unroll
                 for (int i = 0; i < PXT; ++i) {
-                    const uint32_t yv = sample_of<SRC16>(cur.y[vr], i);
-                    const uint32_t av = ALPHA ? sample_of<SRC16>(cur.a[ALPHA ? vr : 0], i) : (uint32_t)p.maxc;
+                    const uint32_t yv = sample_of<SRC16>(yrow, i);
+                    const uint32_t av = ALPHA ? sample_of<SRC16>(arow, i) : (uint32_t)p.maxc;
                     if constexpr (CS == kCsYcc && XS + YS > 0)
                         decode_pixel<CS, DEPTH, ALPHA, TRANSFER, LUT>(p, t, yv, 0, 0, av, &o[i * NCH], ct[i >> XS]);
                     else if constexpr (CS == kCsYcc)
                         decode_pixel<CS, DEPTH, ALPHA, TRANSFER, LUT>(p, t, yv, 0, 0, av, &o[i * NCH],
                                                                       chroma_terms<DEPTH, LUT>(p, t, sample_of<SRC16>(cur.c1, i), sample_of<SRC16>(cur.c2, i)));
                     else if constexpr (CS == kCsRgb)
-                        decode_pixel<CS, DEPTH, ALPHA, TRANSFER, LUT>(p, t, yv, sample_of<SRC16>(cur.g1[vr], i), sample_of<SRC16>(cur.g2[vr], i), av, &o[i * NCH]);
+                        decode_pixel<CS, DEPTH, ALPHA, TRANSFER, LUT>(p, t, yv, sample_of<SRC16>(g1row, i), sample_of<SRC16>(g2row, i), av, &o[i * NCH]);
                     else
                         decode_pixel<CS, DEPTH, ALPHA, TRANSFER, LUT>(p, t, yv, 0, 0, av, &o[i * NCH]);
                 }
