@@ -15,7 +15,7 @@ traffic = {e["config"]: e for e in json.load(open(tpath))} if os.path.exists(tpa
 
 
 def table(pred):
-    out = ["| Config | kernel variant | B/px | ms | GB/s | of 8 TB/s | HBM traffic ÷ algorithmic (PMC) |", "|---|---|---|---|---|---|---|"]
+    out = ["| Config | kernel variant | B/px | ms | Gpx/s | GB/s | of 8 TB/s | HBM traffic ÷ algorithmic (PMC) |", "|---|---|---|---|---|---|---|---|"]
     for r in rows:
         if not pred(r):
             continue
@@ -24,8 +24,8 @@ def table(pred):
         short = m.group(1) + " " + re.sub(r"(depth|planes|out|dst16|transfer|aligned|pxl|nt|prefetch|xcdmap|cs|alpha)=", lambda x: x.group(1)[0] + "", m.group(2)) if m else k
         t = traffic.get(r["config"], {}).get("traffic_over_algorithmic")
         tag = ("" if "icc=" not in k else " icc=" + k.split("icc=")[1].rstrip(">").split()[0]) + (" tables=none" if "tables=none" in k else "")
-        out.append("| %s | `%s` | %g | %.4f | %.0f | %.2f | %s |" % (r["config"], k.split("<")[0] + tag,
-                                                                    r["bytes_per_px"], r["ms_mean"], r["GB_s"], r["frac_of_8TBs"], ("%.4f" % t) if t else "—"))
+        out.append("| %s | `%s` | %g | %.4f | %.0f | %.0f | %.2f | %s |" % (r["config"], k.split("<")[0] + tag,
+                                                                         r["bytes_per_px"], r["ms_mean"], r["Mpx_s"] / 1e3, r["GB_s"], r["frac_of_8TBs"], ("%.4f" % t) if t else "—"))
     return "\n".join(out)
 
 
