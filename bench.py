@@ -83,6 +83,9 @@ def measure_traffic_live(args, kernel_name):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not exe:
         return None
+    # already running under a profiler (the round's profile passes wrap this script in rocprofv3): no profiler inside a profiler
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER_")) for k in os.environ):
+        return {"note": "running under a profiler already: live PMC passes skipped"}
     base = kernel_name.split("<")[0].split()[0]
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--traffic-child", "--width", str(args.width), "--height", str(args.height),
              "--bits", str(args.bits), "--chroma", args.chroma, "--transfer", args.transfer, "--scaling", args.scaling]
@@ -95,7 +98,7 @@ def measure_traffic_live(args, kernel_name):
         d = tempfile.mkdtemp(prefix="avifgpu_pmc_", dir="/tmp")
         try:
             r = subprocess.run([exe, "--pmc", counter, "--kernel-include-regex", base, "-d", d, "-o", "t", "--output-format", "csv", "--", *child],
-                               cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+                               cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
             vals = []
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                 for row in csv.DictReader(open(f, newline="")):

@@ -6,7 +6,7 @@ set -x
 mkdir -p gpurun_out/prof_r03
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-P="python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-c5 --no-pcie --no-rotate"
+P="python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-c5 --no-pcie --no-rotate --no-live-traffic"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_r03/kt -o kt --output-format csv -- bash -c "cd $R && $P > gpurun_out/prof_r03/bench_under_kernel_trace.json" > $R/gpurun_out/prof_r03/kt.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "write_rgb32" -d $R/gpurun_out/prof_r03/fetch -o f --output-format csv -- bash -c "cd $R && $P" > $R/gpurun_out/prof_r03/fetch.log 2>&1
