@@ -180,7 +180,7 @@ void CreateHeifImageInto(FormatRecordPtr formatRecord, AlphaState alphaState, co
     // ICC row transform (replaces converter.ConvertRow, WriteHeifImage.cpp:1012,1031-1034) for the HDR case
     avifgpu_icc_transform icc;
     const avifgpu_icc_transform* iccp = nullptr;
-    std::unique_ptr<avifgpu_icc_sampled32> iccs;                // 32-bit document with sampled curves (768 KiB: on the heap)
+    std::unique_ptr<avifgpu_icc_sampled32> iccs;                // 32-bit document with sampled curves (792 KiB: on the heap)
     if (saveOptions.convertToRec2020) {
         if (formatRecord->depth != 32 || mono || !formatRecord->iCCprofileData || formatRecord->iCCprofileSize <= 0)
             throw OSErrException(AVIFGPU_formatBadParameters);

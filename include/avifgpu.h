@@ -348,7 +348,7 @@ int32_t avifgpu_write_rows_icc(const avifgpu_write_desc* desc, const avifgpu_icc
  * it (65536 floats per channel, the library's arithmetic restated on the host: csrc/icc_profile.cpp), the kernel computes the same
  * index and looks the float up (or interpolates the profile's own table in LDS: the same value); matrix and, for the sRGB target, the inverse curve follow as in avifgpu_icc_transform.
  * All three channels must be sampled (a profile that mixes sampled and parametric channels, and every LUT-based / A2B profile,
- * still returns AVIFGPU_formatCannotRead: the caller keeps lcms2).  768 KiB: allocate it once per save. */
+ * still returns AVIFGPU_formatCannotRead: the caller keeps lcms2).  792 KiB: allocate it once per save. */
 enum { AVIFGPU_ICC_SAMPLED_MAX = 4096 };
 typedef struct avifgpu_icc_sampled32 {
     avifgpu_icc_transform base;  /* matrix, out_curve, out_params as above; trc_type[] = 0 */
