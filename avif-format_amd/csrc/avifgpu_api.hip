@@ -132,7 +132,10 @@ int check_write(const avifgpu_write_desc* d, int row0, int nrows, WriteGeom& g)
     if (d->alpha_state < AVIFGPU_ALPHA_NONE || d->alpha_state > AVIFGPU_ALPHA_PREMULTIPLIED) return fail(AVIFGPU_formatBadParameters, "bad alpha_state");
     g.dst16 = d->bit_depth > 8;
     g.xs = g.ys = 0;
-    if (d->pq_evaluation < AVIFGPU_PQ_AUTO || d->pq_evaluation > AVIFGPU_PQ_CLOSE) return fail(AVIFGPU_formatBadParameters, "bad pq_evaluation %d", d->pq_evaluation);
+    // pq_evaluation took the place of a reserved field in ABI 3: it means something for PQ saves of 32-bit documents only and is
+    // ignored (not range-checked) everywhere else, so a caller that never initialised the old field keeps working for those.
+    if (d->depth == 32 && d->transfer == AVIFGPU_TRANSFER_PQ && (d->pq_evaluation < AVIFGPU_PQ_AUTO || d->pq_evaluation > AVIFGPU_PQ_CLOSE))
+        return fail(AVIFGPU_formatBadParameters, "bad pq_evaluation %d", d->pq_evaluation);
     if (d->depth == 32) {
         if (d->transfer < AVIFGPU_TRANSFER_PQ || d->transfer > AVIFGPU_TRANSFER_CLIP) return fail(AVIFGPU_writErr, "Unsupported color transfer function.");
         if (!g.color && d->transfer != AVIFGPU_TRANSFER_PQ && d->transfer != AVIFGPU_TRANSFER_CLIP)
@@ -472,7 +475,7 @@ int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const Wr
     p.pq_mult = (float)d->peak_nits / 10000.0f;          // ColorTransfer.cpp:86
     p.pq_log2_mult_m1 = (float)((2610.0 / 16384.0) * std::log2((double)p.pq_mult));
     p.log2_maxf = (float)std::log2((double)p.maxv);
-    p.pq_close = d->pq_evaluation == AVIFGPU_PQ_CLOSE || (d->pq_evaluation == AVIFGPU_PQ_AUTO && p.maxv > 1023);
+    p.pq_close = d->pq_evaluation != AVIFGPU_PQ_COMPACT;   // AUTO = CLOSE at every depth since round 4 (the table form costs the kernels nothing measurable)
     p.half = d->chroma_zero_point == AVIFGPU_CHROMA_ZERO_DECODER ? p.maxf * 0.5f : (float)(1 << (d->bit_depth - 1));
     if (d->output == AVIFGPU_OUT_YCBCR) {
         if (d->matrix_coefficients == AVIFGPU_MATRIX_RGB_GBR) {       // lossless, WriteMetadata.cpp:143-146

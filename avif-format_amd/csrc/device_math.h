@@ -68,21 +68,25 @@ AG_DEV float near_ieee_div(float n, float d)
 // native v_log_f32 / v_exp_f32 pair.  Cost: 5 quarter-rate transcendentals (measured 3.45x a v_fma_f32 each on
 // gfx950, tools/alubench.hip) + 12 full-rate ops per sample; the two constant multiplies (mult, maxValue) are
 // folded into the exponents as log2 addends.
-//   log2_mult_m1 = m1 * log2(mult),  log2_max = log2(maxValue).  Returns pq * maxValue (unclamped).
-AG_DEV float fast_linear_to_pq_scaled(float value, float log2_mult_m1, float log2_max)
+//   log2_mult_m1 = m1 * log2(mult).
+// Round 4: the functions return pq CLAMPED to [0, 1] and the caller multiplies by maxValue, like the reference (round 3 folded
+// log2(maxValue) into the last exponent: one rounding more where it hurts, 0.258 % -> 0.234 % mismatching codes at 12 bit).  The clamp
+// is the output modifier of the last v_exp_f32 (v_exp_f32_e64 ... clamp: no instruction of its own; the kernels run with DX10_CLAMP,
+// so a NaN -- a negative or NaN sample after v_log_f32 -- becomes 0, the code the reference stores for a negative sample), which
+// makes the v_med3_f32 in front of the truncation unnecessary: pq * maxValue lies in [0, maxValue].
+AG_DEV float nat_exp2_sat(float x) { return __builtin_amdgcn_fmed3f(nat_exp2(x), 0.0f, 1.0f); }   // folds into v_exp_f32 ... clamp
+AG_DEV float fast_linear_to_pq01(float value, float log2_mult_m1)
 {
     const float l = nat_log2(max0(value));
     const float x = nat_exp2(__builtin_fmaf(kPqM1, l, log2_mult_m1));
     const float n = kPqC1 + kPqC2 * x;                   // -ffp-contract=off: v_mul_f32 + v_add_f32, as the reference
     const float d = 1.0f + kPqC3 * x;
-    return nat_exp2(__builtin_fmaf(kPqM2, nat_log2(near_ieee_div(n, d)), log2_max));
+    return nat_exp2_sat(kPqM2 * nat_log2(near_ieee_div(n, d)));
 }
-// The same function on TWO samples: the twelve full-rate operations of a sample, minus the clamp and the truncation, become six
-// packed ones (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 do two IEEE single operations per lane per issue slot on gfx950: 2.98 vs
-// 2.74 cycles per wave instruction, tools/alubench.hip), element for element the operations above -- so the results are
-// the same bits.  The transcendentals stay one per sample.  AG_PQ_MAX0=0 also drops the max(value, 0): v_log_f32 of a negative
-// number is NaN, NaN flows through every later operation, and the caller's v_med3_f32(NaN, 0, max) returns 0 -- the code the
-// reference stores for a negative sample (the same route +NaN input has always taken).
+// The same function on TWO samples: the full-rate operations become packed ones (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 do two
+// IEEE single operations per lane per instruction), element for element the operations above -- so the results are the same bits.
+// The transcendentals stay one per sample.  AG_PQ_MAX0=0 also drops the max(value, 0): v_log_f32 of a negative number is NaN, NaN
+// flows through every later operation, and the clamp of the last v_exp_f32 returns 0.
 #ifndef AG_PQ_PACKED
 #define AG_PQ_PACKED 1
 #endif
@@ -90,7 +94,7 @@ AG_DEV float fast_linear_to_pq_scaled(float value, float log2_mult_m1, float log
 #define AG_PQ_MAX0 0
 #endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-AG_DEV f32x2 fast_linear_to_pq_scaled2(f32x2 value, float log2_mult_m1, float log2_max)
+AG_DEV f32x2 fast_linear_to_pq01_2(f32x2 value, float log2_mult_m1)
 {
 #if AG_PQ_MAX0
     const f32x2 l = { nat_log2(max0(value.x)), nat_log2(max0(value.y)) };
@@ -104,63 +108,117 @@ AG_DEV f32x2 fast_linear_to_pq_scaled2(f32x2 value, float log2_mult_m1, float lo
     const f32x2 r = { nat_rcp(d.x), nat_rcp(d.y) };
     const f32x2 q0 = n * r;
     const f32x2 q = __builtin_elementwise_fma(__builtin_elementwise_fma(-q0, d, n), r, q0);   // near_ieee_div, two at a time
-    const f32x2 lq = { nat_log2(q.x), nat_log2(q.y) };
-    const f32x2 e2 = __builtin_elementwise_fma((f32x2)kPqM2, lq, (f32x2)log2_max);
-    return f32x2{ nat_exp2(e2.x), nat_exp2(e2.y) };
+    const f32x2 e2 = kPqM2 * f32x2{ nat_log2(q.x), nat_log2(q.y) };
+    return f32x2{ nat_exp2_sat(e2.x), nat_exp2_sat(e2.y) };
 }
 AG_DEV float fast_linear_to_pq(float value, float mult)
 {
-    return fast_linear_to_pq_scaled(value, kPqM1 * nat_log2(mult), 0.0f);
+    return fast_linear_to_pq01(value, kPqM1 * nat_log2(mult));
 }
 
-// ---- the same curve, closer to the reference's bits (round 3; tools/pq_variants.hip, profiles/r03/pq_variants.txt) -----------
+// ---- the same curve, closer to the reference's bits (tools/pq_variants.hip; profiles/r03/pq_variants.txt, profiles/r04/pq_variants.txt) ----
 // Where the codes of the form above differ from the reference's it is almost never the last factor: v_log_f32 is accurate to an
-// ulp of its RESULT on the whole range of q (measured: <= 1.0 ulp for every float in [0.83, 1.012)).  It is x.  The reference
+// ulp of its RESULT on the whole range of q (measured: <= 1.0 ulp for every float in [0.83, 1.012)), and with a correctly rounded
+// x the codes of the 900 k-sample sweep differ in 0.004 % of the samples at 12 bit (column x7 of the tool).  It is x.  The reference
 // rounds q = N(x) / D(x) to float, so an x that is a few 1e-7 away from the reference's powf moves q across a rounding boundary in
 // ~10 % of the samples, and every such flip is 4.7e-6 relative on q^m2 -- 0.8 % of a code at 12 bit.  x = 2^(m1 log2 t) loses its
 // accuracy in the exponent: |m1 log2 t| reaches 4, where a float resolves 2.4e-7, and folding log2(mult) in adds a second rounding.
-// Here
-//     t = value * mult = m 2^e  (v_frexp_*),   A = m1 e = n + f  (n = floor A),   x = 2^n * 2^(m1 log2 m + f)
-// m1 e is EXACT in float (m1 = 2610 / 2^14 has 12 significant bits, |e| < 2^8), so are n and f; the one rounded number the exponent
-// sees is below 1.2 in magnitude, v_log_f32 gets an argument in [0.5, 1), and 2^n is a v_ldexp_f32.  The scale by maxValue is a
-// multiply at the end, like the reference's, instead of an addend of the last exponent (log2 4095 = 12: half an ulp of [8, 16) is
-// 4.8e-7).  Mismatching codes on the 900 k-sample sweep at 12 bit, 80 nits: 0.258 % (compact form) -> 0.234 % (multiply at the
-// end) -> 0.109 % (exact m1 e) -> 0.068 % (this).  +8 issue slots per sample, about half of them packed for two.  Same specials as
-// above: negative -> NaN in v_log_f32 -> code 0; 0 -> x = 0; +inf -> NaN -> code 0; NaN -> code 0.
-#ifndef AG_PQ_HI_SPLIT
-#define AG_PQ_HI_SPLIT 1         /* 0: 2^(m1 log2 m + A) in one v_exp_f32 (no floor / ldexp): the 0.109 % form, for A/B */
-#endif
-AG_DEV float fast_linear_to_pq_scaled_hi(float value, float mult, float maxf)
+//     t = value * mult = m 2^E  (m in [0.5, 1)),   m1 E = N + F  (N integer, |F| <= 1/2),   x = 2^N * 2^(m1 log2 m + F)
+// m1 E is EXACT in float (m1 = 2610 / 2^14 has 12 significant bits, |E| < 2^8), so are N and F; the one rounded number the exponent
+// sees is below 0.66 in magnitude and v_log_f32 gets an argument in [0.5, 1).  Round 3 formed E, m, N and F with v_frexp_*, v_floor,
+// v_cvt and v_ldexp: +8 issue slots per sample, which the 10-bit RGB kernels could not pay (0.777 -> 0.70 of 8 TB/s).  Round 4:
+//   * F and P = 2^N come from two 512-entry float tables in LDS indexed by the SIGN + EXPONENT FIELD of t (v_lshrrev + v_and +
+//     two ds_read_b32; two tables rather than one of pairs so that the F's and P's of two samples can sit in adjacent registers,
+//     the operand form of the packed instructions); the entries of zero / denormal t, of negative t (sign bit set) and of inf / NaN
+//     have P = 2^-100 -- q = c1, code 0, what the reference stores for a negative sample and what this library stores for NaN
+//      -- so no clamp, no special case and no NaN ever reaches the quotient;
+//   * m is the mantissa field under the exponent of 0.5 (one v_and_or_b32);
+//   * x = 2^(m1 log2 m + F) * P is an exact scaling (P is a power of two, the product is a normal number);
+//   * N = rint(m1 E) instead of floor: the exponent that the FMA rounds is half as large.
+// +3 plain and +1 packed issue slots per sample over the compact form, and CLOSER: codes that differ from the reference's on the
+// 900 k-sample sweep, 12 bit / 80 nits: 0.234 % (compact) -> 0.068 % (round 3) -> 0.041 %; at 10 bit 0.063 % -> 0.016 % -> 0.012 %.
+constexpr int kPqTabEntries = 512;
+// The table's contents are exact integer arithmetic on the exponent field (m1 E = 2610 E / 2^14), evaluated at COMPILE time into a
+// 4 KiB constant of the code object; a workgroup copies it into its LDS with two 16-byte loads and stores per thread (computing it
+// in the prologue cost ~80 VALU instructions per workgroup -- 13 % of the RGB f32 kernel, whose waves convert one span each).
+// (the pad keeps the P table at an offset that ds_read2st64_b32 cannot express: merged into one two-dword read, F and P of a sample
+// land in adjacent registers and the packed instructions need moves)
+constexpr int kPqTabPad = 4;
+struct PqExpTable { float f[kPqTabEntries]; float pad[kPqTabPad]; float p[kPqTabEntries]; float pad2[kPqTabPad]; };
+constexpr float pq_pow2(int n) { float v = 1.0f; for (int i = 0; i < (n < 0 ? -n : n); ++i) v = n < 0 ? v * 0.5f : v * 2.0f; return v; }
+constexpr PqExpTable make_pq_exp_table()
 {
-    const float t = value * mult;
-    const float A = kPqM1 * (float)__builtin_amdgcn_frexp_expf(t);                     // exact
-    const float nA = AG_PQ_HI_SPLIT ? __builtin_floorf(A) : 0.0f;
-    const float e1 = __builtin_fmaf(kPqM1, nat_log2(__builtin_amdgcn_frexp_mantf(t)), A - nA);
-    const float x = __builtin_amdgcn_ldexpf(nat_exp2(e1), (int)nA);
+    PqExpTable t{};
+    for (int i = 0; i < kPqTabEntries; ++i) {
+        const int eb = i & 255;
+        float F = 0.0f;
+        int N = -100;                                                     // 0, denormal, negative, inf, NaN: x = 2^-100 * [0.63, 1.42)
+        if (i < 256 && eb != 0 && eb != 255) {
+            const long long num = 2610LL * (eb - 126);                    // m1 E * 2^14; eb - 126 = the frexp exponent of a normal number
+            long long n = (num + 8192) >> 14;                             // floor(m1 E + 1/2)
+            if (((num + 8192) & 16383) == 0 && (n & 1)) n -= 1;           // ties to even, like rintf (never happens: 2610 E is not an odd multiple of 2^13)
+            F = (float)(num - n * 16384) / 16384.0f;                      // exact: |num - n 2^14| <= 2^13
+            N = (int)n;                                                   // |N| <= 21
+        }
+        t.f[i] = F;
+        t.p[i] = pq_pow2(N);
+    }
+    return t;
+}
+__device__ __attribute__((aligned(16))) const PqExpTable kPqExpTableConst = make_pq_exp_table();
+// The table of the calling kernel's workgroup (a function-local __shared__ array is one LDS allocation per kernel that reaches it).
+AG_DEV float* pq_exp_table()
+{
+    __shared__ __attribute__((aligned(16))) float tab[2 * (kPqTabEntries + kPqTabPad)];
+    return tab;
+}
+// Copied by the workgroup's own threads; the caller synchronises.
+AG_DEV void pq_exp_table_fill(int tid, int nthreads)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4* dst = reinterpret_cast<f4*>(pq_exp_table());
+    const f4* src = reinterpret_cast<const f4*>(&kPqExpTableConst);
+    for (int i = tid; i < (kPqTabEntries + kPqTabPad) / 2; i += nthreads) dst[i] = src[i];
+}
+// x = t^m1
+AG_DEV uint32_t pq_tab_offset(float t) { return (__float_as_uint(t) >> 21) & 0x7fcu; }               // byte offset of t's entry in either table
+AG_DEV float pq_tab_f(const float* tab, uint32_t off) { return *reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(tab) + off); }
+AG_DEV float pq_tab_p(const float* tab, uint32_t off) { return *reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(tab + kPqTabEntries + kPqTabPad) + off); }
+AG_DEV float pq_mantissa(float t) { return __uint_as_float((__float_as_uint(t) & 0x007fffffu) | 0x3f000000u); }
+AG_DEV float pq_x_close(float t, const float* tab)
+{
+    const uint32_t off = pq_tab_offset(t);
+    return nat_exp2(__builtin_fmaf(kPqM1, nat_log2(pq_mantissa(t)), pq_tab_f(tab, off))) * pq_tab_p(tab, off);
+}
+AG_DEV f32x2 pq_x_close2(f32x2 t, const float* tab)
+{
+    const uint32_t o0 = pq_tab_offset(t.x), o1 = pq_tab_offset(t.y);
+    const f32x2 F = { pq_tab_f(tab, o0), pq_tab_f(tab, o1) };
+    const f32x2 P = { pq_tab_p(tab, o0), pq_tab_p(tab, o1) };
+    const f32x2 l = { nat_log2(pq_mantissa(t.x)), nat_log2(pq_mantissa(t.y)) };
+    const f32x2 e1 = __builtin_elementwise_fma((f32x2)kPqM1, l, F);
+    return f32x2{ nat_exp2(e1.x), nat_exp2(e1.y) } * P;
+}
+AG_DEV float fast_linear_to_pq01_hi(float value, float mult)
+{
+    const float x = pq_x_close(value * mult, pq_exp_table());
     const float n = kPqC1 + kPqC2 * x;
     const float d = 1.0f + kPqC3 * x;
-    return nat_exp2(kPqM2 * nat_log2(near_ieee_div(n, d))) * maxf;
+    return nat_exp2_sat(kPqM2 * nat_log2(near_ieee_div(n, d)));
 }
-AG_DEV f32x2 fast_linear_to_pq_scaled2_hi(f32x2 value, float mult, float maxf)
+AG_DEV f32x2 fast_linear_to_pq01_2_hi(f32x2 value, float mult)
 {
-    const f32x2 t = value * mult;
-    const f32x2 A = kPqM1 * f32x2{ (float)__builtin_amdgcn_frexp_expf(t.x), (float)__builtin_amdgcn_frexp_expf(t.y) };
-    const f32x2 nA = AG_PQ_HI_SPLIT ? f32x2{ __builtin_floorf(A.x), __builtin_floorf(A.y) } : f32x2{ 0.0f, 0.0f };
-    const f32x2 l = { nat_log2(__builtin_amdgcn_frexp_mantf(t.x)), nat_log2(__builtin_amdgcn_frexp_mantf(t.y)) };
-    const f32x2 e1 = __builtin_elementwise_fma((f32x2)kPqM1, l, A - nA);
-    const f32x2 x = { __builtin_amdgcn_ldexpf(nat_exp2(e1.x), (int)nA.x), __builtin_amdgcn_ldexpf(nat_exp2(e1.y), (int)nA.y) };
+    const f32x2 x = pq_x_close2(value * mult, pq_exp_table());
     const f32x2 n = kPqC1 + kPqC2 * x;
     const f32x2 d = 1.0f + kPqC3 * x;
     const f32x2 r = { nat_rcp(d.x), nat_rcp(d.y) };
     const f32x2 q0 = n * r;
     const f32x2 q = __builtin_elementwise_fma(__builtin_elementwise_fma(-q0, d, n), r, q0);
     const f32x2 e2 = kPqM2 * f32x2{ nat_log2(q.x), nat_log2(q.y) };
-    return f32x2{ nat_exp2(e2.x), nat_exp2(e2.y) } * maxf;
+    return f32x2{ nat_exp2_sat(e2.x), nat_exp2_sat(e2.y) };
 }
 // Build-time override of the per-launch choice (WriteParams::pq_close): 0 = the compact form everywhere, 2 = the close form
-// everywhere, 1 = as the descriptor says.  (AUTO picks the close form for 12-bit output: a code is 4x finer there -- exact-match rate
-// 99.74 % -> 99.93 % on the sweep of tests/test_gpu_t2_truth.py -- and the 12-bit kernels, RGBA above all, have issue slots to spare
-// on most boxes; the 10-bit RGB kernel does not: 0.777 -> 0.70 of 8 TB/s, profiles/r03/pq_hi_library_ab.txt.)
+// everywhere, 1 = as the descriptor says (AUTO = the close form at every depth since round 4).
 #ifndef AG_PQ_HI
 #define AG_PQ_HI 1
 #endif

@@ -44,36 +44,71 @@ template <int ICC> struct IccF32 { static constexpr bool value = (ICC == 2 && AG
 
 // One linear-light sample -> integer code: transfer curve, scale by maxValue, clamp, TRUNCATE
 // (reference WriteHeifImage.cpp:1072-1095).
-// kTransferPqHi: the PQ evaluation that reproduces more of the reference's bits (device_math.h, fast_linear_to_pq_scaled_hi) as a
+// kTransferPqHi: the PQ evaluation that reproduces more of the reference's bits (device_math.h, fast_linear_to_pq01_hi) as a
 // kernel-side transfer id of its own, so that the two forms never share a register allocation.  The launchers pick it once per launch
-// from WriteParams::pq_close (avifgpu_write_desc::pq_evaluation; AUTO: 12-bit output only -- 10-bit saves, the headline configuration,
-// keep the compact form).  AG_PQ_HI = 0 / 2 forces one form at build time for A/B.
+// from WriteParams::pq_close (avifgpu_write_desc::pq_evaluation; AUTO = the close form since round 4).  AG_PQ_HI = 0 / 2 forces one
+// form at build time for A/B.
+// The PQ functions return pq in [0, 1] (clamped inside their last v_exp_f32, NaN -> 0), so pq * maxValue needs no clamp; the other
+// curves keep the v_med3_f32 (which returns 0 for the quiet NaN a v_mul_f32 / v_log_f32 makes of any NaN input).
 constexpr int kTransferPqHi = 4;
 static inline bool pq_hi_launch(const WriteParams& p) { return AG_PQ_HI == 2 || (AG_PQ_HI == 1 && p.pq_close); }
+template <int TRANSFER> constexpr bool is_pq() { return TRANSFER == AVIFGPU_TRANSFER_PQ || TRANSFER == kTransferPqHi; }
+
+// scaled, clamped, not yet truncated: in [0, maxValue]
 template <int TRANSFER>
-AG_DEV uint32_t oetf_code(const WriteParams& p, float f)
+AG_DEV float oetf_scaled(const WriteParams& p, float f)
 {
-    float scaled;
-    if constexpr (TRANSFER == kTransferPqHi) scaled = fast_linear_to_pq_scaled_hi(f, p.pq_mult, p.maxf);
-    else if constexpr (TRANSFER == AVIFGPU_TRANSFER_PQ) scaled = fast_linear_to_pq_scaled(f, p.pq_log2_mult_m1, p.log2_maxf);
-    else if constexpr (TRANSFER == AVIFGPU_TRANSFER_SMPTE428) scaled = fast_linear_to_smpte428(f) * p.maxf;
-    else if constexpr (TRANSFER == AVIFGPU_TRANSFER_HLG) scaled = fast_linear_to_hlg(f) * p.maxf;
-    else scaled = f * p.maxf;                                                   // Clip: exact
-    return (uint32_t)__builtin_amdgcn_fmed3f(scaled, 0.0f, p.maxf);
+    if constexpr (TRANSFER == kTransferPqHi) return fast_linear_to_pq01_hi(f, p.pq_mult) * p.maxf;
+    else if constexpr (TRANSFER == AVIFGPU_TRANSFER_PQ) return fast_linear_to_pq01(f, p.pq_log2_mult_m1) * p.maxf;
+    else if constexpr (TRANSFER == AVIFGPU_TRANSFER_SMPTE428) return __builtin_amdgcn_fmed3f(fast_linear_to_smpte428(f) * p.maxf, 0.0f, p.maxf);
+    else if constexpr (TRANSFER == AVIFGPU_TRANSFER_HLG) return __builtin_amdgcn_fmed3f(fast_linear_to_hlg(f) * p.maxf, 0.0f, p.maxf);
+    else return __builtin_amdgcn_fmed3f(f * p.maxf, 0.0f, p.maxf);               // Clip: exact
 }
+template <int TRANSFER>
+AG_DEV f32x2 oetf_scaled2(const WriteParams& p, float f0, float f1)
+{
+    if constexpr (is_pq<TRANSFER>() && AG_PQ_PACKED) {
+        const f32x2 u = TRANSFER == kTransferPqHi ? fast_linear_to_pq01_2_hi(f32x2{ f0, f1 }, p.pq_mult)
+                                                  : fast_linear_to_pq01_2(f32x2{ f0, f1 }, p.pq_log2_mult_m1);
+        return u * p.maxf;
+    } else {
+        return f32x2{ oetf_scaled<TRANSFER>(p, f0), oetf_scaled<TRANSFER>(p, f1) };
+    }
+}
+template <int TRANSFER>
+AG_DEV uint32_t oetf_code(const WriteParams& p, float f) { return (uint32_t)oetf_scaled<TRANSFER>(p, f); }
 
 // two samples at once: the PQ curve in packed arithmetic (device_math.h), every other curve sample by sample
 template <int TRANSFER>
 AG_DEV void oetf_code2(const WriteParams& p, float f0, float f1, uint32_t& c0, uint32_t& c1)
 {
-    if constexpr ((TRANSFER == AVIFGPU_TRANSFER_PQ || TRANSFER == kTransferPqHi) && AG_PQ_PACKED) {
-        const f32x2 s = TRANSFER == kTransferPqHi ? fast_linear_to_pq_scaled2_hi(f32x2{ f0, f1 }, p.pq_mult, p.maxf)
-                                                  : fast_linear_to_pq_scaled2(f32x2{ f0, f1 }, p.pq_log2_mult_m1, p.log2_maxf);
-        c0 = (uint32_t)__builtin_amdgcn_fmed3f(s.x, 0.0f, p.maxf);
-        c1 = (uint32_t)__builtin_amdgcn_fmed3f(s.y, 0.0f, p.maxf);
-    } else {
-        c0 = oetf_code<TRANSFER>(p, f0);
-        c1 = oetf_code<TRANSFER>(p, f1);
+    const f32x2 s = oetf_scaled2<TRANSFER>(p, f0, f1);
+    c0 = (uint32_t)s.x;
+    c1 = (uint32_t)s.y;
+}
+
+// The same codes as integer-valued FLOATS (truncated): what stage B consumes.  The streaming kernels hand these across their LDS
+// strip instead of packed u16 codes: v_trunc_f32 replaces v_cvt_u32_f32 + half a v_lshl_or + the v_cvt_f32_u32 (sdwa) on the other side.
+template <int TRANSFER>
+AG_DEV f32x2 oetf_level2(const WriteParams& p, float f0, float f1)
+{
+    const f32x2 s = oetf_scaled2<TRANSFER>(p, f0, f1);
+    return f32x2{ __builtin_truncf(s.x), __builtin_truncf(s.y) };
+}
+template <int TRANSFER>
+AG_DEV f32x4_t oetf_level4(const WriteParams& p, f32x4_t v)
+{
+    const f32x2 a = oetf_level2<TRANSFER>(p, v.x, v.y), b = oetf_level2<TRANSFER>(p, v.z, v.w);
+    return f32x4_t{ a.x, a.y, b.x, b.y };
+}
+
+// Every kernel that can be instantiated with kTransferPqHi starts with this: the workgroup fills its exponent table (device_math.h).
+template <int TRANSFER>
+AG_DEV void pq_prologue()
+{
+    if constexpr (TRANSFER == kTransferPqHi) {
+        pq_exp_table_fill((int)threadIdx.x, (int)blockDim.x);
+        __syncthreads();
     }
 }
 
@@ -715,6 +750,7 @@ constexpr int kWpxWaves = AG_WPX_BLOCK / 64;
 template <int DEPTH, int PLANES, int OUT, bool DST16, int XS, int YS, int TRANSFER, bool ALIGNED, int ICC = 0>
 __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
 {
+    pq_prologue<TRANSFER>();
     constexpr int PXT = WriteShape<DST16, PLANES, XS, ICC>::PXT;
     constexpr int VR = 1 << YS;
     constexpr int BPP = PLANES * DEPTH / 8;
@@ -1215,6 +1251,102 @@ typedef float    f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
+// ---- buffer addressing for the streaming kernels (round 4) ------------------------------------------------------------------
+// A wave's span is described by a buffer resource in SGPRs -- base = the span's first byte (wave-uniform), num_records = the span's
+// valid bytes -- and every lane addresses it with ONE 32-bit offset that does not change from span to span (lane * 16); the K loads
+// of a span differ in an immediate / scalar offset.  That takes the per-load 64-bit address arithmetic (v_mad_u64_u32,
+// v_lshl_add_u64, the v_min_i32 of the branch-free row mask: ~30 of 650 VALU instructions per span in the RGB f32 kernel) off the
+// vector ALU, which is what these kernels are short of.  A lane beyond the row reads zeros (the hardware's range check) and stores
+// nothing.  `nt` = non-temporal, as before.
+typedef int i32x4 __attribute__((__vector_size__(16)));
+typedef int i32x2 __attribute__((__vector_size__(8)));
+AG_DEV __amdgpu_buffer_rsrc_t span_rsrc(const void* base, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);   // raw buffer, 32-bit data format
+}
+template <bool NT> AG_DEV f32x4 span_load16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, NT ? 2 : 0);
+    return __builtin_bit_cast(f32x4, v);
+}
+template <bool NT> AG_DEV void span_store16(__amdgpu_buffer_rsrc_t r, uint32_t voff, u32x4 v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), r, (int)voff, 0, NT ? 2 : 0);
+}
+template <bool NT> AG_DEV void span_store8(__amdgpu_buffer_rsrc_t r, uint32_t voff, u32x2 v)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, v), r, (int)voff, 0, NT ? 2 : 0);
+}
+template <bool NT> AG_DEV void span_store4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32((int)v, r, (int)voff, 0, NT ? 2 : 0);
+}
+// the wave's index inside its workgroup, as a scalar (threadIdx.x >> 6 is uniform, but the compiler cannot know)
+AG_DEV int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+// Workgroup size of the RGB f32 streaming kernels (round 4): four waves share one copy of the PQ exponent table, and with the
+// half-span strips below a workgroup needs 16 KiB of LDS -- 8 waves per SIMD again (profiles/r04/occupancy_ab.txt).
+#ifndef AG_F32_STREAM_BLOCK
+#define AG_F32_STREAM_BLOCK 256
+#endif
+constexpr int kF32Waves = AG_F32_STREAM_BLOCK / 64;
+
+// Transfer-major -> lane-major transpose of a wave's span of 64 K float4 (lane l loaded float4 number 64 k + l; it wants numbers
+// K l ... K l + K - 1: its PXL pixels) through a wave-private strip of HALF a span (32 K float4 = 3 KiB for K = 6): the first K / 2
+// loads of every lane are the float4 that lanes 0..31 want, the last K / 2 are those of lanes 32..63, so the strip is written twice
+// and read by one half of the wave each time (ds_read under an exec mask: no instruction more on the vector ALU, and the second
+// half's loads may still be in flight while the first half crosses).  Round 4's first cut kept the whole span in the strip: 12 KiB
+// per 128 threads + the PQ table capped the RGB kernels at 4.5 waves per SIMD and cost them 3-4 %.
+#ifndef AG_HALF_STRIP
+#define AG_HALF_STRIP 1
+#endif
+
+// index of channel ch of a lane's pixel i in the array span_transpose fills
+constexpr int strip_at(int i, int ch) { return 3 * i + ch; }
+template <int K> struct SpanStrip { static constexpr bool kHalves = AG_HALF_STRIP && K % 2 == 0; static constexpr int kDwords = (kHalves ? 32 : 64) * K * 4; };   // (K = 3, the 4-pixel variant for small tiles: whole span)
+template <int K>
+AG_DEV void span_transpose(f32x4* my, int lane, const f32x4 (&in)[K], float (&out)[4 * K])
+{
+    if constexpr (SpanStrip<K>::kHalves) {
+        // everything that produces in[] first: the optimiser otherwise sinks the second half's curves below the first half's reads, and
+        // the first half's 24 floats sit in registers while 12 curves run (77 VGPRs instead of ~50).  Empty asm: no instruction.
+        f32x4 pin[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { pin[k] = in[k]; asm volatile("" : "+v"(pin[k])); }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int k = 0; k < K / 2; ++k) my[64 * k + lane] = pin[h * (K / 2) + k];
+            __builtin_amdgcn_wave_barrier();
+            if (h == 0 || lane >= 32) {                               // first pass: every lane reads (the upper half's registers are defined, and overwritten next)
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const f32x4 t = my[K * (lane & 31) + j];
+                    out[4 * j] = t.x; out[4 * j + 1] = t.y; out[4 * j + 2] = t.z; out[4 * j + 3] = t.w;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) my[64 * k + lane] = in[k];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const f32x4 t = my[K * lane + j];
+            out[4 * j] = t.x; out[4 * j + 1] = t.y; out[4 * j + 2] = t.z; out[4 * j + 3] = t.w;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Luma of stage B without the upper clip: with Kr + Kg + Kb = 1 (every matrix fill_write_params derives; the identity matrix copies G)
+// and levels <= maxValue, r Kr + g Kg + b Kb <= maxValue (1 + 3e-7), so (long)(y + 0.5f) never exceeds maxValue; v_cvt_u32_f32 clips at 0.
+AG_DEV uint32_t luma_code_nc(const WriteParams& p, float r, float g, float b)
+{
+    return (uint32_t)((r * p.my[0] + g * p.my[1] + b * p.my[2]) + 0.5f);
+}
+
 template <bool NT> AG_DEV f32x4 stream_load(const f32x4* p)
 {
     if constexpr (NT) return __builtin_nontemporal_load(p); else return *p;
@@ -1224,104 +1356,122 @@ template <bool NT, typename V> AG_DEV void stream_store(V* p, V v)
     if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
 }
 
+// Round 4: the curve's results cross the strip as integer-valued FLOATS (oetf_level2), not as packed u16 codes -- stage B wants
+// floats, and the conversion pair on either side of the strip cost more than the curve's full-rate half (profiles/r04/hot_f32_strip_ab.txt).
+// AG_HOT_F32_STRIP = 0 keeps round 3's packed hand-over for A/B.
+#ifndef AG_HOT_F32_STRIP
+#define AG_HOT_F32_STRIP 1
+#endif
 template <int TRANSFER, int PXL, bool NT>
-__global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_ycbcr444_hot(const WriteParams p)
+__global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_ycbcr444_hot(const WriteParams p)
 {
-    constexpr int WPB = kStreamWaves;
+    constexpr int WPB = kF32Waves;
     constexpr int K = 3 * PXL / 4;               // float4 per lane per span
     constexpr int SPAN_PX = 64 * PXL;
-    constexpr int SPAN_DW = SPAN_PX * 3 / 2;     // packed u16 codes
-    constexpr int LDW = 3 * PXL / 2;             // packed dwords per lane after the transpose
+    constexpr int SPAN_DW = AG_HOT_F32_STRIP ? SpanStrip<K>::kDwords : SPAN_PX * 3 / 2;     // floats (half a span) | packed u16 codes
+    constexpr int LDW = 3 * PXL / 2;             // packed dwords per lane after the transpose (packed hand-over)
     __shared__ __attribute__((aligned(16))) uint32_t strip[WPB][SPAN_DW];
+    pq_prologue<TRANSFER>();
 
-    const int wave = threadIdx.x >> 6;
+    const int wave = wave_in_block();
     const int lane = threadIdx.x & 63;
     uint32_t* my = strip[wave];
 
-    // span indices fit 32 bits (host checks): 32-bit udiv instead of a 64-bit software divide per trip
+    // span indices fit 32 bits (host checks): 32-bit udiv instead of a 64-bit software divide per trip; everything about a span but
+    // the lane's own offset is wave-uniform and lives in SGPRs
     const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;      // host guarantees width % 4 == 0 and alignment
     const uint32_t total = spans_per_row * (uint32_t)p.nrows;
     const uint32_t step = gridDim.x * WPB;
+    const uint32_t voff = (uint32_t)lane * 16u;
 
     for (uint32_t sidx = blockIdx.x * WPB + wave; sidx < total; sidx += step) {
         const uint32_t r = sidx / spans_per_row;
         const uint32_t sx = sidx - r * spans_per_row;
         const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);             // < SPAN_PX only for the last span of a row
-        const int span_f4 = span_px * 3 / 4;
-        const f32x4* sp = reinterpret_cast<const f32x4*>(p.src + (long long)r * p.src_row_bytes) + (long long)sx * (64 * K);
-        // Branch-free masking: a lane whose float4 lies beyond the row re-reads the row's last float4 (a valid address); whatever it
-        // computes lands in strip positions that only lanes beyond the row read back, and those store nothing.
+        const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)r * p.src_row_bytes + (long long)sx * (SPAN_PX * 12), (uint32_t)span_px * 12u);
         f32x4 cur[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) cur[k] = stream_load<NT>(sp + min(64 * k + lane, span_f4 - 1));
+        for (int k = 0; k < K; ++k) cur[k] = span_load16<NT>(rs, voff, 1024u * k);   // a float4 beyond the row: zeros, and nothing is stored for it
 
+        float R[PXL], G[PXL], B[PXL];
+        if constexpr (AG_HOT_F32_STRIP) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            uint32_t c0, c1, c2, c3;
-            oetf_code2<TRANSFER>(p, cur[k].x, cur[k].y, c0, c1);
-            oetf_code2<TRANSFER>(p, cur[k].z, cur[k].w, c2, c3);
-            u32x2 pk = { c0 | (c1 << 16), c2 | (c3 << 16) };
-            reinterpret_cast<u32x2*>(my)[64 * k + lane] = pk;
-        }
-        __builtin_amdgcn_wave_barrier();
-        uint32_t dw[LDW];
-        if constexpr (PXL == 4) {
+            for (int k = 0; k < K; ++k) cur[k] = oetf_level4<TRANSFER>(p, cur[k]);
+            float c[3 * PXL];
+            span_transpose<K>(reinterpret_cast<f32x4*>(my), lane, cur, c);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const u32x2 v = reinterpret_cast<const u32x2*>(my)[3 * lane + j];
-                dw[2 * j] = v.x; dw[2 * j + 1] = v.y;
-            }
+            for (int i = 0; i < PXL; ++i) { R[i] = c[strip_at(i, 0)]; G[i] = c[strip_at(i, 1)]; B[i] = c[strip_at(i, 2)]; }
         } else {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const u32x4 v = reinterpret_cast<const u32x4*>(my)[3 * lane + j];
-                dw[4 * j] = v.x; dw[4 * j + 1] = v.y; dw[4 * j + 2] = v.z; dw[4 * j + 3] = v.w;
+            for (int k = 0; k < K; ++k) {
+                uint32_t c0, c1, c2, c3;
+                oetf_code2<TRANSFER>(p, cur[k].x, cur[k].y, c0, c1);
+                oetf_code2<TRANSFER>(p, cur[k].z, cur[k].w, c2, c3);
+                u32x2 pk = { c0 | (c1 << 16), c2 | (c3 << 16) };
+                reinterpret_cast<u32x2*>(my)[64 * k + lane] = pk;
             }
+            __builtin_amdgcn_wave_barrier();
+            uint32_t dw[LDW];
+            if constexpr (PXL == 4) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const u32x2 v = reinterpret_cast<const u32x2*>(my)[3 * lane + j];
+                    dw[2 * j] = v.x; dw[2 * j + 1] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const u32x4 v = reinterpret_cast<const u32x4*>(my)[3 * lane + j];
+                    dw[4 * j] = v.x; dw[4 * j + 1] = v.y; dw[4 * j + 2] = v.z; dw[4 * j + 3] = v.w;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            auto code = [&](int i, int c) -> uint32_t {
+                const int e = 3 * i + c;
+                return (e & 1) ? (dw[e >> 1] >> 16) : (dw[e >> 1] & 0xffffu);
+            };
+#pragma unroll
+            for (int i = 0; i < PXL; ++i) { R[i] = (float)code(i, 0); G[i] = (float)code(i, 1); B[i] = (float)code(i, 2); }
         }
-        __builtin_amdgcn_wave_barrier();
 
         uint32_t yv[PXL], cbv[PXL], crv[PXL];
-        auto code = [&](int i, int c) -> uint32_t {
-            const int e = 3 * i + c;
-            return (e & 1) ? (dw[e >> 1] >> 16) : (dw[e >> 1] & 0xffffu);
-        };
 #pragma unroll
         for (int i = 0; i < PXL; ++i) {
-            const uint32_t q0 = code(i, 0), q1 = code(i, 1), q2 = code(i, 2);
-            yv[i] = luma_code(p, q0, q1, q2);
-            const float R = (float)q0, G = (float)q1, B = (float)q2;
-            cbv[i] = clip_round(R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2] + p.half, p.maxv);
-            crv[i] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
+            yv[i] = luma_code_nc(p, R[i], G[i], B[i]);
+            cbv[i] = clip_round(R[i] * p.mcb[0] + G[i] * p.mcb[1] + B[i] * p.mcb[2] + p.half, p.maxv);
+            crv[i] = clip_round(R[i] * p.mcr[0] + G[i] * p.mcr[1] + B[i] * p.mcr[2] + p.half, p.maxv);
         }
-        const long long xoff = ((long long)sx * SPAN_PX + (long long)PXL * lane) * 2;
-        uint8_t* d0 = p.dst[0] + (long long)r * p.dst_stride[0] + xoff;
-        uint8_t* d1 = p.dst[1] + (long long)r * p.dst_stride[1] + xoff;
-        uint8_t* d2 = p.dst[2] + (long long)r * p.dst_stride[2] + xoff;
+        const long long xoff = (long long)sx * (SPAN_PX * 2);
+        const uint32_t plane_bytes = (uint32_t)span_px * 2u;
+        const __amdgpu_buffer_rsrc_t r0 = span_rsrc(p.dst[0] + (long long)r * p.dst_stride[0] + xoff, plane_bytes);
+        const __amdgpu_buffer_rsrc_t r1 = span_rsrc(p.dst[1] + (long long)r * p.dst_stride[1] + xoff, plane_bytes);
+        const __amdgpu_buffer_rsrc_t r2 = span_rsrc(p.dst[2] + (long long)r * p.dst_stride[2] + xoff, plane_bytes);
         const int nv = span_px - PXL * lane;                                       // pixels of this lane inside the row: >= PXL, 4 or <= 0
         if constexpr (PXL == 4) {
             if (nv >= 4) {
+                const uint32_t vo = (uint32_t)lane * 8u;
                 u32x2 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16) };
                 u32x2 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16) };
                 u32x2 c = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16) };
-                stream_store<NT>(reinterpret_cast<u32x2*>(d0), a);
-                stream_store<NT>(reinterpret_cast<u32x2*>(d1), b);
-                stream_store<NT>(reinterpret_cast<u32x2*>(d2), c);
+                span_store8<NT>(r0, vo, a);
+                span_store8<NT>(r1, vo, b);
+                span_store8<NT>(r2, vo, c);
             }
         } else {
             if (nv >= 8) {
                 u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
                 u32x4 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16), cbv[4] | (cbv[5] << 16), cbv[6] | (cbv[7] << 16) };
                 u32x4 c = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16), crv[4] | (crv[5] << 16), crv[6] | (crv[7] << 16) };
-                stream_store<NT>(reinterpret_cast<u32x4*>(d0), a);
-                stream_store<NT>(reinterpret_cast<u32x4*>(d1), b);
-                stream_store<NT>(reinterpret_cast<u32x4*>(d2), c);
+                span_store16<NT>(r0, voff, a);
+                span_store16<NT>(r1, voff, b);
+                span_store16<NT>(r2, voff, c);
             } else if (nv >= 4) {
                 u32x2 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16) };
                 u32x2 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16) };
                 u32x2 c = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16) };
-                stream_store<NT>(reinterpret_cast<u32x2*>(d0), a);
-                stream_store<NT>(reinterpret_cast<u32x2*>(d1), b);
-                stream_store<NT>(reinterpret_cast<u32x2*>(d2), c);
+                span_store8<NT>(r0, voff, a);
+                span_store8<NT>(r1, voff, b);
+                span_store8<NT>(r2, voff, c);
             }
         }
     }
@@ -1337,13 +1487,14 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_ycbcr444_hot(cons
 // ICCV = 4: the sRGB destination of the SDR (Clip) save of a 32-bit document -- the inverse sRGB curve after the matrix, in single
 // precision (icc_inv4_f: exact-match rate 0.99992 against lcms2 instead of 0.99999 with FP64 curves, profiles/r02/icc_f32_ab.txt).
 template <int TRANSFER, int ICCV>
-__global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444_hot(const WriteParams p)
+__global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444_hot(const WriteParams p)
 {
-    constexpr int PXL = 8, K = 6, SPAN_PX = 512, SPAN_DW = SPAN_PX * 3;
-    __shared__ __attribute__((aligned(16))) uint32_t strip[kStreamWaves][SPAN_DW];
+    pq_prologue<TRANSFER>();
+    constexpr int PXL = 8, K = 6, SPAN_PX = 512, SPAN_DW = SpanStrip<K>::kDwords;
+    __shared__ __attribute__((aligned(16))) uint32_t strip[kF32Waves][SPAN_DW];
     __shared__ __attribute__((aligned(16))) f32x4_t pow_t[(ICCV == 4 && !AG_ICC_FASTPOW) ? kIccPowBins : 1];
     if constexpr (ICCV == 4) {
-        static_assert(AG_STREAM_BLOCK >= kIccPowBins, "one table entry per thread");
+        static_assert(AG_F32_STREAM_BLOCK >= kIccPowBins, "one table entry per thread");
         icc_pow_table_fill_f(pow_t, p.icc_pow_tab, threadIdx.x);
         __syncthreads();
     }
@@ -1355,7 +1506,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444_hot
                 m6 = p.icc_m_f[6], m7 = p.icc_m_f[7], m8 = p.icc_m_f[8];
     const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;      // width % 4 == 0 (host)
     const uint32_t total = spans_per_row * (uint32_t)p.nrows;
-    for (uint32_t sidx = blockIdx.x * kStreamWaves + wave; sidx < total; sidx += gridDim.x * kStreamWaves) {
+    for (uint32_t sidx = blockIdx.x * kF32Waves + wave; sidx < total; sidx += gridDim.x * kF32Waves) {
         const uint32_t r = sidx / spans_per_row;
         const uint32_t sx = sidx - r * spans_per_row;
         const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);
@@ -1369,24 +1520,15 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444_hot
 #pragma unroll
             for (int k = 0; k < K; ++k) icc_trc_simple4(q, cur[k]);
         }
-#pragma unroll
-        for (int k = 0; k < K; ++k) my[64 * k + lane] = cur[k];
-        __builtin_amdgcn_wave_barrier();
         float c[PXL * 3];
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const f32x4 v = my[K * lane + j];
-            c[4 * j] = v.x; c[4 * j + 1] = v.y; c[4 * j + 2] = v.z; c[4 * j + 3] = v.w;
-        }
-        __builtin_amdgcn_wave_barrier();
+        span_transpose<K>(my, lane, cur, c);
         uint32_t yv[PXL], cbv[PXL], crv[PXL];
 #pragma unroll
         for (int i = 0; i < PXL; i += 2) {                                         // two pixels = three sample pairs for the packed curve
-            float t[6];
-            uint32_t q[6];
+            float t[6], q[6];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const float R0 = c[3 * (i + h)], G0 = c[3 * (i + h) + 1], B0 = c[3 * (i + h) + 2];
+                const float R0 = c[strip_at(i + h, 0)], G0 = c[strip_at(i + h, 1)], B0 = c[strip_at(i + h, 2)];
                 t[3 * h] = __builtin_fmaf(B0, m2, __builtin_fmaf(G0, m1, R0 * m0));
                 t[3 * h + 1] = __builtin_fmaf(B0, m5, __builtin_fmaf(G0, m4, R0 * m3));
                 t[3 * h + 2] = __builtin_fmaf(B0, m8, __builtin_fmaf(G0, m7, R0 * m6));
@@ -1395,12 +1537,15 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444_hot
                     for (int e = 0; e < 3; ++e) t[3 * h + e] = icc_inv4_f(powT, p.icc_out_f, t[3 * h + e]);
                 }
             }
-            oetf_codes<TRANSFER>(p, t, q);
+#pragma unroll
+            for (int e = 0; e < 6; e += 2) {                                       // levels: the codes as integer-valued floats (oetf_level2)
+                const f32x2 l = oetf_level2<TRANSFER>(p, t[e], t[e + 1]);
+                q[e] = l.x; q[e + 1] = l.y;
+            }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const uint32_t q0 = q[3 * h], q1 = q[3 * h + 1], q2 = q[3 * h + 2];
-                yv[i + h] = luma_code(p, q0, q1, q2);
-                const float R = (float)q0, G = (float)q1, B = (float)q2;
+                const float R = q[3 * h], G = q[3 * h + 1], B = q[3 * h + 2];
+                yv[i + h] = luma_code_f(p, R, G, B);
                 cbv[i + h] = clip_round(R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2] + p.half, p.maxv);
                 crv[i + h] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
             }
@@ -1430,27 +1575,29 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444_hot
 
 // ---- the same streaming structure for 4:2:2 / 4:2:0 (the AVIF default) -----------------------------------------------------
 // A wave owns a span of 512 pixels on 1 (4:2:2) or 2 (4:2:0) consecutive rows.  Per row: coalesced non-temporal float4 loads,
-// curve on the samples as loaded, packed codes through the wave-private LDS strip (reused for the second row), read back
-// pixel-major: lane l then holds pixels [8l, 8l+8) of both rows = the footprint of 4 chroma samples, so the box filter
-// (same operand order as write_px / the oracle) needs no cross-lane traffic.  Stores: 16 B/lane per luma row, 8 B/lane per chroma
-// plane, contiguous across the wave, non-temporal.
-// ICC1: the linear-profile matrix in front, as in write_rgb32_icc1_ycbcr444_hot -- the floats cross the strip, the codes are packed
-// into the same dw[][] layout the rest of the kernel reads.
-template <int TRANSFER, int XS, int YS, int ICCV = 0>       // ICCV: 0 none, 1 linear-profile matrix, 4 matrix + inverse sRGB curve
-__global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot(const WriteParams p)
+// curve on the samples as loaded, the levels (integer-valued floats) through the wave-private LDS strip (reused for the second
+// row), read back pixel-major: lane l then holds pixels [8l, 8l+8) of the row = the footprint of 4 chroma samples, so the box
+// filter needs no cross-lane traffic.  Stores: 16 B/lane per luma row, 8 B/lane per chroma plane, contiguous across the wave,
+// non-temporal.
+// ICC1: the linear-profile matrix in front, as in write_rgb32_icc1_ycbcr444_hot -- the document's floats cross the strip, matrix and
+// curve run pixel-major, and the levels are where the rest of the kernel wants them.
+template <int TRANSFER, int XS, int YS, int ICCV = 0, bool NEAREST = false>       // ICCV: 0 none, 1 linear-profile matrix, 4 matrix + inverse sRGB curve; NEAREST: p.nearest as a constant (libheif 1.14's chroma rule, the shim's default)
+__global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot(const WriteParams p)
 {
+    pq_prologue<TRANSFER>();
     static_assert(XS == 1, "4:2:2 or 4:2:0");
-    constexpr int PXL = 8, K = 6, SPAN_PX = 512, SPAN_DW = SPAN_PX * 3 / 2, LDW = 12, VR = 1 << YS;
+    constexpr int PXL = 8, K = 6, SPAN_PX = 512, SPAN_DW = SpanStrip<K>::kDwords, VR = 1 << YS;
     constexpr bool ICC1 = ICCV != 0;
-    __shared__ __attribute__((aligned(16))) uint32_t strip[kStreamWaves][ICC1 ? 2 * SPAN_DW : SPAN_DW];
+    __shared__ __attribute__((aligned(16))) uint32_t strip[kF32Waves][SPAN_DW];
     __shared__ __attribute__((aligned(16))) f32x4_t pow_t[(ICCV == 4 && !AG_ICC_FASTPOW) ? kIccPowBins : 1];
     if constexpr (ICCV == 4) {
         icc_pow_table_fill_f(pow_t, p.icc_pow_tab, threadIdx.x);
         __syncthreads();
     }
     const IccPowTableF powT = { pow_t };
-    const int wave = threadIdx.x >> 6;
+    const int wave = wave_in_block();
     const int lane = threadIdx.x & 63;
+    const uint32_t voff = (uint32_t)lane * 16u;
     uint32_t* my = strip[wave];
     // ICCV = 4 reads 18 more wave-uniform floats per pixel than the scalar file holds next to the rest of WriteParams (182
     // v_writelane / v_readlane spills in the first build): parked in VGPRs once, like IccRegsF.  (The 24 inlined pows of a row
@@ -1467,46 +1614,44 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot(con
     const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;    // host guarantees width % 4 == 0 and alignment
     const uint32_t groups = ((uint32_t)p.nrows + VR - 1) >> YS;
     const uint32_t total = spans_per_row * groups;
-    for (uint32_t sidx = blockIdx.x * kStreamWaves + wave; sidx < total; sidx += gridDim.x * kStreamWaves) {
+    for (uint32_t sidx = blockIdx.x * kF32Waves + wave; sidx < total; sidx += gridDim.x * kF32Waves) {
         const uint32_t gy = sidx / spans_per_row;
         const uint32_t sx = sidx - gy * spans_per_row;
-        uint32_t dw[VR][LDW];
         f32x4 v[VR][K];
         const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);             // < SPAN_PX only for the last span of a row
-        const int span_f4 = span_px * 3 / 4;
 #pragma unroll
         for (int vr = 0; vr < VR; ++vr) {                              // both rows' loads in flight before any math
             const int r = min((int)(gy * VR) + vr, p.rows_to_end - 1);  // bottom edge: replicate the last IMAGE row
-            const f32x4* sp = reinterpret_cast<const f32x4*>(p.src + (long long)r * p.src_row_bytes) + (long long)sx * (64 * K);
+            const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)r * p.src_row_bytes + (long long)sx * (SPAN_PX * 12), (uint32_t)span_px * 12u);
 #pragma unroll
-            for (int k = 0; k < K; ++k) v[vr][k] = stream_load<true>(sp + min(64 * k + lane, span_f4 - 1));   // branch-free mask, as in the 4:4:4 kernel
+            for (int k = 0; k < K; ++k) v[vr][k] = span_load16<true>(rs, voff, 1024u * k);   // beyond the row: zeros (see the 4:4:4 kernel)
         }
+        const int nv = span_px - PXL * lane;                           // pixels of this lane inside the row: >= 8, 4 or <= 0 (width % 4 == 0)
+        // Round 4: the levels (integer-valued floats, oetf_level2) cross the strip, a row at a time; a row's luma leaves at once and
+        // what the chroma samples need of it -- the left pixel of each pair, or the pair's sum (integers below 2^14: exact in any
+        // order, so (a + b + c + d) * 0.25f of the oracle is ((a + b) + (c + d)) * 0.25f) -- stays in 12 registers.
+        float acc[4][3];
 #pragma unroll
         for (int vr = 0; vr < VR; ++vr) {
+            float c[PXL * 3];
             if constexpr (ICC1) {
                 if constexpr (ICCV == 2) {                                         // the document's curve: per sample, the same for R, G, B
                     const IccSimple q = icc_simple_load(p);
 #pragma unroll
                     for (int k = 0; k < K; ++k) icc_trc_simple4(q, v[vr][k]);
                 }
+            } else {
 #pragma unroll
-                for (int k = 0; k < K; ++k) reinterpret_cast<f32x4*>(my)[64 * k + lane] = v[vr][k];
-                __builtin_amdgcn_wave_barrier();
-                float c[PXL * 3];
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const f32x4 t = reinterpret_cast<const f32x4*>(my)[K * lane + j];
-                    c[4 * j] = t.x; c[4 * j + 1] = t.y; c[4 * j + 2] = t.z; c[4 * j + 3] = t.w;
-                }
-                __builtin_amdgcn_wave_barrier();
-                uint32_t q[PXL * 3];
+                for (int k = 0; k < K; ++k) v[vr][k] = oetf_level4<TRANSFER>(p, v[vr][k]);
+            }
+            span_transpose<K>(reinterpret_cast<f32x4*>(my), lane, v[vr], c);
+            if constexpr (ICC1) {
 #pragma unroll
                 for (int i = 0; i < PXL; i += 2) {                                 // two pixels = three sample pairs for the packed curve
                     float t[6];
-                    uint32_t qq[6];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const float R0 = c[3 * (i + h)], G0 = c[3 * (i + h) + 1], B0 = c[3 * (i + h) + 2];
+                        const float R0 = c[strip_at(i + h, 0)], G0 = c[strip_at(i + h, 1)], B0 = c[strip_at(i + h, 2)];
                         t[3 * h] = __builtin_fmaf(B0, icm[2], __builtin_fmaf(G0, icm[1], R0 * icm[0]));
                         t[3 * h + 1] = __builtin_fmaf(B0, icm[5], __builtin_fmaf(G0, icm[4], R0 * icm[3]));
                         t[3 * h + 2] = __builtin_fmaf(B0, icm[8], __builtin_fmaf(G0, icm[7], R0 * icm[6]));
@@ -1516,86 +1661,69 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot(con
                             __builtin_amdgcn_sched_barrier(0);                      // one pixel's three pows at a time (interleaving all 24 of a row: 224 VGPRs)
                         }
                     }
-                    oetf_codes<TRANSFER>(p, t, qq);
 #pragma unroll
-                    for (int e = 0; e < 6; ++e) q[3 * i + e] = qq[e];
+                    for (int e = 0; e < 6; e += 2) {
+                        const f32x2 l = oetf_level2<TRANSFER>(p, t[e], t[e + 1]);
+                        c[strip_at(i + e / 3, e % 3)] = l.x; c[strip_at(i + (e + 1) / 3, (e + 1) % 3)] = l.y;
+                    }
                 }
-#pragma unroll
-                for (int e = 0; e < LDW; ++e) dw[vr][e] = q[2 * e] | (q[2 * e + 1] << 16);
-                continue;
             }
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                uint32_t c0, c1, c2, c3;
-                oetf_code2<TRANSFER>(p, v[vr][k].x, v[vr][k].y, c0, c1);
-                oetf_code2<TRANSFER>(p, v[vr][k].z, v[vr][k].w, c2, c3);
-                u32x2 pk = { c0 | (c1 << 16), c2 | (c3 << 16) };
-                reinterpret_cast<u32x2*>(my)[64 * k + lane] = pk;
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const u32x4 t = reinterpret_cast<const u32x4*>(my)[3 * lane + j];
-                dw[vr][4 * j] = t.x; dw[vr][4 * j + 1] = t.y; dw[vr][4 * j + 2] = t.z; dw[vr][4 * j + 3] = t.w;
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        auto code = [&](int vr, int i, int c) -> uint32_t {
-            const int e = 3 * i + c;
-            return (e & 1) ? (dw[vr][e >> 1] >> 16) : (dw[vr][e >> 1] & 0xffffu);
-        };
-        const long long xoff = ((long long)sx * SPAN_PX + (long long)PXL * lane) * 2;
-        const int nv = span_px - PXL * lane;                           // pixels of this lane inside the row: >= 8, 4 or <= 0 (width % 4 == 0)
-#pragma unroll
-        for (int vr = 0; vr < VR; ++vr) {
             const int r = (int)(gy * VR) + vr;
-            if (r >= p.nrows) continue;                                // odd last row of the tile: replicated for chroma only
-            uint32_t yv[PXL];
+            if (r < p.nrows) {                                         // (odd last row of the tile: replicated for chroma only)
+                uint32_t yv[PXL];
 #pragma unroll
-            for (int i = 0; i < PXL; ++i) yv[i] = luma_code(p, code(vr, i, 0), code(vr, i, 1), code(vr, i, 2));   // (GBR needs 4:4:4)
-            uint8_t* dy = p.dst[0] + (long long)r * p.dst_stride[0] + xoff;
-            if (nv >= 8) {
-                u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
-                stream_store<true>(reinterpret_cast<u32x4*>(dy), a);
-            } else if (nv >= 4) {
-                u32x2 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16) };
-                stream_store<true>(reinterpret_cast<u32x2*>(dy), a);
+                for (int i = 0; i < PXL; ++i) yv[i] = luma_code_nc(p, c[strip_at(i, 0)], c[strip_at(i, 1)], c[strip_at(i, 2)]);   // (GBR needs 4:4:4)
+                const __amdgpu_buffer_rsrc_t ry = span_rsrc(p.dst[0] + (long long)r * p.dst_stride[0] + (long long)sx * (SPAN_PX * 2), (uint32_t)span_px * 2u);
+                if (nv >= 8) {
+                    u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
+                    span_store16<true>(ry, voff, a);
+                } else if (nv >= 4) {
+                    u32x2 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16) };
+                    span_store8<true>(ry, voff, a);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float left = c[strip_at(2 * j, ch)];
+                    if constexpr (NEAREST) {
+                        if (vr == 0) acc[j][ch] = left;
+                    } else {
+                        const float pair = left + c[strip_at(2 * j + 1, ch)];
+                        if (vr == 0) acc[j][ch] = YS ? pair : pair + pair;
+                        else acc[j][ch] += pair;
+                    }
+                }
             }
         }
         uint32_t cbv[4], crv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int i0 = 2 * j;
-            constexpr int v1 = YS ? 1 : 0;
-            float R = (float)code(0, i0, 0), G = (float)code(0, i0, 1), B = (float)code(0, i0, 2);
-            if (!p.nearest) {
-                R = (R + (float)code(0, i0 + 1, 0) + (float)code(v1, i0, 0) + (float)code(v1, i0 + 1, 0)) * 0.25f;
-                G = (G + (float)code(0, i0 + 1, 1) + (float)code(v1, i0, 1) + (float)code(v1, i0 + 1, 1)) * 0.25f;
-                B = (B + (float)code(0, i0 + 1, 2) + (float)code(v1, i0, 2) + (float)code(v1, i0 + 1, 2)) * 0.25f;
-            }
+            const float R = NEAREST ? acc[j][0] : acc[j][0] * 0.25f, G = NEAREST ? acc[j][1] : acc[j][1] * 0.25f, B = NEAREST ? acc[j][2] : acc[j][2] * 0.25f;
             cbv[j] = clip_round(R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2] + p.half, p.maxv);
             crv[j] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
         }
-        const long long coff = ((long long)sx * (SPAN_PX / 2) + 4LL * lane) * 2;
-        uint8_t* dcb = p.dst[1] + (long long)gy * p.dst_stride[1] + coff;
-        uint8_t* dcr = p.dst[2] + (long long)gy * p.dst_stride[2] + coff;
+        const uint32_t cbytes = (uint32_t)((span_px + 1) / 2) * 2u, cvoff = (uint32_t)lane * 8u;
+        const __amdgpu_buffer_rsrc_t rcb = span_rsrc(p.dst[1] + (long long)gy * p.dst_stride[1] + (long long)sx * SPAN_PX, cbytes);
+        const __amdgpu_buffer_rsrc_t rcr = span_rsrc(p.dst[2] + (long long)gy * p.dst_stride[2] + (long long)sx * SPAN_PX, cbytes);
         if (nv >= 8) {
             u32x2 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16) };
             u32x2 c = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16) };
-            stream_store<true>(reinterpret_cast<u32x2*>(dcb), b);
-            stream_store<true>(reinterpret_cast<u32x2*>(dcr), c);
+            span_store8<true>(rcb, cvoff, b);
+            span_store8<true>(rcr, cvoff, c);
         } else if (nv >= 4) {                                          // 4 pixels = 2 chroma samples
-            stream_store<true>(reinterpret_cast<uint32_t*>(dcb), cbv[0] | (cbv[1] << 16));
-            stream_store<true>(reinterpret_cast<uint32_t*>(dcr), crv[0] | (crv[1] << 16));
+            span_store4<true>(rcb, cvoff, cbv[0] | (cbv[1] << 16));
+            span_store4<true>(rcr, cvoff, crv[0] | (crv[1] << 16));
         }
     }
 }
 
 // ---- RGBA f32 -> Y, Cb, Cr, A planes (4:4:4, BASELINE config C5): the streaming structure with one float4 = one pixel ----
 // A wave owns 256 consecutive pixels of a row.  Lane l loads pixels 64k + l (k = 0..3): four fully coalesced 1-KiB
-// non-temporal wave-loads.  Alpha clamp / premultiply / curve per pixel as loaded; the four u16 codes of a pixel go to the
-// wave-private strip as one 8-byte write, then lane l reads back pixels [4l, 4l+4) (two ds_read_b128 at a padded 12-dword lane
-// stride: conflict-free for the 16-lane service groups) and writes 8 contiguous bytes per plane, non-temporal.
+// non-temporal wave-loads.  Alpha clamp / premultiply / curve per pixel as loaded; the four levels of a pixel (integer-valued
+// floats, oetf_level2; round 3 packed u16 codes) go to the wave-private strip as one 16-byte write, then lane l reads back pixels
+// [4l, 4l+4) (span_transpose: half a span at a time, 2 KiB of LDS per wave) and writes 8 contiguous bytes per plane, non-temporal.
 #ifndef AG_RGBA_HOT_PXL
 #define AG_RGBA_HOT_PXL 4
 #endif
@@ -1607,12 +1735,13 @@ constexpr int kRgbaWaves = AG_RGBA_STREAM_BLOCK / 64;
 template <int TRANSFER, int ICCV = 0>            // ICCV 1: the linear-profile matrix on R, G, B first (ConvertRow runs before the pixel loop and copies alpha); 4: + inverse sRGB curve
 __global__ __launch_bounds__(AG_RGBA_STREAM_BLOCK) void write_rgba32_ycbcra444_hot(const WriteParams p)
 {
+    pq_prologue<TRANSFER>();
     constexpr int PXL = AG_RGBA_HOT_PXL, SPAN_PX = 64 * PXL;
-    constexpr int LSTRIDE = PXL == 4 ? 12 : 20;                        // dwords per lane in the strip (2 * PXL used + 4 pad)
-    __shared__ __attribute__((aligned(16))) uint32_t strip[kRgbaWaves][64 * LSTRIDE];
-    const int wave = threadIdx.x >> 6;
+    __shared__ __attribute__((aligned(16))) uint32_t strip[kRgbaWaves][SpanStrip<PXL>::kDwords];    // half a span of pixels (one float4 each), span_transpose
+    const int wave = wave_in_block();
     const int lane = threadIdx.x & 63;
-    uint32_t* my = strip[wave];
+    f32x4* my = reinterpret_cast<f32x4*>(strip[wave]);
+    const uint32_t voff = (uint32_t)lane * 16u;
 
     const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;    // any width: the last span of a row is masked
     const uint32_t total = spans_per_row * (uint32_t)p.nrows;
@@ -1620,14 +1749,13 @@ __global__ __launch_bounds__(AG_RGBA_STREAM_BLOCK) void write_rgba32_ycbcra444_h
         const uint32_t r = sidx / spans_per_row;
         const uint32_t sx = sidx - r * spans_per_row;
         const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);
-        const f32x4* sp = reinterpret_cast<const f32x4*>(p.src + (long long)r * p.src_row_bytes) + (long long)sx * SPAN_PX;
+        const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)r * p.src_row_bytes + (long long)sx * (SPAN_PX * 16), (uint32_t)span_px * 16u);
         f32x4 v[PXL];
 #pragma unroll
-        for (int k = 0; k < PXL; ++k) v[k] = stream_load<true>(sp + min(64 * k + lane, span_px - 1));       // branch-free mask: see the RGB kernel
+        for (int k = 0; k < PXL; ++k) v[k] = span_load16<true>(rs, voff, 1024u * k);       // a pixel beyond the row: zeros, and nothing is stored for it
 #pragma unroll
         for (int k = 0; k < PXL; k += 2) {                                         // two pixels = three colour-sample pairs for the packed curve
             float t[6], al[2];
-            uint32_t q[6];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 float col[3] = { v[k + h].x, v[k + h].y, v[k + h].z };
@@ -1657,51 +1785,51 @@ __global__ __launch_bounds__(AG_RGBA_STREAM_BLOCK) void write_rgba32_ycbcra444_h
 #pragma unroll
                 for (int c = 0; c < 3; ++c) t[3 * h + c] = col[c];
             }
-            oetf_codes<TRANSFER>(p, t, q);
+            float q[6];
+#pragma unroll
+            for (int e = 0; e < 6; e += 2) {                                        // levels: the codes as integer-valued floats (oetf_level2)
+                const f32x2 l = oetf_level2<TRANSFER>(p, t[e], t[e + 1]);
+                q[e] = l.x; q[e + 1] = l.y;
+            }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const uint32_t c3 = (uint32_t)__builtin_amdgcn_fmed3f(al[h] * p.maxf, 0.0f, p.maxf);   // :1096
-                const int pidx = 64 * (k + h) + lane;
-                u32x2 pk = { q[3 * h] | (q[3 * h + 1] << 16), q[3 * h + 2] | (c3 << 16) };
-                *reinterpret_cast<u32x2*>(my + (pidx / PXL) * LSTRIDE + (pidx % PXL) * 2) = pk;
+                const float a3 = __builtin_truncf(__builtin_amdgcn_fmed3f(al[h] * p.maxf, 0.0f, p.maxf));   // :1096
+                v[k + h] = f32x4{ q[3 * h], q[3 * h + 1], q[3 * h + 2], a3 };
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        uint32_t dw[2 * PXL];
+        float c[4 * PXL];
+        span_transpose<PXL>(my, lane, v, c);                                       // lane l now holds pixels [PXL l, PXL l + PXL)
+        f32x4 px[PXL];
 #pragma unroll
-        for (int j = 0; j < PXL / 2; ++j) {
-            const u32x4 t = *reinterpret_cast<const u32x4*>(my + lane * LSTRIDE + 4 * j);
-            dw[4 * j] = t.x; dw[4 * j + 1] = t.y; dw[4 * j + 2] = t.z; dw[4 * j + 3] = t.w;
-        }
-        __builtin_amdgcn_wave_barrier();
+        for (int j = 0; j < PXL; ++j) px[j] = f32x4{ c[4 * j], c[4 * j + 1], c[4 * j + 2], c[4 * j + 3] };
         uint32_t yv[PXL], cbv[PXL], crv[PXL], av[PXL];
 #pragma unroll
         for (int i = 0; i < PXL; ++i) {
-            const uint32_t q0 = dw[2 * i] & 0xffffu, q1 = dw[2 * i] >> 16, q2 = dw[2 * i + 1] & 0xffffu;
-            av[i] = dw[2 * i + 1] >> 16;
-            yv[i] = luma_code(p, q0, q1, q2);
-            const float R = (float)q0, G = (float)q1, B = (float)q2;
+            const float R = px[i].x, G = px[i].y, B = px[i].z;
+            av[i] = (uint32_t)px[i].w;
+            yv[i] = luma_code_nc(p, R, G, B);
             cbv[i] = clip_round(R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2] + p.half, p.maxv);
             crv[i] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
         }
-        const long long xoff = ((long long)sx * SPAN_PX + (long long)PXL * lane) * 2;
         const uint32_t* planes_v[4] = { yv, cbv, crv, av };
         const int nv = span_px - PXL * lane;                           // pixels of this lane inside the row
+        const uint32_t svo = (uint32_t)lane * (PXL * 2u);
 #pragma unroll
         for (int pl = 0; pl < 4; ++pl) {
             const uint32_t* q = planes_v[pl];
-            uint8_t* dst = p.dst[pl] + (long long)r * p.dst_stride[pl] + xoff;
+            const __amdgpu_buffer_rsrc_t rd = span_rsrc(p.dst[pl] + (long long)r * p.dst_stride[pl] + (long long)sx * (SPAN_PX * 2), (uint32_t)span_px * 2u);
             if (nv >= PXL) {
                 if constexpr (PXL == 4) {
                     u32x2 o = { q[0] | (q[1] << 16), q[2] | (q[3] << 16) };
-                    stream_store<true>(reinterpret_cast<u32x2*>(dst), o);
+                    span_store8<true>(rd, svo, o);
                 } else {
                     u32x4 o = { q[0] | (q[1] << 16), q[2] | (q[3] << 16), q[4] | (q[5] << 16), q[6] | (q[7] << 16) };
-                    stream_store<true>(reinterpret_cast<u32x4*>(dst), o);
+                    span_store16<true>(rd, svo, o);
                 }
             } else {
+                uint16_t* dst = reinterpret_cast<uint16_t*>(p.dst[pl] + (long long)r * p.dst_stride[pl] + ((long long)sx * SPAN_PX + (long long)PXL * lane) * 2);
 #pragma unroll
-                for (int i = 0; i < PXL; ++i) if (i < nv) reinterpret_cast<uint16_t*>(dst)[i] = (uint16_t)q[i];   // the one ragged lane of a row
+                for (int i = 0; i < PXL; ++i) if (i < nv) dst[i] = (uint16_t)q[i];   // the one ragged lane of a row
             }
         }
     }
@@ -1958,6 +2086,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra444_hot(co
 template <int TRANSFER, int PLANES>
 __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_f32_ref_stream(const WriteParams p)
 {
+    pq_prologue<TRANSFER>();
     constexpr int K = 4;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -2436,16 +2565,15 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
         const long long spans = (long long)((p.width + 511) / 512) * ((p.nrows + (1 << ys) - 1) >> ys);
         if (spans == 0) return hipSuccess;
         if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
-            long long blocks = (spans + kStreamWaves - 1) / kStreamWaves;
-            if (blocks > AG_STREAM_BLOCK_CAP * 4 / kStreamWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kStreamWaves;
+            long long blocks = (spans + kF32Waves - 1) / kF32Waves;
+            if (blocks > AG_STREAM_BLOCK_CAP * 4 / kF32Waves) blocks = AG_STREAM_BLOCK_CAP * 4 / kF32Waves;
             snprintf(label, kLabelBytes, "write_rgb32_ycbcr_sub_hot<transfer=%d,xs=1,ys=%d>%s", p.transfer, ys, icc1 ? " icc=1" : icc4 ? " icc=4" : icc2 ? " icc=2" : "");
-#define AG_SUB2(TR, YS_) do { if (icc1) hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<TR, 1, YS_, 1>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); \
-                              else if (icc2) hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<TR, 1, YS_, 2>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); \
-                              else hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<TR, 1, YS_, 0>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); } while (0)
+#define AG_SUB3(TR, YS_, IC) do { if (p.nearest) hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<TR, 1, YS_, IC, true>), dim3((int)blocks), dim3(AG_F32_STREAM_BLOCK), 0, st, p); \
+                                  else hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<TR, 1, YS_, IC, false>), dim3((int)blocks), dim3(AG_F32_STREAM_BLOCK), 0, st, p); } while (0)
+#define AG_SUB2(TR, YS_) do { if (icc1) AG_SUB3(TR, YS_, 1); else if (icc2) AG_SUB3(TR, YS_, 2); else AG_SUB3(TR, YS_, 0); } while (0)
 #define AG_SUB(TR) do { if (ys) AG_SUB2(TR, 1); else AG_SUB2(TR, 0); } while (0)
             if (icc4) {
-                if (ys) hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<AVIFGPU_TRANSFER_CLIP, 1, 1, 4>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p);
-                else hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<AVIFGPU_TRANSFER_CLIP, 1, 0, 4>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p);
+                if (ys) AG_SUB3(AVIFGPU_TRANSFER_CLIP, 1, 4); else AG_SUB3(AVIFGPU_TRANSFER_CLIP, 0, 4);
                 return hipGetLastError();
             }
             switch (p.transfer) {
@@ -2468,12 +2596,12 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
         const long long spans = (long long)((p.width + 511) / 512) * p.nrows;
         if (spans == 0) return hipSuccess;
         if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
-            long long blocks = (spans + kStreamWaves - 1) / kStreamWaves;
-            if (blocks > AG_STREAM_BLOCK_CAP * 4 / kStreamWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kStreamWaves;
+            long long blocks = (spans + kF32Waves - 1) / kF32Waves;
+            if (blocks > AG_STREAM_BLOCK_CAP * 4 / kF32Waves) blocks = AG_STREAM_BLOCK_CAP * 4 / kF32Waves;
             snprintf(label, kLabelBytes, "write_rgb32_icc1_ycbcr444_hot<transfer=%d> icc=%d", p.transfer, icc4 ? 4 : icc2 ? 2 : 1);
-            if (icc4) { hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<AVIFGPU_TRANSFER_CLIP, 4>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); return hipGetLastError(); }
-#define AG_I444(TR) do { if (icc2) hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<TR, 2>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); \
-                         else hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<TR, 1>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); } while (0)
+            if (icc4) { hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<AVIFGPU_TRANSFER_CLIP, 4>), dim3((int)blocks), dim3(AG_F32_STREAM_BLOCK), 0, st, p); return hipGetLastError(); }
+#define AG_I444(TR) do { if (icc2) hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<TR, 2>), dim3((int)blocks), dim3(AG_F32_STREAM_BLOCK), 0, st, p); \
+                         else hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<TR, 1>), dim3((int)blocks), dim3(AG_F32_STREAM_BLOCK), 0, st, p); } while (0)
             switch (p.transfer) {
             case AVIFGPU_TRANSFER_PQ:       if (pq_hi_launch(p)) AG_I444(kTransferPqHi); else AG_I444(AVIFGPU_TRANSFER_PQ); break;
             case AVIFGPU_TRANSFER_HLG:      AG_I444(AVIFGPU_TRANSFER_HLG); break;
@@ -2494,12 +2622,12 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
             const long long spans = (long long)((p.width + span_px - 1) / span_px) * p.nrows;
             if (spans == 0) return hipSuccess;
             if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
-            constexpr int WPB = kStreamWaves;
+            constexpr int WPB = kF32Waves;
             long long blocks = (spans + WPB - 1) / WPB;
             const long long cap = (variant >> 8) ? (variant >> 8) : 256LL * 512 * 4 / WPB;   // 8192^2: one span per wave measured 5-6 % faster than two
             if (blocks > cap) blocks = cap;
             snprintf(label, kLabelBytes, "write_rgb32_ycbcr444_hot<transfer=%d,pxl=%d,nt=%d>", p.transfer, px8 ? 8 : 4, (int)nt);
-#define AG_HOT3(TR, PX, NT_) hipLaunchKernelGGL((write_rgb32_ycbcr444_hot<TR, PX, NT_>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p)
+#define AG_HOT3(TR, PX, NT_) hipLaunchKernelGGL((write_rgb32_ycbcr444_hot<TR, PX, NT_>), dim3((int)blocks), dim3(AG_F32_STREAM_BLOCK), 0, st, p)
 #define AG_HOT2(TR, PX) do { if (nt) AG_HOT3(TR, PX, true); else AG_HOT3(TR, PX, false); } while (0)
 #define AG_HOT1(TR) do { if (px8) AG_HOT2(TR, 8); else AG_HOT2(TR, 4); } while (0)
             switch (p.transfer) {

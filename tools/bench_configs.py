@@ -159,6 +159,15 @@ if __name__ == "__main__":
     bench_write("C4 8192^2 RGB f32 -> 10-bit PQ 4:2:2", width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_422, matrix_coefficients=9, color_primaries=9)
     bench_write("C4 8192^2 RGB f32 -> 10-bit PQ 4:2:0", width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=9, color_primaries=9)
     bench_write("C4 8192^2 RGB f32 -> 10-bit PQ interleaved RRGGBB (reference hand-off)", width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=0)
+    # the plug-in's default HDR save: 12 bit, 4:2:2 (InitGlobals, AvifFormat.cpp:89,95), PQ at 80 nits; both output modes
+    d12 = dict(width=8192, height=8192, depth=32, bit_depth=12, transfer=0, peak_nits=80, matrix_coefficients=9, color_primaries=9)
+    bench_write("D12 8192^2 RGB f32 -> 12-bit PQ 4:2:2 nearest (the plug-in's default HDR save, fused hand-off)", planes=3, alpha_state=0, output=1, chroma=P.CHROMA_422, chroma_downsampling=P.DOWNSAMPLE_NEAREST, **d12)
+    bench_write("D12 8192^2 RGB f32 -> 12-bit PQ 4:4:4", planes=3, alpha_state=0, output=1, chroma=P.CHROMA_444, **d12)
+    bench_write("D12 8192^2 RGB f32 -> 12-bit PQ 4:2:0", planes=3, alpha_state=0, output=1, chroma=P.CHROMA_420, **d12)
+    bench_write("D12 8192^2 RGB f32 -> 12-bit PQ interleaved RRGGBB (reference hand-off, what integration/ uses by default)", planes=3, alpha_state=0, output=0, **d12)
+    bench_write("D12 8192^2 RGBA f32 -> 12-bit PQ 4:2:2 nearest + alpha (fused hand-off)", planes=4, alpha_state=1, output=1, chroma=P.CHROMA_422, chroma_downsampling=P.DOWNSAMPLE_NEAREST, **d12)
+    bench_write("D12 8192^2 RGBA f32 -> 12-bit PQ interleaved RRGGBBAA (reference hand-off)", planes=4, alpha_state=1, output=0, **d12)
+    bench_write("D12 8192^2 RGB16 -> 12-bit 4:2:2 BT.601 nearest (SDR 16-bit document at the default depth, WriteMetadata.cpp:138-140)", width=8192, height=8192, depth=16, planes=3, bit_depth=12, alpha_state=0, output=1, chroma=P.CHROMA_422, chroma_downsampling=P.DOWNSAMPLE_NEAREST, matrix_coefficients=6, color_primaries=1)
     bench_write("BIG 16384^2 RGB f32 -> 10-bit PQ 4:4:4", width=16384, height=16384, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=9, color_primaries=9)
     bench_write("BIG 16384^2 RGB f32 -> 10-bit PQ 4:2:0", width=16384, height=16384, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=9, color_primaries=9)
     bench_write("BIG 16384^2 RGB16 -> 12-bit 4:4:4 BT.2020", width=16384, height=16384, depth=16, planes=3, bit_depth=12, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=P.MATRIX_BT2020_NCL, color_primaries=9)
@@ -223,6 +232,7 @@ if __name__ == "__main__":
     bench_read("R16 8192^2 12-bit 4:4:4 BT.2020 -> RGB16", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_444, bit_depth=12, depth=16, alpha_state=0, matrix_coefficients=9, color_primaries=9)
     bench_read("R32 8192^2 12-bit 4:2:0 BT.2020 PQ + alpha -> RGBA f32", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_420, bit_depth=12, depth=32, alpha_state=1, matrix_coefficients=9, color_primaries=9, transfer_characteristics=16, pq_peak_nits=80)
     bench_read("R32 8192^2 10-bit 4:4:4 BT.2020 PQ -> RGB f32", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_444, bit_depth=10, depth=32, alpha_state=0, matrix_coefficients=9, color_primaries=9, transfer_characteristics=16, pq_peak_nits=80)
+    bench_read("D12 8192^2 12-bit 4:2:2 BT.2020 PQ -> RGB f32 (what the default HDR save decodes to)", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_422, bit_depth=12, depth=32, alpha_state=0, matrix_coefficients=9, color_primaries=9, transfer_characteristics=16, pq_peak_nits=80)
     bench_read("R32 8192^2 10-bit 4:2:0 BT.2020 HLG+OOTF -> RGB f32", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_420, bit_depth=10, depth=32, alpha_state=0, matrix_coefficients=9, color_primaries=9, transfer_characteristics=18, hlg_apply_ootf=1, hlg_display_gamma=1.2, hlg_peak_nits=1000)
     bench_read("R8 8192^2 8-bit planar RGB (lossless GBR) -> RGB8", width=8192, height=8192, colorspace=1, chroma=P.CHROMA_444, bit_depth=8, depth=8, alpha_state=0, matrix_coefficients=0)
     bench_read("R16 8192^2 12-bit planar RGB + alpha premult -> RGBA16", width=8192, height=8192, colorspace=1, chroma=P.CHROMA_444, bit_depth=12, depth=16, alpha_state=2, matrix_coefficients=0)

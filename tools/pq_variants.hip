@@ -39,9 +39,43 @@ template <int XV> __device__ __forceinline__ float pq_x(float value, float mult,
     const float l = nlog2(m);                                                         // [-1, 0)
     const float A = kM1 * ef;                                                         // EXACT: 12-bit x 5-bit integers
     if (XV == 2) return nexp2(fma_(kM1, l, A));
-    // XV == 3: integer part of the exponent applied by ldexp, so that the FMA rounds a number below 2 in magnitude
-    const float n = __builtin_floorf(A), f = A - n;                                   // both exact
-    return __builtin_amdgcn_ldexpf(nexp2(fma_(kM1, l, f)), (int)n);
+    if (XV == 3) {  // integer part of the exponent applied by ldexp, so that the FMA rounds a number below 2 in magnitude
+        const float n = __builtin_floorf(A), f = A - n;                               // both exact
+        return __builtin_amdgcn_ldexpf(nexp2(fma_(kM1, l, f)), (int)n);
+    }
+    // XV >= 4 (round 4): the exponent's contribution comes from a table indexed by the sign + exponent FIELD of t (what the kernels
+    // keep in LDS: entry = { F, N << 23 }, m1 * E = N + F exactly); the mantissa is cut out with one v_and_or_b32; 2^N is an integer
+    // add on the bits of the v_exp_f32 result.  XV 4: N = floor(A) (the same numbers as XV 3), XV 5: N = rint(A), |F| <= 0.5.
+    // XV 6: like 5 with the polynomial exp2 (how much of what is left is v_exp_f32's), XV 7: x in double (what a perfect x leaves).
+    if (XV == 8) {   // like 5, but the table is indexed by the exponent of VALUE and carries the launch's multiplier: m1 (E + log2 mult) = N + F, F rounded to float
+        const uint32_t vb = __float_as_uint(value);
+        const uint32_t vi = vb >> 23;
+        if (vi == 0 || vi >= 255) return vi == 0 ? 0.0f : __builtin_nanf("");
+        const double A8 = (double)kM1 * ((double)((int)vi - 126) + log2((double)mult));
+        const double N8 = rint(A8);
+        const float F8 = (float)(A8 - N8);
+        const float m8 = __uint_as_float((vb & 0x007fffffu) | 0x3f000000u);
+        const float y8 = nexp2(fma_(kM1, nlog2(m8), F8));
+        return __uint_as_float(__float_as_uint(y8) + ((uint32_t)(int)N8 << 23));
+    }
+    const uint32_t tb = __float_as_uint(t);
+    const uint32_t idx = tb >> 23;                                                    // sign + biased exponent
+    if (XV == 7) return (float)pow((double)t, (double)kM1);
+    if (idx == 0 || idx >= 255) return idx == 0 ? 0.0f : __builtin_nanf("");         // 0 / denormal -> code 0; negative, inf, NaN -> code 0 (table entries in the kernels)
+    const float Ei = (float)((int)idx - 126);                                         // frexp exponent of a normal number
+    const float mant = __uint_as_float((tb & 0x007fffffu) | 0x3f000000u);             // [0.5, 1)
+    const float Ai = kM1 * Ei;
+    const float N = (XV == 4) ? __builtin_floorf(Ai) : __builtin_rintf(Ai);
+    const float F = Ai - N;
+    const float e1 = fma_(kM1, nlog2(mant), F);
+    float y;
+    if (XV == 6) {                                                                    // exp2 on [-0.67, 0.5] by a degree-7 polynomial (Horner, fp32)
+        const float z = e1 * 0.6931471805599453f;
+        float p = 1.0f / 5040.0f;
+        p = fma_(p, z, 1.0f / 720.0f); p = fma_(p, z, 1.0f / 120.0f); p = fma_(p, z, 1.0f / 24.0f); p = fma_(p, z, 1.0f / 6.0f);
+        p = fma_(p, z, 0.5f); p = fma_(p, z, 1.0f); y = fma_(p, z, 1.0f);
+    } else y = nexp2(e1);
+    return __uint_as_float(__float_as_uint(y) + ((uint32_t)(int)N << 23));
 }
 
 template <int DV> __device__ __forceinline__ float pq_div(float n, float d)
@@ -61,6 +95,7 @@ template <int XV, int QV, int DV> __device__ __forceinline__ float pq_scaled(flo
     const float n = kC1 + kC2 * x, d = 1.0f + kC3 * x;
     const float q = pq_div<DV>(n, d);
     if (QV == 0) return nexp2(fma_(kM2, nlog2(q), log2_max));
+    if (QV == 2) return (float)pow((double)q, (double)kM2) * maxv;                   // correctly rounded last stage: what x alone costs
     return nexp2(kM2 * nlog2(q)) * maxv;
 }
 
@@ -120,24 +155,30 @@ int main()
         std::vector<uint16_t> got(n), want(n);
         printf("== %s (%d samples): fraction of codes that differ from the glibc-powf reference\n", set ? "C4-like" : "t2 sweep", n);
         printf("%-8s %-6s", "bits", "peak");
-        const char* names[] = { "x0q0d0(lib)", "x0q1d0", "x2q0d0", "x2q1d0", "x2q1d1", "x2q1d2", "x3q1d0", "x3q1d1", "x3q1d2" };
+        const char* names[] = { "x0q0d0(r3)", "x0q1d0", "x2q0d0", "x2q1d0", "x3q1d0(hi)", "x4q1d0", "x5q1d0", "x5q0d0", "x6q1d0", "x7q1d0", "x5q2d0", "x7q2d0", "x0q2d0", "x8q1d0" };
+        const int NV = (int)(sizeof names / sizeof names[0]);
         for (const char* nm : names) printf(" %11s", nm);
         printf("\n");
         for (int bits : { 10, 12 }) for (float peak : { 80.0f, 1000.0f, 10000.0f }) {
             const float maxv = (float)((1 << bits) - 1);
             for (int i = 0; i < n; ++i) { const float v = host_pq(x[i], peak) * maxv; want[i] = (uint16_t)std::min(std::max(v, 0.0f), maxv); }
             printf("%-8d %-6.0f", bits, peak);
-            for (int k = 0; k < 9; ++k) {
+            for (int k = 0; k < NV; ++k) {
                 switch (k) {
                 case 0: launch<0, 0, 0>(din, dout, n, peak, bits); break;
                 case 1: launch<0, 1, 0>(din, dout, n, peak, bits); break;
                 case 2: launch<2, 0, 0>(din, dout, n, peak, bits); break;
                 case 3: launch<2, 1, 0>(din, dout, n, peak, bits); break;
-                case 4: launch<2, 1, 1>(din, dout, n, peak, bits); break;
-                case 5: launch<2, 1, 2>(din, dout, n, peak, bits); break;
-                case 6: launch<3, 1, 0>(din, dout, n, peak, bits); break;
-                case 7: launch<3, 1, 1>(din, dout, n, peak, bits); break;
-                case 8: launch<3, 1, 2>(din, dout, n, peak, bits); break;
+                case 4: launch<3, 1, 0>(din, dout, n, peak, bits); break;
+                case 5: launch<4, 1, 0>(din, dout, n, peak, bits); break;
+                case 6: launch<5, 1, 0>(din, dout, n, peak, bits); break;
+                case 7: launch<5, 0, 0>(din, dout, n, peak, bits); break;
+                case 8: launch<6, 1, 0>(din, dout, n, peak, bits); break;
+                case 9: launch<7, 1, 0>(din, dout, n, peak, bits); break;
+                case 10: launch<5, 2, 0>(din, dout, n, peak, bits); break;
+                case 11: launch<7, 2, 0>(din, dout, n, peak, bits); break;
+                case 12: launch<0, 2, 0>(din, dout, n, peak, bits); break;
+                case 13: launch<8, 1, 0>(din, dout, n, peak, bits); break;
                 }
                 CHECK(hipMemcpy(got.data(), dout, n * sizeof(uint16_t), hipMemcpyDeviceToHost));
                 int bad = 0, worst = 0;
