@@ -114,6 +114,11 @@ class DeviceInfo(ctypes.Structure):
                 ("pci_bus_id", ctypes.c_char * 32), ("cpulist", ctypes.c_char * 256)]
 
 
+class DeviceTraffic(ctypes.Structure):
+    _fields_ = [("device", c_int32), ("copy_helper_pools", c_int32), ("tiles", ctypes.c_uint64), ("bytes_h2d", ctypes.c_uint64),
+                ("bytes_d2h", ctypes.c_uint64), ("bytes_bounced", ctypes.c_uint64)]
+
+
 Transform16Fn = ctypes.CFUNCTYPE(None, c_void_p, POINTER(ctypes.c_uint16), POINTER(ctypes.c_uint16), ctypes.c_uint32)
 TransformF32Fn = ctypes.CFUNCTYPE(None, c_void_p, POINTER(ctypes.c_float), POINTER(ctypes.c_float), ctypes.c_uint32)
 
@@ -128,6 +133,9 @@ ABI = [
     ("avifgpu_device_count", c_int32, []),
     ("avifgpu_shutdown", None, []),
     ("avifgpu_device_topology", c_int32, [c_int32, POINTER(DeviceInfo)]),
+    ("avifgpu_device_traffic_get", c_int32, [c_int32, POINTER(DeviceTraffic)]),
+    ("avifgpu_device_traffic_reset", c_int32, []),
+    ("avifgpu_topology_plan", c_int32, [c_char_p, POINTER(c_char_p), c_int32, POINTER(DeviceInfo)]),
     ("avifgpu_topology_probe", c_int32, [c_char_p, c_char_p, POINTER(c_int32), ctypes.c_char_p, c_int32]),
     ("avifgpu_last_error", c_char_p, []),
     ("avifgpu_write_rows", c_int32, [POINTER(WriteDesc), c_int32, c_int32, c_void_p, c_int64,
@@ -163,7 +171,12 @@ ABI = [
 
 def bind(lib: ctypes.CDLL, table=ABI) -> ctypes.CDLL:
     for name, res, args in table:
-        fn = getattr(lib, name)        # AttributeError if the symbol is not exported
+        try:
+            fn = getattr(lib, name)    # AttributeError if the symbol is not exported
+        except AttributeError:
+            if os.environ.get("AVIFGPU_LIB"):      # developer A/B against an older build (tools/gpu/ab_libs.sh): its newer entry points are just absent
+                continue
+            raise
         fn.restype = res
         fn.argtypes = args
     return lib
@@ -292,6 +305,19 @@ class AvifGpu:
                 break
             out.append({"device": info.device, "pci_bus_id": info.pci_bus_id.decode(), "numa_node": info.numa_node,
                         "cpulist": info.cpulist.decode(), "workers": info.workers, "workers_pinned": bool(info.workers_pinned)})
+        return out
+
+    def traffic(self, reset=False):
+        """[{device, tiles, bytes_h2d, bytes_d2h, bytes_bounced, copy_helper_pools}] per bound device (avifgpu_device_traffic_get)."""
+        out = []
+        for i in range(64):
+            t = DeviceTraffic()
+            if self.lib.avifgpu_device_traffic_get(i, ctypes.byref(t)) != 0:
+                break
+            out.append({"device": t.device, "tiles": t.tiles, "bytes_h2d": t.bytes_h2d, "bytes_d2h": t.bytes_d2h,
+                        "bytes_bounced": t.bytes_bounced, "copy_helper_pools": t.copy_helper_pools})
+        if reset:
+            self.lib.avifgpu_device_traffic_reset()
         return out
 
     def last_kernel(self) -> str:

@@ -169,7 +169,21 @@ struct IccDeviceTables {
     void* icc16 = nullptr; std::vector<uint8_t> icc16_host;    // 33^3 x 4 u16
     void* pow_tab = nullptr;                                    // 128 x float4, constant
     void* s32 = nullptr;   std::vector<uint8_t> s32_host;      // 3 x 65536 floats: sampled curves of a 32-bit document
+    // the caller's table of the last upload and a fingerprint of it: a tile that passes the same struct again (every tile of an image
+    // does) skips the byte-for-byte comparison of 216-792 KiB under g_icc_mu.  A prepared table is immutable while it is in use
+    // (include/avifgpu.h); the fingerprint -- 4096 strided words -- is the guard against a caller that rewrites one in place anyway.
+    const void* s32_src = nullptr;   uint64_t s32_fp = 0;
+    const void* icc16_src = nullptr; uint64_t icc16_fp = 0;
 };
+static uint64_t table_fingerprint(const void* base, size_t bytes)
+{
+    const uint32_t* w = static_cast<const uint32_t*>(base);
+    const size_t n = bytes / 4, step = n / 4096 ? n / 4096 : 1;
+    uint64_t h = 1469598103934665603ull ^ (uint64_t)bytes;
+    for (size_t i = 0; i < n; i += step) h = (h ^ w[i]) * 1099511628211ull;
+    if (n) h = (h ^ w[n - 1]) * 1099511628211ull;
+    return h;
+}
 static std::mutex g_icc_mu;
 static std::map<int, IccDeviceTables> g_icc_tables;            // keyed by HIP device ordinal
 
@@ -222,7 +236,9 @@ int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p)
         e = hipMalloc(&c.icc16, rec_bytes);
         if (e != hipSuccess) { c.icc16 = nullptr; return hip_fail(e, "hipMalloc(icc16 table)", AVIFGPU_memFullErr); }
     }
-    if (c.icc16_host.size() != n || memcmp(c.icc16_host.data(), t->table, n) != 0) {
+    const uint64_t fp = table_fingerprint(t->table, n);
+    const bool same_call = c.icc16_src == t && c.icc16_fp == fp && c.icc16_host.size() == n;
+    if (!same_call && (c.icc16_host.size() != n || memcmp(c.icc16_host.data(), t->table, n) != 0)) {
         std::vector<uint16_t> rec(rec_bytes / 2, 0);
 #if AG_ICC16_DOT2 == 2
         // node-pair tables (kernel_params.h): A[n] = {node n, node n + (1,1,1)}, B[3 m + k] = {node m, node m + e_k}
@@ -269,6 +285,7 @@ int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p)
         if (e != hipSuccess) return hip_fail(e, "upload of the ICC table", AVIFGPU_writErr);
         c.icc16_host.assign(reinterpret_cast<const uint8_t*>(t->table), reinterpret_cast<const uint8_t*>(t->table) + n);
     }
+    c.icc16_src = t; c.icc16_fp = fp;
     p.icc16_clut = static_cast<const uint16_t*>(c.icc16);
     return 0;
 }
@@ -291,12 +308,14 @@ int upload_icc_sampled(const avifgpu_icc_sampled32* t, WriteParams& p)
     }
     const uint8_t* host = reinterpret_cast<const uint8_t*>(t->curve);        // curve[] and table16[] are adjacent members
     static_assert(offsetof(avifgpu_icc_sampled32, table16) == offsetof(avifgpu_icc_sampled32, curve) + sizeof(t->curve), "one span");
-    if (c.s32_host.size() != n || memcmp(c.s32_host.data(), host, n) != 0) {
+    const uint64_t fp = table_fingerprint(host, n);
+    if (!(c.s32_src == t && c.s32_fp == fp && c.s32_host.size() == n) && (c.s32_host.size() != n || memcmp(c.s32_host.data(), host, n) != 0)) {
         e = hipDeviceSynchronize();                             // a launch may still be reading the previous curves
         if (e == hipSuccess) e = hipMemcpy(c.s32, host, n, hipMemcpyHostToDevice);
         if (e != hipSuccess) return hip_fail(e, "upload of the sampled ICC curves", AVIFGPU_writErr);
         c.s32_host.assign(host, host + n);
     }
+    c.s32_src = t; c.s32_fp = fp;
     p.icc_s_tab = static_cast<const float*>(c.s32);
     p.icc_s_tab16 = reinterpret_cast<const uint16_t*>(static_cast<const uint8_t*>(c.s32) + nc);
     const bool lds = t->entries[0] > 0 && t->entries[1] > 0 && t->entries[2] > 0 && !(g_hot_variant & 64);   // bit 6: tests take the memory path
@@ -432,7 +451,13 @@ int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const Wr
                 for (int k = 0; k < 8; ++k) same = same && p.icc_trc[c][k] == p.icc_trc[0][k];
             const double* Q = p.icc_trc[0];                    // g, a, b, thr, c, f, add, nonpos
             const bool linear = p.icc_trc_linear[0] && p.icc_trc_linear[1] && p.icc_trc_linear[2];
-            p.icc_same_simple = !icc.s32 && same && !linear && Q[0] > 0.0 && Q[1] > 0.0 && std::isfinite(Q[3]) && Q[1] * Q[3] + Q[2] >= 0.0 && Q[7] == Q[6];
+            // The kernels evaluate fmaf(a, R, b) with the FLOAT-rounded a, b and thr (icc_trc_f) and no "a R + b > 0" guard, so the
+            // qualification is made on those: fmaf is monotone in R for a > 0, hence fmaf(a, thr, b) >= 0 covers every R >= thr and the
+            // v_log_f32 never sees a negative number (a type-2/3 curve with b != 0 has thr = -b / a, where the rounded operands can land
+            // an ulp below zero: such a curve takes the generic kernel, which has the guard).
+            const float af = p.icc_trc_f[0][2], bf = p.icc_trc_f[0][3], thrf = p.icc_trc_f[0][4];
+            p.icc_same_simple = !icc.s32 && same && !linear && Q[0] > 0.0 && af > 0.0f && std::isfinite(Q[3]) && std::isfinite(thrf) &&
+                                Q[1] * Q[3] + Q[2] >= 0.0 && std::fmaf(af, thrf, bf) >= 0.0f && Q[7] == Q[6];
         }
         for (int k = 0; k < 9; ++k) { p.icc_m[k] = g_icc->matrix[k]; p.icc_m_f[k] = (float)g_icc->matrix[k]; }
         { const int rc = upload_icc_pow_table(p); if (rc) return rc; }
@@ -704,6 +729,23 @@ int32_t avifgpu_init(int32_t device_index) { return avifgpu_init_devices(&device
 int32_t avifgpu_device_count(void) { return bound_device_count(); }
 
 int32_t avifgpu_device_topology(int32_t index, avifgpu_device_info* out) { return device_topology(index, out); }
+int32_t avifgpu_device_traffic_get(int32_t index, avifgpu_device_traffic* out)
+{
+    if (!out) return fail(AVIFGPU_formatBadParameters, "avifgpu_device_traffic_get: null result");
+    return device_traffic(index, out, false);
+}
+int32_t avifgpu_topology_plan(const char* sysfs_root, const char* const* pci_bus_ids, int32_t count, avifgpu_device_info* out)
+{
+    const int rc = topology_plan(sysfs_root, pci_bus_ids, count, out);
+    if (rc == AVIFGPU_formatBadParameters) return fail(rc, "avifgpu_topology_plan: bad arguments");
+    if (rc < 0) return fail(rc, "avifgpu_topology_plan: a device is missing from the sysfs tree or its CPU list does not parse");
+    return rc;
+}
+int32_t avifgpu_device_traffic_reset(void)
+{
+    for (int i = 0; device_traffic(i, nullptr, true) == 0; ++i) {}
+    return 0;
+}
 int32_t avifgpu_topology_probe(const char* sysfs_root, const char* pci_bus_id, int32_t* numa_node, char* cpulist, int32_t cpulist_len)
 {
     return topology_probe_c(sysfs_root, pci_bus_id, numa_node, cpulist, cpulist_len);

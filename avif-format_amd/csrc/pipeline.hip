@@ -28,6 +28,7 @@
 #include <cstring>
 #include <deque>
 #include <memory>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -95,6 +96,9 @@ struct Ctx {
     // pages are first touched (and page-locked) on the socket the GPU's x16 link hangs off
     bool alloc_pending = false; int alloc_slot = 0; size_t alloc_bytes = 0; int alloc_rc = 0;
     bool pinned_to_node = false;
+    // what this context moved over its device's link since the binding (or the last avifgpu_device_traffic_reset): payload bytes of the
+    // tiles it issued, per direction, and how many of them went through a bounce buffer (pageable caller memory)
+    std::atomic<uint64_t> tiles{0}, bytes_h2d{0}, bytes_d2h{0}, bytes_bounced{0};
 };
 
 // Where a bound device sits in the host: PCI bus id, NUMA node, the node's CPUs ("report which GPUs hang off which
@@ -306,8 +310,28 @@ private:
     std::vector<std::thread> threads_;
     bool stop_ = false;
 };
-// never destroyed (like the contexts: their threads may outlive static destruction at process exit); contexts_shutdown() joins the helpers
-CopyHelpers& copy_helpers() { static CopyHelpers* p = new CopyHelpers; return *p; }
+// One pool per NUMA node (round 4; round 3 had one per process): helper threads are created by the first worker that needs them and
+// inherit THAT worker's CPU affinity, so a single pool on a two-socket, eight-GPU node would have done the bounce copies of the other
+// socket's GPUs across the socket link -- the traffic the worker pinning exists to avoid.  A worker registers its node once
+// (t_copy_node: the NUMA node of its device, or 0 when the host does not say); a pool is only ever used by workers of its node.
+// Never destroyed (like the contexts: their threads may outlive static destruction at process exit); contexts_shutdown() joins the helpers.
+thread_local int t_copy_node = 0;
+std::mutex g_helpers_mu;
+std::map<int, CopyHelpers*>& helper_pools() { static std::map<int, CopyHelpers*>* m = new std::map<int, CopyHelpers*>; return *m; }
+CopyHelpers& copy_helpers()
+{
+    std::lock_guard<std::mutex> lk(g_helpers_mu);
+    CopyHelpers*& p = helper_pools()[t_copy_node];
+    if (!p) p = new CopyHelpers;
+    return *p;
+}
+void copy_helpers_shutdown()
+{
+    std::vector<CopyHelpers*> pools;
+    { std::lock_guard<std::mutex> lk(g_helpers_mu); for (auto& kv : helper_pools()) pools.push_back(kv.second); }
+    for (CopyHelpers* p : pools) p->shutdown();
+}
+int copy_helper_pool_count() { std::lock_guard<std::mutex> lk(g_helpers_mu); return (int)helper_pools().size(); }
 
 void host_copy_rows(uint8_t* dst, size_t dst_pitch, const uint8_t* src, size_t src_pitch, size_t bytes, size_t rows)
 {
@@ -431,6 +455,9 @@ int start_write(Ctx& c, Job& j)
         return hipMemcpyAsync(sl.d_in, sl.h_rows, in_pitch * (size_t)j.nrows, hipMemcpyHostToDevice, st);
     });
     if (e != hipSuccess) { (void)hipStreamSynchronize(st); return hip_fail(e, "H2D copy", AVIFGPU_writErr); }
+    c.tiles.fetch_add(1, std::memory_order_relaxed);
+    c.bytes_h2d.fetch_add((uint64_t)row_bytes * (uint64_t)j.nrows, std::memory_order_relaxed);
+    if (!direct) c.bytes_bounced.fetch_add((uint64_t)row_bytes * (uint64_t)j.nrows, std::memory_order_relaxed);
 
     p.src = static_cast<const uint8_t*>(sl.d_in); p.src_row_bytes = (int64_t)in_pitch;
     for (int pl = 0; pl < 4; ++pl) {
@@ -461,6 +488,8 @@ int start_write(Ctx& c, Job& j)
             j.bounce[j.nbounce++] = { static_cast<uint8_t*>(j.planes_out[pl]), j.planes_out_stride[pl], off[pl], pitch[pl], (size_t)pbytes[pl], prow[pl] };
         }
         if (e != hipSuccess) { (void)hipStreamSynchronize(st); return hip_fail(e, "D2H copy", AVIFGPU_writErr); }
+        c.bytes_d2h.fetch_add((uint64_t)pbytes[pl] * (uint64_t)prow[pl], std::memory_order_relaxed);
+        if (!pinned_dst[pl]) c.bytes_bounced.fetch_add((uint64_t)pbytes[pl] * (uint64_t)prow[pl], std::memory_order_relaxed);
     }
     if ((e = hipEventRecord(sl.done, st)) != hipSuccess) { (void)hipStreamSynchronize(st); return hip_fail(e, "event record", AVIFGPU_writErr); }
     return 0;
@@ -519,6 +548,12 @@ int start_read(Ctx& c, Job& j)
         return ce;
     });
     if (e != hipSuccess) { (void)hipStreamSynchronize(st); return hip_fail(e, "H2D copy", AVIFGPU_readErr); }
+    c.tiles.fetch_add(1, std::memory_order_relaxed);
+    for (int pl = 0; pl < 4; ++pl) {
+        if (!read_plane_used(d, g, pl) || prow[pl] == 0) continue;
+        c.bytes_h2d.fetch_add((uint64_t)pbytes[pl] * (uint64_t)prow[pl], std::memory_order_relaxed);
+        if (!pinned_src[pl]) c.bytes_bounced.fetch_add((uint64_t)pbytes[pl] * (uint64_t)prow[pl], std::memory_order_relaxed);
+    }
     p.dst = static_cast<uint8_t*>(sl.d_out); p.dst_row_bytes = (int64_t)out_pitch;
     e = launch_read(p, d->colorspace, d->depth, g.alpha, g.xs, g.ys, st, j.label);
     if (e != hipSuccess) { (void)hipStreamSynchronize(st); return hip_fail(e, "kernel launch", AVIFGPU_readErr); }
@@ -533,6 +568,8 @@ int start_read(Ctx& c, Job& j)
         j.bounce[j.nbounce++] = { static_cast<uint8_t*>(j.rows_out), j.rows_out_stride, 0, out_pitch, row_bytes, j.nrows };
     }
     if (e != hipSuccess) { (void)hipStreamSynchronize(st); return hip_fail(e, "D2H copy", AVIFGPU_readErr); }
+    c.bytes_d2h.fetch_add((uint64_t)row_bytes * (uint64_t)j.nrows, std::memory_order_relaxed);
+    if (j.nbounce) c.bytes_bounced.fetch_add((uint64_t)row_bytes * (uint64_t)j.nrows, std::memory_order_relaxed);
     if ((e = hipEventRecord(sl.done, st)) != hipSuccess) { (void)hipStreamSynchronize(st); return hip_fail(e, "event record", AVIFGPU_readErr); }
     return 0;
 }
@@ -576,6 +613,7 @@ void worker_main(Ctx* cp)
         cpu_set_t set;
         if (t.device == c.device && env_int("AVIFGPU_PIN_WORKERS", 1, 0, 1) && parse_cpulist(t.cpulist, set))
             c.pinned_to_node = pthread_setaffinity_np(pthread_self(), sizeof(set), &set) == 0;
+        if (t.device == c.device) t_copy_node = t.numa_node >= 0 ? t.numa_node : 0;      // this worker's bounce copies use its own node's helper pool
     }
     hipError_t e = hipSetDevice(c.device);
     for (int s = 0; e == hipSuccess && s < c.nslots; ++s) {
@@ -713,7 +751,15 @@ void contexts_shutdown()
     g_ctxs = nullptr;
     g_bound.clear();
     g_topo.clear();
-    copy_helpers().shutdown();                             // the next binding's workers make their own (affinity of THEIR node)
+    copy_helpers_shutdown();                               // the next binding's workers make their own (affinity of THEIR node)
+    {
+        // Upload-order tickets start again with the next binding.  Every ticketed job has been through its UploadTurn by now (the
+        // workers drain their queues before they exit), so next_ticket == serving; resetting both makes that an invariant of a
+        // fresh binding instead of something a dropped job could break for the rest of the process.
+        std::lock_guard<std::mutex> l3(g_upload_mu);
+        for (auto& o : g_upload)
+            if (o) { std::lock_guard<std::mutex> l4(o->mu); o->next_ticket = o->serving = 0; o->head = 0; for (hipEvent_t& ev : o->ring) ev = nullptr; }   // (the ring's events died with their slots)
+    }
 }
 
 int contexts_init(const int32_t* devices, int count)
@@ -803,6 +849,50 @@ int device_topology(int index, avifgpu_device_info* out)
     out->device = t.device; out->numa_node = t.numa_node; out->workers = t.workers; out->workers_pinned = t.pinned ? 1 : 0;
     snprintf(out->pci_bus_id, sizeof(out->pci_bus_id), "%s", t.bdf.c_str());
     snprintf(out->cpulist, sizeof(out->cpulist), "%s", t.cpulist.c_str());
+    return 0;
+}
+
+// The placement a binding of these PCI devices would get, without touching a device: NUMA node and CPU list per device (sysfs),
+// workers per device (AVIFGPU_LANES), and -- the return value -- how many distinct helper pools / pinned-allocation domains that
+// makes (one per NUMA node seen; devices whose node is unknown share pool 0).  contexts_init() does exactly this per bound device.
+int topology_plan(const char* sysfs_root, const char* const* bdfs, int count, avifgpu_device_info* out)
+{
+    if (!bdfs || count < 1 || count > 64 || !out) return AVIFGPU_formatBadParameters;
+    const int lanes = env_int("AVIFGPU_LANES", kDefaultLanes, 1, 4);
+    const bool pin = env_int("AVIFGPU_PIN_WORKERS", 1, 0, 1) != 0;
+    std::vector<int> nodes;
+    for (int i = 0; i < count; ++i) {
+        if (!bdfs[i]) return AVIFGPU_formatBadParameters;
+        int node = -1; std::string list;
+        const int rc = topology_probe(sysfs_root, bdfs[i], node, list);
+        if (rc < 0) return rc;
+        std::memset(&out[i], 0, sizeof(out[i]));
+        out[i].device = i; out[i].numa_node = node; out[i].workers = lanes;
+        cpu_set_t set;
+        out[i].workers_pinned = pin && parse_cpulist(list, set) ? 1 : 0;
+        snprintf(out[i].pci_bus_id, sizeof(out[i].pci_bus_id), "%s", bdfs[i]);
+        snprintf(out[i].cpulist, sizeof(out[i].cpulist), "%s", list.c_str());
+        const int pool = node >= 0 ? node : 0;
+        if (std::find(nodes.begin(), nodes.end(), pool) == nodes.end()) nodes.push_back(pool);
+    }
+    return (int)nodes.size();
+}
+
+int device_traffic(int index, avifgpu_device_traffic* out, bool reset)
+{
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    if (index < 0 || index >= (int)g_topo.size() || !g_ctxs) return AVIFGPU_formatBadParameters;
+    const int dev = g_topo[index].device;
+    avifgpu_device_traffic t;
+    std::memset(&t, 0, sizeof(t));
+    t.device = dev;
+    for (Ctx* c : *g_ctxs) {
+        if (c->device != dev) continue;
+        t.tiles += c->tiles.load(); t.bytes_h2d += c->bytes_h2d.load(); t.bytes_d2h += c->bytes_d2h.load(); t.bytes_bounced += c->bytes_bounced.load();
+        if (reset) { c->tiles = 0; c->bytes_h2d = 0; c->bytes_d2h = 0; c->bytes_bounced = 0; }
+    }
+    t.copy_helper_pools = copy_helper_pool_count();
+    if (out) *out = t;
     return 0;
 }
 

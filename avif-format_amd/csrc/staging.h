@@ -93,6 +93,8 @@ void host_call_unlock();
 struct HostCallGuard { HostCallGuard() { host_call_lock(); } ~HostCallGuard() { host_call_unlock(); } };
 // Topology of the bound devices (avifgpu_device_topology / avifgpu_topology_probe, include/avifgpu.h)
 int  device_topology(int index, avifgpu_device_info* out);
+int  device_traffic(int index, avifgpu_device_traffic* out, bool reset);
+int  topology_plan(const char* sysfs_root, const char* const* bdfs, int count, avifgpu_device_info* out);
 int  topology_probe_c(const char* sysfs_root, const char* bdf, int32_t* numa_node, char* cpulist, int32_t cpulist_len);
 
 // Whole-range host conversions: rows [row0, row0 + nrows) are cut into one contiguous row tile per context (even cuts) and

@@ -2289,8 +2289,7 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, char* label)
     }
     if constexpr (DEPTH == 32 && PLANES >= 3) {
         if (p.icc_s_tab != nullptr) {               // sampled document curves: table lookup in front of the matrix
-            if constexpr (TRANSFER == kTransferPqHi) return hipErrorInvalidValue;       // (launch_tr sends sampled profiles to the plain PQ id)
-            else {
+            {
                 snprintf(label, kLabelBytes, "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=6>",
                          DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned);
                 const size_t lds = p.icc_s_n[0] > 0 ? (size_t)(p.icc_s_n[0] + p.icc_s_n[1] + p.icc_s_n[2]) * 4 : 0;      // <= 48 KiB
@@ -2339,7 +2338,7 @@ static hipError_t launch_tr(const WriteParams& p, hipStream_t st, char* label)
 {
     if constexpr (DEPTH == 32) {
         switch (p.transfer) {
-        case AVIFGPU_TRANSFER_PQ:       if (pq_hi_launch(p) && p.icc_s_tab == nullptr) AG_LAUNCH(DEPTH, PLANES, OUT, DST16, XS, YS, kTransferPqHi); AG_LAUNCH(DEPTH, PLANES, OUT, DST16, XS, YS, 0);
+        case AVIFGPU_TRANSFER_PQ:       if (pq_hi_launch(p)) AG_LAUNCH(DEPTH, PLANES, OUT, DST16, XS, YS, kTransferPqHi); AG_LAUNCH(DEPTH, PLANES, OUT, DST16, XS, YS, 0);
         case AVIFGPU_TRANSFER_HLG:      AG_LAUNCH(DEPTH, PLANES, OUT, DST16, XS, YS, 1);
         case AVIFGPU_TRANSFER_SMPTE428: AG_LAUNCH(DEPTH, PLANES, OUT, DST16, XS, YS, 2);
         default:                        AG_LAUNCH(DEPTH, PLANES, OUT, DST16, XS, YS, 3);

@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--clock-ramp-ms", type=float, default=150.0,
                     help="untimed setup: run the kernel this long before the W warm-up steps so the GPU leaves its idle "
                          "clock state (measured: the first ~50 ms of launches run at up to 2x the steady-state time)")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold single-launch figure (2 s of idle time)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive (host pointers, in-process N-device) figure")
     ap.add_argument("--no-rotate", action="store_true", help="skip the rotating-buffer (Infinity Cache) cross-check of the kernel time")
     ap.add_argument("--no-c5", action="store_true", help="skip the configs[4] (16384^2 RGBA f32) sub-measurement")
@@ -227,6 +228,25 @@ def main():
             print(f"sweep {word:>10s} p10={ts[4]:.4f} p50={ts[20]:.4f} mean={sum(ts)/len(ts):.4f} ms  "
                   f"{ab / (sum(ts)/len(ts)) / 1e6:8.1f} GB/s  {gpu.last_kernel()}", file=sys.stderr, flush=True)
         lib.avifgpu_set_hot_variant(1 | 2 | 4)
+
+    # untimed diagnostic, BEFORE any ramp: what a plug-in save pays -- ONE launch on a GPU that has been idle.  The first launch of the
+    # process also loads the code object; the second figure is the same launch after the device has idled for a second again.
+    cold = None
+    if not args.no_cold:
+        def one_launch():
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t1 = time.perf_counter()
+            a.record(stream); step(); b.record(stream)
+            torch.cuda.synchronize(dev)
+            return a.elapsed_time(b), (time.perf_counter() - t1) * 1e3
+        time.sleep(1.0)
+        first_ev, first_wall = one_launch()
+        time.sleep(1.0)
+        cold_ev, cold_wall = one_launch()
+        cold = {"first_launch_in_process_ms": round(first_ev, 4), "first_launch_in_process_wall_ms": round(first_wall, 3),
+                "cold_first_launch_ms": round(cold_ev, 4), "cold_first_launch_wall_ms": round(cold_wall, 3),
+                "note": "one launch after 1 s of idle GPU, no clock ramp (HIP events on the launch stream; wall = launch call + synchronize); "
+                        "the first launch of the process also loads the kernel's code object"}
 
     # untimed setup: bring the device out of its idle power state (DVFS ramp), then the W warm-up steps
     t_ramp = time.perf_counter()
@@ -344,6 +364,12 @@ def main():
     torch.cuda.synchronize(dev)
     batch_ms = sorted(a.elapsed_time(b) / 10 for a, b in bev)
 
+    # what every rank measured on its own GPU (one SCALE record then answers "which GPU was slow" and "does a 1/N tile take 1/N of
+    # the time": the launch floor of DESIGN.md section 6.5 says no -- 0.89 strong-scaling efficiency projected at N = 8)
+    per_rank = ranks.gather_objects({"rank": rank, "device": dev_index, "rows": nrows, "kernel_ms_mean": round(mean_kernel_s * 1e3, 5),
+                                     "GB_s": round(gpu.write_algorithmic_bytes(desc, nrows) / mean_kernel_s / 1e9, 1),
+                                     "batches_of_10_ms_p50": round(batch_ms[len(batch_ms) // 2], 5),
+                                     "pci_bus_id": (gpu.topology() or [{}])[0].get("pci_bus_id"), "numa_node": (gpu.topology() or [{}])[0].get("numa_node")})
     total_rows = H * world if args.scaling == "weak" else H
     total_px = float(W) * total_rows * args.steps
     value = total_px / elapsed / 1e6
@@ -400,6 +426,10 @@ def main():
     if rotating:
         rotating["frac"] = round(algo_bytes / (rotating["kernel_ms_mean"] / 1e3) / 1e9 / HBM_PEAK_GBPS, 4)
         out["roofline"]["rotating_buffers"] = rotating
+    out["per_rank"] = per_rank
+    if cold:
+        out["cold_launch"] = cold
+        out["roofline"]["cold_first_launch_ms"] = cold["cold_first_launch_ms"]
     out["profile_window"] = {"kernel": kernel_name, "launches_before_timed_region": launches_before_timed, "timed_launches": args.steps}
     # PMC-derived HBM traffic per launch: NOT measured in this run (counters need their own rocprofv3 --pmc passes, which the
     # driver's plain run cannot do) -- read from the committed summary of those passes and labelled as such
@@ -467,10 +497,15 @@ def main():
                     multi.write_rows(full, 0, H, h_src.data_ptr(), h_src.stride(0) * 4, [o.data_ptr() for o in h_out] + [None],
                                      [o.stride(0) for o in h_out] + [0], mem=pkg.MEM_HOST)
                 host_step()
-                best = None
-                for _ in range(5):
-                    t1 = time.perf_counter(); host_step(); dt = time.perf_counter() - t1
-                    best = dt if best is None else min(best, dt)
+                multi.traffic(reset=True)
+                runs = []
+                for _ in range(7):
+                    t1 = time.perf_counter(); host_step(); runs.append(time.perf_counter() - t1)
+                best, median = min(runs), sorted(runs)[len(runs) // 2]
+                traffic = multi.traffic()
+                per_device = [{"device": t["device"], "tiles": t["tiles"],
+                               "H2D_GB_s": round(t["bytes_h2d"] / sum(runs) / 1e9, 2), "D2H_GB_s": round(t["bytes_d2h"] / sum(runs) / 1e9, 2),
+                               "bounced_bytes": t["bytes_bounced"], "copy_helper_pools": t["copy_helper_pools"]} for t in traffic]
                 # the link's own ceiling for this job, same process, same page-locked buffers: the frame up and the planes down as
                 # plain asynchronous copies on two streams at once, no kernel, no tiling (GPU 0's link only)
                 ceiling = up_only = None
@@ -501,14 +536,15 @@ def main():
                 except Exception:                     # noqa: BLE001 -- a diagnostic of a diagnostic
                     ceiling = None
                 out["pcie_inclusive"] = {"value": round(W * H / best / 1e6, 1), "unit": "Mpixels/s", "seconds": round(best, 5),
-                                         "gpus": world, "H2D_GB_s": round(W * H * 12 / best / 1e9, 1), "D2H_GB_s": round(W * H * 6 / best / 1e9, 1),
+                                         "seconds_median": round(median, 5), "value_median": round(W * H / median / 1e6, 1), "runs": len(runs),
+                                         "gpus": world, "per_device": per_device, "H2D_GB_s": round(W * H * 12 / best / 1e9, 1), "D2H_GB_s": round(W * H * 6 / best / 1e9, 1),
                                          "plain_copies_seconds": None if ceiling is None else round(ceiling, 5),
                                          "frac_of_plain_copies": None if ceiling is None or world != 1 else round(ceiling / best, 3),
                                          "upload_only_seconds": None if up_only is None else round(up_only, 5),
                                          "frac_of_upload_only": None if up_only is None or world != 1 else round(up_only / best, 3),
                                          "topology": multi.topology(),
                                          "note": "one process, one calling thread: avifgpu_init_devices + avifgpu_write_rows(MEM_HOST); whole "
-                                                 f"{W}x{H} frame, page-locked rows in / planes out, row tiles dealt across the GPUs, best of 5"}
+                                                 f"{W}x{H} frame, page-locked rows in / planes out, row tiles dealt across the GPUs; value = best of 7, value_median beside it; per_device = each GPU's own link over the 7 runs"}
                 del h_src, h_out
                 gpu = pkg.AvifGpu(dev_index)
             except Exception as exc:      # noqa: BLE001 -- a diagnostic must not lose the headline line

@@ -265,10 +265,32 @@ typedef struct avifgpu_device_info {
 } avifgpu_device_info;
 int32_t avifgpu_device_topology(int32_t index, avifgpu_device_info* out);
 
+/* What bound device `index` (same numbering as avifgpu_device_topology) has carried over its own link since the binding or the last
+ * reset: tiles issued, payload bytes host -> device and device -> host, and how many of those bytes went through a pinned bounce
+ * buffer because the caller's memory was pageable.  With the wall time of a job this is the per-device H2D / D2H rate -- on an
+ * 8-GPU node the first thing to look at is whether the eight x16 links add up (bench.py pcie_inclusive.per_device).
+ * copy_helper_pools = helper-thread pools alive for pageable copies: one per NUMA node that has needed one. */
+typedef struct avifgpu_device_traffic {
+    int32_t  device;             /* HIP ordinal */
+    int32_t  copy_helper_pools;
+    uint64_t tiles;
+    uint64_t bytes_h2d;
+    uint64_t bytes_d2h;
+    uint64_t bytes_bounced;
+} avifgpu_device_traffic;
+int32_t avifgpu_device_traffic_get(int32_t index, avifgpu_device_traffic* out);
+int32_t avifgpu_device_traffic_reset(void);    /* all bound devices */
+
 /* The sysfs part of the above on its own (no device needed): NUMA node and CPU list of PCI device `pci_bus_id` under
  * `sysfs_root` (NULL = "/sys").  Returns the number of CPUs in the list (0 = none known), AVIFGPU_readErr when the tree has no
  * such device or the list does not parse, AVIFGPU_formatBadParameters for a null bus id. */
 int32_t avifgpu_topology_probe(const char* sysfs_root, const char* pci_bus_id, int32_t* numa_node, char* cpulist, int32_t cpulist_len);
+
+/* The placement avifgpu_init_devices would give these PCI devices, computed from sysfs alone (no device needed): out[i] = NUMA node,
+ * CPU list, workers (AVIFGPU_LANES) and whether they would be pinned, for pci_bus_ids[i].  Returns the number of NUMA domains the
+ * binding spans -- each gets its own pool of helper threads for pageable copies and first-touches its own pinned staging -- or a
+ * negative AVIFGPU_* code.  On an 8-GPU MI355X node: 2 domains, four devices (= four worker sets) each. */
+int32_t avifgpu_topology_plan(const char* sysfs_root, const char* const* pci_bus_ids, int32_t count, avifgpu_device_info* out);
 
 /* Message for the last non-zero return on this thread (what LibHeifException / runtime_error carry
  * in the reference, UIWin.cpp:1827-1843). */

@@ -150,6 +150,31 @@ def write_cases():
                                                        transfer=pkg.TRANSFER_CLIP, alpha_state=pkg.ALPHA_PREMULTIPLIED,
                                                        output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444,
                                                        matrix_coefficients=pkg.MATRIX_BT601)),
+        # the plug-in's own default save (InitGlobals, AvifFormat.cpp:89,95: 4:2:2, 12 bit; HDR documents: PQ at 80 nits), both
+        # output modes, with and without alpha, on a span-multiple width (streaming kernels) and on a ragged one; libheif 1.14's
+        # chroma rule (nearest); SDR 16-bit documents carry BT.601 with BT.709 primaries (WriteMetadata.cpp:138-140)
+        ("default-d32-p3-b12-422-pq80-near", dict(width=1024, height=6, depth=32, planes=3, bit_depth=12, transfer=pkg.TRANSFER_PQ,
+                                                  peak_nits=80, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_422,
+                                                  matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020,
+                                                  chroma_downsampling=pkg.DOWNSAMPLE_NEAREST)),
+        ("default-d32-p3-b12-422-pq80-near-tail", dict(width=1004, height=5, depth=32, planes=3, bit_depth=12, transfer=pkg.TRANSFER_PQ,
+                                                       peak_nits=80, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_422,
+                                                       matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020,
+                                                       chroma_downsampling=pkg.DOWNSAMPLE_NEAREST)),
+        ("default-d32-p3-b12-ref-pq80", dict(width=1024, height=6, depth=32, planes=3, bit_depth=12, transfer=pkg.TRANSFER_PQ,
+                                             peak_nits=80, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_REFERENCE)),
+        ("default-d32-p4-b12-422-pq80-near", dict(width=1024, height=6, depth=32, planes=4, bit_depth=12, transfer=pkg.TRANSFER_PQ,
+                                                  peak_nits=80, alpha_state=pkg.ALPHA_STRAIGHT, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_422,
+                                                  matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020,
+                                                  chroma_downsampling=pkg.DOWNSAMPLE_NEAREST)),
+        ("default-d32-p4-b12-ref-pq80-premul", dict(width=1024, height=6, depth=32, planes=4, bit_depth=12, transfer=pkg.TRANSFER_PQ,
+                                                    peak_nits=80, alpha_state=pkg.ALPHA_PREMULTIPLIED, output=pkg.OUT_REFERENCE)),
+        ("default-d16-p3-b12-422-601-near", dict(width=1024, height=6, depth=16, planes=3, bit_depth=12, alpha_state=pkg.ALPHA_NONE,
+                                                 output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_422, matrix_coefficients=pkg.MATRIX_BT601,
+                                                 color_primaries=pkg.PRIMARIES_BT709, chroma_downsampling=pkg.DOWNSAMPLE_NEAREST)),
+        ("default-d8-p3-b12-422-601-near", dict(width=1021, height=5, depth=8, planes=3, bit_depth=12, alpha_state=pkg.ALPHA_NONE,
+                                                output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_422, matrix_coefficients=pkg.MATRIX_BT601,
+                                                color_primaries=pkg.PRIMARIES_BT709, chroma_downsampling=pkg.DOWNSAMPLE_NEAREST)),
         # BASELINE.json config 1 at its real size: 512x512 RGBA8 -> 8-bit 4:2:0 BT.709
         ("baseline-c1-512", dict(width=512, height=512, depth=8, planes=4, bit_depth=8, alpha_state=pkg.ALPHA_STRAIGHT,
                                  output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420, matrix_coefficients=pkg.MATRIX_BT709)),
@@ -251,6 +276,18 @@ def read_cases():
                                                  matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020,
                                                  transfer_characteristics=pkg.TC_HLG, hlg_apply_ootf=1, hlg_display_gamma=1.0,
                                                  hlg_peak_nits=1000)))
+    # what the plug-in's default saves decode to: 12-bit 4:2:2, PQ -> RGB f32 (HDR) / BT.601 -> RGB16 (SDR), with and without alpha
+    out.append(("default-read-b12-422-pq80-f32", dict(width=1024, height=6, colorspace=pkg.COLORSPACE_YCBCR, chroma=pkg.CHROMA_422,
+                                                       bit_depth=12, depth=32, alpha_state=pkg.ALPHA_NONE,
+                                                       matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020,
+                                                       transfer_characteristics=pkg.TC_PQ, pq_peak_nits=80)))
+    out.append(("default-read-b12-422-pq80-f32-alpha-tail", dict(width=1003, height=5, colorspace=pkg.COLORSPACE_YCBCR, chroma=pkg.CHROMA_422,
+                                                                  bit_depth=12, depth=32, alpha_state=pkg.ALPHA_STRAIGHT,
+                                                                  matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020,
+                                                                  transfer_characteristics=pkg.TC_PQ, pq_peak_nits=80)))
+    out.append(("default-read-b12-422-601-rgb16", dict(width=1024, height=6, colorspace=pkg.COLORSPACE_YCBCR, chroma=pkg.CHROMA_422,
+                                                        bit_depth=12, depth=16, alpha_state=pkg.ALPHA_NONE,
+                                                        matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)))
     out.append(("tiny-read-1x1", dict(width=1, height=1, colorspace=pkg.COLORSPACE_YCBCR, chroma=pkg.CHROMA_420,
                                        bit_depth=8, depth=8, alpha_state=pkg.ALPHA_NONE,
                                        matrix_coefficients=pkg.MATRIX_BT709)))

@@ -103,7 +103,9 @@ def test_fullsize(gpu, name):
             got = got.view(np.uint16) if ssz == 2 else got
             diff = np.abs(got.astype(np.int64) - want[pl].astype(np.int64))
             if float_tier:
-                assert diff.max() <= 1 and (diff == 0).mean() > 0.99, (name, pl, int(diff.max()), float((diff == 0).mean()))
+                exact = float((diff == 0).mean())
+                print(f"{name} plane {pl} rows [{r0}, {r0 + n}): exact {exact:.5f}")
+                assert diff.max() <= 1 and exact >= (0.999 if d.bit_depth == 10 else 0.998), (name, pl, int(diff.max()), exact)
             else:
                 assert diff.max() == 0, (name, pl)
         del src_full

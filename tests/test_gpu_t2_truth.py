@@ -9,8 +9,8 @@ they are, including its float-rounded exponents 1/m1, 1/m2 and multipliers) eval
    SMPTE 428) and, code by code, is no larger than the oracle's own error plus that epsilon -- the 1e-4 bar of
    tests/test_gpu_read.py exists because the REFERENCE formula's float32 evaluation (c2 - c3*x cancels) is up to ~5e-5 off
    the truth, not because the kernel is;
- * write direction (OETF -> integer code, truncating): the exact-match rate is asserted at the measured level (>= 99.9 % at 10 and
-   at 12 bit with the default evaluation; the compact form, which 12-bit output no longer takes by default, keeps its >= 99.6 % there:
+ * write direction (OETF -> integer code, truncating): the exact-match rate is asserted at the measured level (>= 99.95 % at 10 and
+   at 12 bit with the default evaluation; the compact form, which nothing takes by default any more, keeps its >= 99.7 % at 12 bit:
    the same relative error meets four times as many code boundaries), and every
    mismatching sample is shown to sit within 2e-5 relative of a code boundary of the exact function.  2e-5 is the float32
    evaluation noise of the reference formula itself: q = (c1 + c2 x) / (1 + c3 x) carries 2-3 roundings of 6e-8 and q^78.84
@@ -83,11 +83,13 @@ def test_eotf_error_against_float64_truth(gpu, bits, curve):
     assert np.all(e_gpu <= e_orc + eps_rel * np.abs(truth) + 1e-12)                               # never worse than the oracle + eps
 
 
-# Round 3: 12-bit output takes the "close" evaluation by default (avifgpu_write_desc.pq_evaluation = AUTO): >= 99.9 % exact, the bar
-# SURVEY 8(a) proposed, at every depth.  COMPACT / CLOSE can be asked for explicitly; their own measured levels are asserted too.
-@pytest.mark.parametrize("bits,peak,mode,min_exact", [(10, 80, 0, 0.999), (10, 1000, 0, 0.999), (10, 10000, 0, 0.999),
-                                                      (12, 80, 0, 0.999), (12, 1000, 0, 0.999),
-                                                      (12, 80, 1, 0.996), (10, 80, 2, 0.9995), (12, 10000, 2, 0.999)])
+# Round 4: every depth takes the "close" evaluation by default (avifgpu_write_desc.pq_evaluation = AUTO), now in its table form:
+# >= 99.95 % exact at 10 AND at 12 bit (measured 99.986-99.990 % / 99.953-99.970 %).  COMPACT can still be asked for explicitly; its
+# own measured level (99.77 % at 12 bit, 99.94 % at 10) is asserted too.  What a value-domain threshold table could reach at best is
+# LOWER than this at 12 bit: the reference's own code is not a monotone function of the sample (tests/test_oracle_properties.py).
+@pytest.mark.parametrize("bits,peak,mode,min_exact", [(10, 80, 0, 0.9995), (10, 1000, 0, 0.9995), (10, 10000, 0, 0.9995),
+                                                      (12, 80, 0, 0.9995), (12, 1000, 0, 0.9995), (12, 10000, 0, 0.9995),
+                                                      (12, 80, 1, 0.997), (10, 80, 1, 0.999), (10, 80, 2, 0.9995), (12, 10000, 2, 0.9995)])
 def test_pq_write_mismatches_are_code_boundary_cases(gpu, bits, peak, mode, min_exact):
     x = np.concatenate([np.linspace(0, 1, 400_000, dtype=np.float32),
                         np.geomspace(1e-9, 12.5, 400_000).astype(np.float32),

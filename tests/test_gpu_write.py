@@ -1,8 +1,9 @@
 """GPU parity, write direction: libavifgpu.so (HIP kernels, through the C-ABI) vs the CPU oracle on the same seeded
 inputs.  Integer-source paths and the Clip curve are bit-exact (tier T1); paths through the PQ / HLG / SMPTE-428
-curves are held to |delta code| <= 1 with >= 99.7 % exact at 10 bit and >= 99 % at 12 bit on these few-thousand-sample cases
+curves are held to |delta code| <= 1 with >= 99.9 % exact at 10 bit and >= 99.8 % at 12 bit on these few-thousand-sample cases
 (tier T2: native v_log/v_exp vs glibc powf, then truncation; the same relative error meets four times as many code boundaries
-at 12 bit).  The million-sample sweeps below and tests/test_gpu_t2_truth.py hold the measured rates: >= 99.9 % / >= 99.6 %."""
+at 12 bit; a case of a few thousand samples may also pass with at most 4 mismatching samples -- 4 of 1920 is 99.79 %).  The
+900 k-sample sweeps below and tests/test_gpu_t2_truth.py hold the measured rates: >= 99.95 % at 10 AND at 12 bit (round 4)."""
 import numpy as np
 import pytest
 
@@ -13,7 +14,8 @@ pkg = harness.pkg
 pytestmark = pytest.mark.gpu
 
 T2_MAX_CODE_DELTA = 1
-T2_MIN_EXACT = {10: 0.997, 12: 0.99}
+T2_MIN_EXACT = {10: 0.999, 12: 0.998}
+T2_SMALL_CASE_MISMATCHES = 4
 
 
 def _check(cid, kw, got, want):
@@ -21,7 +23,8 @@ def _check(cid, kw, got, want):
     if cases.is_float_tier_write(kw):
         assert st["max_abs"] <= T2_MAX_CODE_DELTA, (cid, st)
         if st["n"] >= 1000:
-            assert st["exact_frac"] >= T2_MIN_EXACT[kw["bit_depth"]], (cid, st)
+            mismatches = round((1.0 - st["exact_frac"]) * st["n"])
+            assert st["exact_frac"] >= T2_MIN_EXACT[kw["bit_depth"]] or mismatches <= T2_SMALL_CASE_MISMATCHES, (cid, st)
     else:
         assert st["max_abs"] == 0, (cid, st)
     return st
@@ -84,14 +87,14 @@ def test_write_pq_code_boundaries(gpu):
                         np.linspace(1, 130, 100_000, dtype=np.float32)])
     n = (x.size // 3) * 3
     src = x[:n].reshape(1, n)
-    for bits, peak in ((10, 80), (12, 80), (12, 1000), (10, 10000)):
+    for bits, peak in ((10, 80), (12, 80), (12, 1000), (10, 10000), (12, 10000)):
         d = pkg.WriteDesc(width=n // 3, height=1, depth=32, planes=3, bit_depth=bits, transfer=pkg.TRANSFER_PQ,
                           peak_nits=peak, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_REFERENCE)
         want = harness.oracle_write(d, src)
         got = harness.gpu_write(gpu, d, src)
         st = harness.compare_write(d, want, got)
         print(f"PQ sweep bits={bits} peak={peak}: max|dcode|={st['max_abs']} exact={st['exact_frac']:.6f}")
-        assert st["max_abs"] <= 1 and st["exact_frac"] >= (0.999 if bits == 10 else 0.996), st
+        assert st["max_abs"] <= 1 and st["exact_frac"] >= 0.9995, st          # measured (round 4): 99.986-99.990 % at 10 bit, 99.953-99.970 % at 12 bit
 
 
 def test_write_rejects_and_reports(gpu):

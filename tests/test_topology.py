@@ -47,6 +47,38 @@ def test_probe_reads_node_and_cpus_from_sysfs(tmp_path):
     assert _probe(tmp_path, "0000:04:00.0") == (0, -1, "")
 
 
+def test_two_socket_eight_device_node_gets_four_worker_sets_per_socket(tmp_path):
+    """The tree of an 8-GPU OAM node (four MI355X behind each socket; bus numbers as rocm-smi shows them on such hosts): the
+    placement avifgpu_init_devices would make -- per device its socket's CPUs, AVIFGPU_LANES workers pinned there, and one helper
+    pool / pinned-allocation domain per socket: 2 domains, four worker sets in each."""
+    lib = pkg.load()
+    node0, node1 = "0-63,128-191", "64-127,192-255"
+    bdfs = ["0000:05:00.0", "0000:15:00.0", "0000:65:00.0", "0000:75:00.0", "0000:85:00.0", "0000:95:00.0", "0000:e5:00.0", "0000:f5:00.0"]
+    for i, b in enumerate(bdfs):
+        d = tmp_path / "bus" / "pci" / "devices" / b
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(f"{i // 4}\n")
+    for n, cpus in ((0, node0), (1, node1)):
+        nd = tmp_path / "devices" / "system" / "node" / f"node{n}"
+        nd.mkdir(parents=True)
+        (nd / "cpulist").write_text(cpus + "\n")
+    arr = (ctypes.c_char_p * 8)(*[b.encode() for b in bdfs])
+    out = (pkg.DeviceInfo * 8)()
+    lanes = int(os.environ.get("AVIFGPU_LANES", "2"))
+    assert lib.avifgpu_topology_plan(str(tmp_path).encode(), arr, 8, out) == 2          # two NUMA domains
+    per_node = {0: [], 1: []}
+    for i in range(8):
+        assert out[i].pci_bus_id.decode() == bdfs[i] and out[i].workers == lanes and out[i].workers_pinned == 1
+        assert out[i].cpulist.decode() == (node0 if i < 4 else node1)
+        per_node[out[i].numa_node].append(i)
+    assert per_node == {0: [0, 1, 2, 3], 1: [4, 5, 6, 7]}                               # four worker sets per socket
+    # one socket only: one domain; a device the tree does not know: error, nothing half-planned is used
+    assert lib.avifgpu_topology_plan(str(tmp_path).encode(), arr, 4, out) == 1
+    bad = (ctypes.c_char_p * 2)(bdfs[0].encode(), b"0000:aa:00.0")
+    assert lib.avifgpu_topology_plan(str(tmp_path).encode(), bad, 2, out) == pkg.readErr
+    assert lib.avifgpu_topology_plan(str(tmp_path).encode(), None, 2, out) == pkg.formatBadParameters
+
+
 def test_probe_errors(tmp_path):
     _tree(tmp_path, "0000:05:00.0", 0, node_cpus="0-3,x")
     assert _probe(tmp_path, "0000:05:00.0")[0] == pkg.readErr                         # malformed list
