@@ -1264,6 +1264,14 @@ AG_DEV __amdgpu_buffer_rsrc_t span_rsrc(const void* base, uint32_t bytes)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);   // raw buffer, 32-bit data format
 }
+// AG_EDGE_CACHED = 1 (round 4): the first and the last load of a span -- the ones that may share a 128-byte line with the
+// neighbouring span when rows do not start on line boundaries -- go through the L2 normally instead of non-temporally, so that the
+// neighbour's touch of the shared line can hit there (same workgroup = same XCD for 3 of 4 spans) instead of coming from HBM a
+// second time: 7952 x 5304 4:2:0 0.694 -> 0.73 of 8 TB/s, 8192^2 rows +0...+2 % (profiles/r04/load_policy_ab.txt; every load cached
+// and every second load cached both lose 2-4 %).  Other values: bit 4 + k set = load k cached.
+#ifndef AG_EDGE_CACHED
+#define AG_EDGE_CACHED 1
+#endif
 template <bool NT> AG_DEV f32x4 span_load16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
 {
     const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, NT ? 2 : 0);
@@ -1280,6 +1288,36 @@ template <bool NT> AG_DEV void span_store8(__amdgpu_buffer_rsrc_t r, uint32_t vo
 template <bool NT> AG_DEV void span_store4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t v)
 {
     __builtin_amdgcn_raw_buffer_store_b32((int)v, r, (int)voff, 0, NT ? 2 : 0);
+}
+// A lane's 8 (4) u16 samples -- samples [8 lane, 8 lane + 8) of the span -- into a plane row of ANY length, with no branch on the
+// lane's position: the resource ends at the span's last WHOLE dword, and the hardware's range check (per dword of a multi-dword
+// store) drops what lies beyond -- lanes past the row store nothing, the ragged lane stores the dwords it has.  A span with an odd
+// number of samples (odd image widths) ends in half a dword: the lane that holds that sample stores it as a short (wave-uniform
+// test first: rows of even length never get there).
+template <bool NT> AG_DEV void span_store_samples8(const uint8_t* base, uint32_t span_samples, uint32_t lane, u32x4 v)
+{
+    const uint32_t bytes = span_samples * 2u;
+    span_store16<NT>(span_rsrc(base, bytes & ~3u), lane * 16u, v);
+    if (bytes & 2u) {
+        const uint32_t last = span_samples - 1u;                                  // even
+        if ((last >> 3) == lane) {
+            const uint32_t i = last & 7u;
+            const uint32_t w = i == 0 ? v.x : (i == 2 ? v.y : (i == 4 ? v.z : v.w));
+            __builtin_amdgcn_raw_buffer_store_b16((short)(w & 0xffffu), span_rsrc(base, bytes), (int)(last * 2u), 0, NT ? 2 : 0);
+        }
+    }
+}
+template <bool NT> AG_DEV void span_store_samples4(const uint8_t* base, uint32_t span_samples, uint32_t lane, u32x2 v)
+{
+    const uint32_t bytes = span_samples * 2u;
+    span_store8<NT>(span_rsrc(base, bytes & ~3u), lane * 8u, v);
+    if (bytes & 2u) {
+        const uint32_t last = span_samples - 1u;
+        if ((last >> 2) == lane) {
+            const uint32_t w = (last & 3u) == 0 ? v.x : v.y;
+            __builtin_amdgcn_raw_buffer_store_b16((short)(w & 0xffffu), span_rsrc(base, bytes), (int)(last * 2u), 0, NT ? 2 : 0);
+        }
+    }
 }
 // the wave's index inside its workgroup, as a scalar (threadIdx.x >> 6 is uniform, but the compiler cannot know)
 AG_DEV int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
@@ -1379,7 +1417,7 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_ycbcr444_hot(
 
     // span indices fit 32 bits (host checks): 32-bit udiv instead of a 64-bit software divide per trip; everything about a span but
     // the lane's own offset is wave-uniform and lives in SGPRs
-    const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;      // host guarantees width % 4 == 0 and alignment
+    const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;      // any width (round 4); rows and planes 4-byte aligned (host)
     const uint32_t total = spans_per_row * (uint32_t)p.nrows;
     const uint32_t step = gridDim.x * WPB;
     const uint32_t voff = (uint32_t)lane * 16u;
@@ -1391,7 +1429,7 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_ycbcr444_hot(
         const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)r * p.src_row_bytes + (long long)sx * (SPAN_PX * 12), (uint32_t)span_px * 12u);
         f32x4 cur[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) cur[k] = span_load16<NT>(rs, voff, 1024u * k);   // a float4 beyond the row: zeros, and nothing is stored for it
+        for (int k = 0; k < K; ++k) cur[k] = (AG_EDGE_CACHED == 1 ? (k == 0 || k == K - 1) : ((AG_EDGE_CACHED >> (k + 4)) & 1)) ? span_load16<false>(rs, voff, 1024u * k) : span_load16<NT>(rs, voff, 1024u * k);   // a float4 beyond the row: zeros, and nothing is stored for it
 
         float R[PXL], G[PXL], B[PXL];
         if constexpr (AG_HOT_F32_STRIP) {
@@ -1442,37 +1480,23 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_ycbcr444_hot(
             crv[i] = clip_round(R[i] * p.mcr[0] + G[i] * p.mcr[1] + B[i] * p.mcr[2] + p.half, p.maxv);
         }
         const long long xoff = (long long)sx * (SPAN_PX * 2);
-        const uint32_t plane_bytes = (uint32_t)span_px * 2u;
-        const __amdgpu_buffer_rsrc_t r0 = span_rsrc(p.dst[0] + (long long)r * p.dst_stride[0] + xoff, plane_bytes);
-        const __amdgpu_buffer_rsrc_t r1 = span_rsrc(p.dst[1] + (long long)r * p.dst_stride[1] + xoff, plane_bytes);
-        const __amdgpu_buffer_rsrc_t r2 = span_rsrc(p.dst[2] + (long long)r * p.dst_stride[2] + xoff, plane_bytes);
-        const int nv = span_px - PXL * lane;                                       // pixels of this lane inside the row: >= PXL, 4 or <= 0
+        const uint8_t* b0 = p.dst[0] + (long long)r * p.dst_stride[0] + xoff;
+        const uint8_t* b1 = p.dst[1] + (long long)r * p.dst_stride[1] + xoff;
+        const uint8_t* b2 = p.dst[2] + (long long)r * p.dst_stride[2] + xoff;
         if constexpr (PXL == 4) {
-            if (nv >= 4) {
-                const uint32_t vo = (uint32_t)lane * 8u;
-                u32x2 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16) };
-                u32x2 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16) };
-                u32x2 c = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16) };
-                span_store8<NT>(r0, vo, a);
-                span_store8<NT>(r1, vo, b);
-                span_store8<NT>(r2, vo, c);
-            }
+            u32x2 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16) };
+            u32x2 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16) };
+            u32x2 c = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16) };
+            span_store_samples4<NT>(b0, (uint32_t)span_px, (uint32_t)lane, a);
+            span_store_samples4<NT>(b1, (uint32_t)span_px, (uint32_t)lane, b);
+            span_store_samples4<NT>(b2, (uint32_t)span_px, (uint32_t)lane, c);
         } else {
-            if (nv >= 8) {
-                u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
-                u32x4 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16), cbv[4] | (cbv[5] << 16), cbv[6] | (cbv[7] << 16) };
-                u32x4 c = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16), crv[4] | (crv[5] << 16), crv[6] | (crv[7] << 16) };
-                span_store16<NT>(r0, voff, a);
-                span_store16<NT>(r1, voff, b);
-                span_store16<NT>(r2, voff, c);
-            } else if (nv >= 4) {
-                u32x2 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16) };
-                u32x2 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16) };
-                u32x2 c = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16) };
-                span_store8<NT>(r0, voff, a);
-                span_store8<NT>(r1, voff, b);
-                span_store8<NT>(r2, voff, c);
-            }
+            u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
+            u32x4 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16), cbv[4] | (cbv[5] << 16), cbv[6] | (cbv[7] << 16) };
+            u32x4 c = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16), crv[4] | (crv[5] << 16), crv[6] | (crv[7] << 16) };
+            span_store_samples8<NT>(b0, (uint32_t)span_px, (uint32_t)lane, a);
+            span_store_samples8<NT>(b1, (uint32_t)span_px, (uint32_t)lane, b);
+            span_store_samples8<NT>(b2, (uint32_t)span_px, (uint32_t)lane, c);
         }
     }
 }
@@ -1499,8 +1523,9 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444
         __syncthreads();
     }
     const IccPowTableF powT = { pow_t };
-    const int wave = threadIdx.x >> 6;
+    const int wave = wave_in_block();
     const int lane = threadIdx.x & 63;
+    const uint32_t voff = (uint32_t)lane * 16u;
     f32x4* my = reinterpret_cast<f32x4*>(strip[wave]);
     const float m0 = p.icc_m_f[0], m1 = p.icc_m_f[1], m2 = p.icc_m_f[2], m3 = p.icc_m_f[3], m4 = p.icc_m_f[4], m5 = p.icc_m_f[5],
                 m6 = p.icc_m_f[6], m7 = p.icc_m_f[7], m8 = p.icc_m_f[8];
@@ -1510,11 +1535,10 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444
         const uint32_t r = sidx / spans_per_row;
         const uint32_t sx = sidx - r * spans_per_row;
         const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);
-        const int span_f4 = span_px * 3 / 4;
-        const f32x4* sp = reinterpret_cast<const f32x4*>(p.src + (long long)r * p.src_row_bytes) + (long long)sx * (64 * K);
+        const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)r * p.src_row_bytes + (long long)sx * (SPAN_PX * 12), (uint32_t)span_px * 12u);
         f32x4 cur[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) cur[k] = __builtin_nontemporal_load(sp + min(64 * k + lane, span_f4 - 1));
+        for (int k = 0; k < K; ++k) cur[k] = (AG_EDGE_CACHED == 1 ? (k == 0 || k == K - 1) : ((AG_EDGE_CACHED >> (k + 4)) & 1)) ? span_load16<false>(rs, voff, 1024u * k) : span_load16<true>(rs, voff, 1024u * k);
         if constexpr (ICCV == 2) {                                                 // the document's curve: per sample, the same for R, G, B
             const IccSimple q = icc_simple_load(p);
 #pragma unroll
@@ -1545,31 +1569,18 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const float R = q[3 * h], G = q[3 * h + 1], B = q[3 * h + 2];
-                yv[i + h] = luma_code_f(p, R, G, B);
+                yv[i + h] = luma_code_nc(p, R, G, B);
                 cbv[i + h] = clip_round(R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2] + p.half, p.maxv);
                 crv[i + h] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
             }
         }
-        const long long xoff = ((long long)sx * SPAN_PX + (long long)PXL * lane) * 2;
-        uint8_t* d0 = p.dst[0] + (long long)r * p.dst_stride[0] + xoff;
-        uint8_t* d1 = p.dst[1] + (long long)r * p.dst_stride[1] + xoff;
-        uint8_t* d2 = p.dst[2] + (long long)r * p.dst_stride[2] + xoff;
-        const int nv = span_px - PXL * lane;                                       // >= 8, 4 or <= 0
-        if (nv >= 8) {
-            u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
-            u32x4 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16), cbv[4] | (cbv[5] << 16), cbv[6] | (cbv[7] << 16) };
-            u32x4 cc = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16), crv[4] | (crv[5] << 16), crv[6] | (crv[7] << 16) };
-            __builtin_nontemporal_store(a, reinterpret_cast<u32x4*>(d0));
-            __builtin_nontemporal_store(b, reinterpret_cast<u32x4*>(d1));
-            __builtin_nontemporal_store(cc, reinterpret_cast<u32x4*>(d2));
-        } else if (nv >= 4) {
-            u32x2 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16) };
-            u32x2 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16) };
-            u32x2 cc = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16) };
-            __builtin_nontemporal_store(a, reinterpret_cast<u32x2*>(d0));
-            __builtin_nontemporal_store(b, reinterpret_cast<u32x2*>(d1));
-            __builtin_nontemporal_store(cc, reinterpret_cast<u32x2*>(d2));
-        }
+        const long long xoff = (long long)sx * (SPAN_PX * 2);
+        u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
+        u32x4 bb = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16), cbv[4] | (cbv[5] << 16), cbv[6] | (cbv[7] << 16) };
+        u32x4 cc = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16), crv[4] | (crv[5] << 16), crv[6] | (crv[7] << 16) };
+        span_store_samples8<true>(p.dst[0] + (long long)r * p.dst_stride[0] + xoff, (uint32_t)span_px, (uint32_t)lane, a);
+        span_store_samples8<true>(p.dst[1] + (long long)r * p.dst_stride[1] + xoff, (uint32_t)span_px, (uint32_t)lane, bb);
+        span_store_samples8<true>(p.dst[2] + (long long)r * p.dst_stride[2] + xoff, (uint32_t)span_px, (uint32_t)lane, cc);
     }
 }
 
@@ -1624,7 +1635,7 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot
             const int r = min((int)(gy * VR) + vr, p.rows_to_end - 1);  // bottom edge: replicate the last IMAGE row
             const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)r * p.src_row_bytes + (long long)sx * (SPAN_PX * 12), (uint32_t)span_px * 12u);
 #pragma unroll
-            for (int k = 0; k < K; ++k) v[vr][k] = span_load16<true>(rs, voff, 1024u * k);   // beyond the row: zeros (see the 4:4:4 kernel)
+            for (int k = 0; k < K; ++k) v[vr][k] = (AG_EDGE_CACHED == 1 ? (k == 0 || k == K - 1) : ((AG_EDGE_CACHED >> (k + 4)) & 1)) ? span_load16<false>(rs, voff, 1024u * k) : span_load16<true>(rs, voff, 1024u * k);   // beyond the row: zeros (see the 4:4:4 kernel)
         }
         const int nv = span_px - PXL * lane;                           // pixels of this lane inside the row: >= 8, 4 or <= 0 (width % 4 == 0)
         // Round 4: the levels (integer-valued floats, oetf_level2) cross the strip, a row at a time; a row's luma leaves at once and
@@ -1673,13 +1684,17 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot
                 uint32_t yv[PXL];
 #pragma unroll
                 for (int i = 0; i < PXL; ++i) yv[i] = luma_code_nc(p, c[strip_at(i, 0)], c[strip_at(i, 1)], c[strip_at(i, 2)]);   // (GBR needs 4:4:4)
-                const __amdgpu_buffer_rsrc_t ry = span_rsrc(p.dst[0] + (long long)r * p.dst_stride[0] + (long long)sx * (SPAN_PX * 2), (uint32_t)span_px * 2u);
-                if (nv >= 8) {
-                    u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
-                    span_store16<true>(ry, voff, a);
-                } else if (nv >= 4) {
-                    u32x2 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16) };
-                    span_store8<true>(ry, voff, a);
+                u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
+                span_store_samples8<true>(p.dst[0] + (long long)r * p.dst_stride[0] + (long long)sx * (SPAN_PX * 2), (uint32_t)span_px, (uint32_t)lane, a);
+            }
+            if constexpr (!NEAREST) {
+                if (span_px & 1) {                                     // (wave-uniform) odd image width: the box of the last chroma sample replicates the last column
+#pragma unroll
+                    for (int i = 1; i < PXL; i += 2)
+                        if (i == nv) {
+#pragma unroll
+                            for (int ch = 0; ch < 3; ++ch) c[strip_at(i, ch)] = c[strip_at(i - 1, ch)];
+                        }
                 }
             }
 #pragma unroll
@@ -1704,18 +1719,11 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot
             cbv[j] = clip_round(R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2] + p.half, p.maxv);
             crv[j] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
         }
-        const uint32_t cbytes = (uint32_t)((span_px + 1) / 2) * 2u, cvoff = (uint32_t)lane * 8u;
-        const __amdgpu_buffer_rsrc_t rcb = span_rsrc(p.dst[1] + (long long)gy * p.dst_stride[1] + (long long)sx * SPAN_PX, cbytes);
-        const __amdgpu_buffer_rsrc_t rcr = span_rsrc(p.dst[2] + (long long)gy * p.dst_stride[2] + (long long)sx * SPAN_PX, cbytes);
-        if (nv >= 8) {
-            u32x2 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16) };
-            u32x2 c = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16) };
-            span_store8<true>(rcb, cvoff, b);
-            span_store8<true>(rcr, cvoff, c);
-        } else if (nv >= 4) {                                          // 4 pixels = 2 chroma samples
-            span_store4<true>(rcb, cvoff, cbv[0] | (cbv[1] << 16));
-            span_store4<true>(rcr, cvoff, crv[0] | (crv[1] << 16));
-        }
+        const uint32_t csamples = (uint32_t)(span_px + 1) / 2u;
+        u32x2 cb2 = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16) };
+        u32x2 cr2 = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16) };
+        span_store_samples4<true>(p.dst[1] + (long long)gy * p.dst_stride[1] + (long long)sx * SPAN_PX, csamples, (uint32_t)lane, cb2);
+        span_store_samples4<true>(p.dst[2] + (long long)gy * p.dst_stride[2] + (long long)sx * SPAN_PX, csamples, (uint32_t)lane, cr2);
     }
 }
 
@@ -2558,9 +2566,10 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
     const bool icc4 = icc_lin && p.icc_out == 4 && p.transfer == AVIFGPU_TRANSFER_CLIP;
     const bool icc2 = AG_ICC2_HOT && p.icc_trc_type[0] != 0 && p.icc_same_simple && p.icc_out == 0;
     if ((variant & 1) && (p.icc_trc_type[0] == 0 || icc1 || icc4 || icc2) && depth == 32 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 1 &&
-        (p.width % 4) == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
+        // any width (round 4: buffer addressing clips the ragged lane in hardware); rows and planes dword-aligned
+        (p.src_row_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 3) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |
-          (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2]) & 15) == 0) {
+          (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2]) & 3) == 0) {
         const long long spans = (long long)((p.width + 511) / 512) * ((p.nrows + (1 << ys) - 1) >> ys);
         if (spans == 0) return hipSuccess;
         if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
@@ -2588,10 +2597,10 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
     }
     // ... and with a linear document profile in front (icc = 1)
     if ((variant & 1) && (icc1 || icc4 || icc2) &&
-        depth == 32 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 0 && ys == 0 && (p.width % 4) == 0 &&
-        (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
+        depth == 32 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 0 && ys == 0 &&
+        (p.src_row_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 3) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |
-          (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2]) & 15) == 0) {
+          (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2]) & 3) == 0) {
         const long long spans = (long long)((p.width + 511) / 512) * p.nrows;
         if (spans == 0) return hipSuccess;
         if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
@@ -2612,10 +2621,10 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
         }
     }
     if ((variant & 1) && p.icc_trc_type[0] == 0 && depth == 32 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 0 && ys == 0 &&
-        (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
+        (p.src_row_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 3) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |
-          (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2]) & 15) == 0) {
-        if ((p.width % 4) == 0) {                     // rows stay 16-byte aligned; the last span of a row is masked in the kernel
+          (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2]) & 3) == 0) {
+        {                                             // any width (round 4): the last span of a row is clipped by the buffer resources
             const bool px8 = variant & 2, nt = variant & 4;
             const int span_px = px8 ? 512 : 256;
             const long long spans = (long long)((p.width + span_px - 1) / span_px) * p.nrows;

@@ -150,6 +150,33 @@ def write_cases():
                                                        transfer=pkg.TRANSFER_CLIP, alpha_state=pkg.ALPHA_PREMULTIPLIED,
                                                        output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444,
                                                        matrix_coefficients=pkg.MATRIX_BT601)),
+        # ... and on ODD widths (round 4: any width stays on the streaming kernels; the ragged lane is clipped by the buffer resources,
+        # the row's last sample goes out as a short, the box filter replicates the last column)
+        ("ycc-d32-p3-b10-444-hot-odd515", dict(width=515, height=5, depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_PQ,
+                                               peak_nits=80, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR,
+                                               chroma=pkg.CHROMA_444, matrix_coefficients=pkg.MATRIX_BT2020_NCL,
+                                               color_primaries=pkg.PRIMARIES_BT2020)),
+        ("ycc-d32-p3-b12-444-hot-odd1", dict(width=1, height=3, depth=32, planes=3, bit_depth=12, transfer=pkg.TRANSFER_PQ,
+                                             peak_nits=80, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR,
+                                             chroma=pkg.CHROMA_444, matrix_coefficients=pkg.MATRIX_BT2020_NCL,
+                                             color_primaries=pkg.PRIMARIES_BT2020)),
+        ("ycc-d32-p3-b12-444-hot-odd1029-clip", dict(width=1029, height=4, depth=32, planes=3, bit_depth=12, transfer=pkg.TRANSFER_CLIP,
+                                                     alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444,
+                                                     matrix_coefficients=pkg.MATRIX_BT601)),
+        ("ycc-d32-p3-b10-420-hot-odd1003-avg", dict(width=1003, height=7, depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_PQ,
+                                                    peak_nits=1000, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR,
+                                                    chroma=pkg.CHROMA_420, matrix_coefficients=pkg.MATRIX_BT2020_NCL,
+                                                    color_primaries=pkg.PRIMARIES_BT2020)),
+        ("ycc-d32-p3-b12-422-hot-odd777-near", dict(width=777, height=3, depth=32, planes=3, bit_depth=12, transfer=pkg.TRANSFER_PQ,
+                                                    peak_nits=80, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_422,
+                                                    matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020,
+                                                    chroma_downsampling=pkg.DOWNSAMPLE_NEAREST)),
+        ("ycc-d32-p3-b10-420-hot-odd513-avg-clip", dict(width=513, height=6, depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_CLIP,
+                                                        alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420,
+                                                        matrix_coefficients=pkg.MATRIX_BT601)),
+        ("ycc-d32-p3-b10-422-hot-odd6-avg", dict(width=6, height=2, depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_CLIP,
+                                                 alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_422,
+                                                 matrix_coefficients=pkg.MATRIX_BT601)),
         # the plug-in's own default save (InitGlobals, AvifFormat.cpp:89,95: 4:2:2, 12 bit; HDR documents: PQ at 80 nits), both
         # output modes, with and without alpha, on a span-multiple width (streaming kernels) and on a ragged one; libheif 1.14's
         # chroma rule (nearest); SDR 16-bit documents carry BT.601 with BT.709 primaries (WriteMetadata.cpp:138-140)
