@@ -165,6 +165,7 @@ ABI = [
     ("avifgpu_read_algorithmic_bytes", c_int64, [POINTER(ReadDesc), c_int32]),
     ("avifgpu_last_kernel_name", c_char_p, []),
     ("avifgpu_set_hot_variant", None, [c_int32]),
+    ("avifgpu_probe_pattern_read", c_int32, [POINTER(ReadDesc), c_int32, c_int32, POINTER(_PLANES4), POINTER(_STRIDES4), c_void_p, c_int64, c_void_p]),
     ("avifgpu_probe_pattern_rgb32_444", c_int32, [c_void_p, c_int64, POINTER(c_void_p * 3), POINTER(c_int64 * 3), c_int32, c_int32, c_void_p]),
 ]
 
@@ -306,6 +307,11 @@ class AvifGpu:
             out.append({"device": info.device, "pci_bus_id": info.pci_bus_id.decode(), "numa_node": info.numa_node,
                         "cpulist": info.cpulist.decode(), "workers": info.workers, "workers_pinned": bool(info.workers_pinned)})
         return out
+
+    def probe_pattern_read(self, desc, row0, nrows, ptrs, strides, dst, dst_row_bytes, stream=None):
+        """Launch the math-free twin of the read kernel of `desc` on device buffers (avifgpu_probe_pattern_read)."""
+        self._check(self.lib.avifgpu_probe_pattern_read(ctypes.byref(desc), row0, nrows, ctypes.byref(planes4(ptrs)), ctypes.byref(strides4(strides)),
+                                                        dst, dst_row_bytes, stream))
 
     def traffic(self, reset=False):
         """[{device, tiles, bytes_h2d, bytes_d2h, bytes_bounced, copy_helper_pools}] per bound device (avifgpu_device_traffic_get)."""

@@ -894,4 +894,29 @@ int32_t avifgpu_read_rows(const avifgpu_read_desc* d, int32_t row0, int32_t nrow
     return read_rows_host(d, row0, nrows, src, src_stride, dst, dst_row_bytes);
 }
 
+/* The math-free twin of the kernel avifgpu_read_rows(MEM_DEVICE) would launch for this descriptor (read_kernels.hip, TWIN): the
+ * same loads, table copy, LDS transpose and stores, no decode; dst receives meaningless bytes.  Diagnostic hook for the measured
+ * ceiling of a read pattern (tools/bench_configs.py); available for the 4:2:x colour opens to 8-bit and f32 (PQ) hosts on 16-byte
+ * aligned buffers, AVIFGPU_formatBadParameters otherwise. */
+int32_t avifgpu_probe_pattern_read(const avifgpu_read_desc* d, int32_t row0, int32_t nrows, const void* const src[4], const int64_t src_stride[4],
+                                   void* dst, int64_t dst_row_bytes, void* stream)
+{
+    g_err[0] = 0;
+    ReadGeom g;
+    int err = check_read(d, row0, nrows, g);
+    if (err) return err;
+    if ((err = check_read_buffers(d, g, nrows, src, src_stride, dst, dst_row_bytes))) return err;
+    if (context_count() == 0) return fail(AVIFGPU_formatBadParameters, "%s", kNoDevice);
+    if (nrows == 0) return 0;
+    ReadParams p;
+    if ((err = fill_read_params(d, nrows, g, p))) return err;
+    for (int pl = 0; pl < 4; ++pl) { p.src[pl] = (const uint8_t*)src[pl]; p.src_stride[pl] = src_stride[pl]; }
+    p.dst = (uint8_t*)dst; p.dst_row_bytes = dst_row_bytes;
+    p.twin = 1;
+    const hipError_t e = launch_read(p, d->colorspace, d->depth, g.alpha, g.xs, g.ys, (hipStream_t)stream, g_kernel);
+    if (e == hipErrorInvalidValue) return fail(AVIFGPU_formatBadParameters, "pattern probe: no twin for this configuration (4:2:x colour, no alpha, 8-bit or f32 PQ host, 16-byte aligned buffers)");
+    if (e != hipSuccess) return hip_fail(e, "kernel launch", AVIFGPU_readErr);
+    return 0;
+}
+
 } // extern "C"

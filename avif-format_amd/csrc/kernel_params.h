@@ -111,6 +111,7 @@ struct ReadParams {
     float   hlg_peak;
     float   hlg_luma[3];
     const float* tables;         // device copy of this parameter set's unorm->float tables (read_tables layout), bits <= 12
+    int32_t twin;                // avifgpu_probe_pattern_read: launch the math-free twin of the kernel this set would launch
 };
 
 // Number of 2^bits-entry float tables read_px keeps in LDS (bits <= 12).  Full-range images need ONE: T_A[i] = i/max is

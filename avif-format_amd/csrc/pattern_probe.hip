@@ -1,9 +1,11 @@
 // pattern_probe.hip -- the MATH-FREE twin of write_rgb32_ycbcr444_hot: exactly its memory accesses (per lane six coalesced
-// non-temporal 16-byte loads of the interleaved f32 row, three non-temporal 16-byte u16 plane stores, 128-thread workgroups, one
-// 512-pixel span per wave) and no conversion.  bench.py launches it in the same process, on the same buffers, right after the timed
-// region: its time is what the memory system of THIS box gives THIS access pattern at that moment -- the measured ceiling
-// `roofline.peak_measured` that `roofline.frac_of_measured` is priced against (SURVEY.md 8d asks for a measured peak next to the
-// nominal 8 TB/s).  Diagnostic hook, not part of the reference mapping: the planes receive a checksum of the loaded floats.
+// 16-byte buffer loads of the interleaved f32 row -- the first and the last through the L2, the four in between non-temporal, like
+// the kernel since round 4 -- three non-temporal 16-byte u16 plane stores, 256-thread workgroups, one 512-pixel span per wave) and no
+// conversion.  bench.py launches it in the same process, on the same buffers, right after the timed region: its time is what the
+// memory system of THIS box gives THIS access pattern at that moment -- the measured ceiling `roofline.peak_measured` that
+// `roofline.frac_of_measured` is priced against (SURVEY.md 8d asks for a measured peak next to the nominal 8 TB/s).  Diagnostic
+// hook, not part of the reference mapping: the planes receive a checksum of the loaded floats.  (The read kernels have their twin
+// inside read_kernels.hip: read_px<..., TWIN = true>, avifgpu_probe_pattern_read.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -13,25 +15,33 @@ namespace avifgpu {
 
 typedef float    pp_f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t pp_u4 __attribute__((ext_vector_type(4)));
+typedef int      pp_i4 __attribute__((__vector_size__(16)));
 
-__global__ __launch_bounds__(128) void pattern_rgb32_planes444(const uint8_t* __restrict__ src, long long src_row_bytes, uint8_t* d0, uint8_t* d1,
-                                                               uint8_t* d2, long long s0, long long s1, long long s2, int width, int nrows)
+constexpr int kProbeWaves = 4;
+__global__ __launch_bounds__(64 * kProbeWaves) void pattern_rgb32_planes444(const uint8_t* __restrict__ src, long long src_row_bytes, uint8_t* d0, uint8_t* d1,
+                                                                          uint8_t* d2, long long s0, long long s1, long long s2, int width, int nrows)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t spans_per_row = (uint32_t)width / 512u, total = spans_per_row * (uint32_t)nrows;
-    for (uint32_t s = blockIdx.x * 2 + wave; s < total; s += gridDim.x * 2) {
+    const int voff = lane * 16;
+    for (uint32_t s = blockIdx.x * kProbeWaves + wave; s < total; s += gridDim.x * kProbeWaves) {
         const uint32_t r = s / spans_per_row, sx = s - r * spans_per_row;
-        const pp_f4* sp = reinterpret_cast<const pp_f4*>(src + (long long)r * src_row_bytes) + (long long)sx * 384;
-        pp_f4 v[6];
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src + (long long)r * src_row_bytes + (long long)sx * 6144), 0, 6144, 0x00020000);
+        pp_i4 v[6];
+        v[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) v[k] = __builtin_nontemporal_load(sp + 64 * k + lane);
+        for (int k = 1; k < 5; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 1024 * k, 2);
+        v[5] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 5120, 0);
         uint32_t acc = 0;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) acc ^= __float_as_uint(v[k].x) ^ __float_as_uint(v[k].y) ^ __float_as_uint(v[k].z) ^ __float_as_uint(v[k].w);
-        const long long xoff = ((long long)sx * 512 + 8LL * lane) * 2;
-        __builtin_nontemporal_store(pp_u4{ acc, acc + 1, acc + 2, acc + 3 }, reinterpret_cast<pp_u4*>(d0 + (long long)r * s0 + xoff));
-        __builtin_nontemporal_store(pp_u4{ acc, acc, acc + 2, acc }, reinterpret_cast<pp_u4*>(d1 + (long long)r * s1 + xoff));
-        __builtin_nontemporal_store(pp_u4{ acc + 1, acc, acc, 1u }, reinterpret_cast<pp_u4*>(d2 + (long long)r * s2 + xoff));
+        for (int k = 0; k < 6; ++k) acc ^= (uint32_t)v[k][0] ^ (uint32_t)v[k][1] ^ (uint32_t)v[k][2] ^ (uint32_t)v[k][3];
+        const long long xoff = (long long)sx * 1024;
+        const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(d0 + (long long)r * s0 + xoff, 0, 1024, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(d1 + (long long)r * s1 + xoff, 0, 1024, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(d2 + (long long)r * s2 + xoff, 0, 1024, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pp_i4, pp_u4{ acc, acc + 1, acc + 2, acc + 3 }), r0, voff, 0, 2);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pp_i4, pp_u4{ acc, acc, acc + 2, acc }), r1, voff, 0, 2);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pp_i4, pp_u4{ acc + 1, acc, acc, 1u }), r2, voff, 0, 2);
     }
 }
 
@@ -46,9 +56,9 @@ extern "C" int32_t avifgpu_probe_pattern_rgb32_444(const void* src, int64_t src_
     for (int i = 0; i < 3; ++i) { if (!dst[i]) return fail(AVIFGPU_formatBadParameters, "pattern probe: null plane"); bits |= reinterpret_cast<uintptr_t>(dst[i]) | (uintptr_t)dst_stride[i]; }
     if (bits & 15) return fail(AVIFGPU_formatBadParameters, "pattern probe: pointers and strides must be 16-byte aligned");
     const long long spans = (long long)(width / 512) * nrows;
-    long long blocks = (spans + 1) / 2;
-    if (blocks > 256LL * 512 * 2) blocks = 256LL * 512 * 2;                       // the hot kernel's own cap
-    hipLaunchKernelGGL(pattern_rgb32_planes444, dim3((int)blocks), dim3(128), 0, (hipStream_t)stream, static_cast<const uint8_t*>(src), (long long)src_row_bytes,
+    long long blocks = (spans + kProbeWaves - 1) / kProbeWaves;
+    if (blocks > 256LL * 512 * 4 / kProbeWaves) blocks = 256LL * 512 * 4 / kProbeWaves;   // the hot kernel's own cap
+    hipLaunchKernelGGL(pattern_rgb32_planes444, dim3((int)blocks), dim3(64 * kProbeWaves), 0, (hipStream_t)stream, static_cast<const uint8_t*>(src), (long long)src_row_bytes,
                        static_cast<uint8_t*>(dst[0]), static_cast<uint8_t*>(dst[1]), static_cast<uint8_t*>(dst[2]),
                        (long long)dst_stride[0], (long long)dst_stride[1], (long long)dst_stride[2], width, nrows);
     const hipError_t e = hipGetLastError();

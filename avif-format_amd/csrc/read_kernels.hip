@@ -275,14 +275,27 @@ AG_DEV void decode_pixel(const ReadParams& p, const Tables<LUT>& t, uint32_t u0,
 // Load N consecutive samples of a plane row starting at sample index i0 (right-edge replicated to `count`), kept PACKED
 // as they sit in memory (N * sample-size / 4 dwords): a group's planes then cost a handful of VGPRs, which is what lets
 // the next group's loads be in flight while this one is decoded (AG_READ_PREFETCH).
-template <bool SRC16, int N, bool ALIGNED>
+// Cache policy of the plane loads (round 4; profiles/r04/read_nt_vs_cached.txt, two interleaved passes on one box).  Round 1 made
+// every plane load non-temporal.  Measured again on today's kernels, loads that go through the L2 normally are FASTER wherever a
+// lane's piece of a plane is small against a 128-byte line -- u8 planes (8-bit 4:2:0 -> RGB8 0.70 -> 0.79 of 8 TB/s, + alpha 0.77 ->
+// 0.87, planar RGB 0.79 -> 0.88) and the f32 hosts' u16 planes (12-bit 4:2:2 PQ -> RGB f32 0.63 -> 0.73, HLG 0.75 -> 0.88, gray PQ
+// 0.65 -> 0.81; rows that do not start on line boundaries gain most: 7952-wide 8-bit 4:2:0 0.63 -> 0.71) -- and 1-2 % slower for u16
+// planes -> 16-bit hosts and planar RGB -> f32, which keep the non-temporal hint.  AG_READ_NT_LOADS: 2 = this policy, 1 / 0 = all / none.
+#ifndef AG_READ_NT_LOADS
+#define AG_READ_NT_LOADS 2
+#endif
+template <int CS, int DEPTH> constexpr bool read_nt_loads()
+{
+    return AG_READ_NT_LOADS == 2 ? !(DEPTH == 8 || (DEPTH == 32 && CS != 1 /* kCsRgb */)) : AG_READ_NT_LOADS != 0;
+}
+template <bool SRC16, int N, bool ALIGNED, bool NT = true>
 AG_DEV void load_plane(const uint8_t* row, int i0, int count, uint32_t (&d)[N * (SRC16 ? 2 : 1) / 4])
 {
     constexpr int SSZ = SRC16 ? 2 : 1;
     constexpr int ND = N * SSZ / 4;
     static_assert((N * SSZ) % 4 == 0, "whole dwords per lane");
     if (i0 + N <= count) {
-        load_dwords<ND, true, ALIGNED>(row + (long long)i0 * SSZ, d);   // planar, coalesced, read once: non-temporal
+        load_dwords<ND, NT, ALIGNED>(row + (long long)i0 * SSZ, d);   // planar, coalesced, read once; cache policy: read_nt_loads()
         return;
     }
 #pragma unroll
@@ -463,10 +476,15 @@ template <int CS, int DEPTH, bool ALPHA, int XS> struct ReadShape {
 #define AG_RPX_BLOCK 256
 #endif
 constexpr int kRpxWaves = AG_RPX_BLOCK / 64;
-template <int CS, int DEPTH, bool ALPHA, int XS, int YS, int TRANSFER, bool LUT, bool ALIGNED>
+// TWIN = true: the kernel's MATH-FREE twin (avifgpu_probe_pattern_read): the same work mapping, plane loads, table copy, LDS
+// transpose and stores, with the decode replaced by a few integer operations on the loaded dwords.  Its time is what this box's
+// memory system gives this access pattern -- the measured ceiling next to the nominal 8 TB/s (tools/bench_configs.py prints it
+// beside the rows that have one).  Instantiated for the 4:2:x colour opens only.
+template <int CS, int DEPTH, bool ALPHA, int XS, int YS, int TRANSFER, bool LUT, bool ALIGNED, bool TWIN = false>
 __global__ __launch_bounds__(AG_RPX_BLOCK) void read_px(const ReadParams p)
 {
     constexpr bool SRC16 = DEPTH != 8;
+    constexpr bool NTL = read_nt_loads<CS, DEPTH>();
     constexpr int NC = ReadShape<CS, DEPTH, ALPHA, XS>::NC;
     constexpr int PXT = ReadShape<CS, DEPTH, ALPHA, XS>::PXT;
     constexpr int VR = 1 << YS;
@@ -507,17 +525,17 @@ __global__ __launch_bounds__(AG_RPX_BLOCK) void read_px(const ReadParams p)
         if (gx >= gxn) return;
         const int x0 = gx * PXT;
         if constexpr (CS == kCsYcc) {                       // uvJ = y >> yChromaShift, uvI = x >> xChromaShift
-            load_plane<SRC16, NC, ALIGNED>(p.src[1] + (long long)gy * p.src_stride[1], x0 >> XS, cw, g.c1);
-            load_plane<SRC16, NC, ALIGNED>(p.src[2] + (long long)gy * p.src_stride[2], x0 >> XS, cw, g.c2);
+            load_plane<SRC16, NC, ALIGNED, NTL>(p.src[1] + (long long)gy * p.src_stride[1], x0 >> XS, cw, g.c1);
+            load_plane<SRC16, NC, ALIGNED, NTL>(p.src[2] + (long long)gy * p.src_stride[2], x0 >> XS, cw, g.c2);
         }
 #pragma unroll
         for (int vr = 0; vr < VR; ++vr) {
             const int r = min(gy * VR + vr, p.nrows - 1);   // an odd last row: the duplicate load is never stored
-            load_plane<SRC16, PXT, ALIGNED>(p.src[0] + (long long)r * p.src_stride[0], x0, p.width, g.y[vr]);
-            if constexpr (ALPHA) load_plane<SRC16, PXT, ALIGNED>(p.src[3] + (long long)r * p.src_stride[3], x0, p.width, g.a[vr]);
+            load_plane<SRC16, PXT, ALIGNED, NTL>(p.src[0] + (long long)r * p.src_stride[0], x0, p.width, g.y[vr]);
+            if constexpr (ALPHA) load_plane<SRC16, PXT, ALIGNED, NTL>(p.src[3] + (long long)r * p.src_stride[3], x0, p.width, g.a[vr]);
             if constexpr (CS == kCsRgb) {
-                load_plane<SRC16, PXT, ALIGNED>(p.src[1] + (long long)r * p.src_stride[1], x0, p.width, g.g1[vr]);
-                load_plane<SRC16, PXT, ALIGNED>(p.src[2] + (long long)r * p.src_stride[2], x0, p.width, g.g2[vr]);
+                load_plane<SRC16, PXT, ALIGNED, NTL>(p.src[1] + (long long)r * p.src_stride[1], x0, p.width, g.g1[vr]);
+                load_plane<SRC16, PXT, ALIGNED, NTL>(p.src[2] + (long long)r * p.src_stride[2], x0, p.width, g.g2[vr]);
             }
         }
     };
@@ -557,7 +575,12 @@ __global__ __launch_bounds__(AG_RPX_BLOCK) void read_px(const ReadParams p)
         if constexpr (PACKED8) {
             // chroma-major: the terms of one chroma sample live only while the 1 / 2 / 4 pixels under it are decoded
             uint32_t pk[VR][ND_OUT];
-            if (active) {
+            if constexpr (TWIN) {
+#pragma unroll
+                for (int vr = 0; vr < VR; ++vr)
+#pragma unroll
+                    for (int j = 0; j < ND_OUT; ++j) pk[vr][j] = cur.y[vr][j % NDY] + cur.c1[j % NDC] + (cur.c2[j % NDC] << 1);
+            } else if (active) {
                 if constexpr (!ALPHA) {
 #pragma unroll
                     for (int vr = 0; vr < VR; ++vr)
@@ -627,7 +650,12 @@ __global__ __launch_bounds__(AG_RPX_BLOCK) void read_px(const ReadParams p)
                 g1row[d] = CS == kCsRgb ? (vr == 0 ? cur.g1[0][d] : cur.g1[CS == kCsRgb ? VR - 1 : 0][d]) : 0u;
                 g2row[d] = CS == kCsRgb ? (vr == 0 ? cur.g2[0][d] : cur.g2[CS == kCsRgb ? VR - 1 : 0][d]) : 0u;
             }
-            if (active) {
+            if constexpr (TWIN) {
+#pragma unroll
+                for (int i = 0; i < PXT; ++i)
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) o[i * NCH + k] = sample_of<SRC16>(yrow, i) + (CS == kCsYcc ? sample_of<SRC16>(k == 1 ? cur.c1 : cur.c2, i >> XS) : 0u) + k;
+            } else if (active) {
 #pragma unroll
                 for (int i = 0; i < PXT; ++i) {
                     const uint32_t yv = sample_of<SRC16>(yrow, i);
@@ -794,6 +822,16 @@ static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, char* lab
         if (e != hipSuccess) return e;
     }
 #define AG_READ_LAUNCH(LUT_, AL_) hipLaunchKernelGGL((read_px<CS, DEPTH, ALPHA, XS, YS, TRANSFER, LUT_, AL_>), dim3((int)blocks), dim3(AG_RPX_BLOCK), LUT_ ? lds : lds - lut_bytes, st, q)
+    if (p.twin) {                                            // avifgpu_probe_pattern_read: the math-free twin of the launch below
+        if constexpr (CS == kCsYcc && !ALPHA && XS == 1 && (DEPTH == 8 || (DEPTH == 32 && TRANSFER == AVIFGPU_TRANSFER_PQ))) {
+            if (!aligned || arith || !(DEPTH == 8 || p.bits <= 12)) return hipErrorInvalidValue;
+            snprintf(label + strlen(label), kLabelBytes - strlen(label), " TWIN");
+            hipLaunchKernelGGL((read_px<CS, DEPTH, ALPHA, XS, YS, TRANSFER, true, true, true>), dim3((int)blocks), dim3(AG_RPX_BLOCK), lds, st, q);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     // table-free decode (read_arith_policy): full range only -- limited range keeps its tables (an integer division per entry)
     if (arith) snprintf(label + strlen(label), kLabelBytes - strlen(label), " tables=none");
     if constexpr (DEPTH == 8) {

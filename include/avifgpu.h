@@ -453,6 +453,11 @@ void avifgpu_set_hot_variant(int32_t variant);
  * 16-byte aligned pointers and strides; the planes receive a checksum, not pixels. */
 int32_t avifgpu_probe_pattern_rgb32_444(const void* src, int64_t src_row_bytes, void* const dst[3], const int64_t dst_stride[3],
                                         int32_t width, int32_t nrows, void* stream);
+/* ... and of the READ kernels: the math-free twin of what avifgpu_read_rows(AVIFGPU_MEM_DEVICE) would launch for `desc` (same loads,
+ * table copy, LDS transpose and stores; dst receives meaningless bytes).  4:2:x colour opens to 8-bit and f32 (PQ) hosts on 16-byte
+ * aligned device buffers; AVIFGPU_formatBadParameters for anything else. */
+int32_t avifgpu_probe_pattern_read(const avifgpu_read_desc* desc, int32_t row0, int32_t nrows, const void* const src[4], const int64_t src_stride[4],
+                                   void* dst, int64_t dst_row_bytes, void* stream);
 
 /* Name + last launch geometry of the kernel the previous *_rows call dispatched (for bench/profiles). */
 const char* avifgpu_last_kernel_name(void);

@@ -120,10 +120,23 @@ def bench_read(name, **kw):
                                stream=stream.cuda_stream)
     ab = gpu.read_algorithmic_bytes(d, d.height)
     mean, p50 = time_launch(fn, warm=warm_launches(ab))
-    print(json.dumps({"config": name, "kernel": gpu.last_kernel(), "ms_mean": round(mean, 4), "ms_p50": round(p50, 4),
-                      "Mpx_s": round(d.width * d.height / mean / 1e3, 0), "GB_s": round(ab / mean / 1e6, 1),
-                      "frac_of_8TBs": round(ab / mean / 1e6 / 8000, 3), "bytes_per_px": ab / (d.width * d.height),
-                      "launches": LAST["launches"]}), flush=True)
+    row = {"config": name, "kernel": gpu.last_kernel(), "ms_mean": round(mean, 4), "ms_p50": round(p50, 4),
+           "Mpx_s": round(d.width * d.height / mean / 1e3, 0), "GB_s": round(ab / mean / 1e6, 1),
+           "frac_of_8TBs": round(ab / mean / 1e6 / 8000, 3), "bytes_per_px": ab / (d.width * d.height),
+           "launches": LAST["launches"]}
+    # the measured ceiling of this row's access pattern: the kernel's math-free twin (read_px<..., TWIN>) on the same buffers, where one
+    # exists (BENCH_TWIN=0 skips it: the profiling passes cut the dispatch stream by 'launches' and must see the same stream every pass)
+    if os.environ.get("BENCH_TWIN", "1") != "0":
+        twin = lambda: gpu.probe_pattern_read(d, 0, d.height, ptrs, strides, out.data_ptr(), out.stride(0), stream=stream.cuda_stream)
+        try:
+            twin()
+            tmean, _ = time_launch(twin, warm=200)
+            row.update({"twin_kernel": gpu.last_kernel()[-60:], "twin_ms_mean": round(tmean, 4), "twin_frac_of_8TBs": round(ab / tmean / 1e6 / 8000, 3),
+                        "frac_of_twin": round(tmean / mean, 3)})
+            fn()
+        except pkg.AvifGpuError:
+            pass
+    print(json.dumps(row), flush=True)
 
 
 ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]      # optional substrings: run matching configurations only
