@@ -127,6 +127,30 @@ AG_DEV void eotf_rgb(const ReadParams& p, float (&c)[3])
     }
 }
 
+// PQToLinear over a lane's row of N pixels with NCH interleaved channels (the alpha slot, if any, is left alone): sample pairs through
+// the packed form.  The pairs run across pixel boundaries (R0 G0 | B0 R1 | G1 B1 ...): every colour sample is independent.
+template <int N, int NCH>
+AG_DEV void eotf_row_pq(const ReadParams& p, uint32_t (&o)[N * NCH])
+{
+    static_assert(N % 2 == 0, "pixel pairs");
+    if constexpr (NCH == 3) {
+#pragma unroll
+        for (int e = 0; e < N * 3; e += 2) {
+            const f32x2 r = fast_pq_to_linear_l2_x2(f32x2{ __uint_as_float(o[e]), __uint_as_float(o[e + 1]) }, p.pq_log2_mult);
+            o[e] = __float_as_uint(r.x); o[e + 1] = __float_as_uint(r.y);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; i += 2) {                     // R0 G0 | B0 B1 | R1 G1
+            const f32x2 a = fast_pq_to_linear_l2_x2(f32x2{ __uint_as_float(o[4 * i]), __uint_as_float(o[4 * i + 1]) }, p.pq_log2_mult);
+            const f32x2 b = fast_pq_to_linear_l2_x2(f32x2{ __uint_as_float(o[4 * i + 2]), __uint_as_float(o[4 * i + 6]) }, p.pq_log2_mult);
+            const f32x2 c = fast_pq_to_linear_l2_x2(f32x2{ __uint_as_float(o[4 * i + 4]), __uint_as_float(o[4 * i + 5]) }, p.pq_log2_mult);
+            o[4 * i] = __float_as_uint(a.x); o[4 * i + 1] = __float_as_uint(a.y); o[4 * i + 2] = __float_as_uint(b.x);
+            o[4 * i + 6] = __float_as_uint(b.y); o[4 * i + 4] = __float_as_uint(c.x); o[4 * i + 5] = __float_as_uint(c.y);
+        }
+    }
+}
+
 enum { kCsYcc = 0, kCsRgb = 1, kCsMono = 2 };
 
 // x / kg of the G equation (YuvDecode.cpp:314).  Fast form: exact for the verified divisors (see avifgpu_api.hip).
@@ -175,7 +199,9 @@ AG_DEV ChromaTerms chroma_terms(const ReadParams& p, const Tables<LUT>& t, uint3
 
 // One pixel.  u[] = raw samples (Y,Cb,Cr | R,G,B | Y), ua = alpha sample.  out[] = NCH host samples
 // (u8/u16 values or f32 bit patterns).
-template <int CS, int DEPTH, bool ALPHA, int TRANSFER, bool LUT>
+// PRE (YCbCr -> f32 hosts): stop in front of the EOTF -- out[] receives the clamped (and un-premultiplied) R, G, B, and the caller
+// runs the curve over the whole row, two samples per packed instruction (eotf_row_pq).
+template <int CS, int DEPTH, bool ALPHA, int TRANSFER, bool LUT, bool PRE = false>
 AG_DEV void decode_pixel(const ReadParams& p, const Tables<LUT>& t, uint32_t u0, uint32_t u1, uint32_t u2, uint32_t ua,
                          uint32_t* out, const ChromaTerms& ct = ChromaTerms{})
 {
@@ -259,7 +285,7 @@ AG_DEV void decode_pixel(const ReadParams& p, const Tables<LUT>& t, uint32_t u0,
             }
             if constexpr (DEPTH == 32) {
                 float c[3] = { R, G, B };
-                eotf_rgb<TRANSFER>(p, c);
+                if constexpr (!PRE) eotf_rgb<TRANSFER>(p, c);
                 out[0] = __float_as_uint(c[0]); out[1] = __float_as_uint(c[1]); out[2] = __float_as_uint(c[2]);
                 if constexpr (ALPHA) out[3] = __float_as_uint(look_a(p, t, ua));       // :692
             } else {
@@ -418,6 +444,9 @@ __global__ __launch_bounds__(256) void build_read_tables(const ReadParams p, flo
     (void)read_tables<CS, DEPTH, ALPHA, TRANSFER>(p, dst, t, true, (int)(blockIdx.x * 256 + threadIdx.x), (int)(gridDim.x * 256));
 }
 
+#ifndef AG_READ_ROW_EOTF
+#define AG_READ_ROW_EOTF 1
+#endif
 #ifndef AG_READ_PREFETCH
 #define AG_READ_PREFETCH 0
 #endif
@@ -485,6 +514,7 @@ __global__ __launch_bounds__(AG_RPX_BLOCK) void read_px(const ReadParams p)
 {
     constexpr bool SRC16 = DEPTH != 8;
     constexpr bool NTL = read_nt_loads<CS, DEPTH>();
+    constexpr bool ROW_EOTF = AG_READ_ROW_EOTF && CS == kCsYcc && DEPTH == 32 && TRANSFER == AVIFGPU_TRANSFER_PQ && !TWIN;   // PQToLinear over the row, in packed pairs
     constexpr int NC = ReadShape<CS, DEPTH, ALPHA, XS>::NC;
     constexpr int PXT = ReadShape<CS, DEPTH, ALPHA, XS>::PXT;
     constexpr int VR = 1 << YS;
@@ -661,15 +691,16 @@ __global__ __launch_bounds__(AG_RPX_BLOCK) void read_px(const ReadParams p)
                     const uint32_t yv = sample_of<SRC16>(yrow, i);
                     const uint32_t av = ALPHA ? sample_of<SRC16>(arow, i) : (uint32_t)p.maxc;
                     if constexpr (CS == kCsYcc && XS + YS > 0)
-                        decode_pixel<CS, DEPTH, ALPHA, TRANSFER, LUT>(p, t, yv, 0, 0, av, &o[i * NCH], ct[i >> XS]);
+                        decode_pixel<CS, DEPTH, ALPHA, TRANSFER, LUT, ROW_EOTF>(p, t, yv, 0, 0, av, &o[i * NCH], ct[i >> XS]);
                     else if constexpr (CS == kCsYcc)
-                        decode_pixel<CS, DEPTH, ALPHA, TRANSFER, LUT>(p, t, yv, 0, 0, av, &o[i * NCH],
+                        decode_pixel<CS, DEPTH, ALPHA, TRANSFER, LUT, ROW_EOTF>(p, t, yv, 0, 0, av, &o[i * NCH],
                                                                       chroma_terms<DEPTH, LUT>(p, t, sample_of<SRC16>(cur.c1, i), sample_of<SRC16>(cur.c2, i)));
                     else if constexpr (CS == kCsRgb)
                         decode_pixel<CS, DEPTH, ALPHA, TRANSFER, LUT>(p, t, yv, sample_of<SRC16>(g1row, i), sample_of<SRC16>(g2row, i), av, &o[i * NCH]);
                     else
                         decode_pixel<CS, DEPTH, ALPHA, TRANSFER, LUT>(p, t, yv, 0, 0, av, &o[i * NCH]);
                 }
+                if constexpr (ROW_EOTF) eotf_row_pq<PXT, NCH>(p, o);
             }
 
             if constexpr (ALIGNED && ND_OUT <= 4) {
