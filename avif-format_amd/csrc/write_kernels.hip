@@ -1740,6 +1740,57 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot
 #define AG_RGBA_STREAM_BLOCK 256
 #endif
 constexpr int kRgbaWaves = AG_RGBA_STREAM_BLOCK / 64;
+// Stage A of a lane's PXL RGBA pixels as loaded (one float4 each): [ICC curve / matrix,] alpha clamp, premultiply, transfer curve;
+// v[k] becomes { R, G, B, A } as LEVELS (integer-valued floats, oetf_level2).  WriteHeifImage.cpp:1040-1096.
+template <int TRANSFER, int ICCV, int PXL>
+AG_DEV void rgba_levels(const WriteParams& p, f32x4 (&v)[PXL])
+{
+#pragma unroll
+    for (int k = 0; k < PXL; k += 2) {                                         // two pixels = three colour-sample pairs for the packed curve
+        float t[6], al[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float col[3] = { v[k + h].x, v[k + h].y, v[k + h].z };
+            if constexpr (ICCV == 2) {                                          // the document's curve on R, G, B (alpha is copied)
+                const IccSimple q = icc_simple_load(p);
+                const f32x2 rg = icc_trc_simple2(q, f32x2{ col[0], col[1] });
+                col[0] = rg.x; col[1] = rg.y; col[2] = icc_trc_simple(q, col[2]);
+            }
+            if constexpr (ICCV != 0) {                                          // a pixel is one float4 here: no transpose needed in front
+                const float R0 = col[0], G0 = col[1], B0 = col[2];
+                col[0] = __builtin_fmaf(B0, p.icc_m_f[2], __builtin_fmaf(G0, p.icc_m_f[1], R0 * p.icc_m_f[0]));
+                col[1] = __builtin_fmaf(B0, p.icc_m_f[5], __builtin_fmaf(G0, p.icc_m_f[4], R0 * p.icc_m_f[3]));
+                col[2] = __builtin_fmaf(B0, p.icc_m_f[8], __builtin_fmaf(G0, p.icc_m_f[7], R0 * p.icc_m_f[6]));
+                if constexpr (ICCV == 4) {
+                    static_assert(AG_ICC_FASTPOW, "the RGBA kernel carries no pow table");
+                    const IccPowTableF noT = { nullptr };
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) col[c] = icc_inv4_f(noT, p.icc_out_f, col[c]);
+                }
+            }
+            const float a = cxx_clamp(v[k + h].w, 0.0f, 1.0f);                  // WriteHeifImage.cpp:1047
+            if (p.premultiply && a < 1.0f) {                                    // :1049-1066
+#pragma unroll
+                for (int c = 0; c < 3; ++c) col[c] = (a == 0.0f) ? 0.0f : cxx_clamp(col[c], 0.0f, 1.0f) * a;
+            }
+            al[h] = a;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) t[3 * h + c] = col[c];
+        }
+        float q[6];
+#pragma unroll
+        for (int e = 0; e < 6; e += 2) {                                        // levels: the codes as integer-valued floats (oetf_level2)
+            const f32x2 l = oetf_level2<TRANSFER>(p, t[e], t[e + 1]);
+            q[e] = l.x; q[e + 1] = l.y;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float a3 = __builtin_truncf(__builtin_amdgcn_fmed3f(al[h] * p.maxf, 0.0f, p.maxf));   // :1096
+            v[k + h] = f32x4{ q[3 * h], q[3 * h + 1], q[3 * h + 2], a3 };
+        }
+    }
+}
+
 template <int TRANSFER, int ICCV = 0>            // ICCV 1: the linear-profile matrix on R, G, B first (ConvertRow runs before the pixel loop and copies alpha); 4: + inverse sRGB curve
 __global__ __launch_bounds__(AG_RGBA_STREAM_BLOCK) void write_rgba32_ycbcra444_hot(const WriteParams p)
 {
@@ -1761,50 +1812,7 @@ __global__ __launch_bounds__(AG_RGBA_STREAM_BLOCK) void write_rgba32_ycbcra444_h
         f32x4 v[PXL];
 #pragma unroll
         for (int k = 0; k < PXL; ++k) v[k] = span_load16<true>(rs, voff, 1024u * k);       // a pixel beyond the row: zeros, and nothing is stored for it
-#pragma unroll
-        for (int k = 0; k < PXL; k += 2) {                                         // two pixels = three colour-sample pairs for the packed curve
-            float t[6], al[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float col[3] = { v[k + h].x, v[k + h].y, v[k + h].z };
-                if constexpr (ICCV == 2) {                                          // the document's curve on R, G, B (alpha is copied)
-                    const IccSimple q = icc_simple_load(p);
-                    const f32x2 rg = icc_trc_simple2(q, f32x2{ col[0], col[1] });
-                    col[0] = rg.x; col[1] = rg.y; col[2] = icc_trc_simple(q, col[2]);
-                }
-                if constexpr (ICCV != 0) {                                          // a pixel is one float4 here: no transpose needed in front
-                    const float R0 = col[0], G0 = col[1], B0 = col[2];
-                    col[0] = __builtin_fmaf(B0, p.icc_m_f[2], __builtin_fmaf(G0, p.icc_m_f[1], R0 * p.icc_m_f[0]));
-                    col[1] = __builtin_fmaf(B0, p.icc_m_f[5], __builtin_fmaf(G0, p.icc_m_f[4], R0 * p.icc_m_f[3]));
-                    col[2] = __builtin_fmaf(B0, p.icc_m_f[8], __builtin_fmaf(G0, p.icc_m_f[7], R0 * p.icc_m_f[6]));
-                    if constexpr (ICCV == 4) {
-                        static_assert(AG_ICC_FASTPOW, "the RGBA kernel carries no pow table");
-                        const IccPowTableF noT = { nullptr };
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) col[c] = icc_inv4_f(noT, p.icc_out_f, col[c]);
-                    }
-                }
-                const float a = cxx_clamp(v[k + h].w, 0.0f, 1.0f);                  // WriteHeifImage.cpp:1047
-                if (p.premultiply && a < 1.0f) {                                    // :1049-1066
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) col[c] = (a == 0.0f) ? 0.0f : cxx_clamp(col[c], 0.0f, 1.0f) * a;
-                }
-                al[h] = a;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) t[3 * h + c] = col[c];
-            }
-            float q[6];
-#pragma unroll
-            for (int e = 0; e < 6; e += 2) {                                        // levels: the codes as integer-valued floats (oetf_level2)
-                const f32x2 l = oetf_level2<TRANSFER>(p, t[e], t[e + 1]);
-                q[e] = l.x; q[e + 1] = l.y;
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float a3 = __builtin_truncf(__builtin_amdgcn_fmed3f(al[h] * p.maxf, 0.0f, p.maxf));   // :1096
-                v[k + h] = f32x4{ q[3 * h], q[3 * h + 1], q[3 * h + 2], a3 };
-            }
-        }
+        rgba_levels<TRANSFER, ICCV, PXL>(p, v);
         float c[4 * PXL];
         span_transpose<PXL>(my, lane, v, c);                                       // lane l now holds pixels [PXL l, PXL l + PXL)
         f32x4 px[PXL];
@@ -1839,6 +1847,96 @@ __global__ __launch_bounds__(AG_RGBA_STREAM_BLOCK) void write_rgba32_ycbcra444_h
 #pragma unroll
                 for (int i = 0; i < PXL; ++i) if (i < nv) dst[i] = (uint16_t)q[i];   // the one ragged lane of a row
             }
+        }
+    }
+}
+
+// ---- ... and 4:2:2 / 4:2:0 + alpha (round 4): what the plug-in's default save of a 32-bit document WITH transparency is (4:2:2, 12 bit,
+// AvifFormat.cpp:89,95) and what round 3 left on the generic kernel (0.68 of 8 TB/s).  Same structure, one or two rows per wave trip:
+// a lane ends with pixels [4l, 4l+4) of each row = the footprint of 2 chroma samples; luma and alpha leave row by row (8 bytes per
+// lane and plane), the chroma pair as one dword per plane.  Any width; rows and planes dword-aligned.
+template <int TRANSFER, int YS, bool NEAREST>
+__global__ __launch_bounds__(AG_RGBA_STREAM_BLOCK) void write_rgba32_ycbcra_sub_hot(const WriteParams p)
+{
+    pq_prologue<TRANSFER>();
+    constexpr int PXL = 4, SPAN_PX = 64 * PXL, VR = 1 << YS;
+    __shared__ __attribute__((aligned(16))) uint32_t strip[kRgbaWaves][SpanStrip<PXL>::kDwords];
+    const int wave = wave_in_block();
+    const int lane = threadIdx.x & 63;
+    f32x4* my = reinterpret_cast<f32x4*>(strip[wave]);
+    const uint32_t voff = (uint32_t)lane * 16u;
+    const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;
+    const uint32_t groups = ((uint32_t)p.nrows + VR - 1) >> YS;
+    const uint32_t total = spans_per_row * groups;
+    for (uint32_t sidx = blockIdx.x * kRgbaWaves + wave; sidx < total; sidx += gridDim.x * kRgbaWaves) {
+        const uint32_t gy = sidx / spans_per_row;
+        const uint32_t sx = sidx - gy * spans_per_row;
+        const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);
+        const int nv = span_px - PXL * lane;
+        f32x4 v[VR][PXL];
+#pragma unroll
+        for (int vr = 0; vr < VR; ++vr) {                              // both rows' loads in flight before any math
+            const int r = min((int)(gy * VR) + vr, p.rows_to_end - 1);  // bottom edge: replicate the last IMAGE row
+            const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)r * p.src_row_bytes + (long long)sx * (SPAN_PX * 16), (uint32_t)span_px * 16u);
+#pragma unroll
+            for (int k = 0; k < PXL; ++k) v[vr][k] = span_load16<true>(rs, voff, 1024u * k);
+        }
+        float acc[2][3];
+#pragma unroll
+        for (int vr = 0; vr < VR; ++vr) {
+            rgba_levels<TRANSFER, 0, PXL>(p, v[vr]);
+            float c[4 * PXL];
+            span_transpose<PXL>(my, lane, v[vr], c);                   // lane l: pixels [4l, 4l+4) of this row
+            const int r = (int)(gy * VR) + vr;
+            if (r < p.nrows) {                                         // (odd last row of the tile: replicated for chroma only)
+                uint32_t yv[PXL], av[PXL];
+#pragma unroll
+                for (int i = 0; i < PXL; ++i) { yv[i] = luma_code_nc(p, c[4 * i], c[4 * i + 1], c[4 * i + 2]); av[i] = (uint32_t)c[4 * i + 3]; }
+                const long long xo = (long long)sx * (SPAN_PX * 2);
+                span_store_samples4<true>(p.dst[0] + (long long)r * p.dst_stride[0] + xo, (uint32_t)span_px, (uint32_t)lane, u32x2{ yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16) });
+                span_store_samples4<true>(p.dst[3] + (long long)r * p.dst_stride[3] + xo, (uint32_t)span_px, (uint32_t)lane, u32x2{ av[0] | (av[1] << 16), av[2] | (av[3] << 16) });
+            }
+            if constexpr (!NEAREST) {
+                if (span_px & 1) {                                     // odd image width: the box of the last chroma sample replicates the last column
+#pragma unroll
+                    for (int i = 1; i < PXL; i += 2)
+                        if (i == nv) {
+#pragma unroll
+                            for (int ch = 0; ch < 3; ++ch) c[4 * i + ch] = c[4 * (i - 1) + ch];
+                        }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float left = c[4 * (2 * j) + ch];
+                    if constexpr (NEAREST) {
+                        if (vr == 0) acc[j][ch] = left;
+                    } else {
+                        const float pair = left + c[4 * (2 * j + 1) + ch];
+                        if (vr == 0) acc[j][ch] = YS ? pair : pair + pair;
+                        else acc[j][ch] += pair;
+                    }
+                }
+            }
+        }
+        uint32_t cbv[2], crv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float R = NEAREST ? acc[j][0] : acc[j][0] * 0.25f, G = NEAREST ? acc[j][1] : acc[j][1] * 0.25f, B = NEAREST ? acc[j][2] : acc[j][2] * 0.25f;
+            cbv[j] = clip_round(R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2] + p.half, p.maxv);
+            crv[j] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
+        }
+        // the lane's two chroma samples: one dword per plane; the resource ends at the span's last whole dword, an odd last sample goes out as a short
+        const uint32_t cs = (uint32_t)(span_px + 1) / 2u, cbytes = cs * 2u;
+        const uint8_t* bcb = p.dst[1] + (long long)gy * p.dst_stride[1] + (long long)sx * SPAN_PX;
+        const uint8_t* bcr = p.dst[2] + (long long)gy * p.dst_stride[2] + (long long)sx * SPAN_PX;
+        span_store4<true>(span_rsrc(bcb, cbytes & ~3u), (uint32_t)lane * 4u, cbv[0] | (cbv[1] << 16));
+        span_store4<true>(span_rsrc(bcr, cbytes & ~3u), (uint32_t)lane * 4u, crv[0] | (crv[1] << 16));
+        if ((cbytes & 2u) && ((cs - 1u) >> 1) == (uint32_t)lane) {
+            __builtin_amdgcn_raw_buffer_store_b16((short)cbv[0], span_rsrc(bcb, cbytes), (int)((cs - 1u) * 2u), 0, 2);
+            __builtin_amdgcn_raw_buffer_store_b16((short)crv[0], span_rsrc(bcr, cbytes), (int)((cs - 1u) * 2u), 0, 2);
         }
     }
 }
@@ -2526,6 +2624,33 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
             snprintf(label, kLabelBytes, "write_rgb16_ycbcr_sub_hot<ys=%d>", ys);
             if (ys) hipLaunchKernelGGL((write_rgb16_ycbcr_sub_hot<1>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p);
             else hipLaunchKernelGGL((write_rgb16_ycbcr_sub_hot<0>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p);
+            return hipGetLastError();
+        }
+    }
+// RGBA f32 -> Y, Cb, Cr (4:2:2 / 4:2:0), A: the plug-in's default save of a transparent 32-bit document (no ICC variant: those stay generic)
+    if ((variant & 1) && p.icc_trc_type[0] == 0 && p.icc_s_tab == nullptr && depth == 32 && planes == 4 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 1 &&
+        (p.src_row_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 3) == 0 && p.dst[3] != nullptr &&
+        ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |
+          reinterpret_cast<uintptr_t>(p.dst[3]) | (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2] |
+          (uintptr_t)p.dst_stride[3]) & 3) == 0) {
+        const long long spans = (long long)((p.width + 255) / 256) * ((p.nrows + (1 << ys) - 1) >> ys);
+        if (spans == 0) return hipSuccess;
+        if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
+            long long blocks = (spans + kRgbaWaves - 1) / kRgbaWaves;
+            if (blocks > AG_RGBA_BLOCK_CAP * 4 / kRgbaWaves) blocks = AG_RGBA_BLOCK_CAP * 4 / kRgbaWaves;
+            snprintf(label, kLabelBytes, "write_rgba32_ycbcra_sub_hot<transfer=%d,xs=1,ys=%d,nearest=%d>", p.transfer, ys, p.nearest);
+#define AG_RSUB3(TR, YS_, NR_) hipLaunchKernelGGL((write_rgba32_ycbcra_sub_hot<TR, YS_, NR_>), dim3((int)blocks), dim3(AG_RGBA_STREAM_BLOCK), 0, st, p)
+#define AG_RSUB2(TR, YS_) do { if (p.nearest) AG_RSUB3(TR, YS_, true); else AG_RSUB3(TR, YS_, false); } while (0)
+#define AG_RSUB(TR) do { if (ys) AG_RSUB2(TR, 1); else AG_RSUB2(TR, 0); } while (0)
+            switch (p.transfer) {
+            case AVIFGPU_TRANSFER_PQ:       if (pq_hi_launch(p)) AG_RSUB(kTransferPqHi); else AG_RSUB(AVIFGPU_TRANSFER_PQ); break;
+            case AVIFGPU_TRANSFER_HLG:      AG_RSUB(AVIFGPU_TRANSFER_HLG); break;
+            case AVIFGPU_TRANSFER_SMPTE428: AG_RSUB(AVIFGPU_TRANSFER_SMPTE428); break;
+            default:                        AG_RSUB(AVIFGPU_TRANSFER_CLIP); break;
+            }
+#undef AG_RSUB
+#undef AG_RSUB2
+#undef AG_RSUB3
             return hipGetLastError();
         }
     }

@@ -47,7 +47,7 @@ def main(prof_dir, configs_jsonl, out_json):
     kt.sort(key=lambda r: int(r["Start_Timestamp"]))
     dur = [(r["Kernel_Name"], int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in kt]
     per_counter = {}
-    for name in ("FETCH_SIZE", "WRITE_SIZE"):
+    for name in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU"):
         rs = [r for r in rows(prof_dir + "/%s/**/*counter_collection.csv" % name.lower()) if PAT.search(r["Kernel_Name"]) and r["Counter_Name"] == name]
         rs.sort(key=lambda r: int(r["Dispatch_Id"]))
         per_counter[name] = [float(r["Counter_Value"]) for r in rs]
@@ -66,11 +66,22 @@ def main(prof_dir, configs_jsonl, out_json):
             write = 1024.0 * sum(wch[i][-60:]) / 60
             e["hbm_read_bytes"], e["hbm_write_bytes"] = round(fetch), round(write)
             e["traffic_over_algorithmic"] = round((fetch + write) / e["algorithmic_bytes"], 4)
+        # Vector-ALU issue (round 4).  SQ_ACTIVE_INST_VALU counts the quad-cycles the SIMDs spent issuing vector instructions (it
+        # equals SQ_INSTS_VALU + one more per transcendental on these kernels); a kernel that kept all 1024 SIMDs issuing every cycle
+        # for its whole duration at 2.4 GHz would show valu_issue_frac = 1.  The streaming kernels saturate at ~0.74-0.82 of that.
+        for name, key in (("SQ_INSTS_VALU", "valu_insts"), ("SQ_ACTIVE_INST_VALU", "valu_active_quads")):
+            ch = chunks(per_counter.get(name, []), counts)
+            if i < len(ch) and ch[i]:
+                e[key] = round(sum(ch[i][-60:]) / len(ch[i][-60:]))
+        if "valu_active_quads" in e and "kernel_trace_avg_us" in e:
+            e["valu_issue_frac"] = round(e["valu_active_quads"] * 4.0 / (1024 * 2.4e9 * e["kernel_trace_avg_us"] * 1e-6), 3)
+            px = c["Mpx_s"] * c["ms_mean"] * 1e3
+            e["valu_insts_per_px"] = round(e.get("valu_insts", 0) * 64.0 / px, 1) if px else None
         table.append(e)
     json.dump(table, open(out_json, "w"), indent=1)
     for e in table:
-        print("%-78s kt %8s us  ev %8s us  traffic x%s" % (e["config"][:78], e.get("kernel_trace_avg_us"), e.get("hip_event_avg_us"),
-                                                               e.get("traffic_over_algorithmic")))
+        print("%-78s kt %8s us  ev %8s us  traffic x%s  valu %s" % (e["config"][:78], e.get("kernel_trace_avg_us"), e.get("hip_event_avg_us"),
+                                                                       e.get("traffic_over_algorithmic"), e.get("valu_issue_frac")))
 
 
 if __name__ == "__main__":
