@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AVIFGPU_ABI_VERSION 3
+#define AVIFGPU_ABI_VERSION 4
 
 /* ---- OSErr codes used by the hot path (Photoshop SDK values) ------------------------------- */
 #define AVIFGPU_noErr                0
@@ -154,12 +154,13 @@ enum {
 };
 
 /* How LinearToPQ (ColorTransfer.cpp:69-92) is evaluated -- tier 2 either way (|delta code| <= 1 against the reference's powf): what
- * differs is the share of codes that are EXACTLY the reference's, and the cost (1 M-sample sweep at 80 nits):
- *   COMPACT  5 transcendentals + 12 full-rate operations per sample:   99.93 % exact at 10 bit, 99.74 % at 12 bit
- *   CLOSE    + 8 issue slots (exact m1 * exponent, split 2^n * 2^f):   99.97 % exact at 10 bit, 99.93 % at 12 bit
- * AUTO = COMPACT for 10-bit output (the HBM-bound RGB kernel has no issue slots to spare: 0.78 -> 0.70 of 8 TB/s with CLOSE) and
- * CLOSE for 12-bit output (a code is 4x finer there; the RGBA kernel of BASELINE C5 goes 0.83 -> 0.75 on the fastest box seen, nothing
- * on the others).  A caller that wants the throughput at 12 bit or the exact-match rate at 10 bit says so here. */
+ * differs is the share of codes that are EXACTLY the reference's, and the cost (900 k-sample sweep at 80 nits):
+ *   COMPACT  5 transcendentals + 6 packed operations per sample:                         99.94 % exact at 10 bit, 99.77 % at 12 bit
+ *   CLOSE    + 3 plain, + 1/2 packed issue slots: the exponent's share of t^m1 from LDS
+ *            tables indexed by the exponent field (exact m1 * E, round-to-nearest split): 99.99 % exact at 10 bit, 99.96 % at 12 bit
+ * AUTO = CLOSE at every depth and in every kernel since ABI 4 (round 3's AUTO took its much costlier CLOSE for 12-bit output only).
+ * Meaningful for PQ saves of 32-bit documents; ignored (not even range-checked) everywhere else.  Sampled-curve ICC documents take it
+ * too.  COMPACT is there for callers who want the earlier arithmetic (byte-exact goldens of an older build). */
 enum {
     AVIFGPU_PQ_AUTO    = 0,
     AVIFGPU_PQ_COMPACT = 1,
