@@ -127,29 +127,34 @@ AG_DEV float fast_linear_to_pq(float value, float mult)
 // m1 E is EXACT in float (m1 = 2610 / 2^14 has 12 significant bits, |E| < 2^8), so are N and F; the one rounded number the exponent
 // sees is below 0.66 in magnitude and v_log_f32 gets an argument in [0.5, 1).  Round 3 formed E, m, N and F with v_frexp_*, v_floor,
 // v_cvt and v_ldexp: +8 issue slots per sample, which the 10-bit RGB kernels could not pay (0.777 -> 0.70 of 8 TB/s).  Round 4:
-//   * F, c2 2^N and c3 2^N come from three 512-entry float tables in LDS indexed by the SIGN + EXPONENT FIELD of t (v_lshrrev +
-//     v_and + three ds_read_b32; separate tables rather than one of records so that the values of two samples can sit in adjacent
-//     registers, the operand form of the packed instructions); the entries of zero / denormal t, of negative t (sign bit set) and
-//     of inf / NaN have N = -100 -- q = c1, code 0, what the reference stores for a negative sample and what this library stores
-//     for NaN -- so no clamp, no special case and no NaN ever reaches the quotient;
+//   * F and 2^N come from two 512-entry float tables in LDS indexed by the SIGN + EXPONENT FIELD of t (v_lshrrev + v_and + two
+//     ds_read_b32; two tables rather than one of records so that the values of two samples can sit in adjacent registers, the
+//     operand form of the packed instructions); the entries of zero / denormal t, of negative t (sign bit set) and of inf / NaN
+//     have N = -100 -- q = c1, code 0, what the reference stores for a negative sample and what this library stores for NaN
+//      -- so no clamp, no special case and no NaN ever reaches the quotient;
 //   * m is the mantissa field under the exponent of 0.5 (one v_and_or_b32);
-//   * 2^N never costs an instruction: it rides on c2 and c3 (exact scalings, see the table below);
+//   * x = 2^(m1 log2 m + F) * 2^N is an exact scaling (a power of two moves no mantissa bit; nothing is near the ends of the
+//     exponent range), one packed multiply for two samples;
 //   * N = rint(m1 E) instead of floor: the exponent that the FMA rounds is half as large.
-// +3 plain and +1/2 packed issue slots per sample over the compact form, and CLOSER: codes that differ from the reference's on the
+// +3 plain and +1 packed issue slots per sample over the compact form, and CLOSER: codes that differ from the reference's on the
 // 900 k-sample sweep, 12 bit / 80 nits: 0.234 % (compact) -> 0.068 % (round 3) -> 0.041 %; at 10 bit 0.063 % -> 0.016 % -> 0.012 %.
 constexpr int kPqTabEntries = 512;
 // The tables' contents are exact integer arithmetic on the exponent field (m1 E = 2610 E / 2^14), evaluated at COMPILE time into a
-// 6 KiB constant of the code object; a workgroup copies it into its LDS with 16-byte loads and stores (computing it in the prologue
+// 4 KiB constant of the code object; a workgroup copies it into its LDS with 16-byte loads and stores (computing it in the prologue
 // cost ~80 VALU instructions per workgroup -- 13 % of the RGB f32 kernel, whose waves convert one span each).
-// (the pads keep the tables at offsets that ds_read2st64_b32 cannot express: merged into one two-dword read, F and a multiplier of one
-// sample land in adjacent registers and the packed instructions need moves)
-// Round 4, second cut: the tables carry c2 * 2^N and c3 * 2^N instead of 2^N -- both exact scalings -- so that
-//     N(x) = c1 + c2 x = c1 + (c2 2^N) y,   D(x) = 1 + c3 x = 1 + (c3 2^N) y,   y = 2^(m1 log2 m + F)
-// are formed without x itself: RN(c2 * (y 2^N)) == RN((c2 2^N) * y) bit for bit (a power of two moves no mantissa bit; nothing is
-// near the ends of the exponent range), and the multiply by 2^N is gone from the sample's instruction count.
+// (the pads keep the tables at offsets that ds_read2st64_b32 cannot express: merged into one two-dword read, F and the multiplier
+// of one sample land in adjacent registers and the packed instructions need moves)
+// AG_PQ_TAB_FORM (profiles/r04/pq_table_forms_ab.txt: the three are within a percent of each other on every row; 2 is the default --
+// fewest LDS instructions among the packed ones, 4 KiB): 3 = tables F, c2 2^N, c3 2^N (three ds_read_b32 per sample, N(x) and D(x)
+// formed without x: c2 x == (c2 2^N) y bit for bit); 2 = tables F, 2^N (two reads, x = y 2^N as a packed multiply); 1 = one table
+// of {F, 2^N} records (one ds_read_b64, but the values of two samples are not adjacent: the exponent FMA and the multiply are not packed).
+#ifndef AG_PQ_TAB_FORM
+#define AG_PQ_TAB_FORM 2
+#endif
 constexpr int kPqTabPad = 4;
-struct PqExpTable { float f[kPqTabEntries]; float pad[kPqTabPad]; float c2p[kPqTabEntries]; float pad2[kPqTabPad]; float c3p[kPqTabEntries]; float pad3[kPqTabPad]; };
-constexpr int kPqTabFloats = 3 * (kPqTabEntries + kPqTabPad);
+constexpr int kPqTabCount = AG_PQ_TAB_FORM == 3 ? 3 : 2;
+struct PqExpTable { float t[kPqTabCount][kPqTabEntries + kPqTabPad]; };
+constexpr int kPqTabFloats = kPqTabCount * (kPqTabEntries + kPqTabPad);
 constexpr float pq_pow2(int n) { float v = 1.0f; for (int i = 0; i < (n < 0 ? -n : n); ++i) v = n < 0 ? v * 0.5f : v * 2.0f; return v; }
 constexpr PqExpTable make_pq_exp_table()
 {
@@ -165,9 +170,9 @@ constexpr PqExpTable make_pq_exp_table()
             F = (float)(num - n * 16384) / 16384.0f;                      // exact: |num - n 2^14| <= 2^13
             N = (int)n;                                                   // |N| <= 21
         }
-        t.f[i] = F;
-        t.c2p[i] = kPqC2 * pq_pow2(N);                                    // exact
-        t.c3p[i] = kPqC3 * pq_pow2(N);
+        if (AG_PQ_TAB_FORM == 3) { t.t[0][i] = F; t.t[1][i] = kPqC2 * pq_pow2(N); t.t[kPqTabCount - 1][i] = kPqC3 * pq_pow2(N); }   // exact scalings
+        else if (AG_PQ_TAB_FORM == 2) { t.t[0][i] = F; t.t[1][i] = pq_pow2(N); }
+        else { constexpr int W = kPqTabEntries + kPqTabPad; t.t[(2 * i) / W][(2 * i) % W] = F; t.t[(2 * i + 1) / W][(2 * i + 1) % W] = pq_pow2(N); }   // records
     }
     return t;
 }
@@ -187,9 +192,10 @@ AG_DEV void pq_exp_table_fill(int tid, int nthreads)
     const f4* src = reinterpret_cast<const f4*>(&kPqExpTableConst);
     for (int i = tid; i < kPqTabFloats / 4; i += nthreads) dst[i] = src[i];
 }
-AG_DEV uint32_t pq_tab_offset(float t) { return (__float_as_uint(t) >> 21) & 0x7fcu; }               // byte offset of t's entry in each table
+AG_DEV uint32_t pq_tab_offset(float t) { return (__float_as_uint(t) >> (AG_PQ_TAB_FORM == 1 ? 20 : 21)) & (AG_PQ_TAB_FORM == 1 ? 0xff8u : 0x7fcu); }   // byte offset of t's entry
 AG_DEV float pq_tab_at(const float* tab, int which, uint32_t off)
 {
+    if (AG_PQ_TAB_FORM == 1) return *reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(tab + which) + off);
     return *reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(tab + which * (kPqTabEntries + kPqTabPad)) + off);
 }
 AG_DEV float pq_mantissa(float t) { return __uint_as_float((__float_as_uint(t) & 0x007fffffu) | 0x3f000000u); }
@@ -200,8 +206,9 @@ AG_DEV float fast_linear_to_pq01_hi(float value, float mult)
     const float t = value * mult;
     const uint32_t off = pq_tab_offset(t);
     const float y = nat_exp2(__builtin_fmaf(kPqM1, nat_log2(pq_mantissa(t)), pq_tab_at(tab, 0, off)));
-    const float n = kPqC1 + pq_tab_at(tab, 1, off) * y;
-    const float d = 1.0f + pq_tab_at(tab, 2, off) * y;
+    float n, d;
+    if (AG_PQ_TAB_FORM == 3) { n = kPqC1 + pq_tab_at(tab, 1, off) * y; d = 1.0f + pq_tab_at(tab, 2, off) * y; }
+    else { const float x = y * pq_tab_at(tab, 1, off); n = kPqC1 + kPqC2 * x; d = 1.0f + kPqC3 * x; }
     return nat_exp2_sat(kPqM2 * nat_log2(near_ieee_div(n, d)));
 }
 AG_DEV f32x2 fast_linear_to_pq01_2_hi(f32x2 value, float mult)
@@ -210,13 +217,20 @@ AG_DEV f32x2 fast_linear_to_pq01_2_hi(f32x2 value, float mult)
     const f32x2 t = value * mult;
     const uint32_t o0 = pq_tab_offset(t.x), o1 = pq_tab_offset(t.y);
     const f32x2 F = { pq_tab_at(tab, 0, o0), pq_tab_at(tab, 0, o1) };
-    const f32x2 C2 = { pq_tab_at(tab, 1, o0), pq_tab_at(tab, 1, o1) };
-    const f32x2 C3 = { pq_tab_at(tab, 2, o0), pq_tab_at(tab, 2, o1) };
     const f32x2 l = { nat_log2(pq_mantissa(t.x)), nat_log2(pq_mantissa(t.y)) };
     const f32x2 e1 = __builtin_elementwise_fma((f32x2)kPqM1, l, F);
     const f32x2 y = { nat_exp2(e1.x), nat_exp2(e1.y) };
-    const f32x2 n = kPqC1 + C2 * y;
-    const f32x2 d = 1.0f + C3 * y;
+    f32x2 n, d;
+    if (AG_PQ_TAB_FORM == 3) {
+        const f32x2 C2 = { pq_tab_at(tab, 1, o0), pq_tab_at(tab, 1, o1) };
+        const f32x2 C3 = { pq_tab_at(tab, 2, o0), pq_tab_at(tab, 2, o1) };
+        n = kPqC1 + C2 * y;
+        d = 1.0f + C3 * y;
+    } else {
+        const f32x2 x = y * f32x2{ pq_tab_at(tab, 1, o0), pq_tab_at(tab, 1, o1) };
+        n = kPqC1 + kPqC2 * x;
+        d = 1.0f + kPqC3 * x;
+    }
     const f32x2 r = { nat_rcp(d.x), nat_rcp(d.y) };
     const f32x2 q0 = n * r;
     const f32x2 q = __builtin_elementwise_fma(__builtin_elementwise_fma(-q0, d, n), r, q0);

@@ -156,7 +156,7 @@ enum {
 /* How LinearToPQ (ColorTransfer.cpp:69-92) is evaluated -- tier 2 either way (|delta code| <= 1 against the reference's powf): what
  * differs is the share of codes that are EXACTLY the reference's, and the cost (900 k-sample sweep at 80 nits):
  *   COMPACT  5 transcendentals + 6 packed operations per sample:                         99.94 % exact at 10 bit, 99.77 % at 12 bit
- *   CLOSE    + 3 plain, + 1/2 packed issue slots: the exponent's share of t^m1 from LDS
+ *   CLOSE    + 3 plain, + 1 packed issue slots: the exponent's share of t^m1 from LDS
  *            tables indexed by the exponent field (exact m1 * E, round-to-nearest split): 99.99 % exact at 10 bit, 99.96 % at 12 bit
  * AUTO = CLOSE at every depth and in every kernel since ABI 4 (round 3's AUTO took its much costlier CLOSE for 12-bit output only).
  * Meaningful for PQ saves of 32-bit documents; ignored (not even range-checked) everywhere else.  Sampled-curve ICC documents take it
