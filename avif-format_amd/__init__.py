@@ -97,7 +97,7 @@ ICC_IS_REC2020, ICC_IS_SRGB = 1, 2
 
 class IccSampled32(ctypes.Structure):
     _fields_ = [("base", IccTransform), ("curve", (c_float * 65536) * 3), ("table16", (ctypes.c_uint16 * 4096) * 3),
-                ("entries", c_int32 * 3), ("reserved", c_int32)]
+                ("entries", c_int32 * 3), ("parametric_mask", c_int32)]
 
 
 class IccClut16(ctypes.Structure):

@@ -318,8 +318,18 @@ int upload_icc_sampled(const avifgpu_icc_sampled32* t, WriteParams& p)
     c.s32_src = t; c.s32_fp = fp;
     p.icc_s_tab = static_cast<const float*>(c.s32);
     p.icc_s_tab16 = reinterpret_cast<const uint16_t*>(static_cast<const uint8_t*>(c.s32) + nc);
-    const bool lds = t->entries[0] > 0 && t->entries[1] > 0 && t->entries[2] > 0 && !(g_hot_variant & 64);   // bit 6: tests take the memory path
+    // a mixed profile: the channels of parametric_mask carry a parametric curve (base.trc_type / trc_params), the others a table
+    if (t->parametric_mask < 0 || t->parametric_mask >= 7) return fail(AVIFGPU_formatBadParameters, "sampled ICC curves: parametric_mask must leave at least one sampled channel");
+    bool lds = !(g_hot_variant & 64);                           // bit 6: tests take the memory path
+    for (int ch = 0; ch < 3; ++ch) {
+        const bool par = (t->parametric_mask >> ch) & 1;
+        if (par && t->entries[ch] != 0) return fail(AVIFGPU_formatBadParameters, "sampled ICC curves: a parametric channel has no table entries");
+        if (par != (t->base.trc_type[ch] != 0)) return fail(AVIFGPU_formatBadParameters, "sampled ICC curves: parametric_mask and base.trc_type[] disagree");
+        lds = lds && (par || t->entries[ch] > 0);
+    }
     for (int ch = 0; ch < 3; ++ch) p.icc_s_n[ch] = lds ? t->entries[ch] : 0;
+    p.icc_s_lds = lds;
+    p.icc_s_par = t->parametric_mask;
     return 0;
 }
 
@@ -430,8 +440,8 @@ int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const Wr
             const int rc = upload_icc_sampled(icc.s32, p);
             if (rc) return rc;
         }
-        for (int c = 0; c < 3 && icc.s32; ++c) p.icc_trc_type[c] = 6;           // marks "sampled" for the launchers
-        for (int c = 0; c < 3 && !icc.s32; ++c) {
+        for (int c = 0; c < 3; ++c) {
+            if (icc.s32 && !((p.icc_s_par >> c) & 1)) { p.icc_trc_type[c] = 6; continue; }     // 6 marks "sampled" for the launchers
             if (g_icc->trc_type[c] < 1 || g_icc->trc_type[c] > 5) return fail(AVIFGPU_formatBadParameters, "bad ICC curve type");
             p.icc_trc_type[c] = g_icc->trc_type[c];
             p.icc_trc_linear[c] = g_icc->trc_type[c] == 1 && g_icc->trc_params[c][0] == 1.0;

@@ -259,19 +259,28 @@ extern "C" int32_t avifgpu_icc_prepare_sampled(const void* icc_profile, uint32_t
     Trc trc[3];
     const int rc = prepare_float_pipeline(icc_profile, size, target, &out->base, trc, true);
     if (rc) return rc;
+    // At least one channel carries a table; the others may be parametric (a MIXED profile: lcms2 evaluates each channel's curve by
+    // its own kind, cmsEvalToneCurveFloat per channel in the curves stage) -- those keep their trc_type / trc_params in `base` and
+    // the kernel evaluates them like avifgpu_icc_prepare's.
+    int mask = 0;
+    for (int c = 0; c < 3; ++c) {
+        if (trc[c].type != 0) mask |= 1 << c;
+        else if (trc[c].table.size() < 2) return fail(AVIFGPU_formatCannotRead, "a sampled curve needs at least two entries");
+    }
+    if (mask == 7) return fail(AVIFGPU_formatCannotRead, "no channel carries a sampled curve: parametric profiles take avifgpu_icc_prepare");
+    std::memset(out->curve, 0, sizeof(out->curve));
     for (int c = 0; c < 3; ++c)
-        if (trc[c].type != 0 || trc[c].table.size() < 2)
-            return fail(AVIFGPU_formatCannotRead, "not every channel carries a sampled curve: parametric profiles take avifgpu_icc_prepare");
-    for (int c = 0; c < 3; ++c)
-        for (uint32_t in = 0; in < 65536; ++in) out->curve[c][in] = (float)(eval_table16(trc[c].table, (uint16_t)in) / 65535.0);
+        if (!((mask >> c) & 1))
+            for (uint32_t in = 0; in < 65536; ++in) out->curve[c][in] = (float)(eval_table16(trc[c].table, (uint16_t)in) / 65535.0);
     std::memset(out->table16, 0, sizeof(out->table16));
     bool small = true;
     for (int c = 0; c < 3; ++c) small = small && trc[c].table.size() <= (size_t)AVIFGPU_ICC_SAMPLED_MAX;
     for (int c = 0; c < 3; ++c) {
-        out->entries[c] = small ? (int32_t)trc[c].table.size() : 0;
-        if (small) std::memcpy(out->table16[c], trc[c].table.data(), trc[c].table.size() * sizeof(uint16_t));
+        const bool par = (mask >> c) & 1;
+        out->entries[c] = (small && !par) ? (int32_t)trc[c].table.size() : 0;
+        if (small && !par) std::memcpy(out->table16[c], trc[c].table.data(), trc[c].table.size() * sizeof(uint16_t));
     }
-    out->reserved = 0;
+    out->parametric_mask = mask;
     return 0;
 }
 

@@ -83,7 +83,9 @@ struct WriteParams {
     // sampled curves of a 32-bit document (avifgpu_icc_sampled32): 3 x 65536 floats in device memory (768 KiB, L2-resident)
     const float* icc_s_tab;
     const uint16_t* icc_s_tab16;  // [3][AVIFGPU_ICC_SAMPLED_MAX]: the profile's own tables (LDS LinLerp1D path), behind icc_s_tab on the device
-    int32_t icc_s_n[3];           // their entry counts; 0 = look curve[] up in memory
+    int32_t icc_s_n[3];           // their entry counts; 0 = look curve[] up in memory (or a parametric channel, see icc_s_par)
+    int32_t icc_s_par;            // bit c: channel c of a MIXED profile carries a parametric curve (icc_trc_f[c], evaluated like icc = 2); the rest are sampled
+    int32_t icc_s_lds;            // the sampled channels' tables go to LDS (every one of them has icc_s_n > 0)
 };
 
 struct ReadParams {

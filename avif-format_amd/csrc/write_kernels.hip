@@ -783,7 +783,7 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
 
     // sampled-curve ICC variant: the profile's tables as (T[i], T[i+1]) pairs in dynamic LDS (4 bytes per entry, sized by the launch)
     extern __shared__ uint32_t icc6_pairs[];
-    const bool icc6_lds = ICC == 6 && p.icc_s_n[0] > 0;
+    const bool icc6_lds = ICC == 6 && p.icc_s_lds != 0;
     const int icc6_off[3] = { 0, p.icc_s_n[0], p.icc_s_n[0] + p.icc_s_n[1] };
     if constexpr (ICC == 6) {
         if (icc6_lds) {
@@ -1117,17 +1117,24 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
             if constexpr (ICC == 6 && DEPTH == 32 && (PLANES == 3 || PLANES == 4)) {
                 // sampled document curves, the whole footprint before any pixel goes on; alpha is not looked up.  In LDS where the
                 // profile's tables are small enough (uniform per launch), else one memory lookup per sample, all of them in flight at once.
-                if (icc6_lds) {
+                // A MIXED profile (some channels parametric: icc_s_par) evaluates those like icc = 2 does -- lcms2 does not quantise
+                // the input of a parametric segment -- the choice is uniform per launch and channel.
 #pragma unroll
-                    for (int i = 0; i < PXT; ++i)
+                for (int k = 0; k < 3; ++k) {
+                    if (p.icc_s_par & (1 << k)) {
+                        if (!p.icc_trc_linear[k]) {
+                            const IccPowTableF noT = { nullptr };
 #pragma unroll
-                        for (int k = 0; k < 3; ++k)
+                            for (int i = 0; i < PXT; ++i) s[i][k] = __float_as_uint(icc_trc_f(noT, p.icc_trc_f[k], __uint_as_float(s[i][k])));
+                        }
+                    } else if (icc6_lds) {
+#pragma unroll
+                        for (int i = 0; i < PXT; ++i)
                             s[i][k] = __float_as_uint(icc_sampled_curve_lds(icc6_pairs + icc6_off[k], (uint32_t)p.icc_s_n[k] - 1u, __uint_as_float(s[i][k])));
-                } else {
+                    } else {
 #pragma unroll
-                    for (int i = 0; i < PXT; ++i)
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) s[i][k] = __float_as_uint(icc_sampled_curve(p, k, __uint_as_float(s[i][k])));
+                        for (int i = 0; i < PXT; ++i) s[i][k] = __float_as_uint(icc_sampled_curve(p, k, __uint_as_float(s[i][k])));
+                    }
                 }
             }
             auto stage_row = [&](auto rescale8) {
@@ -2398,7 +2405,7 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, char* label)
             {
                 snprintf(label, kLabelBytes, "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=6>",
                          DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned);
-                const size_t lds = p.icc_s_n[0] > 0 ? (size_t)(p.icc_s_n[0] + p.icc_s_n[1] + p.icc_s_n[2]) * 4 : 0;      // <= 48 KiB
+                const size_t lds = p.icc_s_lds ? (size_t)(p.icc_s_n[0] + p.icc_s_n[1] + p.icc_s_n[2]) * 4 : 0;      // <= 48 KiB
                 if (lds) snprintf(label + strlen(label), kLabelBytes - strlen(label), " lds");
                 if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 6>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), lds, st, p);
                 else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 6>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), lds, st, p);

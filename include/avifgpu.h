@@ -370,17 +370,20 @@ int32_t avifgpu_write_rows_icc(const avifgpu_write_desc* desc, const avifgpu_icc
  * divides back by 65535 -- so per channel the curve stage is a function of a 16-bit index.  avifgpu_icc_prepare_sampled tabulates
  * it (65536 floats per channel, the library's arithmetic restated on the host: csrc/icc_profile.cpp), the kernel computes the same
  * index and looks the float up (or interpolates the profile's own table in LDS: the same value); matrix and, for the sRGB target, the inverse curve follow as in avifgpu_icc_transform.
- * All three channels must be sampled (a profile that mixes sampled and parametric channels, and every LUT-based / A2B profile,
- * still returns AVIFGPU_formatCannotRead: the caller keeps lcms2).  792 KiB: allocate it once per save. */
+ * At least one channel must be sampled; a profile that MIXES sampled and parametric channels is taken too (parametric_mask: those
+ * channels are evaluated on the unquantised sample like avifgpu_icc_transform's, as lcms2 does channel by channel in its curves
+ * stage).  All-parametric profiles take avifgpu_icc_prepare; LUT-based / A2B profiles still return AVIFGPU_formatCannotRead (the
+ * caller keeps lcms2).  792 KiB: allocate it once per save. */
 enum { AVIFGPU_ICC_SAMPLED_MAX = 4096 };
 typedef struct avifgpu_icc_sampled32 {
-    avifgpu_icc_transform base;  /* matrix, out_curve, out_params as above; trc_type[] = 0 */
+    avifgpu_icc_transform base;  /* matrix, out_curve, out_params as above; trc_type[c] = 0 for a sampled channel */
     float curve[3][65536];       /* curve[c][_cmsQuickSaturateWord(v * 65535.0)] = what lcms2's curve stage hands to the matrix for sample v */
     /* The profile's own tables, when none has more than AVIFGPU_ICC_SAMPLED_MAX entries (entries[] = 0 otherwise): the kernel then keeps
      * them in LDS and performs LinLerp1D itself -- the same words, the same floats as curve[], without a scattered memory load per sample. */
     uint16_t table16[3][AVIFGPU_ICC_SAMPLED_MAX];
     int32_t  entries[3];
-    int32_t  reserved;
+    int32_t  parametric_mask;    /* bit c: channel c of a MIXED profile is parametric (base.trc_type[c] / trc_params[c] hold it, curve[c] is unused,
+                                  * entries[c] = 0); 0 for a profile whose three curves are all sampled.  Never 7. */
 } avifgpu_icc_sampled32;
 int32_t avifgpu_icc_prepare_sampled(const void* icc_profile, uint32_t size, int32_t target, avifgpu_icc_sampled32* out);
 int32_t avifgpu_write_rows_icc_sampled(const avifgpu_write_desc* desc, const avifgpu_icc_sampled32* icc,

@@ -23,7 +23,9 @@
  * trc:  0 gamma `g` (curv, count 1; g = 1 -> the "Linear RGB Profile" Photoshop embeds in 32-bit documents),
  *       1 sRGB parametric (para type 3 = lcms type 4), 2 gamma via para type 0,
  *       3 sampled `curv` table of (int)g entries holding the sRGB EOTF, 4 sampled tables of (int)g entries, a different
- *         power law per channel (1.8 / 2.2 / 2.4). */
+ *         power law per channel (1.8 / 2.2 / 2.4),
+ *       5 MIXED: R a sampled table of (int)g entries (sRGB EOTF), G the sRGB parametric curve (lcms type 4), B gamma 2.2 (curv count 1),
+ *       6 MIXED: R gamma 1.0 (identity), G and B sampled tables of (int)g entries (x^2.2, x^2.4). */
 int32_t oracle_icc_make_profile(int32_t kind, int32_t trc, double g, void* out, uint32_t cap)
 {
     static const cmsCIExyYTRIPLE prim[5] = {
@@ -52,6 +54,37 @@ int32_t oracle_icc_make_profile(int32_t kind, int32_t trc, double g, void* out, 
             t3[ch] = cmsBuildTabulatedToneCurve16(NULL, (cmsUInt32Number)n, tab[ch]);
             if (!t3[ch]) return -1;
         }
+        cmsHPROFILE h = cmsCreateRGBProfile(kind == 2 ? &d50 : &d65, &prim[kind], t3);
+        for (int ch = 0; ch < 3; ++ch) cmsFreeToneCurve(t3[ch]);
+        if (!h) return -1;
+        cmsUInt32Number nb = 0;
+        cmsSaveProfileToMem(h, NULL, &nb);
+        int32_t rc = -1;
+        if (nb && nb <= cap && cmsSaveProfileToMem(h, out, &nb)) rc = (int32_t)nb;
+        cmsCloseProfile(h);
+        return rc;
+    }
+    if (trc == 5 || trc == 6) {
+        const int n = (int)g;
+        if (n < 2 || n > 4096) return -1;
+        static cmsUInt16Number mt[2][4096];
+        for (int i = 0; i < n; ++i) {
+            const double x = (double)i / (n - 1);
+            mt[0][i] = (cmsUInt16Number)floor((trc == 5 ? (x <= 0.04045 ? x / 12.92 : pow((x + 0.055) / 1.055, 2.4)) : pow(x, 2.2)) * 65535.0 + 0.5);
+            mt[1][i] = (cmsUInt16Number)floor(pow(x, 2.4) * 65535.0 + 0.5);
+        }
+        cmsFloat64Number sp[5] = { 2.4, 1.0 / 1.055, 0.055 / 1.055, 1.0 / 12.92, 0.04045 };
+        cmsToneCurve* t3[3];
+        if (trc == 5) {
+            t3[0] = cmsBuildTabulatedToneCurve16(NULL, (cmsUInt32Number)n, mt[0]);
+            t3[1] = cmsBuildParametricToneCurve(NULL, 4, sp);
+            t3[2] = cmsBuildGamma(NULL, 2.2);
+        } else {
+            t3[0] = cmsBuildGamma(NULL, 1.0);
+            t3[1] = cmsBuildTabulatedToneCurve16(NULL, (cmsUInt32Number)n, mt[0]);
+            t3[2] = cmsBuildTabulatedToneCurve16(NULL, (cmsUInt32Number)n, mt[1]);
+        }
+        if (!t3[0] || !t3[1] || !t3[2]) return -1;
         cmsHPROFILE h = cmsCreateRGBProfile(kind == 2 ? &d50 : &d65, &prim[kind], t3);
         for (int ch = 0; ch < 3; ++ch) cmsFreeToneCurve(t3[ch]);
         if (!h) return -1;

@@ -437,6 +437,9 @@ def test_host_shim_decides_like_the_plugin_clip_and_kept_profile(gpu, lcms, keep
 
 
 SAMPLED = [("p3-sampled-srgb-1024", 1, 3, 1024), ("adobergb-sampled-per-channel-256", 3, 4, 256), ("prophoto-sampled-per-channel-33", 2, 4, 33)]
+# profiles that MIX the two kinds of curve: (name, kind, trc, entries, parametric_mask)
+MIXED = [("p3-R-sampled-G-srgb-para-B-gamma2.2", 1, 5, 1024, 0b110), ("adobergb-R-linear-GB-sampled-256", 3, 6, 256, 0b001),
+         ("srgb-R-sampled-4096-G-para-B-gamma", 0, 5, 4096, 0b110)]
 
 
 @pytest.mark.gpu
@@ -475,7 +478,7 @@ def test_sampled_curve_tables_equal_lcms2_per_word(lcms):
             fma = lambda a, b, cc: (a.astype(np.float64) * b.astype(np.float64) + cc.astype(np.float64)).astype(np.float32)   # exact product + one rounding
             got = fma(fma(-q0, np.full_like(q0, 65535.0), wf), np.full_like(q0, r), q0)
             assert np.array_equal(got.view(np.uint32), c[ch].view(np.uint32)), (name, ch)
-    # a parametric profile is not "sampled"; a non-profile is rejected
+    # an all-parametric profile is not "sampled"; a non-profile is rejected
     icc = _profile(lcms, 1, 2, 1.8)
     assert lib.avifgpu_icc_prepare_sampled(icc, len(icc), 0, ctypes.byref(pkg.IccSampled32())) == pkg.formatCannotRead
     assert lib.avifgpu_icc_prepare_sampled(bytes(200), 200, 0, ctypes.byref(pkg.IccSampled32())) == pkg.formatCannotRead
@@ -528,6 +531,49 @@ def test_sampled_document_curves_match_lcms2(gpu, lcms, name, kind, trc, g, plan
                 assert np.array_equal(got[pl], mem[pl]), (name, pl)
             st = harness.compare_write(d, want, got)
             print(f"icc-sampled {name} planes {planes} target {target} out {output} {bits}-bit transfer {transfer}: exact {st['exact_frac']:.5f} max {st['max_abs']}")
+            assert st["max_abs"] <= 1, (name, st)
+            assert st["exact_frac"] >= (0.99 if hdr else 0.985), (name, st)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kind,trc,n,mask", MIXED)
+@pytest.mark.parametrize("planes", [3, 4])
+def test_mixed_sampled_and_parametric_curves_match_lcms2(gpu, lcms, name, kind, trc, n, mask, planes):
+    """A 32-bit document whose profile mixes sampled and parametric channels: lcms2's curves stage evaluates each channel by its own
+    kind (cmsEvalToneCurveFloat: the 16-bit word for a table, the double formula on the unquantised float for a segment), and so does
+    the icc = 6 kernel, channel by channel.  Against the REAL lcms2 + the oracle's pixel loop, tier-2 bars; LDS and memory forms agree."""
+    icc = _profile(lcms, kind, trc, n)
+    alpha = pkg.ALPHA_STRAIGHT if planes == 4 else pkg.ALPHA_NONE
+    for target, conv_fn, cfgs in (
+            (pkg.ICC_TARGET_REC2020_LINEAR, lcms.oracle_icc_convert_rows_to_rec2020,
+             ((pkg.OUT_YCBCR, pkg.CHROMA_444, 10, pkg.TRANSFER_PQ), (pkg.OUT_YCBCR, pkg.CHROMA_422, 12, pkg.TRANSFER_PQ))),
+            (pkg.ICC_TARGET_SRGB_FLOAT, lcms.oracle_icc_convert_rows_to_srgb_float,
+             ((pkg.OUT_YCBCR, pkg.CHROMA_420, 12, pkg.TRANSFER_CLIP), (pkg.OUT_REFERENCE, pkg.CHROMA_444, 10, pkg.TRANSFER_CLIP)))):
+        xf = gpu.icc_prepare_sampled(icc, target)
+        assert xf.parametric_mask == mask
+        for output, chroma, bits, transfer in cfgs:
+            hdr = transfer != pkg.TRANSFER_CLIP
+            d = pkg.WriteDesc(width=517, height=18, depth=32, planes=planes, bit_depth=bits, transfer=transfer, peak_nits=80,
+                              alpha_state=alpha, output=output, chroma=chroma, chroma_downsampling=pkg.DOWNSAMPLE_NEAREST if chroma == pkg.CHROMA_422 else 0,
+                              matrix_coefficients=pkg.MATRIX_BT2020_NCL if hdr else pkg.MATRIX_BT601,
+                              color_primaries=pkg.PRIMARIES_BT2020 if hdr else pkg.PRIMARIES_BT709)
+            src = harness.make_write_source(d, seed=47)
+            conv = src.copy()
+            assert conv_fn(icc, len(icc), int(planes == 4), conv.ctypes.data, d.width, d.height, conv.strides[0]) == 0
+            want = harness.oracle_write(d, conv)
+            got = _gpu_write_icc(gpu, d, src, xf)
+            lds = n <= 4096
+            assert "icc=6" in gpu.last_kernel() and (" lds" in gpu.last_kernel()) == lds, gpu.last_kernel()
+            try:
+                gpu.lib.avifgpu_set_hot_variant(1 | 2 | 4 | 64)
+                mem = _gpu_write_icc(gpu, d, src, xf)
+                assert "icc=6" in gpu.last_kernel() and " lds" not in gpu.last_kernel(), gpu.last_kernel()
+            finally:
+                gpu.lib.avifgpu_set_hot_variant(1 | 2 | 4)
+            for pl in got:
+                assert np.array_equal(got[pl], mem[pl]), (name, pl)
+            st = harness.compare_write(d, want, got)
+            print(f"icc-mixed {name} planes {planes} target {target} out {output} {bits}-bit transfer {transfer}: exact {st['exact_frac']:.5f} max {st['max_abs']}")
             assert st["max_abs"] <= 1, (name, st)
             assert st["exact_frac"] >= (0.99 if hdr else 0.985), (name, st)
 

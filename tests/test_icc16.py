@@ -495,3 +495,33 @@ def test_icc_tables_are_bound_to_their_document_depth(gpu, lcms):
     with pytest.raises(pkg.AvifGpuError) as e:
         _gpu(gpu, gray, harness.make_write_source(gray), clut)
     assert e.value.code == pkg.formatBadParameters
+
+
+# profiles that MIX sampled and parametric channels on the 32-bit path: (name, kind, trc, entries, parametric_mask) -- also in test_gpu_icc.py
+MIXED = [("p3-R-sampled-G-srgb-para-B-gamma2.2", 1, 5, 1024, 0b110), ("adobergb-R-linear-GB-sampled-256", 3, 6, 256, 0b001),
+         ("srgb-R-sampled-4096-G-para-B-gamma", 0, 5, 4096, 0b110)]
+
+
+def test_mixed_profiles_prepare_per_channel(lcms):
+    """avifgpu_icc_prepare_sampled on profiles that mix sampled and parametric channels (host only): the sampled channels are tabulated
+    and carry their tables, the parametric ones keep type and parameters in `base` and are named by parametric_mask; the all-parametric
+    form still refuses them (its struct has no room for a table), the all-sampled form refuses all-parametric profiles."""
+    lib = pkg.load()
+    for name, kind, trc, n, mask in MIXED:
+        icc = _profile(lcms, kind, trc, n)
+        assert lib.avifgpu_icc_prepare(icc, len(icc), pkg.ICC_TARGET_REC2020_LINEAR, ctypes.byref(pkg.IccTransform())) == pkg.formatCannotRead
+        t = pkg.IccSampled32()
+        assert lib.avifgpu_icc_prepare_sampled(icc, len(icc), pkg.ICC_TARGET_REC2020_LINEAR, ctypes.byref(t)) == 0, name
+        assert t.parametric_mask == mask, (name, t.parametric_mask)
+        c = np.ctypeslib.as_array(t.curve)
+        for ch in range(3):
+            if (mask >> ch) & 1:
+                assert t.base.trc_type[ch] in (1, 4) and t.entries[ch] == 0 and not c[ch].any(), (name, ch)
+            else:
+                assert t.base.trc_type[ch] == 0 and t.entries[ch] == n, (name, ch, list(t.entries))
+                assert c[ch, 0] == 0.0 and c[ch, 65535] == 1.0 and np.all(np.diff(c[ch]) >= 0), (name, ch)
+        # gamma 2.2 travels as a one-parameter curve (s15Fixed16 in a v4 profile: 2.19999...), the linear channel as gamma 1.0, the parametric sRGB as lcms type 4
+        if trc == 5:
+            assert t.base.trc_type[1] == 4 and t.base.trc_type[2] == 1 and abs(t.base.trc_params[2][0] - 2.2) < 1e-4
+        else:
+            assert t.base.trc_type[0] == 1 and t.base.trc_params[0][0] == 1.0
