@@ -147,39 +147,13 @@ AG_DEV float fast_linear_to_pq(float value, float mult)
 // fewest LDS instructions among the packed ones, 4 KiB): 3 = tables F, c2 2^N, c3 2^N (three ds_read_b32 per sample, N(x) and D(x)
 // formed without x: c2 x == (c2 2^N) y bit for bit); 2 = tables F, 2^N (two reads, x = y 2^N as a packed multiply); 1 = one table
 // of {F, 2^N} records (one ds_read_b64, but the values of two samples are not adjacent: the exponent FMA and the multiply are not packed).
+// (A form WITHOUT the first two transcendentals -- x from a 1024-entry table of 2^(m1 E) c_j^m1 and a cubic in the mantissa's offset
+// from its segment's middle -- was built and measured in round 4 and is in the git history, commit 08521f6: 618 instead of 545 vector
+// instructions per 8 pixels, 73 instead of 121 of them transcendental, 2-3 % SLOWER and fewer exact codes:
+// profiles/r04/pq_polynomial_first_power_ab.txt.  These kernels pay for issue slots, not for the transcendental pipe.)
 #ifndef AG_PQ_TAB_FORM
 #define AG_PQ_TAB_FORM 2
 #endif
-// AG_PQ_TAB_FORM 4 (round 4, second half): NO transcendental in the first power.  A wave64 transcendental occupies the vector ALU for
-// 16 cycles, a full-rate instruction for 4 and a packed one (two samples) for 4: the kernel times of profiles/r04 are the sum of
-// those cycles to within 2 % (headline: 425 x 4 + 120 x 16 = 3620 cycles per wave and 512 pixels -> 0.193 ms at 2.4 GHz, measured
-// 0.197), so the five transcendentals per sample were HALF the kernel.  x = t^m1 does not need its two:
-//     t = clamp(value * mult, 0, 1) = 2^E mant,  j = mant's top three bits,  r = mant * B[j] - 1  (B[j] = 1 / c_j, c_j the middle of
-//     segment j; |r| <= 1/17),   x = A[E, j] * (1 + r)^m1,   A[E, j] = 2^(m1 E) c_j^m1 rounded once (50-digit arithmetic,
-//     tools/gen_pq_pow_table.py), (1 + r)^m1 = 1 + r q(r) with a cubic q (2e-9 from the function), x = fma(A, r q, A):
-// one table value, one fused multiply-add on it -- x is within ~0.6 ulp of t^m1 (tests/test_pq_pow_table.py replays the arithmetic
-// for 2^22 samples), closer than 2^(m1 log2 m + F) was.  The clamp is the multiply's output modifier (values above 1 reach the same
-// top code either way, negative and NaN samples the code 0: no entries for them, 1024 + 8 floats).  Per sample: one packed
-// multiply, shift, two ands, and-or, two ds_read_b32, six packed operations -- 30 cycles where form 2 took 50.
-#if AG_PQ_TAB_FORM == 4
-#ifdef AG_PQ_POW_SEG4
-#include "pq_pow_table_b4.inc"      // four mantissa bits in the index, a quadratic q: 8 KiB of LDS for one packed FMA per pair (A/B only)
-#else
-#include "pq_pow_table.inc"
-#endif
-constexpr int kPqTabEntries = 128 << kPqPowSegBits;
-constexpr int kPqTabPad = 0;
-constexpr int kPqTabCount = 1;
-constexpr int kPqTabFloats = kPqTabEntries + (1 << kPqPowSegBits);
-struct PqExpTable { float a[kPqTabEntries]; float b[1 << kPqPowSegBits]; };
-constexpr PqExpTable make_pq_exp_table()
-{
-    PqExpTable t{};
-    for (int i = 0; i < kPqTabEntries; ++i) t.a[i] = kPqPowA[i];
-    for (int j = 0; j < (1 << kPqPowSegBits); ++j) t.b[j] = kPqPowB[j];
-    return t;
-}
-#else
 constexpr int kPqTabEntries = 512;
 constexpr int kPqTabPad = 4;
 constexpr int kPqTabCount = AG_PQ_TAB_FORM == 3 ? 3 : 2;
@@ -206,7 +180,6 @@ constexpr PqExpTable make_pq_exp_table()
     }
     return t;
 }
-#endif
 __device__ __attribute__((aligned(16))) const PqExpTable kPqExpTableConst = make_pq_exp_table();
 static_assert(sizeof(PqExpTable) == kPqTabFloats * sizeof(float) && kPqTabFloats % 4 == 0, "copied as float4");
 // The table of the calling kernel's workgroup (a function-local __shared__ array is one LDS allocation per kernel that reaches it).
@@ -223,75 +196,6 @@ AG_DEV void pq_exp_table_fill(int tid, int nthreads)
     const f4* src = reinterpret_cast<const f4*>(&kPqExpTableConst);
     for (int i = tid; i < kPqTabFloats / 4; i += nthreads) dst[i] = src[i];
 }
-#if AG_PQ_TAB_FORM == 4
-AG_DEV float pq_sat01(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); }                 // folds into the producing multiply's clamp modifier (NaN -> 0)
-AG_DEV uint32_t pq_tab_offset(float t) { return (__float_as_uint(t) >> (21 - kPqPowSegBits)) & ((uint32_t)(kPqTabEntries - 1) << 2); }   // byte offset of A[eb, j]
-AG_DEV float pq_tab_a(const float* tab, uint32_t off) { return *reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(tab) + off); }
-AG_DEV float pq_tab_b(const float* tab, uint32_t off)
-{
-    return *reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(tab + kPqTabEntries) + (off & (((1u << kPqPowSegBits) - 1u) << 2)));
-}
-AG_DEV float pq_mantissa(float t) { return __uint_as_float((__float_as_uint(t) & 0x007fffffu) | 0x3f800000u); }      // [1, 2)
-// x = t^m1 for t = clamp(value * mult, 0, 1)
-AG_DEV float pq_pow_m1(const float* tab, float t)
-{
-    const uint32_t off = pq_tab_offset(t);
-    const float A = pq_tab_a(tab, off);
-    const float r = __builtin_fmaf(pq_mantissa(t), pq_tab_b(tab, off), -1.0f);
-    float q = kPqPowQ[kPqPowDeg - 1];
-#pragma unroll
-    for (int k = kPqPowDeg - 2; k >= 0; --k) q = __builtin_fmaf(q, r, kPqPowQ[k]);
-    return __builtin_fmaf(A, q * r, A);
-}
-AG_DEV f32x2 pq_pow_m1_2(const float* tab, f32x2 t)
-{
-    const uint32_t o0 = pq_tab_offset(t.x), o1 = pq_tab_offset(t.y);
-    const f32x2 A = { pq_tab_a(tab, o0), pq_tab_a(tab, o1) };
-    const f32x2 B = { pq_tab_b(tab, o0), pq_tab_b(tab, o1) };
-    const f32x2 m = { pq_mantissa(t.x), pq_mantissa(t.y) };
-    const f32x2 r = __builtin_elementwise_fma(m, B, (f32x2)(-1.0f));
-    f32x2 q = (f32x2)kPqPowQ[kPqPowDeg - 1];
-#pragma unroll
-    for (int k = kPqPowDeg - 2; k >= 0; --k) q = __builtin_elementwise_fma(q, r, (f32x2)kPqPowQ[k]);
-    return __builtin_elementwise_fma(A, q * r, A);
-}
-// pq in [0, 1] for t = value * mult
-AG_DEV float fast_linear_to_pq01_hi(float value, float mult)
-{
-    const float x = pq_pow_m1(pq_exp_table(), pq_sat01(value * mult));
-    const float n = kPqC1 + kPqC2 * x, d = 1.0f + kPqC3 * x;
-    return nat_exp2_sat(kPqM2 * nat_log2(near_ieee_div(n, d)));
-}
-// t for two samples: ONE packed multiply whose clamp modifier does the saturation (VOP3P carries the bit for the packed f32
-// operations too: tools/pkclamp_check.hip prints what the hardware does with > 1, < 0, -0, NaN and inf).  AG_PQ_PKCLAMP = 0: the
-// compiler's own form (v_pk_mul_f32 + one v_max_f32 ... clamp per sample).
-#ifndef AG_PQ_PKCLAMP
-#define AG_PQ_PKCLAMP 1
-#endif
-AG_DEV f32x2 pq_scaled_sat01_2(f32x2 value, float mult)
-{
-#if AG_PQ_PKCLAMP
-    f32x2 d;
-    const f32x2 mm = { mult, mult };
-    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(d) : "v"(value), "s"(mm));
-    return d;
-#else
-    const f32x2 tm = value * mult;
-    return f32x2{ pq_sat01(tm.x), pq_sat01(tm.y) };
-#endif
-}
-AG_DEV f32x2 fast_linear_to_pq01_2_hi(f32x2 value, float mult)
-{
-    const f32x2 x = pq_pow_m1_2(pq_exp_table(), pq_scaled_sat01_2(value, mult));
-    const f32x2 n = kPqC1 + kPqC2 * x;
-    const f32x2 d = 1.0f + kPqC3 * x;
-    const f32x2 r = { nat_rcp(d.x), nat_rcp(d.y) };
-    const f32x2 q0 = n * r;
-    const f32x2 q = __builtin_elementwise_fma(__builtin_elementwise_fma(-q0, d, n), r, q0);
-    const f32x2 e2 = kPqM2 * f32x2{ nat_log2(q.x), nat_log2(q.y) };
-    return f32x2{ nat_exp2_sat(e2.x), nat_exp2_sat(e2.y) };
-}
-#else
 AG_DEV uint32_t pq_tab_offset(float t) { return (__float_as_uint(t) >> (AG_PQ_TAB_FORM == 1 ? 20 : 21)) & (AG_PQ_TAB_FORM == 1 ? 0xff8u : 0x7fcu); }   // byte offset of t's entry
 AG_DEV float pq_tab_at(const float* tab, int which, uint32_t off)
 {
@@ -337,7 +241,6 @@ AG_DEV f32x2 fast_linear_to_pq01_2_hi(f32x2 value, float mult)
     const f32x2 e2 = kPqM2 * f32x2{ nat_log2(q.x), nat_log2(q.y) };
     return f32x2{ nat_exp2_sat(e2.x), nat_exp2_sat(e2.y) };
 }
-#endif
 // Build-time override of the per-launch choice (WriteParams::pq_close): 0 = the compact form everywhere, 2 = the close form
 // everywhere, 1 = as the descriptor says (AUTO = the close form at every depth since round 4).
 #ifndef AG_PQ_HI
