@@ -17,6 +17,8 @@ import harness  # noqa: E402
 
 dev = torch.device("cuda", 0)
 gpu = pkg.AvifGpu(0)
+if os.environ.get("BENCH_HOT_VARIANT"):           # tuning bits of avifgpu_set_hot_variant (bits 8+: block cap of the RGB f32 4:4:4 kernel)
+    gpu.lib.avifgpu_set_hot_variant(int(os.environ["BENCH_HOT_VARIANT"], 0))
 stream = torch.cuda.Stream(dev)
 
 
