@@ -146,6 +146,8 @@ _bw, _br = bench_write, bench_read
 
 
 def bench_write(name, **kw):
+    if name.startswith("SZ ") and not any(o.startswith("SZ") for o in ONLY):
+        return                                  # size-sweep rows: only when asked for (tuning launch rules), not part of the table
     if not ONLY or any(o in name for o in ONLY):
         _bw(name, **kw)
 
@@ -171,6 +173,8 @@ if __name__ == "__main__":
     bench_write("W16 8192^2 RGB16 -> 10-bit 4:2:2 BT.709", width=8192, height=8192, depth=16, planes=3, bit_depth=10, alpha_state=0, output=1, chroma=P.CHROMA_422, matrix_coefficients=1)
     bench_write("C3 8192^2 RGB16 -> 12-bit 4:4:4 BT.2020", width=8192, height=8192, depth=16, planes=3, bit_depth=12, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=P.MATRIX_BT2020_NCL, color_primaries=9)
     bench_write("C4 8192^2 RGB f32 -> 10-bit PQ 4:4:4", width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=9, color_primaries=9)
+    for sz in (2048, 4096, 6144, 10240, 11264, 12288, 14336):
+        bench_write("SZ %d^2 RGB f32 -> 10-bit PQ 4:4:4" % sz, width=sz, height=sz, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=9, color_primaries=9)
     bench_write("C4 8192^2 RGB f32 -> 10-bit PQ 4:2:2", width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_422, matrix_coefficients=9, color_primaries=9)
     bench_write("C4 8192^2 RGB f32 -> 10-bit PQ 4:2:0", width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=9, color_primaries=9)
     bench_write("C4 8192^2 RGB f32 -> 10-bit PQ interleaved RRGGBB (reference hand-off)", width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=0)
