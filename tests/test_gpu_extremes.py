@@ -17,7 +17,13 @@ def test_write_extreme_shapes(gpu, w, h):
     for kw in (dict(depth=8, planes=3, bit_depth=8, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420, matrix_coefficients=pkg.MATRIX_BT709),
                dict(depth=16, planes=4, bit_depth=12, alpha_state=pkg.ALPHA_PREMULTIPLIED, output=pkg.OUT_REFERENCE),
                dict(depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_PQ, peak_nits=1000, output=pkg.OUT_YCBCR,
-                    chroma=pkg.CHROMA_422, matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020)):
+                    chroma=pkg.CHROMA_422, matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020),
+               # round 4's streaming kernels: any width on RGB f32 4:4:4, and the transparent document's default save (RGBA f32 -> 4:2:0 + alpha)
+               dict(depth=32, planes=3, bit_depth=12, transfer=pkg.TRANSFER_PQ, peak_nits=80, output=pkg.OUT_YCBCR,
+                    chroma=pkg.CHROMA_444, matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020),
+               dict(depth=32, planes=4, bit_depth=12, transfer=pkg.TRANSFER_PQ, peak_nits=80, alpha_state=pkg.ALPHA_PREMULTIPLIED, output=pkg.OUT_YCBCR,
+                    chroma=pkg.CHROMA_420, chroma_downsampling=pkg.DOWNSAMPLE_NEAREST, matrix_coefficients=pkg.MATRIX_BT2020_NCL,
+                    color_primaries=pkg.PRIMARIES_BT2020)):
         d = pkg.WriteDesc(width=w, height=h, **kw)
         src = harness.make_write_source(d, seed=w % 97)
         want = harness.oracle_write(d, src)
@@ -40,6 +46,13 @@ def test_read_extreme_shapes(gpu, w, h):
         want = harness.oracle_read(d, planes)
         got = harness.gpu_read(gpu, d, planes, mem="device")
         assert np.array_equal(got, want), (w, h, kw)
+    # an HDR open (f32 host, tier 2): what the default HDR save decodes to
+    d = pkg.ReadDesc(width=w, height=h, colorspace=pkg.COLORSPACE_YCBCR, chroma=pkg.CHROMA_422, bit_depth=12, depth=32, alpha_state=pkg.ALPHA_NONE,
+                     transfer_characteristics=pkg.TC_PQ, pq_peak_nits=80, matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020)
+    planes = harness.make_read_source(d, seed=h % 89)
+    w64 = harness.oracle_read(d, planes).astype(np.float64)
+    g64 = harness.gpu_read(gpu, d, planes, mem="device").astype(np.float64)
+    assert np.all(np.isfinite(g64)) and np.all(np.abs(g64 - w64) <= 1e-4 * np.abs(w64) + 1e-9), (w, h)          # the T2 bar of tests/test_gpu_read.py
 
 
 @pytest.mark.parametrize("transfer", [pkg.TRANSFER_PQ, pkg.TRANSFER_HLG, pkg.TRANSFER_SMPTE428, pkg.TRANSFER_CLIP])
