@@ -1392,6 +1392,30 @@ AG_DEV uint32_t luma_code_nc(const WriteParams& p, float r, float g, float b)
     return (uint32_t)((r * p.my[0] + g * p.my[1] + b * p.my[2]) + 0.5f);
 }
 
+// Luma of TWO neighbouring pixels from their six levels as they sit in registers after the strip (R0 G0 B0 R1 G1 B1: three aligned
+// register pairs): the products as three packed multiplies on the pairs AS THEY ARE -- [R0 G0] x [Kr Kg], [B0 R1] x [Kb Kr],
+// [G1 B1] x [Kg Kb] -- and the sums as plain adds, in luma_code_nc's own order ((r Kr + g Kg) + b Kb) + 0.5.  Pairing R0 with R1
+// (one packed multiply per coefficient, packed adds) costs six v_mov per pixel pair to bring the operands together: 12 instructions
+// against 9 here, where luma is all that is computed per pixel (the 4:2:x kernels; with three outputs per pixel the moves pay off).
+#ifndef AG_LUMA_PAIRS
+#define AG_LUMA_PAIRS 1
+#endif
+AG_DEV void luma_pair_nc(const WriteParams& p, const float* c6, uint32_t& y0, uint32_t& y1)
+{
+#if AG_LUMA_PAIRS
+    const f32x2 p0 = f32x2{ c6[0], c6[1] } * f32x2{ p.my[0], p.my[1] };
+    const f32x2 p1 = f32x2{ c6[2], c6[3] } * f32x2{ p.my[2], p.my[0] };
+    const f32x2 p2 = f32x2{ c6[4], c6[5] } * f32x2{ p.my[1], p.my[2] };
+    // (the adds spelled out: left to itself the vectoriser pairs them up again -- and moves their operands together)
+    auto add = [](float a, float b) { float d; asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; };
+    y0 = (uint32_t)add(add(add(p0.x, p0.y), p1.x), 0.5f);
+    y1 = (uint32_t)add(add(add(p1.y, p2.x), p2.y), 0.5f);
+#else
+    y0 = luma_code_nc(p, c6[0], c6[1], c6[2]);
+    y1 = luma_code_nc(p, c6[3], c6[4], c6[5]);
+#endif
+}
+
 template <bool NT> AG_DEV f32x4 stream_load(const f32x4* p)
 {
     if constexpr (NT) return __builtin_nontemporal_load(p); else return *p;
@@ -1690,7 +1714,7 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot
             if (r < p.nrows) {                                         // (odd last row of the tile: replicated for chroma only)
                 uint32_t yv[PXL];
 #pragma unroll
-                for (int i = 0; i < PXL; ++i) yv[i] = luma_code_nc(p, c[strip_at(i, 0)], c[strip_at(i, 1)], c[strip_at(i, 2)]);   // (GBR needs 4:4:4)
+                for (int i = 0; i < PXL; i += 2) luma_pair_nc(p, &c[strip_at(i, 0)], yv[i], yv[i + 1]);   // (GBR needs 4:4:4)
                 u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
                 span_store_samples8<true>(p.dst[0] + (long long)r * p.dst_stride[0] + (long long)sx * (SPAN_PX * 2), (uint32_t)span_px, (uint32_t)lane, a);
             }
