@@ -6,26 +6,23 @@
 // 1 - 2^-17) lands on an even multiple, the integer above.  So the word is floor(v * 65535 + c) with c = 0.5 + 2^-17, taken of the EXACT
 // real.  In single precision: h = RN(v * 65535) and l = fma(v, 65535, -h) give the product exactly (h + l); k = floor(h), f = h - k
 // (exact); u = f + (c - 1) is exact for h >= 1 (both are multiples of 2^-23 below 1 in magnitude); the sign of u + l is the sign of
-// the exact sum (a float addition never rounds across zero), and the word is k + (u + l >= 0).  Below h = 1 the word is 0 or 1 and one
-// compare of the exact product decides.  tools/satword_check.hip compares this with the double form for all 2^32 floats.
+// the exact sum (a float addition never rounds across zero), and the word is k + (u + l >= 0).  tools/satword_check.hip compares this with the double form for all 2^32 floats.
 #pragma once
 #include <stdint.h>
 namespace avifgpu {
 __device__ __forceinline__ uint32_t quick_saturate_word_f32(float v)
 {
     constexpr float c1 = 0.50000762939453125f - 1.0f;           // c - 1 = -(0.5 - 2^-17), exact
-    constexpr float t0 = 0.49999237060546875f;                  // 1 - c
-    const float h = v * 65535.0f;
-    const float l = __builtin_fmaf(v, 65535.0f, -h);            // v * 65535 = h + l exactly
+    // Round 4: no special cases.  v is clamped to [0, 1] first (NaN -> 0: v_med3_f32 returns the minimum of the other two), which
+    // is both saturations: for v >= 1, h = 65535 exactly and the formula gives 65535; every v with d >= 65535 has
+    // floor(v * 65535 + c) = 65535 anyway; v <= 0 gives h = 0 and the word 0.  Below h = 1 the formula holds as it stands: for
+    // h in [0.25, 1) u = h - (1 - c) is exact (Sterbenz: 1 - c = 0.49999237), and for h < 0.25 u < -0.25 while |l| <= 2^-27 -- the
+    // sum is negative, the word 0, what the library's floor of d < 0.75 gives.  10 instructions, was ~20.
+    const float vc = __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f);
+    const float h = vc * 65535.0f;
+    const float l = __builtin_fmaf(vc, 65535.0f, -h);           // vc * 65535 = h + l exactly
     const float k = __builtin_floorf(h);
     const float u = (h - k) + c1;
-    uint32_t w = (uint32_t)k + (((u + l) >= 0.0f) ? 1u : 0u);
-    // h < 1: the word is 0 or 1; RN is monotonic, so h decides unless it sits exactly on the threshold, where the residual does
-    const bool one = h > t0 || (h == t0 && l >= 0.0f);
-    w = h < 1.0f ? (one ? 1u : 0u) : w;
-    // d >= 65535 <=> v * 65535 >= 65534.5 (representable): the same two-step compare
-    const bool top = h > 65534.5f || (h == 65534.5f && l >= 0.0f);
-    w = top ? 0xffffu : w;
-    return v > 0.0f ? w : 0u;                                   // d < 1 for every v <= 0: word 0; NaN: 0 (the double form gives 32767-ish)
+    return (uint32_t)k + (((u + l) >= 0.0f) ? 1u : 0u);
 }
 }  // namespace avifgpu

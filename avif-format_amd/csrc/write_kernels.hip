@@ -445,8 +445,11 @@ AG_DEV float icc_sampled_curve(const WriteParams& p, int channel, float v)
 AG_DEV float icc_sampled_curve_lds(const uint32_t* __restrict__ pairs, uint32_t domain, float v)
 {
     const uint32_t word = icc_quick_saturate_word(v);
-    const uint32_t x = __umul24(domain, word);                                  // < 2^28
-    const uint32_t val3 = x + (uint32_t)(((uint64_t)(x + 0x7fffu) * 0x80008001ull) >> 47);       // (x + 0x7fff) / 0xffff, exact below 2^32
+    // _cmsToFixedDomain: x + (x + 0x7fff) / 0xffff with x = domain * word < 2^28.  y / 0xffff = (y + (y >> 16) + 1) >> 16 for every
+    // y below 2^28 + 2^15 (tests/test_oracle_properties.py checks the whole range): a multiply-add, two shifts and two three-operand
+    // adds, where the multiply-high form cost a quarter-rate instruction
+    const uint32_t y = __umul24(domain, word) + 0x7fffu;
+    const uint32_t val3 = (y - 0x7fffu) + ((y + (y >> 16) + 1u) >> 16);
     const uint32_t pr = pairs[val3 >> 16];
     const uint32_t y0 = pr & 0xffffu, y1 = pr >> 16;
     const uint32_t dif = (uint32_t)__mul24((int)(y1 - y0), (int)(val3 & 0xffffu)) + 0x8000u;     // 17 x 16 signed bits: the wrapped product

@@ -317,3 +317,12 @@ int main(void) {
     subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", str(exe), str(src), "-lm"], check=True)
     n, bad = map(int, subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split())
     assert (n, bad) == (256 + 1024 + 4096 + 65536, 0)
+
+
+def test_division_by_0xffff_as_two_shifts():
+    """The LDS form of lcms2's LinLerp1D (write_kernels.hip, icc_sampled_curve_lds) takes _cmsToFixedDomain's (x + 0x7fff) / 0xffff as
+    (y + (y >> 16) + 1) >> 16: equal for every y the kernel can form (x = domain * word <= 4095 * 65535)."""
+    top = 4095 * 65535 + 0x7fff + 1
+    for start in range(0, top, 1 << 25):
+        y = np.arange(start, min(top, start + (1 << 25)), dtype=np.uint64)
+        assert np.array_equal(y // np.uint64(0xffff), (y + (y >> np.uint64(16)) + np.uint64(1)) >> np.uint64(16))
