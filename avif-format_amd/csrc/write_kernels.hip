@@ -439,7 +439,7 @@ AG_DEV float icc_sampled_curve(const WriteParams& p, int channel, float v)
 // pairs T[i] | T[i+1] << 16 so that one ds_read_b32 fetches both ends of a segment) and the kernel does what cmsEvalToneCurve16 does for
 // a sampled curve -- LinLerp1D (cmsintrp.c): position = _cmsToFixedDomain(domain * word) = x + (x + 0x7fff) / 0xffff, 15.16; the
 // rounded blend y0 + (((y1 - y0) * rest + 0x8000) >> 16) in unsigned 32-bit wrap-around arithmetic -- then divides the word by 65535
-// as a float (three FMAs that equal (float)(w / 65535.0) for every w: tests/test_gpu_icc.py checks all 65536 against curve[]).
+// as a float (a multiply and an FMA that equal (float)(w / 65535.0) for every w: tests/test_gpu_icc.py checks all 65536 against curve[]).
 // A wave-wide scattered load from memory costs the texture addresser ~64 cycles whatever its locality (profiles/r03/icc6_input_probe.txt);
 // an LDS read of 64 different words a handful.
 AG_DEV float icc_sampled_curve_lds(const uint32_t* __restrict__ pairs, uint32_t domain, float v)
@@ -454,8 +454,10 @@ AG_DEV float icc_sampled_curve_lds(const uint32_t* __restrict__ pairs, uint32_t 
     const uint32_t y0 = pr & 0xffffu, y1 = pr >> 16;
     const uint32_t dif = (uint32_t)__mul24((int)(y1 - y0), (int)(val3 & 0xffffu)) + 0x8000u;     // 17 x 16 signed bits: the wrapped product
     const float w = (float)(((dif >> 16) + y0) & 0xffffu);
-    const float q0 = w * (1.0f / 65535.0f);
-    return __builtin_fmaf(__builtin_fmaf(-q0, 65535.0f, w), 1.0f / 65535.0f, q0);
+    // (float)(w / 65535.0) for an integer w < 2^16: 1 / 65535 = rh + rl (two floats), fma(w, rh, RN(w rl)) -- the low product is below
+    // 2^-25 of the result, so the one rounding that matters is the FMA's (all 65536 w: tests/test_gpu_icc.py against curve[])
+    constexpr float rh = (float)(1.0 / 65535.0), rl = (float)(1.0 / 65535.0 - (double)rh);
+    return __builtin_fmaf(w, rh, w * rl);
 }
 // ... and what follows it: the matrix (and the inverse sRGB curve of a Clip save).  t[] = the curve stage's outputs.
 AG_DEV void icc_apply_sampled(const WriteParams& p, float (&c)[3])

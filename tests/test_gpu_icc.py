@@ -458,7 +458,7 @@ def test_sampled_curve_tables_equal_lcms2_per_word(lcms):
         assert c.shape == (3, 65536) and np.all(np.diff(c, axis=1) >= 0), name
         assert np.all(c[:, 0] == 0.0) and np.all(c[:, 65535] == 1.0), name
         # the profile's own tables ride along, and what the kernel does with them in LDS (icc_sampled_curve_lds: LinLerp1D with the
-        # division by 0xffff as a multiply-shift, then w / 65535 as three single-precision FMAs) returns curve[] bit for bit, every word
+        # division by 0xffff, then w / 65535 as a multiply and an FMA on a two-float reciprocal) returns curve[] bit for bit, every word
         n = list(t.entries)
         assert n == [int(g)] * 3, (name, n)
         w = np.arange(65536, dtype=np.uint64)
@@ -466,17 +466,18 @@ def test_sampled_curve_tables_equal_lcms2_per_word(lcms):
             tab = np.ctypeslib.as_array(t.table16)[ch, :n[ch]].astype(np.uint64)
             pairs = tab | (np.append(tab[1:], tab[-1:]) << np.uint64(16))
             x = np.uint64(n[ch] - 1) * w
-            val3 = x + (((x + np.uint64(0x7fff)) * np.uint64(0x80008001)) >> np.uint64(47))
+            y = x + np.uint64(0x7fff)
+            val3 = (y - np.uint64(0x7fff)) + ((y + (y >> np.uint64(16)) + np.uint64(1)) >> np.uint64(16))      # the kernel's form of the division
             assert np.array_equal(val3, x + (x + np.uint64(0x7fff)) // np.uint64(0xffff))
             pr = pairs[(val3 >> np.uint64(16)).astype(np.int64)]
             y0, y1 = pr & np.uint64(0xffff), pr >> np.uint64(16)
             dif = ((y1.astype(np.int64) - y0.astype(np.int64)) * (val3 & np.uint64(0xffff)).astype(np.int64) + 0x8000) & 0xffffffff
             out16 = ((dif >> 16) + y0.astype(np.int64)) & 0xffff
             wf = out16.astype(np.float32)
-            r = np.float32(1.0) / np.float32(65535.0)
-            q0 = wf * r
+            rh = np.float32(1.0 / 65535.0)
+            rl = np.float32(1.0 / 65535.0 - float(rh))
             fma = lambda a, b, cc: (a.astype(np.float64) * b.astype(np.float64) + cc.astype(np.float64)).astype(np.float32)   # exact product + one rounding
-            got = fma(fma(-q0, np.full_like(q0, 65535.0), wf), np.full_like(q0, r), q0)
+            got = fma(wf, np.full_like(wf, rh), wf * rl)
             assert np.array_equal(got.view(np.uint32), c[ch].view(np.uint32)), (name, ch)
     # an all-parametric profile is not "sampled"; a non-profile is rejected
     icc = _profile(lcms, 1, 2, 1.8)
