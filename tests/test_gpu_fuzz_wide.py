@@ -3,6 +3,8 @@ thousand pixels, random small heights, every row padded to 16 bytes (what libhei
 random even-row tile split.  tests/test_gpu_fuzz.py covers the small / unaligned geometries; this one the ragged last spans, the
 one ragged lane of a row, odd heights under 4:2:0 and the tile cuts of the kernels the real documents run on.  Oracle on the same
 bytes, same bars as the parity tests.  The size-gated streaming kernels are forced on (tuning-word bit 3)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -11,6 +13,7 @@ from test_gpu_u8_fast_path import align
 
 pkg = harness.pkg
 pytestmark = pytest.mark.gpu
+FUZZ_N = int(os.environ.get("AVIFGPU_FUZZ_N", "160"))      # a soak run: AVIFGPU_FUZZ_N=3000 (3 min on one MI355X)
 
 
 def gpu_write_padded(gpu, desc, src, row0, nrows):
@@ -57,7 +60,7 @@ def _case(i):
     return kw, cut
 
 
-@pytest.mark.parametrize("i", range(160))
+@pytest.mark.parametrize("i", range(FUZZ_N))
 def test_write_fuzz_wide_aligned(gpu, i):
     kw, cut = _case(i)
     d = pkg.WriteDesc(**kw)
@@ -98,7 +101,7 @@ def _read_case(i):
     return kw
 
 
-@pytest.mark.parametrize("i", range(160))
+@pytest.mark.parametrize("i", range(FUZZ_N))
 def test_read_fuzz_wide_aligned(gpu, i):
     import cases
     from test_gpu_read import _check
