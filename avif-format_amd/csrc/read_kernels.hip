@@ -216,8 +216,14 @@ AG_DEV void decode_pixel(const ReadParams& p, const Tables<LUT>& t, uint32_t u0,
             // The reference skips fully opaque pixels (ua == max); the formula returns the colour unchanged there anyway
             // (c*max/max == c exactly), so only the ua == 0 case needs a select -- no data-dependent branch.
             if (p.premultiplied) {
+                if (DEPTH == 8 || p.maxc <= 4095) {                 // (uniform) the verified domain: one reciprocal for the pixel
+                    const float af = (float)ua, r = 1.0f / af, maxf = (float)p.maxc;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { const uint32_t u = exact_unpremultiply(q[k], ua, (float)p.maxc); q[k] = (ua == 0) ? 0u : u; }
+                    for (int k = 0; k < 3; ++k) { const uint32_t u = exact_unpremultiply_r(q[k], af, r, maxf); q[k] = (ua == 0) ? 0u : u; }
+                } else if constexpr (DEPTH != 8) {                  // 16-bit planes
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { const uint32_t u = exact_unpremultiply(q[k], ua, (float)p.maxc); q[k] = (ua == 0) ? 0u : u; }
+                }
             }
         }
         if constexpr (DEPTH == 32) {
