@@ -167,14 +167,14 @@ AG_DEV float div_by_kg(const ReadParams& p, float x)
 // PremultipliedAlpha.cpp:72-75 / YuvDecode.cpp:383-387.  One IEEE reciprocal r = RN(1/A) per pixel, then each quotient
 // in 3 FMAs: tools/divcheck_unpremul_f.hip proved that form equal to IEEE c / A (after the min) for every alpha code of
 // 8/10/12-bit images and EVERY float c in {0} U [2^-64, 1] (2.2e12 pairs, profiles/r01/divcheck_unpremul_f.txt).
-// A colour outside that domain (cannot arise from table values, kept for rigour) takes the IEEE quotient.
+// A colour outside that domain cannot arise: c is the clamped sum or difference of two floats that are each 0 or at least 1e-5 in
+// magnitude (a table value i / max, a coefficient times (j / max - 1/2), the quotient by Kg of such terms) -- such a sum is 0 or at
+// least an ulp of the smaller operand, 2^-40, twenty-four binades above the domain's lower end.  Round 4 dropped the guard that sent
+// "other" colours through an IEEE division (two compares and a branch per colour, and the division's registers).
 AG_DEV float unpremultiply_one(float c, float A, float r)
 {
-    if (__builtin_expect(c == 0.0f || c >= 5.5e-20f, 1)) {
-        const float q0 = c * r;
-        return cxx_min(__builtin_fmaf(__builtin_fmaf(-q0, A, c), r, q0), 1.0f);
-    }
-    return cxx_min(ieee_div_slow(c, A), 1.0f);
+    const float q0 = c * r;
+    return cxx_min(__builtin_fmaf(__builtin_fmaf(-q0, A, c), r, q0), 1.0f);
 }
 
 // std::clamp(v, 0, 1) for the finite values this path produces (v_med3_f32; a NaN cannot arise from table values).
