@@ -389,6 +389,13 @@ AG_DEV uint32_t exact_unpremultiply(uint32_t color, uint32_t alpha, float maxf)
     const float v = cxx_min((float)color * maxf / (float)alpha, maxf);
     return (uint32_t)cxx_min(roundf(v), maxf);
 }
+// RN(1 / A) for an alpha: v_rcp_f32 and one Newton step -- equal to the IEEE reciprocal for every alpha of 8-, 10- and 12-bit images,
+// as the table value a / max and as the code a itself (tools/rcpcheck_alpha.hip: all 3 x 5373 values) -- 3 instructions for ~10.
+AG_DEV float alpha_reciprocal(float A)
+{
+    const float r0 = __builtin_amdgcn_rcpf(A);
+    return __builtin_fmaf(r0, __builtin_fmaf(-A, r0, 1.0f), r0);
+}
 // The same value for the colours of one pixel from ONE IEEE reciprocal: x = color * max is exact (< 2^24), q = x / alpha in three
 // FMAs, and round() of the clamped non-negative quotient is a truncating conversion of q + 0.5.  Equal to exact_unpremultiply for
 // every (color, alpha) of 8-, 10- and 12-bit images (tools/divcheck_unpremul_i.hip: 17.9 M pairs, profiles/r04/divcheck_unpremul_i.txt);

@@ -217,7 +217,7 @@ AG_DEV void decode_pixel(const ReadParams& p, const Tables<LUT>& t, uint32_t u0,
             // (c*max/max == c exactly), so only the ua == 0 case needs a select -- no data-dependent branch.
             if (p.premultiplied) {
                 if (DEPTH == 8 || p.maxc <= 4095) {                 // (uniform) the verified domain: one reciprocal for the pixel
-                    const float af = (float)ua, r = 1.0f / af, maxf = (float)p.maxc;
+                    const float af = (float)ua, r = alpha_reciprocal(af), maxf = (float)p.maxc;
 #pragma unroll
                     for (int k = 0; k < 3; ++k) { const uint32_t u = exact_unpremultiply_r(q[k], af, r, maxf); q[k] = (ua == 0) ? 0u : u; }
                 } else if constexpr (DEPTH != 8) {                  // 16-bit planes
@@ -281,7 +281,7 @@ AG_DEV void decode_pixel(const ReadParams& p, const Tables<LUT>& t, uint32_t u0,
                     const float A = look_a(p, t, ua);
                     float uR, uG, uB;
                     if constexpr (LUT) {                            // bits <= 12: the proven domain
-                        const float r = 1.0f / A;
+                        const float r = alpha_reciprocal(A);
                         uR = unpremultiply_one(R, A, r); uG = unpremultiply_one(G, A, r); uB = unpremultiply_one(B, A, r);
                     } else {
                         uR = exact_unpremultiply_f(R, A); uG = exact_unpremultiply_f(G, A); uB = exact_unpremultiply_f(B, A);
@@ -366,7 +366,7 @@ AG_DEV void decode_ycc8_packed(const ReadParams& p, const Tables<LUT>& t, int i,
         if (p.premultiplied) {                                                          // :369-388, as decode_pixel
             R = clamp01(R); G = clamp01(G); B = clamp01(B);
             const float A = look_a(p, t, ua);
-            const float r = 1.0f / A;
+            const float r = alpha_reciprocal(A);
             const float uR = unpremultiply_one(R, A, r), uG = unpremultiply_one(G, A, r), uB = unpremultiply_one(B, A, r);
             R = (ua == 0) ? 0.0f : uR; G = (ua == 0) ? 0.0f : uG; B = (ua == 0) ? 0.0f : uB;
         }
