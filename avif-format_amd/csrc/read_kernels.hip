@@ -250,7 +250,9 @@ AG_DEV void decode_pixel(const ReadParams& p, const Tables<LUT>& t, uint32_t u0,
             if constexpr (DEPTH == 32) {
                 if constexpr (ALPHA) {
                     if (p.premultiplied) {                          // integer-domain unpremultiply, :247-260 (ua == max: identity)
-                        const uint32_t u = exact_unpremultiply(u0, ua, (float)p.maxc);
+                        const float af = (float)ua;
+                        const uint32_t u = p.maxc <= 4095 ? exact_unpremultiply_r(u0, af, alpha_reciprocal(af), (float)p.maxc)
+                                                          : exact_unpremultiply(u0, ua, (float)p.maxc);      // (16-bit planes)
                         u0 = (ua == 0) ? 0u : u;
                     }
                 }
