@@ -571,15 +571,32 @@ AG_DEV void wave_span_load(uint32_t* strip, int lane, const uint8_t* span, int s
     __builtin_amdgcn_wave_barrier();
 }
 
-// lane-major registers --> LDS --coalesced NT stores--> global (contiguous span, `span_bytes` valid)
+// lane-major registers --> LDS --coalesced NT stores--> global (contiguous span, `span_bytes` valid), in two steps: a lane may
+// hand its NDW dwords over in PARTS (dwords [first, first + COUNT) of its footprint, COUNT a multiple of the transfer width) as it
+// produces them -- the f32 opens decode, curve and park half a footprint at a time, which is what keeps them under 100 VGPRs --
+// and wave_span_flush sends the strip out.
+template <int NDW, int COUNT>
+AG_DEV void wave_span_put_part(uint32_t* strip, int lane, bool active, const uint32_t (&in)[COUNT], int first)
+{
+    constexpr int VW = WaveSpan<NDW>::VW;
+    static_assert(COUNT % VW == 0, "whole transfers");
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < COUNT / VW; ++j) lds_put<VW>(strip + lane * WaveSpan<NDW>::STRIDE + first + j * VW, &in[j * VW]);
+    }
+}
+template <int NDW>
+AG_DEV void wave_span_flush(uint32_t* strip, int lane, uint8_t* span, int span_bytes);
 template <int NDW>
 AG_DEV void wave_span_store(uint32_t* strip, int lane, bool active, const uint32_t (&in)[NDW], uint8_t* span, int span_bytes)
 {
+    wave_span_put_part<NDW, NDW>(strip, lane, active, in, 0);
+    wave_span_flush<NDW>(strip, lane, span, span_bytes);
+}
+template <int NDW>
+AG_DEV void wave_span_flush(uint32_t* strip, int lane, uint8_t* span, int span_bytes)
+{
     constexpr int VW = WaveSpan<NDW>::VW, NTR = WaveSpan<NDW>::NTR;
-    if (active) {
-#pragma unroll
-        for (int j = 0; j < NTR; ++j) lds_put<VW>(strip + lane * WaveSpan<NDW>::STRIDE + j * VW, &in[j * VW]);
-    }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int j = 0; j < NTR; ++j) {

@@ -458,6 +458,9 @@ __global__ __launch_bounds__(256) void build_read_tables(const ReadParams p, flo
 #ifndef AG_READ_PREFETCH
 #define AG_READ_PREFETCH 0
 #endif
+#ifndef AG_READ_HALVES
+#define AG_READ_HALVES 1
+#endif
 // Which full-range configurations are decoded WITHOUT tables (an entry is unorm_to_float(code), three FMAs): measured per row
 // (profiles/r03/read_table_free_ab.txt, two interleaved passes on one box).  It pays where the lookups were a large share of a small
 // kernel or the table was large: 10/12-bit -> 16-bit hosts, gray (12-bit 0.651 -> 0.805 of 8 TB/s) and 4:4:4 (+6 % at 12 bit), and
@@ -687,6 +690,35 @@ __global__ __launch_bounds__(AG_RPX_BLOCK) void read_px(const ReadParams p)
                 arow[d] = ALPHA ? (vr == 0 ? cur.a[0][d] : cur.a[ALPHA ? VR - 1 : 0][d]) : 0u;
                 g1row[d] = CS == kCsRgb ? (vr == 0 ? cur.g1[0][d] : cur.g1[CS == kCsRgb ? VR - 1 : 0][d]) : 0u;
                 g2row[d] = CS == kCsRgb ? (vr == 0 ? cur.g2[0][d] : cur.g2[CS == kCsRgb ? VR - 1 : 0][d]) : 0u;
+            }
+            // YCbCr -> f32 hosts: half a footprint at a time -- decode, curve, park in the strip -- so that only HP * NCH outputs are live
+            // (the whole row at once: 99-122 VGPRs on the 4:2:x footprints, 4 waves per SIMD, and the kernels wait on data half their time)
+            constexpr bool HALVES = AG_READ_HALVES && CS == kCsYcc && DEPTH == 32 && ALIGNED && ND_OUT > 4 && !TWIN && PXT % 4 == 0 && (PXT / 2 * NCH) % 4 == 0;   // (the 4:2:x footprints: 4:4:4 sits at 60-66 VGPRs as it is)
+            if constexpr (HALVES) {
+                constexpr int HP = PXT / 2;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    uint32_t oh[HP * NCH];
+                    if (active) {
+#pragma unroll
+                        for (int i = 0; i < HP; ++i) {
+                            const int ii = hh * HP + i;
+                            const uint32_t yv = sample_of<SRC16>(yrow, ii);
+                            const uint32_t av = ALPHA ? sample_of<SRC16>(arow, ii) : (uint32_t)p.maxc;
+                            if constexpr (XS + YS > 0)
+                                decode_pixel<CS, DEPTH, ALPHA, TRANSFER, LUT, ROW_EOTF>(p, t, yv, 0, 0, av, &oh[i * NCH], ct[ii >> XS]);
+                            else
+                                decode_pixel<CS, DEPTH, ALPHA, TRANSFER, LUT, ROW_EOTF>(p, t, yv, 0, 0, av, &oh[i * NCH],
+                                                                              chroma_terms<DEPTH, LUT>(p, t, sample_of<SRC16>(cur.c1, ii), sample_of<SRC16>(cur.c2, ii)));
+                        }
+                        if constexpr (ROW_EOTF) eotf_row_pq<HP, NCH>(p, oh);
+                    }
+                    wave_span_put_part<ND_OUT, HP * NCH>(strip, lane, active, oh, hh * HP * NCH);
+                    __builtin_amdgcn_sched_barrier(0);                 // the second half's arithmetic stays behind the first half's hand-over
+                }
+                const int span_px = min(64 * PXT, p.width - wx * 64 * PXT);
+                wave_span_flush<ND_OUT>(strip, lane, p.dst + (long long)r * p.dst_row_bytes + (long long)wx * (64 * PXT * NCH * OSZ), span_px * NCH * OSZ);
+                continue;
             }
             if constexpr (TWIN) {
 #pragma unroll
