@@ -1,4 +1,8 @@
+#!/bin/bash
+# Wave-cycle accounting of chosen rows (waiting on data / waiting for an issue slot / LDS bank conflicts): one --pmc pass per counter pair.
+#   tools/gpu/r04_pmc_reads.sh OUT.json "row substring" ...
 mkdir -p gpurun_out/r04
 export BENCH_TWIN=0
-PMC_GROUPS="SQ_WAVE_CYCLES,SQ_BUSY_CYCLES;SQ_WAIT_INST_ANY,SQ_WAIT_ANY;SQ_ACTIVE_INST_VALU,SQ_ACTIVE_INST_LDS;SQ_INSTS_LDS,SQ_LDS_BANK_CONFLICT;SQ_WAIT_INST_LDS,SQ_LDS_IDX_ACTIVE;SQ_INSTS_VALU,SQ_INSTS_SALU;SQ_ACTIVE_INST_VMEM,SQ_INST_CYCLES_VMEM_RD;SQ_ACTIVE_INST_SCA,SQ_ACTIVE_INST_MISC;SQ_LDS_ADDR_CONFLICT,SQ_LDS_UNALIGNED_STALL;SQ_INSTS_VMEM_RD,SQ_INSTS_VMEM_WR;SQ_IFETCH,SQ_IFETCH_LEVEL" \
-  python tools/gpu/pmc_rows.py gpurun_out/r04/pmc_reads_hdr.json "D12 8192^2 12-bit 4:2:2" "R32 8192^2 12-bit 4:2:0 BT.2020 PQ + alpha" "R32 8192^2 10-bit 4:4:4" "D12 8192^2 RGB f32 -> 12-bit PQ 4:2:2 nearest" > gpurun_out/r04/pmc_reads_hdr.log 2>&1
+out=$1; shift
+PMC_GROUPS="SQ_WAVE_CYCLES,SQ_BUSY_CYCLES;SQ_WAIT_INST_ANY,SQ_WAIT_ANY;SQ_ACTIVE_INST_VALU,SQ_ACTIVE_INST_LDS;SQ_INSTS_LDS,SQ_LDS_BANK_CONFLICT;SQ_WAIT_INST_LDS,SQ_LDS_IDX_ACTIVE;SQ_INSTS_VALU,SQ_INSTS_SALU" \
+  python tools/gpu/pmc_rows.py "$out" "$@" > "${out%.json}.log" 2>&1
