@@ -615,7 +615,8 @@ int fill_read_params(const avifgpu_read_desc* d, int nrows, const ReadGeom& g, R
     if (getenv("AVIFGPU_FORCE_IEEE_DIV")) p.fast_div = 0;        // test hook: exercise the fallback
     p.rcp_kg = 1.0f / p.kg;
     p.maxcf = (float)p.maxc;
-    p.rcp_maxc = 1.0f / p.maxcf;
+    p.rcp_maxc = (float)(1.0 / (double)p.maxc);
+    p.rcp_maxc_lo = (float)(1.0 / (double)p.maxc - (double)p.rcp_maxc);
     if (d->depth == 32) {
         p.pq_mult = 10000.0f / (float)(d->pq_peak_nits > 0 ? d->pq_peak_nits : 1);                                 // ColorTransfer.cpp:114
         p.pq_log2_mult = (float)std::log2((double)p.pq_mult);

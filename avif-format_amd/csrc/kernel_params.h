@@ -99,6 +99,7 @@ struct ReadParams {
     int32_t maxc;                // 2^bits - 1
     float   maxcf;               // (float)maxc
     float   rcp_maxc;            // RN(1 / maxcf): unorm_to_float in read_kernels.hip
+    float   rcp_maxc_lo;         // RN(1 / maxc - rcp_maxc): the low half of the two-float reciprocal
     int32_t full_range;          // effective (nclx ? flag : 1)
     int32_t identity_lut;        // colour image with GBR matrix: T_UV = T_Y (YuvLookupTables.cpp:177-180)
     int32_t premultiplied;

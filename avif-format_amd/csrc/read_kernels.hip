@@ -51,15 +51,15 @@ AG_DEV int lim2full_uv(int bits, int v)
     }
 }
 
-// (float)u / (float)maxc -- the one division every table entry is made of (YuvLookupTables.cpp:171,182,188) -- in three FMAs:
-// q0 = u * RN(1/max), q = fma(fma(-q0, max, u), RN(1/max), q0).  For max = 255, 1023, 4095 and 65535 (the only values there are)
-// this equals the IEEE quotient for EVERY u in [0, max]: tests/test_oracle_properties.py::test_unorm_division_is_exact runs the
-// same C expression over all 70 914 inputs.  It is what lets a full-range image be decoded with no table at all (below).
+// (float)u / (float)maxc -- the one division every table entry is made of (YuvLookupTables.cpp:171,182,188) -- as a multiply and an
+// FMA on a two-float reciprocal: 1 / max = rh + rl, q = fma(u, rh, RN(u rl)).  The low product is below 2^-24 of the quotient, so
+// the FMA's rounding is the only one that counts.  For max = 255, 1023, 4095 and 65535 (the only values there are) this equals the
+// IEEE quotient for EVERY u in [0, max]: tests/test_oracle_properties.py::test_unorm_division_is_exact runs the same C expression
+// over all 70 914 inputs.  It is what lets a full-range image be decoded with no table at all (below).  (Round 3: three FMAs.)
 AG_DEV float unorm_to_float(const ReadParams& p, int u)
 {
     const float x = (float)u;
-    const float q0 = x * p.rcp_maxc;
-    return __builtin_fmaf(__builtin_fmaf(-q0, p.maxcf, x), p.rcp_maxc, q0);
+    return __builtin_fmaf(x, p.rcp_maxc, x * p.rcp_maxc_lo);
 }
 // Table formulas, reference YuvLookupTables.cpp:157-190 (and ReadHeifImage.cpp:402-415 for the alpha form).
 AG_DEV float table_y(const ReadParams& p, int i)
@@ -470,13 +470,17 @@ __global__ __launch_bounds__(256) void build_read_tables(const ReadParams p, flo
 #ifndef AG_READ_ARITH
 #define AG_READ_ARITH 1
 #endif
-template <int CS, int DEPTH, bool ALPHA, int XS> constexpr bool read_arith_policy()
+// Round 4 (the entry is a multiply and an FMA now, and the f32 4:2:2 open runs at 82 VGPRs): measured again per row
+// (profiles/r04/read_table_free_ab_r04.txt) -- 8-bit gray joins (-6 %) and the f32 4:2:2 open without alpha (-4 %: what the default
+// HDR save decodes to); the 8-bit colour opens without alpha still lose 6-9 %, the other f32 hosts 0-3 %.
+template <int CS, int DEPTH, bool ALPHA, int XS, int YS = 0> constexpr bool read_arith_policy()
 {
     if (AG_READ_ARITH == 0) return false;
     if (CS == kCsRgb && DEPTH == 32) return false;          // EOTF per code lives in its table
     if (AG_READ_ARITH == 2) return true;
     if (DEPTH == 16) return CS == kCsMono || (CS == kCsYcc && XS == 0 && !ALPHA);
-    if (DEPTH == 8) return CS == kCsYcc && ALPHA && XS == 1;
+    if (DEPTH == 8) return (CS == kCsYcc && ALPHA && XS == 1) || (CS == kCsMono && !ALPHA);
+    if (DEPTH == 32) return CS == kCsYcc && XS == 1 && YS == 0 && !ALPHA;
     return false;
 }
 #ifndef AG_R8_NC
@@ -887,15 +891,15 @@ static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, char* lab
     snprintf(label, kLabelBytes, "read_px<cs=%d,depth=%d,alpha=%d,xs=%d,ys=%d,transfer=%d,aligned=%d>", CS, DEPTH, (int)ALPHA, XS, YS,
              TRANSFER, (int)aligned);
     ReadParams q = p;
-    const bool arith = p.full_range && p.bits <= 12 && read_arith_policy<CS, DEPTH, ALPHA, XS>();
-    if (lut_bytes && !arith) {
+    const bool arith = p.full_range && p.bits <= 12 && read_arith_policy<CS, DEPTH, ALPHA, XS, YS>();
+    if (lut_bytes && (!arith || p.twin)) {                    // (the twin keeps the table copy of the tabled form: the heavier pattern)
         const hipError_t e = cached_tables<CS, DEPTH, ALPHA, TRANSFER>(p, st, &q.tables);
         if (e != hipSuccess) return e;
     }
 #define AG_READ_LAUNCH(LUT_, AL_) hipLaunchKernelGGL((read_px<CS, DEPTH, ALPHA, XS, YS, TRANSFER, LUT_, AL_>), dim3((int)blocks), dim3(AG_RPX_BLOCK), LUT_ ? lds : lds - lut_bytes, st, q)
     if (p.twin) {                                            // avifgpu_probe_pattern_read: the math-free twin of the launch below
         if constexpr (CS == kCsYcc && !ALPHA && XS == 1 && (DEPTH == 8 || (DEPTH == 32 && TRANSFER == AVIFGPU_TRANSFER_PQ))) {
-            if (!aligned || arith || !(DEPTH == 8 || p.bits <= 12)) return hipErrorInvalidValue;
+            if (!aligned || !(DEPTH == 8 || p.bits <= 12)) return hipErrorInvalidValue;
             snprintf(label + strlen(label), kLabelBytes - strlen(label), " TWIN");
             hipLaunchKernelGGL((read_px<CS, DEPTH, ALPHA, XS, YS, TRANSFER, true, true, true>), dim3((int)blocks), dim3(AG_RPX_BLOCK), lds, st, q);
             return hipGetLastError();
@@ -906,7 +910,7 @@ static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, char* lab
     // table-free decode (read_arith_policy): full range only -- limited range keeps its tables (an integer division per entry)
     if (arith) snprintf(label + strlen(label), kLabelBytes - strlen(label), " tables=none");
     if constexpr (DEPTH == 8) {
-        if constexpr (read_arith_policy<CS, DEPTH, ALPHA, XS>()) {            // (instantiated only where the policy can choose it)
+        if constexpr (read_arith_policy<CS, DEPTH, ALPHA, XS, YS>()) {        // (instantiated only where the policy can choose it)
             if (arith) { if (aligned) AG_READ_LAUNCH(false, true); else AG_READ_LAUNCH(false, false); return hipGetLastError(); }
         }
         if (aligned) AG_READ_LAUNCH(true, true); else AG_READ_LAUNCH(true, false);

@@ -291,7 +291,7 @@ def test_cpu_baseline_structures_equal_whole_frame(oracle, chroma, down):
 
 
 def test_unorm_division_is_exact(tmp_path):
-    """read_kernels.hip::unorm_to_float: (float)u / (float)max as q0 = u * RN(1/max), q = fma(fma(-q0, max, u), RN(1/max), q0) equals the
+    """read_kernels.hip::unorm_to_float: (float)u / (float)max as fma(u, rh, RN(u * rl)) with 1 / max = rh + rl (two floats) equals the
     IEEE quotient for every u in [0, max] and max in {255, 1023, 4095, 65535} -- every entry of every table of
     YuvLookupTables.cpp:157-190 / ReadHeifImage.cpp:402-415.  The same C expression (fmaf is exact), all 70 914 inputs."""
     import subprocess
@@ -303,9 +303,10 @@ int main(void) {
     const int maxes[4] = { 255, 1023, 4095, 65535 };
     int bad = 0, n = 0;
     for (int m = 0; m < 4; ++m) {
-        const float mx = (float)maxes[m], r = 1.0f / mx;
+        const float mx = (float)maxes[m];
+        const float rh = (float)(1.0 / (double)maxes[m]), rl = (float)(1.0 / (double)maxes[m] - (double)rh);
         for (int i = 0; i <= maxes[m]; ++i, ++n) {
-            const float x = (float)i, q0 = x * r, q = fmaf(fmaf(-q0, mx, x), r, q0);
+            const float x = (float)i, q = fmaf(x, rh, x * rl);
             if (q != x / mx) ++bad;
         }
     }
