@@ -121,3 +121,18 @@ def test_hlg_ootf_black_pixels_gamma_one(gpu):
             _check("hlg-black", dict(depth=32), got, want)
             if cs == pkg.COLORSPACE_RGB:
                 assert np.all(got.reshape(H, W, 3)[:, :32] == 0)
+
+
+@pytest.mark.parametrize("tool,needle", [("divcheck_unpremul_i", "differing results 0"), ("rcpcheck_alpha", "differ from IEEE 1/A: 0")])
+def test_unpremultiply_claims_hold_on_this_device(tool, needle):
+    """The two device-side proofs behind the premultiplied-alpha opens (read_kernels.hip, device_math.h): the integer-domain unpremultiply
+    from one reciprocal per pixel equals the reference's float expression for every (colour, alpha) pair of 8-, 10- and 12-bit images
+    (tools/divcheck_unpremul_i), and that reciprocal -- v_rcp_f32 + one Newton step -- equals IEEE 1 / A for every alpha
+    (tools/rcpcheck_alpha).  Built by the package Makefile with hipcc."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", tool)
+    if not os.path.exists(exe):
+        pytest.skip(f"tools/{tool} not built (make -C avif-format_amd)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.count(needle) == 3, r.stdout + r.stderr
