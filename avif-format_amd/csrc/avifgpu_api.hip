@@ -171,7 +171,10 @@ struct IccDeviceTables {
     void* s32 = nullptr;   std::vector<uint8_t> s32_host;      // 3 x 65536 floats: sampled curves of a 32-bit document
     // the caller's table of the last upload and a fingerprint of it: a tile that passes the same struct again (every tile of an image
     // does) skips the byte-for-byte comparison of 216-792 KiB under g_icc_mu.  A prepared table is immutable while it is in use
-    // (include/avifgpu.h); the fingerprint -- 4096 strided words -- is the guard against a caller that rewrites one in place anyway.
+    // (include/avifgpu.h); the fingerprint -- 4096 strided words -- is the guard against a caller that rewrites one in place anyway,
+    // and it is trusted WITHIN an image only: the tile that starts at row 0 always takes the full comparison (round 5, ADVICE r04: a
+    // caller may legally rewrite or reallocate a table at the same address between two saves, and a change the stride misses -- 32
+    // consecutive floats of a 4096-entry curve -- would otherwise keep the stale device copy).
     const void* s32_src = nullptr;   uint64_t s32_fp = 0;
     const void* icc16_src = nullptr; uint64_t icc16_fp = 0;
 };
@@ -214,7 +217,7 @@ int upload_icc_pow_table(WriteParams& p)
     return 0;
 }
 
-int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p)
+int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p, bool first_rows)
 {
     if (t->grid_points != AVIFGPU_ICC_CLUT_GRID) return fail(AVIFGPU_formatBadParameters, "16-bit ICC table: grid_points must be 33");
     const size_t n = sizeof(t->table);
@@ -237,7 +240,7 @@ int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p)
         if (e != hipSuccess) { c.icc16 = nullptr; return hip_fail(e, "hipMalloc(icc16 table)", AVIFGPU_memFullErr); }
     }
     const uint64_t fp = table_fingerprint(t->table, n);
-    const bool same_call = c.icc16_src == t && c.icc16_fp == fp && c.icc16_host.size() == n;
+    const bool same_call = !first_rows && c.icc16_src == t && c.icc16_fp == fp && c.icc16_host.size() == n;
     if (!same_call && (c.icc16_host.size() != n || memcmp(c.icc16_host.data(), t->table, n) != 0)) {
         std::vector<uint16_t> rec(rec_bytes / 2, 0);
 #if AG_ICC16_DOT2 == 2
@@ -290,7 +293,7 @@ int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p)
     return 0;
 }
 
-int upload_icc_sampled(const avifgpu_icc_sampled32* t, WriteParams& p)
+int upload_icc_sampled(const avifgpu_icc_sampled32* t, WriteParams& p, bool first_rows)
 {
     // curve[] (768 KiB) followed by table16[] (24 KiB): one device buffer, one upload when the profile changes
     const size_t nc = sizeof(t->curve), nt = sizeof(t->table16), n = nc + nt;
@@ -309,7 +312,7 @@ int upload_icc_sampled(const avifgpu_icc_sampled32* t, WriteParams& p)
     const uint8_t* host = reinterpret_cast<const uint8_t*>(t->curve);        // curve[] and table16[] are adjacent members
     static_assert(offsetof(avifgpu_icc_sampled32, table16) == offsetof(avifgpu_icc_sampled32, curve) + sizeof(t->curve), "one span");
     const uint64_t fp = table_fingerprint(host, n);
-    if (!(c.s32_src == t && c.s32_fp == fp && c.s32_host.size() == n) && (c.s32_host.size() != n || memcmp(c.s32_host.data(), host, n) != 0)) {
+    if (!(!first_rows && c.s32_src == t && c.s32_fp == fp && c.s32_host.size() == n) && (c.s32_host.size() != n || memcmp(c.s32_host.data(), host, n) != 0)) {
         e = hipDeviceSynchronize();                             // a launch may still be reading the previous curves
         if (e == hipSuccess) e = hipMemcpy(c.s32, host, n, hipMemcpyHostToDevice);
         if (e != hipSuccess) return hip_fail(e, "upload of the sampled ICC curves", AVIFGPU_writErr);
@@ -437,7 +440,7 @@ int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const Wr
         if (d->depth != 32 || d->planes < 3) return fail(AVIFGPU_formatBadParameters, "the ICC row transform applies to 32-bit RGB(A) documents");
         if (icc.s32) {
             // sampled curves: the curve stage is the device table; the matrix / output curve below are shared with the parametric form
-            const int rc = upload_icc_sampled(icc.s32, p);
+            const int rc = upload_icc_sampled(icc.s32, p, row0 == 0);
             if (rc) return rc;
         }
         for (int c = 0; c < 3; ++c) {
@@ -492,7 +495,7 @@ int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const Wr
     }
     if (g_icc16) {
         if (d->depth != 16 || d->planes < 3) return fail(AVIFGPU_formatBadParameters, "the 16-bit ICC table applies to 16-bit RGB(A) documents");
-        const int rc = upload_icc16(g_icc16, p);
+        const int rc = upload_icc16(g_icc16, p, row0 == 0);
         if (rc) return rc;
     }
     if (g_icc8) {
@@ -529,6 +532,13 @@ int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const Wr
             p.mcb[0] = -kr / (1.0f - kb) / 2.0f; p.mcb[1] = -kg / (1.0f - kb) / 2.0f; p.mcb[2] = 0.5f;
             p.mcr[0] = 0.5f;                     p.mcr[1] = -kg / (1.0f - kr) / 2.0f; p.mcr[2] = -kb / (1.0f - kr) / 2.0f;
         }
+        // The streaming kernels form luma without the upper clip (luma_code_nc / luma_pair_nc, write_kernels.hip): that is only the
+        // reference's value while the luma row is a convex combination -- non-negative weights that sum to 1 within float rounding.  Every
+        // matrix derived above is; a limited-range or scaled luma row added later must not get past this line silently.
+        const float ysum = p.my[0] + p.my[1] + p.my[2];
+        if (!(p.my[0] >= 0.0f && p.my[1] >= 0.0f && p.my[2] >= 0.0f && ysum <= 1.0f + 1e-6f))
+            return fail(AVIFGPU_formatBadParameters, "luma coefficients %g %g %g are not a convex combination: the unclipped luma of the streaming kernels does not apply",
+                        (double)p.my[0], (double)p.my[1], (double)p.my[2]);
     }
     (void)g;
     return 0;

@@ -420,6 +420,23 @@ AG_DEV uint32_t clip_round(float v, int maxi)
     return x > (uint32_t)maxi ? (uint32_t)maxi : x;
 }
 
+// ---- AG_MATH_ONLY: the MEMORY-FREE twin of every kernel (a measuring build, never the product) ----------------------------------
+// Built with -DAG_MATH_ONLY=1 (tools/ab_variants.sh ... mathonly) every global load of the pixel streams yields whatever its
+// destination registers hold and every global store is dropped -- no instruction is emitted for either -- while everything else a
+// kernel does stays: address arithmetic, curves, LDS tables and transposes, table gathers (their indices are clamped before use), the
+// launch itself.  What such a kernel takes is the COMPUTE side of the real one measured on the device, the counterpart of the math-free
+// twins (pattern_probe.hip, read_px<..., TWIN>): tools/bench_configs.py run against that library prints the roof a `valu`-bound row
+// is read against (column "math only").  The outputs of such a build are garbage by construction.
+#ifndef AG_MATH_ONLY
+#define AG_MATH_ONLY 0
+#endif
+template <typename V> AG_DEV V mo_value() { V v; asm volatile("; math-only build: load elided" : "=v"(v)); return v; }
+template <typename V> AG_DEV void mo_sink(V v) { asm volatile("; math-only build: store elided" :: "v"(v)); }
+template <typename V> AG_DEV V g_load(const V* p) { if constexpr (AG_MATH_ONLY) return mo_value<V>(); else return *p; }
+template <typename V> AG_DEV V g_load_nt(const V* p) { if constexpr (AG_MATH_ONLY) return mo_value<V>(); else return __builtin_nontemporal_load(p); }
+template <typename V> AG_DEV void g_store(V v, V* p) { if constexpr (AG_MATH_ONLY) mo_sink(v); else *p = v; }
+template <typename V> AG_DEV void g_store_nt(V v, V* p) { if constexpr (AG_MATH_ONLY) mo_sink(v); else __builtin_nontemporal_store(v, p); }
+
 // ---- vector load/store of ND dwords at a runtime-aligned address --------------------------------
 AG_DEV uint32_t ld_u8(const uint8_t* p)  { return *p; }
 AG_DEV uint32_t ld_u16(const uint8_t* p) { return *reinterpret_cast<const uint16_t*>(p); }
@@ -443,8 +460,8 @@ AG_DEV void load_dwords(const uint8_t* p, uint32_t (&d)[ND])
 #pragma unroll
             for (int j = 0; j < ND / 4; ++j) {
                 dm_u32x4 v;
-                if constexpr (NT) v = __builtin_nontemporal_load(reinterpret_cast<const dm_u32x4*>(p) + j);
-                else v = reinterpret_cast<const dm_u32x4*>(p)[j];
+                if constexpr (NT) v = g_load_nt(reinterpret_cast<const dm_u32x4*>(p) + j);
+                else v = g_load(reinterpret_cast<const dm_u32x4*>(p) + j);
                 d[4 * j] = v.x; d[4 * j + 1] = v.y; d[4 * j + 2] = v.z; d[4 * j + 3] = v.w;
             }
             return;
@@ -455,8 +472,8 @@ AG_DEV void load_dwords(const uint8_t* p, uint32_t (&d)[ND])
 #pragma unroll
             for (int j = 0; j < ND / 2; ++j) {
                 dm_u32x2 v;
-                if constexpr (NT) v = __builtin_nontemporal_load(reinterpret_cast<const dm_u32x2*>(p) + j);
-                else v = reinterpret_cast<const dm_u32x2*>(p)[j];
+                if constexpr (NT) v = g_load_nt(reinterpret_cast<const dm_u32x2*>(p) + j);
+                else v = g_load(reinterpret_cast<const dm_u32x2*>(p) + j);
                 d[2 * j] = v.x; d[2 * j + 1] = v.y;
             }
             return;
@@ -464,7 +481,7 @@ AG_DEV void load_dwords(const uint8_t* p, uint32_t (&d)[ND])
     }
     if ((a & 3) == 0) {
 #pragma unroll
-        for (int j = 0; j < ND; ++j) d[j] = reinterpret_cast<const uint32_t*>(p)[j];
+        for (int j = 0; j < ND; ++j) d[j] = g_load(reinterpret_cast<const uint32_t*>(p) + j);
         return;
     }
 #pragma unroll
@@ -481,8 +498,8 @@ AG_DEV void store_dwords(uint8_t* p, const uint32_t (&d)[ND])
 #pragma unroll
             for (int j = 0; j < ND / 4; ++j) {
                 const dm_u32x4 v = { d[4 * j], d[4 * j + 1], d[4 * j + 2], d[4 * j + 3] };
-                if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<dm_u32x4*>(p) + j);
-                else reinterpret_cast<dm_u32x4*>(p)[j] = v;
+                if constexpr (NT) g_store_nt(v, reinterpret_cast<dm_u32x4*>(p) + j);
+                else g_store(v, reinterpret_cast<dm_u32x4*>(p) + j);
             }
             return;
         }
@@ -492,15 +509,15 @@ AG_DEV void store_dwords(uint8_t* p, const uint32_t (&d)[ND])
 #pragma unroll
             for (int j = 0; j < ND / 2; ++j) {
                 const dm_u32x2 v = { d[2 * j], d[2 * j + 1] };
-                if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<dm_u32x2*>(p) + j);
-                else reinterpret_cast<dm_u32x2*>(p)[j] = v;
+                if constexpr (NT) g_store_nt(v, reinterpret_cast<dm_u32x2*>(p) + j);
+                else g_store(v, reinterpret_cast<dm_u32x2*>(p) + j);
             }
             return;
         }
     }
     if ((a & 3) == 0) {
 #pragma unroll
-        for (int j = 0; j < ND; ++j) reinterpret_cast<uint32_t*>(p)[j] = d[j];
+        for (int j = 0; j < ND; ++j) g_store(d[j], reinterpret_cast<uint32_t*>(p) + j);
         return;
     }
 #pragma unroll
@@ -556,9 +573,9 @@ AG_DEV void wave_span_load(uint32_t* strip, int lane, const uint8_t* span, int s
         const int off = (j * 64 + lane) * (VW * 4);
         uint32_t v[4] = { 0, 0, 0, 0 };
         if (off + VW * 4 <= span_bytes) {
-            if constexpr (VW == 4) { const dm_u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const dm_u32x4*>(span + off)); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-            else if constexpr (VW == 2) { const dm_u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const dm_u32x2*>(span + off)); v[0] = t.x; v[1] = t.y; }
-            else v[0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(span + off));
+            if constexpr (VW == 4) { const dm_u32x4 t = g_load_nt(reinterpret_cast<const dm_u32x4*>(span + off)); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+            else if constexpr (VW == 2) { const dm_u32x2 t = g_load_nt(reinterpret_cast<const dm_u32x2*>(span + off)); v[0] = t.x; v[1] = t.y; }
+            else v[0] = g_load_nt(reinterpret_cast<const uint32_t*>(span + off));
         } else if (off < span_bytes) {                                // ragged right edge: byte tail
 #pragma clang loop vectorize(disable) unroll(disable)
             for (int k = 0; k < span_bytes - off; ++k) v[k >> 2] |= (uint32_t)span[off + k] << (8 * (k & 3));
@@ -605,9 +622,9 @@ AG_DEV void wave_span_store(uint32_t* strip, int lane, bool active, const uint32
         if (off + VW * 4 <= span_bytes) {
             uint32_t v[4];
             lds_get<VW>(rd, v);
-            if constexpr (VW == 4) __builtin_nontemporal_store(dm_u32x4{ v[0], v[1], v[2], v[3] }, reinterpret_cast<dm_u32x4*>(span + off));
-            else if constexpr (VW == 2) __builtin_nontemporal_store(dm_u32x2{ v[0], v[1] }, reinterpret_cast<dm_u32x2*>(span + off));
-            else __builtin_nontemporal_store(v[0], reinterpret_cast<uint32_t*>(span + off));
+            if constexpr (VW == 4) g_store_nt(dm_u32x4{ v[0], v[1], v[2], v[3] }, reinterpret_cast<dm_u32x4*>(span + off));
+            else if constexpr (VW == 2) g_store_nt(dm_u32x2{ v[0], v[1] }, reinterpret_cast<dm_u32x2*>(span + off));
+            else g_store_nt(v[0], reinterpret_cast<uint32_t*>(span + off));
         } else if (off < span_bytes) {
             const uint8_t* rb = reinterpret_cast<const uint8_t*>(rd);
 #pragma clang loop vectorize(disable) unroll(disable)
@@ -628,9 +645,9 @@ AG_DEV void wave_span_flush(uint32_t* strip, int lane, uint8_t* span, int span_b
         if (off + VW * 4 <= span_bytes) {
             uint32_t v[4];
             lds_get<VW>(rd, v);
-            if constexpr (VW == 4) __builtin_nontemporal_store(dm_u32x4{ v[0], v[1], v[2], v[3] }, reinterpret_cast<dm_u32x4*>(span + off));
-            else if constexpr (VW == 2) __builtin_nontemporal_store(dm_u32x2{ v[0], v[1] }, reinterpret_cast<dm_u32x2*>(span + off));
-            else __builtin_nontemporal_store(v[0], reinterpret_cast<uint32_t*>(span + off));
+            if constexpr (VW == 4) g_store_nt(dm_u32x4{ v[0], v[1], v[2], v[3] }, reinterpret_cast<dm_u32x4*>(span + off));
+            else if constexpr (VW == 2) g_store_nt(dm_u32x2{ v[0], v[1] }, reinterpret_cast<dm_u32x2*>(span + off));
+            else g_store_nt(v[0], reinterpret_cast<uint32_t*>(span + off));
         } else if (off < span_bytes) {
             const uint8_t* rb = reinterpret_cast<const uint8_t*>(rd);
 #pragma clang loop vectorize(disable) unroll(disable)

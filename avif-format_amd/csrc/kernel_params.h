@@ -12,6 +12,21 @@ namespace avifgpu {
 //   (0 = default).  (Bits 3 and 4 selected a register-prefetch and an XCD-contiguous variant in round 1; both lost and were removed.)
 enum : int { kHotDefault = 1 | 2 | 4 };
 
+// Cache policy of the K 16-byte loads a wave issues per span in the RGB f32 streaming kernels (and in their math-free twin,
+// pattern_probe.hip).  Round 4 sent the first and the last load of a span through the L2 / Infinity Cache normally (= 1), so that a
+// neighbouring span's touch of a shared 128-byte line could hit; in a loop over ONE frame that read +0...+2 % at 8192^2 and +5 % on
+// rows that start inside a line.  Round 5 measured on FRESH data (buffer sets rotating, > 1 GB between two visits of an address:
+// profiles/r05/load_policy_fresh_data_ab.txt, one box, two interleaved passes): the one-set loop had been flattering every allocating
+// load -- 4:4:4 at 8192^2: 0.784-0.788 of 8 TB/s on one set, 0.748-0.752 fresh -- because 2 of 6 loads allocating is 268 MB of an 805-MB
+// frame, about the 256-MiB Infinity Cache.  On fresh data: only the FIRST load allocating (= 16) 0.770-0.781, every load non-temporal
+// (= 0) 0.761-0.762, round 4's choice 0.748-0.752; the rows whose spans share lines (7952- and 6001-wide) keep round 4's gain with the
+// first load alone (0.714 / 0.730-0.740 against 0.701 / 0.713-0.720 all-non-temporal); at 16384^2 the three are equal.
+//   0 = every load non-temporal; 1 = first and last allocate; otherwise bit (4 + k) set = load k allocates.  Default: 16.
+#ifndef AG_EDGE_CACHED
+#define AG_EDGE_CACHED 16
+#endif
+constexpr bool span_load_cached(int k, int K) { return AG_EDGE_CACHED == 1 ? (k == 0 || k == K - 1) : ((AG_EDGE_CACHED >> (k + 4)) & 1) != 0; }
+
 // 16-bit ICC table on the device (upload_icc16 builds it, icc16_tetrahedral_host reads it): AG_ICC16_DOT2 picks the layout.  Both keep
 // node PAIRS per channel (lo | hi << 16), the operand form of v_dot2_u32_u16, and cost a pixel two 12-byte gathers.
 //   2 (default)  node-pair tables, 1.76 MB, L2-resident

@@ -1,6 +1,5 @@
 // pattern_probe.hip -- the MATH-FREE twin of write_rgb32_ycbcr444_hot: exactly its memory accesses (per lane six coalesced
-// 16-byte buffer loads of the interleaved f32 row -- the first and the last through the L2, the four in between non-temporal, like
-// the kernel since round 4 -- three non-temporal 16-byte u16 plane stores, 256-thread workgroups, one 512-pixel span per wave) and no
+// 16-byte buffer loads of the interleaved f32 row with the kernel's own cache policy (span_load_cached, kernel_params.h), three non-temporal 16-byte u16 plane stores, 256-thread workgroups, one 512-pixel span per wave) and no
 // conversion.  bench.py launches it in the same process, on the same buffers, right after the timed region: its time is what the
 // memory system of THIS box gives THIS access pattern at that moment -- the measured ceiling `roofline.peak_measured` that
 // `roofline.frac_of_measured` is priced against (SURVEY.md 8d asks for a measured peak next to the nominal 8 TB/s).  Diagnostic
@@ -10,6 +9,7 @@
 #include <stdint.h>
 
 #include "staging.h"
+#include "kernel_params.h"
 
 namespace avifgpu {
 
@@ -18,6 +18,10 @@ typedef uint32_t pp_u4 __attribute__((ext_vector_type(4)));
 typedef int      pp_i4 __attribute__((__vector_size__(16)));
 
 constexpr int kProbeWaves = 4;
+template <int K> __device__ __forceinline__ pp_i4 probe_load(__amdgpu_buffer_rsrc_t rs, int voff)
+{
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 1024 * K, span_load_cached(K, 6) ? 0 : 2);
+}
 __global__ __launch_bounds__(64 * kProbeWaves) void pattern_rgb32_planes444(const uint8_t* __restrict__ src, long long src_row_bytes, uint8_t* d0, uint8_t* d1,
                                                                           uint8_t* d2, long long s0, long long s1, long long s2, int width, int nrows)
 {
@@ -28,10 +32,8 @@ __global__ __launch_bounds__(64 * kProbeWaves) void pattern_rgb32_planes444(cons
         const uint32_t r = s / spans_per_row, sx = s - r * spans_per_row;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src + (long long)r * src_row_bytes + (long long)sx * 6144), 0, 6144, 0x00020000);
         pp_i4 v[6];
-        v[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
-#pragma unroll
-        for (int k = 1; k < 5; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 1024 * k, 2);
-        v[5] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 5120, 0);
+        v[0] = probe_load<0>(rs, voff); v[1] = probe_load<1>(rs, voff); v[2] = probe_load<2>(rs, voff);      // the kernel's own policy per load
+        v[3] = probe_load<3>(rs, voff); v[4] = probe_load<4>(rs, voff); v[5] = probe_load<5>(rs, voff);
         uint32_t acc = 0;
 #pragma unroll
         for (int k = 0; k < 6; ++k) acc ^= (uint32_t)v[k][0] ^ (uint32_t)v[k][1] ^ (uint32_t)v[k][2] ^ (uint32_t)v[k][3];

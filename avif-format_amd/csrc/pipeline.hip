@@ -327,8 +327,11 @@ CopyHelpers& copy_helpers()
 }
 void copy_helpers_shutdown()
 {
+    // the pools leave the map here, under the lock: copy_helper_pool_count() ("pools alive", avifgpu_device_traffic) then counts the pools
+    // of the CURRENT binding only, not every pool the process ever made.  The thread-less objects themselves are left
+    // alone -- a few hundred bytes each -- because a reference handed out by copy_helpers() may still be on some worker's stack.
     std::vector<CopyHelpers*> pools;
-    { std::lock_guard<std::mutex> lk(g_helpers_mu); for (auto& kv : helper_pools()) pools.push_back(kv.second); }
+    { std::lock_guard<std::mutex> lk(g_helpers_mu); for (auto& kv : helper_pools()) pools.push_back(kv.second); helper_pools().clear(); }
     for (CopyHelpers* p : pools) p->shutdown();
 }
 int copy_helper_pool_count() { std::lock_guard<std::mutex> lk(g_helpers_mu); return (int)helper_pools().size(); }
@@ -888,8 +891,9 @@ int device_traffic(int index, avifgpu_device_traffic* out, bool reset)
     t.device = dev;
     for (Ctx* c : *g_ctxs) {
         if (c->device != dev) continue;
-        t.tiles += c->tiles.load(); t.bytes_h2d += c->bytes_h2d.load(); t.bytes_d2h += c->bytes_d2h.load(); t.bytes_bounced += c->bytes_bounced.load();
-        if (reset) { c->tiles = 0; c->bytes_h2d = 0; c->bytes_d2h = 0; c->bytes_bounced = 0; }
+        // read-and-zero in ONE atomic step when resetting: a tile issued between a load and a separate store would be lost
+        if (reset) { t.tiles += c->tiles.exchange(0); t.bytes_h2d += c->bytes_h2d.exchange(0); t.bytes_d2h += c->bytes_d2h.exchange(0); t.bytes_bounced += c->bytes_bounced.exchange(0); }
+        else { t.tiles += c->tiles.load(); t.bytes_h2d += c->bytes_h2d.load(); t.bytes_d2h += c->bytes_d2h.load(); t.bytes_bounced += c->bytes_bounced.load(); }
     }
     t.copy_helper_pools = copy_helper_pool_count();
     if (out) *out = t;

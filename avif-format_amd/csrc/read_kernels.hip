@@ -309,14 +309,16 @@ AG_DEV void decode_pixel(const ReadParams& p, const Tables<LUT>& t, uint32_t u0,
 // Load N consecutive samples of a plane row starting at sample index i0 (right-edge replicated to `count`), kept PACKED
 // as they sit in memory (N * sample-size / 4 dwords): a group's planes then cost a handful of VGPRs, which is what lets
 // the next group's loads be in flight while this one is decoded (AG_READ_PREFETCH).
-// Cache policy of the plane loads (round 4; profiles/r04/read_nt_vs_cached.txt, two interleaved passes on one box).  Round 1 made
-// every plane load non-temporal.  Measured again on today's kernels, loads that go through the L2 normally are FASTER wherever a
-// lane's piece of a plane is small against a 128-byte line -- u8 planes (8-bit 4:2:0 -> RGB8 0.70 -> 0.79 of 8 TB/s, + alpha 0.77 ->
-// 0.87, planar RGB 0.79 -> 0.88) and the f32 hosts' u16 planes (12-bit 4:2:2 PQ -> RGB f32 0.63 -> 0.73, HLG 0.75 -> 0.88, gray PQ
-// 0.65 -> 0.81; rows that do not start on line boundaries gain most: 7952-wide 8-bit 4:2:0 0.63 -> 0.71) -- and 1-2 % slower for u16
-// planes -> 16-bit hosts and planar RGB -> f32, which keep the non-temporal hint.  AG_READ_NT_LOADS: 2 = this policy, 1 / 0 = all / none.
+// Cache policy of the plane loads.  Round 1 made every plane load non-temporal.  Round 4 measured again, in a loop over ONE buffer set
+// (profiles/r04/read_nt_vs_cached.txt), and let the u8 planes and the f32 hosts' u16 planes allocate in the L2 / Infinity Cache:
+// "+10-25 %" (8-bit 4:2:0 -> RGB8 0.70 -> 0.79 of 8 TB/s, 12-bit 4:2:2 PQ -> RGB f32 0.63 -> 0.73).  Round 5 repeated it on FRESH data
+// (buffer sets rotating, > 1 GB between two visits of an address; profiles/r05/read_policy_fresh_data_ab.txt): the gain was the 256-MiB
+// Infinity Cache holding a 100-MB plane set from one launch of the loop to the next -- on fresh data the allocating policy reads 0.66-0.68
+// / 0.73-0.74 where the same kernels read 0.75-0.77 / 0.81-0.82 on one set, the 16384^2 rows never showed it, and every load
+// non-temporal is the best or equal-best of the three policies on 7 of 9 rows (+0...+4 %; RGBA8 +3 %).  An open decodes every plane byte
+// once: AG_READ_NT_LOADS = 1 (all non-temporal) is the default again; 2 = round 4's per-depth policy, 0 = none.
 #ifndef AG_READ_NT_LOADS
-#define AG_READ_NT_LOADS 2
+#define AG_READ_NT_LOADS 1
 #endif
 template <int CS, int DEPTH> constexpr bool read_nt_loads()
 {

@@ -1128,6 +1128,7 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
                 for (int k = 0; k < 3; ++k) {
                     if (p.icc_s_par & (1 << k)) {
                         if (!p.icc_trc_linear[k]) {
+                            static_assert(AG_ICC_FASTPOW, "the parametric channels of a mixed profile are evaluated without the pow table (noT): fast-pow builds only");
                             const IccPowTableF noT = { nullptr };
 #pragma unroll
                             for (int i = 0; i < PXT; ++i) s[i][k] = __float_as_uint(icc_trc_f(noT, p.icc_trc_f[k], __uint_as_float(s[i][k])));
@@ -1276,30 +1277,24 @@ AG_DEV __amdgpu_buffer_rsrc_t span_rsrc(const void* base, uint32_t bytes)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);   // raw buffer, 32-bit data format
 }
-// AG_EDGE_CACHED = 1 (round 4): the first and the last load of a span -- the ones that may share a 128-byte line with the
-// neighbouring span when rows do not start on line boundaries -- go through the L2 normally instead of non-temporally, so that the
-// neighbour's touch of the shared line can hit there (same workgroup = same XCD for 3 of 4 spans) instead of coming from HBM a
-// second time: 7952 x 5304 4:2:0 0.694 -> 0.73 of 8 TB/s, 8192^2 rows +0...+2 % (profiles/r04/load_policy_ab.txt; every load cached
-// and every second load cached both lose 2-4 %).  Other values: bit 4 + k set = load k cached.
-#ifndef AG_EDGE_CACHED
-#define AG_EDGE_CACHED 1
-#endif
+// (which of a span's loads carry the non-temporal hint: span_load_cached(), kernel_params.h)
 template <bool NT> AG_DEV f32x4 span_load16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
 {
+    if constexpr (AG_MATH_ONLY) return mo_value<f32x4>();
     const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, NT ? 2 : 0);
     return __builtin_bit_cast(f32x4, v);
 }
 template <bool NT> AG_DEV void span_store16(__amdgpu_buffer_rsrc_t r, uint32_t voff, u32x4 v)
 {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), r, (int)voff, 0, NT ? 2 : 0);
+    if constexpr (AG_MATH_ONLY) mo_sink(v); else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), r, (int)voff, 0, NT ? 2 : 0);
 }
 template <bool NT> AG_DEV void span_store8(__amdgpu_buffer_rsrc_t r, uint32_t voff, u32x2 v)
 {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, v), r, (int)voff, 0, NT ? 2 : 0);
+    if constexpr (AG_MATH_ONLY) mo_sink(v); else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, v), r, (int)voff, 0, NT ? 2 : 0);
 }
 template <bool NT> AG_DEV void span_store4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t v)
 {
-    __builtin_amdgcn_raw_buffer_store_b32((int)v, r, (int)voff, 0, NT ? 2 : 0);
+    if constexpr (AG_MATH_ONLY) mo_sink(v); else __builtin_amdgcn_raw_buffer_store_b32((int)v, r, (int)voff, 0, NT ? 2 : 0);
 }
 // A lane's 8 (4) u16 samples -- samples [8 lane, 8 lane + 8) of the span -- into a plane row of ANY length, with no branch on the
 // lane's position: the resource ends at the span's last WHOLE dword, and the hardware's range check (per dword of a multi-dword
@@ -1423,11 +1418,11 @@ AG_DEV void luma_pair_nc(const WriteParams& p, const float* c6, uint32_t& y0, ui
 
 template <bool NT> AG_DEV f32x4 stream_load(const f32x4* p)
 {
-    if constexpr (NT) return __builtin_nontemporal_load(p); else return *p;
+    if constexpr (NT) return g_load_nt(p); else return g_load(p);
 }
 template <bool NT, typename V> AG_DEV void stream_store(V* p, V v)
 {
-    if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
+    if constexpr (NT) g_store_nt(v, p); else g_store(v, p);
 }
 
 // Round 4: the curve's results cross the strip as integer-valued FLOATS (oetf_level2), not as packed u16 codes -- stage B wants
@@ -1465,7 +1460,7 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_ycbcr444_hot(
         const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)r * p.src_row_bytes + (long long)sx * (SPAN_PX * 12), (uint32_t)span_px * 12u);
         f32x4 cur[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) cur[k] = (AG_EDGE_CACHED == 1 ? (k == 0 || k == K - 1) : ((AG_EDGE_CACHED >> (k + 4)) & 1)) ? span_load16<false>(rs, voff, 1024u * k) : span_load16<NT>(rs, voff, 1024u * k);   // a float4 beyond the row: zeros, and nothing is stored for it
+        for (int k = 0; k < K; ++k) cur[k] = span_load_cached(k, K) ? span_load16<false>(rs, voff, 1024u * k) : span_load16<NT>(rs, voff, 1024u * k);   // a float4 beyond the row: zeros, and nothing is stored for it
 
         float R[PXL], G[PXL], B[PXL];
         if constexpr (AG_HOT_F32_STRIP) {
@@ -1574,7 +1569,7 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444
         const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)r * p.src_row_bytes + (long long)sx * (SPAN_PX * 12), (uint32_t)span_px * 12u);
         f32x4 cur[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) cur[k] = (AG_EDGE_CACHED == 1 ? (k == 0 || k == K - 1) : ((AG_EDGE_CACHED >> (k + 4)) & 1)) ? span_load16<false>(rs, voff, 1024u * k) : span_load16<true>(rs, voff, 1024u * k);
+        for (int k = 0; k < K; ++k) cur[k] = span_load_cached(k, K) ? span_load16<false>(rs, voff, 1024u * k) : span_load16<true>(rs, voff, 1024u * k);
         if constexpr (ICCV == 2) {                                                 // the document's curve: per sample, the same for R, G, B
             const IccSimple q = icc_simple_load(p);
 #pragma unroll
@@ -1671,7 +1666,7 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot
             const int r = min((int)(gy * VR) + vr, p.rows_to_end - 1);  // bottom edge: replicate the last IMAGE row
             const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)r * p.src_row_bytes + (long long)sx * (SPAN_PX * 12), (uint32_t)span_px * 12u);
 #pragma unroll
-            for (int k = 0; k < K; ++k) v[vr][k] = (AG_EDGE_CACHED == 1 ? (k == 0 || k == K - 1) : ((AG_EDGE_CACHED >> (k + 4)) & 1)) ? span_load16<false>(rs, voff, 1024u * k) : span_load16<true>(rs, voff, 1024u * k);   // beyond the row: zeros (see the 4:4:4 kernel)
+            for (int k = 0; k < K; ++k) v[vr][k] = span_load_cached(k, K) ? span_load16<false>(rs, voff, 1024u * k) : span_load16<true>(rs, voff, 1024u * k);   // beyond the row: zeros (see the 4:4:4 kernel)
         }
         const int nv = span_px - PXL * lane;                           // pixels of this lane inside the row: >= 8, 4 or <= 0 (width % 4 == 0)
         // Round 4: the levels (integer-valued floats, oetf_level2) cross the strip, a row at a time; a row's luma leaves at once and
@@ -2007,7 +2002,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr444_hot(cons
             const int span_v = min(SPAN_PX, p.width - (int)sx * SPAN_PX) * 3 / 8;      // 16-byte vectors in this span (span_px is a multiple of 8)
             const u32x4* sp = reinterpret_cast<const u32x4*>(p.src + (long long)r * p.src_row_bytes) + (long long)sx * (64 * K);
 #pragma unroll
-            for (int k = 0; k < K; ++k) cur[n][k] = __builtin_nontemporal_load(sp + min(64 * k + lane, span_v - 1));   // branch-free mask, as in the f32 kernel
+            for (int k = 0; k < K; ++k) cur[n][k] = g_load_nt(sp + min(64 * k + lane, span_v - 1));   // branch-free mask, as in the f32 kernel
         }
 #pragma unroll
         for (int n = 0; n < NS; ++n) {
@@ -2052,9 +2047,9 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr444_hot(cons
                 u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
                 u32x4 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16), cbv[4] | (cbv[5] << 16), cbv[6] | (cbv[7] << 16) };
                 u32x4 c = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16), crv[4] | (crv[5] << 16), crv[6] | (crv[7] << 16) };
-                __builtin_nontemporal_store(a, reinterpret_cast<u32x4*>(p.dst[0] + (long long)r * p.dst_stride[0] + xoff));
-                __builtin_nontemporal_store(b, reinterpret_cast<u32x4*>(p.dst[1] + (long long)r * p.dst_stride[1] + xoff));
-                __builtin_nontemporal_store(c, reinterpret_cast<u32x4*>(p.dst[2] + (long long)r * p.dst_stride[2] + xoff));
+                g_store_nt(a, reinterpret_cast<u32x4*>(p.dst[0] + (long long)r * p.dst_stride[0] + xoff));
+                g_store_nt(b, reinterpret_cast<u32x4*>(p.dst[1] + (long long)r * p.dst_stride[1] + xoff));
+                g_store_nt(c, reinterpret_cast<u32x4*>(p.dst[2] + (long long)r * p.dst_stride[2] + xoff));
             }
         }
     }
@@ -2084,7 +2079,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr_sub_hot(con
             const int r = min((int)(gy * VR) + vr, p.rows_to_end - 1);             // bottom edge: replicate the last IMAGE row
             const u32x4* sp = reinterpret_cast<const u32x4*>(p.src + (long long)r * p.src_row_bytes) + (long long)sx * (64 * K);
 #pragma unroll
-            for (int k = 0; k < K; ++k) v[vr][k] = __builtin_nontemporal_load(sp + min(64 * k + lane, span_v - 1));
+            for (int k = 0; k < K; ++k) v[vr][k] = g_load_nt(sp + min(64 * k + lane, span_v - 1));
         }
         uint32_t dw[VR][LDW];
 #pragma unroll
@@ -2122,7 +2117,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr_sub_hot(con
             for (int i = 0; i < PXL; ++i) yv[i] = luma_code(p, code(vr, i, 0), code(vr, i, 1), code(vr, i, 2));
             if (mine) {
                 u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
-                __builtin_nontemporal_store(a, reinterpret_cast<u32x4*>(p.dst[0] + (long long)r * p.dst_stride[0] + xoff));
+                g_store_nt(a, reinterpret_cast<u32x4*>(p.dst[0] + (long long)r * p.dst_stride[0] + xoff));
             }
         }
         uint32_t cbv[4], crv[4];
@@ -2143,8 +2138,8 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr_sub_hot(con
             const long long coff = ((long long)sx * (SPAN_PX / 2) + 4LL * lane) * 2;
             u32x2 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16) };
             u32x2 c = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16) };
-            __builtin_nontemporal_store(b, reinterpret_cast<u32x2*>(p.dst[1] + (long long)gy * p.dst_stride[1] + coff));
-            __builtin_nontemporal_store(c, reinterpret_cast<u32x2*>(p.dst[2] + (long long)gy * p.dst_stride[2] + coff));
+            g_store_nt(b, reinterpret_cast<u32x2*>(p.dst[1] + (long long)gy * p.dst_stride[1] + coff));
+            g_store_nt(c, reinterpret_cast<u32x2*>(p.dst[2] + (long long)gy * p.dst_stride[2] + coff));
         }
     }
 }
@@ -2171,7 +2166,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra444_hot(co
         const u32x4* sp = reinterpret_cast<const u32x4*>(p.src + (long long)r * p.src_row_bytes) + (long long)sx * (64 * K);
         u32x4 cur[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) cur[k] = __builtin_nontemporal_load(sp + min(64 * k + lane, span_v - 1));
+        for (int k = 0; k < K; ++k) cur[k] = g_load_nt(sp + min(64 * k + lane, span_v - 1));
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             uint32_t o[4];
@@ -2216,7 +2211,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra444_hot(co
             for (int c = 0; c < 4; ++c) {
                 const uint32_t* q = pl[c];
                 u32x4 o = { q[0] | (q[1] << 16), q[2] | (q[3] << 16), q[4] | (q[5] << 16), q[6] | (q[7] << 16) };
-                __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(p.dst[c] + (long long)r * p.dst_stride[c] + xoff));
+                g_store_nt(o, reinterpret_cast<u32x4*>(p.dst[c] + (long long)r * p.dst_stride[c] + xoff));
             }
         }
     }
@@ -2312,7 +2307,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_int_ref_stream(const Wr
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             idx[k] = c * (64 * K) + 64 * k + lane;
-            if (idx[k] < nv) v[k] = __builtin_nontemporal_load(sp + idx[k]);
+            if (idx[k] < nv) v[k] = g_load_nt(sp + idx[k]);
         }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -2346,10 +2341,10 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_int_ref_stream(const Wr
                 else o[j] = q[4 * j] | (q[4 * j + 1] << 8) | (q[4 * j + 2] << 16) | (q[4 * j + 3] << 24);
             }
             uint32_t* d = dp + (size_t)idx[k] * ODW;
-            if constexpr (ODW == 2) { u32x2 t = { o[0], o[1] }; __builtin_nontemporal_store(t, reinterpret_cast<u32x2*>(d)); }
+            if constexpr (ODW == 2) { u32x2 t = { o[0], o[1] }; g_store_nt(t, reinterpret_cast<u32x2*>(d)); }
             else {
 #pragma unroll
-                for (int h = 0; h < ODW / 4; ++h) { u32x4 t = { o[4 * h], o[4 * h + 1], o[4 * h + 2], o[4 * h + 3] }; __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(d) + h); }
+                for (int h = 0; h < ODW / 4; ++h) { u32x4 t = { o[4 * h], o[4 * h + 1], o[4 * h + 2], o[4 * h + 3] }; g_store_nt(t, reinterpret_cast<u32x4*>(d) + h); }
             }
         }
     }

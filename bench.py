@@ -17,10 +17,15 @@ MAX-over-ranks of the timed region.  --scaling strong (default): ONE 8192 x 8192
 converts rows [k*H/N, (k+1)*H/N) -- BASELINE.json configs[3] ("row-tiled across 8 MI355X") and the north-star's split of one
 image.  --scaling weak: every rank converts one full frame per step (a batch of N frames).
 
+FRESH DATA (round 5): the plug-in converts every byte once, so the timed region never touches the same buffer twice within the
+reach of the 256-MiB Infinity Cache: the K steps ROTATE over >= 4 disjoint (frame, planes) sets whose footprints add up to > 1 GB
+(`roofline.buffer_sets`).  A benchmark loop that re-converts ONE frame measures the cache for every load that allocates there; that
+figure is kept beside the claimed one as `roofline.frac_same_buffers` (untimed diagnostic pass).
+
 Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per launch (18 B/px: 12 in + 6 out,
-SURVEY.md 8d) / mean kernel time from HIP events recorded on the launch stream; `roofline.peak` = the 8 TB/s spec,
-`roofline.peak_measured` = what the kernel's MATH-FREE twin (same loads and stores, no conversion) reaches on the same buffers in
-the same process, `frac_of_measured` = achieved / that; `read_only_frac` is the north-star's literal "HBM-read" figure (input bytes
+SURVEY.md 8d) / mean kernel time from HIP events recorded on the launch stream around the K rotating launches; `roofline.peak` =
+the 8 TB/s spec, `roofline.peak_measured` = what the kernel's MATH-FREE twin (same loads and stores with the same cache policy, no
+conversion) reaches over the same rotating sets in the same process, `frac_of_measured` = achieved / that; `read_only_frac` is the north-star's literal "HBM-read" figure (input bytes
 only), bounded by 12/18 for 4:4:4 output -- `frac` is the one that is claimed.  `roofline.traffic` = HBM bytes per launch from
 the PMC counters, measured in THIS run at N = 1 by two child `rocprofv3 --pmc` passes over the same kernel (measure_traffic_live;
 about 25 s; --no-live-traffic or a missing rocprofv3 falls back to the committed profiles/traffic.json, and the line says which).
@@ -138,7 +143,8 @@ def main():
                          "clock state (measured: the first ~50 ms of launches run at up to 2x the steady-state time)")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold single-launch figure (2 s of idle time)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive (host pointers, in-process N-device) figure")
-    ap.add_argument("--no-rotate", action="store_true", help="skip the rotating-buffer (Infinity Cache) cross-check of the kernel time")
+    ap.add_argument("--no-rotate", action="store_true", help="diagnostic: ONE buffer set for the timed region too (the pre-round-5 loop; the line says so)")
+    ap.add_argument("--min-footprint-gb", type=float, default=1.25, help="the rotating sets' footprints add up to at least this (>= 4 sets)")
     ap.add_argument("--no-c5", action="store_true", help="skip the configs[4] (16384^2 RGBA f32) sub-measurement")
     ap.add_argument("--no-pattern", action="store_true", help="skip the math-free pattern probe (roofline.peak_measured)")
     ap.add_argument("--no-live-traffic", action="store_true",
@@ -200,9 +206,29 @@ def main():
 
     launches = [0]                             # kernel launches so far (tools/summarize_kernel_trace.py picks the timed ones)
 
-    def step():
+    # ---- fresh data: disjoint (frame rows, planes) sets the steps rotate over ----
+    # Every set is a copy of the frame at other addresses with planes of its own.  With >= 4 sets and > 1 GB between two visits of an
+    # address nothing a launch reads or wrote can still sit in the 256-MiB Infinity Cache when its turn comes again (nor in the 32 MiB
+    # of L2): each launch finds its bytes in HBM, as a save does.  Set 0 is the (frame, planes) pair above.
+    algo_bytes = gpu.write_algorithmic_bytes(desc, nrows)
+    if args.no_rotate:
+        nset = 1
+    else:
+        nset = max(4, int(-(-args.min_footprint_gb * 1e9 // algo_bytes)))
+        nset = min(nset, 64)
+    sets = [(src, ptrs)]
+    keep = []
+    for j in range(1, 2 if args.traffic_child and nset > 1 else nset):
+        f = src.clone()
+        pl = [torch.empty_like(t) for t in planes]
+        keep.append((f, pl))
+        sets.append((f, [t.data_ptr() for t in pl] + [None]))
+    torch.cuda.synchronize(dev)
+
+    def step(same=False):
+        sj, pj = sets[0] if same else sets[launches[0] % len(sets)]
         launches[0] += 1
-        gpu.write_rows(desc, row0, nrows, src.data_ptr(), src.stride(0) * 4, ptrs, strides,
+        gpu.write_rows(desc, row0, nrows, sj.data_ptr(), sj.stride(0) * 4, pj, strides,
                        mem=pkg.MEM_DEVICE, stream=stream.cuda_stream)
 
     if args.traffic_child:                     # under rocprofv3 --pmc (measure_traffic_live): the kernel alone, nothing printed
@@ -291,49 +317,41 @@ def main():
     kernel_ms = sorted(series)
     kernel_name = gpu.last_kernel()
 
-    # untimed diagnostic: the same K back-to-back launches ROTATING over 4 disjoint (source, planes) buffer sets, so that no byte a
-    # launch reads or writes can still sit in the 256-MB Infinity Cache when its address comes round again.  The timed region above
-    # reuses one set, like every benchmark loop; this figure shows how much of its number that reuse is worth.  (For the all-
-    # non-temporal kernels: nothing.  tools/membench_r02.hip shows what a write-back store policy would have "gained" there.)
-    rotating = None
-    if world == 1 and not args.no_rotate:
-        NSET = 4
-        sets = [(src, ptrs)]
-        keep = []
-        for j in range(1, NSET):
-            f = frame.clone()
-            pl = [torch.empty_like(t) for t in planes]
-            keep.append((f, pl))
-            sets.append((f[row0:row0 + nrows], [t.data_ptr() for t in pl] + [None]))
-        def rot_step(i):
-            sj, pj = sets[i % NSET]
-            gpu.write_rows(desc, row0, nrows, sj.data_ptr(), sj.stride(0) * 4, pj, strides, mem=pkg.MEM_DEVICE, stream=stream.cuda_stream)
-        for i in range(40):
-            rot_step(i)
+    # untimed diagnostic: the same K back-to-back launches on ONE buffer set -- the loop every benchmark writes, and what rounds 1-4
+    # reported.  What it gains over the timed region is what the Infinity Cache gives a frame that is converted again before 256 MiB of
+    # other traffic has passed: nothing a save ever sees.  (Loads with the non-temporal hint do not allocate there and gain nothing;
+    # loads that allocate normally do -- round 4's cached edge loads read 3 % faster in this loop and 3 % slower on fresh data.)
+    same_buffers = None
+    if len(sets) > 1:
+        for _ in range(40):
+            step(same=True)
         torch.cuda.synchronize(dev)
         r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         r0.record(stream)
-        for i in range(args.steps):
-            rot_step(i)
+        for _ in range(args.steps):
+            step(same=True)
         r1.record(stream)
         torch.cuda.synchronize(dev)
-        rot_ms = r0.elapsed_time(r1) / args.steps
-        rotating = {"sets": NSET, "kernel_ms_mean": round(rot_ms, 5)}
-        del keep, sets
+        same_buffers = {"kernel_ms_mean": round(r0.elapsed_time(r1) / args.steps, 5)}
 
-    # untimed diagnostic: the MATH-FREE twin of the kernel (avifgpu_probe_pattern_rgb32_444: the same loads and stores, no
-    # conversion) on the same buffers, same stream, same process, launched back to back like the timed region.  Its rate is
-    # what this box's memory system gives this access pattern right now: the MEASURED ceiling next to the nominal 8 TB/s.
+    # untimed diagnostic: the MATH-FREE twin of the kernel (avifgpu_probe_pattern_rgb32_444: the same loads and stores with the same
+    # cache policy, no conversion) over the same rotating sets, same stream, same process, launched back to back like the timed region.
+    # Its rate is what this box's memory system gives this access pattern on fresh data right now: the MEASURED ceiling next to the
+    # nominal 8 TB/s.
     pattern = None
     if args.chroma == "444" and W % 512 == 0 and not args.no_pattern:
         import ctypes
         lib = pkg.load()
         P3, S3 = ctypes.c_void_p * 3, ctypes.c_int64 * 3
-        pp, ss = P3(*ptrs[:3]), S3(*strides[:3])
+        ss = S3(*strides[:3])
+
+        psets = [(sj.data_ptr(), P3(*pj[:3])) for sj, pj in sets]
+        pcount = [0]
 
         def probe():
-            rc = lib.avifgpu_probe_pattern_rgb32_444(src.data_ptr(), src.stride(0) * 4, ctypes.byref(pp), ctypes.byref(ss), W, nrows,
-                                                     stream.cuda_stream)
+            sp, pj = psets[pcount[0] % len(psets)]
+            pcount[0] += 1
+            rc = lib.avifgpu_probe_pattern_rgb32_444(sp, src.stride(0) * 4, ctypes.byref(pj), ctypes.byref(ss), W, nrows, stream.cuda_stream)
             if rc:
                 raise RuntimeError(lib.avifgpu_last_error().decode())
         try:
@@ -348,7 +366,8 @@ def main():
             p1.record(stream)
             torch.cuda.synchronize(dev)
             pattern = {"launches": np_, "kernel_ms_mean": round(p0.elapsed_time(p1) / np_, 5)}
-            step()                                  # the planes hold pixels again (the probe stores a checksum)
+            for _ in range(len(sets)):              # the planes hold pixels again (the probe stores a checksum)
+                step()
             torch.cuda.synchronize(dev)
         except Exception as exc:      # noqa: BLE001
             pattern = {"error": str(exc)}
@@ -373,7 +392,6 @@ def main():
     total_rows = H * world if args.scaling == "weak" else H
     total_px = float(W) * total_rows * args.steps
     value = total_px / elapsed / 1e6
-    algo_bytes = gpu.write_algorithmic_bytes(desc, nrows)
     achieved = algo_bytes / mean_kernel_s / 1e9
 
     out = {
@@ -405,6 +423,11 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": None,
             "algorithmic_bytes_per_launch": algo_bytes,
+            # what the timed region ran on: disjoint (frame, planes) sets visited in turn -- fresh data for every launch
+            "buffer_sets": {"sets": len(sets), "footprint_bytes": algo_bytes * len(sets),
+                            "note": "the K timed launches rotate over these disjoint sets: no byte is touched again before "
+                                    f"{algo_bytes * (len(sets) - 1) / 1e9:.2f} GB of other traffic (Infinity Cache: 0.27 GB)" if len(sets) > 1
+                                    else "ONE set (--no-rotate): loads that allocate in the Infinity Cache re-read it; not a fresh-data figure"},
             "kernel_ms_mean": round(mean_kernel_s * 1e3, 5),
             "isolated_launch_ms_p10_p50_p90": [round(kernel_ms[int(len(kernel_ms) * q)], 5) for q in (0.1, 0.5, 0.9)],
             "batches_of_10_ms_p10_p50_p90": [round(batch_ms[int(len(batch_ms) * q)], 5) for q in (0.1, 0.5, 0.9)],
@@ -419,13 +442,16 @@ def main():
         out["roofline"]["peak_measured"] = round(peak_measured, 1)
         out["roofline"]["frac_of_measured"] = round(achieved / peak_measured, 4)
         out["roofline"]["peak_measured_source"] = (f"math-free twin of the kernel (same accesses, no conversion; avifgpu_probe_pattern_rgb32_444), "
-                                                   f"{pattern['launches']} back-to-back launches in this process, {pattern['kernel_ms_mean']} ms each")
+                                                   f"{pattern['launches']} back-to-back launches over the same {len(sets)} rotating sets in this process, {pattern['kernel_ms_mean']} ms each")
     elif pattern:
         out["roofline"]["peak_measured"] = None
         out["roofline"]["peak_measured_source"] = "probe failed: " + pattern.get("error", "?")
-    if rotating:
-        rotating["frac"] = round(algo_bytes / (rotating["kernel_ms_mean"] / 1e3) / 1e9 / HBM_PEAK_GBPS, 4)
-        out["roofline"]["rotating_buffers"] = rotating
+    if same_buffers:
+        same_buffers["frac"] = round(algo_bytes / (same_buffers["kernel_ms_mean"] / 1e3) / 1e9 / HBM_PEAK_GBPS, 4)
+        out["roofline"]["frac_same_buffers"] = same_buffers["frac"]
+        out["roofline"]["same_buffers"] = same_buffers
+        # kept under its old name for readers of rounds 3-4: the rotating figure IS `frac` now
+        out["roofline"]["rotating_buffers"] = {"sets": len(sets), "kernel_ms_mean": round(mean_kernel_s * 1e3, 5), "frac": round(achieved / HBM_PEAK_GBPS, 4)}
     out["per_rank"] = per_rank
     if cold:
         out["cold_launch"] = cold
@@ -451,6 +477,9 @@ def main():
                 out["roofline"]["traffic_source"] = "profiles/traffic.json (" + tj.get("source", "rocprofv3 --pmc passes") + ")"
         except Exception:
             pass
+
+    n_sets = len(sets)
+    del sets[1:], keep[:]                      # the copies' memory back before C5 and the host-pointer job
 
     # ---- configs[4]: 16384^2 RGBA f32 -> 12-bit PQ Y,Cb,Cr,A, the same N-way row split (device-resident) ----
     if not args.no_c5:

@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """Per-configuration kernel timings (BASELINE.json configs C2..C5 + the read direction) on one MI355X.
 Diagnostic companion of bench.py: prints one line per configuration with HIP-event kernel time, Mpx/s and
-algorithmic GB/s (input read once + output written once)."""
+algorithmic GB/s (input read once + output written once).
+
+Round 5 -- FRESH DATA: every row's launches rotate over disjoint (source, destination) buffer sets, enough of them that the sets'
+footprints add up to > BENCH_FOOTPRINT_GB (1.25) and never fewer than 2: no byte a launch touches can still sit in the 256-MiB
+Infinity Cache when its address comes round again, which is how the plug-in sees memory (each row of a document is converted once).
+`ms_mean` / `frac_of_8TBs` are that figure; `ms_same` / `frac_same` (BENCH_SAME=0 skips them) are the ONE-set loop of rounds 1-4
+beside it -- rows where the two differ are rows whose old number was partly a cache number."""
 import json
 import os
 import sys
@@ -85,23 +91,60 @@ def smooth_src(d):
     return img.to(torch.int32).to(torch.int16).reshape(d.height, -1)
 
 
+FOOTPRINT = float(os.environ.get("BENCH_FOOTPRINT_GB", "1.25")) * 1e9
+SAME = os.environ.get("BENCH_SAME", "1") != "0"
+
+
+def n_sets(algorithmic_bytes):
+    return max(2, min(64, int(-(-FOOTPRINT // algorithmic_bytes))))
+
+
+def rotate(calls):
+    """One callable that walks through `calls` (one launch per call, next buffer set each time)."""
+    state = [0]
+
+    def fn():
+        calls[state[0] % len(calls)]()
+        state[0] += 1
+    return fn
+
+
+def time_row(calls, ab):
+    """(rotating mean, rotating p50, launches, same-buffer mean | None).  The same-buffer pass comes AFTER the rotating one and is not
+    part of 'launches' bookkeeping when BENCH_SAME=0 (the profiling passes: they cut the dispatch stream by 'launches')."""
+    mean, p50 = time_launch(rotate(calls), warm=warm_launches(ab))
+    launches = LAST["launches"]
+    same = None
+    if SAME and len(calls) > 1:
+        same, _ = time_launch(calls[0], warm=100)
+        launches += LAST["launches"]
+    return mean, p50, launches, same
+
+
 def bench_write(name, icc=None, smooth=False, **kw):
     d = pkg.WriteDesc(**kw)
-    src = smooth_src(d) if smooth else rand_src(d)
+    src0 = smooth_src(d) if smooth else rand_src(d)
     ssz = 2 if d.bit_depth > 8 else 1
-    bufs, ptrs, strides = {}, [None] * 4, [0] * 4
-    for pl, (w, xs, ys) in harness.write_planes(d).items():
-        # plane rows padded to 16 bytes, as heif_image_add_plane allocates them
-        bufs[pl] = torch.empty(((d.height + ys) >> ys, (w * ssz + 15) // 16 * 16), dtype=torch.uint8, device=dev)
-        ptrs[pl], strides[pl] = bufs[pl].data_ptr(), bufs[pl].stride(0)
-    fn = lambda: gpu.write_rows(d, 0, d.height, src.data_ptr(), src.stride(0) * src.element_size(), ptrs, strides,
-                                mem=pkg.MEM_DEVICE, stream=stream.cuda_stream, icc=icc)
     ab = gpu.write_algorithmic_bytes(d, d.height)
-    mean, p50 = time_launch(fn, warm=warm_launches(ab))
-    print(json.dumps({"config": name, "kernel": gpu.last_kernel(), "ms_mean": round(mean, 4), "ms_p50": round(p50, 4),
-                      "Mpx_s": round(d.width * d.height / mean / 1e3, 0), "GB_s": round(ab / mean / 1e6, 1),
-                      "frac_of_8TBs": round(ab / mean / 1e6 / 8000, 3), "bytes_per_px": ab / (d.width * d.height),
-                      "launches": LAST["launches"]}), flush=True)
+    calls, keep = [], []
+    for j in range(n_sets(ab)):
+        src = src0 if j == 0 else src0.clone()
+        bufs, ptrs, strides = {}, [None] * 4, [0] * 4
+        for pl, (w, xs, ys) in harness.write_planes(d).items():
+            # plane rows padded to 16 bytes, as heif_image_add_plane allocates them
+            bufs[pl] = torch.empty(((d.height + ys) >> ys, (w * ssz + 15) // 16 * 16), dtype=torch.uint8, device=dev)
+            ptrs[pl], strides[pl] = bufs[pl].data_ptr(), bufs[pl].stride(0)
+        keep.append((src, bufs))
+        calls.append(lambda src=src, ptrs=ptrs, strides=strides: gpu.write_rows(
+            d, 0, d.height, src.data_ptr(), src.stride(0) * src.element_size(), ptrs, strides, mem=pkg.MEM_DEVICE, stream=stream.cuda_stream, icc=icc))
+    mean, p50, launches, same = time_row(calls, ab)
+    row = {"config": name, "kernel": gpu.last_kernel(), "ms_mean": round(mean, 4), "ms_p50": round(p50, 4),
+           "Mpx_s": round(d.width * d.height / mean / 1e3, 0), "GB_s": round(ab / mean / 1e6, 1),
+           "frac_of_8TBs": round(ab / mean / 1e6 / 8000, 3), "bytes_per_px": ab / (d.width * d.height),
+           "launches": launches, "sets": len(calls)}
+    if same:
+        row.update({"ms_same": round(same, 4), "frac_same": round(ab / same / 1e6 / 8000, 3)})
+    print(json.dumps(row), flush=True)
 
 
 def bench_read(name, **kw):
@@ -109,33 +152,43 @@ def bench_read(name, **kw):
     g = torch.Generator(device=dev); g.manual_seed(99)
     maxc = (1 << d.bit_depth) - 1
     ssz = 2 if d.bit_depth > 8 else 1
-    ptrs, strides, keep = [None] * 4, [0] * 4, []
-    for pl, (w, xs, ys) in harness.read_planes(d).items():
-        h = (d.height + ys) >> ys
-        wp = (w * ssz + 15) // 16 * 16 // ssz                # rows padded to 16 bytes, as libheif allocates planes
-        t = torch.randint(0, maxc + 1, (h, wp), generator=g, device=dev, dtype=torch.int32)
-        t = t.to(torch.int16 if ssz == 2 else torch.uint8).contiguous()
-        keep.append(t); ptrs[pl], strides[pl] = t.data_ptr(), t.stride(0) * ssz
     nch = harness.read_channels(d)
-    out = torch.empty((d.height, d.width * nch * (d.depth // 8)), dtype=torch.uint8, device=dev)
-    fn = lambda: gpu.read_rows(d, 0, d.height, ptrs, strides, out.data_ptr(), out.stride(0), mem=pkg.MEM_DEVICE,
-                               stream=stream.cuda_stream)
     ab = gpu.read_algorithmic_bytes(d, d.height)
-    mean, p50 = time_launch(fn, warm=warm_launches(ab))
+    calls, twins, keep = [], [], []
+    for j in range(n_sets(ab)):
+        ptrs, strides, planes = [None] * 4, [0] * 4, []
+        for i, (pl, (w, xs, ys)) in enumerate(harness.read_planes(d).items()):
+            h = (d.height + ys) >> ys
+            wp = (w * ssz + 15) // 16 * 16 // ssz                # rows padded to 16 bytes, as libheif allocates planes
+            if j == 0:
+                t = torch.randint(0, maxc + 1, (h, wp), generator=g, device=dev, dtype=torch.int32)
+                t = t.to(torch.int16 if ssz == 2 else torch.uint8).contiguous()
+            else:
+                t = keep[0][0][i].clone()
+            planes.append(t); ptrs[pl], strides[pl] = t.data_ptr(), t.stride(0) * ssz
+        out = torch.empty((d.height, d.width * nch * (d.depth // 8)), dtype=torch.uint8, device=dev)
+        keep.append((planes, out))
+        calls.append(lambda ptrs=ptrs, strides=strides, out=out: gpu.read_rows(d, 0, d.height, ptrs, strides, out.data_ptr(), out.stride(0),
+                                                                              mem=pkg.MEM_DEVICE, stream=stream.cuda_stream))
+        twins.append(lambda ptrs=ptrs, strides=strides, out=out: gpu.probe_pattern_read(d, 0, d.height, ptrs, strides, out.data_ptr(), out.stride(0),
+                                                                                      stream=stream.cuda_stream))
+    mean, p50, launches, same = time_row(calls, ab)
     row = {"config": name, "kernel": gpu.last_kernel(), "ms_mean": round(mean, 4), "ms_p50": round(p50, 4),
            "Mpx_s": round(d.width * d.height / mean / 1e3, 0), "GB_s": round(ab / mean / 1e6, 1),
            "frac_of_8TBs": round(ab / mean / 1e6 / 8000, 3), "bytes_per_px": ab / (d.width * d.height),
-           "launches": LAST["launches"]}
-    # the measured ceiling of this row's access pattern: the kernel's math-free twin (read_px<..., TWIN>) on the same buffers, where one
-    # exists (BENCH_TWIN=0 skips it: the profiling passes cut the dispatch stream by 'launches' and must see the same stream every pass)
+           "launches": launches, "sets": len(calls)}
+    if same:
+        row.update({"ms_same": round(same, 4), "frac_same": round(ab / same / 1e6 / 8000, 3)})
+    # the measured ceiling of this row's access pattern: the kernel's math-free twin (read_px<..., TWIN>) over the same rotating sets,
+    # where one exists (BENCH_TWIN=0 skips it: the profiling passes cut the dispatch stream by 'launches' and must see the same stream every pass)
     if os.environ.get("BENCH_TWIN", "1") != "0":
-        twin = lambda: gpu.probe_pattern_read(d, 0, d.height, ptrs, strides, out.data_ptr(), out.stride(0), stream=stream.cuda_stream)
         try:
-            twin()
-            tmean, _ = time_launch(twin, warm=200)
+            twins[0]()
+            tmean, _ = time_launch(rotate(twins), warm=200)
             row.update({"twin_kernel": gpu.last_kernel()[-60:], "twin_ms_mean": round(tmean, 4), "twin_frac_of_8TBs": round(ab / tmean / 1e6 / 8000, 3),
                         "frac_of_twin": round(tmean / mean, 3)})
-            fn()
+            for c in calls:
+                c()
         except pkg.AvifGpuError:
             pass
     print(json.dumps(row), flush=True)
