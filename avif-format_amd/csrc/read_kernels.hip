@@ -815,9 +815,22 @@ struct TableKey {
 };
 struct TableSlot { TableKey key; float* dev = nullptr; bool valid = false; };
 struct DeviceTables { TableSlot slots[16]; int next = 0; };
-static std::mutex g_table_mu;
-static std::map<int, DeviceTables> g_tables;        // HIP device ordinal -> its cache
 constexpr size_t kTableSlotFloats = 3 * 4096;
+// ---- code objects (round 5, like write_kernels.hip): the Makefile compiles this file four times -- AG_READ_PART 1 = launch_read(), the table
+// cache's state and no kernel; 8 / 16 / 32 = read_px (and build_read_tables) for hosts of that depth, each a code object the HIP runtime
+// loads on the first open that needs it; 0 = everything in one object (tools/ab_variants.sh).
+#ifndef AG_READ_PART
+#define AG_READ_PART 0
+#endif
+hipError_t launch_read_d8(const ReadParams& p, int colorspace, bool alpha, int xs, int ys, hipStream_t st, char* label);
+hipError_t launch_read_d16(const ReadParams& p, int colorspace, bool alpha, int xs, int ys, hipStream_t st, char* label);
+hipError_t launch_read_d32(const ReadParams& p, int colorspace, bool alpha, int xs, int ys, hipStream_t st, char* label);
+#if AG_READ_PART > 1
+extern std::mutex g_table_mu;
+extern std::map<int, DeviceTables> g_tables;
+#else
+std::mutex g_table_mu;
+std::map<int, DeviceTables> g_tables;        // HIP device ordinal -> its cache
 
 // avifgpu_shutdown: nothing may be in flight any more.
 void release_read_tables()
@@ -835,6 +848,7 @@ void release_read_tables()
     g_tables.clear();
     if (cur >= 0) (void)hipSetDevice(cur);
 }
+#endif
 
 template <int CS, int DEPTH, bool ALPHA, int TRANSFER>
 static hipError_t cached_tables(const ReadParams& p, hipStream_t st, const float** out)
@@ -950,16 +964,26 @@ static hipError_t launch_read_chroma(const ReadParams& p, int xs, int ys, hipStr
     }
 }
 
-template <int CS>
-static hipError_t launch_read_cs(const ReadParams& p, int depth, bool alpha, int xs, int ys, hipStream_t st, char* label)
+template <int DEPTH>
+static hipError_t launch_read_depth(const ReadParams& p, int colorspace, bool alpha, int xs, int ys, hipStream_t st, char* label)
 {
-    switch (depth) {
-    case 8:  return alpha ? launch_read_chroma<CS, 8, true>(p, xs, ys, st, label)  : launch_read_chroma<CS, 8, false>(p, xs, ys, st, label);
-    case 16: return alpha ? launch_read_chroma<CS, 16, true>(p, xs, ys, st, label) : launch_read_chroma<CS, 16, false>(p, xs, ys, st, label);
-    default: return alpha ? launch_read_chroma<CS, 32, true>(p, xs, ys, st, label) : launch_read_chroma<CS, 32, false>(p, xs, ys, st, label);
+    switch (colorspace) {
+    case AVIFGPU_COLORSPACE_YCBCR: return alpha ? launch_read_chroma<kCsYcc, DEPTH, true>(p, xs, ys, st, label) : launch_read_chroma<kCsYcc, DEPTH, false>(p, xs, ys, st, label);
+    case AVIFGPU_COLORSPACE_RGB:   return alpha ? launch_read_chroma<kCsRgb, DEPTH, true>(p, xs, ys, st, label) : launch_read_chroma<kCsRgb, DEPTH, false>(p, xs, ys, st, label);
+    default:                       return alpha ? launch_read_chroma<kCsMono, DEPTH, true>(p, xs, ys, st, label) : launch_read_chroma<kCsMono, DEPTH, false>(p, xs, ys, st, label);
     }
 }
+#if AG_READ_PART == 0 || AG_READ_PART == 8
+hipError_t launch_read_d8(const ReadParams& p, int colorspace, bool alpha, int xs, int ys, hipStream_t st, char* label) { return launch_read_depth<8>(p, colorspace, alpha, xs, ys, st, label); }
+#endif
+#if AG_READ_PART == 0 || AG_READ_PART == 16
+hipError_t launch_read_d16(const ReadParams& p, int colorspace, bool alpha, int xs, int ys, hipStream_t st, char* label) { return launch_read_depth<16>(p, colorspace, alpha, xs, ys, st, label); }
+#endif
+#if AG_READ_PART == 0 || AG_READ_PART == 32
+hipError_t launch_read_d32(const ReadParams& p, int colorspace, bool alpha, int xs, int ys, hipStream_t st, char* label) { return launch_read_depth<32>(p, colorspace, alpha, xs, ys, st, label); }
+#endif
 
+#if AG_READ_PART == 0 || AG_READ_PART == 1
 static hipError_t launch_read_impl(const ReadParams& p, int colorspace, int depth, bool alpha, int xs, int ys, hipStream_t st, char* label);
 
 // FLAT launches, as on the write side (write_kernels.hip, launch_write): with no chroma sub-sampling and contiguous planes and host
@@ -992,11 +1016,12 @@ hipError_t launch_read(const ReadParams& p, int colorspace, int depth, bool alph
 
 static hipError_t launch_read_impl(const ReadParams& p, int colorspace, int depth, bool alpha, int xs, int ys, hipStream_t st, char* label)
 {
-    switch (colorspace) {
-    case AVIFGPU_COLORSPACE_YCBCR: return launch_read_cs<kCsYcc>(p, depth, alpha, xs, ys, st, label);
-    case AVIFGPU_COLORSPACE_RGB:   return launch_read_cs<kCsRgb>(p, depth, alpha, xs, ys, st, label);
-    default:                       return launch_read_cs<kCsMono>(p, depth, alpha, xs, ys, st, label);
+    switch (depth) {                                // a code object per host depth
+    case 8:  return launch_read_d8(p, colorspace, alpha, xs, ys, st, label);
+    case 16: return launch_read_d16(p, colorspace, alpha, xs, ys, st, label);
+    default: return launch_read_d32(p, colorspace, alpha, xs, ys, st, label);
     }
 }
+#endif   // AG_READ_PART == 0 || 1
 
 } // namespace avifgpu

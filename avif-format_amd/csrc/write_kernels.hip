@@ -26,6 +26,28 @@
 
 namespace avifgpu {
 
+// ---- code objects (round 5) ---------------------------------------------------------------------------------------------------
+// The library's Makefile compiles this file FIVE times, each time with another -DAG_WRITE_PART, into five code objects that the HIP
+// runtime loads one by one, on the first launch of a kernel of theirs -- a save then pays for the object its kernels live in, not for
+// all 650 instantiations (round 4: one 6.8-MB object, 18 ms in front of the first launch of a process):
+//    1   the streaming kernels (RGB(A) f32 / RGB(A)16 -> planes, the interleaved hand-offs) + launch_write(), the only entry point
+//    8, 16   write_px, the generic kernel, for 8- and 16-bit documents
+//    32  write_px for gray (+ alpha) f32 documents (their only path), 33 for RGB(A) f32 documents (the fall-back of the streaming kernels
+//        and the parametric-curve ICC variants), 36 write_px<32, ..., icc = 6>: documents whose profile carries sampled curves
+//    0   everything in one object (tools/ab_variants.sh builds its A/B libraries that way).
+// A kernel is emitted where a launch of it is instantiated; the launchers of a part are compiled in that part only (kHere* below), the
+// streaming part reaches the others through the four launch_planes_* functions.
+#ifndef AG_WRITE_PART
+#define AG_WRITE_PART 0
+#endif
+constexpr bool kHerePlain  = AG_WRITE_PART != 36 && AG_WRITE_PART != 1;     // write_px without icc = 6 (of the depth of the part)
+constexpr bool kHereIcc6   = AG_WRITE_PART == 0 || AG_WRITE_PART == 36;
+hipError_t launch_planes_d8(const WriteParams& p, int planes, bool dst16, int output, int xs, int ys, hipStream_t st, char* label);
+hipError_t launch_planes_d16(const WriteParams& p, int planes, bool dst16, int output, int xs, int ys, hipStream_t st, char* label);
+hipError_t launch_planes_d32(const WriteParams& p, int planes, bool dst16, int output, int xs, int ys, hipStream_t st, char* label);
+hipError_t launch_planes_d32_rgb(const WriteParams& p, int planes, bool dst16, int output, int xs, int ys, hipStream_t st, char* label);
+hipError_t launch_planes_d32_icc6(const WriteParams& p, int planes, bool dst16, int output, int xs, int ys, hipStream_t st, char* label);
+
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #ifndef AG_ICC_F32
 #define AG_ICC_F32 1
@@ -717,6 +739,13 @@ enum { kOutRefColor = 0, kOutRefGray = 1, kOutYcbcr = 2 };
 #ifndef AG_W8_NC_ALPHA
 #define AG_W8_NC_ALPHA 4
 #endif
+#ifndef AG_W8_SPANLOAD
+#define AG_W8_SPANLOAD 0
+#endif
+// the generic kernel's lane-strided source loads: 0 = through the L2 normally (they rely on it to merge their 16-byte pieces), 1 = non-temporal
+#ifndef AG_WPX_NT_LOADS
+#define AG_WPX_NT_LOADS 0
+#endif
 // Packed f32 (v_pk_mul_f32 / v_pk_add_f32) in the u8 kernels' stage B: 0 never, 1 behind an ICC stage, 2 always.  Measured: nothing.
 // A wave64 v_fma_f32 issues in ~2.7 cycles on gfx950 and a v_pk_fma_f32 in ~5.8 (tools/alubench, profiles/r03/alubench_int.txt) --
 // two plain instructions cost what one packed one does -- so the 17 % fewer instructions of the 8-bit ICC kernel (2779 -> 2297 static
@@ -767,7 +796,12 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
     // interleaved output, if any) is one contiguous span per row, moved with fully coalesced non-temporal accesses
     // through a wave-private LDS strip (ALIGNED instantiation; the unaligned one keeps per-lane accesses). ----------
     constexpr int NDO = (OUT == kOutRefColor) ? PXT * PLANES * DSZ / 4 : 1;     // interleaved-output dwords per lane per row
-    constexpr int NDS = NDO;
+    // AG_W8_SPANLOAD (round 5): the 8-bit RGB(A) -> u8 planes path (FAST8 below; BASELINE C2) takes its source rows like the streaming
+    // kernels do -- the wave's span as fully coalesced NON-TEMPORAL 16-byte loads, transposed to lane-major through the wave's strip --
+    // instead of lane-strided loads that allocate in the L2 / Infinity Cache so that their 16-byte pieces can be merged there.
+    constexpr bool SPANLOAD8 = AG_W8_SPANLOAD && AG_W8_PACKED && DEPTH == 8 && (PLANES == 3 || PLANES == 4) && OUT == kOutYcbcr && !DST16 &&
+                               (ICC == 0 || (ICC == 3 && AG_ICC8_FAST)) && ALIGNED;
+    constexpr int NDS = SPANLOAD8 ? PXT * PLANES / 4 : NDO;
     __shared__ __attribute__((aligned(16))) uint32_t strips[ALIGNED ? kWpxWaves : 1][ALIGNED ? WaveSpan<NDS>::STRIP_DW : 1];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -861,21 +895,29 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
                                (ICC == 0 || (ICC == 3 && AG_ICC8_FAST)) && ALIGNED;
         constexpr bool PKF32 = AG_W8_PKF32 == 2 || (AG_W8_PKF32 == 1 && ICC != 0);
         if constexpr (FAST8) {
+            constexpr int NDB = PXT * PLANES / 4;                           // dwords of a footprint row as 8-bit codes
+            uint32_t raw[VR][NDB];
+            if constexpr (SPANLOAD8) {                                      // the whole wave, active lanes or not: the transfers are wave-wide
+#pragma unroll
+                for (int vr = 0; vr < VR; ++vr) {
+                    const int r = min(r0 + vr, p.rows_to_end - 1);
+                    wave_span_load<NDB>(strip, lane, p.src + (long long)r * p.src_row_bytes + (long long)wx * (64 * PXT * PLANES), span_px * PLANES, raw[vr]);
+                }
+            }
             if (active) {
                 constexpr int NC = PXT >> XS;
-                constexpr int NDB = PXT * PLANES / 4;                       // dwords of a footprint row as 8-bit codes
-                uint32_t raw[VR][NDB];
 #pragma unroll
                 for (int vr = 0; vr < VR; ++vr) {
                     const int r = min(r0 + vr, p.rows_to_end - 1);          // bottom edge: replicate the last IMAGE row
                     const uint8_t* rowp = p.src + (long long)r * p.src_row_bytes;
                     if (full) {
-                        if constexpr (DEPTH == 8) load_dwords<NDB, false, true>(rowp + (long long)x0 * PLANES, raw[vr]);
+                        if constexpr (SPANLOAD8) { }
+                        else if constexpr (DEPTH == 8) load_dwords<NDB, AG_WPX_NT_LOADS != 0, true>(rowp + (long long)x0 * PLANES, raw[vr]);
                         else {
                             // 16-bit document saved at 8 bit: BuildSixteenBitToEightBitLookup's entry (rescale16_to_8, exact integer form) per
                             // sample as the row arrives, packed to the byte layout an 8-bit document has -- from here on the two are the same
                             uint32_t w[2 * NDB];
-                            load_dwords<2 * NDB, false, true>(rowp + (long long)x0 * PLANES * 2, w);
+                            load_dwords<2 * NDB, AG_WPX_NT_LOADS != 0, true>(rowp + (long long)x0 * PLANES * 2, w);
 #pragma unroll
                             for (int d = 0; d < NDB; ++d) {
                                 const uint32_t b0 = rescale16_to_8(min(w[2 * d] & 0xffffu, 32768u)), b1 = rescale16_to_8(min(w[2 * d] >> 16, 32768u));
@@ -1083,7 +1125,7 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
                 // this measured FASTER than a coalesced-NT + LDS-transpose load stage (which costs 12-20 VGPRs and a wave of
                 // occupancy: C4 4:2:0 0.69 -> 0.47 of peak, profiles/r01/transposed_load_experiment.txt).
                 uint32_t raw[ND];
-                load_dwords<ND, false, ALIGNED>(rowp + (long long)x0 * BPP, raw);
+                load_dwords<ND, AG_WPX_NT_LOADS != 0, ALIGNED>(rowp + (long long)x0 * BPP, raw);
                 if constexpr (ICC == 5 && DEPTH == 16) {
                     // the ICC stage's input clamp (Photoshop's 16-bit white is 32768; the table position is defined up to there), two
                     // samples per v_pk_min_u16 while they are still packed
@@ -1259,6 +1301,12 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
 #define AG_STREAM_BLOCK 128
 #endif
 constexpr int kStreamWaves = AG_STREAM_BLOCK / 64;
+// ... and 256 for the interleaved f32 hand-off: on fresh data 0.782-0.789 -> 0.796-0.801 of 8 TB/s at 8192^2 with nothing else moved
+// (profiles/r05/workgroup_size_fresh_data_ab.txt; the 16-bit kernels and the integer hand-off are indifferent and stay at 128)
+#ifndef AG_F32_REF_BLOCK
+#define AG_F32_REF_BLOCK 256
+#endif
+constexpr int kF32RefWaves = AG_F32_REF_BLOCK / 64;
 
 typedef float    f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -1431,6 +1479,9 @@ template <bool NT, typename V> AG_DEV void stream_store(V* p, V v)
 #ifndef AG_HOT_F32_STRIP
 #define AG_HOT_F32_STRIP 1
 #endif
+#ifndef AG_HOT_PREFETCH
+#define AG_HOT_PREFETCH 0
+#endif
 template <int TRANSFER, int PXL, bool NT>
 __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_ycbcr444_hot(const WriteParams p)
 {
@@ -1453,14 +1504,36 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_ycbcr444_hot(
     const uint32_t step = gridDim.x * WPB;
     const uint32_t voff = (uint32_t)lane * 16u;
 
+    // AG_HOT_PREFETCH (round 5, A/B switch, off): software pipeline of the span loop -- a wave issues the K loads of its NEXT span before
+    // it starts on the curves of the one it holds, so that its requests fly under its own math; a span beyond the tile gets a zero-sized
+    // resource (no traffic, zeros).  Measured on fresh data over grid caps of 1792 ... 16384 blocks (profiles/r05/prefetch_pipeline_ab.txt)
+    // and NOT adopted: a wave that loops over spans loses to one-span-per-wave dispatch at every cap with or without the prefetch (8192^2
+    // 0.70-0.75 of 8 TB/s against 0.77, 16384^2 0.56-0.64 against 0.72-0.74 -- the in-order block dispatch keeps the chip's accesses in a
+    // compact moving window, persistent waves drift apart), the 24 registers cost the eighth wave per SIMD (70 VGPRs; -4 % at one span per
+    // wave), and the compiler's loop-head wait is vmcnt(6): the previous span's stores must be acknowledged before the math starts.
+    auto issue = [&](uint32_t s, f32x4 (&dst)[K]) {
+        const uint32_t r = s / spans_per_row;
+        const uint32_t sx = s - r * spans_per_row;
+        const int span_px = s < total ? min(SPAN_PX, p.width - (int)sx * SPAN_PX) : 0;
+        const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)(s < total ? r : 0) * p.src_row_bytes + (long long)(s < total ? sx : 0) * (SPAN_PX * 12), (uint32_t)span_px * 12u);
+#pragma unroll
+        for (int k = 0; k < K; ++k) dst[k] = span_load_cached(k, K) ? span_load16<false>(rs, voff, 1024u * k) : span_load16<NT>(rs, voff, 1024u * k);   // a float4 beyond the row: zeros, and nothing is stored for it
+    };
+    f32x4 nxt[AG_HOT_PREFETCH ? K : 1];
+    if constexpr (AG_HOT_PREFETCH) issue(blockIdx.x * WPB + wave, nxt);
     for (uint32_t sidx = blockIdx.x * WPB + wave; sidx < total; sidx += step) {
         const uint32_t r = sidx / spans_per_row;
         const uint32_t sx = sidx - r * spans_per_row;
         const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);             // < SPAN_PX only for the last span of a row
-        const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)r * p.src_row_bytes + (long long)sx * (SPAN_PX * 12), (uint32_t)span_px * 12u);
         f32x4 cur[K];
+        if constexpr (AG_HOT_PREFETCH) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) cur[k] = span_load_cached(k, K) ? span_load16<false>(rs, voff, 1024u * k) : span_load16<NT>(rs, voff, 1024u * k);   // a float4 beyond the row: zeros, and nothing is stored for it
+            for (int k = 0; k < K; ++k) cur[k] = nxt[k];
+            issue(sidx + step, nxt);
+            __builtin_amdgcn_sched_barrier(0);                                     // the next span's loads leave before this span's math starts
+        } else {
+            issue(sidx, cur);
+        }
 
         float R[PXL], G[PXL], B[PXL];
         if constexpr (AG_HOT_F32_STRIP) {
@@ -2149,6 +2222,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr_sub_hot(con
 // Rescale (per sample) and the integer premultiply (per pixel) run on the vector as loaded; the codes go back into the same two
 // dwords per pixel and cross the strip as one ds_write_b128 (lane stride padded 16 -> 20 dwords: conflict-free b128 read-back);
 // lane l then holds pixels [8l, 8l+8) and writes 16 bytes per plane.  width % 8 == 0 (whole lanes).
+template <int PART_ANCHOR = 0>          // a template only so that it is emitted where it is launched (the streaming part)
 __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra444_hot(const WriteParams p)
 {
     constexpr int PXL = 8, K = 4, SPAN_PX = 512, LSTRIDE = 20;
@@ -2221,7 +2295,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra444_hot(co
 // Output sample i is a function of input sample i (RGB) or of its own pixel's float4 (RGBA): no transposition at all.  A wave
 // streams 64 x 4 float4 per trip: coalesced non-temporal 16-byte loads, the curve, 8-byte non-temporal stores at the same index.
 template <int TRANSFER, int PLANES>
-__global__ __launch_bounds__(AG_STREAM_BLOCK) void write_f32_ref_stream(const WriteParams p)
+__global__ __launch_bounds__(AG_F32_REF_BLOCK) void write_f32_ref_stream(const WriteParams p)
 {
     pq_prologue<TRANSFER>();
     constexpr int K = 4;
@@ -2230,7 +2304,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_f32_ref_stream(const Wr
     const uint32_t n4 = (uint32_t)p.width * PLANES / 4;                // float4 per row (host: width * PLANES % 4 == 0)
     const uint32_t chunks = (n4 + 64 * K - 1) / (64 * K);
     const uint32_t total = chunks * (uint32_t)p.nrows;
-    for (uint32_t widx = blockIdx.x * kStreamWaves + wave; widx < total; widx += gridDim.x * kStreamWaves) {
+    for (uint32_t widx = blockIdx.x * kF32RefWaves + wave; widx < total; widx += gridDim.x * kF32RefWaves) {
         const uint32_t r = widx / chunks;
         const uint32_t c = widx - r * chunks;
         const f32x4* sp = reinterpret_cast<const f32x4*>(p.src + (long long)r * p.src_row_bytes);
@@ -2382,6 +2456,20 @@ static inline int grid_icc(long long threads_needed)
     return (int)(b > AG_ICC_BLOCK_CAP ? AG_ICC_BLOCK_CAP : b);
 }
 
+// A workgroup of the generic kernel that evaluates PQ in its close form starts by copying the 4-KiB exponent table to LDS: at one footprint
+// group per workgroup that is 4 KiB of LDS fill per 6 KiB of pixels for a gray f32 document.  A capped grid lets a workgroup run several
+// groups per copy: Gray32 -> 10-bit PQ at 8192^2 on fresh data 0.528 of 8 TB/s uncapped (65 536 blocks), 0.623 at 8192 or 16 384 blocks,
+// 0.59 at 32 768 (round 5; the streaming kernels, whose waves own 6-12 KiB each, prefer one span per wave: profiles/r05/prefetch_pipeline_ab.txt).
+#ifndef AG_PQ_TABLE_BLOCK_CAP
+#define AG_PQ_TABLE_BLOCK_CAP (256LL * 32)
+#endif
+template <int TRANSFER>
+static inline int grid_px(long long threads_needed)
+{
+    const long long b = grid_for(threads_needed);
+    return (int)((TRANSFER == kTransferPqHi && b > AG_PQ_TABLE_BLOCK_CAP) ? AG_PQ_TABLE_BLOCK_CAP : b);
+}
+
 template <int DEPTH, int PLANES, int OUT, bool DST16, int XS, int YS, int TRANSFER>
 static hipError_t launch_one(const WriteParams& p, hipStream_t st, char* label)
 {
@@ -2426,7 +2514,9 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, char* label)
     }
     if constexpr (DEPTH == 32 && PLANES >= 3) {
         if (p.icc_s_tab != nullptr) {               // sampled document curves: table lookup in front of the matrix
-            {
+            if constexpr (!kHereIcc6) {             // those kernels live in a code object of their own (AG_WRITE_PART 36)
+                return launch_planes_d32_icc6(p, PLANES, DST16, OUT == kOutRefColor ? AVIFGPU_OUT_REFERENCE : AVIFGPU_OUT_YCBCR, XS, YS, st, label);
+            } else {
                 snprintf(label, kLabelBytes, "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=6>",
                          DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned);
                 const size_t lds = p.icc_s_lds ? (size_t)(p.icc_s_n[0] + p.icc_s_n[1] + p.icc_s_n[2]) * 4 : 0;      // <= 48 KiB
@@ -2436,6 +2526,11 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, char* label)
                 return hipGetLastError();
             }
         }
+    }
+    if constexpr (!kHerePlain) {
+        return hipErrorInvalidValue;                // part 36 holds the icc = 6 launches only, the streaming part none of write_px
+    } else {
+    if constexpr (DEPTH == 32 && PLANES >= 3) {
         if (p.icc_trc_type[0] != 0) {               // ICC row transform requested: separate instantiations, the others pay nothing
             bool linear = true;
             for (int c = 0; c < 3; ++c) linear = linear && p.icc_trc_linear[c] != 0;
@@ -2453,8 +2548,8 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, char* label)
             snprintf(label, kLabelBytes, "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=%d>",
                      DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned, linear ? 1 : 2);
             if (linear) {
-                if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 1>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
-                else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 1>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
+                if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 1>), dim3(grid_px<TRANSFER>(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
+                else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 1>), dim3(grid_px<TRANSFER>(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
             } else {
                 if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 2>), dim3(grid_icc(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
                 else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 2>), dim3(grid_icc(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
@@ -2462,9 +2557,10 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, char* label)
             return hipGetLastError();
         }
     }
-    if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
-    else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
+    if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true>), dim3(grid_px<TRANSFER>(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
+    else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false>), dim3(grid_px<TRANSFER>(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
     return hipGetLastError();
+    }
 }
 
 #define AG_LAUNCH(DEPTH, PLANES, OUT, DST16, XS, YS, TR) \
@@ -2498,22 +2594,66 @@ static hipError_t launch_out(const WriteParams& p, int output, int xs, int ys, h
     }
 }
 
+template <int DEPTH, int PLANES>
+static hipError_t launch_planes_n(const WriteParams& p, bool dst16, int output, int xs, int ys, hipStream_t st, char* label)
+{
+    if (dst16) return launch_out<DEPTH, PLANES, true>(p, output, xs, ys, st, label);
+    if constexpr (DEPTH == 32) return hipErrorInvalidValue;          // a 32-bit document is never saved at 8 bit
+    else return launch_out<DEPTH, PLANES, false>(p, output, xs, ys, st, label);
+}
 template <int DEPTH>
 static hipError_t launch_planes(const WriteParams& p, int planes, bool dst16, int output, int xs, int ys,
                                 hipStream_t st, char* label)
 {
+    // 32-bit documents: gray (+ alpha) lives in part 32, RGB(A) -- the fall-back of the streaming kernels -- in part 33 (36: its icc = 6 half)
+    constexpr bool gray_here = DEPTH != 32 || AG_WRITE_PART == 0 || AG_WRITE_PART == 32;
+    constexpr bool rgb_here = DEPTH != 32 || AG_WRITE_PART == 0 || AG_WRITE_PART == 33 || AG_WRITE_PART == 36;
     switch (planes) {
-    case 1: return dst16 ? launch_out<DEPTH, 1, true>(p, output, xs, ys, st, label)
-                         : (DEPTH == 32 ? hipErrorInvalidValue : launch_out<DEPTH == 32 ? 16 : DEPTH, 1, false>(p, output, xs, ys, st, label));
-    case 2: return dst16 ? launch_out<DEPTH, 2, true>(p, output, xs, ys, st, label)
-                         : (DEPTH == 32 ? hipErrorInvalidValue : launch_out<DEPTH == 32 ? 16 : DEPTH, 2, false>(p, output, xs, ys, st, label));
-    case 3: return dst16 ? launch_out<DEPTH, 3, true>(p, output, xs, ys, st, label)
-                         : (DEPTH == 32 ? hipErrorInvalidValue : launch_out<DEPTH == 32 ? 16 : DEPTH, 3, false>(p, output, xs, ys, st, label));
-    default: return dst16 ? launch_out<DEPTH, 4, true>(p, output, xs, ys, st, label)
-                          : (DEPTH == 32 ? hipErrorInvalidValue : launch_out<DEPTH == 32 ? 16 : DEPTH, 4, false>(p, output, xs, ys, st, label));
+    case 1:  if constexpr (gray_here) return launch_planes_n<DEPTH, 1>(p, dst16, output, xs, ys, st, label); else return hipErrorInvalidValue;
+    case 2:  if constexpr (gray_here) return launch_planes_n<DEPTH, 2>(p, dst16, output, xs, ys, st, label); else return hipErrorInvalidValue;
+    case 3:  if constexpr (rgb_here) return launch_planes_n<DEPTH, 3>(p, dst16, output, xs, ys, st, label); else return launch_planes_d32_rgb(p, planes, dst16, output, xs, ys, st, label);
+    default: if constexpr (rgb_here) return launch_planes_n<DEPTH, 4>(p, dst16, output, xs, ys, st, label); else return launch_planes_d32_rgb(p, planes, dst16, output, xs, ys, st, label);
     }
 }
 
+// ---- the parts' entry points (see AG_WRITE_PART at the top) ----
+#if AG_WRITE_PART == 0 || AG_WRITE_PART == 8
+hipError_t launch_planes_d8(const WriteParams& p, int planes, bool dst16, int output, int xs, int ys, hipStream_t st, char* label)
+{
+    return launch_planes<8>(p, planes, dst16, output, xs, ys, st, label);
+}
+#endif
+#if AG_WRITE_PART == 0 || AG_WRITE_PART == 16
+hipError_t launch_planes_d16(const WriteParams& p, int planes, bool dst16, int output, int xs, int ys, hipStream_t st, char* label)
+{
+    return launch_planes<16>(p, planes, dst16, output, xs, ys, st, label);
+}
+#endif
+#if AG_WRITE_PART == 0 || AG_WRITE_PART == 32
+hipError_t launch_planes_d32(const WriteParams& p, int planes, bool dst16, int output, int xs, int ys, hipStream_t st, char* label)
+{
+    return launch_planes<32>(p, planes, dst16, output, xs, ys, st, label);
+}
+#endif
+#if AG_WRITE_PART == 0 || AG_WRITE_PART == 33
+hipError_t launch_planes_d32_rgb(const WriteParams& p, int planes, bool dst16, int output, int xs, int ys, hipStream_t st, char* label)
+{
+    return launch_planes<32>(p, planes, dst16, output, xs, ys, st, label);
+}
+#endif
+#if AG_WRITE_PART == 0 || AG_WRITE_PART == 36
+hipError_t launch_planes_d32_icc6(const WriteParams& p, int planes, bool dst16, int output, int xs, int ys, hipStream_t st, char* label)
+{
+#if AG_WRITE_PART == 0
+    (void)p; (void)planes; (void)dst16; (void)output; (void)xs; (void)ys; (void)st; (void)label;
+    return hipErrorInvalidValue;                    // one object: launch_one launches the sampled-curve kernels itself
+#else
+    return launch_planes<32>(p, planes, dst16, output, xs, ys, st, label);     // here launch_one compiles the icc = 6 launches only
+#endif
+}
+#endif
+
+#if AG_WRITE_PART == 0 || AG_WRITE_PART == 1
 static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes, bool dst16, int output, int xs, int ys,
                                     int variant, hipStream_t st, char* label);
 
@@ -2584,11 +2724,11 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
         const long long waves = ((n4 + 255) / 256) * p.nrows;
         if (waves == 0) return hipSuccess;
         if (waves + 8LL * 65536 * 4 < 0x7fffffffLL) {
-            long long blocks = (waves + kStreamWaves - 1) / kStreamWaves;
-            if (blocks > AG_STREAM_BLOCK_CAP * 4 / kStreamWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kStreamWaves;
+            long long blocks = (waves + kF32RefWaves - 1) / kF32RefWaves;
+            if (blocks > AG_STREAM_BLOCK_CAP * 4 / kF32RefWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kF32RefWaves;
             snprintf(label, kLabelBytes, "write_f32_ref_stream<transfer=%d,planes=%d>", p.transfer, planes);
-#define AG_REF(TR) do { if (planes == 4) hipLaunchKernelGGL((write_f32_ref_stream<TR, 4>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); \
-                        else hipLaunchKernelGGL((write_f32_ref_stream<TR, 3>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); } while (0)
+#define AG_REF(TR) do { if (planes == 4) hipLaunchKernelGGL((write_f32_ref_stream<TR, 4>), dim3((int)blocks), dim3(AG_F32_REF_BLOCK), 0, st, p); \
+                        else hipLaunchKernelGGL((write_f32_ref_stream<TR, 3>), dim3((int)blocks), dim3(AG_F32_REF_BLOCK), 0, st, p); } while (0)
             switch (p.transfer) {
             case AVIFGPU_TRANSFER_PQ:       if (pq_hi_launch(p)) AG_REF(kTransferPqHi); else AG_REF(AVIFGPU_TRANSFER_PQ); break;
             case AVIFGPU_TRANSFER_HLG:      AG_REF(AVIFGPU_TRANSFER_HLG); break;
@@ -2635,7 +2775,7 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
             long long blocks = (spans + kStreamWaves - 1) / kStreamWaves;
             if (blocks > AG_STREAM_BLOCK_CAP * 4 / kStreamWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kStreamWaves;
             snprintf(label, kLabelBytes, "write_rgba16_ycbcra444_hot");
-            hipLaunchKernelGGL(write_rgba16_ycbcra444_hot, dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p);
+            hipLaunchKernelGGL((write_rgba16_ycbcra444_hot<0>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p);
             return hipGetLastError();
         }
     }
@@ -2804,11 +2944,12 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
             }
         }
     }
-    switch (depth) {
-    case 8:  return launch_planes<8>(p, planes, dst16, output, xs, ys, st, label);
-    case 16: return launch_planes<16>(p, planes, dst16, output, xs, ys, st, label);
-    default: return launch_planes<32>(p, planes, dst16, output, xs, ys, st, label);
+    switch (depth) {                                // the generic kernel: a code object per document depth
+    case 8:  return launch_planes_d8(p, planes, dst16, output, xs, ys, st, label);
+    case 16: return launch_planes_d16(p, planes, dst16, output, xs, ys, st, label);
+    default: return launch_planes_d32(p, planes, dst16, output, xs, ys, st, label);
     }
 }
+#endif   // AG_WRITE_PART == 0 || 1
 
 } // namespace avifgpu

@@ -73,7 +73,7 @@ def test_save_hdr_float_tier(gpu):
     d, src, host, img, code = _save(gpu, kw, 264 * 12 * 10, pkg.OUT_YCBCR, matrix=pkg.MATRIX_BT2020_NCL)
     assert code == 0
     st = harness.compare_write(d, harness.oracle_write(d, src), _planes_of(img, d))
-    assert st["max_abs"] <= 1 and st["exact_frac"] > 0.99, st
+    assert st["max_abs"] <= 1 and harness.t2_exact_ok(st, harness.T2_MIN_EXACT[d.bit_depth]), st
     gpu.lib.avifgpu_image_free(ctypes.byref(img))
 
 

@@ -14,8 +14,8 @@ pkg = harness.pkg
 pytestmark = pytest.mark.gpu
 
 T2_MAX_CODE_DELTA = 1
-T2_MIN_EXACT = {10: 0.999, 12: 0.998}
-T2_SMALL_CASE_MISMATCHES = 4
+T2_MIN_EXACT = harness.T2_MIN_EXACT
+T2_SMALL_CASE_MISMATCHES = harness.T2_SMALL_CASE_MISMATCHES
 
 
 def _check(cid, kw, got, want):

@@ -278,6 +278,7 @@ if __name__ == "__main__":
         # ... at the plug-in's default depth and chroma format: what saving a typical 32-bit document (linear Display-P3 working space) as HDR does
         bench_write("D12 + ICC (linear Display-P3 doc -> Rec.2020) 8192^2 RGB f32 -> 12-bit PQ 4:2:2 nearest (default HDR save of a linear-profile document)", icc=xf, planes=3, alpha_state=0, output=1, chroma=P.CHROMA_422, chroma_downsampling=P.DOWNSAMPLE_NEAREST, **d12)
         bench_write("D12 + ICC (linear Display-P3 doc -> Rec.2020) 8192^2 RGB f32 -> 12-bit PQ 4:4:4", icc=xf, planes=3, alpha_state=0, output=1, chroma=P.CHROMA_444, **d12)
+        bench_write("D12 + ICC (linear Display-P3 doc -> Rec.2020) 8192^2 RGB f32 -> 12-bit PQ interleaved RRGGBB (reference hand-off behind the document's profile: integration/'s default for a 32-bit document)", icc=xf, planes=3, alpha_state=0, output=0, **d12)
         n = L.oracle_icc_make_profile(0, 1, 0.0, buf, len(buf))
         xf2 = gpu.icc_prepare(buf.raw[:n])
         bench_write("C4 + ICC (sRGB parametric TRC doc -> Rec.2020) 8192^2 RGB f32 -> 10-bit PQ 4:4:4", icc=xf2, width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=9, color_primaries=9)

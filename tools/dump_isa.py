@@ -27,7 +27,7 @@ def main():
     pats = [re.compile(p) for p in sys.argv[2:]]
     os.makedirs(out, exist_ok=True)
     rows = []
-    for obj in sorted(glob.glob(os.path.join(ROOT, "avif-format_amd", "build", "*.hip.o"))):
+    for obj in sorted(glob.glob(os.path.join(os.environ.get("ISA_OBJDIR", os.path.join(ROOT, "avif-format_amd", "build")), "*.hip.o"))):
         base = os.path.basename(obj).split(".")[0]
         fat, co = f"/tmp/{base}.fat", f"/tmp/{base}.co"
         subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat], check=True)
