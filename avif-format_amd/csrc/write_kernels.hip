@@ -1614,11 +1614,16 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_ycbcr444_hot(
 // which moves the exact-match rate of the codes by nothing measurable (profiles/r02/icc_f32_ab.txt; bar of tests/test_gpu_icc.py).
 // ICCV = 4: the sRGB destination of the SDR (Clip) save of a 32-bit document -- the inverse sRGB curve after the matrix, in single
 // precision (icc_inv4_f: exact-match rate 0.99992 against lcms2 instead of 0.99999 with FP64 curves, profiles/r02/icc_f32_ab.txt).
-template <int TRANSFER, int ICCV>
+// OUTREF (round 5): the same kernel for the reference's own interleaved hand-off (AVIFGPU_OUT_REFERENCE, what integration/ asks for by
+// default): no stage B -- the lane's 24 codes are packed RRGGBB and leave through the strip again as coalesced 16-byte stores
+// (wave_span_store; the strip of a 6-float4 half span is exactly a lane-major span of 12 dwords per lane).  A 32-bit document with a linear
+// profile saved through the default adapter ran on the generic kernel until then (0.68 of 8 TB/s at 8192^2).
+template <int TRANSFER, int ICCV, bool OUTREF = false>
 __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444_hot(const WriteParams p)
 {
     pq_prologue<TRANSFER>();
     constexpr int PXL = 8, K = 6, SPAN_PX = 512, SPAN_DW = SpanStrip<K>::kDwords;
+    static_assert(!OUTREF || SPAN_DW >= WaveSpan<12>::STRIP_DW, "the strip also carries the packed codes back");
     __shared__ __attribute__((aligned(16))) uint32_t strip[kF32Waves][SPAN_DW];
     __shared__ __attribute__((aligned(16))) f32x4_t pow_t[(ICCV == 4 && !AG_ICC_FASTPOW) ? kIccPowBins : 1];
     if constexpr (ICCV == 4) {
@@ -1651,6 +1656,7 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444
         float c[PXL * 3];
         span_transpose<K>(my, lane, cur, c);
         uint32_t yv[PXL], cbv[PXL], crv[PXL];
+        uint32_t pk[OUTREF ? 12 : 1];
 #pragma unroll
         for (int i = 0; i < PXL; i += 2) {                                         // two pixels = three sample pairs for the packed curve
             float t[6], q[6];
@@ -1670,6 +1676,10 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444
                 const f32x2 l = oetf_level2<TRANSFER>(p, t[e], t[e + 1]);
                 q[e] = l.x; q[e + 1] = l.y;
             }
+            if constexpr (OUTREF) {                                                // six levels = three dwords of RRGGBB codes (:1093: the level IS the code)
+#pragma unroll
+                for (int e = 0; e < 6; e += 2) pk[(3 * i + e) >> 1] = (uint32_t)q[e] | ((uint32_t)q[e + 1] << 16);
+            } else {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const float R = q[3 * h], G = q[3 * h + 1], B = q[3 * h + 2];
@@ -1677,6 +1687,11 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444
                 cbv[i + h] = clip_round(R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2] + p.half, p.maxv);
                 crv[i + h] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
             }
+            }
+        }
+        if constexpr (OUTREF) {
+            wave_span_store<12>(strip[wave], lane, true, pk, p.dst[0] + (long long)r * p.dst_stride[0] + (long long)sx * (SPAN_PX * 6), span_px * 6);
+            continue;
         }
         const long long xoff = (long long)sx * (SPAN_PX * 2);
         u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
@@ -2715,6 +2730,33 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
             if (planes == 4) AG_IREF(16, 4); else AG_IREF(16, 3);
 #undef AG_IREF
             return hipGetLastError();
+        }
+    }
+    {   // ... behind a linear (or one simple parametric) document profile: the streaming ICC kernel with the interleaved hand-off as its output
+        const bool lin = AG_ICC1_HOT && p.icc_trc_type[0] != 0 && p.icc_s_tab == nullptr && p.icc_trc_linear[0] && p.icc_trc_linear[1] && p.icc_trc_linear[2];
+        const bool r1 = lin && p.icc_out == 0, r4 = lin && p.icc_out == 4 && p.transfer == AVIFGPU_TRANSFER_CLIP;
+        const bool r2 = AG_ICC2_HOT && p.icc_trc_type[0] != 0 && p.icc_s_tab == nullptr && p.icc_same_simple && p.icc_out == 0;
+        if ((variant & 1) && (r1 || r4 || r2) && depth == 32 && planes == 3 && dst16 && output == AVIFGPU_OUT_REFERENCE &&
+            (p.src_row_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 3) == 0 &&
+            ((reinterpret_cast<uintptr_t>(p.dst[0]) | (uintptr_t)p.dst_stride[0]) & 15) == 0) {
+            const long long spans = (long long)((p.width + 511) / 512) * p.nrows;
+            if (spans == 0) return hipSuccess;
+            if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
+                long long blocks = (spans + kF32Waves - 1) / kF32Waves;
+                if (blocks > AG_STREAM_BLOCK_CAP * 4 / kF32Waves) blocks = AG_STREAM_BLOCK_CAP * 4 / kF32Waves;
+                snprintf(label, kLabelBytes, "write_rgb32_icc1_ycbcr444_hot<transfer=%d,out=ref> icc=%d", p.transfer, r4 ? 4 : r2 ? 2 : 1);
+                if (r4) { hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<AVIFGPU_TRANSFER_CLIP, 4, true>), dim3((int)blocks), dim3(AG_F32_STREAM_BLOCK), 0, st, p); return hipGetLastError(); }
+#define AG_IREF32(TR) do { if (r2) hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<TR, 2, true>), dim3((int)blocks), dim3(AG_F32_STREAM_BLOCK), 0, st, p); \
+                           else hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<TR, 1, true>), dim3((int)blocks), dim3(AG_F32_STREAM_BLOCK), 0, st, p); } while (0)
+                switch (p.transfer) {
+                case AVIFGPU_TRANSFER_PQ:       if (pq_hi_launch(p)) AG_IREF32(kTransferPqHi); else AG_IREF32(AVIFGPU_TRANSFER_PQ); break;
+                case AVIFGPU_TRANSFER_HLG:      AG_IREF32(AVIFGPU_TRANSFER_HLG); break;
+                case AVIFGPU_TRANSFER_SMPTE428: AG_IREF32(AVIFGPU_TRANSFER_SMPTE428); break;
+                default:                        AG_IREF32(AVIFGPU_TRANSFER_CLIP); break;
+                }
+#undef AG_IREF32
+                return hipGetLastError();
+            }
         }
     }
     if ((variant & 1) && p.icc_trc_type[0] == 0 && depth == 32 && planes >= 3 && dst16 && output == AVIFGPU_OUT_REFERENCE &&

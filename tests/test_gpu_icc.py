@@ -101,6 +101,44 @@ def test_icc1_streaming_kernel_matches_lcms2(gpu, lcms, name, kind, trc, g, widt
         assert st["exact_frac"] >= (0.99 if transfer != pkg.TRANSFER_CLIP else 0.985) or d.width * d.height < 1000, (name, st)
 
 
+@pytest.mark.parametrize("name,kind,trc,g", PROFILES)
+@pytest.mark.parametrize("width", [1024, 520, 516, 8])
+def test_icc_streaming_reference_handoff_matches_lcms2(gpu, lcms, name, kind, trc, g, width):
+    """Round 5: the interleaved RRGGBB hand-off (AVIFGPU_OUT_REFERENCE -- what integration/ asks for by default) behind a linear or a
+    simple parametric document profile runs on the streaming ICC kernel (write_rgb32_icc1_ycbcr444_hot<..., OUTREF>: the codes leave
+    through the wave's strip as coalesced stores) where the plane rows are 16-byte aligned; same arithmetic as the 4:4:4 form, same bars."""
+    icc = _profile(lcms, kind, trc, g)
+    xf = gpu.icc_prepare(icc)
+    for bits, transfer, peak in ((10, pkg.TRANSFER_PQ, 80), (12, pkg.TRANSFER_PQ, 1000), (12, pkg.TRANSFER_CLIP, 80), (10, pkg.TRANSFER_HLG, 80),
+                                 (12, pkg.TRANSFER_SMPTE428, 80)):
+        d = pkg.WriteDesc(width=width, height=11, depth=32, planes=3, bit_depth=bits, transfer=transfer, peak_nits=peak,
+                          alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_REFERENCE, chroma=pkg.CHROMA_444,
+                          matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020)
+        src = harness.make_write_source(d, seed=width + bits)
+        if trc != 0 or g != 1.0:
+            src = np.abs(src)
+        conv = src.copy()
+        assert lcms.oracle_icc_convert_rows_to_rec2020(icc, len(icc), 0, conv.ctypes.data, d.width, d.height, conv.strides[0]) == 0
+        want = harness.oracle_write(d, conv)
+        got = _gpu_write_icc(gpu, d, src, xf)
+        k = gpu.last_kernel()
+        if (width * 6) % 16 == 0:
+            assert "write_rgb32_icc1_ycbcr444_hot" in k and "out=ref" in k, k
+        st = harness.compare_write(d, want, got)
+        print(f"icc-ref-streaming {name} width {width} {bits}-bit transfer {transfer}: exact {st['exact_frac']:.5f} max {st['max_abs']}  {k}")
+        assert st["max_abs"] <= 1, (name, k, st)
+        assert harness.t2_exact_ok(st, 0.99 if transfer != pkg.TRANSFER_CLIP else 0.985), (name, k, st)
+        # ... and the generic kernel (tuning word 0: no streaming kernels) on the same rows agrees within the tier
+        gpu.lib.avifgpu_set_hot_variant(0)
+        try:
+            ref = _gpu_write_icc(gpu, d, src, xf)
+            assert "write_px" in gpu.last_kernel(), gpu.last_kernel()
+        finally:
+            gpu.lib.avifgpu_set_hot_variant(7)
+        st2 = harness.compare_write(d, ref, got)
+        assert st2["max_abs"] <= 1 and harness.t2_exact_ok(st2, 0.99), (name, st2)
+
+
 @pytest.mark.parametrize("name,kind,trc,g", [p for p in PROFILES if not (p[2] == 0 and p[3] == 1.0)])
 @pytest.mark.parametrize("width", [1024, 516])
 def test_icc2_streaming_kernels_match_lcms2(gpu, lcms, name, kind, trc, g, width):
