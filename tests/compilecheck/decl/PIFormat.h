@@ -10,6 +10,10 @@ typedef Ptr (*LockBufferProc)(BufferID bufferID, Boolean moveHigh);
 typedef void (*UnlockBufferProc)(BufferID bufferID);
 typedef void (*FreeBufferProc)(BufferID bufferID);
 typedef int32 (*BufferSpaceProc)(void);
+#define kCurrentBufferProcsVersion 2
+#define kCurrentBufferProcsCount 5
+#define kCurrentHandleProcsVersion 1
+#define kCurrentHandleProcsCount 6
 struct BufferProcs { int16 bufferProcsVersion; int16 numBufferProcs; AllocateBufferProc allocateProc; LockBufferProc lockProc; UnlockBufferProc unlockProc; FreeBufferProc freeProc; BufferSpaceProc spaceProc; };
 typedef Handle (*NewPIHandleProc)(int32 size);
 typedef void (*DisposePIHandleProc)(Handle h);

@@ -6,10 +6,11 @@ set -x
 mkdir -p gpurun_out/prof_cfg
 export TMPDIR=/tmp
 export BENCH_TWIN=0
+export BENCH_SAME=0      # round 5: the rotating (fresh-data) launches only; the one-set pass beside them belongs to the plain pass
 R=$GRAFT_REPO_ROOT
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace -d $R/gpurun_out/prof_cfg/kt -o kt --output-format csv -- bash -c "cd $R && python tools/bench_configs.py 2>/dev/null > gpurun_out/prof_cfg/configs_under_trace.jsonl" > $R/gpurun_out/prof_cfg/kt.log 2>&1
-for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU; do
+for c in ${PMC_COUNTERS:-FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU}; do
   d=$(echo $c | tr A-Z a-z)
   timeout 900 rocprofv3 --pmc $c --kernel-include-regex "write_|read_px" -d $R/gpurun_out/prof_cfg/$d -o p --output-format csv -- bash -c "cd $R && python tools/bench_configs.py > /dev/null 2>&1" > $R/gpurun_out/prof_cfg/$d.log 2>&1
 done
