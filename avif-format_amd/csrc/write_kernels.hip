@@ -2306,6 +2306,173 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra444_hot(co
     }
 }
 
+// ---- RGB8 -> Y, Cb, Cr u8 planes: the plug-in's default save and BASELINE C2 as a streaming kernel (round 5) ---------------------------
+// 8-bit documents saved at 8 bit: stage A is the identity (WriteHeifImage.cpp:629-806 copies the bytes; maxValue 255, no rescale), so the
+// row bytes as loaded are the codes and the kernel is stage B (libheif's RGB -> YCbCr + chroma sub-sampling) on them.  Until round 5 this
+// ran on the generic kernel's packed path (FAST8): lane-strided 48-byte loads that must allocate in the L2 so that their 16-byte pieces
+// merge there (every line crosses the L1 three times), 76 VGPRs = 6 waves per SIMD at 4:2:0.  Here a wave owns a span of 1024 pixels on
+// 1 (4:4:4, 4:2:2) or 2 (4:2:0) rows: three fully coalesced 1-KiB buffer loads per row (hardware range clipping at the row's end), the
+// row through the wave-private strip (3 KiB) to become lane-major -- lane l: pixels [16 l, 16 l + 16) = 12 packed dwords, the footprint
+// of 8 chroma samples -- and the same chroma-major arithmetic as FAST8: v_cvt_f32_ubyteN on the packed dwords, the oracle's expressions
+// in the oracle's order, v_floor_f32 + v_cvt_pk_u8_f32 straight into the lane's packed plane vectors.  Stores: 16 bytes per lane per
+// luma row, 8 (16 at 4:4:4) per chroma plane, contiguous across the wave, non-temporal.  Same bytes as the generic kernel
+// (tests/test_gpu_kernel_equivalence.py).  Widths that are multiples of 8, rows and planes dword-aligned; everything else stays generic.
+#ifndef AG_RGB8_HOT
+#define AG_RGB8_HOT 1
+#endif
+// Workgroup size: 128 threads for 4:2:0, 256 otherwise (same-box A/B on fresh data, profiles/r05/rgb8_streaming_kernel_ab.txt: 8192^2 4:2:0
+// 0.749 -> 0.769 of 8 TB/s with 128, 4:2:2 0.782 -> 0.775, 4:4:4 and 16384^2 indifferent).
+template <int XS, int YS, bool NEAREST, int kRgb8Waves>
+__global__ __launch_bounds__(64 * kRgb8Waves) void write_rgb8_ycbcr_hot(const WriteParams p)
+{
+    constexpr int PXL = 16, K = 3, SPAN_PX = 64 * PXL, VR = 1 << YS, NC = PXL >> XS, NDB = 12;
+    __shared__ __attribute__((aligned(16))) uint32_t strip[kRgb8Waves][64 * NDB];
+    const int wave = wave_in_block();
+    const int lane = threadIdx.x & 63;
+    const uint32_t voff = (uint32_t)lane * 16u;
+    u32x4* my = reinterpret_cast<u32x4*>(strip[wave]);
+    const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;
+    const uint32_t groups = ((uint32_t)p.nrows + VR - 1) >> YS;
+    const uint32_t total = spans_per_row * groups;
+    for (uint32_t sidx = blockIdx.x * kRgb8Waves + wave; sidx < total; sidx += gridDim.x * kRgb8Waves) {
+        const uint32_t gy = sidx / spans_per_row;
+        const uint32_t sx = sidx - gy * spans_per_row;
+        const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);             // < SPAN_PX only for the last span of a row; a multiple of 8
+        f32x4 v[VR][K];
+#pragma unroll
+        for (int vr = 0; vr < VR; ++vr) {                                          // every load of the span group in flight before the first is used
+            const int r = min((int)(gy * VR) + vr, p.rows_to_end - 1);             // bottom edge: replicate the last IMAGE row
+            const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)r * p.src_row_bytes + (long long)sx * (SPAN_PX * 3), (uint32_t)span_px * 3u);
+#pragma unroll
+            for (int k = 0; k < K; ++k) v[vr][k] = span_load_cached(k, K) ? span_load16<false>(rs, voff, 1024u * k) : span_load16<true>(rs, voff, 1024u * k);
+        }
+        uint32_t raw[VR][NDB];
+#pragma unroll
+        for (int vr = 0; vr < VR; ++vr) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) my[64 * k + lane] = __builtin_bit_cast(u32x4, v[vr][k]);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const u32x4 t = my[3 * lane + j];
+                raw[vr][4 * j] = t.x; raw[vr][4 * j + 1] = t.y; raw[vr][4 * j + 2] = t.z; raw[vr][4 * j + 3] = t.w;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        uint32_t ypk[VR][PXL / 4], cbpk[NC / 4], crpk[NC / 4];
+#pragma unroll
+        for (int vr = 0; vr < VR; ++vr)
+#pragma unroll
+            for (int j = 0; j < PXL / 4; ++j) ypk[vr][j] = 0;
+#pragma unroll
+        for (int j = 0; j < NC / 4; ++j) { cbpk[j] = 0; crpk[j] = 0; }
+        auto code = [&](int vr, int i, int k) -> float {                            // (float)code: v_cvt_f32_ubyteN on the packed dword
+            const int e = 3 * i + k;
+            return (float)((raw[vr][e >> 2] >> (8 * (e & 3))) & 0xffu);
+        };
+        if constexpr (YS) {
+            // 4:2:0: luma row by row, four pixels = one packed dword at a time, then chroma from both rows -- two short phases instead of the
+            // chroma-major interleave below, which at two rows holds 89 VGPRs (5 waves per SIMD) whatever is pinned; here 24 packed
+            // registers + one phase's temporaries.  The bytes are converted twice (once per phase): this kernel has the issue slots.
+#pragma unroll
+            for (int vr = 0; vr < VR; ++vr)
+#pragma unroll
+                for (int g = 0; g < PXL / 4; ++g) {
+#pragma unroll
+                    for (int d = 0; d < NDB; ++d) asm volatile("" : "+v"(raw[vr][d]));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int i = 4 * g + k;
+                        put_u8(ypk[vr], i, (code(vr, i, 0) * p.my[0] + code(vr, i, 1) * p.my[1] + code(vr, i, 2) * p.my[2]) + 0.5f);      // luma_code
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            if constexpr (!NEAREST) {
+                // the box's vertical half in the integer domain, four bytes per pair of instructions: row 0 + row 1 as two u16 lanes per
+                // dword (bytes 0, 2 in raw[0][d], bytes 1, 3 in raw[1][d]) IN PLACE -- sums of four bytes are exact in float in any order,
+                // so (a + b + c + d) * 0.25f of the oracle is (float)((a + c) + (b + d)) * 0.25f
+#pragma unroll
+                for (int d = 0; d < NDB; ++d) {
+                    const uint32_t a = raw[0][d], b = raw[1][d];
+                    raw[0][d] = (a & 0x00ff00ffu) + (b & 0x00ff00ffu);
+                    raw[1][d] = ((a >> 8) & 0x00ff00ffu) + ((b >> 8) & 0x00ff00ffu);
+                }
+            }
+            auto vsum = [&](int e) -> uint32_t {                                   // row 0 + row 1 of byte e of the footprint row
+                const uint32_t w = raw[e & 1][e >> 2];
+                return (e & 2) ? (w >> 16) : (w & 0xffffu);
+            };
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                if constexpr (NEAREST) {
+#pragma unroll
+                    for (int d = 0; d < NDB; ++d) asm volatile("" : "+v"(raw[0][d]));
+                }
+                float R, G, B;
+                if constexpr (!NEAREST) {
+                    R = (float)(vsum(6 * j) + vsum(6 * j + 3)) * 0.25f;
+                    G = (float)(vsum(6 * j + 1) + vsum(6 * j + 4)) * 0.25f;
+                    B = (float)(vsum(6 * j + 2) + vsum(6 * j + 5)) * 0.25f;
+                } else {
+                    R = code(0, 2 * j, 0); G = code(0, 2 * j, 1); B = code(0, 2 * j, 2);
+                }
+                const float cb = R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2];
+                const float cr = R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2];
+                put_u8(cbpk, j, (cb + p.half) + 0.5f);                             // clip_round(cb + half, 255)
+                put_u8(crpk, j, (cr + p.half) + 0.5f);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            // chroma-major, one sample at a time (the order is pinned as in write_px's packed path: left alone, instruction selection
+            // hoists the products of every sample to the top and the footprint needs twice the registers)
+#pragma unroll
+            for (int vr = 0; vr < VR; ++vr)
+#pragma unroll
+                for (int d = 0; d < NDB; ++d) asm volatile("" : "+v"(raw[vr][d]));
+            float c[VR][1 << XS][3];
+#pragma unroll
+            for (int vr = 0; vr < VR; ++vr)
+#pragma unroll
+                for (int k = 0; k < (1 << XS); ++k) {
+                    const int i = (j << XS) + k;
+                    c[vr][k][0] = code(vr, i, 0); c[vr][k][1] = code(vr, i, 1); c[vr][k][2] = code(vr, i, 2);
+                    put_u8(ypk[vr], i, (c[vr][k][0] * p.my[0] + c[vr][k][1] * p.my[1] + c[vr][k][2] * p.my[2]) + 0.5f);      // luma_code
+                }
+            float R = c[0][0][0], G = c[0][0][1], B = c[0][0][2];
+            if constexpr ((XS || YS) && !NEAREST) {
+                constexpr int k1 = XS ? 1 : 0, v1 = YS ? 1 : 0;
+                R = (R + c[0][k1][0] + c[v1][0][0] + c[v1][k1][0]) * 0.25f;
+                G = (G + c[0][k1][1] + c[v1][0][1] + c[v1][k1][1]) * 0.25f;
+                B = (B + c[0][k1][2] + c[v1][0][2] + c[v1][k1][2]) * 0.25f;
+            }
+            const float cb = R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2];
+            const float cr = R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2];
+            put_u8(cbpk, j, (cb + p.half) + 0.5f);                                 // clip_round(cb + half, 255)
+            put_u8(crpk, j, (cr + p.half) + 0.5f);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const long long xoff = (long long)sx * SPAN_PX;
+#pragma unroll
+        for (int vr = 0; vr < VR; ++vr) {
+            const int r = (int)(gy * VR) + vr;
+            if (r >= p.nrows) continue;                                            // odd last row of the tile: replicated for chroma only
+            span_store16<true>(span_rsrc(p.dst[0] + (long long)r * p.dst_stride[0] + xoff, (uint32_t)span_px), voff,
+                               u32x4{ ypk[vr][0], ypk[vr][1], ypk[vr][2], ypk[vr][3] });
+        }
+        const uint32_t cbytes = (uint32_t)span_px >> XS;                           // a multiple of 4 (width % 8 == 0)
+        const long long coff = xoff >> XS;
+        if constexpr (XS) {
+            span_store8<true>(span_rsrc(p.dst[1] + (long long)gy * p.dst_stride[1] + coff, cbytes), (uint32_t)lane * 8u, u32x2{ cbpk[0], cbpk[1] });
+            span_store8<true>(span_rsrc(p.dst[2] + (long long)gy * p.dst_stride[2] + coff, cbytes), (uint32_t)lane * 8u, u32x2{ crpk[0], crpk[1] });
+        } else {
+            span_store16<true>(span_rsrc(p.dst[1] + (long long)gy * p.dst_stride[1] + coff, cbytes), voff, u32x4{ cbpk[0], cbpk[1], cbpk[2], cbpk[3] });
+            span_store16<true>(span_rsrc(p.dst[2] + (long long)gy * p.dst_stride[2] + coff, cbytes), voff, u32x4{ crpk[0], crpk[1], crpk[2], crpk[3] });
+        }
+    }
+}
+
 // ---- RGB(A) f32 -> interleaved RRGGBB(AA) u16: the reference's own hand-off (CreateHeifImageRGBThirtyTwoBit) ------------------
 // Output sample i is a function of input sample i (RGB) or of its own pixel's float4 (RGBA): no transposition at all.  A wave
 // streams 64 x 4 float4 per trip: coalesced non-temporal 16-byte loads, the curve, 8-byte non-temporal stores at the same index.
@@ -2778,6 +2945,26 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
             default:                        AG_REF(AVIFGPU_TRANSFER_CLIP); break;
             }
 #undef AG_REF
+            return hipGetLastError();
+        }
+    }
+    // RGB8 -> u8 Y, Cb, Cr (the plug-in's default save; BASELINE C2): widths of whole 8-pixel groups, dword-aligned rows and planes
+    if (AG_RGB8_HOT && (variant & 1) && p.icc8_s1 == nullptr && depth == 8 && planes == 3 && !dst16 && output == AVIFGPU_OUT_YCBCR && p.maxv == 255 &&
+        (p.width % 8) == 0 && (p.src_row_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |
+          (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2]) & 3) == 0) {
+        const long long spans = (long long)((p.width + 1023) / 1024) * ((p.nrows + (1 << ys) - 1) >> ys);
+        if (spans == 0) return hipSuccess;
+        if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
+            const int wpb = ys ? 2 : 4;                                            // waves per workgroup
+            long long blocks = (spans + wpb - 1) / wpb;
+            if (blocks > AG_STREAM_BLOCK_CAP * 4 / wpb) blocks = AG_STREAM_BLOCK_CAP * 4 / wpb;
+            snprintf(label, kLabelBytes, "write_rgb8_ycbcr_hot<xs=%d,ys=%d,nearest=%d>", xs, ys, (xs || ys) ? p.nearest : 0);
+#define AG_R8(XS_, YS_, NR_) hipLaunchKernelGGL((write_rgb8_ycbcr_hot<XS_, YS_, NR_, (YS_ ? 2 : 4)>), dim3((int)blocks), dim3(64 * (YS_ ? 2 : 4)), 0, st, p)
+            if (xs == 0) AG_R8(0, 0, false);
+            else if (ys == 0) { if (p.nearest) AG_R8(1, 0, true); else AG_R8(1, 0, false); }
+            else { if (p.nearest) AG_R8(1, 1, true); else AG_R8(1, 1, false); }
+#undef AG_R8
             return hipGetLastError();
         }
     }

@@ -53,6 +53,22 @@ CASES = [
                                         output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444, matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)),
     ("write_rgba16_ycbcra444_hot", dict(width=8, height=2, depth=16, planes=4, bit_depth=12, alpha_state=pkg.ALPHA_PREMULTIPLIED,
                                         output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444, **BT2020)),
+    # round 5: RGB8 -> u8 planes, the plug-in's default save (whole spans of 1024 pixels, a ragged last span, a single 8-pixel group; odd heights)
+    ("write_rgb8_ycbcr_hot", dict(width=2048, height=6, depth=8, planes=3, bit_depth=8, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420,
+                                  matrix_coefficients=pkg.MATRIX_BT709, color_primaries=pkg.PRIMARIES_BT709)),
+    ("write_rgb8_ycbcr_hot", dict(width=1512, height=7, depth=8, planes=3, bit_depth=8, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420,
+                                  matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)),
+    ("write_rgb8_ycbcr_hot", dict(width=1512, height=5, depth=8, planes=3, bit_depth=8, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420,
+                                  chroma_downsampling=pkg.DOWNSAMPLE_NEAREST, matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)),
+    ("write_rgb8_ycbcr_hot", dict(width=1000, height=5, depth=8, planes=3, bit_depth=8, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_422,
+                                  chroma_downsampling=pkg.DOWNSAMPLE_NEAREST, matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)),
+    ("write_rgb8_ycbcr_hot", dict(width=1000, height=4, depth=8, planes=3, bit_depth=8, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_422,
+                                  matrix_coefficients=pkg.MATRIX_BT709, color_primaries=pkg.PRIMARIES_BT709)),
+    ("write_rgb8_ycbcr_hot", dict(width=1032, height=3, depth=8, planes=3, bit_depth=8, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444, **BT2020)),
+    ("write_rgb8_ycbcr_hot", dict(width=8, height=1, depth=8, planes=3, bit_depth=8, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420,
+                                  matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)),
+    ("write_rgb8_ycbcr_hot", dict(width=16, height=2, depth=8, planes=3, bit_depth=8, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444,
+                                  matrix_coefficients=pkg.MATRIX_RGB_GBR)),
     ("write_int_ref_stream", dict(width=1000, height=5, depth=16, planes=3, bit_depth=12, output=pkg.OUT_REFERENCE)),
     ("write_int_ref_stream", dict(width=502, height=3, depth=16, planes=4, bit_depth=8, alpha_state=pkg.ALPHA_PREMULTIPLIED,
                                   output=pkg.OUT_REFERENCE)),

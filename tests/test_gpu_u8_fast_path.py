@@ -35,7 +35,7 @@ def gpu_write_padded(gpu, desc, src):
     return harness._trim(desc, raw, H, harness.write_planes), raw
 
 
-WIDTHS = [1040, 1001, 1000, 24, 17, 2050]
+WIDTHS = [1040, 1001, 1000, 24, 17, 2050, 2048, 8, 1032]
 CHROMAS = [pkg.CHROMA_444, pkg.CHROMA_422, pkg.CHROMA_420]
 
 
@@ -51,13 +51,24 @@ def test_write_u8_fast_path_padded_rows(gpu, planes, alpha, chroma, width):
         d = pkg.WriteDesc(**kw)
         src = harness.make_write_source(d, seed=width + height)
         want = harness.oracle_write(d, src)
-        got, raw = gpu_write_padded(gpu, d, src)
-        assert "aligned=1" in gpu.last_kernel() and "depth=8" in gpu.last_kernel(), gpu.last_kernel()
-        for pl in want:
-            assert np.array_equal(want[pl], got[pl]), (pl, width, height, near, int(np.abs(want[pl].astype(int) - got[pl].astype(int)).max()))
-        # nothing written beyond the valid samples of a row (the guard pattern of the padding survives)
-        for pl, (w, xs, ys) in harness.write_planes(d).items():
-            assert np.all(raw[pl][:, w:] == 0xA5), (pl, width)
+        # tuning word 7 = the library's choice: RGB8 rows of whole 8-pixel groups take the streaming kernel (round 5), everything else the
+        # packed path of the generic kernel; tuning word 0 = no streaming kernels: the packed path on every case
+        for variant in (7, 0):
+            gpu.lib.avifgpu_set_hot_variant(variant)
+            try:
+                got, raw = gpu_write_padded(gpu, d, src)
+                k = gpu.last_kernel()
+            finally:
+                gpu.lib.avifgpu_set_hot_variant(7)
+            if variant == 7 and planes == 3 and width % 8 == 0:
+                assert "write_rgb8_ycbcr_hot" in k, k
+            else:
+                assert "aligned=1" in k and "depth=8" in k, k
+            for pl in want:
+                assert np.array_equal(want[pl], got[pl]), (k, pl, width, height, near, int(np.abs(want[pl].astype(int) - got[pl].astype(int)).max()))
+            # nothing written beyond the valid samples of a row (the guard pattern of the padding survives)
+            for pl, (w, xs, ys) in harness.write_planes(d).items():
+                assert np.all(raw[pl][:, w:] == 0xA5), (k, pl, width)
 
 
 @pytest.mark.parametrize("planes,alpha", [(4, pkg.ALPHA_STRAIGHT), (4, pkg.ALPHA_PREMULTIPLIED), (3, pkg.ALPHA_NONE)])
