@@ -2320,6 +2320,9 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra444_hot(co
 #ifndef AG_RGB8_HOT
 #define AG_RGB8_HOT 1
 #endif
+#ifndef AG_RGB8_FIRST_CACHED
+#define AG_RGB8_FIRST_CACHED 1     /* the first of a span's three loads allocates (kernel_params.h, span_load_cached); 0 = all non-temporal */
+#endif
 // Workgroup size: 128 threads for 4:2:0, 256 otherwise (same-box A/B on fresh data, profiles/r05/rgb8_streaming_kernel_ab.txt: 8192^2 4:2:0
 // 0.749 -> 0.769 of 8 TB/s with 128, 4:2:2 0.782 -> 0.775, 4:4:4 and 16384^2 indifferent).
 template <int XS, int YS, bool NEAREST, int kRgb8Waves>
@@ -2344,7 +2347,7 @@ __global__ __launch_bounds__(64 * kRgb8Waves) void write_rgb8_ycbcr_hot(const Wr
             const int r = min((int)(gy * VR) + vr, p.rows_to_end - 1);             // bottom edge: replicate the last IMAGE row
             const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)r * p.src_row_bytes + (long long)sx * (SPAN_PX * 3), (uint32_t)span_px * 3u);
 #pragma unroll
-            for (int k = 0; k < K; ++k) v[vr][k] = span_load_cached(k, K) ? span_load16<false>(rs, voff, 1024u * k) : span_load16<true>(rs, voff, 1024u * k);
+            for (int k = 0; k < K; ++k) v[vr][k] = (AG_RGB8_FIRST_CACHED && k == 0) ? span_load16<false>(rs, voff, 1024u * k) : span_load16<true>(rs, voff, 1024u * k);
         }
         uint32_t raw[VR][NDB];
 #pragma unroll
@@ -2968,11 +2971,12 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
             return hipGetLastError();
         }
     }
-    // RGB16 -> u16 Y, Cb, Cr 4:4:4 (BASELINE C3).  Only for large launches: the generic kernel holds 0.76-0.80 of 8 TB/s up to ~45 Mpx
-    // and falls to 0.70-0.72 at 8192^2 / 16384^2, the streaming one holds 0.74-0.80 everywhere (+10-14 % at 8192^2, -0...4 % at
-    // 6000 x 4000; profiles/r02/rgb16_streaming_geometry.txt).  Both produce the same bytes (tests/test_gpu_kernel_equivalence.py).
+    // RGB16 -> u16 Y, Cb, Cr 4:4:4 (BASELINE C3).  At every size since round 5: round 2 had gated it to launches of >= 40 Mpx because the
+    // generic kernel "held 0.76-0.80 up to ~45 Mpx" -- in a one-set loop, where its allocating loads re-read the Infinity Cache.  On fresh
+    // data the streaming kernel wins wherever it was gated off: 6000 x 4000 0.68 -> 0.74 of 8 TB/s, 4096^2 0.64 -> 0.70
+    // (profiles/r05/rgb16_streaming_gates_fresh_data.txt).  Both produce the same bytes (tests/test_gpu_kernel_equivalence.py).
 #ifndef AG_RGB16_MIN_PX
-#define AG_RGB16_MIN_PX (40LL << 20)
+#define AG_RGB16_MIN_PX 0
 #endif
     if ((variant & 1) && p.icc16_clut == nullptr && depth == 16 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 0 && ys == 0 &&
         ((long long)p.width * p.nrows >= AG_RGB16_MIN_PX || (variant & 8)) &&
@@ -3008,11 +3012,10 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
             return hipGetLastError();
         }
     }
-    // RGB16 -> u16 Y, Cb, Cr 4:2:2 / 4:2:0.  Taken where it wins (profiles/r02/rgb16_streaming_geometry.txt): rows of whole spans
-    // (8192: +9 %, 4096: +5 %, 6144 / 6656: +2-3 %); a ragged last span per row costs it 4-6 % against the generic kernel
-    // (6000, 7952 wide), so those stay generic.  Same bytes either way.
+    // RGB16 -> u16 Y, Cb, Cr 4:2:2 / 4:2:0.  Any width of whole 8-pixel groups since round 5: round 2 kept rows with a ragged last span
+    // (6000, 7952 wide) on the generic kernel, "4-6 % faster" there in a one-set loop; on fresh data the streaming kernel is 4-6 % ahead
+    // on exactly those rows (7952 x 5304 4:2:0 0.64 -> 0.67, 4:2:2 0.72 -> 0.765, 6000 x 4000 4:2:0 0.61 -> 0.65).  Same bytes either way.
     if ((variant & 1) && p.icc16_clut == nullptr && depth == 16 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 1 &&
-        ((p.width % 512) == 0 || (variant & 8)) &&
         (p.width % 8) == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |
           (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2]) & 15) == 0) {

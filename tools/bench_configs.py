@@ -199,7 +199,9 @@ _bw, _br = bench_write, bench_read
 
 
 def bench_write(name, **kw):
-    if name.startswith("SZ ") and not any(o.startswith("SZ") for o in ONLY):
+    if name.startswith("SZ16") and "SZ16" not in ONLY:
+        return
+    if name.startswith("SZ ") and not any(o.startswith("SZ") and o != "SZ16" for o in ONLY):
         return                                  # size-sweep rows: only when asked for (tuning launch rules), not part of the table
     if not ONLY or any(o in name for o in ONLY):
         _bw(name, **kw)
@@ -225,6 +227,10 @@ if __name__ == "__main__":
     bench_write("W16 8192^2 RGB16 -> 12-bit 4:2:0 BT.2020 (a 16-bit photograph saved as 12-bit AVIF)", width=8192, height=8192, depth=16, planes=3, bit_depth=12, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=P.MATRIX_BT2020_NCL, color_primaries=9)
     bench_write("W16 8192^2 RGB16 -> 10-bit 4:2:2 BT.709", width=8192, height=8192, depth=16, planes=3, bit_depth=10, alpha_state=0, output=1, chroma=P.CHROMA_422, matrix_coefficients=1)
     bench_write("C3 8192^2 RGB16 -> 12-bit 4:4:4 BT.2020", width=8192, height=8192, depth=16, planes=3, bit_depth=12, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=P.MATRIX_BT2020_NCL, color_primaries=9)
+    for w, h in ((2048, 2048), (4096, 4096), (6000, 4000), (7952, 5304)):      # size / geometry sweep of the RGB16 kernels (only when asked for: "SZ16")
+        bench_write("SZ16 %dx%d RGB16 -> 12-bit 4:4:4" % (w, h), width=w, height=h, depth=16, planes=3, bit_depth=12, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=6, color_primaries=1)
+        bench_write("SZ16 %dx%d RGB16 -> 12-bit 4:2:0" % (w, h), width=w, height=h, depth=16, planes=3, bit_depth=12, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=6, color_primaries=1)
+        bench_write("SZ16 %dx%d RGB16 -> 10-bit 4:2:2 nearest" % (w, h), width=w, height=h, depth=16, planes=3, bit_depth=10, alpha_state=0, output=1, chroma=P.CHROMA_422, chroma_downsampling=P.DOWNSAMPLE_NEAREST, matrix_coefficients=6, color_primaries=1)
     bench_write("C4 8192^2 RGB f32 -> 10-bit PQ 4:4:4", width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=9, color_primaries=9)
     for sz in (2048, 4096, 6144, 10240, 11264, 12288, 14336):
         bench_write("SZ %d^2 RGB f32 -> 10-bit PQ 4:4:4" % sz, width=sz, height=sz, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=9, color_primaries=9)
