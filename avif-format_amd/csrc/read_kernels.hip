@@ -324,23 +324,74 @@ template <int CS, int DEPTH> constexpr bool read_nt_loads()
 {
     return AG_READ_NT_LOADS == 2 ? !(DEPTH == 8 || (DEPTH == 32 && CS != 1 /* kCsRgb */)) : AG_READ_NT_LOADS != 0;
 }
-template <bool SRC16, int N, bool ALIGNED, bool NT = true>
+// AG_READ_BUFFER_LOADS (round 5), BUF: a plane row as a buffer resource -- base = the row (wave-uniform), num_records = its samples' bytes
+// rounded up to a dword -- and the lane's N samples as ONE buffer load at offset i0: the hardware's per-dword range check returns zeros
+// beyond the row, so there is no ragged-lane path.  (The samples beyond `count` feed pixels beyond the image width, which are never stored;
+// the last partial dword of a row lies inside the row's own 16-byte-aligned pitch and cannot straddle a page.)  The replicating byte-load
+// path below had been setting the register count of the whole kernel -- N single-sample loads in flight, each with a 64-bit address.
+// Taken by the ALIGNED kernels of 8-bit hosts only: same-box A/B on fresh data (profiles/r05/read_buffer_loads_and_pins_ab.txt): with the
+// pins above 8-bit 4:2:0 -> RGB8 0.687 -> 0.727 of 8 TB/s, 4:2:2 0.674 -> 0.722, 4:4:4 0.667 -> 0.68, RGBA8 and gray unchanged; on the
+// 16-bit and f32 hosts' kernels, whose register counts it does not move, the same loads as buffer loads measured 0...-7 % and stay global.
+#ifndef AG_READ_BUFFER_LOADS
+#define AG_READ_BUFFER_LOADS 1
+#endif
+template <bool SRC16, int N, bool ALIGNED, bool NT = true, bool BUF = false>
 AG_DEV void load_plane(const uint8_t* row, int i0, int count, uint32_t (&d)[N * (SRC16 ? 2 : 1) / 4])
 {
     constexpr int SSZ = SRC16 ? 2 : 1;
     constexpr int ND = N * SSZ / 4;
     static_assert((N * SSZ) % 4 == 0, "whole dwords per lane");
+    if constexpr (ALIGNED && BUF) {
+        if constexpr (AG_MATH_ONLY) {
+#pragma unroll
+            for (int k = 0; k < ND; ++k) d[k] = mo_value<uint32_t>();
+            return;
+        }
+        typedef int bl_i4 __attribute__((__vector_size__(16)));
+        typedef int bl_i2 __attribute__((__vector_size__(8)));
+        const uint64_t a = reinterpret_cast<uint64_t>(row);          // the row is the wave's (one row group per wave); say so
+        const uint64_t ua = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a) |
+                            ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32);
+        const uint32_t bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)count * SSZ + 3u) & ~3u));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(ua), 0, (int)bytes, 0x00020000);
+        const int voff = i0 * SSZ;
+        if constexpr (ND % 4 == 0) {
+#pragma unroll
+            for (int j = 0; j < ND / 4; ++j) {
+                const bl_i4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16 * j, 0, NT ? 2 : 0);
+                d[4 * j] = (uint32_t)v[0]; d[4 * j + 1] = (uint32_t)v[1]; d[4 * j + 2] = (uint32_t)v[2]; d[4 * j + 3] = (uint32_t)v[3];
+            }
+        } else if constexpr (ND % 2 == 0) {
+#pragma unroll
+            for (int j = 0; j < ND / 2; ++j) {
+                const bl_i2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + 8 * j, 0, NT ? 2 : 0);
+                d[2 * j] = (uint32_t)v[0]; d[2 * j + 1] = (uint32_t)v[1];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < ND; ++j) d[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, voff + 4 * j, 0, NT ? 2 : 0);
+        }
+        return;
+    }
     if (i0 + N <= count) {
         load_dwords<ND, NT, ALIGNED>(row + (long long)i0 * SSZ, d);   // planar, coalesced, read once; cache policy: read_nt_loads()
         return;
     }
+    // the one ragged lane of a row (right edge replicated): a dword's samples at a time, with a compiler barrier behind each dword --
+    // unrolled freely, the N single-sample loads are all hoisted, each with a 64-bit address of its own, and this rare path set the VGPR
+    // count of the whole kernel (8-bit 4:2:0 -> RGB8: 92 VGPRs = 5 waves per SIMD; round 5)
 #pragma unroll
-    for (int k = 0; k < ND; ++k) d[k] = 0;
+    for (int k = 0; k < ND; ++k) {
+        uint32_t w = 0;
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        const int i = min(i0 + j, count - 1);
-        const uint32_t v = SRC16 ? ld_u16(row + 2LL * i) : ld_u8(row + i);
-        if constexpr (SRC16) d[j >> 1] |= v << (16 * (j & 1)); else d[j >> 2] |= v << (8 * (j & 3));
+        for (int h = 0; h < 4 / SSZ; ++h) {
+            const int j = k * (4 / SSZ) + h;
+            const int i = min(i0 + j, count - 1);
+            const uint32_t v = SRC16 ? ld_u16(row + 2LL * i) : ld_u8(row + i);
+            w |= v << (8 * SSZ * h);
+        }
+        d[k] = w;
+        asm volatile("" ::: "memory");
     }
 }
 template <bool SRC16> AG_DEV uint32_t sample_of(const uint32_t* d, int j)
@@ -457,6 +508,11 @@ __global__ __launch_bounds__(256) void build_read_tables(const ReadParams p, flo
 #ifndef AG_READ_ROW_EOTF
 #define AG_READ_ROW_EOTF 1
 #endif
+// AG_R8_PIN_MORE (round 5): the packed 8-bit decode pins the chroma planes' dwords and the packed output dwords per chroma sample as well
+// (empty asm, no instruction), not only luma: 8-bit 4:2:2 -> RGB8 73 -> 56 VGPRs, 4:4:4 64 -> 48, 4:2:0 94 -> 80 (with the buffer loads below).
+#ifndef AG_R8_PIN_MORE
+#define AG_R8_PIN_MORE 1
+#endif
 #ifndef AG_READ_PREFETCH
 #define AG_READ_PREFETCH 0
 #endif
@@ -531,6 +587,7 @@ __global__ __launch_bounds__(AG_RPX_BLOCK) void read_px(const ReadParams p)
 {
     constexpr bool SRC16 = DEPTH != 8;
     constexpr bool NTL = read_nt_loads<CS, DEPTH>();
+    constexpr bool BUFL = AG_READ_BUFFER_LOADS && ALIGNED && DEPTH == 8;      // plane rows as buffer resources (load_plane)
     constexpr bool ROW_EOTF = AG_READ_ROW_EOTF && CS == kCsYcc && DEPTH == 32 && TRANSFER == AVIFGPU_TRANSFER_PQ && !TWIN;   // PQToLinear over the row, in packed pairs
     constexpr int NC = ReadShape<CS, DEPTH, ALPHA, XS>::NC;
     constexpr int PXT = ReadShape<CS, DEPTH, ALPHA, XS>::PXT;
@@ -572,17 +629,17 @@ __global__ __launch_bounds__(AG_RPX_BLOCK) void read_px(const ReadParams p)
         if (gx >= gxn) return;
         const int x0 = gx * PXT;
         if constexpr (CS == kCsYcc) {                       // uvJ = y >> yChromaShift, uvI = x >> xChromaShift
-            load_plane<SRC16, NC, ALIGNED, NTL>(p.src[1] + (long long)gy * p.src_stride[1], x0 >> XS, cw, g.c1);
-            load_plane<SRC16, NC, ALIGNED, NTL>(p.src[2] + (long long)gy * p.src_stride[2], x0 >> XS, cw, g.c2);
+            load_plane<SRC16, NC, ALIGNED, NTL, BUFL>(p.src[1] + (long long)gy * p.src_stride[1], x0 >> XS, cw, g.c1);
+            load_plane<SRC16, NC, ALIGNED, NTL, BUFL>(p.src[2] + (long long)gy * p.src_stride[2], x0 >> XS, cw, g.c2);
         }
 #pragma unroll
         for (int vr = 0; vr < VR; ++vr) {
             const int r = min(gy * VR + vr, p.nrows - 1);   // an odd last row: the duplicate load is never stored
-            load_plane<SRC16, PXT, ALIGNED, NTL>(p.src[0] + (long long)r * p.src_stride[0], x0, p.width, g.y[vr]);
-            if constexpr (ALPHA) load_plane<SRC16, PXT, ALIGNED, NTL>(p.src[3] + (long long)r * p.src_stride[3], x0, p.width, g.a[vr]);
+            load_plane<SRC16, PXT, ALIGNED, NTL, BUFL>(p.src[0] + (long long)r * p.src_stride[0], x0, p.width, g.y[vr]);
+            if constexpr (ALPHA) load_plane<SRC16, PXT, ALIGNED, NTL, BUFL>(p.src[3] + (long long)r * p.src_stride[3], x0, p.width, g.a[vr]);
             if constexpr (CS == kCsRgb) {
-                load_plane<SRC16, PXT, ALIGNED, NTL>(p.src[1] + (long long)r * p.src_stride[1], x0, p.width, g.g1[vr]);
-                load_plane<SRC16, PXT, ALIGNED, NTL>(p.src[2] + (long long)r * p.src_stride[2], x0, p.width, g.g2[vr]);
+                load_plane<SRC16, PXT, ALIGNED, NTL, BUFL>(p.src[1] + (long long)r * p.src_stride[1], x0, p.width, g.g1[vr]);
+                load_plane<SRC16, PXT, ALIGNED, NTL, BUFL>(p.src[2] + (long long)r * p.src_stride[2], x0, p.width, g.g2[vr]);
             }
         }
     };
@@ -642,6 +699,14 @@ __global__ __launch_bounds__(AG_RPX_BLOCK) void read_px(const ReadParams p)
                     for (int vr = 0; vr < VR; ++vr)
 #pragma unroll
                         for (int d = 0; d < NDY; ++d) asm volatile("" : "+v"(cur.y[vr][d]));
+#if AG_R8_PIN_MORE
+#pragma unroll
+                    for (int d = 0; d < NDC; ++d) { asm volatile("" : "+v"(cur.c1[d])); asm volatile("" : "+v"(cur.c2[d])); }
+#pragma unroll
+                    for (int vr = 0; vr < VR; ++vr)
+#pragma unroll
+                        for (int d = 0; d < ND_OUT; ++d) asm volatile("" : "+v"(pk[vr][d]));
+#endif
                     const ChromaTerms c = chroma_terms<DEPTH, LUT>(p, t, sample_of<SRC16>(cur.c1, j), sample_of<SRC16>(cur.c2, j));
 #pragma unroll
                     for (int vr = 0; vr < VR; ++vr) {

@@ -201,6 +201,8 @@ _bw, _br = bench_write, bench_read
 def bench_write(name, **kw):
     if name.startswith("SZ16") and "SZ16" not in ONLY:
         return
+    if name.startswith("TILE") and "TILE" not in ONLY:
+        return
     if name.startswith("SZ ") and not any(o.startswith("SZ") and o != "SZ16" for o in ONLY):
         return                                  # size-sweep rows: only when asked for (tuning launch rules), not part of the table
     if not ONLY or any(o in name for o in ONLY):
@@ -234,6 +236,8 @@ if __name__ == "__main__":
     bench_write("C4 8192^2 RGB f32 -> 10-bit PQ 4:4:4", width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=9, color_primaries=9)
     for sz in (2048, 4096, 6144, 10240, 11264, 12288, 14336):
         bench_write("SZ %d^2 RGB f32 -> 10-bit PQ 4:4:4" % sz, width=sz, height=sz, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=9, color_primaries=9)
+    for h in (512, 1024, 2048, 4096):          # the row tiles of an N-way split of the C4 frame (N = 16, 8, 4, 2); only when asked for ("TILE")
+        bench_write("TILE 8192x%d RGB f32 -> 10-bit PQ 4:4:4" % h, width=8192, height=h, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=9, color_primaries=9)
     bench_write("C4 8192^2 RGB f32 -> 10-bit PQ 4:2:2", width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_422, matrix_coefficients=9, color_primaries=9)
     bench_write("C4 8192^2 RGB f32 -> 10-bit PQ 4:2:0", width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=9, color_primaries=9)
     bench_write("C4 8192^2 RGB f32 -> 10-bit PQ interleaved RRGGBB (reference hand-off)", width=8192, height=8192, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=0)
