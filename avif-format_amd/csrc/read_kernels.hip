@@ -960,7 +960,7 @@ static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, char* lab
     // Grid cap, measured (profiles/r01/ab_read_variants.txt, second table): with the tables copied from the device cache
     // instead of rebuilt per workgroup, a 16k-block grid beats 2k by 5-10 % on the f32 and 10-bit kernels.
 #ifndef AG_READ_BLOCK_CAP
-#define AG_READ_BLOCK_CAP (256LL * 64)   /* 16384^2 frames: 64k / 128k measured within noise of 16k for the read kernels */
+#define AG_READ_BLOCK_CAP (256LL * 128)  /* round 5, fresh data: 32k blocks +2-3 % over 16k on the 4:4:4 opens and at 16384^2, 128k -4 % where tables are copied per block (profiles/r05/read_grid_cap_fresh_data.txt) */
 #endif
     if (blocks > AG_READ_BLOCK_CAP) blocks = AG_READ_BLOCK_CAP;
     const size_t lut_bytes = p.bits <= 12 ? (size_t)read_table_count(CS == kCsYcc, CS == kCsMono, ALPHA, DEPTH, p.full_range != 0, p.identity_lut != 0, p.premultiplied != 0) *

@@ -2070,7 +2070,7 @@ __global__ __launch_bounds__(AG_RGBA_STREAM_BLOCK) void write_rgba32_ycbcra_sub_
 #ifndef AG_RGB16_NS
 #define AG_RGB16_NS 1      /* 2 and 4 measured 2-9 % slower on every geometry (profiles/r02/rgb16_streaming_geometry.txt) */
 #endif
-template <int NS>      // spans per wave trip: all NS x 3 loads are issued before the first is consumed
+template <int NS, bool TO8 = false>      // spans per wave trip: all NS x 3 loads are issued before the first is consumed; TO8: u8 planes (see write_rgb16_ycbcr_sub_hot)
 __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr444_hot(const WriteParams p)
 {
     constexpr int PXL = 8, K = 3, SPAN_PX = 512, SPAN_DW = SPAN_PX * 3 / 2, LDW = 12;
@@ -2130,6 +2130,15 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr444_hot(cons
                 cbv[i] = clip_round(R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2] + p.half, p.maxv);
                 crv[i] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
             }
+            if constexpr (TO8) {
+                if (PXL * lane < span_px) {
+                    const long long xoff = (long long)sx * SPAN_PX + (long long)PXL * lane;
+                    auto pk8 = [](const uint32_t (&v)[PXL]) { return u32x2{ v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24), v[4] | (v[5] << 8) | (v[6] << 16) | (v[7] << 24) }; };
+                    g_store_nt(pk8(yv), reinterpret_cast<u32x2*>(p.dst[0] + (long long)r * p.dst_stride[0] + xoff));
+                    g_store_nt(pk8(cbv), reinterpret_cast<u32x2*>(p.dst[1] + (long long)r * p.dst_stride[1] + xoff));
+                    g_store_nt(pk8(crv), reinterpret_cast<u32x2*>(p.dst[2] + (long long)r * p.dst_stride[2] + xoff));
+                }
+            } else
             if (PXL * lane < span_px) {
                 const long long xoff = ((long long)sx * SPAN_PX + (long long)PXL * lane) * 2;
                 u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
@@ -2145,7 +2154,10 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr444_hot(cons
 
 // ... and its 4:2:2 / 4:2:0 sibling (a 16-bit photograph saved as 10/12-bit 4:2:0 AVIF): write_rgb32_ycbcr_sub_hot's structure with the
 // 16-bit front end.  A wave owns 512 pixels on 1 or 2 rows; both rows' loads are in flight before any arithmetic.
-template <int YS>
+// TO8 (round 5): the same kernel for a 16-bit document saved at 8 bit -- BuildSixteenBitToEightBitLookup's entry is the same float expression
+// with maxValue 255 (exact_rescale16_pair covers it: device_math.h), the codes then fit bytes and the planes are u8: 8 bytes of luma and 4 of
+// each chroma plane per lane.  Ran on the generic kernel until then (0.70-0.72 of 8 TB/s on fresh data).
+template <int YS, bool TO8 = false>
 __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr_sub_hot(const WriteParams p)
 {
     constexpr int PXL = 8, K = 3, SPAN_PX = 512, SPAN_DW = SPAN_PX * 3 / 2, LDW = 12, VR = 1 << YS;
@@ -2195,7 +2207,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr_sub_hot(con
             return (e & 1) ? (dw[vr][e >> 1] >> 16) : (dw[vr][e >> 1] & 0xffffu);
         };
         const bool mine = PXL * lane < span_px;                                    // whole lane or idle (width % 8 == 0)
-        const long long xoff = ((long long)sx * SPAN_PX + (long long)PXL * lane) * 2;
+        const long long xoff = ((long long)sx * SPAN_PX + (long long)PXL * lane) * (TO8 ? 1 : 2);
 #pragma unroll
         for (int vr = 0; vr < VR; ++vr) {
             const int r = (int)(gy * VR) + vr;
@@ -2204,8 +2216,13 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr_sub_hot(con
 #pragma unroll
             for (int i = 0; i < PXL; ++i) yv[i] = luma_code(p, code(vr, i, 0), code(vr, i, 1), code(vr, i, 2));
             if (mine) {
+                if constexpr (TO8) {
+                    u32x2 a = { yv[0] | (yv[1] << 8) | (yv[2] << 16) | (yv[3] << 24), yv[4] | (yv[5] << 8) | (yv[6] << 16) | (yv[7] << 24) };
+                    g_store_nt(a, reinterpret_cast<u32x2*>(p.dst[0] + (long long)r * p.dst_stride[0] + xoff));
+                } else {
                 u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
                 g_store_nt(a, reinterpret_cast<u32x4*>(p.dst[0] + (long long)r * p.dst_stride[0] + xoff));
+                }
             }
         }
         uint32_t cbv[4], crv[4];
@@ -2223,11 +2240,16 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr_sub_hot(con
             crv[j] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
         }
         if (mine) {
-            const long long coff = ((long long)sx * (SPAN_PX / 2) + 4LL * lane) * 2;
+            const long long coff = ((long long)sx * (SPAN_PX / 2) + 4LL * lane) * (TO8 ? 1 : 2);
+            if constexpr (TO8) {
+                g_store_nt(cbv[0] | (cbv[1] << 8) | (cbv[2] << 16) | (cbv[3] << 24), reinterpret_cast<uint32_t*>(p.dst[1] + (long long)gy * p.dst_stride[1] + coff));
+                g_store_nt(crv[0] | (crv[1] << 8) | (crv[2] << 16) | (crv[3] << 24), reinterpret_cast<uint32_t*>(p.dst[2] + (long long)gy * p.dst_stride[2] + coff));
+            } else {
             u32x2 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16) };
             u32x2 c = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16) };
             g_store_nt(b, reinterpret_cast<u32x2*>(p.dst[1] + (long long)gy * p.dst_stride[1] + coff));
             g_store_nt(c, reinterpret_cast<u32x2*>(p.dst[2] + (long long)gy * p.dst_stride[2] + coff));
+            }
         }
     }
 }
@@ -2978,7 +3000,7 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
 #ifndef AG_RGB16_MIN_PX
 #define AG_RGB16_MIN_PX 0
 #endif
-    if ((variant & 1) && p.icc16_clut == nullptr && depth == 16 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 0 && ys == 0 &&
+    if ((variant & 1) && p.icc16_clut == nullptr && depth == 16 && planes == 3 && (dst16 || p.maxv == 255) && output == AVIFGPU_OUT_YCBCR && xs == 0 && ys == 0 &&
         ((long long)p.width * p.nrows >= AG_RGB16_MIN_PX || (variant & 8)) &&
         (p.width % 8) == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |
@@ -2988,8 +3010,9 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
         if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
             long long blocks = (spans + kStreamWaves * AG_RGB16_NS - 1) / (kStreamWaves * AG_RGB16_NS);
             if (blocks > AG_STREAM_BLOCK_CAP * 4 / kStreamWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kStreamWaves;
-            snprintf(label, kLabelBytes, "write_rgb16_ycbcr444_hot<ns=%d>", AG_RGB16_NS);
-            hipLaunchKernelGGL((write_rgb16_ycbcr444_hot<AG_RGB16_NS>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p);
+            snprintf(label, kLabelBytes, "write_rgb16_ycbcr444_hot<ns=%d%s>", AG_RGB16_NS, dst16 ? "" : ",to8");
+            if (dst16) hipLaunchKernelGGL((write_rgb16_ycbcr444_hot<AG_RGB16_NS>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p);
+            else hipLaunchKernelGGL((write_rgb16_ycbcr444_hot<AG_RGB16_NS, true>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p);
             return hipGetLastError();
         }
     }
@@ -3015,7 +3038,7 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
     // RGB16 -> u16 Y, Cb, Cr 4:2:2 / 4:2:0.  Any width of whole 8-pixel groups since round 5: round 2 kept rows with a ragged last span
     // (6000, 7952 wide) on the generic kernel, "4-6 % faster" there in a one-set loop; on fresh data the streaming kernel is 4-6 % ahead
     // on exactly those rows (7952 x 5304 4:2:0 0.64 -> 0.67, 4:2:2 0.72 -> 0.765, 6000 x 4000 4:2:0 0.61 -> 0.65).  Same bytes either way.
-    if ((variant & 1) && p.icc16_clut == nullptr && depth == 16 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 1 &&
+    if ((variant & 1) && p.icc16_clut == nullptr && depth == 16 && planes == 3 && (dst16 || p.maxv == 255) && output == AVIFGPU_OUT_YCBCR && xs == 1 &&
         (p.width % 8) == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |
           (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2]) & 15) == 0) {
@@ -3024,9 +3047,11 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
         if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
             long long blocks = (spans + kStreamWaves - 1) / kStreamWaves;
             if (blocks > AG_STREAM_BLOCK_CAP * 4 / kStreamWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kStreamWaves;
-            snprintf(label, kLabelBytes, "write_rgb16_ycbcr_sub_hot<ys=%d>", ys);
-            if (ys) hipLaunchKernelGGL((write_rgb16_ycbcr_sub_hot<1>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p);
-            else hipLaunchKernelGGL((write_rgb16_ycbcr_sub_hot<0>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p);
+            snprintf(label, kLabelBytes, "write_rgb16_ycbcr_sub_hot<ys=%d%s>", ys, dst16 ? "" : ",to8");
+            if (dst16) { if (ys) hipLaunchKernelGGL((write_rgb16_ycbcr_sub_hot<1>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p);
+                         else hipLaunchKernelGGL((write_rgb16_ycbcr_sub_hot<0>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); }
+            else { if (ys) hipLaunchKernelGGL((write_rgb16_ycbcr_sub_hot<1, true>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p);
+                   else hipLaunchKernelGGL((write_rgb16_ycbcr_sub_hot<0, true>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); }
             return hipGetLastError();
         }
     }

@@ -73,7 +73,7 @@ def test_write_u8_fast_path_padded_rows(gpu, planes, alpha, chroma, width):
 
 @pytest.mark.parametrize("planes,alpha", [(4, pkg.ALPHA_STRAIGHT), (4, pkg.ALPHA_PREMULTIPLIED), (3, pkg.ALPHA_NONE)])
 @pytest.mark.parametrize("chroma", CHROMAS)
-@pytest.mark.parametrize("width", [1040, 1001, 24, 17, 2050])
+@pytest.mark.parametrize("width", [1040, 1001, 24, 17, 2050, 1000, 8])
 def test_write_16bit_document_to_u8_planes_padded_rows(gpu, planes, alpha, chroma, width):
     """A 16-bit document saved at 8 bit: RGBA16 takes the packed footprint too (samples rescaled with the reference's 16 -> 8 table
     expression and packed as the row arrives), RGB16 the generic kernel -- same cases either way, incl. samples beyond 32768."""
@@ -86,12 +86,22 @@ def test_write_16bit_document_to_u8_planes_padded_rows(gpu, planes, alpha, chrom
         src = harness.make_write_source(d, seed=width + height + planes)
         src.reshape(-1)[5::97] = 40000                     # beyond Photoshop's range: clamped like the reference's table index
         want = harness.oracle_write(d, src)
-        got, raw = gpu_write_padded(gpu, d, src)
-        assert "aligned=1" in gpu.last_kernel() and "depth=16" in gpu.last_kernel(), gpu.last_kernel()
-        for pl in want:
-            assert np.array_equal(want[pl], got[pl]), (pl, width, height, near, int(np.abs(want[pl].astype(int) - got[pl].astype(int)).max()))
-        for pl, (w, xs, ys) in harness.write_planes(d).items():
-            assert np.all(raw[pl][:, w:] == 0xA5), (pl, width)
+        # tuning word 7: RGB16 rows of whole 8-pixel groups take the RGB16 streaming kernels with u8 planes (round 5); word 0: the generic kernel
+        for variant in (7, 0):
+            gpu.lib.avifgpu_set_hot_variant(variant)
+            try:
+                got, raw = gpu_write_padded(gpu, d, src)
+                k = gpu.last_kernel()
+            finally:
+                gpu.lib.avifgpu_set_hot_variant(7)
+            if variant == 7 and planes == 3 and width % 8 == 0:
+                assert "write_rgb16_ycbcr" in k and "to8" in k, k
+            else:
+                assert "aligned=1" in k and "depth=16" in k, k
+            for pl in want:
+                assert np.array_equal(want[pl], got[pl]), (k, pl, width, height, near, int(np.abs(want[pl].astype(int) - got[pl].astype(int)).max()))
+            for pl, (w, xs, ys) in harness.write_planes(d).items():
+                assert np.all(raw[pl][:, w:] == 0xA5), (k, pl, width)
 
 
 @pytest.mark.parametrize("alpha", [pkg.ALPHA_NONE, pkg.ALPHA_STRAIGHT, pkg.ALPHA_PREMULTIPLIED])
