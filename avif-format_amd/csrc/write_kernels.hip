@@ -2498,6 +2498,123 @@ __global__ __launch_bounds__(64 * kRgb8Waves) void write_rgb8_ycbcr_hot(const Wr
     }
 }
 
+// ---- RGBA8 -> Y, Cb, Cr, A u8 planes: the default save of a transparent 8-bit document as a streaming kernel (round 5) ---------------------
+// The structure of write_rgb8_ycbcr_hot with one dword = one pixel: a wave owns a span of 512 pixels on 1 or 2 rows, two coalesced 1-KiB
+// buffer loads per row, the row through the wave-private strip (2 KiB) to lane-major -- lane l: pixels [8 l, 8 l + 8), the footprint of 4
+// chroma samples -- alpha gathered with v_perm_b32 and stored at once, then chroma-major: the colours of the 1 / 2 / 4 pixels under a chroma
+// sample as floats, premultiplied where the alpha state asks for it (exact_premultiply_fast_f: WriteHeifImage.cpp:691-708), luma and the box
+// with the oracle's expressions.  Stores: 8 bytes per lane per luma / alpha row, 4 (8 at 4:4:4) per chroma plane, contiguous across the wave.
+// Same bytes as the generic kernel's packed path (FAST8, 92 VGPRs = 5 waves per SIMD at 4:2:0).  Widths that are multiples of 8.
+template <int XS, int YS, bool NEAREST, bool PREMUL>
+__global__ __launch_bounds__(256) void write_rgba8_ycbcra_hot(const WriteParams p)
+{
+    constexpr int WPB = 4, PXL = 8, K = 2, SPAN_PX = 64 * PXL, VR = 1 << YS, NC = PXL >> XS, NDB = 8;
+    __shared__ __attribute__((aligned(16))) uint32_t strip[WPB][64 * NDB];
+    const int wave = wave_in_block();
+    const int lane = threadIdx.x & 63;
+    const uint32_t voff = (uint32_t)lane * 16u;
+    u32x4* my = reinterpret_cast<u32x4*>(strip[wave]);
+    const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;
+    const uint32_t groups = ((uint32_t)p.nrows + VR - 1) >> YS;
+    const uint32_t total = spans_per_row * groups;
+    for (uint32_t sidx = blockIdx.x * WPB + wave; sidx < total; sidx += gridDim.x * WPB) {
+        const uint32_t gy = sidx / spans_per_row;
+        const uint32_t sx = sidx - gy * spans_per_row;
+        const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);             // a multiple of 8
+        f32x4 v[VR][K];
+#pragma unroll
+        for (int vr = 0; vr < VR; ++vr) {
+            const int r = min((int)(gy * VR) + vr, p.rows_to_end - 1);             // bottom edge: replicate the last IMAGE row
+            const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)r * p.src_row_bytes + (long long)sx * (SPAN_PX * 4), (uint32_t)span_px * 4u);
+#pragma unroll
+            for (int k = 0; k < K; ++k) v[vr][k] = (k == 0) ? span_load16<false>(rs, voff, 1024u * k) : span_load16<true>(rs, voff, 1024u * k);
+        }
+        uint32_t raw[VR][NDB];
+        const long long xoff = (long long)sx * SPAN_PX;
+#pragma unroll
+        for (int vr = 0; vr < VR; ++vr) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) my[64 * k + lane] = __builtin_bit_cast(u32x4, v[vr][k]);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const u32x4 t = my[2 * lane + j];
+                raw[vr][4 * j] = t.x; raw[vr][4 * j + 1] = t.y; raw[vr][4 * j + 2] = t.z; raw[vr][4 * j + 3] = t.w;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int r = (int)(gy * VR) + vr;
+            if (r < p.nrows) {                                                     // the alpha plane: byte 3 of every pixel dword (v_perm_b32), out at once
+                uint32_t apk[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const uint32_t t0 = __builtin_amdgcn_perm(raw[vr][4 * m + 1], raw[vr][4 * m], 0x0c0c0703u);
+                    const uint32_t t1 = __builtin_amdgcn_perm(raw[vr][4 * m + 3], raw[vr][4 * m + 2], 0x0c0c0703u);
+                    apk[m] = __builtin_amdgcn_perm(t1, t0, 0x05040100u);
+                }
+                span_store8<true>(span_rsrc(p.dst[3] + (long long)r * p.dst_stride[3] + xoff, (uint32_t)span_px), (uint32_t)lane * 8u, u32x2{ apk[0], apk[1] });
+            }
+        }
+        uint32_t ypk[VR][PXL / 4], cbpk[(NC + 3) / 4], crpk[(NC + 3) / 4];
+#pragma unroll
+        for (int vr = 0; vr < VR; ++vr)
+#pragma unroll
+            for (int j = 0; j < PXL / 4; ++j) ypk[vr][j] = 0;
+#pragma unroll
+        for (int j = 0; j < (NC + 3) / 4; ++j) { cbpk[j] = 0; crpk[j] = 0; }
+        auto code = [&](int vr, int i, int k) -> float {                            // (float)code: v_cvt_f32_ubyteN on the pixel's dword
+            return (float)((raw[vr][i] >> (8 * k)) & 0xffu);
+        };
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+#pragma unroll
+            for (int vr = 0; vr < VR; ++vr)
+#pragma unroll
+                for (int d = 0; d < NDB; ++d) asm volatile("" : "+v"(raw[vr][d]));
+            float c[VR][1 << XS][3];
+#pragma unroll
+            for (int vr = 0; vr < VR; ++vr)
+#pragma unroll
+                for (int k = 0; k < (1 << XS); ++k) {
+                    const int i = (j << XS) + k;
+                    c[vr][k][0] = code(vr, i, 0); c[vr][k][1] = code(vr, i, 1); c[vr][k][2] = code(vr, i, 2);
+                    if constexpr (PREMUL) {
+                        const float a = code(vr, i, 3);
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) c[vr][k][ch] = exact_premultiply_fast_f(c[vr][k][ch], a, p.maxf, p.rcp_maxf);
+                    }
+                    put_u8(ypk[vr], i, (c[vr][k][0] * p.my[0] + c[vr][k][1] * p.my[1] + c[vr][k][2] * p.my[2]) + 0.5f);      // luma_code
+                }
+            float R = c[0][0][0], G = c[0][0][1], B = c[0][0][2];
+            if constexpr ((XS || YS) && !NEAREST) {
+                constexpr int k1 = XS ? 1 : 0, v1 = YS ? 1 : 0;
+                R = (R + c[0][k1][0] + c[v1][0][0] + c[v1][k1][0]) * 0.25f;
+                G = (G + c[0][k1][1] + c[v1][0][1] + c[v1][k1][1]) * 0.25f;
+                B = (B + c[0][k1][2] + c[v1][0][2] + c[v1][k1][2]) * 0.25f;
+            }
+            const float cb = R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2];
+            const float cr = R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2];
+            put_u8(cbpk, j, (cb + p.half) + 0.5f);                                 // clip_round(cb + half, 255)
+            put_u8(crpk, j, (cr + p.half) + 0.5f);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int vr = 0; vr < VR; ++vr) {
+            const int r = (int)(gy * VR) + vr;
+            if (r >= p.nrows) continue;
+            span_store8<true>(span_rsrc(p.dst[0] + (long long)r * p.dst_stride[0] + xoff, (uint32_t)span_px), (uint32_t)lane * 8u, u32x2{ ypk[vr][0], ypk[vr][1] });
+        }
+        const uint32_t cbytes = (uint32_t)span_px >> XS;                           // a multiple of 4 (width % 8 == 0)
+        const long long coff = xoff >> XS;
+        if constexpr (XS) {
+            span_store4<true>(span_rsrc(p.dst[1] + (long long)gy * p.dst_stride[1] + coff, cbytes), (uint32_t)lane * 4u, cbpk[0]);
+            span_store4<true>(span_rsrc(p.dst[2] + (long long)gy * p.dst_stride[2] + coff, cbytes), (uint32_t)lane * 4u, crpk[0]);
+        } else {
+            span_store8<true>(span_rsrc(p.dst[1] + (long long)gy * p.dst_stride[1] + coff, cbytes), (uint32_t)lane * 8u, u32x2{ cbpk[0], cbpk[1] });
+            span_store8<true>(span_rsrc(p.dst[2] + (long long)gy * p.dst_stride[2] + coff, cbytes), (uint32_t)lane * 8u, u32x2{ crpk[0], crpk[1] });
+        }
+    }
+}
+
 // ---- RGB(A) f32 -> interleaved RRGGBB(AA) u16: the reference's own hand-off (CreateHeifImageRGBThirtyTwoBit) ------------------
 // Output sample i is a function of input sample i (RGB) or of its own pixel's float4 (RGBA): no transposition at all.  A wave
 // streams 64 x 4 float4 per trip: coalesced non-temporal 16-byte loads, the curve, 8-byte non-temporal stores at the same index.
@@ -2990,6 +3107,26 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
             else if (ys == 0) { if (p.nearest) AG_R8(1, 0, true); else AG_R8(1, 0, false); }
             else { if (p.nearest) AG_R8(1, 1, true); else AG_R8(1, 1, false); }
 #undef AG_R8
+            return hipGetLastError();
+        }
+    }
+    // RGBA8 -> u8 Y, Cb, Cr, A (a transparent 8-bit document's save): widths of whole 8-pixel groups, dword-aligned rows and planes
+    if (AG_RGB8_HOT && (variant & 1) && p.icc8_s1 == nullptr && depth == 8 && planes == 4 && !dst16 && output == AVIFGPU_OUT_YCBCR && p.maxv == 255 && p.dst[3] != nullptr &&
+        (p.width % 8) == 0 && (p.src_row_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) | reinterpret_cast<uintptr_t>(p.dst[3]) |
+          (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2] | (uintptr_t)p.dst_stride[3]) & 3) == 0) {
+        const long long spans = (long long)((p.width + 511) / 512) * ((p.nrows + (1 << ys) - 1) >> ys);
+        if (spans == 0) return hipSuccess;
+        if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
+            long long blocks = (spans + 3) / 4;
+            if (blocks > AG_STREAM_BLOCK_CAP) blocks = AG_STREAM_BLOCK_CAP;
+            snprintf(label, kLabelBytes, "write_rgba8_ycbcra_hot<xs=%d,ys=%d,nearest=%d,premultiply=%d>", xs, ys, (xs || ys) ? p.nearest : 0, p.premultiply);
+#define AG_RA8(XS_, YS_, NR_) do { if (p.premultiply) hipLaunchKernelGGL((write_rgba8_ycbcra_hot<XS_, YS_, NR_, true>), dim3((int)blocks), dim3(256), 0, st, p); \
+                                   else hipLaunchKernelGGL((write_rgba8_ycbcra_hot<XS_, YS_, NR_, false>), dim3((int)blocks), dim3(256), 0, st, p); } while (0)
+            if (xs == 0) AG_RA8(0, 0, false);
+            else if (ys == 0) { if (p.nearest) AG_RA8(1, 0, true); else AG_RA8(1, 0, false); }
+            else { if (p.nearest) AG_RA8(1, 1, true); else AG_RA8(1, 1, false); }
+#undef AG_RA8
             return hipGetLastError();
         }
     }

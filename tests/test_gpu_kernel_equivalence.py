@@ -69,6 +69,21 @@ CASES = [
                                   matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)),
     ("write_rgb8_ycbcr_hot", dict(width=16, height=2, depth=8, planes=3, bit_depth=8, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444,
                                   matrix_coefficients=pkg.MATRIX_RGB_GBR)),
+    # round 5: RGBA8 -> u8 planes + alpha (straight and premultiplied), every chroma format
+    ("write_rgba8_ycbcra_hot", dict(width=1024, height=6, depth=8, planes=4, bit_depth=8, alpha_state=pkg.ALPHA_PREMULTIPLIED, output=pkg.OUT_YCBCR,
+                                    chroma=pkg.CHROMA_420, matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)),
+    ("write_rgba8_ycbcra_hot", dict(width=1000, height=7, depth=8, planes=4, bit_depth=8, alpha_state=pkg.ALPHA_STRAIGHT, output=pkg.OUT_YCBCR,
+                                    chroma=pkg.CHROMA_420, matrix_coefficients=pkg.MATRIX_BT709, color_primaries=pkg.PRIMARIES_BT709)),
+    ("write_rgba8_ycbcra_hot", dict(width=1000, height=5, depth=8, planes=4, bit_depth=8, alpha_state=pkg.ALPHA_PREMULTIPLIED, output=pkg.OUT_YCBCR,
+                                    chroma=pkg.CHROMA_420, chroma_downsampling=pkg.DOWNSAMPLE_NEAREST, matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)),
+    ("write_rgba8_ycbcra_hot", dict(width=520, height=5, depth=8, planes=4, bit_depth=8, alpha_state=pkg.ALPHA_PREMULTIPLIED, output=pkg.OUT_YCBCR,
+                                    chroma=pkg.CHROMA_422, matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)),
+    ("write_rgba8_ycbcra_hot", dict(width=520, height=4, depth=8, planes=4, bit_depth=8, alpha_state=pkg.ALPHA_STRAIGHT, output=pkg.OUT_YCBCR,
+                                    chroma=pkg.CHROMA_422, chroma_downsampling=pkg.DOWNSAMPLE_NEAREST, matrix_coefficients=pkg.MATRIX_BT709, color_primaries=pkg.PRIMARIES_BT709)),
+    ("write_rgba8_ycbcra_hot", dict(width=1032, height=3, depth=8, planes=4, bit_depth=8, alpha_state=pkg.ALPHA_PREMULTIPLIED, output=pkg.OUT_YCBCR,
+                                    chroma=pkg.CHROMA_444, **BT2020)),
+    ("write_rgba8_ycbcra_hot", dict(width=8, height=1, depth=8, planes=4, bit_depth=8, alpha_state=pkg.ALPHA_STRAIGHT, output=pkg.OUT_YCBCR,
+                                    chroma=pkg.CHROMA_420, matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)),
     # round 5: 16-bit documents saved at 8 bit on the RGB16 streaming kernels (u8 planes)
     ("write_rgb16_ycbcr_sub_hot", dict(width=1024, height=7, depth=16, planes=3, bit_depth=8, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420,
                                        matrix_coefficients=pkg.MATRIX_BT709, color_primaries=pkg.PRIMARIES_BT709)),

@@ -60,8 +60,8 @@ def test_write_u8_fast_path_padded_rows(gpu, planes, alpha, chroma, width):
                 k = gpu.last_kernel()
             finally:
                 gpu.lib.avifgpu_set_hot_variant(7)
-            if variant == 7 and planes == 3 and width % 8 == 0:
-                assert "write_rgb8_ycbcr_hot" in k, k
+            if variant == 7 and width % 8 == 0:
+                assert ("write_rgb8_ycbcr_hot" if planes == 3 else "write_rgba8_ycbcra_hot") in k, k
             else:
                 assert "aligned=1" in k and "depth=8" in k, k
             for pl in want:
