@@ -30,7 +30,8 @@ namespace avifgpu {
 // The library's Makefile compiles this file FIVE times, each time with another -DAG_WRITE_PART, into five code objects that the HIP
 // runtime loads one by one, on the first launch of a kernel of theirs -- a save then pays for the object its kernels live in, not for
 // all 650 instantiations (round 4: one 6.8-MB object, 18 ms in front of the first launch of a process):
-//    1   the streaming kernels (RGB(A) f32 / RGB(A)16 -> planes, the interleaved hand-offs) + launch_write(), the only entry point
+//    1   launch_write(), the only entry point, + the RGB f32 4:4:4 streaming kernels (the headline, with and without a profile in front) and
+//        the f32 interleaved hand-off;  2  the 8- and 16-bit streaming kernels;  3  RGB f32 4:2:2 / 4:2:0 and RGBA f32 streaming kernels
 //    8, 16   write_px, the generic kernel, for 8- and 16-bit documents
 //    32  write_px for gray (+ alpha) f32 documents (their only path), 33 for RGB(A) f32 documents (the fall-back of the streaming kernels
 //        and the parametric-curve ICC variants), 36 write_px<32, ..., icc = 6>: documents whose profile carries sampled curves
@@ -2977,53 +2978,14 @@ hipError_t launch_planes_d32_icc6(const WriteParams& p, int planes, bool dst16, 
 }
 #endif
 
-#if AG_WRITE_PART == 0 || AG_WRITE_PART == 1
-static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes, bool dst16, int output, int xs, int ys,
-                                    int variant, hipStream_t st, char* label);
-
-// Entry used by avifgpu_api.hip.  `variant` selects the hot-path implementation when it applies.
-//
-// FLAT launches (round 3).  When nothing depends on where a row ends -- 4:4:4 or 4:2:2 planes or the interleaved hand-off, 16- /
-// 32-bit documents -- and source and planes are contiguous (row stride == row bytes: the library's own staging buffers whenever a row is a
-// multiple of 16 bytes, and any tightly packed caller buffer), the tile IS one long row of width x nrows pixels.  Launched as such,
-// every wave's span starts on a span boundary of the buffer instead of a row boundary: no half-empty last span per row (7952-wide
-// rows fill 15.53 spans of 512 pixels) and no rows that start in the middle of a 128-byte line (7952 x 12 B = 745.5 lines).  Same
-// kernels, same per-pixel arithmetic, same bytes (tests/test_gpu_kernel_equivalence.py); variant bit 4 (16) turns it off for A/B.
-#ifndef AG_FLAT
-#define AG_FLAT 1
-#endif
-hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16, int output, int xs, int ys,
-                        int variant, hipStream_t st, char* label)
+// The streaming launches in three code objects (AG_WRITE_PART 1 / 2 / 3, see the top of the file): every `return` inside one of the two
+// functions below is a launch (or an empty tile) -- *taken says so; falling off the end hands the tile to the next candidate.
+hipError_t launch_stream_int(const WriteParams& p, int depth, int planes, bool dst16, int output, int xs, int ys, int variant, hipStream_t st, char* label, bool* taken);
+hipError_t launch_stream_f32_sub_rgba(const WriteParams& p, int depth, int planes, bool dst16, int output, int xs, int ys, int variant, hipStream_t st, char* label, bool* taken);
+#if AG_WRITE_PART == 0 || AG_WRITE_PART == 2
+hipError_t launch_stream_int(const WriteParams& p, int depth, int planes, bool dst16, int output, int xs, int ys, int variant, hipStream_t st, char* label, bool* taken)
 {
-    const long long px = (long long)p.width * p.nrows;
-    // 4:2:2 qualifies too (chroma is sub-sampled along the row only): even width, chroma planes of width / 2 samples per row
-    const bool h422 = xs == 1 && ys == 0 && (p.width & 1) == 0 && output == AVIFGPU_OUT_YCBCR;
-    bool flat = AG_FLAT && (variant & 1) && !(variant & 16) && p.nrows > 1 && planes >= 3 && (depth == 16 || depth == 32) && ys == 0 && (xs == 0 || h422) &&
-                px < (1LL << 29) && p.src_row_bytes == (long long)p.width * planes * (depth / 8);
-    const int dsz = dst16 ? 2 : 1;
-    auto plane_px = [&](int pl, long long w) { return (h422 && (pl == 1 || pl == 2)) ? w / 2 : w; };
-    if (flat) {
-        if (output == AVIFGPU_OUT_REFERENCE) flat = p.dst_stride[0] == (long long)p.width * planes * dsz;
-        else for (int pl = 0; pl < (planes == 4 ? 4 : 3); ++pl) flat = flat && p.dst[pl] != nullptr && p.dst_stride[pl] == plane_px(pl, p.width) * dsz;
-    }
-    if (!flat) return launch_write_impl(p, depth, planes, dst16, output, xs, ys, variant, st, label);
-    WriteParams q = p;
-    q.width = (int32_t)px; q.nrows = 1; q.rows_to_end = 1;
-    q.src_row_bytes = px * planes * (depth / 8);
-    for (int pl = 0; pl < 4; ++pl) if (q.dst[pl]) q.dst_stride[pl] = (output == AVIFGPU_OUT_REFERENCE ? px * planes : plane_px(pl, px)) * dsz;
-    const hipError_t e = launch_write_impl(q, depth, planes, dst16, output, xs, ys, variant, st, label);
-    const size_t n = strlen(label);
-    if (n + 6 < (size_t)kLabelBytes) snprintf(label + n, kLabelBytes - n, " flat");
-    return e;
-}
-
-static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes, bool dst16, int output, int xs, int ys,
-                                    int variant, hipStream_t st, char* label)
-{
-    // hot path: RGB f32 (no alpha) -> YCbCr 4:4:4 u16 with aligned rows; `variant` is a tuning word:
-    //   bit0 enable, bit1 PXL=8 (else 4), bit2 non-temporal, bit3 take the size-gated streaming kernels at any size (tests);
-    //   bits 8.. = blocks (0 = default).
-    // (8-bit documents stay on write_px: measured 0.057 vs 0.069 ms for the RGB8 copy, 0.090 vs 0.095 ms for RGBA8 premultiplied)
+    *taken = true;
     if ((variant & 1) && p.icc16_clut == nullptr && depth == 16 && planes >= 3 && output == AVIFGPU_OUT_REFERENCE &&
         ((long long)p.width * planes * (depth / 8)) % 16 == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | (uintptr_t)p.dst_stride[0]) & 15) == 0) {
@@ -3038,55 +3000,6 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
                            else hipLaunchKernelGGL((write_int_ref_stream<D, P, false>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); } while (0)
             if (planes == 4) AG_IREF(16, 4); else AG_IREF(16, 3);
 #undef AG_IREF
-            return hipGetLastError();
-        }
-    }
-    {   // ... behind a linear (or one simple parametric) document profile: the streaming ICC kernel with the interleaved hand-off as its output
-        const bool lin = AG_ICC1_HOT && p.icc_trc_type[0] != 0 && p.icc_s_tab == nullptr && p.icc_trc_linear[0] && p.icc_trc_linear[1] && p.icc_trc_linear[2];
-        const bool r1 = lin && p.icc_out == 0, r4 = lin && p.icc_out == 4 && p.transfer == AVIFGPU_TRANSFER_CLIP;
-        const bool r2 = AG_ICC2_HOT && p.icc_trc_type[0] != 0 && p.icc_s_tab == nullptr && p.icc_same_simple && p.icc_out == 0;
-        if ((variant & 1) && (r1 || r4 || r2) && depth == 32 && planes == 3 && dst16 && output == AVIFGPU_OUT_REFERENCE &&
-            (p.src_row_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 3) == 0 &&
-            ((reinterpret_cast<uintptr_t>(p.dst[0]) | (uintptr_t)p.dst_stride[0]) & 15) == 0) {
-            const long long spans = (long long)((p.width + 511) / 512) * p.nrows;
-            if (spans == 0) return hipSuccess;
-            if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
-                long long blocks = (spans + kF32Waves - 1) / kF32Waves;
-                if (blocks > AG_STREAM_BLOCK_CAP * 4 / kF32Waves) blocks = AG_STREAM_BLOCK_CAP * 4 / kF32Waves;
-                snprintf(label, kLabelBytes, "write_rgb32_icc1_ycbcr444_hot<transfer=%d,out=ref> icc=%d", p.transfer, r4 ? 4 : r2 ? 2 : 1);
-                if (r4) { hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<AVIFGPU_TRANSFER_CLIP, 4, true>), dim3((int)blocks), dim3(AG_F32_STREAM_BLOCK), 0, st, p); return hipGetLastError(); }
-#define AG_IREF32(TR) do { if (r2) hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<TR, 2, true>), dim3((int)blocks), dim3(AG_F32_STREAM_BLOCK), 0, st, p); \
-                           else hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<TR, 1, true>), dim3((int)blocks), dim3(AG_F32_STREAM_BLOCK), 0, st, p); } while (0)
-                switch (p.transfer) {
-                case AVIFGPU_TRANSFER_PQ:       if (pq_hi_launch(p)) AG_IREF32(kTransferPqHi); else AG_IREF32(AVIFGPU_TRANSFER_PQ); break;
-                case AVIFGPU_TRANSFER_HLG:      AG_IREF32(AVIFGPU_TRANSFER_HLG); break;
-                case AVIFGPU_TRANSFER_SMPTE428: AG_IREF32(AVIFGPU_TRANSFER_SMPTE428); break;
-                default:                        AG_IREF32(AVIFGPU_TRANSFER_CLIP); break;
-                }
-#undef AG_IREF32
-                return hipGetLastError();
-            }
-        }
-    }
-    if ((variant & 1) && p.icc_trc_type[0] == 0 && depth == 32 && planes >= 3 && dst16 && output == AVIFGPU_OUT_REFERENCE &&
-        ((long long)p.width * planes) % 4 == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
-        ((reinterpret_cast<uintptr_t>(p.dst[0]) | (uintptr_t)p.dst_stride[0]) & 7) == 0) {
-        const long long n4 = (long long)p.width * planes / 4;
-        const long long waves = ((n4 + 255) / 256) * p.nrows;
-        if (waves == 0) return hipSuccess;
-        if (waves + 8LL * 65536 * 4 < 0x7fffffffLL) {
-            long long blocks = (waves + kF32RefWaves - 1) / kF32RefWaves;
-            if (blocks > AG_STREAM_BLOCK_CAP * 4 / kF32RefWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kF32RefWaves;
-            snprintf(label, kLabelBytes, "write_f32_ref_stream<transfer=%d,planes=%d>", p.transfer, planes);
-#define AG_REF(TR) do { if (planes == 4) hipLaunchKernelGGL((write_f32_ref_stream<TR, 4>), dim3((int)blocks), dim3(AG_F32_REF_BLOCK), 0, st, p); \
-                        else hipLaunchKernelGGL((write_f32_ref_stream<TR, 3>), dim3((int)blocks), dim3(AG_F32_REF_BLOCK), 0, st, p); } while (0)
-            switch (p.transfer) {
-            case AVIFGPU_TRANSFER_PQ:       if (pq_hi_launch(p)) AG_REF(kTransferPqHi); else AG_REF(AVIFGPU_TRANSFER_PQ); break;
-            case AVIFGPU_TRANSFER_HLG:      AG_REF(AVIFGPU_TRANSFER_HLG); break;
-            case AVIFGPU_TRANSFER_SMPTE428: AG_REF(AVIFGPU_TRANSFER_SMPTE428); break;
-            default:                        AG_REF(AVIFGPU_TRANSFER_CLIP); break;
-            }
-#undef AG_REF
             return hipGetLastError();
         }
     }
@@ -3192,6 +3105,14 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
             return hipGetLastError();
         }
     }
+    *taken = false;
+    return hipSuccess;
+}
+#endif
+#if AG_WRITE_PART == 0 || AG_WRITE_PART == 3
+hipError_t launch_stream_f32_sub_rgba(const WriteParams& p, int depth, int planes, bool dst16, int output, int xs, int ys, int variant, hipStream_t st, char* label, bool* taken)
+{
+    *taken = true;
 // RGBA f32 -> Y, Cb, Cr (4:2:2 / 4:2:0), A: the plug-in's default save of a transparent 32-bit document (no ICC variant: those stay generic)
     if ((variant & 1) && p.icc_trc_type[0] == 0 && p.icc_s_tab == nullptr && depth == 32 && planes == 4 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 1 &&
         (p.src_row_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 3) == 0 && p.dst[3] != nullptr &&
@@ -3285,6 +3206,117 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
             return hipGetLastError();
         }
     }
+    *taken = false;
+    return hipSuccess;
+}
+#endif
+
+#if AG_WRITE_PART == 0 || AG_WRITE_PART == 1
+static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes, bool dst16, int output, int xs, int ys,
+                                    int variant, hipStream_t st, char* label);
+
+// Entry used by avifgpu_api.hip.  `variant` selects the hot-path implementation when it applies.
+//
+// FLAT launches (round 3).  When nothing depends on where a row ends -- 4:4:4 or 4:2:2 planes or the interleaved hand-off, 16- /
+// 32-bit documents -- and source and planes are contiguous (row stride == row bytes: the library's own staging buffers whenever a row is a
+// multiple of 16 bytes, and any tightly packed caller buffer), the tile IS one long row of width x nrows pixels.  Launched as such,
+// every wave's span starts on a span boundary of the buffer instead of a row boundary: no half-empty last span per row (7952-wide
+// rows fill 15.53 spans of 512 pixels) and no rows that start in the middle of a 128-byte line (7952 x 12 B = 745.5 lines).  Same
+// kernels, same per-pixel arithmetic, same bytes (tests/test_gpu_kernel_equivalence.py); variant bit 4 (16) turns it off for A/B.
+#ifndef AG_FLAT
+#define AG_FLAT 1
+#endif
+hipError_t launch_write(const WriteParams& p, int depth, int planes, bool dst16, int output, int xs, int ys,
+                        int variant, hipStream_t st, char* label)
+{
+    const long long px = (long long)p.width * p.nrows;
+    // 4:2:2 qualifies too (chroma is sub-sampled along the row only): even width, chroma planes of width / 2 samples per row
+    const bool h422 = xs == 1 && ys == 0 && (p.width & 1) == 0 && output == AVIFGPU_OUT_YCBCR;
+    bool flat = AG_FLAT && (variant & 1) && !(variant & 16) && p.nrows > 1 && planes >= 3 && (depth == 16 || depth == 32) && ys == 0 && (xs == 0 || h422) &&
+                px < (1LL << 29) && p.src_row_bytes == (long long)p.width * planes * (depth / 8);
+    const int dsz = dst16 ? 2 : 1;
+    auto plane_px = [&](int pl, long long w) { return (h422 && (pl == 1 || pl == 2)) ? w / 2 : w; };
+    if (flat) {
+        if (output == AVIFGPU_OUT_REFERENCE) flat = p.dst_stride[0] == (long long)p.width * planes * dsz;
+        else for (int pl = 0; pl < (planes == 4 ? 4 : 3); ++pl) flat = flat && p.dst[pl] != nullptr && p.dst_stride[pl] == plane_px(pl, p.width) * dsz;
+    }
+    if (!flat) return launch_write_impl(p, depth, planes, dst16, output, xs, ys, variant, st, label);
+    WriteParams q = p;
+    q.width = (int32_t)px; q.nrows = 1; q.rows_to_end = 1;
+    q.src_row_bytes = px * planes * (depth / 8);
+    for (int pl = 0; pl < 4; ++pl) if (q.dst[pl]) q.dst_stride[pl] = (output == AVIFGPU_OUT_REFERENCE ? px * planes : plane_px(pl, px)) * dsz;
+    const hipError_t e = launch_write_impl(q, depth, planes, dst16, output, xs, ys, variant, st, label);
+    const size_t n = strlen(label);
+    if (n + 6 < (size_t)kLabelBytes) snprintf(label + n, kLabelBytes - n, " flat");
+    return e;
+}
+
+static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes, bool dst16, int output, int xs, int ys,
+                                    int variant, hipStream_t st, char* label)
+{
+    // hot path: RGB f32 (no alpha) -> YCbCr 4:4:4 u16 with aligned rows; `variant` is a tuning word:
+    //   bit0 enable, bit1 PXL=8 (else 4), bit2 non-temporal, bit3 take the size-gated streaming kernels at any size (tests);
+    //   bits 8.. = blocks (0 = default).
+    // (8-bit documents stay on write_px: measured 0.057 vs 0.069 ms for the RGB8 copy, 0.090 vs 0.095 ms for RGBA8 premultiplied)
+    {   // 8- and 16-bit documents: part 2; f32 documents saved 4:2:2 / 4:2:0 or with transparency: part 3; the rest of this function: part 1
+        bool taken = false;
+        const hipError_t e = depth != 32 ? launch_stream_int(p, depth, planes, dst16, output, xs, ys, variant, st, label, &taken)
+                                         : launch_stream_f32_sub_rgba(p, depth, planes, dst16, output, xs, ys, variant, st, label, &taken);
+        if (taken) return e;
+    }
+    {   // ... behind a linear (or one simple parametric) document profile: the streaming ICC kernel with the interleaved hand-off as its output
+        const bool lin = AG_ICC1_HOT && p.icc_trc_type[0] != 0 && p.icc_s_tab == nullptr && p.icc_trc_linear[0] && p.icc_trc_linear[1] && p.icc_trc_linear[2];
+        const bool r1 = lin && p.icc_out == 0, r4 = lin && p.icc_out == 4 && p.transfer == AVIFGPU_TRANSFER_CLIP;
+        const bool r2 = AG_ICC2_HOT && p.icc_trc_type[0] != 0 && p.icc_s_tab == nullptr && p.icc_same_simple && p.icc_out == 0;
+        if ((variant & 1) && (r1 || r4 || r2) && depth == 32 && planes == 3 && dst16 && output == AVIFGPU_OUT_REFERENCE &&
+            (p.src_row_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 3) == 0 &&
+            ((reinterpret_cast<uintptr_t>(p.dst[0]) | (uintptr_t)p.dst_stride[0]) & 15) == 0) {
+            const long long spans = (long long)((p.width + 511) / 512) * p.nrows;
+            if (spans == 0) return hipSuccess;
+            if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
+                long long blocks = (spans + kF32Waves - 1) / kF32Waves;
+                if (blocks > AG_STREAM_BLOCK_CAP * 4 / kF32Waves) blocks = AG_STREAM_BLOCK_CAP * 4 / kF32Waves;
+                snprintf(label, kLabelBytes, "write_rgb32_icc1_ycbcr444_hot<transfer=%d,out=ref> icc=%d", p.transfer, r4 ? 4 : r2 ? 2 : 1);
+                if (r4) { hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<AVIFGPU_TRANSFER_CLIP, 4, true>), dim3((int)blocks), dim3(AG_F32_STREAM_BLOCK), 0, st, p); return hipGetLastError(); }
+#define AG_IREF32(TR) do { if (r2) hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<TR, 2, true>), dim3((int)blocks), dim3(AG_F32_STREAM_BLOCK), 0, st, p); \
+                           else hipLaunchKernelGGL((write_rgb32_icc1_ycbcr444_hot<TR, 1, true>), dim3((int)blocks), dim3(AG_F32_STREAM_BLOCK), 0, st, p); } while (0)
+                switch (p.transfer) {
+                case AVIFGPU_TRANSFER_PQ:       if (pq_hi_launch(p)) AG_IREF32(kTransferPqHi); else AG_IREF32(AVIFGPU_TRANSFER_PQ); break;
+                case AVIFGPU_TRANSFER_HLG:      AG_IREF32(AVIFGPU_TRANSFER_HLG); break;
+                case AVIFGPU_TRANSFER_SMPTE428: AG_IREF32(AVIFGPU_TRANSFER_SMPTE428); break;
+                default:                        AG_IREF32(AVIFGPU_TRANSFER_CLIP); break;
+                }
+#undef AG_IREF32
+                return hipGetLastError();
+            }
+        }
+    }
+    if ((variant & 1) && p.icc_trc_type[0] == 0 && depth == 32 && planes >= 3 && dst16 && output == AVIFGPU_OUT_REFERENCE &&
+        ((long long)p.width * planes) % 4 == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
+        ((reinterpret_cast<uintptr_t>(p.dst[0]) | (uintptr_t)p.dst_stride[0]) & 7) == 0) {
+        const long long n4 = (long long)p.width * planes / 4;
+        const long long waves = ((n4 + 255) / 256) * p.nrows;
+        if (waves == 0) return hipSuccess;
+        if (waves + 8LL * 65536 * 4 < 0x7fffffffLL) {
+            long long blocks = (waves + kF32RefWaves - 1) / kF32RefWaves;
+            if (blocks > AG_STREAM_BLOCK_CAP * 4 / kF32RefWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kF32RefWaves;
+            snprintf(label, kLabelBytes, "write_f32_ref_stream<transfer=%d,planes=%d>", p.transfer, planes);
+#define AG_REF(TR) do { if (planes == 4) hipLaunchKernelGGL((write_f32_ref_stream<TR, 4>), dim3((int)blocks), dim3(AG_F32_REF_BLOCK), 0, st, p); \
+                        else hipLaunchKernelGGL((write_f32_ref_stream<TR, 3>), dim3((int)blocks), dim3(AG_F32_REF_BLOCK), 0, st, p); } while (0)
+            switch (p.transfer) {
+            case AVIFGPU_TRANSFER_PQ:       if (pq_hi_launch(p)) AG_REF(kTransferPqHi); else AG_REF(AVIFGPU_TRANSFER_PQ); break;
+            case AVIFGPU_TRANSFER_HLG:      AG_REF(AVIFGPU_TRANSFER_HLG); break;
+            case AVIFGPU_TRANSFER_SMPTE428: AG_REF(AVIFGPU_TRANSFER_SMPTE428); break;
+            default:                        AG_REF(AVIFGPU_TRANSFER_CLIP); break;
+            }
+#undef AG_REF
+            return hipGetLastError();
+        }
+    }
+    const bool icc_lin = AG_ICC1_HOT && p.icc_trc_type[0] != 0 && p.icc_trc_linear[0] && p.icc_trc_linear[1] && p.icc_trc_linear[2];
+    const bool icc1 = icc_lin && p.icc_out == 0;
+    const bool icc4 = icc_lin && p.icc_out == 4 && p.transfer == AVIFGPU_TRANSFER_CLIP;
+    const bool icc2 = AG_ICC2_HOT && p.icc_trc_type[0] != 0 && p.icc_same_simple && p.icc_out == 0;
     // ... and with a linear document profile in front (icc = 1)
     if ((variant & 1) && (icc1 || icc4 || icc2) &&
         depth == 32 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 0 && ys == 0 &&

@@ -26,11 +26,11 @@ def once(name, d, src, planes):
 
 f32 = torch.rand((H, W * 3), dtype=torch.float32, device=dev)
 u16p = lambda n, w=W: [torch.empty((H, w * 2), dtype=torch.uint8, device=dev) for _ in range(n)]
-once("f32 streaming (part 1)", pkg.WriteDesc(width=W, height=H, depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_PQ, peak_nits=80, alpha_state=0, output=pkg.OUT_YCBCR,
+once("RGB f32 -> PQ 4:4:4 (part 1: the headline kernel)", pkg.WriteDesc(width=W, height=H, depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_PQ, peak_nits=80, alpha_state=0, output=pkg.OUT_YCBCR,
                                              chroma=pkg.CHROMA_444, matrix_coefficients=9, color_primaries=9), f32, u16p(3))
 u8 = torch.randint(0, 256, (H, W * 3), dtype=torch.uint8, device=dev)
-once("8-bit generic (part 8)", pkg.WriteDesc(width=W, height=H, depth=8, planes=3, bit_depth=8, alpha_state=0, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420, matrix_coefficients=1),
+once("RGB8 -> 8-bit 4:2:0 (part 2: 8/16-bit streaming)", pkg.WriteDesc(width=W, height=H, depth=8, planes=3, bit_depth=8, alpha_state=0, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420, matrix_coefficients=1),
      u8, [torch.empty((H, W), dtype=torch.uint8, device=dev), torch.empty((H // 2, W // 2), dtype=torch.uint8, device=dev), torch.empty((H // 2, W // 2), dtype=torch.uint8, device=dev)])
 g32 = torch.rand((H, W), dtype=torch.float32, device=dev)
-once("gray f32 generic (part 32)", pkg.WriteDesc(width=W, height=H, depth=32, planes=1, bit_depth=10, transfer=pkg.TRANSFER_PQ, peak_nits=80, alpha_state=0, output=pkg.OUT_REFERENCE), g32, u16p(1))
+once("gray f32 -> PQ (part 32: generic, gray f32)", pkg.WriteDesc(width=W, height=H, depth=32, planes=1, bit_depth=10, transfer=pkg.TRANSFER_PQ, peak_nits=80, alpha_state=0, output=pkg.OUT_REFERENCE), g32, u16p(1))
 print("avifgpu_init %.2f ms | " % t_init + " | ".join(out), flush=True)
