@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
 from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_void_p
 
 from . import sharding  # noqa: E402,F401  (row-tile partition used by bench.py / host shim tests)
@@ -170,16 +171,28 @@ ABI = [
 ]
 
 
+# Entry points that a library of an OLDER round may lack (they arrived with ABI 4, rounds 3-4).  Only these may be missing, only when the
+# developer asks for it (AVIFGPU_AB_OLD_LIB=1, the A/B of tools/gpu/ab_libs.sh against e.g. variants/libavifgpu_r03.so), and every skip is
+# reported: a stale or wrong AVIFGPU_LIB must fail HERE, at bind time, not later with an AttributeError or a call without argtypes.
+ABI4_NEW = frozenset(("avifgpu_probe_pattern_read", "avifgpu_probe_pattern_rgb32_444", "avifgpu_device_traffic_get", "avifgpu_device_traffic_reset",
+                      "avifgpu_topology_plan", "avifgpu_icc_prepare_sampled", "avifgpu_write_rows_icc_sampled",
+                      "avifgpu_icc_clut16_from_transforms"))
+
+
 def bind(lib: ctypes.CDLL, table=ABI) -> ctypes.CDLL:
+    skipped = []
     for name, res, args in table:
         try:
             fn = getattr(lib, name)    # AttributeError if the symbol is not exported
         except AttributeError:
-            if os.environ.get("AVIFGPU_LIB"):      # developer A/B against an older build (tools/gpu/ab_libs.sh): its newer entry points are just absent
+            if os.environ.get("AVIFGPU_AB_OLD_LIB") == "1" and os.environ.get("AVIFGPU_LIB") and name in ABI4_NEW:
+                skipped.append(name)
                 continue
             raise
         fn.restype = res
         fn.argtypes = args
+    if skipped:
+        sys.stderr.write("avif-format_amd: AVIFGPU_AB_OLD_LIB=1: %s lacks %s\n" % (os.environ.get("AVIFGPU_LIB"), ", ".join(skipped)))
     return lib
 
 

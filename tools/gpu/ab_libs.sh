@@ -7,7 +7,7 @@ for v in "$@"; do
   lib=$PWD/avif-format_amd/variants/libavifgpu_$v.so
   [ "$v" = tree ] && lib=$PWD/avif-format_amd/libavifgpu.so
   echo "== $v (pass $rep)"
-  AVIFGPU_LIB=$lib python tools/bench_configs.py "${pats[@]}" 2>/dev/null | python -c "
+  AVIFGPU_AB_OLD_LIB=1 AVIFGPU_LIB=$lib python tools/bench_configs.py "${pats[@]}" 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     try: d=json.loads(l)
