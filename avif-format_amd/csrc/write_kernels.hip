@@ -14,6 +14,7 @@
 // (write_rgb32_ycbcr444_lds) whose global loads are fully coalesced 1-KiB wave transactions.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 #include "kernel_params.h"
@@ -3357,7 +3358,10 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
             const long long cap = (variant >> 8) ? (variant >> 8) : 256LL * 512 * 4 / WPB;   // 8192^2: one span per wave measured 5-6 % faster than two
             if (blocks > cap) blocks = cap;
             snprintf(label, kLabelBytes, "write_rgb32_ycbcr444_hot<transfer=%d,pxl=%d,nt=%d>", p.transfer, px8 ? 8 : 4, (int)nt);
-#define AG_HOT3(TR, PX, NT_) hipLaunchKernelGGL((write_rgb32_ycbcr444_hot<TR, PX, NT_>), dim3((int)blocks), dim3(AG_F32_STREAM_BLOCK), 0, st, p)
+            // measuring knob (not a tuning word of the product): AVIFGPU_DEBUG_LDS_PAD = bytes of unused dynamic LDS per workgroup, i.e. fewer
+            // resident workgroups per CU -- how the kernel's rate depends on the number of waves per SIMD (profiles/r05/occupancy_sweep_444.txt)
+            static const size_t lds_pad = [] { const char* e = getenv("AVIFGPU_DEBUG_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
+#define AG_HOT3(TR, PX, NT_) hipLaunchKernelGGL((write_rgb32_ycbcr444_hot<TR, PX, NT_>), dim3((int)blocks), dim3(AG_F32_STREAM_BLOCK), lds_pad, st, p)
 #define AG_HOT2(TR, PX) do { if (nt) AG_HOT3(TR, PX, true); else AG_HOT3(TR, PX, false); } while (0)
 #define AG_HOT1(TR) do { if (px8) AG_HOT2(TR, 8); else AG_HOT2(TR, 4); } while (0)
             switch (p.transfer) {
