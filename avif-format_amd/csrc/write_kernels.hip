@@ -2979,6 +2979,12 @@ hipError_t launch_planes_d32_icc6(const WriteParams& p, int planes, bool dst16, 
 }
 #endif
 
+// AG_IREF8 (round 5): RGBA8 documents through the interleaved hand-off (what integration/ asks for by default; the integer premultiply where the
+// alpha state asks for it) on the streaming hand-off kernel: 0.66 -> 0.73 of 8 TB/s on fresh data.  Round 2 had kept every 8-bit document on
+// the generic kernel on one-set-loop figures (0.75-0.77 there).  The RGB8 hand-off -- a plain copy -- stays generic: 0.76 against 0.71 here.
+#ifndef AG_IREF8
+#define AG_IREF8 1
+#endif
 // The streaming launches in three code objects (AG_WRITE_PART 1 / 2 / 3, see the top of the file): every `return` inside one of the two
 // functions below is a launch (or an empty tile) -- *taken says so; falling off the end hands the tile to the next candidate.
 hipError_t launch_stream_int(const WriteParams& p, int depth, int planes, bool dst16, int output, int xs, int ys, int variant, hipStream_t st, char* label, bool* taken);
@@ -2987,7 +2993,7 @@ hipError_t launch_stream_f32_sub_rgba(const WriteParams& p, int depth, int plane
 hipError_t launch_stream_int(const WriteParams& p, int depth, int planes, bool dst16, int output, int xs, int ys, int variant, hipStream_t st, char* label, bool* taken)
 {
     *taken = true;
-    if ((variant & 1) && p.icc16_clut == nullptr && depth == 16 && planes >= 3 && output == AVIFGPU_OUT_REFERENCE &&
+    if ((variant & 1) && p.icc16_clut == nullptr && p.icc8_s1 == nullptr && (depth == 16 || (AG_IREF8 && depth == 8 && planes == 4)) && planes >= 3 && output == AVIFGPU_OUT_REFERENCE &&
         ((long long)p.width * planes * (depth / 8)) % 16 == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | (uintptr_t)p.dst_stride[0]) & 15) == 0) {
         const long long nv = (long long)p.width * planes * (depth / 8) / 16;
@@ -2999,7 +3005,8 @@ hipError_t launch_stream_int(const WriteParams& p, int depth, int planes, bool d
             snprintf(label, kLabelBytes, "write_int_ref_stream<depth=%d,planes=%d,dst16=%d>", depth, planes, (int)dst16);
 #define AG_IREF(D, P) do { if (dst16) hipLaunchKernelGGL((write_int_ref_stream<D, P, true>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); \
                            else hipLaunchKernelGGL((write_int_ref_stream<D, P, false>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); } while (0)
-            if (planes == 4) AG_IREF(16, 4); else AG_IREF(16, 3);
+            if (depth == 8) AG_IREF(8, 4);
+            else { if (planes == 4) AG_IREF(16, 4); else AG_IREF(16, 3); }
 #undef AG_IREF
             return hipGetLastError();
         }
