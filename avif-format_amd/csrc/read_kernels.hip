@@ -531,6 +531,9 @@ __global__ __launch_bounds__(256) void build_read_tables(const ReadParams p, flo
 // Round 4 (the entry is a multiply and an FMA now, and the f32 4:2:2 open runs at 82 VGPRs): measured again per row
 // (profiles/r04/read_table_free_ab_r04.txt) -- 8-bit gray joins (-6 %) and the f32 4:2:2 open without alpha (-4 %: what the default
 // HDR save decodes to); the 8-bit colour opens without alpha still lose 6-9 %, the other f32 hosts 0-3 %.
+// Round 5, the whole policy against none / all on FRESH data (profiles/r05/read_table_free_policy_fresh_data.txt): it stands row for row (12-bit
+// gray -> Gray16 0.54 tabled / 0.75 table-free, 12-bit 4:4:4 -> RGB16 0.66 / 0.77, 12-bit 4:2:2 PQ -> RGB f32 0.61 / 0.73; all-table-free loses
+// 5-7 % on the alpha rows) with one addition: gray -> Gray f32 (10-bit PQ 0.639 -> 0.658).
 template <int CS, int DEPTH, bool ALPHA, int XS, int YS = 0> constexpr bool read_arith_policy()
 {
     if (AG_READ_ARITH == 0) return false;
@@ -538,7 +541,7 @@ template <int CS, int DEPTH, bool ALPHA, int XS, int YS = 0> constexpr bool read
     if (AG_READ_ARITH == 2) return true;
     if (DEPTH == 16) return CS == kCsMono || (CS == kCsYcc && XS == 0 && !ALPHA);
     if (DEPTH == 8) return (CS == kCsYcc && ALPHA && XS == 1) || (CS == kCsMono && !ALPHA);
-    if (DEPTH == 32) return CS == kCsYcc && XS == 1 && YS == 0 && !ALPHA;
+    if (DEPTH == 32) return (CS == kCsYcc && XS == 1 && YS == 0 && !ALPHA) || CS == kCsMono;   // gray -> f32 joined in round 5 (fresh data: +3 %)
     return false;
 }
 #ifndef AG_R8_NC
