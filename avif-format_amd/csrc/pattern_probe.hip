@@ -7,6 +7,7 @@
 // inside read_kernels.hip: read_px<..., TWIN = true>, avifgpu_probe_pattern_read.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "staging.h"
 #include "kernel_params.h"
@@ -23,7 +24,7 @@ template <int K> __device__ __forceinline__ pp_i4 probe_load(__amdgpu_buffer_rsr
     return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 1024 * K, span_load_cached(K, 6) ? 0 : 2);
 }
 __global__ __launch_bounds__(64 * kProbeWaves) void pattern_rgb32_planes444(const uint8_t* __restrict__ src, long long src_row_bytes, uint8_t* d0, uint8_t* d1,
-                                                                          uint8_t* d2, long long s0, long long s1, long long s2, int width, int nrows)
+                                                                          uint8_t* d2, long long s0, long long s1, long long s2, int width, int nrows, int pace)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t spans_per_row = (uint32_t)width / 512u, total = spans_per_row * (uint32_t)nrows;
@@ -34,6 +35,9 @@ __global__ __launch_bounds__(64 * kProbeWaves) void pattern_rgb32_planes444(cons
         pp_i4 v[6];
         v[0] = probe_load<0>(rs, voff); v[1] = probe_load<1>(rs, voff); v[2] = probe_load<2>(rs, voff);      // the kernel's own policy per load
         v[3] = probe_load<3>(rs, voff); v[4] = probe_load<4>(rs, voff); v[5] = probe_load<5>(rs, voff);
+        // measuring knob AVIFGPU_PROBE_PACE: idle for `pace` x 64 cycles between the loads' arrival and the stores, the place where the real kernel
+        // does its math -- does the memory system give a PACED pattern more than a flooding one?  (profiles/r05/probe_pacing.txt)
+        for (int i = 0; i < pace; ++i) __builtin_amdgcn_s_sleep(1);
         uint32_t acc = 0;
 #pragma unroll
         for (int k = 0; k < 6; ++k) acc ^= (uint32_t)v[k][0] ^ (uint32_t)v[k][1] ^ (uint32_t)v[k][2] ^ (uint32_t)v[k][3];
@@ -57,12 +61,13 @@ extern "C" int32_t avifgpu_probe_pattern_rgb32_444(const void* src, int64_t src_
     uintptr_t bits = reinterpret_cast<uintptr_t>(src) | (uintptr_t)src_row_bytes;
     for (int i = 0; i < 3; ++i) { if (!dst[i]) return fail(AVIFGPU_formatBadParameters, "pattern probe: null plane"); bits |= reinterpret_cast<uintptr_t>(dst[i]) | (uintptr_t)dst_stride[i]; }
     if (bits & 15) return fail(AVIFGPU_formatBadParameters, "pattern probe: pointers and strides must be 16-byte aligned");
+    static const int pace = [] { const char* e = getenv("AVIFGPU_PROBE_PACE"); return e ? atoi(e) : 0; }();
     const long long spans = (long long)(width / 512) * nrows;
     long long blocks = (spans + kProbeWaves - 1) / kProbeWaves;
     if (blocks > 256LL * 512 * 4 / kProbeWaves) blocks = 256LL * 512 * 4 / kProbeWaves;   // the hot kernel's own cap
     hipLaunchKernelGGL(pattern_rgb32_planes444, dim3((int)blocks), dim3(64 * kProbeWaves), 0, (hipStream_t)stream, static_cast<const uint8_t*>(src), (long long)src_row_bytes,
                        static_cast<uint8_t*>(dst[0]), static_cast<uint8_t*>(dst[1]), static_cast<uint8_t*>(dst[2]),
-                       (long long)dst_stride[0], (long long)dst_stride[1], (long long)dst_stride[2], width, nrows);
+                       (long long)dst_stride[0], (long long)dst_stride[1], (long long)dst_stride[2], width, nrows, pace);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "pattern probe launch", AVIFGPU_writErr);
 }
