@@ -478,7 +478,6 @@ def main():
         except Exception:
             pass
 
-    n_sets = len(sets)
     del sets[1:], keep[:]                      # the copies' memory back before C5 and the host-pointer job
 
     # ---- configs[4]: 16384^2 RGBA f32 -> 12-bit PQ Y,Cb,Cr,A, the same N-way row split (device-resident) ----
