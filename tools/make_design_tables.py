@@ -5,7 +5,6 @@ compute side alone) and configs_traffic.json (kernel-trace durations + FETCH_SIZ
 the committed measurements.      python tools/make_design_tables.py [round directory, default r05]"""
 import json
 import os
-import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
