@@ -15,15 +15,17 @@ enum : int { kHotDefault = 1 | 2 | 4 };
 // Cache policy of the K 16-byte loads a wave issues per span in the RGB f32 streaming kernels (and in their math-free twin,
 // pattern_probe.hip).  Round 4 sent the first and the last load of a span through the L2 / Infinity Cache normally (= 1), so that a
 // neighbouring span's touch of a shared 128-byte line could hit; in a loop over ONE frame that read +0...+2 % at 8192^2 and +5 % on
-// rows that start inside a line.  Round 5 measured on FRESH data (buffer sets rotating, > 1 GB between two visits of an address:
-// profiles/r05/load_policy_fresh_data_ab.txt, one box, two interleaved passes): the one-set loop had been flattering every allocating
-// load -- 4:4:4 at 8192^2: 0.784-0.788 of 8 TB/s on one set, 0.748-0.752 fresh -- because 2 of 6 loads allocating is 268 MB of an 805-MB
-// frame, about the 256-MiB Infinity Cache.  On fresh data: only the FIRST load allocating (= 16) 0.770-0.781, every load non-temporal
-// (= 0) 0.761-0.762, round 4's choice 0.748-0.752; the rows whose spans share lines (7952- and 6001-wide) keep round 4's gain with the
-// first load alone (0.714 / 0.730-0.740 against 0.701 / 0.713-0.720 all-non-temporal); at 16384^2 the three are equal.
-//   0 = every load non-temporal; 1 = first and last allocate; otherwise bit (4 + k) set = load k allocates.  Default: 16.
+// rows that start inside a line.  Round 5 measured on FRESH data (profiles/r05/load_policy_fresh_data_ab.txt, same-box interleaved
+// passes), twice.  First with two rotating buffer sets (1.25 GB between two visits of an address): round 4's choice 0.748-0.752 of 8 TB/s
+// against 0.784-0.788 in its one-set loop -- 2 of 6 loads allocating is 268 MB of an 805-MB frame, about the 256-MiB Infinity Cache --
+// and "only the first load allocates" (= 16) looked best, 0.770-0.781.  Then with >= 3 sets / 3.5 GB, after it turned out that two sets
+// still leave a kernel part of its allocating lines in the cache (profiles/r05/rotation_depth_check.txt): every load non-temporal (= 0)
+// is equal or ahead on every row -- 4:4:4 0.761 -> 0.766, 4:2:0 0.716 -> 0.730, 16384^2 +1 %, bench.py 0.760 -> 0.768, the rows whose
+// spans share lines (7952-, 6001-wide) equal -- and its one-set loop and its fresh figure agree (0.768 / 0.768).  Each byte of a document
+// is read once: nothing allocates.
+//   0 = every load non-temporal (default since round 5); 1 = first and last allocate; otherwise bit (4 + k) set = load k allocates.
 #ifndef AG_EDGE_CACHED
-#define AG_EDGE_CACHED 16
+#define AG_EDGE_CACHED 0
 #endif
 constexpr bool span_load_cached(int k, int K) { return AG_EDGE_CACHED == 1 ? (k == 0 || k == K - 1) : ((AG_EDGE_CACHED >> (k + 4)) & 1) != 0; }
 

@@ -2345,7 +2345,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra444_hot(co
 #define AG_RGB8_HOT 1
 #endif
 #ifndef AG_RGB8_FIRST_CACHED
-#define AG_RGB8_FIRST_CACHED 1     /* the first of a span's three loads allocates (kernel_params.h, span_load_cached); 0 = all non-temporal */
+#define AG_RGB8_FIRST_CACHED 0     /* 1 = the first of a span's loads allocates; 0 = all non-temporal (equal or ahead on truly fresh data: kernel_params.h, AG_EDGE_CACHED) */
 #endif
 // Workgroup size: 128 threads for 4:2:0, 256 otherwise (same-box A/B on fresh data, profiles/r05/rgb8_streaming_kernel_ab.txt: 8192^2 4:2:0
 // 0.749 -> 0.769 of 8 TB/s with 128, 4:2:2 0.782 -> 0.775, 4:4:4 and 16384^2 indifferent).
@@ -2529,7 +2529,7 @@ __global__ __launch_bounds__(256) void write_rgba8_ycbcra_hot(const WriteParams 
             const int r = min((int)(gy * VR) + vr, p.rows_to_end - 1);             // bottom edge: replicate the last IMAGE row
             const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)r * p.src_row_bytes + (long long)sx * (SPAN_PX * 4), (uint32_t)span_px * 4u);
 #pragma unroll
-            for (int k = 0; k < K; ++k) v[vr][k] = (k == 0) ? span_load16<false>(rs, voff, 1024u * k) : span_load16<true>(rs, voff, 1024u * k);
+            for (int k = 0; k < K; ++k) v[vr][k] = (AG_RGB8_FIRST_CACHED && k == 0) ? span_load16<false>(rs, voff, 1024u * k) : span_load16<true>(rs, voff, 1024u * k);
         }
         uint32_t raw[VR][NDB];
         const long long xoff = (long long)sx * SPAN_PX;

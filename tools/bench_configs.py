@@ -4,7 +4,7 @@ Diagnostic companion of bench.py: prints one line per configuration with HIP-eve
 algorithmic GB/s (input read once + output written once).
 
 Round 5 -- FRESH DATA: every row's launches rotate over disjoint (source, destination) buffer sets, enough of them that the sets'
-footprints add up to > BENCH_FOOTPRINT_GB (1.25) and never fewer than 2: no byte a launch touches can still sit in the 256-MiB
+footprints add up to > BENCH_FOOTPRINT_GB (3.5) and never fewer than 3 (two sets of 1.2 GB still left 2-4 % of cache in it): no byte a launch touches can still sit in the 256-MiB
 Infinity Cache when its address comes round again, which is how the plug-in sees memory (each row of a document is converted once).
 `ms_mean` / `frac_of_8TBs` are that figure; `ms_same` / `frac_same` (BENCH_SAME=0 skips them) are the ONE-set loop of rounds 1-4
 beside it -- rows where the two differ are rows whose old number was partly a cache number."""
@@ -91,12 +91,16 @@ def smooth_src(d):
     return img.to(torch.int32).to(torch.int16).reshape(d.height, -1)
 
 
-FOOTPRINT = float(os.environ.get("BENCH_FOOTPRINT_GB", "1.25")) * 1e9
+# How much is enough: with 1.25 GB (two sets of an 8192^2 f32 frame) a kernel whose FIRST span load allocates still found part of its
+# 134 MB of allocating lines in the 256-MiB Infinity Cache one visit later and read 2-4 % high (C4 0.775 against 0.758 with 3 or 4 sets;
+# all-non-temporal kernels: no difference) -- profiles/r05/rotation_depth_check.txt.  3.5 GB and never fewer than 3 sets since then.
+FOOTPRINT = float(os.environ.get("BENCH_FOOTPRINT_GB", "3.5")) * 1e9
+MIN_SETS = int(os.environ.get("BENCH_MIN_SETS", "3"))
 SAME = os.environ.get("BENCH_SAME", "1") != "0"
 
 
 def n_sets(algorithmic_bytes):
-    return max(2, min(64, int(-(-FOOTPRINT // algorithmic_bytes))))
+    return max(MIN_SETS, min(64, int(-(-FOOTPRINT // algorithmic_bytes))))
 
 
 def rotate(calls):
