@@ -70,7 +70,7 @@ def test_icc_then_pq_matches_lcms2(gpu, lcms, name, kind, trc, g, planes):
         st = harness.compare_write(d, want, got)
         print(f"icc->rec2020 {name} planes {planes} out {output} {bits}-bit transfer {transfer}: exact {st['exact_frac']:.5f} max {st['max_abs']}")
         assert st["max_abs"] <= 1, (name, output, st)
-        assert st["exact_frac"] >= (0.99 if transfer == pkg.TRANSFER_PQ else 0.985), (name, output, st)
+        assert harness.t2_exact_ok(st, harness.T2_MIN_EXACT_ICC), (name, output, st)
         assert ("icc=1" if (trc == 0 and g == 1.0) else "icc=2") in gpu.last_kernel()
 
 
@@ -98,7 +98,7 @@ def test_icc1_streaming_kernel_matches_lcms2(gpu, lcms, name, kind, trc, g, widt
         st = harness.compare_write(d, want, got)
         print(f"icc1-streaming {name} width {width} {bits}-bit transfer {transfer} chroma {chroma}: exact {st['exact_frac']:.5f} max {st['max_abs']}")
         assert st["max_abs"] <= 1, (name, st)
-        assert st["exact_frac"] >= (0.99 if transfer != pkg.TRANSFER_CLIP else 0.985) or d.width * d.height < 1000, (name, st)
+        assert harness.t2_exact_ok(st, harness.T2_MIN_EXACT_ICC), (name, st)
 
 
 @pytest.mark.parametrize("name,kind,trc,g", PROFILES)
@@ -127,7 +127,7 @@ def test_icc_streaming_reference_handoff_matches_lcms2(gpu, lcms, name, kind, tr
         st = harness.compare_write(d, want, got)
         print(f"icc-ref-streaming {name} width {width} {bits}-bit transfer {transfer}: exact {st['exact_frac']:.5f} max {st['max_abs']}  {k}")
         assert st["max_abs"] <= 1, (name, k, st)
-        assert harness.t2_exact_ok(st, 0.99 if transfer != pkg.TRANSFER_CLIP else 0.985), (name, k, st)
+        assert harness.t2_exact_ok(st, harness.T2_MIN_EXACT_ICC), (name, k, st)
         # ... and the generic kernel (tuning word 0: no streaming kernels) on the same rows agrees within the tier
         gpu.lib.avifgpu_set_hot_variant(0)
         try:
@@ -217,7 +217,7 @@ def test_icc4_rgba_streaming_kernel_matches_lcms2(gpu, lcms, name, kind, trc, g,
         assert "write_rgba32_ycbcra444_hot" in k and "icc=4" in k, k
         st = harness.compare_write(d, want, got)
         print(f"icc4-rgba-streaming {name} width {width} {bits}-bit: exact {st['exact_frac']:.5f} max {st['max_abs']}")
-        assert st["max_abs"] <= 1 and st["exact_frac"] >= 0.985, (name, st)
+        assert st["max_abs"] <= 1 and harness.t2_exact_ok(st, harness.T2_MIN_EXACT_ICC), (name, st)
 
 
 @pytest.mark.parametrize("name,kind,trc,g", [p for p in PROFILES if p[2] == 0 and p[3] == 1.0])
@@ -243,7 +243,7 @@ def test_icc4_streaming_kernel_matches_lcms2(gpu, lcms, name, kind, trc, g, widt
         print(f"icc4-streaming {name} width {width} {bits}-bit chroma {chroma}: exact {st['exact_frac']:.5f} max {st['max_abs']}")
         assert st["max_abs"] <= 1, (name, st)
         worst = min(worst, st["exact_frac"])
-    assert worst >= 0.985, (name, worst)
+    assert worst >= harness.T2_MIN_EXACT_ICC, (name, worst)
 
 
 @pytest.mark.parametrize("name,kind,trc,g", PROFILES)
@@ -274,7 +274,7 @@ def test_icc_to_srgb_then_clip_matches_lcms2(gpu, lcms, name, kind, trc, g, plan
         assert st["max_abs"] <= 1, (name, output, st)
         worst = min(worst, st["exact_frac"])
         assert "icc=4" in gpu.last_kernel()
-    assert worst >= 0.985, (name, worst)
+    assert worst >= harness.T2_MIN_EXACT_ICC, (name, worst)
     # the sRGB target belongs to the Clip save only (the reference never builds it for PQ / SMPTE 428)
     d = pkg.WriteDesc(width=16, height=2, depth=32, planes=planes, bit_depth=10, transfer=pkg.TRANSFER_PQ, peak_nits=1000,
                       alpha_state=alpha, output=pkg.OUT_REFERENCE)
@@ -421,7 +421,7 @@ def test_host_shim_sdr_save_of_32bit_document(gpu, lcms):
         raw = (ctypes.c_uint8 * (img.stride[pl] * h)).from_address(img.plane[pl])
         got[pl] = np.frombuffer(raw, dtype=np.uint8).reshape(h, img.stride[pl])[:, :w * 2].view(np.uint16).copy()
     st = harness.compare_write(d, want, got)
-    assert st["max_abs"] <= 1 and st["exact_frac"] >= 0.985, st
+    assert st["max_abs"] <= 1 and harness.t2_exact_ok(st, harness.T2_MIN_EXACT_ICC), st
     gpu.lib.avifgpu_image_free(ctypes.byref(img))
 
 
@@ -458,7 +458,7 @@ def test_host_shim_decides_like_the_plugin_clip_and_kept_profile(gpu, lcms, keep
     if keep:
         assert st["max_abs"] == 0, st                     # no ICC arithmetic at all: the plain Clip path, bit-exact
     else:
-        assert st["max_abs"] <= 1 and st["exact_frac"] >= 0.985, st
+        assert st["max_abs"] <= 1 and harness.t2_exact_ok(st, harness.T2_MIN_EXACT_ICC), st
     gpu.lib.avifgpu_image_free(ctypes.byref(img))
     # a profile that cannot be opened where the reference opens it: runtime_error -> writErr + the reference's message
     junk = ctypes.create_string_buffer(b"\0" * 256)
@@ -571,7 +571,7 @@ def test_sampled_document_curves_match_lcms2(gpu, lcms, name, kind, trc, g, plan
             st = harness.compare_write(d, want, got)
             print(f"icc-sampled {name} planes {planes} target {target} out {output} {bits}-bit transfer {transfer}: exact {st['exact_frac']:.5f} max {st['max_abs']}")
             assert st["max_abs"] <= 1, (name, st)
-            assert st["exact_frac"] >= (0.99 if hdr else 0.985), (name, st)
+            assert harness.t2_exact_ok(st, harness.T2_MIN_EXACT_ICC), (name, st)
 
 
 @pytest.mark.gpu
@@ -614,7 +614,7 @@ def test_mixed_sampled_and_parametric_curves_match_lcms2(gpu, lcms, name, kind, 
             st = harness.compare_write(d, want, got)
             print(f"icc-mixed {name} planes {planes} target {target} out {output} {bits}-bit transfer {transfer}: exact {st['exact_frac']:.5f} max {st['max_abs']}")
             assert st["max_abs"] <= 1, (name, st)
-            assert st["exact_frac"] >= (0.99 if hdr else 0.985), (name, st)
+            assert harness.t2_exact_ok(st, harness.T2_MIN_EXACT_ICC), (name, st)
 
 
 def test_host_shim_takes_sampled_profiles_itself(gpu, lcms):
