@@ -154,6 +154,10 @@ AG_DEV float fast_linear_to_pq(float value, float mult)
 #ifndef AG_PQ_TAB_FORM
 #define AG_PQ_TAB_FORM 2
 #endif
+// AG_PQ_ND_FMA (round 5, A/B): N(x) = c1 + c2 x and D(x) = 1 + c3 x as one FMA each instead of multiply + add
+#ifndef AG_PQ_ND_FMA
+#define AG_PQ_ND_FMA 0
+#endif
 constexpr int kPqTabEntries = 512;
 constexpr int kPqTabPad = 4;
 constexpr int kPqTabCount = AG_PQ_TAB_FORM == 3 ? 3 : 2;
@@ -196,6 +200,38 @@ AG_DEV void pq_exp_table_fill(int tid, int nthreads)
     const f4* src = reinterpret_cast<const f4*>(&kPqExpTableConst);
     for (int i = tid; i < kPqTabFloats / 4; i += nthreads) dst[i] = src[i];
 }
+// The same fill in two steps, for the streaming kernels: a workgroup that copies its table BEFORE it asks for its pixels keeps every
+// wave's slot empty-handed for one L2 round trip + a barrier (about a microsecond of a wave's ~12).  load() issues the table's global
+// loads, the caller then issues its span loads, store() writes the table to LDS (a wave's loads return in order: the table arrives
+// first, the wait in front of the LDS writes is vmcnt(span loads), not vmcnt(0)); the caller synchronises with pq_table_barrier().
+template <int NTHREADS> struct PqTableFill {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    static constexpr int kVec = kPqTabFloats / 4, N = (kVec + NTHREADS - 1) / NTHREADS;
+    f4 v[N];
+    AG_DEV void load(int tid)
+    {
+        const f4* src = reinterpret_cast<const f4*>(&kPqExpTableConst);
+#pragma unroll
+        for (int i = 0; i < N; ++i) { const int idx = tid + i * NTHREADS; v[i] = src[idx < kVec ? idx : kVec - 1]; }
+        __builtin_amdgcn_sched_barrier(0);      // (seen without it: a table load sunk below the span loads, and vmcnt(0) in front of the barrier)
+    }
+    AG_DEV void store(int tid)
+    {
+        f4* dst = reinterpret_cast<f4*>(pq_exp_table());
+#pragma unroll
+        // no test here either: the threads past the table's end hold its last entry (load()) and write it to its own place again -- a store
+        // under a branch is where the optimiser sinks the table's LOAD to, behind the span loads, and the wait becomes vmcnt(0)
+        for (int i = 0; i < N; ++i) { const int idx = tid + i * NTHREADS; dst[idx < kVec ? idx : kVec - 1] = v[i]; }
+    }
+};
+// LDS writes of this wave done, then the workgroup's barrier -- and NOT __syncthreads(): its fences cover global memory too and make the
+// compiler wait for every outstanding global load (s_waitcnt vmcnt(0)) in front of the barrier, which is the wait this split avoids.
+AG_DEV void pq_table_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 AG_DEV uint32_t pq_tab_offset(float t) { return (__float_as_uint(t) >> (AG_PQ_TAB_FORM == 1 ? 20 : 21)) & (AG_PQ_TAB_FORM == 1 ? 0xff8u : 0x7fcu); }   // byte offset of t's entry
 AG_DEV float pq_tab_at(const float* tab, int which, uint32_t off)
 {
@@ -211,7 +247,9 @@ AG_DEV float fast_linear_to_pq01_hi(float value, float mult)
     const uint32_t off = pq_tab_offset(t);
     const float y = nat_exp2(__builtin_fmaf(kPqM1, nat_log2(pq_mantissa(t)), pq_tab_at(tab, 0, off)));
     float n, d;
-    if (AG_PQ_TAB_FORM == 3) { n = kPqC1 + pq_tab_at(tab, 1, off) * y; d = 1.0f + pq_tab_at(tab, 2, off) * y; }
+    if (AG_PQ_TAB_FORM == 3 && AG_PQ_ND_FMA) { n = __builtin_fmaf(pq_tab_at(tab, 1, off), y, kPqC1); d = __builtin_fmaf(pq_tab_at(tab, 2, off), y, 1.0f); }
+    else if (AG_PQ_TAB_FORM == 3) { n = kPqC1 + pq_tab_at(tab, 1, off) * y; d = 1.0f + pq_tab_at(tab, 2, off) * y; }
+    else if (AG_PQ_ND_FMA) { const float x = y * pq_tab_at(tab, 1, off); n = __builtin_fmaf(kPqC2, x, kPqC1); d = __builtin_fmaf(kPqC3, x, 1.0f); }
     else { const float x = y * pq_tab_at(tab, 1, off); n = kPqC1 + kPqC2 * x; d = 1.0f + kPqC3 * x; }
     return nat_exp2_sat(kPqM2 * nat_log2(near_ieee_div(n, d)));
 }
@@ -228,12 +266,12 @@ AG_DEV f32x2 fast_linear_to_pq01_2_hi(f32x2 value, float mult)
     if (AG_PQ_TAB_FORM == 3) {
         const f32x2 C2 = { pq_tab_at(tab, 1, o0), pq_tab_at(tab, 1, o1) };
         const f32x2 C3 = { pq_tab_at(tab, 2, o0), pq_tab_at(tab, 2, o1) };
-        n = kPqC1 + C2 * y;
-        d = 1.0f + C3 * y;
+        if (AG_PQ_ND_FMA) { n = __builtin_elementwise_fma(C2, y, (f32x2)kPqC1); d = __builtin_elementwise_fma(C3, y, (f32x2)1.0f); }
+        else { n = kPqC1 + C2 * y; d = 1.0f + C3 * y; }
     } else {
         const f32x2 x = y * f32x2{ pq_tab_at(tab, 1, o0), pq_tab_at(tab, 1, o1) };
-        n = kPqC1 + kPqC2 * x;
-        d = 1.0f + kPqC3 * x;
+        if (AG_PQ_ND_FMA) { n = __builtin_elementwise_fma((f32x2)kPqC2, x, (f32x2)kPqC1); d = __builtin_elementwise_fma((f32x2)kPqC3, x, (f32x2)1.0f); }
+        else { n = kPqC1 + kPqC2 * x; d = 1.0f + kPqC3 * x; }
     }
     const f32x2 r = { nat_rcp(d.x), nat_rcp(d.y) };
     const f32x2 q0 = n * r;

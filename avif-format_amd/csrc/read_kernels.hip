@@ -513,6 +513,9 @@ __global__ __launch_bounds__(256) void build_read_tables(const ReadParams p, flo
 #ifndef AG_R8_PIN_MORE
 #define AG_R8_PIN_MORE 1
 #endif
+#ifndef AG_READ_PRIO
+#define AG_READ_PRIO 1
+#endif
 #ifndef AG_READ_PREFETCH
 #define AG_READ_PREFETCH 0
 #endif
@@ -656,6 +659,10 @@ __global__ __launch_bounds__(AG_RPX_BLOCK) void read_px(const ReadParams p)
     // Forcing occupancy with amdgpu_waves_per_eu was measured too: 5 or 6 waves spill the 4:2:0 kernels to 2-3.5x their time.
     // (profiles/r02/read_variants_ab.txt)
     constexpr bool EARLY = CS == kCsMono;
+    // Round 5 (profiles/r05/late_table_fill_and_priority_ab.txt): a wave's instruction priority raised until its first group's loads have left --
+    // Gray8 +5 %, the 4:2:2 -> f32 open +1.5 %; every other open measured 1-2 % slower with it (HLG 4:2:0: -5 %), so only those two
+    constexpr bool PRIO = AG_READ_PRIO && ((CS == kCsMono && DEPTH == 8 && !ALPHA) || (CS == kCsYcc && DEPTH == 32 && XS == 1 && YS == 0 && !ALPHA));
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(3);
     if ((AG_READ_PREFETCH || EARLY) && wv < total_waves) load_group(wv, cur);
     bool loaded = EARLY;
     if constexpr (LUT) {
@@ -677,6 +684,7 @@ __global__ __launch_bounds__(AG_RPX_BLOCK) void read_px(const ReadParams p)
         Group nxt;
         if constexpr (AG_READ_PREFETCH) { if (wv + wstep < total_waves) load_group(wv + wstep, nxt); }   // in flight during the decode below
         else { if (!loaded) load_group(wv, cur); loaded = false; }
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
 
         constexpr bool PACKED8 = AG_R8_PACKED && DEPTH == 8 && CS == kCsYcc && ALIGNED && ND_OUT > 4;
         if constexpr (PACKED8) {

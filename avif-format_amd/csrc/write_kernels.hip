@@ -1484,16 +1484,61 @@ template <bool NT, typename V> AG_DEV void stream_store(V* p, V v)
 #ifndef AG_HOT_PREFETCH
 #define AG_HOT_PREFETCH 0
 #endif
+#ifndef AG_PQ_LATE_FILL
+#define AG_PQ_LATE_FILL 1
+#endif
+// Round 5, the head of the f32 streaming kernels (profiles/r05/late_table_fill_and_priority_ab.txt; fresh data, 4-5 interleaved passes):
+//  * AG_PQ_LATE_FILL: a workgroup used to copy the PQ exponent table to LDS, synchronise, and only then ask for its pixels -- every wave
+//    held its slot empty-handed for an L2 round trip + a barrier.  Now the table's global loads go first, the first span's loads right
+//    behind them, and the table's LDS writes + the barrier (pq_table_barrier: LDS-only fences, no vmcnt(0)) run under the span loads'
+//    flight; the span loop is rotated (the next span's loads at the END of the body) so that the loads need no flag and no second copy.
+//    +0.5-3 % on the three-plane kernels, +3 % on the interleaved hand-off, +3-5 % on the RGBA kernels.
+//  * AG_*_PRIO: s_setprio 3 from the kernel's first instruction until its span loads have left -- a new wave's ~80 scalar instructions
+//    of address arithmetic otherwise queue behind seven waves' worth of curve math.  +1 % on the three-plane kernels (4:4:4, 4:2:2,
+//    the linear-profile 4:4:4), nothing on 4:2:0; -5 % on the profile kernel's interleaved output and -1 % on the RGBA / hand-off kernels:
+//    off there.  The integer kernels (AG_INT_PRIO): RGB16 / RGB8 -> 4:2:2 +1-4 %, RGB8 -> 4:4:4 +2.6 %; 4:2:0 and RGB16 4:4:4 -2-4 %: only
+//    the former carry it.
+#ifndef AG_HOT_PRIO
+#define AG_HOT_PRIO 1
+#endif
+#ifndef AG_SUB_PRIO
+#define AG_SUB_PRIO 1
+#endif
+#ifndef AG_RGBA_PRIO
+#define AG_RGBA_PRIO 0
+#endif
+#ifndef AG_REF_PRIO
+#define AG_REF_PRIO 0
+#endif
+#ifndef AG_INT_PRIO
+#define AG_INT_PRIO 1
+#endif
+// A/B switches of round 5's last experiment (profiles/r05/probe_shapes.txt: the bare pattern runs 4-8 % faster from 64- / 128-thread
+// workgroups and as global_load / global_store than from 256 threads through buffer resources): the workgroup of THIS kernel, and
+// whole spans addressed with 64-bit lane pointers (the ragged last span of a row keeps the buffer form).
+#ifndef AG_HOT444_BLOCK
+#define AG_HOT444_BLOCK AG_F32_STREAM_BLOCK
+#endif
+#ifndef AG_HOT444_GLOBAL
+#define AG_HOT444_GLOBAL 0
+#endif
+constexpr int kHot444Waves = AG_HOT444_BLOCK / 64;
 template <int TRANSFER, int PXL, bool NT>
-__global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_ycbcr444_hot(const WriteParams p)
+__global__ __launch_bounds__(AG_HOT444_BLOCK) void write_rgb32_ycbcr444_hot(const WriteParams p)
 {
-    constexpr int WPB = kF32Waves;
+    constexpr int WPB = kHot444Waves;
     constexpr int K = 3 * PXL / 4;               // float4 per lane per span
     constexpr int SPAN_PX = 64 * PXL;
     constexpr int SPAN_DW = AG_HOT_F32_STRIP ? SpanStrip<K>::kDwords : SPAN_PX * 3 / 2;     // floats (half a span) | packed u16 codes
     constexpr int LDW = 3 * PXL / 2;             // packed dwords per lane after the transpose (packed hand-over)
     __shared__ __attribute__((aligned(16))) uint32_t strip[WPB][SPAN_DW];
-    pq_prologue<TRANSFER>();
+    // (round 5) the PQ table's loads first, the first span's loads right behind them, the table's LDS writes and the barrier under the
+    // span loads' flight -- instead of table, barrier, and only then the first request for pixels
+    constexpr bool LATE = AG_PQ_LATE_FILL && TRANSFER == kTransferPqHi && !AG_HOT_PREFETCH;
+    // AG_HOT_PRIO: a wave's instruction priority raised until its span loads have left (1); 2 = again for its last stage (measured: no gain)
+    if constexpr (AG_HOT_PRIO) __builtin_amdgcn_s_setprio(3);
+    PqTableFill<AG_HOT444_BLOCK> tfill;
+    if constexpr (LATE) tfill.load((int)threadIdx.x); else pq_prologue<TRANSFER>();
 
     const int wave = wave_in_block();
     const int lane = threadIdx.x & 63;
@@ -1517,24 +1562,36 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_ycbcr444_hot(
         const uint32_t r = s / spans_per_row;
         const uint32_t sx = s - r * spans_per_row;
         const int span_px = s < total ? min(SPAN_PX, p.width - (int)sx * SPAN_PX) : 0;
+        if constexpr (AG_HOT444_GLOBAL && !AG_HOT_PREFETCH) {
+            if (span_px == SPAN_PX) {
+                const f32x4* g = reinterpret_cast<const f32x4*>(p.src + (long long)r * p.src_row_bytes + (long long)sx * (SPAN_PX * 12)) + lane;
+#pragma unroll
+                for (int k = 0; k < K; ++k) dst[k] = stream_load<NT>(g + 64 * k);
+                return;
+            }
+        }
         const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)(s < total ? r : 0) * p.src_row_bytes + (long long)(s < total ? sx : 0) * (SPAN_PX * 12), (uint32_t)span_px * 12u);
 #pragma unroll
         for (int k = 0; k < K; ++k) dst[k] = span_load_cached(k, K) ? span_load16<false>(rs, voff, 1024u * k) : span_load16<NT>(rs, voff, 1024u * k);   // a float4 beyond the row: zeros, and nothing is stored for it
     };
     f32x4 nxt[AG_HOT_PREFETCH ? K : 1];
     if constexpr (AG_HOT_PREFETCH) issue(blockIdx.x * WPB + wave, nxt);
+    f32x4 cur[K];
+    if constexpr (!AG_HOT_PREFETCH) issue(blockIdx.x * WPB + wave, cur);           // (a wave beyond the tile: a zero-sized resource, no traffic)
+    if constexpr (AG_HOT_PRIO) __builtin_amdgcn_s_setprio(0);
+    if constexpr (LATE) {
+        tfill.store((int)threadIdx.x);
+        pq_table_barrier();
+    }
     for (uint32_t sidx = blockIdx.x * WPB + wave; sidx < total; sidx += step) {
         const uint32_t r = sidx / spans_per_row;
         const uint32_t sx = sidx - r * spans_per_row;
         const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);             // < SPAN_PX only for the last span of a row
-        f32x4 cur[K];
         if constexpr (AG_HOT_PREFETCH) {
 #pragma unroll
             for (int k = 0; k < K; ++k) cur[k] = nxt[k];
             issue(sidx + step, nxt);
             __builtin_amdgcn_sched_barrier(0);                                     // the next span's loads leave before this span's math starts
-        } else {
-            issue(sidx, cur);
         }
 
         float R[PXL], G[PXL], B[PXL];
@@ -1578,6 +1635,7 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_ycbcr444_hot(
             for (int i = 0; i < PXL; ++i) { R[i] = (float)code(i, 0); G[i] = (float)code(i, 1); B[i] = (float)code(i, 2); }
         }
 
+        if constexpr (AG_HOT_PRIO == 2) __builtin_amdgcn_s_setprio(2);
         uint32_t yv[PXL], cbv[PXL], crv[PXL];
 #pragma unroll
         for (int i = 0; i < PXL; ++i) {
@@ -1600,10 +1658,20 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_ycbcr444_hot(
             u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
             u32x4 b = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16), cbv[4] | (cbv[5] << 16), cbv[6] | (cbv[7] << 16) };
             u32x4 c = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16), crv[4] | (crv[5] << 16), crv[6] | (crv[7] << 16) };
+            if constexpr (AG_HOT444_GLOBAL) {
+                if (span_px == SPAN_PX) {
+                    stream_store<NT>(reinterpret_cast<u32x4*>(const_cast<uint8_t*>(b0)) + lane, a);
+                    stream_store<NT>(reinterpret_cast<u32x4*>(const_cast<uint8_t*>(b1)) + lane, b);
+                    stream_store<NT>(reinterpret_cast<u32x4*>(const_cast<uint8_t*>(b2)) + lane, c);
+                }
+            }
+            if (!(AG_HOT444_GLOBAL && span_px == SPAN_PX)) {
             span_store_samples8<NT>(b0, (uint32_t)span_px, (uint32_t)lane, a);
             span_store_samples8<NT>(b1, (uint32_t)span_px, (uint32_t)lane, b);
             span_store_samples8<NT>(b2, (uint32_t)span_px, (uint32_t)lane, c);
+            }
         }
+        if constexpr (!AG_HOT_PREFETCH) { if (sidx + step < total) issue(sidx + step, cur); }   // (capped grids: the loop's next span)
     }
 }
 
@@ -1623,7 +1691,10 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_ycbcr444_hot(
 template <int TRANSFER, int ICCV, bool OUTREF = false>
 __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444_hot(const WriteParams p)
 {
-    pq_prologue<TRANSFER>();
+    constexpr bool LATE = AG_PQ_LATE_FILL && TRANSFER == kTransferPqHi;            // (round 5: as in write_rgb32_ycbcr444_hot)
+    if constexpr (AG_SUB_PRIO && !OUTREF) __builtin_amdgcn_s_setprio(3);
+    PqTableFill<AG_F32_STREAM_BLOCK> tfill;
+    if constexpr (LATE) tfill.load((int)threadIdx.x); else pq_prologue<TRANSFER>();
     constexpr int PXL = 8, K = 6, SPAN_PX = 512, SPAN_DW = SpanStrip<K>::kDwords;
     static_assert(!OUTREF || SPAN_DW >= WaveSpan<12>::STRIP_DW, "the strip also carries the packed codes back");
     __shared__ __attribute__((aligned(16))) uint32_t strip[kF32Waves][SPAN_DW];
@@ -1642,14 +1713,26 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444
                 m6 = p.icc_m_f[6], m7 = p.icc_m_f[7], m8 = p.icc_m_f[8];
     const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;      // width % 4 == 0 (host)
     const uint32_t total = spans_per_row * (uint32_t)p.nrows;
-    for (uint32_t sidx = blockIdx.x * kF32Waves + wave; sidx < total; sidx += gridDim.x * kF32Waves) {
+    const uint32_t step = gridDim.x * kF32Waves;
+    f32x4 cur[K];
+    auto issue = [&](uint32_t s) {                                                 // a span beyond the tile: a zero-sized resource, no traffic
+        const uint32_t r = s / spans_per_row;
+        const uint32_t sx = s - r * spans_per_row;
+        const int span_px = s < total ? min(SPAN_PX, p.width - (int)sx * SPAN_PX) : 0;
+        const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)(s < total ? r : 0) * p.src_row_bytes + (long long)(s < total ? sx : 0) * (SPAN_PX * 12), (uint32_t)span_px * 12u);
+#pragma unroll
+        for (int k = 0; k < K; ++k) cur[k] = span_load_cached(k, K) ? span_load16<false>(rs, voff, 1024u * k) : span_load16<true>(rs, voff, 1024u * k);
+    };
+    issue(blockIdx.x * kF32Waves + wave);
+    if constexpr (AG_SUB_PRIO && !OUTREF) __builtin_amdgcn_s_setprio(0);
+    if constexpr (LATE) {
+        tfill.store((int)threadIdx.x);
+        pq_table_barrier();
+    }
+    for (uint32_t sidx = blockIdx.x * kF32Waves + wave; sidx < total; sidx += step) {
         const uint32_t r = sidx / spans_per_row;
         const uint32_t sx = sidx - r * spans_per_row;
         const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);
-        const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)r * p.src_row_bytes + (long long)sx * (SPAN_PX * 12), (uint32_t)span_px * 12u);
-        f32x4 cur[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) cur[k] = span_load_cached(k, K) ? span_load16<false>(rs, voff, 1024u * k) : span_load16<true>(rs, voff, 1024u * k);
         if constexpr (ICCV == 2) {                                                 // the document's curve: per sample, the same for R, G, B
             const IccSimple q = icc_simple_load(p);
 #pragma unroll
@@ -1693,15 +1776,16 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444
         }
         if constexpr (OUTREF) {
             wave_span_store<12>(strip[wave], lane, true, pk, p.dst[0] + (long long)r * p.dst_stride[0] + (long long)sx * (SPAN_PX * 6), span_px * 6);
-            continue;
+        } else {
+            const long long xoff = (long long)sx * (SPAN_PX * 2);
+            u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
+            u32x4 bb = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16), cbv[4] | (cbv[5] << 16), cbv[6] | (cbv[7] << 16) };
+            u32x4 cc = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16), crv[4] | (crv[5] << 16), crv[6] | (crv[7] << 16) };
+            span_store_samples8<true>(p.dst[0] + (long long)r * p.dst_stride[0] + xoff, (uint32_t)span_px, (uint32_t)lane, a);
+            span_store_samples8<true>(p.dst[1] + (long long)r * p.dst_stride[1] + xoff, (uint32_t)span_px, (uint32_t)lane, bb);
+            span_store_samples8<true>(p.dst[2] + (long long)r * p.dst_stride[2] + xoff, (uint32_t)span_px, (uint32_t)lane, cc);
         }
-        const long long xoff = (long long)sx * (SPAN_PX * 2);
-        u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
-        u32x4 bb = { cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16), cbv[4] | (cbv[5] << 16), cbv[6] | (cbv[7] << 16) };
-        u32x4 cc = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16), crv[4] | (crv[5] << 16), crv[6] | (crv[7] << 16) };
-        span_store_samples8<true>(p.dst[0] + (long long)r * p.dst_stride[0] + xoff, (uint32_t)span_px, (uint32_t)lane, a);
-        span_store_samples8<true>(p.dst[1] + (long long)r * p.dst_stride[1] + xoff, (uint32_t)span_px, (uint32_t)lane, bb);
-        span_store_samples8<true>(p.dst[2] + (long long)r * p.dst_stride[2] + xoff, (uint32_t)span_px, (uint32_t)lane, cc);
+        if (sidx + step < total) issue(sidx + step);                               // (capped grids: the loop's next span)
     }
 }
 
@@ -1716,7 +1800,11 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444
 template <int TRANSFER, int XS, int YS, int ICCV = 0, bool NEAREST = false>       // ICCV: 0 none, 1 linear-profile matrix, 4 matrix + inverse sRGB curve; NEAREST: p.nearest as a constant (libheif 1.14's chroma rule, the shim's default)
 __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot(const WriteParams p)
 {
-    pq_prologue<TRANSFER>();
+    // (round 5, as in the 4:4:4 kernel) the PQ table's loads, then the first span's, the table's LDS writes + barrier under their flight
+    constexpr bool LATE = AG_PQ_LATE_FILL && TRANSFER == kTransferPqHi;
+    if constexpr (AG_SUB_PRIO) __builtin_amdgcn_s_setprio(3);
+    PqTableFill<AG_F32_STREAM_BLOCK> tfill;
+    if constexpr (LATE) tfill.load((int)threadIdx.x); else pq_prologue<TRANSFER>();
     static_assert(XS == 1, "4:2:2 or 4:2:0");
     constexpr int PXL = 8, K = 6, SPAN_PX = 512, SPAN_DW = SpanStrip<K>::kDwords, VR = 1 << YS;
     constexpr bool ICC1 = ICCV != 0;
@@ -1746,18 +1834,30 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot
     const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;    // host guarantees width % 4 == 0 and alignment
     const uint32_t groups = ((uint32_t)p.nrows + VR - 1) >> YS;
     const uint32_t total = spans_per_row * groups;
-    for (uint32_t sidx = blockIdx.x * kF32Waves + wave; sidx < total; sidx += gridDim.x * kF32Waves) {
-        const uint32_t gy = sidx / spans_per_row;
-        const uint32_t sx = sidx - gy * spans_per_row;
-        f32x4 v[VR][K];
-        const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);             // < SPAN_PX only for the last span of a row
+    const uint32_t step = gridDim.x * kF32Waves;
+    f32x4 v[VR][K];
+    auto issue = [&](uint32_t s) {                                     // both rows' loads in flight before any math; a span beyond the tile: a zero-sized resource
+        const uint32_t gy = s / spans_per_row;
+        const uint32_t sx = s - gy * spans_per_row;
+        const int span_px = s < total ? min(SPAN_PX, p.width - (int)sx * SPAN_PX) : 0;
 #pragma unroll
-        for (int vr = 0; vr < VR; ++vr) {                              // both rows' loads in flight before any math
-            const int r = min((int)(gy * VR) + vr, p.rows_to_end - 1);  // bottom edge: replicate the last IMAGE row
-            const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)r * p.src_row_bytes + (long long)sx * (SPAN_PX * 12), (uint32_t)span_px * 12u);
+        for (int vr = 0; vr < VR; ++vr) {
+            const int r = s < total ? min((int)(gy * VR) + vr, p.rows_to_end - 1) : 0;   // bottom edge: replicate the last IMAGE row
+            const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)r * p.src_row_bytes + (long long)(s < total ? sx : 0) * (SPAN_PX * 12), (uint32_t)span_px * 12u);
 #pragma unroll
             for (int k = 0; k < K; ++k) v[vr][k] = span_load_cached(k, K) ? span_load16<false>(rs, voff, 1024u * k) : span_load16<true>(rs, voff, 1024u * k);   // beyond the row: zeros (see the 4:4:4 kernel)
         }
+    };
+    issue(blockIdx.x * kF32Waves + wave);
+    if constexpr (AG_SUB_PRIO) __builtin_amdgcn_s_setprio(0);
+    if constexpr (LATE) {
+        tfill.store((int)threadIdx.x);
+        pq_table_barrier();
+    }
+    for (uint32_t sidx = blockIdx.x * kF32Waves + wave; sidx < total; sidx += step) {
+        const uint32_t gy = sidx / spans_per_row;
+        const uint32_t sx = sidx - gy * spans_per_row;
+        const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);             // < SPAN_PX only for the last span of a row
         const int nv = span_px - PXL * lane;                           // pixels of this lane inside the row: >= 8, 4 or <= 0 (width % 4 == 0)
         // Round 4: the levels (integer-valued floats, oetf_level2) cross the strip, a row at a time; a row's luma leaves at once and
         // what the chroma samples need of it -- the left pixel of each pair, or the pair's sum (integers below 2^14: exact in any
@@ -1845,6 +1945,7 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot
         u32x2 cr2 = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16) };
         span_store_samples4<true>(p.dst[1] + (long long)gy * p.dst_stride[1] + (long long)sx * SPAN_PX, csamples, (uint32_t)lane, cb2);
         span_store_samples4<true>(p.dst[2] + (long long)gy * p.dst_stride[2] + (long long)sx * SPAN_PX, csamples, (uint32_t)lane, cr2);
+        if (sidx + step < total) issue(sidx + step);                   // (capped grids: the loop's next span)
     }
 }
 
@@ -1915,7 +2016,10 @@ AG_DEV void rgba_levels(const WriteParams& p, f32x4 (&v)[PXL])
 template <int TRANSFER, int ICCV = 0>            // ICCV 1: the linear-profile matrix on R, G, B first (ConvertRow runs before the pixel loop and copies alpha); 4: + inverse sRGB curve
 __global__ __launch_bounds__(AG_RGBA_STREAM_BLOCK) void write_rgba32_ycbcra444_hot(const WriteParams p)
 {
-    pq_prologue<TRANSFER>();
+    constexpr bool LATE = AG_PQ_LATE_FILL && TRANSFER == kTransferPqHi;            // (round 5: as in write_rgb32_ycbcr444_hot)
+    if constexpr (AG_RGBA_PRIO) __builtin_amdgcn_s_setprio(3);
+    PqTableFill<AG_RGBA_STREAM_BLOCK> tfill;
+    if constexpr (LATE) tfill.load((int)threadIdx.x); else pq_prologue<TRANSFER>();
     constexpr int PXL = AG_RGBA_HOT_PXL, SPAN_PX = 64 * PXL;
     __shared__ __attribute__((aligned(16))) uint32_t strip[kRgbaWaves][SpanStrip<PXL>::kDwords];    // half a span of pixels (one float4 each), span_transpose
     const int wave = wave_in_block();
@@ -1925,14 +2029,26 @@ __global__ __launch_bounds__(AG_RGBA_STREAM_BLOCK) void write_rgba32_ycbcra444_h
 
     const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;    // any width: the last span of a row is masked
     const uint32_t total = spans_per_row * (uint32_t)p.nrows;
-    for (uint32_t sidx = blockIdx.x * kRgbaWaves + wave; sidx < total; sidx += gridDim.x * kRgbaWaves) {
+    const uint32_t step = gridDim.x * kRgbaWaves;
+    f32x4 v[PXL];
+    auto issue = [&](uint32_t s) {                                                 // a span beyond the tile: a zero-sized resource, no traffic
+        const uint32_t r = s / spans_per_row;
+        const uint32_t sx = s - r * spans_per_row;
+        const int span_px = s < total ? min(SPAN_PX, p.width - (int)sx * SPAN_PX) : 0;
+        const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)(s < total ? r : 0) * p.src_row_bytes + (long long)(s < total ? sx : 0) * (SPAN_PX * 16), (uint32_t)span_px * 16u);
+#pragma unroll
+        for (int k = 0; k < PXL; ++k) v[k] = span_load16<true>(rs, voff, 1024u * k);       // a pixel beyond the row: zeros, and nothing is stored for it
+    };
+    issue(blockIdx.x * kRgbaWaves + wave);
+    if constexpr (AG_RGBA_PRIO) __builtin_amdgcn_s_setprio(0);
+    if constexpr (LATE) {
+        tfill.store((int)threadIdx.x);
+        pq_table_barrier();
+    }
+    for (uint32_t sidx = blockIdx.x * kRgbaWaves + wave; sidx < total; sidx += step) {
         const uint32_t r = sidx / spans_per_row;
         const uint32_t sx = sidx - r * spans_per_row;
         const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);
-        const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)r * p.src_row_bytes + (long long)sx * (SPAN_PX * 16), (uint32_t)span_px * 16u);
-        f32x4 v[PXL];
-#pragma unroll
-        for (int k = 0; k < PXL; ++k) v[k] = span_load16<true>(rs, voff, 1024u * k);       // a pixel beyond the row: zeros, and nothing is stored for it
         rgba_levels<TRANSFER, ICCV, PXL>(p, v);
         float c[4 * PXL];
         span_transpose<PXL>(my, lane, v, c);                                       // lane l now holds pixels [PXL l, PXL l + PXL)
@@ -1969,6 +2085,7 @@ __global__ __launch_bounds__(AG_RGBA_STREAM_BLOCK) void write_rgba32_ycbcra444_h
                 for (int i = 0; i < PXL; ++i) if (i < nv) dst[i] = (uint16_t)q[i];   // the one ragged lane of a row
             }
         }
+        if (sidx + step < total) issue(sidx + step);                               // (capped grids: the loop's next span)
     }
 }
 
@@ -1979,7 +2096,10 @@ __global__ __launch_bounds__(AG_RGBA_STREAM_BLOCK) void write_rgba32_ycbcra444_h
 template <int TRANSFER, int YS, bool NEAREST>
 __global__ __launch_bounds__(AG_RGBA_STREAM_BLOCK) void write_rgba32_ycbcra_sub_hot(const WriteParams p)
 {
-    pq_prologue<TRANSFER>();
+    constexpr bool LATE = AG_PQ_LATE_FILL && TRANSFER == kTransferPqHi;            // (round 5: as in write_rgb32_ycbcr444_hot)
+    if constexpr (AG_RGBA_PRIO) __builtin_amdgcn_s_setprio(3);
+    PqTableFill<AG_RGBA_STREAM_BLOCK> tfill;
+    if constexpr (LATE) tfill.load((int)threadIdx.x); else pq_prologue<TRANSFER>();
     constexpr int PXL = 4, SPAN_PX = 64 * PXL, VR = 1 << YS;
     __shared__ __attribute__((aligned(16))) uint32_t strip[kRgbaWaves][SpanStrip<PXL>::kDwords];
     const int wave = wave_in_block();
@@ -1989,19 +2109,31 @@ __global__ __launch_bounds__(AG_RGBA_STREAM_BLOCK) void write_rgba32_ycbcra_sub_
     const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;
     const uint32_t groups = ((uint32_t)p.nrows + VR - 1) >> YS;
     const uint32_t total = spans_per_row * groups;
-    for (uint32_t sidx = blockIdx.x * kRgbaWaves + wave; sidx < total; sidx += gridDim.x * kRgbaWaves) {
+    const uint32_t step = gridDim.x * kRgbaWaves;
+    f32x4 v[VR][PXL];
+    auto issue = [&](uint32_t s) {                                     // both rows' loads in flight before any math; a span beyond the tile: a zero-sized resource
+        const uint32_t gy = s / spans_per_row;
+        const uint32_t sx = s - gy * spans_per_row;
+        const int span_px = s < total ? min(SPAN_PX, p.width - (int)sx * SPAN_PX) : 0;
+#pragma unroll
+        for (int vr = 0; vr < VR; ++vr) {
+            const int r = s < total ? min((int)(gy * VR) + vr, p.rows_to_end - 1) : 0;   // bottom edge: replicate the last IMAGE row
+            const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)r * p.src_row_bytes + (long long)(s < total ? sx : 0) * (SPAN_PX * 16), (uint32_t)span_px * 16u);
+#pragma unroll
+            for (int k = 0; k < PXL; ++k) v[vr][k] = span_load16<true>(rs, voff, 1024u * k);
+        }
+    };
+    issue(blockIdx.x * kRgbaWaves + wave);
+    if constexpr (AG_RGBA_PRIO) __builtin_amdgcn_s_setprio(0);
+    if constexpr (LATE) {
+        tfill.store((int)threadIdx.x);
+        pq_table_barrier();
+    }
+    for (uint32_t sidx = blockIdx.x * kRgbaWaves + wave; sidx < total; sidx += step) {
         const uint32_t gy = sidx / spans_per_row;
         const uint32_t sx = sidx - gy * spans_per_row;
         const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);
         const int nv = span_px - PXL * lane;
-        f32x4 v[VR][PXL];
-#pragma unroll
-        for (int vr = 0; vr < VR; ++vr) {                              // both rows' loads in flight before any math
-            const int r = min((int)(gy * VR) + vr, p.rows_to_end - 1);  // bottom edge: replicate the last IMAGE row
-            const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)r * p.src_row_bytes + (long long)sx * (SPAN_PX * 16), (uint32_t)span_px * 16u);
-#pragma unroll
-            for (int k = 0; k < PXL; ++k) v[vr][k] = span_load16<true>(rs, voff, 1024u * k);
-        }
         float acc[2][3];
 #pragma unroll
         for (int vr = 0; vr < VR; ++vr) {
@@ -2059,6 +2191,7 @@ __global__ __launch_bounds__(AG_RGBA_STREAM_BLOCK) void write_rgba32_ycbcra_sub_
             __builtin_amdgcn_raw_buffer_store_b16((short)cbv[0], span_rsrc(bcb, cbytes), (int)((cs - 1u) * 2u), 0, 2);
             __builtin_amdgcn_raw_buffer_store_b16((short)crv[0], span_rsrc(bcr, cbytes), (int)((cs - 1u) * 2u), 0, 2);
         }
+        if (sidx + step < total) issue(sidx + step);                   // (capped grids: the loop's next span)
     }
 }
 
@@ -2163,6 +2296,7 @@ template <int YS, bool TO8 = false>
 __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr_sub_hot(const WriteParams p)
 {
     constexpr int PXL = 8, K = 3, SPAN_PX = 512, SPAN_DW = SPAN_PX * 3 / 2, LDW = 12, VR = 1 << YS;
+    if constexpr (AG_INT_PRIO && YS == 0) __builtin_amdgcn_s_setprio(3);      // (4:2:2: +1-4 %; 4:2:0 and 4:4:4: -2-4 %, profiles/r05/late_table_fill_and_priority_ab.txt)
     __shared__ __attribute__((aligned(16))) uint32_t strip[kStreamWaves][SPAN_DW];
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -2183,6 +2317,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr_sub_hot(con
 #pragma unroll
             for (int k = 0; k < K; ++k) v[vr][k] = g_load_nt(sp + min(64 * k + lane, span_v - 1));
         }
+        if constexpr (AG_INT_PRIO && YS == 0) __builtin_amdgcn_s_setprio(0);
         uint32_t dw[VR][LDW];
 #pragma unroll
         for (int vr = 0; vr < VR; ++vr) {
@@ -2352,6 +2487,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra444_hot(co
 template <int XS, int YS, bool NEAREST, int kRgb8Waves>
 __global__ __launch_bounds__(64 * kRgb8Waves) void write_rgb8_ycbcr_hot(const WriteParams p)
 {
+    if constexpr (AG_INT_PRIO && YS == 0) __builtin_amdgcn_s_setprio(3);      // (4:2:2 and 4:4:4: +1-3 %; 4:2:0: -2-4 %)
     constexpr int PXL = 16, K = 3, SPAN_PX = 64 * PXL, VR = 1 << YS, NC = PXL >> XS, NDB = 12;
     __shared__ __attribute__((aligned(16))) uint32_t strip[kRgb8Waves][64 * NDB];
     const int wave = wave_in_block();
@@ -2373,6 +2509,7 @@ __global__ __launch_bounds__(64 * kRgb8Waves) void write_rgb8_ycbcr_hot(const Wr
 #pragma unroll
             for (int k = 0; k < K; ++k) v[vr][k] = (AG_RGB8_FIRST_CACHED && k == 0) ? span_load16<false>(rs, voff, 1024u * k) : span_load16<true>(rs, voff, 1024u * k);
         }
+        if constexpr (AG_INT_PRIO && YS == 0) __builtin_amdgcn_s_setprio(0);
         uint32_t raw[VR][NDB];
 #pragma unroll
         for (int vr = 0; vr < VR; ++vr) {
@@ -2623,26 +2760,42 @@ __global__ __launch_bounds__(256) void write_rgba8_ycbcra_hot(const WriteParams 
 template <int TRANSFER, int PLANES>
 __global__ __launch_bounds__(AG_F32_REF_BLOCK) void write_f32_ref_stream(const WriteParams p)
 {
-    pq_prologue<TRANSFER>();
+    constexpr bool LATE = AG_PQ_LATE_FILL && TRANSFER == kTransferPqHi;            // (round 5: as in write_rgb32_ycbcr444_hot)
+    if constexpr (AG_REF_PRIO) __builtin_amdgcn_s_setprio(3);
+    PqTableFill<AG_F32_REF_BLOCK> tfill;
+    if constexpr (LATE) tfill.load((int)threadIdx.x); else pq_prologue<TRANSFER>();
     constexpr int K = 4;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = wave_in_block();                                  // (a scalar: the row's buffer resource lives in SGPRs)
     const uint32_t n4 = (uint32_t)p.width * PLANES / 4;                // float4 per row (host: width * PLANES % 4 == 0)
     const uint32_t chunks = (n4 + 64 * K - 1) / (64 * K);
     const uint32_t total = chunks * (uint32_t)p.nrows;
-    for (uint32_t widx = blockIdx.x * kF32RefWaves + wave; widx < total; widx += gridDim.x * kF32RefWaves) {
+    const uint32_t step = gridDim.x * kF32RefWaves;
+    f32x4 v[K];
+    // the row as a buffer resource (round 5; 64-bit lane pointers under a per-load test until then -- which, once the loads stood in front
+    // of the table's barrier, the compiler serialised with a vmcnt(0) inside every branch): a float4 beyond the row reads zeros, a chunk
+    // beyond the tile gets a zero-sized resource, and no load is conditional
+    auto issue = [&](uint32_t w) {
+        const uint32_t r = w / chunks;
+        const uint32_t c = w - r * chunks;
+        const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)(w < total ? r : 0) * p.src_row_bytes, w < total ? n4 * 16u : 0u);
+        const uint32_t vo = (c * (64 * K) + (uint32_t)lane) * 16u;
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = span_load16<true>(rs, vo, 1024u * k);
+    };
+    issue(blockIdx.x * kF32RefWaves + wave);
+    if constexpr (AG_REF_PRIO) __builtin_amdgcn_s_setprio(0);
+    if constexpr (LATE) {
+        tfill.store((int)threadIdx.x);
+        pq_table_barrier();
+    }
+    for (uint32_t widx = blockIdx.x * kF32RefWaves + wave; widx < total; widx += step) {
         const uint32_t r = widx / chunks;
         const uint32_t c = widx - r * chunks;
-        const f32x4* sp = reinterpret_cast<const f32x4*>(p.src + (long long)r * p.src_row_bytes);
         u32x2* dp = reinterpret_cast<u32x2*>(p.dst[0] + (long long)r * p.dst_stride[0]);
-        f32x4 v[K];
         uint32_t idx[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            idx[k] = c * (64 * K) + 64 * k + lane;
-            v[k] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };                                // beyond the row: nothing loaded, nothing stored, arithmetic defined
-            if (idx[k] < n4) v[k] = stream_load<true>(sp + idx[k]);
-        }
+        for (int k = 0; k < K; ++k) idx[k] = c * (64 * K) + 64 * k + lane;
 #pragma unroll
         for (int k = 0; k < K; k += 2) {                                           // two float4 at a time: sample pairs for the packed curve
             float t[8];
@@ -2676,6 +2829,7 @@ __global__ __launch_bounds__(AG_F32_REF_BLOCK) void write_f32_ref_stream(const W
                 stream_store<true>(dp + idx[k + h], o);
             }
         }
+        if (widx + step < total) issue(widx + step);                               // (capped grids: the loop's next chunk)
     }
 }
 
@@ -3360,7 +3514,7 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
             const long long spans = (long long)((p.width + span_px - 1) / span_px) * p.nrows;
             if (spans == 0) return hipSuccess;
             if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
-            constexpr int WPB = kF32Waves;
+            constexpr int WPB = kHot444Waves;
             long long blocks = (spans + WPB - 1) / WPB;
             const long long cap = (variant >> 8) ? (variant >> 8) : 256LL * 512 * 4 / WPB;   // 8192^2: one span per wave measured 5-6 % faster than two
             if (blocks > cap) blocks = cap;
@@ -3368,7 +3522,7 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
             // measuring knob (not a tuning word of the product): AVIFGPU_DEBUG_LDS_PAD = bytes of unused dynamic LDS per workgroup, i.e. fewer
             // resident workgroups per CU -- how the kernel's rate depends on the number of waves per SIMD (profiles/r05/occupancy_sweep_444.txt)
             static const size_t lds_pad = [] { const char* e = getenv("AVIFGPU_DEBUG_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
-#define AG_HOT3(TR, PX, NT_) hipLaunchKernelGGL((write_rgb32_ycbcr444_hot<TR, PX, NT_>), dim3((int)blocks), dim3(AG_F32_STREAM_BLOCK), lds_pad, st, p)
+#define AG_HOT3(TR, PX, NT_) hipLaunchKernelGGL((write_rgb32_ycbcr444_hot<TR, PX, NT_>), dim3((int)blocks), dim3(AG_HOT444_BLOCK), lds_pad, st, p)
 #define AG_HOT2(TR, PX) do { if (nt) AG_HOT3(TR, PX, true); else AG_HOT3(TR, PX, false); } while (0)
 #define AG_HOT1(TR) do { if (px8) AG_HOT2(TR, 8); else AG_HOT2(TR, 4); } while (0)
             switch (p.transfer) {

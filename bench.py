@@ -25,7 +25,9 @@ figure is kept beside the claimed one as `roofline.frac_same_buffers` (untimed d
 Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per launch (18 B/px: 12 in + 6 out,
 SURVEY.md 8d) / mean kernel time from HIP events recorded on the launch stream around the K rotating launches; `roofline.peak` =
 the 8 TB/s spec, `roofline.peak_measured` = what the kernel's MATH-FREE twin (same loads and stores with the same cache policy, no
-conversion) reaches over the same rotating sets in the same process, `frac_of_measured` = achieved / that; `read_only_frac` is the north-star's literal "HBM-read" figure (input bytes
+conversion) reaches over the same rotating sets in the same process IN THE FASTEST OF SIX LAUNCH SHAPES (workgroups of 4 / 2 / 1 waves,
+buffer or 64-bit global addressing: `pattern_shapes_ms`; the kernel's own shape is the slowest of them, so round 1-4's figure --
+kept as `frac_of_twin_in_kernel_shape` -- flattered the kernel), `frac_of_measured` = achieved / that; `read_only_frac` is the north-star's literal "HBM-read" figure (input bytes
 only), bounded by 12/18 for 4:4:4 output -- `frac` is the one that is claimed.  `roofline.traffic` = HBM bytes per launch from
 the PMC counters, measured in THIS run at N = 1 by two child `rocprofv3 --pmc` passes over the same kernel (measure_traffic_live;
 about 25 s; --no-live-traffic or a missing rocprofv3 falls back to the committed profiles/traffic.json, and the line says which).
@@ -354,18 +356,34 @@ def main():
             rc = lib.avifgpu_probe_pattern_rgb32_444(sp, src.stride(0) * 4, ctypes.byref(pj), ctypes.byref(ss), W, nrows, stream.cuda_stream)
             if rc:
                 raise RuntimeError(lib.avifgpu_last_error().decode())
+        # Round 5: the pattern in SIX launch shapes -- workgroups of 4 / 2 / 1 waves, buffer or 64-bit global addressing (AVIFGPU_PROBE_WAVES /
+        # _GLOBAL, read by the probe on every call).  The kernel's own shape (4 waves, buffer form) is the slowest of them on every box
+        # measured (profiles/r05/probe_shapes_and_kernel_shapes.txt); the ceiling the kernel is priced against is the FASTEST.
         try:
-            for _ in range(20):
-                probe()
-            torch.cuda.synchronize(dev)
-            p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             np_ = max(20, min(args.steps, 200))
-            p0.record(stream)
-            for _ in range(np_):
-                probe()
-            p1.record(stream)
-            torch.cuda.synchronize(dev)
-            pattern = {"launches": np_, "kernel_ms_mean": round(p0.elapsed_time(p1) / np_, 5)}
+            shapes = {}
+            saved = {k: os.environ.get(k) for k in ("AVIFGPU_PROBE_WAVES", "AVIFGPU_PROBE_GLOBAL")}
+            for glob in (0, 1):
+                for waves in (4, 2, 1):
+                    os.environ["AVIFGPU_PROBE_WAVES"], os.environ["AVIFGPU_PROBE_GLOBAL"] = str(waves), str(glob)
+                    for _ in range(20):
+                        probe()
+                    torch.cuda.synchronize(dev)
+                    p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    p0.record(stream)
+                    for _ in range(np_):
+                        probe()
+                    p1.record(stream)
+                    torch.cuda.synchronize(dev)
+                    shapes["%d waves, %s" % (waves, "global" if glob else "buffer")] = round(p0.elapsed_time(p1) / np_, 5)
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+            best = min(shapes, key=shapes.get)
+            pattern = {"launches": np_, "kernel_ms_mean": shapes[best], "shape": best, "shapes_ms": shapes,
+                       "kernel_shape_ms": shapes["4 waves, buffer"]}
             for _ in range(len(sets)):              # the planes hold pixels again (the probe stores a checksum)
                 step()
             torch.cuda.synchronize(dev)
@@ -441,8 +459,11 @@ def main():
         peak_measured = algo_bytes / (pattern["kernel_ms_mean"] / 1e3) / 1e9
         out["roofline"]["peak_measured"] = round(peak_measured, 1)
         out["roofline"]["frac_of_measured"] = round(achieved / peak_measured, 4)
-        out["roofline"]["peak_measured_source"] = (f"math-free twin of the kernel (same accesses, no conversion; avifgpu_probe_pattern_rgb32_444), "
-                                                   f"{pattern['launches']} back-to-back launches over the same {len(sets)} rotating sets in this process, {pattern['kernel_ms_mean']} ms each")
+        out["roofline"]["peak_measured_source"] = (f"math-free twin of the kernel (same accesses, no conversion; avifgpu_probe_pattern_rgb32_444) in its FASTEST of six launch "
+                                                   f"shapes ({pattern['shape']}), {pattern['launches']} back-to-back launches over the same {len(sets)} rotating sets in this process, "
+                                                   f"{pattern['kernel_ms_mean']} ms each")
+        out["roofline"]["pattern_shapes_ms"] = pattern["shapes_ms"]
+        out["roofline"]["frac_of_twin_in_kernel_shape"] = round(pattern["kernel_shape_ms"] / (mean_kernel_s * 1e3), 4)   # (round 1-4's frac_of_measured: 4 waves, buffer form)
     elif pattern:
         out["roofline"]["peak_measured"] = None
         out["roofline"]["peak_measured_source"] = "probe failed: " + pattern.get("error", "?")

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round 5: A/B of bench_configs rows over library builds on FRESH data (rotating buffer sets), interleaved twice on one box:
-#   ONLY="pat|pat" [SAME=1] tools/gpu/ab_fresh.sh name1 name2 ...     (avif-format_amd/variants/libavifgpu_<name>.so; "tree" = this tree's)
+#   ONLY="pat|pat" [SAME=1] [REPS=n] tools/gpu/ab_fresh.sh name1 name2 ...     (avif-format_amd/variants/libavifgpu_<name>.so; "tree" = this tree's)
 IFS="|" read -ra pats <<< "${ONLY:-C4 8192}"
 export BENCH_TWIN=0 BENCH_SAME=${SAME:-0}
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
 for v in "$@"; do
   lib=$PWD/avif-format_amd/variants/libavifgpu_$v.so
   [ "$v" = tree ] && lib=$PWD/avif-format_amd/libavifgpu.so
