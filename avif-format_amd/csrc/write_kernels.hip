@@ -1536,7 +1536,8 @@ __global__ __launch_bounds__(AG_HOT444_BLOCK) void write_rgb32_ycbcr444_hot(cons
     // span loads' flight -- instead of table, barrier, and only then the first request for pixels
     constexpr bool LATE = AG_PQ_LATE_FILL && TRANSFER == kTransferPqHi && !AG_HOT_PREFETCH;
     // AG_HOT_PRIO: a wave's instruction priority raised until its span loads have left (1); 2 = again for its last stage (measured: no gain)
-    if constexpr (AG_HOT_PRIO) __builtin_amdgcn_s_setprio(3);
+    constexpr bool PRIO = AG_HOT_PRIO && TRANSFER == kTransferPqHi;    // (the compact PQ form measured 1.5 % SLOWER with it: only the default form carries it)
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(3);
     PqTableFill<AG_HOT444_BLOCK> tfill;
     if constexpr (LATE) tfill.load((int)threadIdx.x); else pq_prologue<TRANSFER>();
 
@@ -1578,7 +1579,7 @@ __global__ __launch_bounds__(AG_HOT444_BLOCK) void write_rgb32_ycbcr444_hot(cons
     if constexpr (AG_HOT_PREFETCH) issue(blockIdx.x * WPB + wave, nxt);
     f32x4 cur[K];
     if constexpr (!AG_HOT_PREFETCH) issue(blockIdx.x * WPB + wave, cur);           // (a wave beyond the tile: a zero-sized resource, no traffic)
-    if constexpr (AG_HOT_PRIO) __builtin_amdgcn_s_setprio(0);
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     if constexpr (LATE) {
         tfill.store((int)threadIdx.x);
         pq_table_barrier();
