@@ -2813,6 +2813,9 @@ __global__ __launch_bounds__(AG_F32_REF_BLOCK) void write_f32_ref_stream(const W
                     }
                     ca[h] = (uint32_t)__builtin_amdgcn_fmed3f(a * p.maxf, 0.0f, p.maxf);   // :1096
                 }
+                if constexpr (PLANES == 1) {                                        // gray, no alpha: clamped to [0, 1] in front of the curve (:602), unlike RGB
+                    s0 = cxx_clamp(s0, 0.0f, 1.0f); s1 = cxx_clamp(s1, 0.0f, 1.0f); s2 = cxx_clamp(s2, 0.0f, 1.0f); s3 = cxx_clamp(s3, 0.0f, 1.0f);
+                }
                 t[4 * h] = s0; t[4 * h + 1] = s1; t[4 * h + 2] = s2; t[4 * h + 3] = s3;
             }
             if constexpr (PLANES == 4) {
@@ -2828,6 +2831,73 @@ __global__ __launch_bounds__(AG_F32_REF_BLOCK) void write_f32_ref_stream(const W
                 if (idx[k + h] >= n4) continue;
                 u32x2 o = { q[4 * h] | (q[4 * h + 1] << 16), q[4 * h + 2] | (q[4 * h + 3] << 16) };
                 stream_store<true>(dp + idx[k + h], o);
+            }
+        }
+        if (widx + step < total) issue(widx + step);                               // (capped grids: the loop's next chunk)
+    }
+}
+
+// ---- Gray + alpha (16-bit and f32 documents) -> Y and Alpha u16 planes (round 5, last series) ----------------------------------------------
+// A gray document with transparency is two interleaved samples per pixel and two planes out (WriteHeifImage.cpp:181-252 / :540-620): no
+// transposition either -- a lane's 16-byte vector holds 4 (u16) or 2 (f32) whole pixels, stage A (stage_a itself: the generic kernel's
+// function, so the codes are its codes) runs per pixel, and the lane stores its pixels' Y codes and alpha codes at the same pixel
+// index of the two planes: 8 or 4 contiguous bytes per lane and plane, contiguous across the wave.  The row is a buffer resource
+// (no conditional load; a vector beyond the row reads zeros and its stores are clipped).  The generic kernel ran these at 0.70 of 8 TB/s.
+template <int DEPTH, int TRANSFER>
+__global__ __launch_bounds__(AG_F32_REF_BLOCK) void write_ga_stream(const WriteParams p)
+{
+    static_assert(DEPTH == 16 || DEPTH == 32, "u16 or f32 samples");
+    constexpr bool LATE = AG_PQ_LATE_FILL && DEPTH == 32 && TRANSFER == kTransferPqHi;
+    PqTableFill<AG_F32_REF_BLOCK> tfill;
+    if constexpr (LATE) tfill.load((int)threadIdx.x); else if constexpr (DEPTH == 32) pq_prologue<TRANSFER>();
+    constexpr int K = 4;
+    constexpr int PXV = DEPTH == 16 ? 4 : 2;                            // pixels per 16-byte vector
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_in_block();
+    const uint32_t nv = (uint32_t)p.width / PXV;                        // vectors per row (host: width % PXV == 0)
+    const uint32_t chunks = (nv + 64 * K - 1) / (64 * K);
+    const uint32_t total = chunks * (uint32_t)p.nrows;
+    const uint32_t step = gridDim.x * kF32RefWaves;
+    f32x4 v[K];
+    auto issue = [&](uint32_t w) {
+        const uint32_t r = w / chunks;
+        const uint32_t c = w - r * chunks;
+        const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)(w < total ? r : 0) * p.src_row_bytes, w < total ? nv * 16u : 0u);
+        const uint32_t vo = (c * (64 * K) + (uint32_t)lane) * 16u;
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = span_load16<true>(rs, vo, 1024u * k);
+    };
+    issue(blockIdx.x * kF32RefWaves + wave);
+    if constexpr (LATE) {
+        tfill.store((int)threadIdx.x);
+        pq_table_barrier();
+    }
+    for (uint32_t widx = blockIdx.x * kF32RefWaves + wave; widx < total; widx += step) {
+        const uint32_t r = widx / chunks;
+        const uint32_t c = widx - r * chunks;
+        const uint32_t row_bytes = (uint32_t)p.width * 2u;             // of a u16 plane row
+        const __amdgpu_buffer_rsrc_t ry = span_rsrc(p.dst[0] + (long long)r * p.dst_stride[0], row_bytes);
+        const __amdgpu_buffer_rsrc_t ra = span_rsrc(p.dst[3] + (long long)r * p.dst_stride[3], row_bytes);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t idx = c * (64 * K) + 64 * k + (uint32_t)lane;          // vector index in the row
+            const u32x4 in = __builtin_bit_cast(u32x4, v[k]);
+            const uint32_t w4[4] = { in.x, in.y, in.z, in.w };
+            uint32_t yq[PXV], aq[PXV];
+#pragma unroll
+            for (int i = 0; i < PXV; ++i) {
+                uint32_t sm[2], q[4];
+                if constexpr (DEPTH == 16) { sm[0] = w4[i] & 0xffffu; sm[1] = w4[i] >> 16; }
+                else { sm[0] = w4[2 * i]; sm[1] = w4[2 * i + 1]; }
+                stage_a<DEPTH, 2, TRANSFER>(p, sm, q);
+                yq[i] = q[0]; aq[i] = q[3];
+            }
+            if constexpr (DEPTH == 16) {
+                span_store8<true>(ry, idx * 8u, u32x2{ yq[0] | (yq[1] << 16), yq[2] | (yq[3] << 16) });
+                span_store8<true>(ra, idx * 8u, u32x2{ aq[0] | (aq[1] << 16), aq[2] | (aq[3] << 16) });
+            } else {
+                span_store4<true>(ry, idx * 4u, yq[0] | (yq[1] << 16));
+                span_store4<true>(ra, idx * 4u, aq[0] | (aq[1] << 16));
             }
         }
         if (widx + step < total) issue(widx + step);                               // (capped grids: the loop's next chunk)
@@ -3148,7 +3218,8 @@ hipError_t launch_stream_f32_sub_rgba(const WriteParams& p, int depth, int plane
 hipError_t launch_stream_int(const WriteParams& p, int depth, int planes, bool dst16, int output, int xs, int ys, int variant, hipStream_t st, char* label, bool* taken)
 {
     *taken = true;
-    if ((variant & 1) && p.icc16_clut == nullptr && p.icc8_s1 == nullptr && (depth == 16 || (AG_IREF8 && depth == 8 && planes == 4)) && planes >= 3 && output == AVIFGPU_OUT_REFERENCE &&
+    if ((variant & 1) && p.icc16_clut == nullptr && p.icc8_s1 == nullptr && (depth == 16 || (AG_IREF8 && depth == 8 && planes == 4)) &&
+        ((planes >= 3 && output == AVIFGPU_OUT_REFERENCE) || (planes == 1 && depth == 16)) &&      // (Gray16 -> Y plane: elementwise too, round 5)
         ((long long)p.width * planes * (depth / 8)) % 16 == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | (uintptr_t)p.dst_stride[0]) & 15) == 0) {
         const long long nv = (long long)p.width * planes * (depth / 8) / 16;
@@ -3161,8 +3232,21 @@ hipError_t launch_stream_int(const WriteParams& p, int depth, int planes, bool d
 #define AG_IREF(D, P) do { if (dst16) hipLaunchKernelGGL((write_int_ref_stream<D, P, true>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); \
                            else hipLaunchKernelGGL((write_int_ref_stream<D, P, false>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); } while (0)
             if (depth == 8) AG_IREF(8, 4);
-            else { if (planes == 4) AG_IREF(16, 4); else AG_IREF(16, 3); }
+            else { if (planes == 4) AG_IREF(16, 4); else if (planes == 1) AG_IREF(16, 1); else AG_IREF(16, 3); }
 #undef AG_IREF
+            return hipGetLastError();
+        }
+    }
+    // Gray16 + alpha -> Y and Alpha u16 planes (round 5): widths of whole 4-pixel vectors, dword-aligned rows and planes
+    if (depth == 16 && (p.width % 4) == 0 && (variant & 1) && planes == 2 && dst16 && p.dst[3] != nullptr && (p.src_row_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[3]) | (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[3]) & 3) == 0) {
+        const long long waves = (((long long)p.width / 4 + 255) / 256) * p.nrows;
+        if (waves == 0) return hipSuccess;
+        if (waves + 8LL * 65536 * 4 < 0x7fffffffLL) {
+            long long blocks = (waves + kF32RefWaves - 1) / kF32RefWaves;
+            if (blocks > AG_STREAM_BLOCK_CAP * 4 / kF32RefWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kF32RefWaves;
+            snprintf(label, kLabelBytes, "write_ga_stream<depth=16>");
+            hipLaunchKernelGGL((write_ga_stream<16, AVIFGPU_TRANSFER_CLIP>), dim3((int)blocks), dim3(AG_F32_REF_BLOCK), 0, st, p);
             return hipGetLastError();
         }
     }
@@ -3276,6 +3360,24 @@ hipError_t launch_stream_int(const WriteParams& p, int depth, int planes, bool d
 hipError_t launch_stream_f32_sub_rgba(const WriteParams& p, int depth, int planes, bool dst16, int output, int xs, int ys, int variant, hipStream_t st, char* label, bool* taken)
 {
     *taken = true;
+    // Gray32 + alpha -> Y and Alpha u16 planes (round 5): even widths, dword-aligned rows and planes
+    if (depth == 32 && (p.width % 2) == 0 && (variant & 1) && planes == 2 && dst16 && p.dst[3] != nullptr && (p.src_row_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[3]) | (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[3]) & 3) == 0) {
+        const long long waves = (((long long)p.width / 2 + 255) / 256) * p.nrows;
+        if (waves == 0) return hipSuccess;
+        if (waves + 8LL * 65536 * 4 < 0x7fffffffLL) {
+            long long blocks = (waves + kF32RefWaves - 1) / kF32RefWaves;
+            if (blocks > AG_STREAM_BLOCK_CAP * 4 / kF32RefWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kF32RefWaves;
+            snprintf(label, kLabelBytes, "write_ga_stream<depth=32,transfer=%d>", p.transfer);
+            if (p.transfer == AVIFGPU_TRANSFER_PQ) {
+                if (pq_hi_launch(p)) hipLaunchKernelGGL((write_ga_stream<32, kTransferPqHi>), dim3((int)blocks), dim3(AG_F32_REF_BLOCK), 0, st, p);
+                else hipLaunchKernelGGL((write_ga_stream<32, AVIFGPU_TRANSFER_PQ>), dim3((int)blocks), dim3(AG_F32_REF_BLOCK), 0, st, p);
+            } else {
+                hipLaunchKernelGGL((write_ga_stream<32, AVIFGPU_TRANSFER_CLIP>), dim3((int)blocks), dim3(AG_F32_REF_BLOCK), 0, st, p);   // (gray saves: PQ or Clip, avifgpu_api.hip)
+            }
+            return hipGetLastError();
+        }
+    }
 // RGBA f32 -> Y, Cb, Cr (4:2:2 / 4:2:0), A: the plug-in's default save of a transparent 32-bit document (no ICC variant: those stay generic)
     if ((variant & 1) && p.icc_trc_type[0] == 0 && p.icc_s_tab == nullptr && depth == 32 && planes == 4 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 1 &&
         (p.src_row_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 3) == 0 && p.dst[3] != nullptr &&
@@ -3454,7 +3556,9 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
             }
         }
     }
-    if ((variant & 1) && p.icc_trc_type[0] == 0 && depth == 32 && planes >= 3 && dst16 && output == AVIFGPU_OUT_REFERENCE &&
+    // (round 5) ... and Gray32 -> Y plane: a gray document without alpha IS its Y plane sample for sample (WriteHeifImage.cpp:181-252), the same
+    // elementwise kernel with one sample per pixel (0.62 of 8 TB/s on the generic kernel)
+    if ((variant & 1) && p.icc_trc_type[0] == 0 && depth == 32 && ((planes >= 3 && output == AVIFGPU_OUT_REFERENCE) || planes == 1) && dst16 &&
         ((long long)p.width * planes) % 4 == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | (uintptr_t)p.dst_stride[0]) & 7) == 0) {
         const long long n4 = (long long)p.width * planes / 4;
@@ -3465,6 +3569,7 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
             if (blocks > AG_STREAM_BLOCK_CAP * 4 / kF32RefWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kF32RefWaves;
             snprintf(label, kLabelBytes, "write_f32_ref_stream<transfer=%d,planes=%d>", p.transfer, planes);
 #define AG_REF(TR) do { if (planes == 4) hipLaunchKernelGGL((write_f32_ref_stream<TR, 4>), dim3((int)blocks), dim3(AG_F32_REF_BLOCK), 0, st, p); \
+                        else if (planes == 1) hipLaunchKernelGGL((write_f32_ref_stream<TR, 1>), dim3((int)blocks), dim3(AG_F32_REF_BLOCK), 0, st, p); \
                         else hipLaunchKernelGGL((write_f32_ref_stream<TR, 3>), dim3((int)blocks), dim3(AG_F32_REF_BLOCK), 0, st, p); } while (0)
             switch (p.transfer) {
             case AVIFGPU_TRANSFER_PQ:       if (pq_hi_launch(p)) AG_REF(kTransferPqHi); else AG_REF(AVIFGPU_TRANSFER_PQ); break;

@@ -98,6 +98,21 @@ CASES = [
     ("write_int_ref_stream", dict(width=1000, height=5, depth=16, planes=3, bit_depth=12, output=pkg.OUT_REFERENCE)),
     ("write_int_ref_stream", dict(width=502, height=3, depth=16, planes=4, bit_depth=8, alpha_state=pkg.ALPHA_PREMULTIPLIED,
                                   output=pkg.OUT_REFERENCE)),
+    # round 5 (last series): gray documents without alpha ARE their Y plane sample for sample -- the elementwise kernels with one sample per pixel
+    ("write_f32_ref_stream", dict(width=1000, height=5, depth=32, planes=1, bit_depth=10, transfer=pkg.TRANSFER_PQ, peak_nits=80)),
+    ("write_f32_ref_stream", dict(width=1028, height=3, depth=32, planes=1, bit_depth=12, transfer=pkg.TRANSFER_PQ, peak_nits=1000)),
+    ("write_f32_ref_stream", dict(width=516, height=4, depth=32, planes=1, bit_depth=12, transfer=pkg.TRANSFER_CLIP)),       # (gray saves take PQ or Clip only, WriteHeifImage.cpp:581)
+    ("write_f32_ref_stream", dict(width=4, height=2, depth=32, planes=1, bit_depth=10, transfer=pkg.TRANSFER_CLIP)),
+    ("write_int_ref_stream", dict(width=1000, height=5, depth=16, planes=1, bit_depth=12)),
+    ("write_int_ref_stream", dict(width=1032, height=3, depth=16, planes=1, bit_depth=10)),
+    ("write_int_ref_stream", dict(width=8, height=2, depth=16, planes=1, bit_depth=8)),
+    # ... and gray + alpha: two interleaved samples per pixel, two planes out, stage_a itself per pixel (write_ga_stream)
+    ("write_ga_stream", dict(width=1000, height=5, depth=16, planes=2, bit_depth=12, alpha_state=pkg.ALPHA_PREMULTIPLIED)),
+    ("write_ga_stream", dict(width=1028, height=3, depth=16, planes=2, bit_depth=10, alpha_state=pkg.ALPHA_STRAIGHT)),
+    ("write_ga_stream", dict(width=4, height=2, depth=16, planes=2, bit_depth=12, alpha_state=pkg.ALPHA_PREMULTIPLIED)),
+    ("write_ga_stream", dict(width=1000, height=5, depth=32, planes=2, bit_depth=10, transfer=pkg.TRANSFER_PQ, peak_nits=80, alpha_state=pkg.ALPHA_PREMULTIPLIED)),
+    ("write_ga_stream", dict(width=514, height=3, depth=32, planes=2, bit_depth=12, transfer=pkg.TRANSFER_PQ, peak_nits=1000, alpha_state=pkg.ALPHA_STRAIGHT)),
+    ("write_ga_stream", dict(width=2, height=2, depth=32, planes=2, bit_depth=12, transfer=pkg.TRANSFER_CLIP, alpha_state=pkg.ALPHA_PREMULTIPLIED)),
 ]
 
 

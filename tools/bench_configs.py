@@ -267,6 +267,8 @@ if __name__ == "__main__":
     bench_write("REF RGBA16 premultiplied -> 10-bit interleaved (reference hand-off) 8192^2", width=8192, height=8192, depth=16, planes=4, bit_depth=10, alpha_state=2, output=0)
     bench_write("Gray16+alpha premultiplied -> 12-bit Y + A planes 8192^2", width=8192, height=8192, depth=16, planes=2, bit_depth=12, alpha_state=2, output=0)
     bench_write("Gray32 -> 10-bit PQ Y plane 8192^2", width=8192, height=8192, depth=32, planes=1, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=0)
+    bench_write("Gray32+alpha -> 12-bit PQ Y + A planes 8192^2", width=8192, height=8192, depth=32, planes=2, bit_depth=12, transfer=0, peak_nits=80, alpha_state=1, output=0)
+    bench_write("Gray16 -> 12-bit Y plane 8192^2", width=8192, height=8192, depth=16, planes=1, bit_depth=12, alpha_state=0, output=0)
     # real document geometries (not powers of two): 42 Mpx / 24 Mpx camera frames and an odd width (rows not 16-byte aligned:
     # the generic kernel's unaligned instantiation)
     hdr = dict(depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, matrix_coefficients=9, color_primaries=9)
