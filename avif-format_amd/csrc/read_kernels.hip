@@ -559,6 +559,15 @@ template <int CS, int DEPTH, bool ALPHA, int XS, int YS = 0> constexpr bool read
 #ifndef AG_MONO16_NC
 #define AG_MONO16_NC 8
 #endif
+// Round 5, fresh data (profiles/r05/read_samples_per_lane_fresh_data.txt): samples per lane re-measured -- u16 planes 4:4:4 without alpha take 8
+// (RGB16 +5-6 %, f32 +1-3 %; every 4:2:x and alpha footprint loses 5-30 % with 8 and keeps 4), gray -> f32 takes 8 (+15 %), gray -> 16 bit
+// keeps 8 (16: -2 %), planar RGB keeps 8 (16: -12...-18 %), the 8-bit 4:2:x opens keep 8 (16: -5...-12 %), 8-bit 4:4:4 takes 16 (+15 %).
+#ifndef AG_MONO32_NC
+#define AG_MONO32_NC 8
+#endif
+#ifndef AG_R16_NC_444
+#define AG_R16_NC_444 8
+#endif
 // Measured on MI355X (profiles/r01/ab_read_variants.txt): YCbCr keeps 4 chroma samples per lane for u16 planes (8 cost a wave
 // of occupancy and 30-40 % on the 4:2:x kernels); planar RGB / mono have no chroma state and run 13 % faster with 16-byte loads.
 #ifndef AG_R8_NC_SMALL
@@ -571,11 +580,12 @@ template <int CS, int DEPTH, bool ALPHA, int XS> struct ReadShape {
 #define AG_MONO8_NC 16   /* 16-byte loads and stores: 0.037 -> 0.030 ms at 8192^2 */
 #endif
 #ifndef AG_R8_NC_444
-#define AG_R8_NC_444 8   /* 4:4:4 without alpha: 4 -> 0.095 ms, 8 -> 0.088 ms, 16 -> 0.097 ms at 8192^2 */
+#define AG_R8_NC_444 16  /* 4:4:4 without alpha.  Round 1, one-set loop: 4 -> 0.095 ms, 8 -> 0.088, 16 -> 0.097 at 8192^2; round 5, fresh data: 4 -> 0.090, 8 -> 0.079, 16 -> 0.069 (profiles/r05/read_samples_per_lane_fresh_data.txt) */
 #endif
     static constexpr int NC8 = CS == 2 ? (ALPHA ? 8 : AG_MONO8_NC)
                              : ((CS == 0 && XS == 0 && !ALPHA) ? AG_R8_NC_444 : ((CS == 0 && (XS == 0 || ALPHA)) ? AG_R8_NC_SMALL : AG_R8_NC));
-    static constexpr int NC = DEPTH == 8 ? NC8 : (CS == 1 ? AG_RGB16_NC : (CS == 2 ? (DEPTH == 32 ? 4 : AG_MONO16_NC) : AG_R16_NC));
+    static constexpr int NC = DEPTH == 8 ? NC8 : (CS == 1 ? AG_RGB16_NC : (CS == 2 ? (DEPTH == 32 ? AG_MONO32_NC : AG_MONO16_NC)
+                                                                                  : ((XS == 0 && !ALPHA) ? AG_R16_NC_444 : AG_R16_NC)));
     static constexpr int PXT = NC << XS;
 };
 

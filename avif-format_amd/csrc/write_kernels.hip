@@ -738,6 +738,9 @@ enum { kOutRefColor = 0, kOutRefGray = 1, kOutYcbcr = 2 };
 #ifndef AG_W8_PACKED
 #define AG_W8_PACKED 1
 #endif
+#ifndef AG_W16_NC
+#define AG_W16_NC 4        /* chroma samples per lane of the generic kernel into u16 planes (no ICC) */
+#endif
 #ifndef AG_W8_NC_ALPHA
 #define AG_W8_NC_ALPHA 4
 #endif
@@ -774,7 +777,7 @@ template <bool DST16, int PLANES, int XS, int ICC = 0> struct WriteShape {
     // ICC == 5 (the 16-bit table transform) saved to u8 planes: 4 chroma samples per lane like the u16 layouts.  With 8, a 4:2:0 footprint
     // is 32 pixels x two 16-byte gathers each, all hoisted: 315 VGPRs = ONE wave per SIMD (profiles/r02/isa/resources.tsv); with 4 it is
     // 16 pixels and the kernel fits 3-4 waves.
-    static constexpr int NC = ((ICC == 2 || ICC == 4) && XS == 1) ? 2 : ((DST16 || ICC == 5) ? 4 : ((PLANES == 2 || PLANES == 4) ? AG_W8_NC_ALPHA : AG_W8_NC));
+    static constexpr int NC = ((ICC == 2 || ICC == 4) && XS == 1) ? 2 : ((DST16 && ICC == 0) ? AG_W16_NC : ((DST16 || ICC == 5) ? 4 : ((PLANES == 2 || PLANES == 4) ? AG_W8_NC_ALPHA : AG_W8_NC)));
     static constexpr int PXT = NC << XS;
 };
 
