@@ -782,8 +782,15 @@ template <bool DST16, int PLANES, int XS, int ICC = 0> struct WriteShape {
 };
 
 // Workgroup size of the generic write kernel (its waves share only the per-workgroup tables).
+// Round 5, fresh data (profiles/r05/read_samples_per_lane_fresh_data.txt, block 5): 256 threads stand for every generic kernel (128: 0...-20 %,
+// 512: -1...-9 %) except the sampled-curve profile kernel (icc = 6, a code object of its own: part 36), whose workgroups copy up to 48 KiB of
+// curve tables to LDS -- 512 threads halve the copies per pixel: 0.437 -> 0.384 ms at 8192^2 (+14 %).
 #ifndef AG_WPX_BLOCK
+#if AG_WRITE_PART == 36
+#define AG_WPX_BLOCK 512
+#else
 #define AG_WPX_BLOCK 256
+#endif
 #endif
 constexpr int kWpxWaves = AG_WPX_BLOCK / 64;
 template <int DEPTH, int PLANES, int OUT, bool DST16, int XS, int YS, int TRANSFER, bool ALIGNED, int ICC = 0>
