@@ -1523,6 +1523,9 @@ template <bool NT, typename V> AG_DEV void stream_store(V* p, V v)
 #ifndef AG_INT_PRIO
 #define AG_INT_PRIO 1
 #endif
+#ifndef AG_IREF_BUFFER
+#define AG_IREF_BUFFER 1      /* round 5: 0 = 64-bit lane pointers under a per-vector test, 1 = loads through a buffer resource of the row (RGBA: stores too), 2 = stores too everywhere */
+#endif
 // A/B switches of round 5's last experiment (profiles/r05/probe_shapes.txt: the bare pattern runs 4-8 % faster from 64- / 128-thread
 // workgroups and as global_load / global_store than from 256 threads through buffer resources): the workgroup of THIS kernel, and
 // whole spans addressed with 64-bit lane pointers (the ragged last span of a row keeps the buffer form).
@@ -2921,6 +2924,9 @@ template <int DEPTH, int PLANES, bool DST16>
 __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_int_ref_stream(const WriteParams p)
 {
     constexpr int K = 4;
+    // loads through a buffer resource of the row (no conditional load): +4-9 %; the stores too where a vector is whole pixels with alpha
+    // (RGBA8 +7 % against +4.6 %, RGBA16 +1.5 % against -1.7 %; RGB16 +1.3 % against +3.6 %): profiles/r05/int_handoff_buffer_addressing_ab.txt
+    constexpr int IREF = AG_IREF_BUFFER == 1 ? (PLANES == 4 ? 2 : 1) : AG_IREF_BUFFER;
     constexpr int NS = 16 / (DEPTH / 8);                                // samples per 16-byte input vector
     constexpr int ODW = NS * (DST16 ? 2 : 1) / 4;                       // output dwords per input vector: 2, 4 or 8
     __shared__ uint16_t lut8[DEPTH == 8 ? 256 : 2];                     // 8-bit documents saved at 10/12 bit (:87-112)
@@ -2928,7 +2934,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_int_ref_stream(const Wr
         if (p.maxv > 255) { for (int i = threadIdx.x; i < 256; i += AG_STREAM_BLOCK) lut8[i] = (uint16_t)exact_rescale(i, 255.0f, p.maxf, p.maxv); __syncthreads(); }
     }
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = IREF ? wave_in_block() : (int)(threadIdx.x >> 6);
     const uint32_t nv = (uint32_t)((long long)p.width * PLANES * (DEPTH / 8) / 16);   // vectors per row (host: exact)
     const uint32_t chunks = (nv + 64 * K - 1) / (64 * K);
     const uint32_t total = chunks * (uint32_t)p.nrows;
@@ -2939,14 +2945,21 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_int_ref_stream(const Wr
         uint32_t* dp = reinterpret_cast<uint32_t*>(p.dst[0] + (long long)r * p.dst_stride[0]);
         u32x4 v[K];
         uint32_t idx[K];
+        if constexpr (IREF != 0) {                                    // the row as a buffer resource: no conditional load (as in write_f32_ref_stream)
+            const __amdgpu_buffer_rsrc_t rs = span_rsrc(sp, nv * 16u);
+            const uint32_t vo = (c * (64 * K) + (uint32_t)lane) * 16u;
+#pragma unroll
+            for (int k = 0; k < K; ++k) { idx[k] = c * (64 * K) + 64 * k + lane; v[k] = __builtin_bit_cast(u32x4, span_load16<true>(rs, vo, 1024u * k)); }
+        } else {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             idx[k] = c * (64 * K) + 64 * k + lane;
             if (idx[k] < nv) v[k] = g_load_nt(sp + idx[k]);
         }
+        }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            if (idx[k] >= nv) continue;
+            if (IREF != 2 && idx[k] >= nv) continue;              // (buffer stores: the hardware's range check drops a vector beyond the row)
             const uint32_t in[4] = { v[k].x, v[k].y, v[k].z, v[k].w };
             uint32_t q[NS];
 #pragma unroll
@@ -2974,6 +2987,16 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_int_ref_stream(const Wr
             for (int j = 0; j < ODW; ++j) {
                 if constexpr (DST16) o[j] = q[2 * j] | (q[2 * j + 1] << 16);
                 else o[j] = q[4 * j] | (q[4 * j + 1] << 8) | (q[4 * j + 2] << 16) | (q[4 * j + 3] << 24);
+            }
+            if constexpr (IREF == 2) {                              // (stores through a buffer resource of the output row as well)
+                const __amdgpu_buffer_rsrc_t rd = span_rsrc(dp, nv * (uint32_t)(ODW * 4));
+                const uint32_t so = idx[k] * (uint32_t)(ODW * 4);
+                if constexpr (ODW == 2) span_store8<true>(rd, so, u32x2{ o[0], o[1] });
+                else {
+#pragma unroll
+                    for (int h = 0; h < ODW / 4; ++h) span_store16<true>(rd, so + 16u * h, u32x4{ o[4 * h], o[4 * h + 1], o[4 * h + 2], o[4 * h + 3] });
+                }
+                continue;
             }
             uint32_t* d = dp + (size_t)idx[k] * ODW;
             if constexpr (ODW == 2) { u32x2 t = { o[0], o[1] }; g_store_nt(t, reinterpret_cast<u32x2*>(d)); }
