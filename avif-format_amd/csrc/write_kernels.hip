@@ -1523,6 +1523,12 @@ template <bool NT, typename V> AG_DEV void stream_store(V* p, V v)
 #ifndef AG_INT_PRIO
 #define AG_INT_PRIO 1
 #endif
+#ifndef AG_REF_BUFFER_STORES
+#define AG_REF_BUFFER_STORES 0
+#endif
+#ifndef AG_RGB16_BUFFER
+#define AG_RGB16_BUFFER 0
+#endif
 #ifndef AG_IREF_BUFFER
 #define AG_IREF_BUFFER 1      /* round 5: 0 = 64-bit lane pointers under a per-vector test, 1 = loads through a buffer resource of the row (RGBA: stores too), 2 = stores too everywhere */
 #endif
@@ -2224,7 +2230,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr444_hot(cons
 {
     constexpr int PXL = 8, K = 3, SPAN_PX = 512, SPAN_DW = SPAN_PX * 3 / 2, LDW = 12;
     __shared__ __attribute__((aligned(16))) uint32_t strip[kStreamWaves][SPAN_DW];
-    const int wave = threadIdx.x >> 6;
+    const int wave = AG_RGB16_BUFFER ? wave_in_block() : (int)(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     uint32_t* my = strip[wave];
     const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;
@@ -2238,8 +2244,14 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr444_hot(cons
             const uint32_t sx = sidx - r * spans_per_row;
             const int span_v = min(SPAN_PX, p.width - (int)sx * SPAN_PX) * 3 / 8;      // 16-byte vectors in this span (span_px is a multiple of 8)
             const u32x4* sp = reinterpret_cast<const u32x4*>(p.src + (long long)r * p.src_row_bytes) + (long long)sx * (64 * K);
+            if constexpr (AG_RGB16_BUFFER) {                                            // the span as a buffer resource (a vector beyond it: zeros, never stored)
+                const __amdgpu_buffer_rsrc_t rs = span_rsrc(sp, (uint32_t)span_v * 16u);
+#pragma unroll
+                for (int k = 0; k < K; ++k) cur[n][k] = __builtin_bit_cast(u32x4, span_load16<true>(rs, (uint32_t)lane * 16u, 1024u * k));
+            } else {
 #pragma unroll
             for (int k = 0; k < K; ++k) cur[n][k] = g_load_nt(sp + min(64 * k + lane, span_v - 1));   // branch-free mask, as in the f32 kernel
+            }
         }
 #pragma unroll
         for (int n = 0; n < NS; ++n) {
@@ -2312,7 +2324,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr_sub_hot(con
     constexpr int PXL = 8, K = 3, SPAN_PX = 512, SPAN_DW = SPAN_PX * 3 / 2, LDW = 12, VR = 1 << YS;
     if constexpr (AG_INT_PRIO && YS == 0) __builtin_amdgcn_s_setprio(3);      // (4:2:2: +1-4 %; 4:2:0 and 4:4:4: -2-4 %, profiles/r05/late_table_fill_and_priority_ab.txt)
     __shared__ __attribute__((aligned(16))) uint32_t strip[kStreamWaves][SPAN_DW];
-    const int wave = threadIdx.x >> 6;
+    const int wave = AG_RGB16_BUFFER ? wave_in_block() : (int)(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     uint32_t* my = strip[wave];
     const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;
@@ -2328,8 +2340,14 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr_sub_hot(con
         for (int vr = 0; vr < VR; ++vr) {
             const int r = min((int)(gy * VR) + vr, p.rows_to_end - 1);             // bottom edge: replicate the last IMAGE row
             const u32x4* sp = reinterpret_cast<const u32x4*>(p.src + (long long)r * p.src_row_bytes) + (long long)sx * (64 * K);
+            if constexpr (AG_RGB16_BUFFER) {
+                const __amdgpu_buffer_rsrc_t rs = span_rsrc(sp, (uint32_t)span_v * 16u);
+#pragma unroll
+                for (int k = 0; k < K; ++k) v[vr][k] = __builtin_bit_cast(u32x4, span_load16<true>(rs, (uint32_t)lane * 16u, 1024u * k));
+            } else {
 #pragma unroll
             for (int k = 0; k < K; ++k) v[vr][k] = g_load_nt(sp + min(64 * k + lane, span_v - 1));
+            }
         }
         if constexpr (AG_INT_PRIO && YS == 0) __builtin_amdgcn_s_setprio(0);
         uint32_t dw[VR][LDW];
@@ -2841,9 +2859,13 @@ __global__ __launch_bounds__(AG_F32_REF_BLOCK) void write_f32_ref_stream(const W
             }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                if (idx[k + h] >= n4) continue;
                 u32x2 o = { q[4 * h] | (q[4 * h + 1] << 16), q[4 * h + 2] | (q[4 * h + 3] << 16) };
-                stream_store<true>(dp + idx[k + h], o);
+                if constexpr (AG_REF_BUFFER_STORES) {                               // the output row as a buffer resource: no test, the range check clips
+                    span_store8<true>(span_rsrc(dp, n4 * 8u), idx[k + h] * 8u, o);
+                } else {
+                    if (idx[k + h] >= n4) continue;
+                    stream_store<true>(dp + idx[k + h], o);
+                }
             }
         }
         if (widx + step < total) issue(widx + step);                               // (capped grids: the loop's next chunk)
