@@ -2497,6 +2497,108 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra444_hot(co
     }
 }
 
+// ---- ... and 4:2:2 / 4:2:0 + alpha (round 5, last series): the plug-in's DEFAULT save of a transparent 16-bit document (4:2:2, 12 bit) ----
+// The 4:4:4 kernel above with one or two rows per wave trip: a row's codes cross the strip, its luma and alpha leave at once (16 bytes per
+// lane and plane), the chroma box sums (integer codes <= 4095: exact in float in any order) stay in 12 registers; a lane's 8 pixels are the
+// footprint of 4 chroma samples = 8 bytes per chroma plane.  width % 8 == 0, rows and planes 16- (chroma: 8-) byte aligned; the generic kernel ran
+// these at 0.76 of 8 TB/s.
+template <int YS, bool NEAREST>
+__global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra_sub_hot(const WriteParams p)
+{
+    constexpr int PXL = 8, K = 4, SPAN_PX = 512, LSTRIDE = 20, VR = 1 << YS;
+    __shared__ __attribute__((aligned(16))) uint32_t strip[kStreamWaves][64 * LSTRIDE];
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    uint32_t* my = strip[wave];
+    const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;
+    const uint32_t groups = ((uint32_t)p.nrows + VR - 1) >> YS;
+    const uint32_t total = spans_per_row * groups;
+    for (uint32_t sidx = blockIdx.x * kStreamWaves + wave; sidx < total; sidx += gridDim.x * kStreamWaves) {
+        const uint32_t gy = sidx / spans_per_row;
+        const uint32_t sx = sidx - gy * spans_per_row;
+        const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);             // a multiple of 8
+        const int span_v = span_px / 2;                                            // 16-byte vectors (2 pixels each)
+        u32x4 cur[VR][K];
+#pragma unroll
+        for (int vr = 0; vr < VR; ++vr) {                                          // both rows' loads in flight before any arithmetic
+            const int r = min((int)(gy * VR) + vr, p.rows_to_end - 1);             // bottom edge: replicate the last IMAGE row
+            const u32x4* sp = reinterpret_cast<const u32x4*>(p.src + (long long)r * p.src_row_bytes) + (long long)sx * (64 * K);
+#pragma unroll
+            for (int k = 0; k < K; ++k) cur[vr][k] = g_load_nt(sp + min(64 * k + lane, span_v - 1));
+        }
+        const bool inside = PXL * lane < span_px;
+        const long long xoff = ((long long)sx * SPAN_PX + (long long)PXL * lane) * 2;
+        uint32_t acc01[4], acc2[4];                                                // the box sums as packed u16 integers (R | G << 16, B | .): <= 4 x 4095 per half
+#pragma unroll
+        for (int vr = 0; vr < VR; ++vr) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                uint32_t o[4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {                                      // the vector's two pixels: rescale, premultiply (as in the 4:4:4 kernel)
+                    const uint32_t w0 = h == 0 ? cur[vr][k].x : cur[vr][k].z, w1 = h == 0 ? cur[vr][k].y : cur[vr][k].w;
+                    const uint32_t q01 = exact_rescale16_pair(w0, p.maxf * (1.0f / 32768.0f)), q2a = exact_rescale16_pair(w1, p.maxf * (1.0f / 32768.0f));
+                    uint32_t c0 = q01 & 0xffffu, c1 = q01 >> 16, c2 = q2a & 0xffffu;
+                    const uint32_t a = q2a >> 16;
+                    if (p.premultiply) {
+                        c0 = exact_premultiply_fast(c0, a, p.maxf, p.rcp_maxf);
+                        c1 = exact_premultiply_fast(c1, a, p.maxf, p.rcp_maxf);
+                        c2 = exact_premultiply_fast(c2, a, p.maxf, p.rcp_maxf);
+                    }
+                    o[2 * h] = c0 | (c1 << 16); o[2 * h + 1] = c2 | (a << 16);
+                }
+                const int v = 64 * k + lane;
+                *reinterpret_cast<u32x4*>(my + (v >> 2) * LSTRIDE + (v & 3) * 4) = u32x4{ o[0], o[1], o[2], o[3] };
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint32_t dw[2 * PXL];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u32x4 t = *reinterpret_cast<const u32x4*>(my + lane * LSTRIDE + 4 * j);
+                dw[4 * j] = t.x; dw[4 * j + 1] = t.y; dw[4 * j + 2] = t.z; dw[4 * j + 3] = t.w;
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint32_t yv[PXL], av[PXL];
+#pragma unroll
+            for (int i = 0; i < PXL; ++i) {
+                const uint32_t q0 = dw[2 * i] & 0xffffu, q1 = dw[2 * i] >> 16, q2 = dw[2 * i + 1] & 0xffffu;
+                av[i] = dw[2 * i + 1] >> 16;
+                yv[i] = luma_code(p, q0, q1, q2);
+            }
+            const int r = (int)(gy * VR) + vr;
+            if (inside && r < p.nrows) {                                           // (odd last row of the tile: replicated for chroma only)
+                g_store_nt(u32x4{ yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) },
+                           reinterpret_cast<u32x4*>(p.dst[0] + (long long)r * p.dst_stride[0] + xoff));
+                g_store_nt(u32x4{ av[0] | (av[1] << 16), av[2] | (av[3] << 16), av[4] | (av[5] << 16), av[6] | (av[7] << 16) },
+                           reinterpret_cast<u32x4*>(p.dst[3] + (long long)r * p.dst_stride[3] + xoff));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                                          // pixels 2j, 2j + 1 = dwords 4j .. 4j + 3 (the alpha halves ride along, unused)
+                if constexpr (NEAREST) {
+                    if (vr == 0) { acc01[j] = dw[4 * j]; acc2[j] = dw[4 * j + 1]; }
+                } else {
+                    const uint32_t p01 = dw[4 * j] + dw[4 * j + 2], p2 = dw[4 * j + 1] + dw[4 * j + 3];
+                    if (vr == 0) { acc01[j] = p01; acc2[j] = p2; } else { acc01[j] += p01; acc2[j] += p2; }
+                }
+            }
+        }
+        uint32_t cbv[4], crv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // (a + b + c + d) * 0.25f of the oracle: integer sums are exact in any order; 4:2:2's (pair + pair) * 0.25f is pair * 0.5f exactly
+            constexpr float scale = NEAREST ? 1.0f : (YS ? 0.25f : 0.5f);
+            const float R = (float)(acc01[j] & 0xffffu) * scale, G = (float)(acc01[j] >> 16) * scale, B = (float)(acc2[j] & 0xffffu) * scale;
+            cbv[j] = clip_round(R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2] + p.half, p.maxv);
+            crv[j] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
+        }
+        if (inside) {
+            const long long coff = xoff >> 1;                                      // 4 chroma samples of 2 bytes per lane
+            g_store_nt(u32x2{ cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16) }, reinterpret_cast<u32x2*>(p.dst[1] + (long long)gy * p.dst_stride[1] + coff));
+            g_store_nt(u32x2{ crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16) }, reinterpret_cast<u32x2*>(p.dst[2] + (long long)gy * p.dst_stride[2] + coff));
+        }
+    }
+}
+
 // ---- RGB8 -> Y, Cb, Cr u8 planes: the plug-in's default save and BASELINE C2 as a streaming kernel (round 5) ---------------------------
 // 8-bit documents saved at 8 bit: stage A is the identity (WriteHeifImage.cpp:629-806 copies the bytes; maxValue 255, no rescale), so the
 // row bytes as loaded are the codes and the kernel is stage B (libheif's RGB -> YCbCr + chroma sub-sampling) on them.  Until round 5 this
@@ -3384,6 +3486,24 @@ hipError_t launch_stream_int(const WriteParams& p, int depth, int planes, bool d
             if (blocks > AG_STREAM_BLOCK_CAP * 4 / kStreamWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kStreamWaves;
             snprintf(label, kLabelBytes, "write_rgba16_ycbcra444_hot");
             hipLaunchKernelGGL((write_rgba16_ycbcra444_hot<0>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p);
+            return hipGetLastError();
+        }
+    }
+    // RGBA16 -> u16 Y, Cb, Cr (4:2:2 / 4:2:0), A: the plug-in's default save of a transparent 16-bit document (round 5, last series)
+    if ((variant & 1) && p.icc16_clut == nullptr && depth == 16 && planes == 4 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 1 && p.dst[3] != nullptr &&
+        (p.width % 8) == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
+        ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[3]) | (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[3]) & 15) == 0 &&
+        ((reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2]) & 7) == 0) {
+        const long long spans = (long long)((p.width + 511) / 512) * ((p.nrows + (1 << ys) - 1) >> ys);
+        if (spans == 0) return hipSuccess;
+        if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
+            long long blocks = (spans + kStreamWaves - 1) / kStreamWaves;
+            if (blocks > AG_STREAM_BLOCK_CAP * 4 / kStreamWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kStreamWaves;
+            snprintf(label, kLabelBytes, "write_rgba16_ycbcra_sub_hot<ys=%d,nearest=%d>", ys, p.nearest);
+#define AG_RA16(YS_) do { if (p.nearest) hipLaunchKernelGGL((write_rgba16_ycbcra_sub_hot<YS_, true>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); \
+                          else hipLaunchKernelGGL((write_rgba16_ycbcra_sub_hot<YS_, false>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); } while (0)
+            if (ys) AG_RA16(1); else AG_RA16(0);
+#undef AG_RA16
             return hipGetLastError();
         }
     }

@@ -106,6 +106,17 @@ CASES = [
     ("write_int_ref_stream", dict(width=1000, height=5, depth=16, planes=1, bit_depth=12)),
     ("write_int_ref_stream", dict(width=1032, height=3, depth=16, planes=1, bit_depth=10)),
     ("write_int_ref_stream", dict(width=8, height=2, depth=16, planes=1, bit_depth=8)),
+    # ... a transparent 16-bit document saved 4:2:2 / 4:2:0 (the plug-in's default is 4:2:2): box and nearest, premultiplied and straight, odd heights
+    ("write_rgba16_ycbcra_sub_hot", dict(width=1024, height=6, depth=16, planes=4, bit_depth=12, alpha_state=pkg.ALPHA_PREMULTIPLIED, output=pkg.OUT_YCBCR,
+                                         chroma=pkg.CHROMA_422, chroma_downsampling=pkg.DOWNSAMPLE_NEAREST, **BT2020)),
+    ("write_rgba16_ycbcra_sub_hot", dict(width=1000, height=7, depth=16, planes=4, bit_depth=10, alpha_state=pkg.ALPHA_STRAIGHT, output=pkg.OUT_YCBCR,
+                                         chroma=pkg.CHROMA_420, matrix_coefficients=pkg.MATRIX_BT709, color_primaries=pkg.PRIMARIES_BT709)),
+    ("write_rgba16_ycbcra_sub_hot", dict(width=520, height=5, depth=16, planes=4, bit_depth=12, alpha_state=pkg.ALPHA_PREMULTIPLIED, output=pkg.OUT_YCBCR,
+                                         chroma=pkg.CHROMA_420, chroma_downsampling=pkg.DOWNSAMPLE_NEAREST, matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)),
+    ("write_rgba16_ycbcra_sub_hot", dict(width=1512, height=4, depth=16, planes=4, bit_depth=10, alpha_state=pkg.ALPHA_PREMULTIPLIED, output=pkg.OUT_YCBCR,
+                                         chroma=pkg.CHROMA_422, matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)),
+    ("write_rgba16_ycbcra_sub_hot", dict(width=8, height=1, depth=16, planes=4, bit_depth=12, alpha_state=pkg.ALPHA_STRAIGHT, output=pkg.OUT_YCBCR,
+                                         chroma=pkg.CHROMA_420, **BT2020)),
     # ... and gray + alpha: two interleaved samples per pixel, two planes out, stage_a itself per pixel (write_ga_stream)
     ("write_ga_stream", dict(width=1000, height=5, depth=16, planes=2, bit_depth=12, alpha_state=pkg.ALPHA_PREMULTIPLIED)),
     ("write_ga_stream", dict(width=1028, height=3, depth=16, planes=2, bit_depth=10, alpha_state=pkg.ALPHA_STRAIGHT)),
