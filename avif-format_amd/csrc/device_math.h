@@ -414,6 +414,17 @@ AG_DEV uint32_t exact_premultiply_fast(uint32_t color, uint32_t alpha, float max
     const float v = __builtin_fmaf(__builtin_fmaf(-q0, maxf, x), rcp_maxf, q0);
     return (uint32_t)cxx_min(floorf(v + 0.5f), maxf);
 }
+// Two colours of one pixel (a packed dword c0 | c1 << 16) against its alpha in packed single precision: element for element the sequence
+// above (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 round each element like their scalar forms), packed result.
+AG_DEV uint32_t exact_premultiply_fast_pair(uint32_t c01, uint32_t alpha, float maxf, float rcp_maxf)
+{
+    const dm_f32x2 c = { (float)(c01 & 0xffffu), (float)(c01 >> 16) };
+    const dm_f32x2 x = c * (float)alpha;
+    const dm_f32x2 q0 = x * rcp_maxf;
+    const dm_f32x2 v = __builtin_elementwise_fma(__builtin_elementwise_fma(-q0, (dm_f32x2)maxf, x), (dm_f32x2)rcp_maxf, q0) + 0.5f;
+    const float v0 = cxx_min(floorf(v.x), maxf), v1 = cxx_min(floorf(v.y), maxf);
+    return (uint32_t)v0 | ((uint32_t)v1 << 16);
+}
 // the same value as a float, from float operands (integer-valued; the u8 fast path keeps its codes in float)
 AG_DEV float exact_premultiply_fast_f(float color, float alpha, float maxf, float rcp_maxf)
 {

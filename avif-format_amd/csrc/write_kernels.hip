@@ -1523,6 +1523,9 @@ template <bool NT, typename V> AG_DEV void stream_store(V* p, V v)
 #ifndef AG_INT_PRIO
 #define AG_INT_PRIO 1
 #endif
+#ifndef AG_PREMUL_PAIR
+#define AG_PREMUL_PAIR 1      /* RGBA16 streaming kernels: R and G of a pixel premultiplied in packed single precision (same bits) */
+#endif
 #ifndef AG_REF_BUFFER_STORES
 #define AG_REF_BUFFER_STORES 0
 #endif
@@ -2454,14 +2457,14 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra444_hot(co
             for (int h = 0; h < 2; ++h) {                                          // the vector's two pixels
                 const uint32_t w0 = h == 0 ? cur[k].x : cur[k].z, w1 = h == 0 ? cur[k].y : cur[k].w;
                 const uint32_t q01 = exact_rescale16_pair(w0, p.maxf * (1.0f / 32768.0f)), q2a = exact_rescale16_pair(w1, p.maxf * (1.0f / 32768.0f));
-                uint32_t c0 = q01 & 0xffffu, c1 = q01 >> 16, c2 = q2a & 0xffffu;
+                uint32_t c01 = q01, c2 = q2a & 0xffffu;
                 const uint32_t a = q2a >> 16;
                 if (p.premultiply) {                                               // stage_a: after the rescale, in the plane's code domain
-                    c0 = exact_premultiply_fast(c0, a, p.maxf, p.rcp_maxf);
-                    c1 = exact_premultiply_fast(c1, a, p.maxf, p.rcp_maxf);
+                    if constexpr (AG_PREMUL_PAIR) c01 = exact_premultiply_fast_pair(c01, a, p.maxf, p.rcp_maxf);
+                    else c01 = exact_premultiply_fast(c01 & 0xffffu, a, p.maxf, p.rcp_maxf) | (exact_premultiply_fast(c01 >> 16, a, p.maxf, p.rcp_maxf) << 16);
                     c2 = exact_premultiply_fast(c2, a, p.maxf, p.rcp_maxf);
                 }
-                o[2 * h] = c0 | (c1 << 16); o[2 * h + 1] = c2 | (a << 16);
+                o[2 * h] = c01; o[2 * h + 1] = c2 | (a << 16);
             }
             const int v = 64 * k + lane;                                           // vector index in the span: pixels 2v, 2v + 1
             *reinterpret_cast<u32x4*>(my + (v >> 2) * LSTRIDE + (v & 3) * 4) = u32x4{ o[0], o[1], o[2], o[3] };
@@ -2538,14 +2541,14 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra_sub_hot(c
                 for (int h = 0; h < 2; ++h) {                                      // the vector's two pixels: rescale, premultiply (as in the 4:4:4 kernel)
                     const uint32_t w0 = h == 0 ? cur[vr][k].x : cur[vr][k].z, w1 = h == 0 ? cur[vr][k].y : cur[vr][k].w;
                     const uint32_t q01 = exact_rescale16_pair(w0, p.maxf * (1.0f / 32768.0f)), q2a = exact_rescale16_pair(w1, p.maxf * (1.0f / 32768.0f));
-                    uint32_t c0 = q01 & 0xffffu, c1 = q01 >> 16, c2 = q2a & 0xffffu;
+                    uint32_t c01 = q01, c2 = q2a & 0xffffu;
                     const uint32_t a = q2a >> 16;
                     if (p.premultiply) {
-                        c0 = exact_premultiply_fast(c0, a, p.maxf, p.rcp_maxf);
-                        c1 = exact_premultiply_fast(c1, a, p.maxf, p.rcp_maxf);
+                        if constexpr (AG_PREMUL_PAIR) c01 = exact_premultiply_fast_pair(c01, a, p.maxf, p.rcp_maxf);
+                        else c01 = exact_premultiply_fast(c01 & 0xffffu, a, p.maxf, p.rcp_maxf) | (exact_premultiply_fast(c01 >> 16, a, p.maxf, p.rcp_maxf) << 16);
                         c2 = exact_premultiply_fast(c2, a, p.maxf, p.rcp_maxf);
                     }
-                    o[2 * h] = c0 | (c1 << 16); o[2 * h + 1] = c2 | (a << 16);
+                    o[2 * h] = c01; o[2 * h + 1] = c2 | (a << 16);
                 }
                 const int v = 64 * k + lane;
                 *reinterpret_cast<u32x4*>(my + (v >> 2) * LSTRIDE + (v & 3) * 4) = u32x4{ o[0], o[1], o[2], o[3] };
