@@ -539,7 +539,7 @@ AG_DEV uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_m
 // host[] <= 32768 (the caller clamps: packed, as the row arrives)
 AG_DEV void icc16_tetrahedral_host(const uint16_t* __restrict__ clut, const uint32_t (&host)[3], uint32_t (&out)[3])
 {
-    constexpr uint32_t G = AVIFGPU_ICC_CLUT_GRID;
+    [[maybe_unused]] constexpr uint32_t G = AVIFGPU_ICC_CLUT_GRID;       // (used by one of the two record layouts below)
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     uint32_t c0i[3], r[3];
 #pragma unroll
