@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Median per variant of a tools/gpu/ab_fresh.sh log (several interleaved passes of tools/bench_configs.py rows under different library builds):
+    python tools/ab_summary.py LOG BASE_VARIANT
+prints, per row, every variant's median ms, its gain over BASE_VARIANT's median, and the passes' values in 0.1 us -- the form of the A/B files
+of profiles/r05 that are marked LAST SERIES."""
 import re,collections,sys
 d=collections.defaultdict(lambda: collections.defaultdict(list))
 v=None; base=sys.argv[2]
