@@ -5,13 +5,15 @@
 // RGB -> YCbCr + chroma-subsample stage behind them (reference call site src/common/Write.cpp:44).
 //
 // Work shape: pure streaming, HBM-bound, no reuse => no MFMA, no cross-block traffic, no XCD swizzle
-// (T1 only pays when neighbouring blocks share operands).  One thread owns PXT = (4 or 8) << XS horizontally
-// adjacent pixels on 1 << YS rows, i.e. exactly the footprint of 4 chroma samples, so
-//   * every plane store is one 8-byte (u16) / 4-byte (u8) vector per lane, contiguous across the wave;
-//   * the chroma box filter needs no cross-lane traffic;
-//   * the interleaved source is read as whole dwordx4/x2 vectors (lane stride = PXT*bytes-per-pixel).
-// The dominant configuration (RGB f32 -> PQ -> 4:4:4 u16) additionally has an LDS-transposed variant
-// (write_rgb32_ycbcr444_lds) whose global loads are fully coalesced 1-KiB wave transactions.
+// (T1 only pays when neighbouring blocks share operands).  Two families:
+//   * write_px, the GENERIC kernel (every configuration the API accepts; the fall-back of everything below): one thread owns
+//     PXT = (4 or 8) << XS horizontally adjacent pixels on 1 << YS rows, i.e. exactly the footprint of 4 (8) chroma samples, so every plane
+//     store is one 8-byte (u16) / 4-byte (u8) vector per lane, contiguous across the wave, the chroma box filter needs no cross-lane
+//     traffic, and the interleaved source is read as whole dwordx4/x2 vectors (lane stride = PXT * bytes per pixel);
+//   * the STREAMING kernels (write_*_hot, write_*_stream), one per common document kind: a wave owns a span of a row (or of
+//     two rows), loads it as fully coalesced 1-KiB wave transactions through a buffer resource, transposes it to lane-major through a
+//     wave-private LDS strip where the layout needs it, and stores 16 / 8 contiguous bytes per lane and plane.  Same device functions,
+//     same bytes as the generic kernel (tests/test_gpu_kernel_equivalence.py).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -28,13 +30,14 @@
 namespace avifgpu {
 
 // ---- code objects (round 5) ---------------------------------------------------------------------------------------------------
-// The library's Makefile compiles this file FIVE times, each time with another -DAG_WRITE_PART, into five code objects that the HIP
+// The library's Makefile compiles this file EIGHT times, each time with another -DAG_WRITE_PART, into eight code objects that the HIP
 // runtime loads one by one, on the first launch of a kernel of theirs -- a save then pays for the object its kernels live in, not for
 // all 650 instantiations (round 4: one 6.8-MB object, 18 ms in front of the first launch of a process):
 //    1   launch_write(), the only entry point, + the RGB f32 4:4:4 streaming kernels (the headline, with and without a profile in front) and
-//        the f32 interleaved hand-off;  2  the 8- and 16-bit streaming kernels;  3  RGB f32 4:2:2 / 4:2:0 and RGBA f32 streaming kernels
+//        the f32 interleaved hand-off (which Gray32 without alpha takes too);  2  the 8- and 16-bit streaming kernels (RGB8, RGBA8, RGB16,
+//        RGBA16 4:4:4 and 4:2:x, Gray16 + alpha, the integer hand-off);  3  RGB f32 4:2:2 / 4:2:0, RGBA f32 and Gray32 + alpha streaming kernels
 //    8, 16   write_px, the generic kernel, for 8- and 16-bit documents
-//    32  write_px for gray (+ alpha) f32 documents (their only path), 33 for RGB(A) f32 documents (the fall-back of the streaming kernels
+//    32  write_px for gray (+ alpha) f32 documents (the fall-back of their streaming kernels), 33 for RGB(A) f32 documents (the fall-back of the streaming kernels
 //        and the parametric-curve ICC variants), 36 write_px<32, ..., icc = 6>: documents whose profile carries sampled curves
 //    0   everything in one object (tools/ab_variants.sh builds its A/B libraries that way).
 // A kernel is emitted where a launch of it is instantiated; the launchers of a part are compiled in that part only (kHere* below), the
