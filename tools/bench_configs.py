@@ -254,7 +254,8 @@ if __name__ == "__main__":
     bench_write("D12 8192^2 RGBA f32 -> 12-bit PQ 4:2:2 nearest + alpha (fused hand-off)", planes=4, alpha_state=1, output=1, chroma=P.CHROMA_422, chroma_downsampling=P.DOWNSAMPLE_NEAREST, **d12)
     bench_write("D12 8192^2 RGBA f32 -> 12-bit PQ interleaved RRGGBBAA (reference hand-off)", planes=4, alpha_state=1, output=0, **d12)
     bench_write("D12 8192^2 RGB16 -> 12-bit 4:2:2 BT.601 nearest (SDR 16-bit document at the default depth, WriteMetadata.cpp:138-140)", width=8192, height=8192, depth=16, planes=3, bit_depth=12, alpha_state=0, output=1, chroma=P.CHROMA_422, chroma_downsampling=P.DOWNSAMPLE_NEAREST, matrix_coefficients=6, color_primaries=1)
-    bench_write("D12 8192^2 RGBA16 premult -> 12-bit 4:2:2 BT.601 nearest + alpha (transparent SDR 16-bit document at the plug-in's defaults)", width=8192, height=8192, depth=16, planes=4, bit_depth=12, alpha_state=2, output=1, chroma=P.CHROMA_422, chroma_downsampling=P.DOWNSAMPLE_NEAREST, matrix_coefficients=6, color_primaries=1)
+    bench_write("D12 8192^2 RGBA16 -> 12-bit 4:2:2 BT.601 nearest + alpha (transparent SDR 16-bit document at the plug-in's defaults: straight alpha, AvifFormat.cpp:99)", width=8192, height=8192, depth=16, planes=4, bit_depth=12, alpha_state=1, output=1, chroma=P.CHROMA_422, chroma_downsampling=P.DOWNSAMPLE_NEAREST, matrix_coefficients=6, color_primaries=1)
+    bench_write("D12 8192^2 RGBA16 premult -> 12-bit 4:2:2 BT.601 nearest + alpha (transparent SDR 16-bit document, premultiplied-alpha option on)", width=8192, height=8192, depth=16, planes=4, bit_depth=12, alpha_state=2, output=1, chroma=P.CHROMA_422, chroma_downsampling=P.DOWNSAMPLE_NEAREST, matrix_coefficients=6, color_primaries=1)
     bench_write("BIG 16384^2 RGB f32 -> 10-bit PQ 4:4:4", width=16384, height=16384, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=9, color_primaries=9)
     bench_write("BIG 16384^2 RGB f32 -> 10-bit PQ 4:2:0", width=16384, height=16384, depth=32, planes=3, bit_depth=10, transfer=0, peak_nits=80, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=9, color_primaries=9)
     bench_write("BIG 16384^2 RGB16 -> 12-bit 4:4:4 BT.2020", width=16384, height=16384, depth=16, planes=3, bit_depth=12, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=P.MATRIX_BT2020_NCL, color_primaries=9)
