@@ -63,6 +63,8 @@ int32_t oracle_write_image_row_callback(const avifgpu_write_desc* desc, const vo
                                         void* const dst[4], const int64_t dst_stride[4]);
 int32_t oracle_write_image_all_cores(const avifgpu_write_desc* desc, const void* image, int64_t image_row_bytes,
                                      void* const dst[4], const int64_t dst_stride[4], int32_t* threads_used);
+int32_t oracle_read_image_all_cores(const avifgpu_read_desc* desc, const void* const src[4], const int64_t src_stride[4],
+                                    void* image, int64_t image_row_bytes, int32_t* threads_used);
 
 #ifdef __cplusplus
 }

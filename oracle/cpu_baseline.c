@@ -8,7 +8,9 @@
  *                                    Photoshop's copy amounts to), then that row is converted.  One thread.
  *   oracle_write_image_all_cores     OpenMP over blocks of rows on every host core: a courtesy figure (the reference is
  *                                    single-threaded), reported with the thread count it actually ran on.
- * Both produce byte-identical planes to oracle_write_rows (tests/test_oracle_properties.py).
+ *   oracle_read_image_all_cores      the read-direction twin (round 6): oracle_read_rows over 32-row blocks on every host core, so
+ *                                    that the GPU tests can check a WHOLE BASELINE-size frame against the oracle in about a second.
+ * All produce bytes identical to oracle_write_rows / oracle_read_rows on the whole image (tests/test_oracle_properties.py).
  */
 #include "avif_oracle.h"
 
@@ -86,6 +88,45 @@ int32_t oracle_write_image_all_cores(const avifgpu_write_desc* d, const void* im
         void* t[4];
         tile_planes(d, y, dst, dst_stride, t);
         err = oracle_write_rows(d, y, n, (const uint8_t*)image + (int64_t)y * image_row_bytes, image_row_bytes, t, dst_stride);
+    }
+#endif
+    if (threads_used) *threads_used = threads;
+    return err;
+}
+
+int32_t oracle_read_image_all_cores(const avifgpu_read_desc* d, const void* const src[4], const int64_t src_stride[4],
+                                    void* image, int64_t image_row_bytes, int32_t* threads_used)
+{
+    if (!d || !src || !src_stride || !image) return AVIFGPU_formatBadParameters;
+    const int ys = (d->colorspace == AVIFGPU_COLORSPACE_YCBCR && d->chroma == AVIFGPU_CHROMA_420) ? 1 : 0;
+    const int block = 32;                                              /* even: a tile starts on a chroma row (ReadHeifImage.cpp:143) */
+    const int nblocks = (d->height + block - 1) / block;
+    int32_t err = 0;
+    int threads = 1;
+#ifdef _OPENMP
+#pragma omp parallel
+    {
+#pragma omp single
+        threads = omp_get_num_threads();
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (int b = 0; b < nblocks; ++b) {
+            const int y = b * block;
+            const int n = (y + block <= d->height) ? block : d->height - y;
+            const void* t[4];
+            for (int pl = 0; pl < 4; ++pl) {
+                const int chroma = d->colorspace == AVIFGPU_COLORSPACE_YCBCR && (pl == 1 || pl == 2);
+                t[pl] = src[pl] ? (const uint8_t*)src[pl] + (int64_t)(chroma ? (y >> ys) : y) * src_stride[pl] : NULL;
+            }
+            const int32_t e = oracle_read_rows(d, y, n, t, src_stride, (uint8_t*)image + (int64_t)y * image_row_bytes, image_row_bytes);
+            if (e) {
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+                err = e;
+            }
+        }
+#ifdef _OPENMP
     }
 #endif
     if (threads_used) *threads_used = threads;

@@ -55,5 +55,7 @@ def load() -> ctypes.CDLL:
     L.oracle_write_image_row_callback.argtypes = [c_void_p, c_void_p, c_int64, POINTER(P4), POINTER(S4)]
     L.oracle_write_image_all_cores.restype = c_int32
     L.oracle_write_image_all_cores.argtypes = [c_void_p, c_void_p, c_int64, POINTER(P4), POINTER(S4), POINTER(c_int32)]
+    L.oracle_read_image_all_cores.restype = c_int32
+    L.oracle_read_image_all_cores.argtypes = [c_void_p, POINTER(P4), POINTER(S4), c_void_p, c_int64, POINTER(c_int32)]
     _lib = L
     return L

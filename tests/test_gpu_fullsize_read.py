@@ -1,9 +1,10 @@
-"""READ direction at FULL size on one MI355X (VERDICT r03, item 5): what test_gpu_fullsize.py does for the write direction.
- (a) oracle-checked stripes of rows -- top, an interior odd-ish offset, and the bottom edge -- of the frame converted in ONE launch
-     (the stripes are run through the CPU oracle as tiles of the full image, so the chroma rows they need are addressed exactly
-     like the kernel addresses them);
+"""READ direction at FULL size on one MI355X: what test_gpu_fullsize.py does for the write direction.
+ (a) the WHOLE frame decoded in ONE launch against the CPU oracle run on the same planes on all host cores (round 6; rounds 3-5 compared
+     three stripes of 42 rows): oracle_read_image_all_cores = oracle_read_rows over 32-row blocks, byte-identical to the whole-image call
+     (tests/test_oracle_properties.py).  Reference lines the frames reproduce: YuvDecode.cpp:281-696 under ReadHeifImage.cpp:83-400;
  (b) row-tile invariance: the frame converted as 8 even-row tiles (the 8-GPU sharding) is byte-identical to the one-launch frame.
-Bars: integer hosts bit-exact; f32 hosts the T2 read bar of tests/test_gpu_read.py (|gpu - oracle| <= 1e-4 |oracle| + 1e-9)."""
+Bars: integer hosts bit-exact on every byte; f32 hosts the T2 read bar of tests/test_gpu_read.py (|gpu - oracle| <= 1e-4 |oracle| + 1e-9)
+on every sample."""
 import ctypes
 
 import numpy as np
@@ -58,22 +59,23 @@ def _run(gpu, torch, dev, d, planes, tiles):
     return out, row_bytes
 
 
-def _oracle_stripe(d, planes, r0, n):
-    """The CPU oracle on rows [r0, r0 + n) as a tile of the full image: hand it host copies of exactly the plane rows the tile touches,
-    with the pointers of `row r0 of the tile` like avifgpu_read_rows takes them."""
+def _oracle_frame(d, planes, stride):
+    """The whole frame through the oracle on all host cores; returns the (height, stride) byte image."""
+    import time
     import oracle_binding
     L = oracle_binding.load()
     host, ptrs, strides = {}, [None] * 4, [0] * 4
-    for pl, (w, xs, ys) in harness.read_planes(d).items():
-        first = r0 >> ys
-        last = min((r0 + n - 1) >> ys, planes[pl].shape[0] - 1)
-        host[pl] = np.ascontiguousarray(planes[pl][first:last + 1].cpu().numpy())
+    for pl in harness.read_planes(d):
+        host[pl] = planes[pl].cpu().numpy()
         ptrs[pl], strides[pl] = host[pl].ctypes.data, host[pl].strides[0]
-    buf, row_bytes = harness._alloc_read_out(d, n)
-    code = L.oracle_read_rows(ctypes.byref(d), r0, n, ctypes.byref(pkg.planes4(ptrs)), ctypes.byref(pkg.strides4(strides)),
-                              buf.ctypes.data, buf.strides[0])
+    out = np.empty((d.height, stride), dtype=np.uint8)
+    n = ctypes.c_int32(0)
+    t0 = time.perf_counter()
+    code = L.oracle_read_image_all_cores(ctypes.byref(d), ctypes.byref(pkg.planes4(ptrs)), ctypes.byref(pkg.strides4(strides)),
+                                         out.ctypes.data, out.strides[0], ctypes.byref(n))
     assert code == 0
-    return harness._view_read(d, buf, n, row_bytes)
+    print(f"   oracle: {d.width}x{d.height} on {n.value} threads in {time.perf_counter() - t0:.2f} s")
+    return out
 
 
 @pytest.mark.parametrize("name", list(CONFIGS))
@@ -86,14 +88,19 @@ def test_fullsize_read(gpu, name):
     tiled, _ = _run(gpu, torch, dev, d, planes, pkg.sharding.all_tiles(d.height, 8))
     assert torch.equal(whole, tiled), name
     del tiled
-    mid = d.height // 2 + 6                                   # even: tiles start on chroma-row boundaries (the oracle takes any row0 of a tile)
-    for r0, n in ((0, 16), (mid, 16), (d.height - 10 - (d.height - 10) % 2, 10 + (d.height - 10) % 2)):
-        want = _oracle_stripe(d, planes, r0, n)
-        got = whole[r0:r0 + n, :row_bytes].cpu().numpy().copy().view(harness.src_dtype(d.depth)).reshape(n, -1)
-        if d.depth == 32:
-            w64, g64 = want.astype(np.float64), got.astype(np.float64)
-            assert np.all(np.isfinite(g64)), name
-            err = np.abs(g64 - w64)
-            assert np.all(err <= 1e-4 * np.abs(w64) + 1e-9), (name, r0, float(np.max(err / np.maximum(np.abs(w64), 1e-30))))
-        else:
-            assert np.array_equal(got, want), (name, r0)
+    want = torch.from_numpy(_oracle_frame(d, planes, whole.stride(0))).to(dev)
+    esz = d.depth // 8
+    dt = {8: torch.uint8, 16: torch.int16, 32: torch.float32}[d.depth]
+    g = whole.view(dt)[:, :row_bytes // esz]
+    w = want.view(dt)[:, :row_bytes // esz]
+    if d.depth == 32:
+        assert bool(torch.isfinite(g).all()), name
+        worst = 0.0
+        for r in range(0, d.height, 2048):                  # float64 temporaries of 2048 rows at a time
+            g64, w64 = g[r:r + 2048].double(), w[r:r + 2048].double()
+            err = (g64 - w64).abs()
+            assert bool((err <= 1e-4 * w64.abs() + 1e-9).all()), (name, r)
+            worst = max(worst, float((err / w64.abs().clamp_min(1e-6)).max()))
+        print(f"{name}: {d.height}x{row_bytes // esz} samples, max relative error against the oracle {worst:.2e}")
+    else:
+        assert torch.equal(g, w), name

@@ -290,6 +290,28 @@ def test_cpu_baseline_structures_equal_whole_frame(oracle, chroma, down):
             assert np.array_equal(bufs[pl], want[pl]), (which, pl)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(colorspace=0, chroma=1, bit_depth=8, depth=8, alpha_state=0, matrix_coefficients=1),
+    dict(colorspace=0, chroma=2, bit_depth=12, depth=32, alpha_state=0, matrix_coefficients=9, color_primaries=9, transfer_characteristics=16),
+    dict(colorspace=0, chroma=1, bit_depth=12, depth=16, alpha_state=2, matrix_coefficients=9, color_primaries=9),
+    dict(colorspace=2, chroma=0, bit_depth=10, depth=16, alpha_state=1),
+])
+def test_cpu_read_all_cores_equals_whole_frame(oracle, kw):
+    """oracle_read_image_all_cores (what the full-size GPU tests check whole frames against) == oracle_read_rows on the whole image."""
+    import ctypes
+    d = pkg.ReadDesc(width=131, height=77, **kw)
+    planes = harness.make_read_source(d, seed=11)
+    want = harness.oracle_read(d, planes)
+    buf, row_bytes = harness._alloc_read_out(d, d.height)
+    ptrs, strides = harness._tile_read_ptrs(d, planes, 0, lambda pl: planes[pl].ctypes.data)
+    n = ctypes.c_int32(0)
+    rc = oracle.oracle_read_image_all_cores(ctypes.byref(d), ctypes.byref(pkg.planes4(ptrs)), ctypes.byref(pkg.strides4(strides)),
+                                            buf.ctypes.data, buf.strides[0], ctypes.byref(n))
+    assert rc == 0 and n.value >= 1
+    got = harness._view_read(d, buf, d.height, row_bytes)
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+
+
 def test_unorm_division_is_exact(tmp_path):
     """read_kernels.hip::unorm_to_float: (float)u / (float)max as fma(u, rh, RN(u * rl)) with 1 / max = rh + rl (two floats) equals the
     IEEE quotient for every u in [0, max] and max in {255, 1023, 4095, 65535} -- every entry of every table of
