@@ -5,6 +5,7 @@
 // (one worker thread + staging slots per context, row tiles dealt across contexts); device-pointer calls
 // launch directly on the caller's stream and device.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstddef>
 #include <cmath>
 #include <cstdarg>
@@ -172,12 +173,23 @@ struct IccDeviceTables {
     // the caller's table of the last upload and a fingerprint of it: a tile that passes the same struct again (every tile of an image
     // does) skips the byte-for-byte comparison of 216-792 KiB under g_icc_mu.  A prepared table is immutable while it is in use
     // (include/avifgpu.h); the fingerprint -- 4096 strided words -- is the guard against a caller that rewrites one in place anyway,
-    // and it is trusted WITHIN an image only: the tile that starts at row 0 always takes the full comparison (round 5, ADVICE r04: a
-    // caller may legally rewrite or reallocate a table at the same address between two saves, and a change the stride misses -- 32
-    // consecutive floats of a 4096-entry curve -- would otherwise keep the stale device copy).
-    const void* s32_src = nullptr;   uint64_t s32_fp = 0;
-    const void* icc16_src = nullptr; uint64_t icc16_fp = 0;
+    // and it is trusted WITHIN an image only (round 5, ADVICE r04: a caller may legally rewrite or reallocate a table at the same address
+    // between two saves, and a change the stride misses -- 32 consecutive floats of a 4096-entry curve -- would otherwise keep the stale
+    // device copy).  "Within an image" is an EPOCH, not "row0 != 0" (round 6): the tables are cached per device and a
+    // multi-GPU save hands row 0 to one device only, so the first tile EACH device sees in an epoch takes the full comparison.  The
+    // epoch advances whenever a calling thread's row sequence restarts (row0 <= the row0 of its previous ICC call: a new image, or the
+    // same tile of the next image) -- icc_epoch_for_call() below.
+    const void* s32_src = nullptr;   uint64_t s32_fp = 0;   uint64_t s32_epoch = 0;
+    const void* icc16_src = nullptr; uint64_t icc16_fp = 0; uint64_t icc16_epoch = 0;
 };
+static std::atomic<uint64_t> g_icc_epoch{1};
+// Called once per C-ABI write call that carries an ICC table, on the caller's thread, before any tile is dealt.
+void icc_epoch_for_call(int row0)
+{
+    thread_local int last_row0 = 0x7fffffff;
+    if (row0 <= last_row0) g_icc_epoch.fetch_add(1, std::memory_order_relaxed);
+    last_row0 = row0;
+}
 static uint64_t table_fingerprint(const void* base, size_t bytes)
 {
     const uint32_t* w = static_cast<const uint32_t*>(base);
@@ -217,7 +229,7 @@ int upload_icc_pow_table(WriteParams& p)
     return 0;
 }
 
-int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p, bool first_rows)
+int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p)
 {
     if (t->grid_points != AVIFGPU_ICC_CLUT_GRID) return fail(AVIFGPU_formatBadParameters, "16-bit ICC table: grid_points must be 33");
     const size_t n = sizeof(t->table);
@@ -240,7 +252,8 @@ int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p, bool first_rows)
         if (e != hipSuccess) { c.icc16 = nullptr; return hip_fail(e, "hipMalloc(icc16 table)", AVIFGPU_memFullErr); }
     }
     const uint64_t fp = table_fingerprint(t->table, n);
-    const bool same_call = !first_rows && c.icc16_src == t && c.icc16_fp == fp && c.icc16_host.size() == n;
+    const uint64_t epoch = g_icc_epoch.load(std::memory_order_relaxed);
+    const bool same_call = c.icc16_epoch == epoch && c.icc16_src == t && c.icc16_fp == fp && c.icc16_host.size() == n;
     if (!same_call && (c.icc16_host.size() != n || memcmp(c.icc16_host.data(), t->table, n) != 0)) {
         std::vector<uint16_t> rec(rec_bytes / 2, 0);
 #if AG_ICC16_DOT2 == 2
@@ -288,12 +301,12 @@ int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p, bool first_rows)
         if (e != hipSuccess) return hip_fail(e, "upload of the ICC table", AVIFGPU_writErr);
         c.icc16_host.assign(reinterpret_cast<const uint8_t*>(t->table), reinterpret_cast<const uint8_t*>(t->table) + n);
     }
-    c.icc16_src = t; c.icc16_fp = fp;
+    c.icc16_src = t; c.icc16_fp = fp; c.icc16_epoch = epoch;
     p.icc16_clut = static_cast<const uint16_t*>(c.icc16);
     return 0;
 }
 
-int upload_icc_sampled(const avifgpu_icc_sampled32* t, WriteParams& p, bool first_rows)
+int upload_icc_sampled(const avifgpu_icc_sampled32* t, WriteParams& p)
 {
     // curve[] (768 KiB) followed by table16[] (24 KiB): one device buffer, one upload when the profile changes
     const size_t nc = sizeof(t->curve), nt = sizeof(t->table16), n = nc + nt;
@@ -312,13 +325,14 @@ int upload_icc_sampled(const avifgpu_icc_sampled32* t, WriteParams& p, bool firs
     const uint8_t* host = reinterpret_cast<const uint8_t*>(t->curve);        // curve[] and table16[] are adjacent members
     static_assert(offsetof(avifgpu_icc_sampled32, table16) == offsetof(avifgpu_icc_sampled32, curve) + sizeof(t->curve), "one span");
     const uint64_t fp = table_fingerprint(host, n);
-    if (!(!first_rows && c.s32_src == t && c.s32_fp == fp && c.s32_host.size() == n) && (c.s32_host.size() != n || memcmp(c.s32_host.data(), host, n) != 0)) {
+    const uint64_t epoch = g_icc_epoch.load(std::memory_order_relaxed);
+    if (!(c.s32_epoch == epoch && c.s32_src == t && c.s32_fp == fp && c.s32_host.size() == n) && (c.s32_host.size() != n || memcmp(c.s32_host.data(), host, n) != 0)) {
         e = hipDeviceSynchronize();                             // a launch may still be reading the previous curves
         if (e == hipSuccess) e = hipMemcpy(c.s32, host, n, hipMemcpyHostToDevice);
         if (e != hipSuccess) return hip_fail(e, "upload of the sampled ICC curves", AVIFGPU_writErr);
         c.s32_host.assign(host, host + n);
     }
-    c.s32_src = t; c.s32_fp = fp;
+    c.s32_src = t; c.s32_fp = fp; c.s32_epoch = epoch;
     p.icc_s_tab = static_cast<const float*>(c.s32);
     p.icc_s_tab16 = reinterpret_cast<const uint16_t*>(static_cast<const uint8_t*>(c.s32) + nc);
     // a mixed profile: the channels of parametric_mask carry a parametric curve (base.trc_type / trc_params), the others a table
@@ -440,7 +454,7 @@ int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const Wr
         if (d->depth != 32 || d->planes < 3) return fail(AVIFGPU_formatBadParameters, "the ICC row transform applies to 32-bit RGB(A) documents");
         if (icc.s32) {
             // sampled curves: the curve stage is the device table; the matrix / output curve below are shared with the parametric form
-            const int rc = upload_icc_sampled(icc.s32, p, row0 == 0);
+            const int rc = upload_icc_sampled(icc.s32, p);
             if (rc) return rc;
         }
         for (int c = 0; c < 3; ++c) {
@@ -495,7 +509,7 @@ int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const Wr
     }
     if (g_icc16) {
         if (d->depth != 16 || d->planes < 3) return fail(AVIFGPU_formatBadParameters, "the 16-bit ICC table applies to 16-bit RGB(A) documents");
-        const int rc = upload_icc16(g_icc16, p, row0 == 0);
+        const int rc = upload_icc16(g_icc16, p);
         if (rc) return rc;
     }
     if (g_icc8) {
@@ -710,6 +724,7 @@ int write_rows_any(const avifgpu_write_desc* d, const IccArgs& icc, int32_t row0
     if ((err = check_write_buffers(d, g, nrows, src, src_row_bytes, dst, dst_stride))) return err;
     if (context_count() == 0) return fail(AVIFGPU_formatBadParameters, "%s", kNoDevice);
     if (nrows == 0) return 0;
+    if (icc.c16 || icc.s32) icc_epoch_for_call(row0);       // the device copies of these tables are re-verified once per device and epoch
 
     if (mem_kind == AVIFGPU_MEM_DEVICE) {
         // zero-copy: the kernel is enqueued on the caller's stream, on the caller's current device (where the pointers live)

@@ -58,8 +58,8 @@ void release_device_caches();                        // read tables + ICC tables
 
 // Device copies of the ICC tables, cached per HIP device, re-uploaded only when the contents change.
 int  upload_icc8(const avifgpu_icc_shaper8* t, WriteParams& p);
-int  upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p, bool first_rows);
-int  upload_icc_sampled(const avifgpu_icc_sampled32* t, WriteParams& p, bool first_rows);
+int  upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p);
+int  upload_icc_sampled(const avifgpu_icc_sampled32* t, WriteParams& p);
 
 // ---- pipeline.hip: bound contexts, staging slots, the row-tile scheduler --------------------------------------------
 // A context = one HIP device ordinal + one worker thread + kSlots staging slots (device in/out buffers, pinned host in/out

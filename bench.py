@@ -35,6 +35,8 @@ Extra objects on the same line:
   c5              BASELINE.json configs[4] (16384 x 16384 RGBA f32 -> 12-bit PQ Y,Cb,Cr,A), the same N-way row split, device-resident
   pcie_inclusive  rank 0 alone, ONE process, the library's in-process row-tile scheduler on the N GPUs of the run
                   (avifgpu_init_devices): page-locked host rows in, host planes out -- what N x16 links buy this path
+  c2, c3, d12, d12_reference_handoff, d8, open_d12, open_d8   N = 1 only (round 6): BASELINE.json configs[1], configs[2], the plug-in's
+                  default HDR / SDR saves and what they decode to -- K rotating launches each: ms, GB_s, frac, kernel (extra_configs)
   cpu_baseline    N = 1 only: the C restatement on the host cores (1 thread whole frame = the comparator; the reference's
                   one-row-buffer loop and an OpenMP all-cores run as sub-fields)
 """
@@ -125,6 +127,108 @@ def measure_traffic_live(args, kernel_name):
                       f"{got['FETCH_SIZE'][1]} + {got['WRITE_SIZE'][1]} launches of {base}; FETCH_SIZE KiB x 2 (gfx950 counts a 128-B read as 64) "
                       f"+ WRITE_SIZE KiB; {time.perf_counter() - t0:.0f} s"}
 
+def extra_configs(torch, pkg, gpu, dev, stream, steps):
+    """Round 6: the other BASELINE.json GPU configurations and the plug-in's DEFAULT saves / open on the driver-run line (N = 1 only,
+    untimed diagnostics beside the headline): per row K >= 20 back-to-back launches ROTATING over disjoint buffer sets (>= 3 sets, > 3.5 GB
+    between two visits of an address, like tools/bench_configs.py) after ~0.15 s of the same kernel as clock ramp, one HIP event pair on
+    the launch stream around them.  ms = span / K; GB_s = algorithmic bytes / ms; frac against the 8 TB/s spec.
+    The dispatch these rows mirror: reference Write.cpp:303-336 (save) and Read.cpp:592-625 (open)."""
+    import harness
+    P = pkg
+    hdr = dict(width=8192, height=8192, depth=32, planes=3, transfer=P.TRANSFER_PQ, peak_nits=80, alpha_state=P.ALPHA_NONE,
+               matrix_coefficients=P.MATRIX_BT2020_NCL, color_primaries=P.PRIMARIES_BT2020)
+    rows = [
+        ("c2", "write", "4096x4096 RGB8 -> 8-bit BT.709 YCbCr 4:2:0 planes (BASELINE.json configs[1])",
+         dict(width=4096, height=4096, depth=8, planes=3, bit_depth=8, alpha_state=0, output=P.OUT_YCBCR, chroma=P.CHROMA_420, matrix_coefficients=1)),
+        ("c3", "write", "8192x8192 RGB16 -> 12-bit BT.2020-NCL YCbCr 4:4:4 planes, SDR clip (BASELINE.json configs[2])",
+         dict(width=8192, height=8192, depth=16, planes=3, bit_depth=12, alpha_state=0, output=P.OUT_YCBCR, chroma=P.CHROMA_444,
+              matrix_coefficients=P.MATRIX_BT2020_NCL, color_primaries=P.PRIMARIES_BT2020)),
+        ("d12", "write", "8192x8192 RGB f32 -> PQ(80 nits) -> 12-bit YCbCr 4:2:2 (top-left chroma sample, libheif 1.14): the plug-in's DEFAULT HDR save "
+                         "(AvifFormat.cpp:89,95), fused hand-off",
+         dict(bit_depth=12, output=P.OUT_YCBCR, chroma=P.CHROMA_422, chroma_downsampling=P.DOWNSAMPLE_NEAREST, **hdr)),
+        ("d12_reference_handoff", "write", "8192x8192 RGB f32 -> PQ(80 nits) -> 12-bit interleaved RRGGBB: the same save through the reference's own "
+                                           "hand-off (WriteHeifImage.cpp:990-1139), what integration/ ships by default",
+         dict(bit_depth=12, output=P.OUT_REFERENCE, **hdr)),
+        ("d8", "write", "8192x8192 RGB8 -> 8-bit BT.601 YCbCr 4:2:2 (top-left chroma sample): the plug-in's DEFAULT SDR save (AvifFormat.cpp:89, "
+                        "WriteMetadata.cpp:138-140)",
+         dict(width=8192, height=8192, depth=8, planes=3, bit_depth=8, alpha_state=0, output=P.OUT_YCBCR, chroma=P.CHROMA_422,
+              chroma_downsampling=P.DOWNSAMPLE_NEAREST, matrix_coefficients=6)),
+        ("open_d12", "read", "8192x8192 12-bit BT.2020-NCL YCbCr 4:2:2 PQ planes -> RGB f32 (what the default HDR save decodes to; "
+                             "ReadHeifImageRGBThirtyTwoBit, YuvDecode.cpp:521-595)",
+         dict(width=8192, height=8192, colorspace=0, chroma=P.CHROMA_422, bit_depth=12, depth=32, alpha_state=0, matrix_coefficients=9, color_primaries=9,
+              transfer_characteristics=16, pq_peak_nits=80)),
+        ("open_d8", "read", "8192x8192 8-bit BT.601 YCbCr 4:2:2 planes -> RGB8 (what the default SDR save decodes to; YuvDecode.cpp:281-326)",
+         dict(width=8192, height=8192, colorspace=0, chroma=P.CHROMA_422, bit_depth=8, depth=8, alpha_state=0, matrix_coefficients=6)),
+    ]
+    out = {}
+    K = max(20, min(steps, 100))
+    for key, direction, workload, kw in rows:
+        try:
+            g = torch.Generator(device=dev)
+            g.manual_seed(1234)
+            calls, keep = [], []
+            if direction == "write":
+                d = P.WriteDesc(**kw)
+                ab = gpu.write_algorithmic_bytes(d, d.height)
+                n = d.height * d.width * d.planes
+                if d.depth == 8:
+                    src0 = torch.randint(0, 256, (n,), generator=g, device=dev, dtype=torch.uint8).view(d.height, -1)
+                elif d.depth == 16:
+                    src0 = torch.randint(0, 32769, (n,), generator=g, device=dev, dtype=torch.int32).to(torch.int16).view(d.height, -1)
+                else:
+                    src0 = make_frame(torch, dev, d.width, d.height, d.planes, 1234)
+                ssz = 2 if d.bit_depth > 8 else 1
+                nset = max(3, min(64, int(-(-3.5e9 // ab))))
+                for j in range(nset):
+                    src = src0 if j == 0 else src0.clone()
+                    bufs, ptrs, strides = {}, [None] * 4, [0] * 4
+                    for pl, (w, xs, ys) in harness.write_planes(d).items():
+                        bufs[pl] = torch.empty(((d.height + ys) >> ys, (w * ssz + 15) // 16 * 16), dtype=torch.uint8, device=dev)
+                        ptrs[pl], strides[pl] = bufs[pl].data_ptr(), bufs[pl].stride(0)
+                    keep.append((src, bufs))
+                    calls.append(lambda src=src, ptrs=ptrs, strides=strides: gpu.write_rows(
+                        d, 0, d.height, src.data_ptr(), src.stride(0) * src.element_size(), ptrs, strides, mem=P.MEM_DEVICE, stream=stream.cuda_stream))
+            else:
+                d = P.ReadDesc(**kw)
+                ab = gpu.read_algorithmic_bytes(d, d.height)
+                maxc, ssz, nch = (1 << d.bit_depth) - 1, (2 if d.bit_depth > 8 else 1), harness.read_channels(d)
+                nset = max(3, min(64, int(-(-3.5e9 // ab))))
+                for j in range(nset):
+                    ptrs, strides, planes = [None] * 4, [0] * 4, []
+                    for i, (pl, (w, xs, ys)) in enumerate(harness.read_planes(d).items()):
+                        h = (d.height + ys) >> ys
+                        wp = (w * ssz + 15) // 16 * 16 // ssz
+                        if j == 0:
+                            t = torch.randint(0, maxc + 1, (h, wp), generator=g, device=dev, dtype=torch.int32).to(torch.int16 if ssz == 2 else torch.uint8).contiguous()
+                        else:
+                            t = keep[0][0][i].clone()
+                        planes.append(t)
+                        ptrs[pl], strides[pl] = t.data_ptr(), t.stride(0) * ssz
+                    o = torch.empty((d.height, d.width * nch * (d.depth // 8)), dtype=torch.uint8, device=dev)
+                    keep.append((planes, o))
+                    calls.append(lambda ptrs=ptrs, strides=strides, o=o: gpu.read_rows(d, 0, d.height, ptrs, strides, o.data_ptr(), o.stride(0),
+                                                                                       mem=P.MEM_DEVICE, stream=stream.cuda_stream))
+            torch.cuda.synchronize(dev)
+            i = 0
+            warm = max(150, min(20000, int(0.15 / max(ab / 5.0e12, 1e-7))))      # ~0.15 s of THIS kernel (tools/bench_configs.py: warm_launches)
+            for _ in range(warm):
+                calls[i % nset](); i += 1
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(K):
+                calls[i % nset](); i += 1
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            ms = e0.elapsed_time(e1) / K
+            out[key] = {"workload": workload, "kernel": gpu.last_kernel(), "launches": K, "sets": nset, "ms": round(ms, 5),
+                        "Mpixels_s": round(d.width * d.height / ms / 1e3, 1), "algorithmic_bytes_per_launch": ab,
+                        "GB_s": round(ab / ms / 1e6, 1), "frac": round(ab / ms / 1e6 / HBM_PEAK_GBPS, 4)}
+            del calls, keep
+        except Exception as exc:      # noqa: BLE001 -- a diagnostic must not lose the headline line
+            out[key] = {"workload": workload, "error": str(exc)}
+    return out
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -148,6 +252,7 @@ def main():
     ap.add_argument("--no-rotate", action="store_true", help="diagnostic: ONE buffer set for the timed region too (the pre-round-5 loop; the line says so)")
     ap.add_argument("--min-footprint-gb", type=float, default=1.25, help="the rotating sets' footprints add up to at least this (>= 4 sets)")
     ap.add_argument("--no-c5", action="store_true", help="skip the configs[4] (16384^2 RGBA f32) sub-measurement")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip c2 / c3 / d12 / d8 / open_* (N = 1 only)")
     ap.add_argument("--no-pattern", action="store_true", help="skip the math-free pattern probe (roofline.peak_measured)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not measure roofline.traffic in this run (two child rocprofv3 --pmc passes); use profiles/traffic.json")
@@ -168,11 +273,15 @@ def main():
         raise SystemExit("bench.py needs a GPU; there is no CPU fallback")
     # AVIFGPU_BENCH_SHARE_DEVICE=1 (rehearsal only): ranks wrap around the visible devices and meet over gloo, so the N > 1
     # code path can be exercised on a 1-GPU box; the numbers of such a run mean nothing.
-    share = os.environ.get("AVIFGPU_BENCH_SHARE_DEVICE") == "1"
+    # AVIFGPU_BENCH_SHARE_DEVICE=nccl: the same wrap-around, but the ranks still ASK for RCCL -- the branch the driver's 8-GPU run takes,
+    # exercised on one GPU (tests/test_gpu_bench_nccl_branch.py): either RCCL accepts two ranks on one device, or every rank falls back to
+    # gloo together (distrib.py) and the line says which.
+    share_mode = os.environ.get("AVIFGPU_BENCH_SHARE_DEVICE", "")
+    share = share_mode in ("1", "nccl")
     dev_index = local_rank % torch.cuda.device_count() if share else local_rank
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
-    ranks = pkg.distrib.Ranks(backend="gloo" if share else "nccl", device=dev)   # RCCL: barrier + MAX only, no pixel traffic
+    ranks = pkg.distrib.Ranks(backend="gloo" if share_mode == "1" else "nccl", device=dev)   # RCCL: barrier + MAX only, no pixel traffic
     rank = ranks.rank
 
     gpu = pkg.AvifGpu(dev_index)
@@ -509,6 +618,8 @@ def main():
         # kept under its old name for readers of rounds 3-4: the rotating figure IS `frac` now
         out["roofline"]["rotating_buffers"] = {"sets": len(sets), "kernel_ms_mean": round(mean_kernel_s * 1e3, 5), "frac": round(achieved / HBM_PEAK_GBPS, 4)}
     out["per_rank"] = per_rank
+    if world > 1:
+        out["rank_backend"] = {"backend": ranks.dist.get_backend() if ranks.dist is not None else None, "fallback_reason": ranks.fallback_reason}
     if cold:
         out["cold_launch"] = cold
         out["roofline"]["cold_first_launch_ms"] = cold["cold_first_launch_ms"]
@@ -564,6 +675,10 @@ def main():
                      "rows_per_gpu": n5, "kernel": gpu.last_kernel(),
                      "per_gpu_GB_s": round(ab5 * k5 / e5 / 1e9, 1), "per_gpu_frac_of_8TBs": round(ab5 * k5 / e5 / 1e9 / HBM_PEAK_GBPS, 4)}
         del f5, p5
+
+    # ---- the other BASELINE configurations and the default saves / opens (N = 1: each needs the whole GPU's memory system to itself) ----
+    if world == 1 and not args.no_extra_configs:
+        out.update(extra_configs(torch, pkg, gpu, dev, stream, args.steps))
 
     # ---- PCIe-inclusive: ONE process (rank 0), the library's in-process scheduler on the N GPUs of this run ----
     ranks.barrier()

@@ -294,6 +294,36 @@ def _gpu(gpu, d, src, icc16):
 
 
 @pytest.mark.gpu
+def test_gpu_table_rewritten_in_place_between_two_tile_calls_is_seen(gpu, lcms):
+    """the device copy of a table is verified byte for byte once per device and EPOCH, and an epoch ends when the caller's row
+    sequence restarts -- not only at row 0 (a device of a multi-GPU save, or a rank that owns rows [k H / N, ...), never sees row 0).
+    A tile at row0 = 16 converted twice with the SAME struct, rewritten in between at a word the strided fingerprint does not sample,
+    must come out like a fresh struct with those contents."""
+    import torch
+    icc = _profile(lcms, *PROFILES[0][1:])
+    clut = gpu.icc_prepare_clut16(icc)
+    dev = f"cuda:{gpu.device}"
+    w, h, r0, n = 256, 64, 16, 32
+    d = pkg.WriteDesc(width=w, height=h, depth=16, planes=3, bit_depth=12, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_REFERENCE)
+    src = torch.zeros((h, w * 3), dtype=torch.int16, device=dev)               # black: the result IS node (0, 0, 0) of the table
+
+    def run(table):
+        out = torch.zeros((h, w * 3), dtype=torch.int16, device=dev)
+        gpu.write_rows(d, r0, n, src[r0].data_ptr(), src.stride(0) * 2, [out[r0].data_ptr(), None, None, None], [out.stride(0) * 2, 0, 0, 0],
+                       mem=pkg.MEM_DEVICE, stream=torch.cuda.current_stream(dev).cuda_stream, icc=table)
+        torch.cuda.synchronize(dev)
+        return out[r0:r0 + n].cpu().numpy()
+    first = run(clut)
+    clut.table[0][2] = (clut.table[0][2] + 0x4000) & 0xffff                   # word 1 of 71 874: the fingerprint reads every 17th word
+    second = run(clut)                                                        # same address, same fingerprint, row0 != 0
+    fresh = pkg.IccClut16()
+    ctypes.memmove(ctypes.byref(fresh), ctypes.byref(clut), ctypes.sizeof(clut))
+    third = run(fresh)
+    assert not np.array_equal(first, third), "the rewrite must change the output of a black tile"
+    assert np.array_equal(second, third), "stale device copy of a table rewritten in place"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,kind,trc,g", PROFILES)
 def test_gpu_16bit_rows_bit_exact(gpu, lcms, name, kind, trc, g):
     """4 M pixels over Photoshop's whole 16-bit range (edges, neutrals, random): fused ICC + 12-bit rescale == range map,

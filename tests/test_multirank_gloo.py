@@ -85,6 +85,44 @@ def test_two_rank_tiles_library(chroma):
     _run_ranks(chroma, use_gpu=True)
 
 
+def _nccl_fallback_worker(rank, world, port, q, errdir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.stderr = open(os.path.join(errdir, f"rank{rank}.err"), "w")
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+    pkg = entry.load_package()
+    ranks = pkg.distrib.Ranks(backend="nccl", device=None)            # no GPU here: RCCL cannot come up
+    assert ranks.dist.get_backend() == "gloo" and ranks.fallback_reason
+    assert ranks.max_over_ranks(float(rank + 1)) == float(world)
+    got = ranks.gather_objects(rank)
+    ranks.host_barrier()
+    ranks.close()
+    sys.stderr.flush()
+    q.put((rank, got))
+
+
+def test_nccl_request_without_rccl_falls_back_to_gloo_on_every_rank(tmp_path):
+    """bench.py asks for backend "nccl"; where RCCL cannot come up (here: no GPU at all) EVERY rank moves to gloo together -- the vote of
+    distrib.Ranks._init_nccl_or_gloo -- rank 0 says so in exactly ONE stderr line, and barrier / MAX / gather work."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: tests/test_gpu_bench_nccl_branch.py covers the GPU outcome")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nccl_fallback_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [(0, [0, 1]), (1, [0, 1])]
+    lines0 = [l for l in open(tmp_path / "rank0.err").read().splitlines() if l.startswith("[distrib]")]
+    lines1 = [l for l in open(tmp_path / "rank1.err").read().splitlines() if l.startswith("[distrib]")]
+    assert len(lines0) == 1 and "using gloo" in lines0[0] and lines1 == [], (lines0, lines1)
+
+
 def test_row_tiles_partition():
     sys.path.insert(0, ROOT)
     import __graft_entry__ as entry
