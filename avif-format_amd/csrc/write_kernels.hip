@@ -2434,7 +2434,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr_sub_hot(con
 // Rescale (per sample) and the integer premultiply (per pixel) run on the vector as loaded; the codes go back into the same two
 // dwords per pixel and cross the strip as one ds_write_b128 (lane stride padded 16 -> 20 dwords: conflict-free b128 read-back);
 // lane l then holds pixels [8l, 8l+8) and writes 16 bytes per plane.  width % 8 == 0 (whole lanes).
-template <int PART_ANCHOR = 0>          // a template only so that it is emitted where it is launched (the streaming part)
+template <bool TO8 = false>             // TO8 (round 6): a transparent 16-bit document saved at 8 bit -- the same codes in bytes, u8 planes (see write_rgb16_ycbcr_sub_hot)
 __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra444_hot(const WriteParams p)
 {
     constexpr int PXL = 8, K = 4, SPAN_PX = 512, LSTRIDE = 20;
@@ -2491,13 +2491,18 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra444_hot(co
             crv[i] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
         }
         if (PXL * lane < span_px) {
-            const long long xoff = ((long long)sx * SPAN_PX + (long long)PXL * lane) * 2;
+            const long long xoff = ((long long)sx * SPAN_PX + (long long)PXL * lane) * (TO8 ? 1 : 2);
             const uint32_t* pl[4] = { yv, cbv, crv, av };
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const uint32_t* q = pl[c];
+                if constexpr (TO8) {
+                    u32x2 o = { q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24), q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24) };
+                    g_store_nt(o, reinterpret_cast<u32x2*>(p.dst[c] + (long long)r * p.dst_stride[c] + xoff));
+                } else {
                 u32x4 o = { q[0] | (q[1] << 16), q[2] | (q[3] << 16), q[4] | (q[5] << 16), q[6] | (q[7] << 16) };
                 g_store_nt(o, reinterpret_cast<u32x4*>(p.dst[c] + (long long)r * p.dst_stride[c] + xoff));
+                }
             }
         }
     }
@@ -2508,7 +2513,9 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra444_hot(co
 // lane and plane), the chroma box sums (integer codes <= 4095: exact in float in any order) stay in 12 registers; a lane's 8 pixels are the
 // footprint of 4 chroma samples = 8 bytes per chroma plane.  width % 8 == 0, rows and planes 16- (chroma: 8-) byte aligned; the generic kernel ran
 // these at 0.76 of 8 TB/s.
-template <int YS, bool NEAREST>
+// TO8 (round 6): the same document saved at 8 bit (the rescale and the premultiply are the same expressions with maxValue 255; the codes fit
+// bytes and the planes are u8: 8 bytes of luma and of alpha, 4 of each chroma plane per lane).  Ran on the generic kernel until then (0.70).
+template <int YS, bool NEAREST, bool TO8 = false>
 __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra_sub_hot(const WriteParams p)
 {
     constexpr int PXL = 8, K = 4, SPAN_PX = 512, LSTRIDE = 20, VR = 1 << YS;
@@ -2533,7 +2540,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra_sub_hot(c
             for (int k = 0; k < K; ++k) cur[vr][k] = g_load_nt(sp + min(64 * k + lane, span_v - 1));
         }
         const bool inside = PXL * lane < span_px;
-        const long long xoff = ((long long)sx * SPAN_PX + (long long)PXL * lane) * 2;
+        const long long xoff = ((long long)sx * SPAN_PX + (long long)PXL * lane) * (TO8 ? 1 : 2);
         uint32_t acc01[4], acc2[4];                                                // the box sums as packed u16 integers (R | G << 16, B | .): <= 4 x 4095 per half
 #pragma unroll
         for (int vr = 0; vr < VR; ++vr) {
@@ -2573,10 +2580,17 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra_sub_hot(c
             }
             const int r = (int)(gy * VR) + vr;
             if (inside && r < p.nrows) {                                           // (odd last row of the tile: replicated for chroma only)
+                if constexpr (TO8) {
+                    g_store_nt(u32x2{ yv[0] | (yv[1] << 8) | (yv[2] << 16) | (yv[3] << 24), yv[4] | (yv[5] << 8) | (yv[6] << 16) | (yv[7] << 24) },
+                               reinterpret_cast<u32x2*>(p.dst[0] + (long long)r * p.dst_stride[0] + xoff));
+                    g_store_nt(u32x2{ av[0] | (av[1] << 8) | (av[2] << 16) | (av[3] << 24), av[4] | (av[5] << 8) | (av[6] << 16) | (av[7] << 24) },
+                               reinterpret_cast<u32x2*>(p.dst[3] + (long long)r * p.dst_stride[3] + xoff));
+                } else {
                 g_store_nt(u32x4{ yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) },
                            reinterpret_cast<u32x4*>(p.dst[0] + (long long)r * p.dst_stride[0] + xoff));
                 g_store_nt(u32x4{ av[0] | (av[1] << 16), av[2] | (av[3] << 16), av[4] | (av[5] << 16), av[6] | (av[7] << 16) },
                            reinterpret_cast<u32x4*>(p.dst[3] + (long long)r * p.dst_stride[3] + xoff));
+                }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {                                          // pixels 2j, 2j + 1 = dwords 4j .. 4j + 3 (the alpha halves ride along, unused)
@@ -2598,9 +2612,14 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra_sub_hot(c
             crv[j] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
         }
         if (inside) {
-            const long long coff = xoff >> 1;                                      // 4 chroma samples of 2 bytes per lane
+            const long long coff = xoff >> 1;                                      // 4 chroma samples of 2 bytes (TO8: 1 byte) per lane
+            if constexpr (TO8) {
+                g_store_nt(cbv[0] | (cbv[1] << 8) | (cbv[2] << 16) | (cbv[3] << 24), reinterpret_cast<uint32_t*>(p.dst[1] + (long long)gy * p.dst_stride[1] + coff));
+                g_store_nt(crv[0] | (crv[1] << 8) | (crv[2] << 16) | (crv[3] << 24), reinterpret_cast<uint32_t*>(p.dst[2] + (long long)gy * p.dst_stride[2] + coff));
+            } else {
             g_store_nt(u32x2{ cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16) }, reinterpret_cast<u32x2*>(p.dst[1] + (long long)gy * p.dst_stride[1] + coff));
             g_store_nt(u32x2{ crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16) }, reinterpret_cast<u32x2*>(p.dst[2] + (long long)gy * p.dst_stride[2] + coff));
+            }
         }
     }
 }
@@ -2618,6 +2637,9 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra_sub_hot(c
 // (tests/test_gpu_kernel_equivalence.py).  Widths that are multiples of 8, rows and planes dword-aligned; everything else stays generic.
 #ifndef AG_RGB8_HOT
 #define AG_RGB8_HOT 1
+#endif
+#ifndef AG_RGB8_16_WAVES
+#define AG_RGB8_16_WAVES 2         /* waves per workgroup of write_rgb8_ycbcr16_hot */
 #endif
 #ifndef AG_RGB8_FIRST_CACHED
 #define AG_RGB8_FIRST_CACHED 0     /* 1 = the first of a span's loads allocates; 0 = all non-temporal (equal or ahead on truly fresh data: kernel_params.h, AG_EDGE_CACHED) */
@@ -2773,6 +2795,119 @@ __global__ __launch_bounds__(64 * kRgb8Waves) void write_rgb8_ycbcr_hot(const Wr
         } else {
             span_store16<true>(span_rsrc(p.dst[1] + (long long)gy * p.dst_stride[1] + coff, cbytes), voff, u32x4{ cbpk[0], cbpk[1], cbpk[2], cbpk[3] });
             span_store16<true>(span_rsrc(p.dst[2] + (long long)gy * p.dst_stride[2] + coff, cbytes), voff, u32x4{ crpk[0], crpk[1], crpk[2], crpk[3] });
+        }
+    }
+}
+
+// ---- RGB8 -> Y, Cb, Cr u16 planes (round 6): an 8-bit document saved at 10 or 12 bit (WriteHeifImage.cpp:657-727) ---------------------------
+// The last colour save without a profile that still ran on the generic kernel (0.69 of 8 TB/s on fresh data).  Same front end as
+// write_rgb8_ycbcr_hot: a wave owns a span of 1024 pixels on 1 or 2 rows, three coalesced 1-KiB buffer loads per row, the row through the
+// wave-private strip (3 KiB).  The planes are u16 here, so a lane's share is read back as TWO groups of 8 pixels -- pixels [8 l, 8 l + 8)
+// of each 512-pixel HALF of the span (24 bytes at byte 1536 h + 24 l: three ds_read_b64) -- and every store instruction then writes
+// 16 (chroma 4:2:x: 8) bytes per lane that are contiguous across the wave, like the f32 kernels' (one lane holding 16 neighbouring
+// pixels would store two 16-byte vectors at a 32-byte lane stride).
+// Stage A is BuildEightBitToHeifImageLookup's entry (:87-112), (int)((i / 255.0f) * max + 0.5f), evaluated arithmetically as
+// floor(fma(i, max / 255, 0.5)): i * max / 255 never comes closer to a half-integer than 1 / 170 (max = 1023: i * 341 / 85; 4095: i * 273 / 17
+// -- twice the value is even over odd), 20x the float error of either form, so the two agree on all 256 inputs at both depths
+// (tests/test_oracle_properties.py::test_rescale8_fma_form_equals_the_table).  The levels are integer-valued floats: what stage B wants
+// (luma_pair_nc, the chroma sums of the f32 4:2:x kernel).  Same bytes as the generic kernel (tests/test_gpu_kernel_equivalence.py).
+// Widths that are multiples of 8, rows and planes dword-aligned; everything else stays generic.
+template <int XS, int YS, bool NEAREST, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void write_rgb8_ycbcr16_hot(const WriteParams p)
+{
+    constexpr int K = 3, SPAN_PX = 1024, HALF_PX = 512, PXH = 8, VR = 1 << YS, NCH = PXH >> XS;
+    __shared__ __attribute__((aligned(16))) uint32_t strip[WAVES][SPAN_PX * 3 / 4];
+    const int wave = wave_in_block();
+    const int lane = threadIdx.x & 63;
+    const uint32_t voff = (uint32_t)lane * 16u;
+    u32x4* my4 = reinterpret_cast<u32x4*>(strip[wave]);
+    const u32x2* my2 = reinterpret_cast<const u32x2*>(strip[wave]);
+    const float ks = p.maxv > 1023 ? (4095.0f / 255.0f) : (1023.0f / 255.0f);      // RN(max / 255): folded at compile time
+    const uint32_t spans_per_row = ((uint32_t)p.width + SPAN_PX - 1) / SPAN_PX;
+    const uint32_t groups = ((uint32_t)p.nrows + VR - 1) >> YS;
+    const uint32_t total = spans_per_row * groups;
+    for (uint32_t sidx = blockIdx.x * WAVES + wave; sidx < total; sidx += gridDim.x * WAVES) {
+        const uint32_t gy = sidx / spans_per_row;
+        const uint32_t sx = sidx - gy * spans_per_row;
+        const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);             // < SPAN_PX only for the last span of a row; a multiple of 8
+        f32x4 v[VR][K];
+#pragma unroll
+        for (int vr = 0; vr < VR; ++vr) {                                          // every load of the span group in flight before the first is used
+            const int r = min((int)(gy * VR) + vr, p.rows_to_end - 1);             // bottom edge: replicate the last IMAGE row
+            const __amdgpu_buffer_rsrc_t rs = span_rsrc(p.src + (long long)r * p.src_row_bytes + (long long)sx * (SPAN_PX * 3), (uint32_t)span_px * 3u);
+#pragma unroll
+            for (int k = 0; k < K; ++k) v[vr][k] = span_load16<true>(rs, voff, 1024u * k);
+        }
+        uint32_t raw[VR][2][6];                                                    // [row][half][24 bytes = 8 pixels]
+#pragma unroll
+        for (int vr = 0; vr < VR; ++vr) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) my4[64 * k + lane] = __builtin_bit_cast(u32x4, v[vr][k]);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const u32x2 t = my2[(HALF_PX * 3 / 8) * h + 3 * lane + j];
+                    raw[vr][h][2 * j] = t.x; raw[vr][h][2 * j + 1] = t.y;
+                }
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int half_px = min(HALF_PX, span_px - HALF_PX * h);                // pixels of the row in this half (wave-uniform); <= 0: nothing
+            if (half_px <= 0) break;
+            const long long xs16 = ((long long)sx * SPAN_PX + HALF_PX * h) * 2;     // byte offset of the half in a luma row
+            float acc[NCH][3];
+#pragma unroll
+            for (int vr = 0; vr < VR; ++vr) {
+                float c[PXH * 3];                                                  // the levels: R0 G0 B0 R1 ... (integer-valued floats)
+#pragma unroll
+                for (int e = 0; e < PXH * 3; ++e) {
+                    const float b = (float)((raw[vr][h][e >> 2] >> (8 * (e & 3))) & 0xffu);       // v_cvt_f32_ubyteN
+                    c[e] = __builtin_floorf(__builtin_fmaf(b, ks, 0.5f));
+                }
+                const int r = (int)(gy * VR) + vr;
+                if (r < p.nrows) {                                                 // (odd last row of the tile: replicated for chroma only)
+                    uint32_t yv[PXH];
+#pragma unroll
+                    for (int i = 0; i < PXH; i += 2) luma_pair_nc(p, &c[3 * i], yv[i], yv[i + 1]);
+                    u32x4 a = { yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16), yv[4] | (yv[5] << 16), yv[6] | (yv[7] << 16) };
+                    span_store_samples8<true>(p.dst[0] + (long long)r * p.dst_stride[0] + xs16, (uint32_t)half_px, (uint32_t)lane, a);
+                }
+#pragma unroll
+                for (int j = 0; j < NCH; ++j)
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const float left = c[3 * (j << XS) + ch];
+                        if constexpr (XS == 0 || NEAREST) {
+                            if (vr == 0) acc[j][ch] = left;
+                        } else {                                                   // integer sums below 2^15: exact in any order (see write_rgb32_ycbcr_sub_hot)
+                            const float pair = left + c[3 * (2 * j + 1) + ch];
+                            if (vr == 0) acc[j][ch] = YS ? pair : pair + pair;
+                            else acc[j][ch] += pair;
+                        }
+                    }
+            }
+            uint32_t cbv[NCH], crv[NCH];
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                constexpr bool AVG = XS != 0 && !NEAREST;
+                const float R = AVG ? acc[j][0] * 0.25f : acc[j][0], G = AVG ? acc[j][1] * 0.25f : acc[j][1], B = AVG ? acc[j][2] * 0.25f : acc[j][2];
+                cbv[j] = clip_round(R * p.mcb[0] + G * p.mcb[1] + B * p.mcb[2] + p.half, p.maxv);
+                crv[j] = clip_round(R * p.mcr[0] + G * p.mcr[1] + B * p.mcr[2] + p.half, p.maxv);
+            }
+            const uint32_t csamples = (uint32_t)half_px >> XS;
+            const long long coff = xs16 >> XS;
+            if constexpr (XS) {
+                span_store_samples4<true>(p.dst[1] + (long long)gy * p.dst_stride[1] + coff, csamples, (uint32_t)lane, u32x2{ cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16) });
+                span_store_samples4<true>(p.dst[2] + (long long)gy * p.dst_stride[2] + coff, csamples, (uint32_t)lane, u32x2{ crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16) });
+            } else {
+                span_store_samples8<true>(p.dst[1] + (long long)gy * p.dst_stride[1] + coff, csamples, (uint32_t)lane,
+                                          u32x4{ cbv[0] | (cbv[1] << 16), cbv[2] | (cbv[3] << 16), cbv[4] | (cbv[5] << 16), cbv[6] | (cbv[7] << 16) });
+                span_store_samples8<true>(p.dst[2] + (long long)gy * p.dst_stride[2] + coff, csamples, (uint32_t)lane,
+                                          u32x4{ crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16), crv[4] | (crv[5] << 16), crv[6] | (crv[7] << 16) });
+            }
         }
     }
 }
@@ -3138,6 +3273,41 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_int_ref_stream(const Wr
     }
 }
 
+// ---- 8-bit documents saved at 8 bit through the reference's own hand-off: a COPY (round 6) ---------------------------------------------------
+// CreateHeifImageRGBEightBit / ...GrayEightBit at 8 bit without premultiplication write the host's bytes as they are (WriteHeifImage.cpp:756-801,
+// :247-252 for gray without alpha): no per-sample work at all.  The generic kernel ran this at 0.76 of 8 TB/s (its loads allocate: 0.89 in a
+// one-set loop), write_int_ref_stream at 0.71.  Here a wave owns 4 KiB of a row: four 1-KiB non-temporal buffer loads, four stores at the same
+// offsets, nothing else; a tile whose rows are contiguous on both sides is ONE row (the launcher).  Row bytes, pointers and strides dword-aligned.
+struct CopyParams { const uint8_t* src; uint8_t* dst; long long src_stride, dst_stride, row_bytes; int32_t nrows; };
+#ifndef AG_COPY_BLOCK
+#define AG_COPY_BLOCK 128
+#endif
+template <int K>
+__global__ __launch_bounds__(AG_COPY_BLOCK) void copy_rows_stream(const CopyParams c)
+{
+    constexpr int WAVES = AG_COPY_BLOCK / 64;
+    const int wave = wave_in_block();
+    const uint32_t voff = (uint32_t)(threadIdx.x & 63) * 16u;
+    const uint32_t chunks = (uint32_t)((c.row_bytes + (1024 * K - 1)) / (1024 * K));
+    const uint32_t total = chunks * (uint32_t)c.nrows;                             // < 2^31 (host)
+    for (uint32_t widx = blockIdx.x * WAVES + wave; widx < total; widx += gridDim.x * WAVES) {
+        const uint32_t r = widx / chunks;
+        const long long off = (long long)(widx - r * chunks) * (1024 * K);
+        const long long left = c.row_bytes - off;
+        const uint32_t bytes = left < 1024 * K ? (uint32_t)left : (uint32_t)(1024 * K);
+        const __amdgpu_buffer_rsrc_t rs = span_rsrc(c.src + (long long)r * c.src_stride + off, bytes);
+        const __amdgpu_buffer_rsrc_t rd = span_rsrc(c.dst + (long long)r * c.dst_stride + off, bytes);
+        f32x4 v[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = span_load16<true>(rs, voff, 1024u * k);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if constexpr (AG_MATH_ONLY) mo_sink(v[k]);
+            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v[k]), rd, (int)voff, 1024 * k, 2);
+        }
+    }
+}
+
 // ---- dispatch --------------------------------------------------------------------------------------
 #ifndef AG_RGBA_BLOCK_CAP
 #define AG_RGBA_BLOCK_CAP (256LL * 512)       // C5 (1 M spans): 1.18 ms at 16k blocks, 1.01 at 64k, 0.99 at 128k, 1.01 at 256k
@@ -3373,6 +3543,9 @@ hipError_t launch_planes_d32_icc6(const WriteParams& p, int planes, bool dst16, 
 #ifndef AG_IREF8
 #define AG_IREF8 1
 #endif
+#ifndef AG_COPY8
+#define AG_COPY8 1
+#endif
 // The streaming launches in three code objects (AG_WRITE_PART 1 / 2 / 3, see the top of the file): every `return` inside one of the two
 // functions below is a launch (or an empty tile) -- *taken says so; falling off the end hands the tile to the next candidate.
 hipError_t launch_stream_int(const WriteParams& p, int depth, int planes, bool dst16, int output, int xs, int ys, int variant, hipStream_t st, char* label, bool* taken);
@@ -3381,6 +3554,25 @@ hipError_t launch_stream_f32_sub_rgba(const WriteParams& p, int depth, int plane
 hipError_t launch_stream_int(const WriteParams& p, int depth, int planes, bool dst16, int output, int xs, int ys, int variant, hipStream_t st, char* label, bool* taken)
 {
     *taken = true;
+    // 8-bit document, 8-bit hand-off, nothing to premultiply: the reference copies the bytes (round 6)
+    if (AG_COPY8 && (variant & 1) && p.icc8_s1 == nullptr && depth == 8 && !dst16 && p.maxv == 255 && output == AVIFGPU_OUT_REFERENCE &&
+        (planes == 3 || planes == 1 || (planes == 4 && !p.premultiply)) &&
+        (((long long)p.width * planes) & 3) == 0 && ((p.src_row_bytes | p.dst_stride[0]) & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(p.src) | reinterpret_cast<uintptr_t>(p.dst[0])) & 3) == 0) {
+        CopyParams c = { p.src, p.dst[0], p.src_row_bytes, p.dst_stride[0], (long long)p.width * planes, p.nrows };
+        const bool one = !(variant & 16) && c.nrows > 1 && c.src_stride == c.row_bytes && c.dst_stride == c.row_bytes;     // contiguous on both sides: one row
+        if (one) { c.row_bytes *= c.nrows; c.nrows = 1; }
+        constexpr int kCopyK = 4, kCopyWaves = AG_COPY_BLOCK / 64;
+        const long long waves = ((c.row_bytes + 1024 * kCopyK - 1) / (1024 * kCopyK)) * c.nrows;
+        if (waves == 0) return hipSuccess;
+        if (waves + 8LL * 65536 * 4 < 0x7fffffffLL) {
+            long long blocks = (waves + kCopyWaves - 1) / kCopyWaves;
+            if (blocks > AG_STREAM_BLOCK_CAP * 4 / kCopyWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kCopyWaves;
+            snprintf(label, kLabelBytes, "copy_rows_stream<planes=%d>%s", planes, one ? " flat" : "");
+            hipLaunchKernelGGL((copy_rows_stream<kCopyK>), dim3((int)blocks), dim3(AG_COPY_BLOCK), 0, st, c);
+            return hipGetLastError();
+        }
+    }
     if ((variant & 1) && p.icc16_clut == nullptr && p.icc8_s1 == nullptr && (depth == 16 || (AG_IREF8 && depth == 8 && planes == 4)) &&
         ((planes >= 3 && output == AVIFGPU_OUT_REFERENCE) || (planes == 1 && depth == 16)) &&      // (Gray16 -> Y plane: elementwise too, round 5)
         ((long long)p.width * planes * (depth / 8)) % 16 == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
@@ -3433,6 +3625,26 @@ hipError_t launch_stream_int(const WriteParams& p, int depth, int planes, bool d
             return hipGetLastError();
         }
     }
+    // RGB8 -> u16 Y, Cb, Cr (round 6): an 8-bit document saved at 10 / 12 bit; the same conditions
+    if (AG_RGB8_HOT && (variant & 1) && p.icc8_s1 == nullptr && depth == 8 && planes == 3 && dst16 && output == AVIFGPU_OUT_YCBCR && (p.maxv == 1023 || p.maxv == 4095) &&
+        (p.width % 8) == 0 && (p.src_row_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) |
+          (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2]) & 3) == 0) {
+        const long long spans = (long long)((p.width + 1023) / 1024) * ((p.nrows + (1 << ys) - 1) >> ys);
+        if (spans == 0) return hipSuccess;
+        if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
+            constexpr int wpb = AG_RGB8_16_WAVES;
+            long long blocks = (spans + wpb - 1) / wpb;
+            if (blocks > AG_STREAM_BLOCK_CAP * 4 / wpb) blocks = AG_STREAM_BLOCK_CAP * 4 / wpb;
+            snprintf(label, kLabelBytes, "write_rgb8_ycbcr16_hot<xs=%d,ys=%d,nearest=%d>", xs, ys, (xs || ys) ? p.nearest : 0);
+#define AG_R816(XS_, YS_, NR_) hipLaunchKernelGGL((write_rgb8_ycbcr16_hot<XS_, YS_, NR_, wpb>), dim3((int)blocks), dim3(64 * wpb), 0, st, p)
+            if (xs == 0) AG_R816(0, 0, false);
+            else if (ys == 0) { if (p.nearest) AG_R816(1, 0, true); else AG_R816(1, 0, false); }
+            else { if (p.nearest) AG_R816(1, 1, true); else AG_R816(1, 1, false); }
+#undef AG_R816
+            return hipGetLastError();
+        }
+    }
     // RGBA8 -> u8 Y, Cb, Cr, A (a transparent 8-bit document's save): widths of whole 8-pixel groups, dword-aligned rows and planes
     if (AG_RGB8_HOT && (variant & 1) && p.icc8_s1 == nullptr && depth == 8 && planes == 4 && !dst16 && output == AVIFGPU_OUT_YCBCR && p.maxv == 255 && p.dst[3] != nullptr &&
         (p.width % 8) == 0 && (p.src_row_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 3) == 0 &&
@@ -3480,7 +3692,7 @@ hipError_t launch_stream_int(const WriteParams& p, int depth, int planes, bool d
 #define AG_RGBA16_MIN_PX 0
 #endif
     // RGBA16 -> u16 Y, Cb, Cr, A 4:4:4
-    if ((variant & 1) && p.icc16_clut == nullptr && depth == 16 && planes == 4 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 0 && ys == 0 &&
+    if ((variant & 1) && p.icc16_clut == nullptr && depth == 16 && planes == 4 && (dst16 || p.maxv == 255) && output == AVIFGPU_OUT_YCBCR && xs == 0 && ys == 0 &&
         ((long long)p.width * p.nrows >= AG_RGBA16_MIN_PX || (variant & 8)) && p.dst[3] != nullptr &&
         (p.width % 8) == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) | reinterpret_cast<uintptr_t>(p.dst[3]) |
@@ -3490,13 +3702,14 @@ hipError_t launch_stream_int(const WriteParams& p, int depth, int planes, bool d
         if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
             long long blocks = (spans + kStreamWaves - 1) / kStreamWaves;
             if (blocks > AG_STREAM_BLOCK_CAP * 4 / kStreamWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kStreamWaves;
-            snprintf(label, kLabelBytes, "write_rgba16_ycbcra444_hot");
-            hipLaunchKernelGGL((write_rgba16_ycbcra444_hot<0>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p);
+            snprintf(label, kLabelBytes, "write_rgba16_ycbcra444_hot%s", dst16 ? "" : "<to8>");
+            if (dst16) hipLaunchKernelGGL((write_rgba16_ycbcra444_hot<false>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p);
+            else hipLaunchKernelGGL((write_rgba16_ycbcra444_hot<true>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p);
             return hipGetLastError();
         }
     }
     // RGBA16 -> u16 Y, Cb, Cr (4:2:2 / 4:2:0), A: the plug-in's default save of a transparent 16-bit document (round 5, last series)
-    if ((variant & 1) && p.icc16_clut == nullptr && depth == 16 && planes == 4 && dst16 && output == AVIFGPU_OUT_YCBCR && xs == 1 && p.dst[3] != nullptr &&
+    if ((variant & 1) && p.icc16_clut == nullptr && depth == 16 && planes == 4 && (dst16 || p.maxv == 255) && output == AVIFGPU_OUT_YCBCR && xs == 1 && p.dst[3] != nullptr &&
         (p.width % 8) == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[3]) | (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[3]) & 15) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2]) & 7) == 0) {
@@ -3505,11 +3718,13 @@ hipError_t launch_stream_int(const WriteParams& p, int depth, int planes, bool d
         if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
             long long blocks = (spans + kStreamWaves - 1) / kStreamWaves;
             if (blocks > AG_STREAM_BLOCK_CAP * 4 / kStreamWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kStreamWaves;
-            snprintf(label, kLabelBytes, "write_rgba16_ycbcra_sub_hot<ys=%d,nearest=%d>", ys, p.nearest);
-#define AG_RA16(YS_) do { if (p.nearest) hipLaunchKernelGGL((write_rgba16_ycbcra_sub_hot<YS_, true>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); \
-                          else hipLaunchKernelGGL((write_rgba16_ycbcra_sub_hot<YS_, false>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); } while (0)
+            snprintf(label, kLabelBytes, "write_rgba16_ycbcra_sub_hot<ys=%d,nearest=%d%s>", ys, p.nearest, dst16 ? "" : ",to8");
+#define AG_RA16B(YS_, T8) do { if (p.nearest) hipLaunchKernelGGL((write_rgba16_ycbcra_sub_hot<YS_, true, T8>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); \
+                               else hipLaunchKernelGGL((write_rgba16_ycbcra_sub_hot<YS_, false, T8>), dim3((int)blocks), dim3(AG_STREAM_BLOCK), 0, st, p); } while (0)
+#define AG_RA16(YS_) do { if (dst16) AG_RA16B(YS_, false); else AG_RA16B(YS_, true); } while (0)
             if (ys) AG_RA16(1); else AG_RA16(0);
 #undef AG_RA16
+#undef AG_RA16B
             return hipGetLastError();
         }
     }

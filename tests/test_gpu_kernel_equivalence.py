@@ -69,6 +69,23 @@ CASES = [
                                   matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)),
     ("write_rgb8_ycbcr_hot", dict(width=16, height=2, depth=8, planes=3, bit_depth=8, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444,
                                   matrix_coefficients=pkg.MATRIX_RGB_GBR)),
+    # round 6: RGB8 -> u16 planes (an 8-bit document saved at 10 / 12 bit): whole spans, a ragged last span inside the first and inside the second
+    # 512-pixel half, a single 8-pixel group; odd heights; box and nearest
+    ("write_rgb8_ycbcr16_hot", dict(width=2048, height=6, depth=8, planes=3, bit_depth=10, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420,
+                                    matrix_coefficients=pkg.MATRIX_BT709, color_primaries=pkg.PRIMARIES_BT709)),
+    ("write_rgb8_ycbcr16_hot", dict(width=1512, height=7, depth=8, planes=3, bit_depth=12, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420,
+                                    matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)),
+    ("write_rgb8_ycbcr16_hot", dict(width=1320, height=5, depth=8, planes=3, bit_depth=12, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420,
+                                    chroma_downsampling=pkg.DOWNSAMPLE_NEAREST, matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)),
+    ("write_rgb8_ycbcr16_hot", dict(width=1000, height=5, depth=8, planes=3, bit_depth=10, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_422,
+                                    chroma_downsampling=pkg.DOWNSAMPLE_NEAREST, matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)),
+    ("write_rgb8_ycbcr16_hot", dict(width=1544, height=4, depth=8, planes=3, bit_depth=12, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_422,
+                                    matrix_coefficients=pkg.MATRIX_BT709, color_primaries=pkg.PRIMARIES_BT709)),
+    ("write_rgb8_ycbcr16_hot", dict(width=1032, height=3, depth=8, planes=3, bit_depth=10, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444, **BT2020)),
+    ("write_rgb8_ycbcr16_hot", dict(width=8, height=1, depth=8, planes=3, bit_depth=12, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420,
+                                    matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)),
+    ("write_rgb8_ycbcr16_hot", dict(width=520, height=2, depth=8, planes=3, bit_depth=12, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444,
+                                    matrix_coefficients=pkg.MATRIX_RGB_GBR)),
     # round 5: RGBA8 -> u8 planes + alpha (straight and premultiplied), every chroma format
     ("write_rgba8_ycbcra_hot", dict(width=1024, height=6, depth=8, planes=4, bit_depth=8, alpha_state=pkg.ALPHA_PREMULTIPLIED, output=pkg.OUT_YCBCR,
                                     chroma=pkg.CHROMA_420, matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)),
@@ -117,6 +134,24 @@ CASES = [
                                          chroma=pkg.CHROMA_422, matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)),
     ("write_rgba16_ycbcra_sub_hot", dict(width=8, height=1, depth=16, planes=4, bit_depth=12, alpha_state=pkg.ALPHA_STRAIGHT, output=pkg.OUT_YCBCR,
                                          chroma=pkg.CHROMA_420, **BT2020)),
+    # round 6: ... saved at 8 bit (u8 planes): 4:2:0 / 4:2:2 / 4:4:4, premultiplied and straight
+    ("write_rgba16_ycbcra_sub_hot", dict(width=1024, height=6, depth=16, planes=4, bit_depth=8, alpha_state=pkg.ALPHA_PREMULTIPLIED, output=pkg.OUT_YCBCR,
+                                         chroma=pkg.CHROMA_420, matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)),
+    ("write_rgba16_ycbcra_sub_hot", dict(width=1000, height=7, depth=16, planes=4, bit_depth=8, alpha_state=pkg.ALPHA_STRAIGHT, output=pkg.OUT_YCBCR,
+                                         chroma=pkg.CHROMA_420, chroma_downsampling=pkg.DOWNSAMPLE_NEAREST, matrix_coefficients=pkg.MATRIX_BT709, color_primaries=pkg.PRIMARIES_BT709)),
+    ("write_rgba16_ycbcra_sub_hot", dict(width=520, height=5, depth=16, planes=4, bit_depth=8, alpha_state=pkg.ALPHA_PREMULTIPLIED, output=pkg.OUT_YCBCR,
+                                         chroma=pkg.CHROMA_422, chroma_downsampling=pkg.DOWNSAMPLE_NEAREST, matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)),
+    ("write_rgba16_ycbcra_sub_hot", dict(width=8, height=1, depth=16, planes=4, bit_depth=8, alpha_state=pkg.ALPHA_PREMULTIPLIED, output=pkg.OUT_YCBCR,
+                                         chroma=pkg.CHROMA_422, matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)),
+    ("write_rgba16_ycbcra444_hot", dict(width=1000, height=4, depth=16, planes=4, bit_depth=8, alpha_state=pkg.ALPHA_PREMULTIPLIED,
+                                        output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444, matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)),
+    # round 6: 8-bit documents through the 8-bit hand-off without premultiplication are a copy (contiguous rows: one flat row; padded rows; ragged ends)
+    ("copy_rows_stream", dict(width=1024, height=5, depth=8, planes=3, bit_depth=8, output=pkg.OUT_REFERENCE)),
+    ("copy_rows_stream", dict(width=1000, height=7, depth=8, planes=3, bit_depth=8, output=pkg.OUT_REFERENCE)),
+    ("copy_rows_stream", dict(width=2732, height=3, depth=8, planes=3, bit_depth=8, output=pkg.OUT_REFERENCE)),
+    ("copy_rows_stream", dict(width=1001, height=4, depth=8, planes=4, bit_depth=8, alpha_state=pkg.ALPHA_STRAIGHT, output=pkg.OUT_REFERENCE)),
+    ("copy_rows_stream", dict(width=4100, height=3, depth=8, planes=1, bit_depth=8)),
+    ("copy_rows_stream", dict(width=4, height=1, depth=8, planes=3, bit_depth=8, output=pkg.OUT_REFERENCE)),
     # ... and gray + alpha: two interleaved samples per pixel, two planes out, stage_a itself per pixel (write_ga_stream)
     ("write_ga_stream", dict(width=1000, height=5, depth=16, planes=2, bit_depth=12, alpha_state=pkg.ALPHA_PREMULTIPLIED)),
     ("write_ga_stream", dict(width=1028, height=3, depth=16, planes=2, bit_depth=10, alpha_state=pkg.ALPHA_STRAIGHT)),

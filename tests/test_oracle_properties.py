@@ -312,6 +312,23 @@ def test_cpu_read_all_cores_equals_whole_frame(oracle, kw):
     assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
 
 
+def test_rescale8_fma_form_equals_the_table(oracle):
+    """write_rgb8_ycbcr16_hot (round 6) evaluates BuildEightBitToHeifImageLookup's entry (WriteHeifImage.cpp:87-112) as
+    floor(fma(i, RN(max / 255), 0.5)) instead of reading the 256-entry table: equal for all 256 inputs at 10 and at 12 bit."""
+    import ctypes
+    for bits in (10, 12):
+        lut = (ctypes.c_uint16 * 256)()
+        oracle.oracle_build_lut_8_to_n(bits, lut)
+        maxv = (1 << bits) - 1
+        ks = np.float32(maxv) / np.float32(255.0)
+        i = np.arange(256, dtype=np.float64)
+        fma = (i * float(ks) + 0.5).astype(np.float32)          # i * ks is exact in double (8 x 24 bits), + 0.5 too: ONE rounding, like v_fma_f32
+        assert np.array_equal(np.floor(fma).astype(np.int64), np.array(lut[:], dtype=np.int64)), bits
+        # and the distance argument of the kernel's comment: 2 * i * max / 255 is never an odd integer
+        frac = (np.arange(256) * maxv * 2) % 255
+        assert not np.any((frac == 0) & (((np.arange(256) * maxv * 2) // 255) % 2 == 1))
+
+
 def test_unorm_division_is_exact(tmp_path):
     """read_kernels.hip::unorm_to_float: (float)u / (float)max as fma(u, rh, RN(u * rl)) with 1 / max = rh + rl (two floats) equals the
     IEEE quotient for every u in [0, max] and max in {255, 1023, 4095, 65535} -- every entry of every table of
