@@ -2429,6 +2429,28 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgb16_ycbcr_sub_hot(con
     }
 }
 
+// One RGBA16 pixel (w0 = R | G << 16, w1 = B | A << 16) -> its 8-bit codes in the same two-dword form, for the TO8 variants of the kernels below
+// (round 6).  Integer arithmetic throughout -- these kernels are short of issue slots once the premultiply is in (0.64 of 8 TB/s with the float forms):
+//   * BuildSixteenBitToEightBitLookup's entry is (i * 255 + 16384) >> 15 for every i (rescale16_to_8, device_math.h);
+//   * PremultiplyColor(uint8, uint8) = min(roundf(c * a / 255.0f), 255) (PremultipliedAlpha.cpp:54-61) is round-half-up of the EXACT quotient:
+//     2 c a = 255 (2 k + 1) has no solution (even = odd), so c a / 255 is never within 1 / 510 of a half-integer and neither the float quotient's
+//     rounding nor roundf's tie rule can matter; and round(x / 255) = (t + (t >> 8)) >> 8 with t = x + 128 for every x <= 65025.  Two colours
+//     ride in one dword (x + 128 <= 65153 < 2^16: no carry between the halves).  All 65 536 (colour, alpha) pairs:
+//     tests/test_oracle_properties.py::test_premultiply_u8_integer_form.
+AG_DEV void rgba16_pixel_to8(uint32_t w0, uint32_t w1, bool premultiply, uint32_t& o0, uint32_t& o1)
+{
+    const uint32_t r = rescale16_to_8(min(w0 & 0xffffu, 32768u)), g = rescale16_to_8(min(w0 >> 16, 32768u));
+    const uint32_t b = rescale16_to_8(min(w1 & 0xffffu, 32768u)), a = rescale16_to_8(min(w1 >> 16, 32768u));
+    uint32_t c01 = r | (g << 16), c2 = b;
+    if (premultiply) {
+        const uint32_t t = c01 * a + 0x00800080u;                                  // (v_mad_u32_u24: both factors fit 24 bits)
+        c01 = ((t + ((t >> 8) & 0x00ff00ffu)) >> 8) & 0x00ff00ffu;
+        const uint32_t u = c2 * a + 128u;
+        c2 = (u + (u >> 8)) >> 8;
+    }
+    o0 = c01; o1 = c2 | (a << 16);
+}
+
 // ---- RGBA16 -> Y, Cb, Cr, A u16 planes (4:4:4): the streaming structure for 16-bit documents with transparency -------------------
 // A wave owns 512 pixels of a row = 4 KiB: four coalesced non-temporal 16-byte loads per lane, each holding two whole RGBA pixels.
 // Rescale (per sample) and the integer premultiply (per pixel) run on the vector as loaded; the codes go back into the same two
@@ -2459,6 +2481,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra444_hot(co
 #pragma unroll
             for (int h = 0; h < 2; ++h) {                                          // the vector's two pixels
                 const uint32_t w0 = h == 0 ? cur[k].x : cur[k].z, w1 = h == 0 ? cur[k].y : cur[k].w;
+                if constexpr (TO8) { rgba16_pixel_to8(w0, w1, p.premultiply != 0, o[2 * h], o[2 * h + 1]); continue; }
                 const uint32_t q01 = exact_rescale16_pair(w0, p.maxf * (1.0f / 32768.0f)), q2a = exact_rescale16_pair(w1, p.maxf * (1.0f / 32768.0f));
                 uint32_t c01 = q01, c2 = q2a & 0xffffu;
                 const uint32_t a = q2a >> 16;
@@ -2550,6 +2573,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra_sub_hot(c
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {                                      // the vector's two pixels: rescale, premultiply (as in the 4:4:4 kernel)
                     const uint32_t w0 = h == 0 ? cur[vr][k].x : cur[vr][k].z, w1 = h == 0 ? cur[vr][k].y : cur[vr][k].w;
+                    if constexpr (TO8) { rgba16_pixel_to8(w0, w1, p.premultiply != 0, o[2 * h], o[2 * h + 1]); continue; }
                     const uint32_t q01 = exact_rescale16_pair(w0, p.maxf * (1.0f / 32768.0f)), q2a = exact_rescale16_pair(w1, p.maxf * (1.0f / 32768.0f));
                     uint32_t c01 = q01, c2 = q2a & 0xffffu;
                     const uint32_t a = q2a >> 16;
@@ -3282,6 +3306,9 @@ struct CopyParams { const uint8_t* src; uint8_t* dst; long long src_stride, dst_
 #ifndef AG_COPY_BLOCK
 #define AG_COPY_BLOCK 128
 #endif
+#ifndef AG_COPY_K
+#define AG_COPY_K 2               /* 16-byte vectors per lane and wave trip */
+#endif
 template <int K>
 __global__ __launch_bounds__(AG_COPY_BLOCK) void copy_rows_stream(const CopyParams c)
 {
@@ -3546,6 +3573,9 @@ hipError_t launch_planes_d32_icc6(const WriteParams& p, int planes, bool dst16, 
 #ifndef AG_COPY8
 #define AG_COPY8 1
 #endif
+#ifndef AG_RGBA16_TO8
+#define AG_RGBA16_TO8 1
+#endif
 // The streaming launches in three code objects (AG_WRITE_PART 1 / 2 / 3, see the top of the file): every `return` inside one of the two
 // functions below is a launch (or an empty tile) -- *taken says so; falling off the end hands the tile to the next candidate.
 hipError_t launch_stream_int(const WriteParams& p, int depth, int planes, bool dst16, int output, int xs, int ys, int variant, hipStream_t st, char* label, bool* taken);
@@ -3562,13 +3592,13 @@ hipError_t launch_stream_int(const WriteParams& p, int depth, int planes, bool d
         CopyParams c = { p.src, p.dst[0], p.src_row_bytes, p.dst_stride[0], (long long)p.width * planes, p.nrows };
         const bool one = !(variant & 16) && c.nrows > 1 && c.src_stride == c.row_bytes && c.dst_stride == c.row_bytes;     // contiguous on both sides: one row
         if (one) { c.row_bytes *= c.nrows; c.nrows = 1; }
-        constexpr int kCopyK = 4, kCopyWaves = AG_COPY_BLOCK / 64;
+        constexpr int kCopyK = AG_COPY_K, kCopyWaves = AG_COPY_BLOCK / 64;
         const long long waves = ((c.row_bytes + 1024 * kCopyK - 1) / (1024 * kCopyK)) * c.nrows;
         if (waves == 0) return hipSuccess;
         if (waves + 8LL * 65536 * 4 < 0x7fffffffLL) {
             long long blocks = (waves + kCopyWaves - 1) / kCopyWaves;
             if (blocks > AG_STREAM_BLOCK_CAP * 4 / kCopyWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kCopyWaves;
-            snprintf(label, kLabelBytes, "copy_rows_stream<planes=%d>%s", planes, one ? " flat" : "");
+            snprintf(label, kLabelBytes, "write_copy_rows_stream<planes=%d>%s", planes, one ? " flat" : "");
             hipLaunchKernelGGL((copy_rows_stream<kCopyK>), dim3((int)blocks), dim3(AG_COPY_BLOCK), 0, st, c);
             return hipGetLastError();
         }
@@ -3692,7 +3722,7 @@ hipError_t launch_stream_int(const WriteParams& p, int depth, int planes, bool d
 #define AG_RGBA16_MIN_PX 0
 #endif
     // RGBA16 -> u16 Y, Cb, Cr, A 4:4:4
-    if ((variant & 1) && p.icc16_clut == nullptr && depth == 16 && planes == 4 && (dst16 || p.maxv == 255) && output == AVIFGPU_OUT_YCBCR && xs == 0 && ys == 0 &&
+    if ((variant & 1) && p.icc16_clut == nullptr && depth == 16 && planes == 4 && (dst16 || (AG_RGBA16_TO8 && p.maxv == 255)) && output == AVIFGPU_OUT_YCBCR && xs == 0 && ys == 0 &&
         ((long long)p.width * p.nrows >= AG_RGBA16_MIN_PX || (variant & 8)) && p.dst[3] != nullptr &&
         (p.width % 8) == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) | reinterpret_cast<uintptr_t>(p.dst[3]) |
@@ -3709,7 +3739,7 @@ hipError_t launch_stream_int(const WriteParams& p, int depth, int planes, bool d
         }
     }
     // RGBA16 -> u16 Y, Cb, Cr (4:2:2 / 4:2:0), A: the plug-in's default save of a transparent 16-bit document (round 5, last series)
-    if ((variant & 1) && p.icc16_clut == nullptr && depth == 16 && planes == 4 && (dst16 || p.maxv == 255) && output == AVIFGPU_OUT_YCBCR && xs == 1 && p.dst[3] != nullptr &&
+    if ((variant & 1) && p.icc16_clut == nullptr && depth == 16 && planes == 4 && (dst16 || (AG_RGBA16_TO8 && p.maxv == 255)) && output == AVIFGPU_OUT_YCBCR && xs == 1 && p.dst[3] != nullptr &&
         (p.width % 8) == 0 && (p.src_row_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[0]) | reinterpret_cast<uintptr_t>(p.dst[3]) | (uintptr_t)p.dst_stride[0] | (uintptr_t)p.dst_stride[3]) & 15) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.dst[1]) | reinterpret_cast<uintptr_t>(p.dst[2]) | (uintptr_t)p.dst_stride[1] | (uintptr_t)p.dst_stride[2]) & 7) == 0) {

@@ -146,12 +146,12 @@ CASES = [
     ("write_rgba16_ycbcra444_hot", dict(width=1000, height=4, depth=16, planes=4, bit_depth=8, alpha_state=pkg.ALPHA_PREMULTIPLIED,
                                         output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_444, matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)),
     # round 6: 8-bit documents through the 8-bit hand-off without premultiplication are a copy (contiguous rows: one flat row; padded rows; ragged ends)
-    ("copy_rows_stream", dict(width=1024, height=5, depth=8, planes=3, bit_depth=8, output=pkg.OUT_REFERENCE)),
-    ("copy_rows_stream", dict(width=1000, height=7, depth=8, planes=3, bit_depth=8, output=pkg.OUT_REFERENCE)),
-    ("copy_rows_stream", dict(width=2732, height=3, depth=8, planes=3, bit_depth=8, output=pkg.OUT_REFERENCE)),
-    ("copy_rows_stream", dict(width=1001, height=4, depth=8, planes=4, bit_depth=8, alpha_state=pkg.ALPHA_STRAIGHT, output=pkg.OUT_REFERENCE)),
-    ("copy_rows_stream", dict(width=4100, height=3, depth=8, planes=1, bit_depth=8)),
-    ("copy_rows_stream", dict(width=4, height=1, depth=8, planes=3, bit_depth=8, output=pkg.OUT_REFERENCE)),
+    ("write_copy_rows_stream", dict(width=1024, height=5, depth=8, planes=3, bit_depth=8, output=pkg.OUT_REFERENCE)),
+    ("write_copy_rows_stream", dict(width=1000, height=7, depth=8, planes=3, bit_depth=8, output=pkg.OUT_REFERENCE)),
+    ("write_copy_rows_stream", dict(width=2732, height=3, depth=8, planes=3, bit_depth=8, output=pkg.OUT_REFERENCE)),
+    ("write_copy_rows_stream", dict(width=1001, height=4, depth=8, planes=4, bit_depth=8, alpha_state=pkg.ALPHA_STRAIGHT, output=pkg.OUT_REFERENCE)),
+    ("write_copy_rows_stream", dict(width=4100, height=3, depth=8, planes=1, bit_depth=8)),
+    ("write_copy_rows_stream", dict(width=4, height=1, depth=8, planes=3, bit_depth=8, output=pkg.OUT_REFERENCE)),
     # ... and gray + alpha: two interleaved samples per pixel, two planes out, stage_a itself per pixel (write_ga_stream)
     ("write_ga_stream", dict(width=1000, height=5, depth=16, planes=2, bit_depth=12, alpha_state=pkg.ALPHA_PREMULTIPLIED)),
     ("write_ga_stream", dict(width=1028, height=3, depth=16, planes=2, bit_depth=10, alpha_state=pkg.ALPHA_STRAIGHT)),

@@ -75,8 +75,9 @@ def test_write_u8_fast_path_padded_rows(gpu, planes, alpha, chroma, width):
 @pytest.mark.parametrize("chroma", CHROMAS)
 @pytest.mark.parametrize("width", [1040, 1001, 24, 17, 2050, 1000, 8])
 def test_write_16bit_document_to_u8_planes_padded_rows(gpu, planes, alpha, chroma, width):
-    """A 16-bit document saved at 8 bit: RGBA16 takes the packed footprint too (samples rescaled with the reference's 16 -> 8 table
-    expression and packed as the row arrives), RGB16 the generic kernel -- same cases either way, incl. samples beyond 32768."""
+    """A 16-bit document saved at 8 bit: rows of whole 8-pixel groups take the RGB16 / RGBA16 streaming kernels with u8 planes (rounds 5 / 6: the
+    RGBA16 ones rescale and premultiply in integer arithmetic, rgba16_pixel_to8), everything else the generic kernel's packed footprint -- same
+    cases either way, incl. samples beyond 32768."""
     for height, near in ((7, False), (4, True)):
         kw = dict(width=width, height=height, depth=16, planes=planes, bit_depth=8, alpha_state=alpha, output=pkg.OUT_YCBCR,
                   chroma=chroma, matrix_coefficients=pkg.MATRIX_BT601, color_primaries=pkg.PRIMARIES_BT709)
@@ -96,6 +97,8 @@ def test_write_16bit_document_to_u8_planes_padded_rows(gpu, planes, alpha, chrom
                 gpu.lib.avifgpu_set_hot_variant(7)
             if variant == 7 and planes == 3 and width % 8 == 0:
                 assert "write_rgb16_ycbcr" in k and "to8" in k, k
+            elif variant == 7 and planes == 4 and width % 8 == 0:           # round 6: RGBA16 -> u8 planes on the RGBA16 streaming kernels too
+                assert "write_rgba16_ycbcra" in k and "to8" in k, k
             else:
                 assert "aligned=1" in k and "depth=16" in k, k
             for pl in want:

@@ -329,6 +329,27 @@ def test_rescale8_fma_form_equals_the_table(oracle):
         assert not np.any((frac == 0) & (((np.arange(256) * maxv * 2) // 255) % 2 == 1))
 
 
+def test_premultiply_u8_integer_form(oracle):
+    """rgba16_pixel_to8 (write_kernels.hip, round 6): PremultiplyColor(uint8, uint8) (PremultipliedAlpha.cpp:54-61) as (t + (t >> 8)) >> 8 with
+    t = c * a + 128, two colours per dword -- equal to the oracle's float expression for all 65 536 (colour, alpha) pairs; and
+    BuildSixteenBitToEightBitLookup's entry as (i * 255 + 16384) >> 15 for all 32 769 inputs."""
+    import ctypes
+    c, a = np.meshgrid(np.arange(256, dtype=np.uint32), np.arange(256, dtype=np.uint32), indexing="ij")
+    t = c * a + 128
+    single = (t + (t >> 8)) >> 8
+    g = c[::-1, :]                                                        # another colour in the upper half of the dword
+    c01 = c | (g << 16)
+    tp = c01 * a + np.uint32(0x00800080)
+    pair = ((tp + ((tp >> 8) & np.uint32(0x00ff00ff))) >> 8) & np.uint32(0x00ff00ff)
+    want = np.array([[oracle.oracle_premultiply_u8(int(ci), int(ai)) for ai in range(256)] for ci in range(256)], dtype=np.uint32)
+    assert np.array_equal(single, want)
+    assert np.array_equal(pair & 0xffff, want) and np.array_equal(pair >> 16, want[::-1, :])
+    lut = (ctypes.c_uint8 * 32769)()
+    oracle.oracle_build_lut_16_to_8(lut)
+    i = np.arange(32769, dtype=np.uint64)
+    assert np.array_equal((i * 255 + 16384) >> 15, np.array(lut[:], dtype=np.uint64))
+
+
 def test_unorm_division_is_exact(tmp_path):
     """read_kernels.hip::unorm_to_float: (float)u / (float)max as fma(u, rh, RN(u * rl)) with 1 / max = rh + rl (two floats) equals the
     IEEE quotient for every u in [0, max] and max in {255, 1023, 4095, 65535} -- every entry of every table of

@@ -227,6 +227,10 @@ if __name__ == "__main__":
     bench_write("W8 8192^2 RGB8 -> 8-bit 4:4:4 BT.601", width=8192, height=8192, depth=8, planes=3, bit_depth=8, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=6)
     bench_write("W8 8192^2 RGB8 -> 10-bit 4:2:0 BT.601", width=8192, height=8192, depth=8, planes=3, bit_depth=10, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=6)
     bench_write("W16 8192^2 RGBA16 premult -> 8-bit 4:2:0 BT.601 + alpha", width=8192, height=8192, depth=16, planes=4, bit_depth=8, alpha_state=2, output=1, chroma=P.CHROMA_420, matrix_coefficients=6)
+    bench_write("W16 8192^2 RGBA16 -> 8-bit 4:2:2 BT.601 nearest + alpha (a transparent 16-bit document saved at 8 bit with the plug-in's defaults)", width=8192, height=8192, depth=16, planes=4, bit_depth=8, alpha_state=1, output=1, chroma=P.CHROMA_422, chroma_downsampling=P.DOWNSAMPLE_NEAREST, matrix_coefficients=6)
+    bench_write("W16 8192^2 RGBA16 premult -> 8-bit 4:4:4 BT.601 + alpha", width=8192, height=8192, depth=16, planes=4, bit_depth=8, alpha_state=2, output=1, chroma=P.CHROMA_444, matrix_coefficients=6)
+    bench_write("W8 8192^2 RGB8 -> 12-bit 4:2:2 BT.601 nearest (an 8-bit document saved at the plug-in's default depth)", width=8192, height=8192, depth=8, planes=3, bit_depth=12, alpha_state=0, output=1, chroma=P.CHROMA_422, chroma_downsampling=P.DOWNSAMPLE_NEAREST, matrix_coefficients=6)
+    bench_write("W8 8192^2 RGB8 -> 10-bit 4:4:4 BT.601", width=8192, height=8192, depth=8, planes=3, bit_depth=10, alpha_state=0, output=1, chroma=P.CHROMA_444, matrix_coefficients=6)
     bench_write("W16 8192^2 RGBA16 premult -> 12-bit 4:4:4 BT.2020 + alpha", width=8192, height=8192, depth=16, planes=4, bit_depth=12, alpha_state=2, output=1, chroma=P.CHROMA_444, matrix_coefficients=P.MATRIX_BT2020_NCL, color_primaries=9)
     bench_write("W16 8192^2 RGBA16 -> 10-bit 4:2:0 BT.709 + alpha", width=8192, height=8192, depth=16, planes=4, bit_depth=10, alpha_state=1, output=1, chroma=P.CHROMA_420, matrix_coefficients=1)
     bench_write("W16 8192^2 RGB16 -> 8-bit 4:2:0 BT.709 (a 16-bit photograph saved as 8-bit AVIF)", width=8192, height=8192, depth=16, planes=3, bit_depth=8, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=P.MATRIX_BT709, color_primaries=1)
