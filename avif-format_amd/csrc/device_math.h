@@ -414,6 +414,20 @@ AG_DEV uint32_t exact_premultiply_fast(uint32_t color, uint32_t alpha, float max
     const float v = __builtin_fmaf(__builtin_fmaf(-q0, maxf, x), rcp_maxf, q0);
     return (uint32_t)cxx_min(floorf(v + 0.5f), maxf);
 }
+// Round 6: the same value in INTEGER arithmetic, 4 issue slots per colour.  c * a / max is a rational with an odd denominator, so it never lies
+// within 1 / (2 max) of a half-integer -- further than the float quotient's rounding error can reach (half an ulp of 4095 is 2^-13 < 1 / 8190) --
+// hence min(roundf(c * a / maxf), maxf) is round-half-up of the exact quotient, and round(x / (2^b - 1)) = (t + (t >> b)) >> b with
+// t = x + 2^(b-1) for every x <= (2^b - 1)^2.  All (colour, alpha) pairs at 8, 10 and 12 bit against the reference's float expression:
+// tests/test_oracle_properties.py::test_premultiply_integer_form_all_pairs.  bits = 8 / 10 / 12 (wave-uniform).
+#ifndef AG_PREMUL_INT
+#define AG_PREMUL_INT 1       /* 0: the float forms of rounds 1-5 (A/B) */
+#endif
+AG_DEV uint32_t premultiply_bits(int maxv) { return maxv > 1023 ? 12u : (maxv > 255 ? 10u : 8u); }
+AG_DEV uint32_t exact_premultiply_int(uint32_t color, uint32_t alpha, uint32_t bits)
+{
+    const uint32_t t = __umul24(color, alpha) + (1u << (bits - 1u));          // v_mad_u32_u24 (both factors <= 4095)
+    return (t + (t >> bits)) >> bits;
+}
 // Two colours of one pixel (a packed dword c0 | c1 << 16) against its alpha in packed single precision: element for element the sequence
 // above (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 round each element like their scalar forms), packed result.
 AG_DEV uint32_t exact_premultiply_fast_pair(uint32_t c01, uint32_t alpha, float maxf, float rcp_maxf)

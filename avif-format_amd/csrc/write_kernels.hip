@@ -702,7 +702,7 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
                 // the reference's early-outs (a == max: unchanged, a == 0: zero) are what the formula returns anyway --
                 // c*max/max == c and c*0/max == 0 exactly -- so no data-dependent branch is needed here
 #pragma unroll
-                for (int k = 0; k < NCOL; ++k) v[k] = exact_premultiply_fast(v[k], a, p.maxf, p.rcp_maxf);
+                for (int k = 0; k < NCOL; ++k) v[k] = AG_PREMUL_INT ? exact_premultiply_int(v[k], a, premultiply_bits(p.maxv)) : exact_premultiply_fast(v[k], a, p.maxf, p.rcp_maxf);
             }
         }
 #pragma unroll
@@ -2443,9 +2443,9 @@ AG_DEV void rgba16_pixel_to8(uint32_t w0, uint32_t w1, bool premultiply, uint32_
     const uint32_t b = rescale16_to_8(min(w1 & 0xffffu, 32768u)), a = rescale16_to_8(min(w1 >> 16, 32768u));
     uint32_t c01 = r | (g << 16), c2 = b;
     if (premultiply) {
-        const uint32_t t = c01 * a + 0x00800080u;                                  // (v_mad_u32_u24: both factors fit 24 bits)
+        const uint32_t t = __umul24(c01, a) + 0x00800080u;                         // v_mad_u32_u24: both factors fit 24 bits (c01 <= 0x00ff00ff)
         c01 = ((t + ((t >> 8) & 0x00ff00ffu)) >> 8) & 0x00ff00ffu;
-        const uint32_t u = c2 * a + 128u;
+        const uint32_t u = __umul24(c2, a) + 128u;
         c2 = (u + (u >> 8)) >> 8;
     }
     o0 = c01; o1 = c2 | (a << 16);
@@ -2486,9 +2486,15 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra444_hot(co
                 uint32_t c01 = q01, c2 = q2a & 0xffffu;
                 const uint32_t a = q2a >> 16;
                 if (p.premultiply) {                                               // stage_a: after the rescale, in the plane's code domain
+                    if constexpr (AG_PREMUL_INT) {                                  // round 6: integer form, 4 issue slots per colour (device_math.h)
+                        const uint32_t pb = premultiply_bits(p.maxv);
+                        c01 = exact_premultiply_int(c01 & 0xffffu, a, pb) | (exact_premultiply_int(c01 >> 16, a, pb) << 16);
+                        c2 = exact_premultiply_int(c2, a, pb);
+                    } else {
                     if constexpr (AG_PREMUL_PAIR) c01 = exact_premultiply_fast_pair(c01, a, p.maxf, p.rcp_maxf);
                     else c01 = exact_premultiply_fast(c01 & 0xffffu, a, p.maxf, p.rcp_maxf) | (exact_premultiply_fast(c01 >> 16, a, p.maxf, p.rcp_maxf) << 16);
                     c2 = exact_premultiply_fast(c2, a, p.maxf, p.rcp_maxf);
+                    }
                 }
                 o[2 * h] = c01; o[2 * h + 1] = c2 | (a << 16);
             }
@@ -2578,9 +2584,15 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_rgba16_ycbcra_sub_hot(c
                     uint32_t c01 = q01, c2 = q2a & 0xffffu;
                     const uint32_t a = q2a >> 16;
                     if (p.premultiply) {
+                        if constexpr (AG_PREMUL_INT) {                                  // round 6: integer form, 4 issue slots per colour (device_math.h)
+                            const uint32_t pb = premultiply_bits(p.maxv);
+                            c01 = exact_premultiply_int(c01 & 0xffffu, a, pb) | (exact_premultiply_int(c01 >> 16, a, pb) << 16);
+                            c2 = exact_premultiply_int(c2, a, pb);
+                        } else {
                         if constexpr (AG_PREMUL_PAIR) c01 = exact_premultiply_fast_pair(c01, a, p.maxf, p.rcp_maxf);
                         else c01 = exact_premultiply_fast(c01 & 0xffffu, a, p.maxf, p.rcp_maxf) | (exact_premultiply_fast(c01 >> 16, a, p.maxf, p.rcp_maxf) << 16);
                         c2 = exact_premultiply_fast(c2, a, p.maxf, p.rcp_maxf);
+                        }
                     }
                     o[2 * h] = c01; o[2 * h + 1] = c2 | (a << 16);
                 }
@@ -3268,7 +3280,7 @@ __global__ __launch_bounds__(AG_STREAM_BLOCK) void write_int_ref_stream(const Wr
                     for (int px = 0; px < NS / 4; ++px)
 #pragma unroll
                         for (int ch = 0; ch < 3; ++ch)
-                            q[4 * px + ch] = exact_premultiply_fast(q[4 * px + ch], q[4 * px + 3], p.maxf, p.rcp_maxf);
+                            q[4 * px + ch] = AG_PREMUL_INT ? exact_premultiply_int(q[4 * px + ch], q[4 * px + 3], premultiply_bits(p.maxv)) : exact_premultiply_fast(q[4 * px + ch], q[4 * px + 3], p.maxf, p.rcp_maxf);
                 }
             }
             uint32_t o[ODW];

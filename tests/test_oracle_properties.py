@@ -350,6 +350,32 @@ def test_premultiply_u8_integer_form(oracle):
     assert np.array_equal((i * 255 + 16384) >> 15, np.array(lut[:], dtype=np.uint64))
 
 
+def test_premultiply_integer_form_all_pairs(oracle):
+    """exact_premultiply_int (device_math.h, round 6): (t + (t >> b)) >> b with t = c * a + 2^(b-1) equals PremultiplyColor(uint, uint, max)
+    (PremultipliedAlpha.cpp:54-70: min(roundf(c * a / maxf), maxf) in float) for EVERY (colour, alpha) pair at 8, 10 and 12 bit -- 17.9 M pairs,
+    the float expression restated in numpy float32 and that restatement pinned to the oracle's C function on a sample."""
+    f32 = np.float32
+
+    def float_form(c, a, mx):
+        v = (c.astype(f32) * a.astype(f32)) / f32(mx)
+        r = np.trunc(v)
+        r = r + ((v - r) >= f32(0.5))                       # roundf: half away from zero (v >= 0; v - trunc(v) is exact)
+        return np.minimum(r, f32(mx)).astype(np.uint32)
+    rng = np.random.default_rng(5)
+    for bits in (10, 12):
+        mx = (1 << bits) - 1
+        cs, as_ = rng.integers(0, mx + 1, 20000), rng.integers(0, mx + 1, 20000)
+        want = np.array([oracle.oracle_premultiply_u16(int(c), int(a), mx) for c, a in zip(cs, as_)], dtype=np.uint32)
+        assert np.array_equal(float_form(cs.astype(np.uint32), as_.astype(np.uint32), mx), want)
+    for bits in (8, 10, 12):
+        mx = (1 << bits) - 1
+        a = np.arange(mx + 1, dtype=np.uint32)[None, :]
+        for c0 in range(0, mx + 1, 512):
+            c = np.arange(c0, min(c0 + 512, mx + 1), dtype=np.uint32)[:, None]
+            t = c * a + np.uint32(1 << (bits - 1))
+            assert np.array_equal((t + (t >> np.uint32(bits))) >> np.uint32(bits), float_form(c, a, mx)), (bits, c0)
+
+
 def test_unorm_division_is_exact(tmp_path):
     """read_kernels.hip::unorm_to_float: (float)u / (float)max as fma(u, rh, RN(u * rl)) with 1 / max = rh + rl (two floats) equals the
     IEEE quotient for every u in [0, max] and max in {255, 1023, 4095, 65535} -- every entry of every table of
