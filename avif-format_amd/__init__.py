@@ -154,6 +154,9 @@ ABI = [
     ("avifgpu_icc_clut16_from_transforms", c_int32, [c_void_p, c_void_p, c_void_p, POINTER(IccClut16)]),
     ("avifgpu_write_rows_icc16", c_int32, [POINTER(WriteDesc), POINTER(IccClut16), c_int32, c_int32, c_void_p, c_int64,
                                            POINTER(_PLANES4), POINTER(_STRIDES4), c_int32, c_void_p]),
+    ("avifgpu_icc_clut8_from_transforms", c_int32, [c_void_p, c_void_p, c_void_p, POINTER(IccClut16)]),
+    ("avifgpu_write_rows_icc8_table", c_int32, [POINTER(WriteDesc), POINTER(IccClut16), c_int32, c_int32, c_void_p, c_int64,
+                                                POINTER(_PLANES4), POINTER(_STRIDES4), c_int32, c_void_p]),
     ("avifgpu_icc_prepare_shaper8", c_int32, [c_void_p, ctypes.c_uint32, POINTER(IccShaper8)]),
     ("avifgpu_write_rows_icc8", c_int32, [POINTER(WriteDesc), POINTER(IccShaper8), c_int32, c_int32, c_void_p, c_int64,
                                           POINTER(_PLANES4), POINTER(_STRIDES4), c_int32, c_void_p]),
@@ -176,7 +179,8 @@ ABI = [
 # reported: a stale or wrong AVIFGPU_LIB must fail HERE, at bind time, not later with an AttributeError or a call without argtypes.
 ABI4_NEW = frozenset(("avifgpu_probe_pattern_read", "avifgpu_probe_pattern_rgb32_444", "avifgpu_device_traffic_get", "avifgpu_device_traffic_reset",
                       "avifgpu_topology_plan", "avifgpu_icc_prepare_sampled", "avifgpu_write_rows_icc_sampled",
-                      "avifgpu_icc_clut16_from_transforms"))
+                      "avifgpu_icc_clut16_from_transforms",
+                      "avifgpu_icc_clut8_from_transforms", "avifgpu_write_rows_icc8_table"))       # (ABI 5, round 6)
 
 
 def bind(lib: ctypes.CDLL, table=ABI) -> ctypes.CDLL:
@@ -260,6 +264,11 @@ class AvifGpu:
 
     def write_rows(self, desc: WriteDesc, row0, nrows, src_ptr, src_row_bytes, dst_ptrs, dst_strides,
                    mem=MEM_DEVICE, stream=0, icc=None):
+        if isinstance(icc, IccClut16) and desc.depth == 8:          # an 8-bit document behind a LUT-based profile: the same table, PrelinEval8's evaluation
+            self._check(self.lib.avifgpu_write_rows_icc8_table(ctypes.byref(desc), ctypes.byref(icc), row0, nrows, src_ptr, src_row_bytes,
+                                                               ctypes.byref(planes4(dst_ptrs)), ctypes.byref(strides4(dst_strides)),
+                                                               mem, stream or None))
+            return
         if isinstance(icc, IccClut16):
             self._check(self.lib.avifgpu_write_rows_icc16(ctypes.byref(desc), ctypes.byref(icc), row0, nrows, src_ptr, src_row_bytes,
                                                           ctypes.byref(planes4(dst_ptrs)), ctypes.byref(strides4(dst_strides)),

@@ -512,6 +512,12 @@ int fill_write_params(const avifgpu_write_desc* d, int row0, int nrows, const Wr
         const int rc = upload_icc16(g_icc16, p);
         if (rc) return rc;
     }
+    if (icc.c8t) {
+        if (d->depth != 8 || d->planes < 3) return fail(AVIFGPU_formatBadParameters, "the 8-bit ICC table applies to 8-bit RGB(A) documents");
+        if (g_icc8) return fail(AVIFGPU_formatBadParameters, "one ICC transform per call");
+        const int rc = upload_icc16(icc.c8t, p);            // the same 33^3 table, the same device layout; the kernel differs (icc = 7)
+        if (rc) return rc;
+    }
     if (g_icc8) {
         if (d->depth != 8 || d->planes < 3) return fail(AVIFGPU_formatBadParameters, "the 8-bit ICC shaper applies to 8-bit RGB(A) documents");
         const int rc = upload_icc8(g_icc8, p);
@@ -724,7 +730,7 @@ int write_rows_any(const avifgpu_write_desc* d, const IccArgs& icc, int32_t row0
     if ((err = check_write_buffers(d, g, nrows, src, src_row_bytes, dst, dst_stride))) return err;
     if (context_count() == 0) return fail(AVIFGPU_formatBadParameters, "%s", kNoDevice);
     if (nrows == 0) return 0;
-    if (icc.c16 || icc.s32) icc_epoch_for_call(row0);       // the device copies of these tables are re-verified once per device and epoch
+    if (icc.c16 || icc.s32 || icc.c8t) icc_epoch_for_call(row0);       // the device copies of these tables are re-verified once per device and epoch
 
     if (mem_kind == AVIFGPU_MEM_DEVICE) {
         // zero-copy: the kernel is enqueued on the caller's stream, on the caller's current device (where the pointers live)
@@ -900,6 +906,14 @@ int32_t avifgpu_write_rows_icc8(const avifgpu_write_desc* d, const avifgpu_icc_s
                                 int32_t mem_kind, void* stream)
 {
     IccArgs a; a.s8 = icc;
+    return write_rows_any(d, a, row0, nrows, src, src_row_bytes, dst, dst_stride, mem_kind, stream);
+}
+
+int32_t avifgpu_write_rows_icc8_table(const avifgpu_write_desc* d, const avifgpu_icc_clut16* icc, int32_t row0, int32_t nrows,
+                                      const void* src, int64_t src_row_bytes, void* const dst[4], const int64_t dst_stride[4],
+                                      int32_t mem_kind, void* stream)
+{
+    IccArgs a; a.c8t = icc;
     return write_rows_any(d, a, row0, nrows, src, src_row_bytes, dst, dst_stride, mem_kind, stream);
 }
 

@@ -222,9 +222,11 @@ void CreateHeifImageInto(FormatRecordPtr formatRecord, AlphaState alphaState, co
     } else if (saveOptions.convertToSRGB) {
         if (formatRecord->depth != 8 || mono || !formatRecord->iCCprofileData || formatRecord->iCCprofileSize <= 0)
             throw OSErrException(AVIFGPU_formatBadParameters);
-        icc8.reset(new avifgpu_icc_shaper8);
-        const int rc = avifgpu_icc_prepare_shaper8(formatRecord->iCCprofileData, (uint32_t)formatRecord->iCCprofileSize, icc8.get());
-        if (rc) throw OSErrException((OSErr)rc);
+        if (!documentToSRGB16) {                       // else (round 6): the caller's own table (avifgpu_icc_clut8_from_transforms), a LUT-based profile
+            icc8.reset(new avifgpu_icc_shaper8);
+            const int rc = avifgpu_icc_prepare_shaper8(formatRecord->iCCprofileData, (uint32_t)formatRecord->iCCprofileSize, icc8.get());
+            if (rc) throw OSErrException((OSErr)rc);
+        }
     }
 
     const bool even = d.output == AVIFGPU_OUT_YCBCR && d.chroma == AVIFGPU_CHROMA_420;
@@ -235,6 +237,7 @@ void CreateHeifImageInto(FormatRecordPtr formatRecord, AlphaState alphaState, co
     if (ts.nctx == 0) { avifgpu::set_error("avifgpu_init has not succeeded: no HIP device bound (no CPU fallback)"); throw OSErrException(AVIFGPU_formatBadParameters); }
     avifgpu::IccArgs iccArgs;
     iccArgs.f32 = iccp; iccArgs.s8 = icc8.get(); iccArgs.c16 = icc16 ? icc16.get() : (saveOptions.convertToSRGB && formatRecord->depth == 16 ? documentToSRGB16 : nullptr); iccArgs.s32 = iccs.get();
+    iccArgs.c8t = (saveOptions.convertToSRGB && formatRecord->depth == 8 && !icc8) ? documentToSRGB16 : nullptr;
 
     // Every exit path drains the contexts: no tile may still be reading a pinned buffer or writing a plane afterwards.
     auto bail = [&](OSErr e) { (void)avifgpu::wait_all(); formatRecord->data = nullptr; throw OSErrException(e); };

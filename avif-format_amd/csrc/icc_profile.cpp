@@ -344,32 +344,37 @@ static void fix_white_misalignment(avifgpu_icc_clut16& t)
 // have used, against which the result is PROVEN: 4096 pseudo-random colours (uniform, neutrals with tied fractions, words around
 // the nodes) go through the 16-bit callback and through the library's own interpolation of the table; one differing sample (another
 // CMM, cmsFLAGS_NOOPTIMIZE, a different grid, a different lcms2) fails the call with AVIFGPU_formatCannotRead and the caller keeps its CPU path.
-extern "C" int32_t avifgpu_icc_clut16_from_transforms(avifgpu_transform_f32_fn float_fn, avifgpu_transform16_fn word_fn, void* user,
-                                                      avifgpu_icc_clut16* out)
+// the 35 937 nodes through the caller's float transform, the way XFormSampler16 computes them (shared by the 16- and the 8-bit entry point)
+static void clut_nodes_from_float_transform(avifgpu_transform_f32_fn float_fn, void* user, avifgpu_icc_clut16* out, uint16_t (&node)[AVIFGPU_ICC_CLUT_GRID])
 {
-    if (!float_fn || !word_fn || !out) return fail(AVIFGPU_formatBadParameters, "null transform callback / table");
     constexpr int G = AVIFGPU_ICC_CLUT_GRID;
     std::memset(out, 0, sizeof(*out));
     out->grid_points = G;
-    uint16_t node[G];
     float fnode[G];
     for (int i = 0; i < G; ++i) {
         node[i] = quick_saturate_word((double)i * 65535.0 / (double)(G - 1));             // _cmsQuantizeVal
         fnode[i] = (float)(node[i] / 65535.0);                                            // XFormSampler16's input
     }
-    {
-        std::vector<float> in((size_t)G * G * G * 3), res((size_t)G * G * G * 3);
-        for (int r = 0; r < G; ++r) for (int g = 0; g < G; ++g) for (int b = 0; b < G; ++b) {
-            float* p = &in[((size_t)(r * G + g) * G + b) * 3];
-            p[0] = fnode[r]; p[1] = fnode[g]; p[2] = fnode[b];
-        }
-        float_fn(user, in.data(), res.data(), (uint32_t)(G * G * G));
-        for (size_t i = 0; i < (size_t)G * G * G; ++i) {
-            for (int c = 0; c < 3; ++c) out->table[i][c] = quick_saturate_word((double)res[3 * i + c] * 65535.0);
-            out->table[i][3] = 0;
-        }
+    std::vector<float> in((size_t)G * G * G * 3), res((size_t)G * G * G * 3);
+    for (int r = 0; r < G; ++r) for (int g = 0; g < G; ++g) for (int b = 0; b < G; ++b) {
+        float* p = &in[((size_t)(r * G + g) * G + b) * 3];
+        p[0] = fnode[r]; p[1] = fnode[g]; p[2] = fnode[b];
+    }
+    float_fn(user, in.data(), res.data(), (uint32_t)(G * G * G));
+    for (size_t i = 0; i < (size_t)G * G * G; ++i) {
+        for (int c = 0; c < 3; ++c) out->table[i][c] = quick_saturate_word((double)res[3 * i + c] * 65535.0);
+        out->table[i][3] = 0;
     }
     fix_white_misalignment(*out);
+}
+
+extern "C" int32_t avifgpu_icc_clut16_from_transforms(avifgpu_transform_f32_fn float_fn, avifgpu_transform16_fn word_fn, void* user,
+                                                      avifgpu_icc_clut16* out)
+{
+    if (!float_fn || !word_fn || !out) return fail(AVIFGPU_formatBadParameters, "null transform callback / table");
+    constexpr int G = AVIFGPU_ICC_CLUT_GRID;
+    uint16_t node[G];
+    clut_nodes_from_float_transform(float_fn, user, out, node);
     constexpr uint32_t N = 4096;
     std::vector<uint16_t> pin(N * 3), pwant(N * 3);
     uint64_t st = 0x9e3779b97f4a7c15ull;
@@ -393,6 +398,47 @@ extern "C" int32_t avifgpu_icc_clut16_from_transforms(avifgpu_transform_f32_fn f
     if (bad) {
         char msg[200];
         std::snprintf(msg, sizeof(msg), "the 16-bit transform is not the 33^3 tetrahedral table of the float one (%u of %u probe colours differ): keep the CPU path", bad, N);
+        return fail(AVIFGPU_formatCannotRead, msg);
+    }
+    return 0;
+}
+
+// Round 6 -- the same for an 8-BIT document (include/avifgpu.h): the table is the one lcms2 builds for any formatters; the proof runs the
+// caller's TYPE_RGB_8 transform against PrelinEval8 restated on the table: byte b -> word 257 b (FROM_8_TO_16), TetrahedralInterp16's sum
+// (tetra16_host: the 256-entry position tables of Prelin8Data hold exactly _cmsToFixedDomain(32 * 257 b)), FROM_16_TO_8 on the way out.
+// A matrix/TRC profile fails the proof -- lcms2 runs its matrix-shaper on 8-bit rows, different arithmetic -- and is sent to
+// avifgpu_icc_prepare_shaper8 by the message.
+extern "C" int32_t avifgpu_icc_clut8_from_transforms(avifgpu_transform_f32_fn float_fn, avifgpu_transform8_fn byte_fn, void* user,
+                                                     avifgpu_icc_clut16* out)
+{
+    if (!float_fn || !byte_fn || !out) return fail(AVIFGPU_formatBadParameters, "null transform callback / table");
+    constexpr int G = AVIFGPU_ICC_CLUT_GRID;
+    uint16_t node[G];
+    clut_nodes_from_float_transform(float_fn, user, out, node);
+    constexpr uint32_t N = 16384;
+    std::vector<uint8_t> pin(N * 3), pwant(N * 3);
+    uint64_t st = 0x2545f4914f6cdd1dull;
+    auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(st >> 33); };
+    for (uint32_t i = 0; i < N; ++i) {
+        uint8_t* p = &pin[3 * i];
+        if (i < 256) { p[0] = p[1] = p[2] = (uint8_t)i; }                                  // every neutral: all three fractions tie
+        else if ((i & 7) == 1) { for (int c = 0; c < 3; ++c) p[c] = (uint8_t)((node[rnd() % G] >> 8) + (int)(rnd() % 3) - 1); }   // bytes around the nodes
+        else if ((i & 7) == 2) { p[0] = (uint8_t)rnd(); p[1] = p[0]; p[2] = (uint8_t)rnd(); }                                      // two tied fractions
+        else { for (int c = 0; c < 3; ++c) p[c] = (uint8_t)rnd(); }
+    }
+    byte_fn(user, pin.data(), pwant.data(), N);
+    uint32_t bad = 0;
+    for (uint32_t i = 0; i < N; ++i) {
+        const uint16_t w[3] = { (uint16_t)(pin[3 * i] * 257u), (uint16_t)(pin[3 * i + 1] * 257u), (uint16_t)(pin[3 * i + 2] * 257u) };
+        uint16_t got[3];
+        tetra16_host(*out, w, got);
+        for (int c = 0; c < 3; ++c)
+            if ((uint8_t)(((uint32_t)got[c] * 65281u + 8388608u) >> 24) != pwant[3 * i + c]) { ++bad; break; }
+    }
+    if (bad) {
+        char msg[256];
+        std::snprintf(msg, sizeof(msg), "the 8-bit transform is not the 33^3 tetrahedral table of the float one (%u of %u probe colours differ; a matrix/TRC "
+                                        "profile takes avifgpu_icc_prepare_shaper8): keep the CPU path", bad, N);
         return fail(AVIFGPU_formatCannotRead, msg);
     }
     return 0;

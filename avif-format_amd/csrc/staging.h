@@ -18,6 +18,7 @@ struct IccArgs {
     const avifgpu_icc_shaper8*   s8 = nullptr;      // 8-bit documents  (avifgpu_write_rows_icc8)
     const avifgpu_icc_clut16*    c16 = nullptr;     // 16-bit documents (avifgpu_write_rows_icc16)
     const avifgpu_icc_sampled32* s32 = nullptr;     // 32-bit documents with sampled curves (avifgpu_write_rows_icc_sampled)
+    const avifgpu_icc_clut16*    c8t = nullptr;     // 8-bit documents behind a LUT-based profile: the 33^3 table (avifgpu_write_rows_icc8_table)
 };
 
 constexpr int kLabelBytes = 192;                    // kernel label buffers handed to launch_*()

@@ -539,17 +539,16 @@ AG_DEV int mad24_sv(int s_coef, int v, int acc) { int d; asm("v_mad_i32_i24 %0, 
 AG_DEV uint32_t umax3(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_max3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 AG_DEV uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_min3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 AG_DEV uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_med3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
-// host[] <= 32768 (the caller clamps: packed, as the row arrives)
-AG_DEV void icc16_tetrahedral_host(const uint16_t* __restrict__ clut, const uint32_t (&host)[3], uint32_t (&out)[3])
+// fx[] = the three 16.16 grid positions (_cmsToFixedDomain(32 * word)); out[] = the interpolated 16-bit words
+AG_DEV void icc16_tetrahedral_fixed(const uint16_t* __restrict__ clut, const uint32_t (&fx)[3], uint32_t (&out)[3])
 {
     [[maybe_unused]] constexpr uint32_t G = AVIFGPU_ICC_CLUT_GRID;       // (used by one of the two record layouts below)
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     uint32_t c0i[3], r[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const uint32_t f = icc16_host_to_fixed(host[k]);
-        c0i[k] = f >> 16;
-        r[k] = f & 0xffffu;
+        c0i[k] = fx[k] >> 16;
+        r[k] = fx[k] & 0xffffu;
     }
     const uint32_t mx = umax3(r[0], r[1], r[2]), mn = umin3(r[0], r[1], r[2]), md = umed3(r[0], r[1], r[2]);
     const uint32_t w12 = (mx - md) | ((md - mn) << 16), w03 = (mx ^ 0xffffu) | (mn << 16);
@@ -597,6 +596,27 @@ AG_DEV void icc16_tetrahedral_host(const uint16_t* __restrict__ clut, const uint
         const int32_t t = (int32_t)acc;
         out[k] = (p0 + (uint32_t)((t + (t >> 16)) >> 16)) & 0xffffu;
     }
+}
+// host[] <= 32768 (the caller clamps: packed, as the row arrives)
+AG_DEV void icc16_tetrahedral_host(const uint16_t* __restrict__ clut, const uint32_t (&host)[3], uint32_t (&out)[3])
+{
+    const uint32_t fx[3] = { icc16_host_to_fixed(host[0]), icc16_host_to_fixed(host[1]), icc16_host_to_fixed(host[2]) };
+    icc16_tetrahedral_fixed(clut, fx, out);
+}
+// Round 6 -- an 8-BIT document behind a LUT-based (A2B) profile, icc = 7.  lcms2 resamples such a profile pair into the same 33^3 table whatever
+// the formatters are; for 8-bit ones its evaluator is PrelinEval8 (cmsopt.c): the byte b enters as the word FROM_8_TO_16(b) = 257 b, its grid
+// position _cmsToFixedDomain(32 * 257 b) comes out of a 256-entry table filled with exactly that expression, the six-way tetrahedral sum and
+// its rounding are TetrahedralInterp16's, and the output formatter packs the word with FROM_16_TO_8(w) = (w * 65281 + 8388608) >> 24.
+// Position: with j = 257 b, 32 j + (32 j + 0x7fff) / 0xffff = (j << 5) + ((j + 1024) >> 11) (the identity icc16_host_to_fixed uses).
+// Bit-exact against the real library on all 2^24 RGB triples (tests/test_icc8.py).
+AG_DEV void icc8_tetrahedral_bytes(const uint16_t* __restrict__ clut, const uint32_t (&b)[3], uint32_t (&out)[3])
+{
+    uint32_t fx[3], w[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) fx[k] = __umul24(b[k], 8224u) + ((__umul24(b[k], 257u) + 1024u) >> 11);
+    icc16_tetrahedral_fixed(clut, fx, w);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[k] = (__umul24(w[k], 65281u) + 8388608u) >> 24;
 }
 
 // ---- stage A: one source pixel -> integer codes (reference WriteHeifImage.cpp inner loops) --------
@@ -666,6 +686,13 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
             sx[0] = cout[0]; sx[1] = cout[1]; sx[2] = cout[2];
 #pragma unroll
             for (int k = 0; k < PLANES; ++k) sx[k] = icc16_lcms_to_host(sx[k]);
+        }
+        if constexpr (ICC == 7 && DEPTH == 8 && COLOR) {
+            // ConvertRow for 8-bit rows behind a LUT-based profile (ColorProfileConversion.cpp:159-187, TYPE_RGB[A]_8): the table the caller's own
+            // transforms yielded (avifgpu_icc_clut8_from_transforms), evaluated like PrelinEval8; alpha is copied (cmsFLAGS_COPY_ALPHA)
+            uint32_t cin[3] = { sx[0], sx[1], sx[2] }, cout[3];
+            icc8_tetrahedral_bytes(p.icc16_clut, cin, cout);
+            sx[0] = cout[0]; sx[1] = cout[1]; sx[2] = cout[2];
         }
         if constexpr (ICC == 3 && DEPTH == 8 && COLOR) {
             // lcms2's 8-bit matrix-shaper evaluation (MatShaperEval16), bit for bit: 1.14 fixed-point tables and matrix
@@ -780,7 +807,7 @@ template <bool DST16, int PLANES, int XS, int ICC = 0> struct WriteShape {
     // ICC == 5 (the 16-bit table transform) saved to u8 planes: 4 chroma samples per lane like the u16 layouts.  With 8, a 4:2:0 footprint
     // is 32 pixels x two 16-byte gathers each, all hoisted: 315 VGPRs = ONE wave per SIMD (profiles/r02/isa/resources.tsv); with 4 it is
     // 16 pixels and the kernel fits 3-4 waves.
-    static constexpr int NC = ((ICC == 2 || ICC == 4) && XS == 1) ? 2 : ((DST16 && ICC == 0) ? AG_W16_NC : ((DST16 || ICC == 5) ? 4 : ((PLANES == 2 || PLANES == 4) ? AG_W8_NC_ALPHA : AG_W8_NC)));
+    static constexpr int NC = ((ICC == 2 || ICC == 4) && XS == 1) ? 2 : ((DST16 && ICC == 0) ? AG_W16_NC : ((DST16 || ICC == 5 || ICC == 7) ? 4 : ((PLANES == 2 || PLANES == 4) ? AG_W8_NC_ALPHA : AG_W8_NC)));
     static constexpr int PXT = NC << XS;
 };
 
@@ -3424,6 +3451,17 @@ static hipError_t launch_one(const WriteParams& p, hipStream_t st, char* label)
             return hipGetLastError();
         }
     }
+    if constexpr (DEPTH == 8 && PLANES >= 3) {
+        if (p.icc16_clut != nullptr) {              // 8-bit document behind a LUT-based profile: the 33^3 table, evaluated like PrelinEval8 (round 6)
+            constexpr int PXT7 = WriteShape<DST16, PLANES, XS, 7>::PXT;
+            groups = (long long)((p.width + PXT7 - 1) / PXT7) * ((p.nrows + (1 << YS) - 1) >> YS);
+            snprintf(label, kLabelBytes, "write_px<depth=%d,planes=%d,out=%d,dst16=%d,xs=%d,ys=%d,transfer=%d,aligned=%d,icc=7>",
+                     DEPTH, PLANES, OUT, (int)DST16, XS, YS, TRANSFER, (int)aligned);
+            if (aligned) hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, true, 7>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
+            else hipLaunchKernelGGL((write_px<DEPTH, PLANES, OUT, DST16, XS, YS, TRANSFER, false, 7>), dim3(grid_for(groups)), dim3(AG_WPX_BLOCK), 0, st, p);
+            return hipGetLastError();
+        }
+    }
     if constexpr (DEPTH == 16 && PLANES >= 3) {
         if (p.icc16_clut != nullptr) {              // 16-bit CLUT ICC transform requested
             constexpr int PXT5 = WriteShape<DST16, PLANES, XS, 5>::PXT;
@@ -3596,6 +3634,7 @@ hipError_t launch_stream_f32_sub_rgba(const WriteParams& p, int depth, int plane
 hipError_t launch_stream_int(const WriteParams& p, int depth, int planes, bool dst16, int output, int xs, int ys, int variant, hipStream_t st, char* label, bool* taken)
 {
     *taken = true;
+    if (depth == 8 && p.icc16_clut != nullptr) { *taken = false; return hipSuccess; }      // an 8-bit document behind a table profile: write_px<..., icc = 7>
     // 8-bit document, 8-bit hand-off, nothing to premultiply: the reference copies the bytes (round 6)
     if (AG_COPY8 && (variant & 1) && p.icc8_s1 == nullptr && depth == 8 && !dst16 && p.maxv == 255 && output == AVIFGPU_OUT_REFERENCE &&
         (planes == 3 || planes == 1 || (planes == 4 && !p.premultiply)) &&

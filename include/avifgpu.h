@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AVIFGPU_ABI_VERSION 4
+#define AVIFGPU_ABI_VERSION 5
 
 /* ---- OSErr codes used by the hot path (Photoshop SDK values) ------------------------------- */
 #define AVIFGPU_noErr                0
@@ -506,6 +506,31 @@ int32_t avifgpu_write_rows_icc16(const avifgpu_write_desc* desc, const avifgpu_i
                                  const void* src, int64_t src_row_bytes,
                                  void* const dst[4], const int64_t dst_stride[4],
                                  int32_t mem_kind, void* stream);
+
+/* ---- ... and of the 8-bit SDR save path behind a LUT-based (A2B) document profile (round 6) --------------------------------
+ * avifgpu_icc_prepare_shaper8 covers matrix/TRC profiles (lcms2's 8-bit matrix-shaper).  For every other profile pair lcms2 resamples the
+ * pipeline into the SAME 33^3 table as for 16-bit formatters (OptimizeByResampling does not look at the formatters' depth) and evaluates it
+ * for 8-bit rows with PrelinEval8: the byte b enters as the word 257 b, the tetrahedral sum and its rounding are TetrahedralInterp16's,
+ * the output formatter packs the word with FROM_16_TO_8 -- integer arithmetic once the table exists, reproduced bit for bit
+ * (tests/test_icc8.py: all 2^24 RGB triples against the real library).  As for 16-bit documents the table comes from transforms the
+ * CALLER owns and is PROVEN before use:
+ *   float_fn: cmsDoTransform on a TYPE_RGB_FLT transform of the same profiles, intent and flags (computes the 35937 nodes), and
+ *   byte_fn:  cmsDoTransform on the TYPE_RGB_8 transform the plug-in would have run per row (ColorProfileConversion.cpp:268-331):
+ *             16384 probe colours -- every neutral, words around the nodes, random triples -- must come out of the library's evaluation
+ *             of the table exactly as out of byte_fn.
+ * AVIFGPU_formatCannotRead (keep lcms2) if they do not: a matrix/TRC profile (lcms2 runs its matrix-shaper there -- use
+ * avifgpu_icc_prepare_shaper8), another CMM, cmsFLAGS_NOOPTIMIZE.  Host-only; both callbacks run on the calling thread.
+ * 32-bit documents behind such a profile stay on lcms2: its float pipeline evaluates the profile's own LUT in floating point. */
+typedef void (*avifgpu_transform8_fn)(void* user, const uint8_t* rgb_in, uint8_t* rgb_out, uint32_t pixel_count);
+int32_t avifgpu_icc_clut8_from_transforms(avifgpu_transform_f32_fn float_fn, avifgpu_transform8_fn byte_fn, void* user,
+                                          avifgpu_icc_clut16* out);
+
+/* avifgpu_write_rows for 8-bit RGB(A) documents with that table transform applied to R, G, B first (alpha copied: cmsFLAGS_COPY_ALPHA). */
+int32_t avifgpu_write_rows_icc8_table(const avifgpu_write_desc* desc, const avifgpu_icc_clut16* icc,
+                                      int32_t row0, int32_t nrows,
+                                      const void* src, int64_t src_row_bytes,
+                                      void* const dst[4], const int64_t dst_stride[4],
+                                      int32_t mem_kind, void* stream);
 
 #ifdef __cplusplus
 }

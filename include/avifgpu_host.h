@@ -155,10 +155,12 @@ avifgpu_OSErr avifgpu_host_create_heif_image(avifgpu_FormatRecord* formatRecord,
                                              int32_t matrix_coefficients, int32_t color_primaries,
                                              avifgpu_image* img);
 
-/* The same with the document -> sRGB table of a 16-bit RGB document supplied by the caller (avifgpu_icc_clut16_from_transforms:
- * LUT-based and any other profile lcms2 opens; integration/LcmsTableBridge.cpp builds it).  The table is used exactly where the
- * plain entry would have parsed the profile itself -- depth 16 and the decision (explicit or LIKE_PLUGIN) says "to sRGB" -- and is
- * ignored everywhere else; NULL = the plain entry. */
+/* The same with the document -> sRGB table of a 16-bit -- or, since round 6, an 8-bit -- RGB document supplied by the caller
+ * (avifgpu_icc_clut16_from_transforms / avifgpu_icc_clut8_from_transforms: LUT-based and any other profile lcms2 opens;
+ * integration/LcmsTableBridge.cpp builds it from the matching pair of transforms).  The table is used exactly where the plain entry would
+ * have parsed the profile itself -- depth 16 or 8 and the decision (explicit or LIKE_PLUGIN) says "to sRGB" -- and is ignored everywhere
+ * else; NULL = the plain entry.  A table proven against a 16-bit transform must not be passed for an 8-bit document or vice versa only in
+ * so far as the PROOF differs: the nodes are the same 35 937 words either way. */
 avifgpu_OSErr avifgpu_host_create_heif_image_with_table(avifgpu_FormatRecord* formatRecord, int32_t alphaState,
                                                         const avifgpu_SaveUIOptions* saveOptions, int32_t output,
                                                         int32_t matrix_coefficients, int32_t color_primaries,

@@ -185,17 +185,23 @@ namespace
         bridge.real = formatRecord; bridge.shim = &shim; bridge.converter = nullptr; bridge.width = imageSize.h;
         const int32_t output = fused ? AVIFGPU_OUT_YCBCR : AVIFGPU_OUT_REFERENCE;
         avifgpu_OSErr err = avifgpu_host_create_heif_image(&shim, static_cast<int32_t>(alphaState), &o, output, -1, -1, &out);
-        if (err == formatCannotRead && formatRecord->depth == 16 && avifgpu_host_required_conversion_for_record(&shim, &o) == AVIFGPU_CONVERT_TO_SRGB)
+        if (err == formatCannotRead && (formatRecord->depth == 16 || formatRecord->depth == 8) &&
+            avifgpu_host_required_conversion_for_record(&shim, &o) == AVIFGPU_CONVERT_TO_SRGB)
         {
-            // LUT-based (A2B) profile of a 16-bit document: lcms2's transform for it is still a 33^3 table; LcmsTableBridge.cpp computes
-            // it from two lcms2 transforms created like InitializeForSRGBConversion's and the library proves it before use
+            // LUT-based (A2B) profile of a 16-bit or (round 6) 8-bit document: lcms2's transform for it is still a 33^3 table (for 8-bit rows
+            // evaluated by PrelinEval8); LcmsTableBridge.cpp computes it from two lcms2 transforms created like InitializeForSRGBConversion's
+            // and the library proves it against the one the plug-in would have run before use
             std::unique_ptr<avifgpu_icc_clut16> table(new avifgpu_icc_clut16);
-            if (avifgpu_lcms_document_to_srgb_clut16(shim.iCCprofileData, static_cast<uint32_t>(shim.iCCprofileSize), table.get()) == noErr)
+            const int32_t got = formatRecord->depth == 16
+                ? avifgpu_lcms_document_to_srgb_clut16(shim.iCCprofileData, static_cast<uint32_t>(shim.iCCprofileSize), table.get())
+                : avifgpu_lcms_document_to_srgb_clut8(shim.iCCprofileData, static_cast<uint32_t>(shim.iCCprofileSize), table.get());
+            if (got == noErr)
                 err = avifgpu_host_create_heif_image_with_table(&shim, static_cast<int32_t>(alphaState), &o, output, -1, -1, table.get(), &out);
         }
         if (err == formatCannotRead && avifgpu_host_required_conversion_for_record(&shim, &o) > 0)
         {
-            // a profile the GPU stage does not take (LUT-based at 8 / 32 bit ...): keep the reference's CPU transform, convert the rest on the GPU
+            // a profile the GPU stage does not take (LUT-based at 32 bit: lcms2 evaluates the profile's own LUT in floating point there ...): keep the
+            // reference's CPU transform, convert the rest on the GPU
             std::unique_ptr<ColorProfileConversion> converter(formatRecord->depth == 32
                 ? new ColorProfileConversion(formatRecord, hasAlpha, saveOptions.hdrTransferFunction, saveOptions.keepColorProfile)
                 : new ColorProfileConversion(formatRecord, hasAlpha, formatRecord->depth, saveOptions.keepColorProfile));

@@ -449,3 +449,27 @@ void oracle_icc_transform16_close(void* user)
     cmsDeleteContext(h->ctx);
     free(h);
 }
+
+/* Round 6: the same handle with a TYPE_RGB_8 transform in the word slot -- what the plug-in owns for an 8-bit document
+ * (ColorProfileConversion.cpp:268-331, hostBitsPerChannel == 8) -- for avifgpu_icc_clut8_from_transforms' callbacks. */
+void* oracle_icc_transform8_open(const void* icc, uint32_t icc_size, uint32_t extra_flags)
+{
+    transform16_handle* h = (transform16_handle*)calloc(1, sizeof(*h));
+    if (!h) return NULL;
+    h->ctx = cmsCreateContext(NULL, NULL);
+    cmsHPROFILE doc = cmsOpenProfileFromMemTHR(h->ctx, icc, icc_size);
+    cmsHPROFILE out = cmsCreate_sRGBProfileTHR(h->ctx);
+    if (doc && out)
+    {
+        h->t = cmsCreateTransformTHR(h->ctx, doc, TYPE_RGB_8, out, TYPE_RGB_8, INTENT_PERCEPTUAL, cmsFLAGS_BLACKPOINTCOMPENSATION | extra_flags);
+        h->tf = cmsCreateTransformTHR(h->ctx, doc, TYPE_RGB_FLT, out, TYPE_RGB_FLT, INTENT_PERCEPTUAL, cmsFLAGS_BLACKPOINTCOMPENSATION);
+    }
+    if (doc) cmsCloseProfile(doc);
+    if (out) cmsCloseProfile(out);
+    if (!h->t || !h->tf) { if (h->t) cmsDeleteTransform(h->t); if (h->tf) cmsDeleteTransform(h->tf); cmsDeleteContext(h->ctx); free(h); return NULL; }
+    return h;
+}
+void oracle_icc_transform8_run(void* user, const uint8_t* in, uint8_t* out, uint32_t pixel_count)
+{
+    cmsDoTransform(((transform16_handle*)user)->t, in, out, pixel_count);
+}

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert set(declared) == bound, set(declared) ^ bound
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.avifgpu_abi_version() == 4
+    assert lib.avifgpu_abi_version() == 5
     host_declared = [n for n in _header_symbols("avifgpu_host.h") if n.startswith(("avifgpu_host_", "avifgpu_image_"))]
     assert sorted(host_declared) == sorted(n for n, _, _ in pkg.host.HOST_ABI)
     for name in host_declared:

@@ -511,10 +511,18 @@ def test_icc_tables_are_bound_to_their_document_depth(gpu, lcms):
     sh8 = gpu.icc_prepare_shaper8(icc)
     d8 = pkg.WriteDesc(width=16, height=2, depth=8, planes=3, bit_depth=8, output=pkg.OUT_REFERENCE)
     d16 = pkg.WriteDesc(width=16, height=2, depth=16, planes=3, bit_depth=10, output=pkg.OUT_REFERENCE)
-    for d, table in ((d8, clut), (d16, sh8)):
-        with pytest.raises(pkg.AvifGpuError) as e:
-            _gpu(gpu, d, harness.make_write_source(d), table)
-        assert e.value.code == pkg.formatBadParameters
+    with pytest.raises(pkg.AvifGpuError) as e:
+        _gpu(gpu, d16, harness.make_write_source(d16), sh8)
+    assert e.value.code == pkg.formatBadParameters
+    # the C entry points themselves (the Python wrapper routes a table by the document's depth since round 6: an 8-bit document behind a
+    # table profile is avifgpu_write_rows_icc8_table, PrelinEval8's evaluation): each refuses the other depth
+    L = gpu.lib
+    for fn, d in ((L.avifgpu_write_rows_icc16, d8), (L.avifgpu_write_rows_icc8_table, d16)):
+        src = harness.make_write_source(d)
+        out = np.zeros((2, 256), dtype=np.uint8)
+        rc = fn(ctypes.byref(d), ctypes.byref(clut), 0, 2, src.ctypes.data, src.strides[0], ctypes.byref(pkg.planes4([out.ctypes.data, None, None, None])),
+                ctypes.byref(pkg.strides4([out.strides[0], 0, 0, 0])), pkg.MEM_HOST, None)
+        assert rc == pkg.formatBadParameters, (fn.__name__, L.avifgpu_last_error())
     bad = pkg.IccClut16()
     ctypes.memmove(ctypes.byref(bad), ctypes.byref(clut), ctypes.sizeof(bad))
     bad.grid_points = 17
