@@ -1544,6 +1544,12 @@ template <bool NT, typename V> AG_DEV void stream_store(V* p, V v)
 #ifndef AG_SUB_PRIO
 #define AG_SUB_PRIO 1
 #endif
+#ifndef AG_SUB_SPW2
+#define AG_SUB_SPW2 1                  /* 4:2:2 tiles of whole 512-pixel spans: two spans per wave (write_rgb32_ycbcr_sub_hot's loop) */
+#endif
+#ifndef AG_SUB_SPW2_MIN_SPANS
+#define AG_SUB_SPW2_MIN_SPANS 32768
+#endif
 #ifndef AG_RGBA_PRIO
 #define AG_RGBA_PRIO 0
 #endif
@@ -1901,13 +1907,19 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot
             for (int k = 0; k < K; ++k) v[vr][k] = span_load_cached(k, K) ? span_load16<false>(rs, voff, 1024u * k) : span_load16<true>(rs, voff, 1024u * k);   // beyond the row: zeros (see the 4:4:4 kernel)
         }
     };
-    issue(blockIdx.x * kF32Waves + wave);
+    // Round 6 -- spans per wave: the launcher sizes the grid (launch_stream_f32_sub_rgba); a wave's spans lie a grid apart (w0 + it * step).
+    // TWO spans per wave halve the workgroup dispatches and the PQ-table copies per pixel and put the second span's loads in flight behind the
+    // first span's stores: 4:2:2 at 8192^2 0.745 -> 0.76 of 8 TB/s (10 and 12 bit), 4:2:0 nothing, odd geometries -4 %, three or four spans and
+    // spans that are neighbours in memory lose everywhere (profiles/r06/sub_hot_spans_per_wave_ab.txt) -- so 4:2:2 tiles of >= 32 Ki spans take two.
+    const uint32_t w0 = blockIdx.x * kF32Waves + wave;
+    auto span_of = [&](uint32_t it) -> uint32_t { return w0 + it * step; };
+    issue(span_of(0));
     if constexpr (AG_SUB_PRIO) __builtin_amdgcn_s_setprio(0);
     if constexpr (LATE) {
         tfill.store((int)threadIdx.x);
         pq_table_barrier();
     }
-    for (uint32_t sidx = blockIdx.x * kF32Waves + wave; sidx < total; sidx += step) {
+    for (uint32_t it = 0, sidx = span_of(0); sidx < total; sidx = span_of(++it)) {
         const uint32_t gy = sidx / spans_per_row;
         const uint32_t sx = sidx - gy * spans_per_row;
         const int span_px = min(SPAN_PX, p.width - (int)sx * SPAN_PX);             // < SPAN_PX only for the last span of a row
@@ -1998,7 +2010,7 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot
         u32x2 cr2 = { crv[0] | (crv[1] << 16), crv[2] | (crv[3] << 16) };
         span_store_samples4<true>(p.dst[1] + (long long)gy * p.dst_stride[1] + (long long)sx * SPAN_PX, csamples, (uint32_t)lane, cb2);
         span_store_samples4<true>(p.dst[2] + (long long)gy * p.dst_stride[2] + (long long)sx * SPAN_PX, csamples, (uint32_t)lane, cr2);
-        if (sidx + step < total) issue(sidx + step);                   // (capped grids: the loop's next span)
+        if (span_of(it + 1) < total) issue(span_of(it + 1));           // the wave's next span (rotated loop: its loads leave behind this span's stores)
     }
 }
 
@@ -3926,7 +3938,8 @@ hipError_t launch_stream_f32_sub_rgba(const WriteParams& p, int depth, int plane
         const long long spans = (long long)((p.width + 511) / 512) * ((p.nrows + (1 << ys) - 1) >> ys);
         if (spans == 0) return hipSuccess;
         if (spans + 8LL * 65536 * 4 < 0x7fffffffLL) {
-            long long blocks = (spans + kF32Waves - 1) / kF32Waves;
+            const int spw = (AG_SUB_SPW2 && ys == 0 && (p.width % 512) == 0 && spans >= AG_SUB_SPW2_MIN_SPANS) ? 2 : 1;      // spans per wave (see the kernel's loop)
+            long long blocks = (spans + kF32Waves * spw - 1) / (kF32Waves * spw);
             if (blocks > AG_STREAM_BLOCK_CAP * 4 / kF32Waves) blocks = AG_STREAM_BLOCK_CAP * 4 / kF32Waves;
             snprintf(label, kLabelBytes, "write_rgb32_ycbcr_sub_hot<transfer=%d,xs=1,ys=%d>%s", p.transfer, ys, icc1 ? " icc=1" : icc4 ? " icc=4" : icc2 ? " icc=2" : "");
 #define AG_SUB3(TR, YS_, IC) do { if (p.nearest) hipLaunchKernelGGL((write_rgb32_ycbcr_sub_hot<TR, 1, YS_, IC, true>), dim3((int)blocks), dim3(AG_F32_STREAM_BLOCK), 0, st, p); \
