@@ -1544,6 +1544,14 @@ template <bool NT, typename V> AG_DEV void stream_store(V* p, V v)
 #ifndef AG_SUB_PRIO
 #define AG_SUB_PRIO 1
 #endif
+// Round 6: SGPR budget of the f32 streaming kernels.  MI355X admits min(8, 800 / (ceil(sgpr / 16) * 16 + 16)) waves per SIMD (MI355X_MICROARCH.md,
+// "Residency"): <= 80 SGPRs -> 8 waves, 82-96 -> 7, 98-112 -> 6.  These kernels sat at 98-106 (WriteParams is large) = SIX waves per SIMD whatever
+// their 46 VGPRs allow -- tools/dump_isa.py's occupancy column looked at VGPRs only until this round.  Measured with
+// AG_F32_SGPRS = __attribute__((amdgpu_num_sgpr(80))) (78 SGPRs, +1 VGPR, no scratch: 8 waves) and (96) (7 waves): nothing, or -1 % -- the curve of
+// profiles/r05/occupancy_sweep_444.txt (flat above ~5 waves) holds at the top end too.  Left empty; profiles/r06/sgpr_budget_ab.txt.
+#ifndef AG_F32_SGPRS
+#define AG_F32_SGPRS
+#endif
 #ifndef AG_SUB_SPW2
 #define AG_SUB_SPW2 1                  /* 4:2:2 tiles of whole 512-pixel spans: two spans per wave (write_rgb32_ycbcr_sub_hot's loop) */
 #endif
@@ -1582,7 +1590,7 @@ template <bool NT, typename V> AG_DEV void stream_store(V* p, V v)
 #endif
 constexpr int kHot444Waves = AG_HOT444_BLOCK / 64;
 template <int TRANSFER, int PXL, bool NT>
-__global__ __launch_bounds__(AG_HOT444_BLOCK) void write_rgb32_ycbcr444_hot(const WriteParams p)
+__global__ __launch_bounds__(AG_HOT444_BLOCK) AG_F32_SGPRS void write_rgb32_ycbcr444_hot(const WriteParams p)
 {
     constexpr int WPB = kHot444Waves;
     constexpr int K = 3 * PXL / 4;               // float4 per lane per span
@@ -1748,7 +1756,7 @@ __global__ __launch_bounds__(AG_HOT444_BLOCK) void write_rgb32_ycbcr444_hot(cons
 // (wave_span_store; the strip of a 6-float4 half span is exactly a lane-major span of 12 dwords per lane).  A 32-bit document with a linear
 // profile saved through the default adapter ran on the generic kernel until then (0.68 of 8 TB/s at 8192^2).
 template <int TRANSFER, int ICCV, bool OUTREF = false>
-__global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444_hot(const WriteParams p)
+__global__ __launch_bounds__(AG_F32_STREAM_BLOCK) AG_F32_SGPRS void write_rgb32_icc1_ycbcr444_hot(const WriteParams p)
 {
     constexpr bool LATE = AG_PQ_LATE_FILL && TRANSFER == kTransferPqHi;            // (round 5: as in write_rgb32_ycbcr444_hot)
     if constexpr (AG_SUB_PRIO && !OUTREF) __builtin_amdgcn_s_setprio(3);
@@ -1857,7 +1865,7 @@ __global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_icc1_ycbcr444
 // ICC1: the linear-profile matrix in front, as in write_rgb32_icc1_ycbcr444_hot -- the document's floats cross the strip, matrix and
 // curve run pixel-major, and the levels are where the rest of the kernel wants them.
 template <int TRANSFER, int XS, int YS, int ICCV = 0, bool NEAREST = false>       // ICCV: 0 none, 1 linear-profile matrix, 4 matrix + inverse sRGB curve; NEAREST: p.nearest as a constant (libheif 1.14's chroma rule, the shim's default)
-__global__ __launch_bounds__(AG_F32_STREAM_BLOCK) void write_rgb32_ycbcr_sub_hot(const WriteParams p)
+__global__ __launch_bounds__(AG_F32_STREAM_BLOCK) AG_F32_SGPRS void write_rgb32_ycbcr_sub_hot(const WriteParams p)
 {
     // (round 5, as in the 4:4:4 kernel) the PQ table's loads, then the first span's, the table's LDS writes + barrier under their flight
     constexpr bool LATE = AG_PQ_LATE_FILL && TRANSFER == kTransferPqHi;
@@ -2079,7 +2087,7 @@ AG_DEV void rgba_levels(const WriteParams& p, f32x4 (&v)[PXL])
 }
 
 template <int TRANSFER, int ICCV = 0>            // ICCV 1: the linear-profile matrix on R, G, B first (ConvertRow runs before the pixel loop and copies alpha); 4: + inverse sRGB curve
-__global__ __launch_bounds__(AG_RGBA_STREAM_BLOCK) void write_rgba32_ycbcra444_hot(const WriteParams p)
+__global__ __launch_bounds__(AG_RGBA_STREAM_BLOCK) AG_F32_SGPRS void write_rgba32_ycbcra444_hot(const WriteParams p)
 {
     constexpr bool LATE = AG_PQ_LATE_FILL && TRANSFER == kTransferPqHi;            // (round 5: as in write_rgb32_ycbcr444_hot)
     if constexpr (AG_RGBA_PRIO) __builtin_amdgcn_s_setprio(3);
@@ -2159,7 +2167,7 @@ __global__ __launch_bounds__(AG_RGBA_STREAM_BLOCK) void write_rgba32_ycbcra444_h
 // a lane ends with pixels [4l, 4l+4) of each row = the footprint of 2 chroma samples; luma and alpha leave row by row (8 bytes per
 // lane and plane), the chroma pair as one dword per plane.  Any width; rows and planes dword-aligned.
 template <int TRANSFER, int YS, bool NEAREST>
-__global__ __launch_bounds__(AG_RGBA_STREAM_BLOCK) void write_rgba32_ycbcra_sub_hot(const WriteParams p)
+__global__ __launch_bounds__(AG_RGBA_STREAM_BLOCK) AG_F32_SGPRS void write_rgba32_ycbcra_sub_hot(const WriteParams p)
 {
     constexpr bool LATE = AG_PQ_LATE_FILL && TRANSFER == kTransferPqHi;            // (round 5: as in write_rgb32_ycbcr444_hot)
     if constexpr (AG_RGBA_PRIO) __builtin_amdgcn_s_setprio(3);
@@ -3108,7 +3116,7 @@ __global__ __launch_bounds__(256) void write_rgba8_ycbcra_hot(const WriteParams 
 // Output sample i is a function of input sample i (RGB) or of its own pixel's float4 (RGBA): no transposition at all.  A wave
 // streams 64 x 4 float4 per trip: coalesced non-temporal 16-byte loads, the curve, 8-byte non-temporal stores at the same index.
 template <int TRANSFER, int PLANES>
-__global__ __launch_bounds__(AG_F32_REF_BLOCK) void write_f32_ref_stream(const WriteParams p)
+__global__ __launch_bounds__(AG_F32_REF_BLOCK) AG_F32_SGPRS void write_f32_ref_stream(const WriteParams p)
 {
     constexpr bool LATE = AG_PQ_LATE_FILL && TRANSFER == kTransferPqHi;            // (round 5: as in write_rgb32_ycbcr444_hot)
     if constexpr (AG_REF_PRIO) __builtin_amdgcn_s_setprio(3);

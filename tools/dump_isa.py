@@ -4,8 +4,8 @@
   python tools/dump_isa.py OUTDIR [regex ...]
 
 For every avif-format_amd/build/*.hip.o: pulls the gfx950 code object out of .hip_fatbin (objcopy + clang-offload-bundler),
-reads the AMDGPU metadata notes (VGPRs, AGPRs, SGPRs, LDS, scratch, occupancy derived from VGPRs), and writes
-  OUTDIR/resources.tsv   one row per kernel (demangled name, vgpr, agpr, sgpr, lds bytes, scratch bytes, waves/SIMD by VGPR)
+reads the AMDGPU metadata notes (VGPRs, AGPRs, SGPRs, LDS, scratch, occupancy derived from VGPRs and -- since round 6 -- SGPRs), and writes
+  OUTDIR/resources.tsv   one row per kernel (demangled name, vgpr, agpr, sgpr, lds bytes, scratch bytes, waves/SIMD by VGPR and SGPR)
   OUTDIR/<n>.s           llvm-objdump -d of every kernel whose demangled name matches one of the regexes
 so that statements like "54 VGPRs, 8 waves/SIMD, 6 x global_load_dwordx4 nt" in DESIGN.md can be checked against files."""
 import glob
@@ -53,7 +53,10 @@ def main():
         for k, dn in zip(kernels, names):
             vg, ag = int(k.get("vgpr_count", 0)), int(k.get("agpr_count", 0))
             tot = max(vg + ag, 1)                      # unified 512-entry file per SIMD lane, allocation granule 8
-            waves = min(8, 512 // (((tot + 7) // 8) * 8))
+            sg = int(k.get("sgpr_count", 0))
+            # ... and the scalar file (round 6): MI355X admits min(8, 800 // (ceil(sgpr / 16) * 16 + 16)) waves per SIMD
+            # (MI355X_MICROARCH.md, "Residency": <= 80 SGPRs -> 8, 82-96 -> 7, 98-112 -> 6) -- rounds 1-5 looked at VGPRs only
+            waves = min(8, 512 // (((tot + 7) // 8) * 8), 800 // (((sg + 15) // 16) * 16 + 16) if sg else 8)
             rows.append((base, dn, vg, ag, int(k.get("sgpr_count", 0)), int(k.get("group_segment_fixed_size", 0)),
                          int(k.get("private_segment_fixed_size", 0)), waves))
             if any(p.search(dn) for p in pats):
