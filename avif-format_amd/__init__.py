@@ -170,6 +170,7 @@ ABI = [
     ("avifgpu_last_kernel_name", c_char_p, []),
     ("avifgpu_set_hot_variant", None, [c_int32]),
     ("avifgpu_probe_pattern_read", c_int32, [POINTER(ReadDesc), c_int32, c_int32, POINTER(_PLANES4), POINTER(_STRIDES4), c_void_p, c_int64, c_void_p]),
+    ("avifgpu_probe_set_shape", None, [c_int32, c_int32, c_int32]),
     ("avifgpu_probe_pattern_rgb32_444", c_int32, [c_void_p, c_int64, POINTER(c_void_p * 3), POINTER(c_int64 * 3), c_int32, c_int32, c_void_p]),
 ]
 
@@ -180,7 +181,7 @@ ABI = [
 ABI4_NEW = frozenset(("avifgpu_probe_pattern_read", "avifgpu_probe_pattern_rgb32_444", "avifgpu_device_traffic_get", "avifgpu_device_traffic_reset",
                       "avifgpu_topology_plan", "avifgpu_icc_prepare_sampled", "avifgpu_write_rows_icc_sampled",
                       "avifgpu_icc_clut16_from_transforms",
-                      "avifgpu_icc_clut8_from_transforms", "avifgpu_write_rows_icc8_table"))       # (ABI 5, round 6)
+                      "avifgpu_icc_clut8_from_transforms", "avifgpu_write_rows_icc8_table", "avifgpu_probe_set_shape"))       # (ABI 5, round 6)
 
 
 def bind(lib: ctypes.CDLL, table=ABI) -> ctypes.CDLL:

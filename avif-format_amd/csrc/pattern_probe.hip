@@ -9,6 +9,7 @@
 // hook, not part of the reference mapping: the planes receive a checksum of the loaded floats.  (The read kernels have their twin
 // inside read_kernels.hip: read_px<..., TWIN = true>, avifgpu_probe_pattern_read.)
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -21,7 +22,7 @@ typedef float    pp_f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t pp_u4 __attribute__((ext_vector_type(4)));
 typedef int      pp_i4 __attribute__((__vector_size__(16)));
 
-constexpr int kProbeWaves = 4;                 // the hot kernel's workgroup; AVIFGPU_PROBE_WAVES = 1 / 2 measures the pattern from smaller ones
+constexpr int kProbeWaves = 4;                 // the hot kernel's workgroup; avifgpu_probe_set_shape(1 | 2, ...) measures the pattern from smaller ones
 template <int K> __device__ __forceinline__ pp_i4 probe_load(__amdgpu_buffer_rsrc_t rs, int voff)
 {
     return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 1024 * K, span_load_cached(K, 6) ? 0 : 2);
@@ -71,6 +72,18 @@ __global__ __launch_bounds__(64 * WAVES) void pattern_rgb32_planes444(const uint
 
 } // namespace avifgpu
 
+namespace {
+std::atomic<int> g_probe_waves{avifgpu::kProbeWaves}, g_probe_global{0}, g_probe_pace{0};
+}
+// Measurement hook: the launch shape of the probe below -- workgroups of 4 / 2 / 1 waves (anything else: the kernel's own, 4), buffer (0) or
+// 64-bit global (1) addressing, and an optional pacing count (0 = none).  Process-wide; not part of the reference mapping.
+extern "C" void avifgpu_probe_set_shape(int32_t waves, int32_t global_addressing, int32_t pace)
+{
+    g_probe_waves.store((waves == 1 || waves == 2) ? waves : avifgpu::kProbeWaves, std::memory_order_relaxed);
+    g_probe_global.store(global_addressing != 0, std::memory_order_relaxed);
+    g_probe_pace.store(pace > 0 ? pace : 0, std::memory_order_relaxed);
+}
+
 extern "C" int32_t avifgpu_probe_pattern_rgb32_444(const void* src, int64_t src_row_bytes, void* const dst[3], const int64_t dst_stride[3],
                                                    int32_t width, int32_t nrows, void* stream)
 {
@@ -79,12 +92,11 @@ extern "C" int32_t avifgpu_probe_pattern_rgb32_444(const void* src, int64_t src_
     uintptr_t bits = reinterpret_cast<uintptr_t>(src) | (uintptr_t)src_row_bytes;
     for (int i = 0; i < 3; ++i) { if (!dst[i]) return fail(AVIFGPU_formatBadParameters, "pattern probe: null plane"); bits |= reinterpret_cast<uintptr_t>(dst[i]) | (uintptr_t)dst_stride[i]; }
     if (bits & 15) return fail(AVIFGPU_formatBadParameters, "pattern probe: pointers and strides must be 16-byte aligned");
-    static const int pace = [] { const char* e = getenv("AVIFGPU_PROBE_PACE"); return e ? atoi(e) : 0; }();
-    // (read on every call: bench.py times all six shapes in one process and prices the kernel against the FASTEST of them)
-    const char* ew = getenv("AVIFGPU_PROBE_WAVES");
-    const char* eg = getenv("AVIFGPU_PROBE_GLOBAL");
-    const int waves = ew && (atoi(ew) == 1 || atoi(ew) == 2) ? atoi(ew) : kProbeWaves;
-    const bool global = eg && atoi(eg) != 0;
+    // the launch shape comes from avifgpu_probe_set_shape (round 6; rounds 4-5 read AVIFGPU_PROBE_* from the environment on every call):
+    // bench.py times all six shapes in one process and prices the kernel against the FASTEST of them
+    const int pace = g_probe_pace.load(std::memory_order_relaxed);
+    const int waves = g_probe_waves.load(std::memory_order_relaxed);
+    const bool global = g_probe_global.load(std::memory_order_relaxed) != 0;
     const long long spans = (long long)(width / 512) * nrows;
     long long blocks = (spans + waves - 1) / waves;
     if (blocks > 256LL * 512 * 4 / waves) blocks = 256LL * 512 * 4 / waves;   // the hot kernel's own cap

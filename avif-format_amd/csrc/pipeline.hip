@@ -275,10 +275,13 @@ public:
     {
         { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
         cv_.notify_all();
-        for (std::thread& t : threads_) if (t.joinable()) t.join();
-        threads_.clear();
+        std::vector<std::thread> mine;
+        { std::lock_guard<std::mutex> lk(mu_); mine.swap(threads_); }
+        for (std::thread& t : mine) if (t.joinable()) t.join();
+        std::lock_guard<std::mutex> lk(mu_);
         stop_ = false;
     }
+    int thread_count() { std::lock_guard<std::mutex> lk(mu_); return (int)threads_.size(); }
 private:
     static int want() { return env_int("AVIFGPU_COPY_THREADS", 3, 0, 15); }
     static void run(const Piece& p)
@@ -327,14 +330,22 @@ CopyHelpers& copy_helpers()
 }
 void copy_helpers_shutdown()
 {
-    // the pools leave the map here, under the lock: copy_helper_pool_count() ("pools alive", avifgpu_device_traffic) then counts the pools
-    // of the CURRENT binding only, not every pool the process ever made.  The thread-less objects themselves are left
-    // alone -- a few hundred bytes each -- because a reference handed out by copy_helpers() may still be on some worker's stack.
+    // The pools STAY in the map (round 6; round 5 dropped them from it and leaked the objects): a worker that still holds a
+    // reference from copy_helpers() and calls copy() after this point re-spawns helper threads on a pool a later shutdown still finds and
+    // joins, and a re-binding reuses its node's pool instead of making another.  shutdown() joins the threads; the thread-less object is a
+    // few hundred bytes and is never destroyed (like the contexts: a reference may be on some worker's stack at process exit).
     std::vector<CopyHelpers*> pools;
-    { std::lock_guard<std::mutex> lk(g_helpers_mu); for (auto& kv : helper_pools()) pools.push_back(kv.second); helper_pools().clear(); }
+    { std::lock_guard<std::mutex> lk(g_helpers_mu); for (auto& kv : helper_pools()) pools.push_back(kv.second); }
     for (CopyHelpers* p : pools) p->shutdown();
 }
-int copy_helper_pool_count() { std::lock_guard<std::mutex> lk(g_helpers_mu); return (int)helper_pools().size(); }
+// "pools alive" (avifgpu_device_traffic): the pools of the CURRENT binding that have helper threads, not every pool the process ever made
+int copy_helper_pool_count()
+{
+    std::lock_guard<std::mutex> lk(g_helpers_mu);
+    int n = 0;
+    for (auto& kv : helper_pools()) if (kv.second && kv.second->thread_count() > 0) ++n;
+    return n;
+}
 
 void host_copy_rows(uint8_t* dst, size_t dst_pitch, const uint8_t* src, size_t src_pitch, size_t bytes, size_t rows)
 {

@@ -988,7 +988,16 @@ static hipError_t launch_read_one(const ReadParams& p, hipStream_t st, char* lab
                                                 (1u << p.bits) * sizeof(float) : 0;
     uintptr_t bits = reinterpret_cast<uintptr_t>(p.dst) | (uintptr_t)p.dst_row_bytes;
     for (int pl = 0; pl < 4; ++pl) if (p.src[pl]) bits |= reinterpret_cast<uintptr_t>(p.src[pl]) | (uintptr_t)p.src_stride[pl];
-    const bool aligned = (bits & 15) == 0;      // => branch-free vector loads + LDS-transposed coalesced stores
+    bool aligned = (bits & 15) == 0;            // => branch-free vector loads + LDS-transposed coalesced stores
+    // The ALIGNED 8-bit kernels take a plane row as a buffer resource of round4(row bytes) (load_plane, BUF): every row must own that many
+    // bytes of its pitch.  16-byte pitches >= the row (check_read_buffers) give it by construction (flat launches: one row = the whole
+    // plane); stated here as a check of its own so that a future relaxation of either cannot silently read into the next row.
+    if (aligned && DEPTH == 8)
+        for (int pl = 0; pl < 4; ++pl)
+            if (p.src[pl] && p.nrows > 1) {
+                const long long w = (CS == kCsYcc && (pl == 1 || pl == 2)) ? ((long long)p.width + (1 << XS) - 1) >> XS : (long long)p.width;
+                if (p.src_stride[pl] < ((w + 3) & ~3LL)) aligned = false;
+            }
     const size_t lds = lut_bytes + ((aligned && ND_OUT > 4) ? (size_t)kRpxWaves * WaveSpan<ND_OUT>::STRIP_DW * sizeof(uint32_t) : 0);
     snprintf(label, kLabelBytes, "read_px<cs=%d,depth=%d,alpha=%d,xs=%d,ys=%d,transfer=%d,aligned=%d>", CS, DEPTH, (int)ALPHA, XS, YS,
              TRANSFER, (int)aligned);

@@ -1585,6 +1585,9 @@ template <bool NT, typename V> AG_DEV void stream_store(V* p, V v)
 #ifndef AG_HOT444_BLOCK
 #define AG_HOT444_BLOCK AG_F32_STREAM_BLOCK
 #endif
+#ifndef AG_MEASURE
+#define AG_MEASURE 0          /* 1: measuring knobs that read the environment (AVIFGPU_DEBUG_LDS_PAD) are compiled in */
+#endif
 #ifndef AG_HOT444_GLOBAL
 #define AG_HOT444_GLOBAL 0
 #endif
@@ -4125,7 +4128,12 @@ static hipError_t launch_write_impl(const WriteParams& p, int depth, int planes,
             snprintf(label, kLabelBytes, "write_rgb32_ycbcr444_hot<transfer=%d,pxl=%d,nt=%d>", p.transfer, px8 ? 8 : 4, (int)nt);
             // measuring knob (not a tuning word of the product): AVIFGPU_DEBUG_LDS_PAD = bytes of unused dynamic LDS per workgroup, i.e. fewer
             // resident workgroups per CU -- how the kernel's rate depends on the number of waves per SIMD (profiles/r05/occupancy_sweep_444.txt)
-            static const size_t lds_pad = [] { const char* e = getenv("AVIFGPU_DEBUG_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
+            // Compiled in only with -DAG_MEASURE=1 (tools/ab_variants.sh): a product launch reads no environment variable.
+#if AG_MEASURE
+            static const size_t lds_pad = [] { const char* e = getenv("AVIFGPU_DEBUG_LDS_PAD"); const long v = e ? atol(e) : 0; return (size_t)(v < 0 ? 0 : (v > 140000 ? 140000 : v)); }();
+#else
+            constexpr size_t lds_pad = 0;
+#endif
 #define AG_HOT3(TR, PX, NT_) hipLaunchKernelGGL((write_rgb32_ycbcr444_hot<TR, PX, NT_>), dim3((int)blocks), dim3(AG_HOT444_BLOCK), lds_pad, st, p)
 #define AG_HOT2(TR, PX) do { if (nt) AG_HOT3(TR, PX, true); else AG_HOT3(TR, PX, false); } while (0)
 #define AG_HOT1(TR) do { if (px8) AG_HOT2(TR, 8); else AG_HOT2(TR, 4); } while (0)

@@ -495,16 +495,15 @@ def main():
             rc = lib.avifgpu_probe_pattern_rgb32_444(sp, src.stride(0) * 4, ctypes.byref(pj), ctypes.byref(ss), W, nrows, stream.cuda_stream)
             if rc:
                 raise RuntimeError(lib.avifgpu_last_error().decode())
-        # Round 5: the pattern in SIX launch shapes -- workgroups of 4 / 2 / 1 waves, buffer or 64-bit global addressing (AVIFGPU_PROBE_WAVES /
-        # _GLOBAL, read by the probe on every call).  The kernel's own shape (4 waves, buffer form) is the slowest of them on every box
+        # Round 5: the pattern in SIX launch shapes -- workgroups of 4 / 2 / 1 waves, buffer or 64-bit global addressing
+        # (avifgpu_probe_set_shape).  The kernel's own shape (4 waves, buffer form) is the slowest of them on every box
         # measured (profiles/r05/probe_shapes_and_kernel_shapes.txt); the ceiling the kernel is priced against is the FASTEST.
         try:
             np_ = max(20, min(args.steps, 200))
             shapes = {}
-            saved = {k: os.environ.get(k) for k in ("AVIFGPU_PROBE_WAVES", "AVIFGPU_PROBE_GLOBAL")}
             for glob in (0, 1):
                 for waves in (4, 2, 1):
-                    os.environ["AVIFGPU_PROBE_WAVES"], os.environ["AVIFGPU_PROBE_GLOBAL"] = str(waves), str(glob)
+                    lib.avifgpu_probe_set_shape(waves, glob, 0)
                     for _ in range(20):
                         probe()
                     torch.cuda.synchronize(dev)
@@ -515,11 +514,7 @@ def main():
                     p1.record(stream)
                     torch.cuda.synchronize(dev)
                     shapes["%d waves, %s" % (waves, "global" if glob else "buffer")] = round(p0.elapsed_time(p1) / np_, 5)
-            for k, v in saved.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
+            lib.avifgpu_probe_set_shape(4, 0, 0)
             best = min(shapes, key=shapes.get)
             pattern = {"launches": np_, "kernel_ms_mean": shapes[best], "shape": best, "shapes_ms": shapes,
                        "kernel_shape_ms": shapes["4 waves, buffer"]}

@@ -457,6 +457,8 @@ void avifgpu_set_hot_variant(int32_t variant);
  * 16-byte aligned pointers and strides; the planes receive a checksum, not pixels. */
 int32_t avifgpu_probe_pattern_rgb32_444(const void* src, int64_t src_row_bytes, void* const dst[3], const int64_t dst_stride[3],
                                         int32_t width, int32_t nrows, void* stream);
+/* Launch shape of that probe (round 6; process-wide): workgroups of 4 / 2 / 1 waves, buffer (0) or 64-bit global (1) addressing, pacing 0. */
+void avifgpu_probe_set_shape(int32_t waves, int32_t global_addressing, int32_t pace);
 /* ... and of the READ kernels: the math-free twin of what avifgpu_read_rows(AVIFGPU_MEM_DEVICE) would launch for `desc` (same loads,
  * table copy, LDS transpose and stores; dst receives meaningless bytes).  4:2:x colour opens to 8-bit and f32 (PQ) hosts on 16-byte
  * aligned device buffers; AVIFGPU_formatBadParameters for anything else. */

@@ -136,3 +136,33 @@ def test_unpremultiply_claims_hold_on_this_device(tool, needle):
         pytest.skip(f"tools/{tool} not built (make -C avif-format_amd)")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.count(needle) == 3, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("chroma,alpha", [(pkg.CHROMA_420, pkg.ALPHA_NONE), (pkg.CHROMA_422, pkg.ALPHA_NONE), (pkg.CHROMA_444, pkg.ALPHA_NONE),
+                                          (pkg.CHROMA_420, pkg.ALPHA_STRAIGHT)])
+def test_read_u8_planes_that_end_at_their_last_sample(gpu, chroma, alpha):
+    """the ALIGNED 8-bit kernels load a plane row through a buffer resource of round4(row bytes) and zero-fill beyond it.  Planes
+    whose ALLOCATION ends exactly at the last row's last sample (16-byte pitch, a width that is not a multiple of 4: the last row owns no
+    padding) must decode like the oracle -- nothing of the tail of a row may feed a stored pixel, nothing beyond the plane may be needed."""
+    import torch
+    dev = f"cuda:{gpu.device}"
+    d = pkg.ReadDesc(width=1001, height=7, colorspace=pkg.COLORSPACE_YCBCR, chroma=chroma, bit_depth=8, depth=8, alpha_state=alpha,
+                     matrix_coefficients=pkg.MATRIX_BT601)
+    planes = harness.make_read_source(d, seed=77)
+    want = harness.oracle_read(d, planes)
+    nch = harness.read_channels(d)
+    ptrs, strides, keep = [None] * 4, [0] * 4, []
+    for pl, (w, xs, ys) in harness.read_planes(d).items():
+        h = (d.height + ys) >> ys
+        pitch = (w + 15) // 16 * 16
+        flat = torch.zeros((h - 1) * pitch + w, dtype=torch.uint8, device=dev)          # ends at the last row's last sample
+        for r in range(h):
+            flat[r * pitch:r * pitch + w] = torch.from_numpy(planes[pl][r, :w].copy()).to(dev)
+        keep.append(flat)
+        ptrs[pl], strides[pl] = flat.data_ptr(), pitch
+    out = torch.zeros((d.height, (d.width * nch + 15) // 16 * 16), dtype=torch.uint8, device=dev)
+    gpu.read_rows(d, 0, d.height, ptrs, strides, out.data_ptr(), out.stride(0), mem=pkg.MEM_DEVICE, stream=torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
+    if all(t.data_ptr() % 16 == 0 for t in keep):
+        assert "aligned=1" in gpu.last_kernel(), gpu.last_kernel()
+    assert np.array_equal(out[:, :d.width * nch].cpu().numpy(), want)

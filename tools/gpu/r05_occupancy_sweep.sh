@@ -1,4 +1,5 @@
 #!/bin/bash
+# (round 6: AVIFGPU_DEBUG_LDS_PAD is compiled in only with -DAG_MEASURE=1: build the library with tools/ab_variants.sh write_kernels_p1 "-DAG_MEASURE=1" measure first)
 # Round 5: how the headline kernel's fresh-data rate depends on the waves per SIMD (unused dynamic LDS limits the resident workgroups:
 # 16 KiB static per 4-wave workgroup, 160 KiB per CU): pad 0 -> 8 waves per SIMD, 7000 -> 7, 11000 -> 6, 16500 -> 5, 24500 -> 4, 37500 -> 3
 for rep in 1 2; do for pad in 0 7000 11000 16500 24500 37500; do

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 6: bench.py sets the probe's shape through avifgpu_probe_set_shape and reports all six shapes itself -- pattern_shapes_ms; the two
+#  environment variables below are no longer read by the library.  Kept as the recipe of profiles/r05/probe_shapes_and_kernel_shapes.txt.)
 # Round 5: the headline kernel's math-free twin from workgroups of 1 / 2 / 4 waves, as buffer accesses (the kernels' form) and as
 # global_load / global_store with 64-bit lane addresses (tools/membench_r02's form), against membench_r02 itself on the same box.
 # Question: membench's bare C4 pattern runs at 0.80 of 8 TB/s from 128-thread workgroups and 0.72 from 256 -- is that reachable by
