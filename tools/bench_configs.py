@@ -318,6 +318,22 @@ if __name__ == "__main__":
         bench_write("16-bit doc + ICC, photograph-like input, saved as 8-bit 8192^2 RGB16 -> 8-bit 4:2:0", icc=gpu.icc_prepare_clut16(buf.raw[:n]), smooth=True, width=8192, height=8192, depth=16, planes=3, bit_depth=8, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=6, color_primaries=1)
         bench_write("8-bit doc + ICC (AdobeRGB -> sRGB, matrix-shaper) 8192^2 RGB8 -> 8-bit 4:2:0", icc=gpu.icc_prepare_shaper8(buf.raw[:n]), width=8192, height=8192, depth=8, planes=3, bit_depth=8, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=6, color_primaries=1)
         bench_write("8-bit doc + ICC, photograph-like input (smooth + noise) 8192^2 RGB8 -> 8-bit 4:2:0", icc=gpu.icc_prepare_shaper8(buf.raw[:n]), smooth=True, width=8192, height=8192, depth=8, planes=3, bit_depth=8, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=6, color_primaries=1)
+        # round 6: an 8-bit document behind a LUT-based (A2B) profile -- the 33^3 table read out of the caller's own transforms, PrelinEval8's evaluation
+        try:
+            L.oracle_icc_make_a2b_profile.restype = ctypes.c_int32
+            L.oracle_icc_make_a2b_profile.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_uint32]
+            L.oracle_icc_transform8_open.restype = ctypes.c_void_p
+            L.oracle_icc_transform8_open.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
+            L.oracle_icc_transform16_close.argtypes = [ctypes.c_void_p]
+            n = L.oracle_icc_make_a2b_profile(1, big, len(big))
+            h = L.oracle_icc_transform8_open(big.raw[:n], n, 0)
+            t8 = P.IccClut16()
+            if h and gpu.lib.avifgpu_icc_clut8_from_transforms(ctypes.cast(L.oracle_icc_transform16_run_float, ctypes.c_void_p), ctypes.cast(L.oracle_icc_transform8_run, ctypes.c_void_p), h, ctypes.byref(t8)) == 0:
+                bench_write("8-bit doc + ICC (LUT-based A2B profile -> sRGB, 33^3 table), photograph-like input 8192^2 RGB8 -> 8-bit 4:2:0", icc=t8, smooth=True, width=8192, height=8192, depth=8, planes=3, bit_depth=8, alpha_state=0, output=1, chroma=P.CHROMA_420, matrix_coefficients=6, color_primaries=1)
+            if h:
+                L.oracle_icc_transform16_close(h)
+        except AttributeError:
+            pass
     bench_read("R8 8192^2 8-bit 4:2:0 BT.709 -> RGB8", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_420, bit_depth=8, depth=8, alpha_state=0, matrix_coefficients=1)
     bench_read("R8 8192^2 8-bit 4:2:2 BT.601 -> RGB8 (what the default save decodes to)", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_422, bit_depth=8, depth=8, alpha_state=0, matrix_coefficients=6)
     bench_read("R8 8192^2 8-bit 4:4:4 BT.601 -> RGB8", width=8192, height=8192, colorspace=0, chroma=P.CHROMA_444, bit_depth=8, depth=8, alpha_state=0, matrix_coefficients=6)
