@@ -3372,7 +3372,7 @@ struct CopyParams { const uint8_t* src; uint8_t* dst; long long src_stride, dst_
 #define AG_COPY_K 2               /* 16-byte vectors per lane and wave trip */
 #endif
 template <int K>
-__global__ __launch_bounds__(AG_COPY_BLOCK) void copy_rows_stream(const CopyParams c)
+__global__ __launch_bounds__(AG_COPY_BLOCK) void write_copy_rows_stream(const CopyParams c)
 {
     constexpr int WAVES = AG_COPY_BLOCK / 64;
     const int wave = wave_in_block();
@@ -3673,7 +3673,7 @@ hipError_t launch_stream_int(const WriteParams& p, int depth, int planes, bool d
             long long blocks = (waves + kCopyWaves - 1) / kCopyWaves;
             if (blocks > AG_STREAM_BLOCK_CAP * 4 / kCopyWaves) blocks = AG_STREAM_BLOCK_CAP * 4 / kCopyWaves;
             snprintf(label, kLabelBytes, "write_copy_rows_stream<planes=%d>%s", planes, one ? " flat" : "");
-            hipLaunchKernelGGL((copy_rows_stream<kCopyK>), dim3((int)blocks), dim3(AG_COPY_BLOCK), 0, st, c);
+            hipLaunchKernelGGL((write_copy_rows_stream<kCopyK>), dim3((int)blocks), dim3(AG_COPY_BLOCK), 0, st, c);
             return hipGetLastError();
         }
     }

@@ -7,11 +7,11 @@ set -x
 out=gpurun_out/prof_r06; mkdir -p $out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-P="python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-c5 --no-pcie --no-live-traffic"
+P="python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-c5 --no-pcie --no-live-traffic --no-extra-configs"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/$out/kt -o kt --output-format csv -- bash -c "cd $R && $P > $out/bench_under_kernel_trace.json" > $R/$out/kt.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "write_rgb32" -d $R/$out/fetch -o f --output-format csv -- bash -c "cd $R && $P" > $R/$out/fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "write_rgb32" -d $R/$out/write -o w --output-format csv -- bash -c "cd $R && $P" > $R/$out/write.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "write_rgb32_ycbcr444_hot" -d $R/$out/fetch -o f --output-format csv -- bash -c "cd $R && $P" > $R/$out/fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "write_rgb32_ycbcr444_hot" -d $R/$out/write -o w --output-format csv -- bash -c "cd $R && $P" > $R/$out/write.log 2>&1
 cd $R
 python tools/summarize_kernel_trace.py $out/kt $out/bench_under_kernel_trace.json $out/kernel_stats_c4_444_timed_region.csv
 find $out/kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats_c4_444_all_launches.csv
@@ -21,7 +21,7 @@ def mean(pat, col):
     v = []
     for f in glob.glob(pat, recursive=True):
         for r in csv.DictReader(open(f)):
-            if r.get("Counter_Name") == col and "write_rgb32" in r["Kernel_Name"]:
+            if r.get("Counter_Name") == col and "write_rgb32_ycbcr444_hot" in r["Kernel_Name"]:
                 v.append(float(r["Counter_Value"]))
     return (sum(v) / len(v), len(v)) if v else (None, 0)
 f, nf = mean("gpurun_out/prof_r06/fetch/**/*counter_collection.csv", "FETCH_SIZE")
