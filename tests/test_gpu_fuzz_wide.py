@@ -40,7 +40,8 @@ def _case(i):
     depth = int(rng.choice([8, 8, 16, 32, 32]))
     planes = int(rng.choice([3, 3, 4]))
     chroma = int(rng.choice([pkg.CHROMA_444, pkg.CHROMA_422, pkg.CHROMA_420]))
-    bits = {8: [8, 8, 10], 16: [10, 12, 8], 32: [10, 12]}[depth][int(rng.integers(0, 3 if depth != 32 else 2))]
+    choices = {8: [8, 8, 10, 12], 16: [10, 12, 8], 32: [10, 12]}[depth]          # (round 6: 8-bit documents at 12 bit too -- write_rgb8_ycbcr16_hot)
+    bits = choices[int(rng.integers(0, len(choices)))]
     w = int(rng.integers(40, 3000))
     w -= w % int(rng.choice([1, 4, 8, 16]))
     w = max(w, 8)
@@ -57,6 +58,8 @@ def _case(i):
         if alpha == pkg.ALPHA_PREMULTIPLIED and kw["transfer"] != pkg.TRANSFER_CLIP:
             kw["alpha_state"] = pkg.ALPHA_STRAIGHT               # premultiply is disabled for HDR saves (Write.cpp:251-257)
     cut = 2 * int(rng.integers(0, h // 2 + 1))
+    if rng.random() < 0.2:                                       # round 6: the reference's own interleaved hand-off as well (the 8-bit identity case is a copy kernel)
+        kw["output"] = pkg.OUT_REFERENCE
     return kw, cut
 
 
