@@ -6,7 +6,8 @@
 //
 // Work shape: pure streaming, HBM-bound, no reuse => no MFMA, no cross-block traffic, no XCD swizzle
 // (T1 only pays when neighbouring blocks share operands).  Two families:
-//   * write_px, the GENERIC kernel (every configuration the API accepts; the fall-back of everything below): one thread owns
+//   * write_px, the GENERIC kernel (every configuration the API accepts; the fall-back of everything below and -- since round 6 no save without
+//     an ICC profile runs here unless its geometry disqualifies it -- the home of the table-driven ICC stages icc = 3 / 5 / 6 / 7): one thread owns
 //     PXT = (4 or 8) << XS horizontally adjacent pixels on 1 << YS rows, i.e. exactly the footprint of 4 (8) chroma samples, so every plane
 //     store is one 8-byte (u16) / 4-byte (u8) vector per lane, contiguous across the wave, the chroma box filter needs no cross-lane
 //     traffic, and the interleaved source is read as whole dwordx4/x2 vectors (lane stride = PXT * bytes per pixel);
@@ -34,8 +35,9 @@ namespace avifgpu {
 // runtime loads one by one, on the first launch of a kernel of theirs -- a save then pays for the object its kernels live in, not for
 // all 650 instantiations (round 4: one 6.8-MB object, 18 ms in front of the first launch of a process):
 //    1   launch_write(), the only entry point, + the RGB f32 4:4:4 streaming kernels (the headline, with and without a profile in front) and
-//        the f32 interleaved hand-off (which Gray32 without alpha takes too);  2  the 8- and 16-bit streaming kernels (RGB8, RGBA8, RGB16,
-//        RGBA16 4:4:4 and 4:2:x, Gray16 + alpha, the integer hand-off);  3  RGB f32 4:2:2 / 4:2:0, RGBA f32 and Gray32 + alpha streaming kernels
+//        the f32 interleaved hand-off (which Gray32 without alpha takes too);  2  the 8- and 16-bit streaming kernels (RGB8 -> u8 and -- round 6 --
+//        u16 planes, RGBA8, RGB16, RGBA16 4:4:4 and 4:2:x incl. their u8-plane variants, Gray16 + alpha, the integer hand-off, the 8-bit identity
+//        hand-off as a copy);  3  RGB f32 4:2:2 / 4:2:0, RGBA f32 and Gray32 + alpha streaming kernels
 //    8, 16   write_px, the generic kernel, for 8- and 16-bit documents
 //    32  write_px for gray (+ alpha) f32 documents (the fall-back of their streaming kernels), 33 for RGB(A) f32 documents (the fall-back of the streaming kernels
 //        and the parametric-curve ICC variants), 36 write_px<32, ..., icc = 6>: documents whose profile carries sampled curves
