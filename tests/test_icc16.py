@@ -504,6 +504,43 @@ def test_host_shim_converts_a_lut_based_16bit_document_with_the_callers_table(gp
 
 
 @pytest.mark.gpu
+def test_host_shim_sees_a_table_rewritten_in_place_between_two_saves(gpu, lcms):
+    """The shim queues its tiles past avifgpu_write_rows; it must advance the ICC table epoch all the same: two saves of a black 16-bit
+    document with the SAME table struct, rewritten in between at a word the strided fingerprint does not sample, differ like a fresh struct does."""
+    from fake_host import FakeHost
+    H = pkg.host
+    icc = _a2b_profile(lcms, 1)
+    rc, table = _bridge_table(icc)
+    assert rc == 0
+    keep = ctypes.create_string_buffer(icc, len(icc))
+    w, h = 256, 48
+    src = np.zeros((h, w * 3), dtype=np.uint16)
+    opts = H.SaveUIOptions(imageBitDepth=12, hdrTransferFunction=pkg.TRANSFER_CLIP, pq=H.PQOptions(1000), chromaSubsampling=pkg.CHROMA_444,
+                           lossless=0, keepColorProfile=0, iccDecision=H.ICC_LIKE_PLUGIN)
+
+    def save(t):
+        host = FakeHost(w, h, 16, 3, max_data=w * 6 * 7, image=src)              # several tiles per save
+        host.fr.iCCprofileData = ctypes.cast(keep, ctypes.c_void_p)
+        host.fr.iCCprofileSize = len(icc)
+        img = H.Image()
+        code = gpu.lib.avifgpu_host_create_heif_image_with_table(ctypes.byref(host.fr), pkg.ALPHA_NONE, ctypes.byref(opts), pkg.OUT_REFERENCE,
+                                                                 pkg.MATRIX_BT601, pkg.PRIMARIES_BT709, ctypes.byref(t), ctypes.byref(img))
+        assert code == 0, gpu.lib.avifgpu_last_error()
+        raw = (ctypes.c_uint8 * (img.stride[0] * h)).from_address(img.plane[0])
+        out = np.frombuffer(raw, dtype=np.uint8).reshape(h, img.stride[0])[:, :w * 6].copy()
+        gpu.lib.avifgpu_image_free(ctypes.byref(img))
+        return out
+    first = save(table)
+    table.table[0][2] = (table.table[0][2] + 0x4000) & 0xffff
+    second = save(table)
+    fresh = pkg.IccClut16()
+    ctypes.memmove(ctypes.byref(fresh), ctypes.byref(table), ctypes.sizeof(table))
+    third = save(fresh)
+    assert not np.array_equal(first, third)
+    assert np.array_equal(second, third), "stale device copy of a table rewritten in place between two shim saves"
+
+
+@pytest.mark.gpu
 def test_icc_tables_are_bound_to_their_document_depth(gpu, lcms):
     """A 16-bit table on an 8-bit document (and vice versa), or a table with a foreign grid size, is a caller error."""
     icc = _profile(lcms, 3, 0, 2.19921875)
