@@ -254,7 +254,7 @@ def test_rebind_and_device_pointers_after_multi(rebind):
 def test_fullsize_c4_eight_contexts_equal_one(rebind):
     """BASELINE.json configs[3] at full size (8192 x 8192 RGB f32 -> 10-bit PQ YCbCr 4:4:4: 805 MB in, 403 MB out) from host memory:
     the planes produced by 8 contexts (the 8-GPU split of one image; here 8 x 2 workers on the visible device(s)) are
-    byte-identical to the 1-context planes, and a stripe of them matches the oracle."""
+    byte-identical to the 1-context planes, and every sample of them matches the oracle (T2 bar at 10 bit)."""
     import torch
     W = H_ = 8192
     d = pkg.WriteDesc(width=W, height=H_, depth=32, planes=3, bit_depth=10, transfer=pkg.TRANSFER_PQ, peak_nits=80,
@@ -271,15 +271,15 @@ def test_fullsize_c4_eight_contexts_equal_one(rebind):
         outs[n] = planes
     for a, b in zip(outs[1], outs[8]):
         assert torch.equal(a, b)
-    r0, nr = 4090, 12                                        # a stripe across the cut between contexts 3 and 4 (row 4096)
-    sub = src[r0:r0 + nr].numpy()
-    want = {}
-    bufs = harness._alloc_write_out(d, nr)
-    ptrs = pkg.planes4([bufs[i].ctypes.data if i in bufs else None for i in range(4)])
-    strides = pkg.strides4([bufs[i].strides[0] if i in bufs else 0 for i in range(4)])
-    import oracle_binding
-    assert oracle_binding.load().oracle_write_rows(ctypes.byref(d), r0, nr, sub.ctypes.data, sub.strides[0], ctypes.byref(ptrs), ctypes.byref(strides)) == 0
+    # ... and the WHOLE frame against the oracle on every host core (round 6; rounds 3-5 compared a 12-row stripe across one cut)
+    from test_gpu_fullsize import _oracle_frame
+    want = _oracle_frame(d, src.numpy())
     for pl in range(3):
-        got = outs[8][pl][r0:r0 + nr].numpy().view(np.uint16)
-        diff = np.abs(got.astype(np.int64) - bufs[pl][:nr, :W].astype(np.int64))
-        assert diff.max() <= 1 and (diff == 0).mean() > 0.997, (pl, int(diff.max()), float((diff == 0).mean()))
+        got = outs[8][pl].numpy().view(np.uint16)
+        bad, worst = 0, 0
+        for r in range(0, H_, 1024):
+            diff = np.abs(got[r:r + 1024].astype(np.int32) - want[pl][r:r + 1024, :W].astype(np.int32))
+            bad += int(np.count_nonzero(diff))
+            worst = max(worst, int(diff.max()))
+        exact = 1.0 - bad / (H_ * W)
+        assert worst <= 1 and exact >= 0.9995, (pl, worst, exact)
