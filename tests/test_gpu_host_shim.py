@@ -129,3 +129,35 @@ def test_open_hdr_requires_nclx(gpu):
     code = gpu.lib.avifgpu_host_read_heif_image(ctypes.byref(img), pkg.ALPHA_NONE, None, None, ctypes.byref(host.fr))
     assert code == pkg.readErr and b"nclxProfile is null" in gpu.lib.avifgpu_last_error()
 
+
+
+@pytest.mark.parametrize("tc,load", [
+    (pkg.TC_PQ, dict(pq=1000)), (pkg.TC_HLG, dict(ootf=1, gamma=1.4, peak=600)), (pkg.TC_HLG, dict(ootf=0)), (pkg.TC_SMPTE428, dict())],
+    ids=["pq-1000nits", "hlg-ootf-gamma1.4-600nits", "hlg-no-ootf", "smpte428"])
+def test_open_hdr_takes_the_load_options(gpu, tc, load):
+    """A 32-bit open through the shim: LoadUIOptions (Read.cpp:592-625 hands them to ReadHeifImage*ThirtyTwoBit) must reach the kernel --
+    PQ nominal peak, HLG OOTF on/off with its display gamma and peak (ColorTransfer.cpp:192-205) -- tiles of 5 rows, against the oracle
+    driven with the same values in its descriptor (T2 read bar)."""
+    w, h = 131, 37
+    opts = H.LoadUIOptions(hlg=H.HLGOptions(load.get("ootf", 0), load.get("gamma", 1.2), load.get("peak", 1000)), pq=H.PQOptions(load.get("pq", 80)))
+    d = pkg.ReadDesc(width=w, height=h, colorspace=pkg.COLORSPACE_YCBCR, chroma=pkg.CHROMA_420, bit_depth=10, depth=32, alpha_state=pkg.ALPHA_NONE,
+                     matrix_coefficients=pkg.MATRIX_BT2020_NCL, color_primaries=pkg.PRIMARIES_BT2020, transfer_characteristics=tc,
+                     pq_peak_nits=opts.pq.nominalPeakBrightness, hlg_apply_ootf=opts.hlg.applyOOTF, hlg_display_gamma=opts.hlg.displayGamma,
+                     hlg_peak_nits=opts.hlg.nominalPeakBrightness)
+    planes = harness.make_read_source(d)
+    want = harness.oracle_read(d, planes)
+    host = FakeHost(w, h, 32, 3, max_data=w * 3 * 4 * 5)
+    img = H.Image(width=w, height=h, colorspace=d.colorspace, chroma=d.chroma, bit_depth=d.bit_depth)
+    for pl, a in planes.items():
+        img.plane[pl], img.stride[pl] = a.ctypes.data, a.strides[0]
+    nclx = H.Nclx(d.color_primaries, d.transfer_characteristics, d.matrix_coefficients, d.full_range_flag)
+    code = gpu.lib.avifgpu_host_read_heif_image(ctypes.byref(img), pkg.ALPHA_NONE, ctypes.byref(nclx), ctypes.byref(opts), ctypes.byref(host.fr))
+    assert code == 0, gpu.lib.avifgpu_last_error()
+    assert len(host.rects) > 3
+    got = host.image.astype(np.float64)
+    assert np.all(np.abs(got - want) <= 1e-4 * np.abs(want) + 1e-9), (tc, load, float(np.abs(got - want).max()))
+    # the options matter: the same planes decoded with the defaults (80 nits; gamma 1.2 / 1000 nits) differ wherever they are used
+    if load.get("pq") or load.get("ootf"):
+        dflt = pkg.ReadDesc(width=w, height=h, colorspace=d.colorspace, chroma=d.chroma, bit_depth=10, depth=32, alpha_state=pkg.ALPHA_NONE,
+                            matrix_coefficients=d.matrix_coefficients, color_primaries=d.color_primaries, transfer_characteristics=tc)
+        assert not np.allclose(harness.oracle_read(dflt, planes), want)
