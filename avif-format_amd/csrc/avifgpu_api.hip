@@ -177,18 +177,21 @@ struct IccDeviceTables {
     // between two saves, and a change the stride misses -- 32 consecutive floats of a 4096-entry curve -- would otherwise keep the stale
     // device copy).  "Within an image" is an EPOCH, not "row0 != 0" (round 6): the tables are cached per device and a
     // multi-GPU save hands row 0 to one device only, so the first tile EACH device sees in an epoch takes the full comparison.  The
-    // epoch advances whenever a calling thread's row sequence restarts (row0 <= the row0 of its previous ICC call: a new image, or the
-    // same tile of the next image) -- icc_epoch_for_call() below.
+    // epoch advances with every call that does not continue the calling thread's previous one row for row (a new image, a rank's own
+    // tile of the next image, tiles out of order) -- icc_epoch_for_call() below.
     const void* s32_src = nullptr;   uint64_t s32_fp = 0;   uint64_t s32_epoch = 0;
     const void* icc16_src = nullptr; uint64_t icc16_fp = 0; uint64_t icc16_epoch = 0;
 };
 static std::atomic<uint64_t> g_icc_epoch{1};
-// Called once per C-ABI write call that carries an ICC table, on the caller's thread, before any tile is dealt.
-void icc_epoch_for_call(int row0)
+// Called once per C-ABI write call (or shim tile) that carries an ICC table, on the caller's thread, before any tile is dealt.  Only a call
+// that CONTINUES the calling thread's previous one -- row0 == the row after its last -- stays in its epoch: the tiles of one save, handed over
+// top to bottom.  Anything else (row 0, a restart, a gap, tiles out of order, another geometry) starts a new epoch and costs each device
+// one byte-for-byte comparison of the table.
+void icc_epoch_for_call(int row0, int nrows)
 {
-    thread_local int last_row0 = 0x7fffffff;
-    if (row0 <= last_row0) g_icc_epoch.fetch_add(1, std::memory_order_relaxed);
-    last_row0 = row0;
+    thread_local long long next_row = -1;
+    if (row0 == 0 || (long long)row0 != next_row) g_icc_epoch.fetch_add(1, std::memory_order_relaxed);
+    next_row = (long long)row0 + nrows;
 }
 static uint64_t table_fingerprint(const void* base, size_t bytes)
 {
@@ -240,7 +243,7 @@ int upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p)
     // node stored up to eight times, 4.6 MB: two gathers from one line, but the table did not stay in the 4 MB L2 next to the streams
     // and uniformly random input re-fetched it from the Infinity Cache at 2.4 x the algorithmic traffic; layout 1 below, kept for A/B).
     constexpr size_t G = AVIFGPU_ICC_CLUT_GRID;
-    constexpr size_t kRecU16 = kIcc16RecBytes / 2;
+    [[maybe_unused]] constexpr size_t kRecU16 = kIcc16RecBytes / 2;       // (layout 1 only)
     const size_t rec_bytes = AG_ICC16_DOT2 == 2 ? (size_t)kIcc16PairTablesBytes : G * G * G * kIcc16RecBytes;
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
@@ -730,7 +733,7 @@ int write_rows_any(const avifgpu_write_desc* d, const IccArgs& icc, int32_t row0
     if ((err = check_write_buffers(d, g, nrows, src, src_row_bytes, dst, dst_stride))) return err;
     if (context_count() == 0) return fail(AVIFGPU_formatBadParameters, "%s", kNoDevice);
     if (nrows == 0) return 0;
-    if (icc.c16 || icc.s32 || icc.c8t) icc_epoch_for_call(row0);       // the device copies of these tables are re-verified once per device and epoch
+    if (icc.c16 || icc.s32 || icc.c8t) icc_epoch_for_call(row0, nrows);       // the device copies of these tables are re-verified once per device and epoch
 
     if (mem_kind == AVIFGPU_MEM_DEVICE) {
         // zero-copy: the kernel is enqueued on the caller's stream, on the caller's current device (where the pointers live)

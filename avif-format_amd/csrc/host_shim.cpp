@@ -268,8 +268,8 @@ void CreateHeifImageInto(FormatRecordPtr formatRecord, AlphaState alphaState, co
             stride[pl] = img->stride[pl];
         }
         // (the shim queues tiles itself, past avifgpu_write_rows: it advances the ICC table epoch the way that entry does -- the rows of a
-        //  save ascend, so the first tile of every save starts a new epoch and each device re-verifies its copy of the table once per save)
-        if (iccArgs.c16 || iccArgs.s32 || iccArgs.c8t) avifgpu::icc_epoch_for_call(top);
+        //  save ascend without a gap, so the first tile of every save starts a new epoch and each device re-verifies its copy of the table once per save)
+        if (iccArgs.c16 || iccArgs.s32 || iccArgs.c8t) avifgpu::icc_epoch_for_call(top, bottom - top);
         const int err = avifgpu::write_tile_enqueue(ctx, slot, &d, top, bottom - top, tile, formatRecord->rowBytes, dst, stride, iccArgs);
         if (err) bail((OSErr)err);
     }

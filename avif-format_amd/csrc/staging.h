@@ -59,7 +59,7 @@ void release_device_caches();                        // read tables + ICC tables
 
 // Device copies of the ICC tables, cached per HIP device, re-uploaded only when the contents change.
 int  upload_icc8(const avifgpu_icc_shaper8* t, WriteParams& p);
-void icc_epoch_for_call(int row0);                                  // one call per C-ABI write call / shim tile that carries an ICC table (see IccDeviceTables)
+void icc_epoch_for_call(int row0, int nrows);                                  // one call per C-ABI write call / shim tile that carries an ICC table (see IccDeviceTables)
 int  upload_icc16(const avifgpu_icc_clut16* t, WriteParams& p);
 int  upload_icc_sampled(const avifgpu_icc_sampled32* t, WriteParams& p);
 

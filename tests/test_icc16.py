@@ -324,6 +324,32 @@ def test_gpu_table_rewritten_in_place_between_two_tile_calls_is_seen(gpu, lcms):
 
 
 @pytest.mark.gpu
+def test_gpu_only_a_call_that_continues_the_previous_one_keeps_its_epoch(gpu, lcms):
+    """The epoch rule itself: a call whose row0 is the row after the previous call's last (the next tile of the same save) trusts the
+    fingerprint; a call further down (a gap: another image, a rank's tile) re-verifies the table and sees a rewrite the fingerprint misses."""
+    import torch
+    icc = _profile(lcms, *PROFILES[0][1:])
+    clut = gpu.icc_prepare_clut16(icc)
+    dev = f"cuda:{gpu.device}"
+    w, h = 256, 96
+    d = pkg.WriteDesc(width=w, height=h, depth=16, planes=3, bit_depth=12, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_REFERENCE)
+    src = torch.zeros((h, w * 3), dtype=torch.int16, device=dev)
+
+    def run(table, r0, n):
+        out = torch.zeros((h, w * 3), dtype=torch.int16, device=dev)
+        gpu.write_rows(d, r0, n, src[r0].data_ptr(), src.stride(0) * 2, [out[r0].data_ptr(), None, None, None], [out.stride(0) * 2, 0, 0, 0],
+                       mem=pkg.MEM_DEVICE, stream=torch.cuda.current_stream(dev).cuda_stream, icc=table)
+        torch.cuda.synchronize(dev)
+        return out[r0:r0 + n].cpu().numpy()
+    before = run(clut, 8, 8)                                                   # rows [8, 16)
+    clut.table[0][2] = (clut.table[0][2] + 0x4000) & 0xffff                   # a word the strided fingerprint does not read
+    continued = run(clut, 16, 8)                                               # rows [16, 24): the next tile of the same save -- the contract says
+    assert np.array_equal(continued, before)                                   # the table is immutable here, and the cheap check is what runs
+    below = run(clut, 40, 8)                                                   # rows [40, 48): not a continuation -> full comparison
+    assert not np.array_equal(below, before), "a call that does not continue the previous one must re-verify the table"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,kind,trc,g", PROFILES)
 def test_gpu_16bit_rows_bit_exact(gpu, lcms, name, kind, trc, g):
     """4 M pixels over Photoshop's whole 16-bit range (edges, neutrals, random): fused ICC + 12-bit rescale == range map,
