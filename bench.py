@@ -133,8 +133,21 @@ def extra_configs(torch, pkg, gpu, dev, stream, steps):
     between two visits of an address, like tools/bench_configs.py) after ~0.15 s of the same kernel as clock ramp, one HIP event pair on
     the launch stream around them.  ms = span / K; GB_s = algorithmic bytes / ms; frac against the 8 TB/s spec.
     The dispatch these rows mirror: reference Write.cpp:303-336 (save) and Read.cpp:592-625 (open)."""
-    import harness
     P = pkg
+
+    def write_plane_shapes(d):
+        """{plane: (rows, row bytes padded to 16)} from the library's own geometry (avifgpu_write_plane_geometry)."""
+        shapes = {}
+        for pl in ((0,) if d.output == P.OUT_REFERENCE else (0, 1, 2)):       # every save row below: RGB without alpha
+            w, h, bps, spp = gpu.write_plane_geometry(d, pl)
+            shapes[pl] = (h, (w * bps * spp + 15) // 16 * 16)
+        return shapes
+
+    def read_plane_shapes(d):
+        """The three planes of a 4:x:x YCbCr image without alpha (every open row below is one): {plane: (rows, samples per row)}."""
+        xs, ys = {P.CHROMA_444: (0, 0), P.CHROMA_422: (1, 0), P.CHROMA_420: (1, 1)}[d.chroma]
+        cw, ch = (d.width + xs) >> xs, (d.height + ys) >> ys
+        return {0: (d.height, d.width), 1: (ch, cw), 2: (ch, cw)}
     hdr = dict(width=8192, height=8192, depth=32, planes=3, transfer=P.TRANSFER_PQ, peak_nits=80, alpha_state=P.ALPHA_NONE,
                matrix_coefficients=P.MATRIX_BT2020_NCL, color_primaries=P.PRIMARIES_BT2020)
     rows = [
@@ -177,13 +190,12 @@ def extra_configs(torch, pkg, gpu, dev, stream, steps):
                     src0 = torch.randint(0, 32769, (n,), generator=g, device=dev, dtype=torch.int32).to(torch.int16).view(d.height, -1)
                 else:
                     src0 = make_frame(torch, dev, d.width, d.height, d.planes, 1234)
-                ssz = 2 if d.bit_depth > 8 else 1
                 nset = max(3, min(64, int(-(-3.5e9 // ab))))
                 for j in range(nset):
                     src = src0 if j == 0 else src0.clone()
                     bufs, ptrs, strides = {}, [None] * 4, [0] * 4
-                    for pl, (w, xs, ys) in harness.write_planes(d).items():
-                        bufs[pl] = torch.empty(((d.height + ys) >> ys, (w * ssz + 15) // 16 * 16), dtype=torch.uint8, device=dev)
+                    for pl, (rows_pl, row_bytes) in write_plane_shapes(d).items():
+                        bufs[pl] = torch.empty((rows_pl, row_bytes), dtype=torch.uint8, device=dev)
                         ptrs[pl], strides[pl] = bufs[pl].data_ptr(), bufs[pl].stride(0)
                     keep.append((src, bufs))
                     calls.append(lambda src=src, ptrs=ptrs, strides=strides: gpu.write_rows(
@@ -191,12 +203,11 @@ def extra_configs(torch, pkg, gpu, dev, stream, steps):
             else:
                 d = P.ReadDesc(**kw)
                 ab = gpu.read_algorithmic_bytes(d, d.height)
-                maxc, ssz, nch = (1 << d.bit_depth) - 1, (2 if d.bit_depth > 8 else 1), harness.read_channels(d)
+                maxc, ssz, nch = (1 << d.bit_depth) - 1, (2 if d.bit_depth > 8 else 1), 3
                 nset = max(3, min(64, int(-(-3.5e9 // ab))))
                 for j in range(nset):
                     ptrs, strides, planes = [None] * 4, [0] * 4, []
-                    for i, (pl, (w, xs, ys)) in enumerate(harness.read_planes(d).items()):
-                        h = (d.height + ys) >> ys
+                    for i, (pl, (h, w)) in enumerate(read_plane_shapes(d).items()):
                         wp = (w * ssz + 15) // 16 * 16 // ssz
                         if j == 0:
                             t = torch.randint(0, maxc + 1, (h, wp), generator=g, device=dev, dtype=torch.int32).to(torch.int16 if ssz == 2 else torch.uint8).contiguous()
