@@ -542,16 +542,17 @@ AG_DEV uint32_t umax3(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_m
 AG_DEV uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_min3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 AG_DEV uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_med3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 // fx[] = the three 16.16 grid positions (_cmsToFixedDomain(32 * word)); out[] = the interpolated 16-bit words
-AG_DEV void icc16_tetrahedral_fixed(const uint16_t* __restrict__ clut, const uint32_t (&fx)[3], uint32_t (&out)[3])
+// The byte offset of a cell's base node in the device table is linear in the three cell indices: kIcc16CellStride[k] per step of axis k
+// (both record layouts).  icc = 7 reads the three products -- and the fractions -- from a 256-entry table per channel (AG_ICC7_LDS).
+#if AG_ICC16_DOT2 == 2
+constexpr uint32_t kIcc16CellStride[3] = { 33u * 33u * (uint32_t)kIcc16PairBytes, 33u * (uint32_t)kIcc16PairBytes, (uint32_t)kIcc16PairBytes };
+#else
+constexpr uint32_t kIcc16CellStride[3] = { 33u * 33u * (uint32_t)kIcc16RecBytes, 33u * (uint32_t)kIcc16RecBytes, (uint32_t)kIcc16RecBytes };
+#endif
+// cell = byte offset of the cell's base node (sum of c0i[k] * kIcc16CellStride[k]); r[] = the three 16-bit fractions
+AG_DEV void icc16_tetrahedral_cell(const uint16_t* __restrict__ clut, uint32_t cell, const uint32_t (&r)[3], uint32_t (&out)[3])
 {
-    [[maybe_unused]] constexpr uint32_t G = AVIFGPU_ICC_CLUT_GRID;       // (used by one of the two record layouts below)
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-    uint32_t c0i[3], r[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        c0i[k] = fx[k] >> 16;
-        r[k] = fx[k] & 0xffffu;
-    }
     const uint32_t mx = umax3(r[0], r[1], r[2]), mn = umin3(r[0], r[1], r[2]), md = umed3(r[0], r[1], r[2]);
     const uint32_t w12 = (mx - md) | ((md - mn) << 16), w03 = (mx ^ 0xffffu) | (mn << 16);
     typedef uint32_t u3 __attribute__((ext_vector_type(3)));     // 12 bytes: lo | hi << 16 per channel
@@ -560,7 +561,7 @@ AG_DEV void icc16_tetrahedral_fixed(const uint16_t* __restrict__ clut, const uin
     // node-pair tables (kernel_params.h): {p0, p3} = A[n], {p1, p2} = B[3 (n + stride(amax)) + mid].  The order of the three fractions
     // picks one of six byte offsets -- 36 stride(amax) + 12 mid, table A's size folded in -- through a tree of selects on the three
     // compares; ties resolve to ANY order holding a maximal and a minimal axis (the sum is the same).
-    const uint32_t n12 = (uint32_t)mad24_sv(33 * 33 * (int)kIcc16PairBytes, (int)c0i[0], mad24_sv(33 * (int)kIcc16PairBytes, (int)c0i[1], (int)(c0i[2] * kIcc16PairBytes)));
+    const uint32_t n12 = cell;
     constexpr uint32_t S0 = 33u * 33u * 36u, S1 = 33u * 36u, S2 = 36u, TA = kIcc16TableABytes;
     const bool c01 = r[0] >= r[1], c12 = r[1] >= r[2], c02 = r[0] >= r[2];
     //                     r0>=r1>=r2: max 0, mid 1      r0>=r2>r1: max 0, mid 2         r2>r0>=r1: max 2, mid 0
@@ -570,7 +571,7 @@ AG_DEV void icc16_tetrahedral_fixed(const uint16_t* __restrict__ clut, const uin
     const uint32_t pair_off = (uint32_t)mad24_sv(3, (int)n12, (int)(c01 ? hi01 : lo01));          // < 2^21
     const u3 u03 = *reinterpret_cast<const u3*>(base + n12), u12 = *reinterpret_cast<const u3*>(base + pair_off);
 #else
-    const uint32_t cell_off = ((c0i[0] * G + c0i[1]) * G + c0i[2]) * (uint32_t)kIcc16RecBytes;      // < 2^23: 32-bit offsets from the table base
+    const uint32_t cell_off = cell;                                                                 // < 2^23: 32-bit offsets from the table base
     // the record is addressed by the outcome of the three compares, idx = (r0 >= r1) + 2 (r1 >= r2) + 4 (r0 >= r2): unit idx holds the
     // middle node pair of that order (upload_icc16, kIcc16UnitOfIdx); idx 3 and 4 cannot occur -- unit 3 holds {corner 0, corner 7}.
     // Ties resolve to ANY order holding a maximal and a minimal axis: the sum is the same.  (v_cmp + v_addc_co: idx = 2 idx + carry.)
@@ -599,6 +600,12 @@ AG_DEV void icc16_tetrahedral_fixed(const uint16_t* __restrict__ clut, const uin
         out[k] = (p0 + (uint32_t)((t + (t >> 16)) >> 16)) & 0xffffu;
     }
 }
+AG_DEV void icc16_tetrahedral_fixed(const uint16_t* __restrict__ clut, const uint32_t (&fx)[3], uint32_t (&out)[3])
+{
+    const uint32_t r[3] = { fx[0] & 0xffffu, fx[1] & 0xffffu, fx[2] & 0xffffu };
+    const uint32_t cell = (uint32_t)mad24_sv((int)kIcc16CellStride[0], (int)(fx[0] >> 16), mad24_sv((int)kIcc16CellStride[1], (int)(fx[1] >> 16), (int)((fx[2] >> 16) * kIcc16CellStride[2])));
+    icc16_tetrahedral_cell(clut, cell, r, out);
+}
 // host[] <= 32768 (the caller clamps: packed, as the row arrives)
 AG_DEV void icc16_tetrahedral_host(const uint16_t* __restrict__ clut, const uint32_t (&host)[3], uint32_t (&out)[3])
 {
@@ -611,12 +618,24 @@ AG_DEV void icc16_tetrahedral_host(const uint16_t* __restrict__ clut, const uint
 // its rounding are TetrahedralInterp16's, and the output formatter packs the word with FROM_16_TO_8(w) = (w * 65281 + 8388608) >> 24.
 // Position: with j = 257 b, 32 j + (32 j + 0x7fff) / 0xffff = (j << 5) + ((j + 1024) >> 11) (the identity icc16_host_to_fixed uses).
 // Bit-exact against the real library on all 2^24 RGB triples (tests/test_icc8.py).
-AG_DEV void icc8_tetrahedral_bytes(const uint16_t* __restrict__ clut, const uint32_t (&b)[3], uint32_t (&out)[3])
+#ifndef AG_ICC7_LDS
+#define AG_ICC7_LDS 0          /* 1 = a byte's cell offset and fraction from a per-workgroup 3 x 256 table (what Prelin8Data is in lcms2): 14 VALU instructions
+                                  fewer per pixel, 14 more VGPRs (4:2:0: 138, 3 waves per SIMD) -- measured 5 % SLOWER (profiles/r06/icc7_position_table_ab.txt);
+                                  0 = the position computed per sample */
+#endif
+AG_DEV uint32_t icc8_byte_to_fixed(uint32_t b) { return __umul24(b, 8224u) + ((__umul24(b, 257u) + 1024u) >> 11); }
+// pos = the workgroup's table (write_px fills it): pos[256 k + b] = { cell-offset share of channel k, fraction }
+AG_DEV void icc8_tetrahedral_bytes(const uint16_t* __restrict__ clut, const uint32_t (&b)[3], uint32_t (&out)[3], const uint2* pos)
 {
-    uint32_t fx[3], w[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) fx[k] = __umul24(b[k], 8224u) + ((__umul24(b[k], 257u) + 1024u) >> 11);
-    icc16_tetrahedral_fixed(clut, fx, w);
+    uint32_t w[3];
+    if (AG_ICC7_LDS && pos != nullptr) {
+        const uint2 e0 = pos[b[0]], e1 = pos[256u + b[1]], e2 = pos[512u + b[2]];
+        const uint32_t r[3] = { e0.y, e1.y, e2.y };
+        icc16_tetrahedral_cell(clut, e0.x + e1.x + e2.x, r, w);
+    } else {
+        const uint32_t fx[3] = { icc8_byte_to_fixed(b[0]), icc8_byte_to_fixed(b[1]), icc8_byte_to_fixed(b[2]) };
+        icc16_tetrahedral_fixed(clut, fx, w);
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) out[k] = (__umul24(w[k], 65281u) + 8388608u) >> 24;
 }
@@ -629,7 +648,7 @@ template <int DEPTH, int PLANES, int TRANSFER, int ICC = 0, int RESCALE8 = 2, bo
 AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t (&q)[4],
                     const int32_t* icc8_lds_s1 = nullptr, const uint8_t* icc8_lds_s2 = nullptr, const uint16_t* lut8 = nullptr,
                     const IccPowTable& powT = IccPowTable{ nullptr, nullptr }, const IccRegs* iccRegs = nullptr,
-                    const IccPowTableF& powTf = IccPowTableF{ nullptr }, const IccRegsF* iccRegsF = nullptr)
+                    const IccPowTableF& powTf = IccPowTableF{ nullptr }, const IccRegsF* iccRegsF = nullptr, const uint2* icc7_pos = nullptr)
 {
     constexpr bool COLOR = PLANES >= 3;
     constexpr bool ALPHA = (PLANES == 2 || PLANES == 4);
@@ -693,7 +712,7 @@ AG_DEV void stage_a(const WriteParams& p, const uint32_t (&s)[PLANES], uint32_t 
             // ConvertRow for 8-bit rows behind a LUT-based profile (ColorProfileConversion.cpp:159-187, TYPE_RGB[A]_8): the table the caller's own
             // transforms yielded (avifgpu_icc_clut8_from_transforms), evaluated like PrelinEval8; alpha is copied (cmsFLAGS_COPY_ALPHA)
             uint32_t cin[3] = { sx[0], sx[1], sx[2] }, cout[3];
-            icc8_tetrahedral_bytes(p.icc16_clut, cin, cout);
+            icc8_tetrahedral_bytes(p.icc16_clut, cin, cout, icc7_pos);
             sx[0] = cout[0]; sx[1] = cout[1]; sx[2] = cout[2];
         }
         if constexpr (ICC == 3 && DEPTH == 8 && COLOR) {
@@ -862,6 +881,19 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
         for (int i = threadIdx.x; i < 16388 / 4; i += AG_WPX_BLOCK)
             reinterpret_cast<uint32_t*>(icc8_s2)[i] = reinterpret_cast<const uint32_t*>(p.icc8_s2)[i];
         __syncthreads();
+    }
+
+    // 8-bit documents behind a LUT-based profile (icc = 7): what lcms2 keeps in Prelin8Data -- per channel and byte the cell (here: its
+    // share of the base node's byte offset in the device table) and the 16-bit fraction of _cmsToFixedDomain(32 * 257 b); 6 KiB per workgroup
+    __shared__ uint2 icc7_tab[(ICC == 7 && AG_ICC7_LDS) ? 768 : 1];
+    const uint2* icc7_pos = nullptr;
+    if constexpr (ICC == 7 && AG_ICC7_LDS) {
+        for (int i = threadIdx.x; i < 768; i += AG_WPX_BLOCK) {
+            const uint32_t fx = icc8_byte_to_fixed((uint32_t)i & 255u);
+            icc7_tab[i] = make_uint2((fx >> 16) * kIcc16CellStride[i >> 8], fx & 0xffffu);
+        }
+        __syncthreads();
+        icc7_pos = icc7_tab;
     }
 
     // sampled-curve ICC variant: the profile's tables as (T[i], T[i+1]) pairs in dynamic LDS (4 bytes per entry, sized by the launch)
@@ -1233,7 +1265,7 @@ __global__ __launch_bounds__(AG_WPX_BLOCK) void write_px(const WriteParams p)
 #pragma unroll
                 for (int i = 0; i < PXT; ++i) {
                     uint32_t q[4] = { 0, 0, 0, 0 };        // gray fills [0] and [3] only
-                    stage_a<DEPTH, PLANES, TRANSFER, ICC, decltype(rescale8)::value, !DST16, QF>(p, s[i], q, icc8_s1, icc8_s2, lut8, powT, &iccRegs, powTf, &iccRegsF);
+                    stage_a<DEPTH, PLANES, TRANSFER, ICC, decltype(rescale8)::value, !DST16, QF>(p, s[i], q, icc8_s1, icc8_s2, lut8, powT, &iccRegs, powTf, &iccRegsF, icc7_pos);
                     if constexpr (!PACK) { qp[vr][i][0] = q[0]; qp[vr][i][1] = q[1]; qp[vr][i][2] = q[2]; qp[vr][i][3] = q[3]; }
                     else if constexpr (DST16) { qp[vr][i][0] = q[0] | (q[1] << 16); qp[vr][i][1] = q[2] | (q[3] << 16); }
                     else qp[vr][i][0] = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
