@@ -620,7 +620,7 @@ AG_DEV void icc16_tetrahedral_host(const uint16_t* __restrict__ clut, const uint
 // Bit-exact against the real library on all 2^24 RGB triples (tests/test_icc8.py).
 #ifndef AG_ICC7_LDS
 #define AG_ICC7_LDS 0          /* 1 = a byte's cell offset and fraction from a per-workgroup 3 x 256 table (what Prelin8Data is in lcms2): 14 VALU instructions
-                                  fewer per pixel, 14 more VGPRs (4:2:0: 138, 3 waves per SIMD) -- measured 5 % SLOWER (profiles/r06/icc7_position_table_ab.txt);
+                                  fewer per pixel, 14 more VGPRs (4:2:0: 138, 3 waves per SIMD) -- measured 5 % SLOWER (profiles/r06/icc_table_kernels_ab.txt);
                                   0 = the position computed per sample */
 #endif
 AG_DEV uint32_t icc8_byte_to_fixed(uint32_t b) { return __umul24(b, 8224u) + ((__umul24(b, 257u) + 1024u) >> 11); }
@@ -824,11 +824,14 @@ template <int DEPTH, int PLANES, int OUT, bool DST16, bool ALIGNED, int ICC> con
 // The parametric ICC variants (2, 4) carry ~300 instructions and up to 86 parameter VGPRs per pixel stream: with sub-sampled chroma
 // 2 chroma samples per lane keep a 4:2:0 footprint at 8 pixels (16: 197 VGPRs, 2 waves/SIMD, 6.9 k instructions; measured
 // 0.412 -> 0.370 ms).  4:4:4 keeps 4 pixels per lane (2 measured slower: 0.487 -> 0.507 ms, narrower loads and stores).
+#ifndef AG_ICC_TAB_NC2
+#define AG_ICC_TAB_NC2 0        /* 1 = the table-driven ICC stages (5, 7) with sub-sampled chroma: 2 chroma samples per lane (A/B hook) */
+#endif
 template <bool DST16, int PLANES, int XS, int ICC = 0> struct WriteShape {
     // ICC == 5 (the 16-bit table transform) saved to u8 planes: 4 chroma samples per lane like the u16 layouts.  With 8, a 4:2:0 footprint
     // is 32 pixels x two 16-byte gathers each, all hoisted: 315 VGPRs = ONE wave per SIMD (profiles/r02/isa/resources.tsv); with 4 it is
     // 16 pixels and the kernel fits 3-4 waves.
-    static constexpr int NC = ((ICC == 2 || ICC == 4) && XS == 1) ? 2 : ((DST16 && ICC == 0) ? AG_W16_NC : ((DST16 || ICC == 5 || ICC == 7) ? 4 : ((PLANES == 2 || PLANES == 4) ? AG_W8_NC_ALPHA : AG_W8_NC)));
+    static constexpr int NC = ((ICC == 2 || ICC == 4 || ((ICC == 5 || ICC == 7) && AG_ICC_TAB_NC2)) && XS == 1) ? 2 : ((DST16 && ICC == 0) ? AG_W16_NC : ((DST16 || ICC == 5 || ICC == 7) ? 4 : ((PLANES == 2 || PLANES == 4) ? AG_W8_NC_ALPHA : AG_W8_NC)));
     static constexpr int PXT = NC << XS;
 };
 
