@@ -645,7 +645,7 @@ int fill_read_params(const avifgpu_read_desc* d, int nrows, const ReadGeom& g, R
     uint32_t kg_bits; memcpy(&kg_bits, &p.kg, 4);
     p.fast_div = 0;
     for (uint32_t v : kVerifiedKg) if (v == kg_bits) p.fast_div = 1;
-    if (getenv("AVIFGPU_FORCE_IEEE_DIV")) p.fast_div = 0;        // test hook: exercise the fallback
+    if (g_hot_variant & 128) p.fast_div = 0;                     // bit 7 of the tuning word: tests exercise the fallback (an environment read until round 6)
     p.rcp_kg = 1.0f / p.kg;
     p.maxcf = (float)p.maxc;
     p.rcp_maxc = (float)(1.0 / (double)p.maxc);

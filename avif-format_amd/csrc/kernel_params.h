@@ -8,7 +8,7 @@ namespace avifgpu {
 // Tuning word of the dominant kernel (RGB f32 -> curve -> YCbCr 4:4:4 u16), see launch_write():
 //   bit0 enable the streaming kernels, bit1 8 px/lane (else 4), bit2 non-temporal loads+stores, bit3 take the geometry-gated
 //   streaming kernels (RGB16) whatever the frame size (tests use it to reach them on small frames), bit4 (16) no FLAT launches
-//   (launch_write: contiguous 4:4:4 / interleaved tiles are launched as one long row), bit5 (32) no v_dot2 in the packed 8-bit ICC stage, bit6 (64) sampled ICC curves looked up in memory instead of interpolated in LDS, bits 8.. = block cap
+//   (launch_write: contiguous 4:4:4 / interleaved tiles are launched as one long row), bit5 (32) no v_dot2 in the packed 8-bit ICC stage, bit6 (64) sampled ICC curves looked up in memory instead of interpolated in LDS, bit7 (128) IEEE division in the read kernels whatever the divisor, bits 8.. = block cap
 //   (0 = default).  (Bits 3 and 4 selected a register-prefetch and an XCD-contiguous variant in round 1; both lost and were removed.)
 enum : int { kHotDefault = 1 | 2 | 4 };
 

@@ -90,14 +90,18 @@ def test_read_float_error_report(gpu):
             assert np.all(np.abs(got - want) <= T2_RTOL * np.abs(want) + T2_ATOL)
 
 
-def test_read_ieee_division_fallback(gpu, monkeypatch):
+def test_read_ieee_division_fallback(gpu):
     """x / kg normally takes the 3-FMA form proven exact for every kg the reference's tables can produce
-    (tools/divcheck.hip, profiles/r01/divcheck.txt); any other divisor keeps IEEE division -- exercise that path too."""
-    monkeypatch.setenv("AVIFGPU_FORCE_IEEE_DIV", "1")
-    for cid, kw in [c for c in cases.read_cases() if c[0].startswith(("ycc-b8-d8-c1", "ycc-b12-d16-c3"))][:12]:
-        d = pkg.ReadDesc(**kw)
-        planes = harness.make_read_source(d)
-        assert np.array_equal(harness.gpu_read(gpu, d, planes), harness.oracle_read(d, planes)), cid
+    (tools/divcheck.hip, profiles/r01/divcheck.txt); any other divisor keeps IEEE division -- exercise that path too
+    (bit 7 of the tuning word; no environment variable is read on a launch)."""
+    try:
+        gpu.lib.avifgpu_set_hot_variant(1 | 2 | 4 | 128)
+        for cid, kw in [c for c in cases.read_cases() if c[0].startswith(("ycc-b8-d8-c1", "ycc-b12-d16-c3"))][:12]:
+            d = pkg.ReadDesc(**kw)
+            planes = harness.make_read_source(d)
+            assert np.array_equal(harness.gpu_read(gpu, d, planes), harness.oracle_read(d, planes)), cid
+    finally:
+        gpu.lib.avifgpu_set_hot_variant(1 | 2 | 4)
 
 
 def test_hlg_ootf_black_pixels_gamma_one(gpu):
