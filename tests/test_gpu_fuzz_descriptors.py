@@ -160,3 +160,59 @@ def test_read_descriptor_fuzz(gpu, i):
     else:
         g, w_ = got.view(np.float32).astype(np.float64), want.view(np.float32).astype(np.float64)
         assert np.all(np.abs(g - w_) <= 1e-4 * np.abs(w_) + 1e-9), kw
+
+
+def test_buffer_arguments_are_checked_before_anything_is_launched(gpu):
+    """The pointers and pitches of a call (plain C arguments: the reference has C++ objects there, so these checks are the library's own):
+    a null source / destination, a null plane the descriptor needs, a pitch below the row -- formatBadParameters and a message, nothing
+    written; planes the descriptor does not produce may be null."""
+    import torch
+    dev = f"cuda:{gpu.device}"
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    d = pkg.WriteDesc(width=32, height=8, depth=16, planes=3, bit_depth=10, alpha_state=pkg.ALPHA_NONE, output=pkg.OUT_YCBCR, chroma=pkg.CHROMA_420,
+                      matrix_coefficients=pkg.MATRIX_BT601)
+    src = torch.zeros((8, 32 * 3), dtype=torch.int16, device=dev)
+    planes = [torch.full((8, 64), 0x5a, dtype=torch.uint8, device=dev) for _ in range(3)]
+
+    def write(src_ptr, src_pitch, ptrs, pitches):
+        code = gpu.lib.avifgpu_write_rows(ctypes.byref(d), 0, 8, src_ptr, src_pitch, ctypes.byref(pkg.planes4(ptrs)), ctypes.byref(pkg.strides4(pitches)),
+                                          pkg.MEM_DEVICE, stream)
+        torch.cuda.synchronize(dev)
+        return code, gpu.lib.avifgpu_last_error()
+    good_ptrs, good_pitches = [t.data_ptr() for t in planes] + [None], [64, 64, 64, 0]
+    assert write(src.data_ptr(), 32 * 6, good_ptrs, good_pitches)[0] == 0                      # the alpha plane is not produced: null is fine
+    for t in planes:
+        t.fill_(0x5a)
+    bad = [(None, 32 * 6, good_ptrs, good_pitches, b"null buffer"),
+           (src.data_ptr(), 32 * 6 - 2, good_ptrs, good_pitches, b"src_row_bytes"),
+           (src.data_ptr(), 32 * 6, [good_ptrs[0], None, good_ptrs[2], None], good_pitches, b"destination plane 1 is null"),
+           (src.data_ptr(), 32 * 6, good_ptrs, [64, 31, 64, 0], b"dst_stride[1]"),
+           (src.data_ptr(), 32 * 6, good_ptrs, [63, 64, 64, 0], b"dst_stride[0]"),
+           (src.data_ptr(), 32 * 6, good_ptrs, [64, 64, -64, 0], b"dst_stride[2]")]
+    for src_ptr, pitch, ptrs, pitches, text in bad:
+        code, msg = write(src_ptr, pitch, ptrs, pitches)
+        assert code == pkg.formatBadParameters and text in msg, (text, code, msg)
+    assert all(bool((t == 0x5a).all()) for t in planes), "a rejected call must not write"
+    code = gpu.lib.avifgpu_write_rows(ctypes.byref(d), 0, 8, src.data_ptr(), 32 * 6, ctypes.byref(pkg.planes4(good_ptrs)), ctypes.byref(pkg.strides4(good_pitches)), 7, stream)
+    assert code == pkg.formatBadParameters, "unknown mem_kind"
+
+    r = pkg.ReadDesc(width=32, height=8, colorspace=pkg.COLORSPACE_YCBCR, chroma=pkg.CHROMA_422, bit_depth=8, depth=8, alpha_state=pkg.ALPHA_NONE,
+                     matrix_coefficients=pkg.MATRIX_BT601)
+    rp = [torch.zeros((8, 32), dtype=torch.uint8, device=dev) for _ in range(3)]
+    out = torch.full((8, 96), 0x5a, dtype=torch.uint8, device=dev)
+
+    def read(ptrs, pitches, dst, dst_pitch):
+        code = gpu.lib.avifgpu_read_rows(ctypes.byref(r), 0, 8, ctypes.byref(pkg.planes4(ptrs)), ctypes.byref(pkg.strides4(pitches)), dst, dst_pitch,
+                                         pkg.MEM_DEVICE, stream)
+        torch.cuda.synchronize(dev)
+        return code, gpu.lib.avifgpu_last_error()
+    gp, gs = [t.data_ptr() for t in rp] + [None], [32, 32, 32, 0]
+    assert read(gp, gs, out.data_ptr(), 96)[0] == 0
+    out.fill_(0x5a)
+    for ptrs, pitches, dst, dpitch, text in [(gp, gs, None, 96, b"null buffer"), (gp, gs, out.data_ptr(), 95, b"dst_row_bytes too small"),
+                                              ([gp[0], gp[1], None, None], gs, out.data_ptr(), 96, b"source plane 2 is null"),
+                                              (gp, [31, 32, 32, 0], out.data_ptr(), 96, b"src_stride[0] too small"),
+                                              (gp, [32, 15, 32, 0], out.data_ptr(), 96, b"src_stride[1] too small")]:
+        code, msg = read(ptrs, pitches, dst, dpitch)
+        assert code == pkg.formatBadParameters and text in msg, (text, code, msg)
+    assert bool((out == 0x5a).all()), "a rejected call must not write"
