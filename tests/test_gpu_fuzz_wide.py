@@ -38,7 +38,7 @@ def gpu_write_padded(gpu, desc, src, row0, nrows):
 def _case(i):
     rng = np.random.default_rng(4242 + i)
     depth = int(rng.choice([8, 8, 16, 32, 32]))
-    planes = int(rng.choice([3, 3, 4]))
+    planes = int(rng.choice([3, 3, 4, 3, 4, 1, 2]))          # (round 6: gray and gray + alpha documents too -- write_ga_stream / write_int_ref_stream / write_f32_ref_stream)
     chroma = int(rng.choice([pkg.CHROMA_444, pkg.CHROMA_422, pkg.CHROMA_420]))
     choices = {8: [8, 8, 10, 12], 16: [10, 12, 8], 32: [10, 12]}[depth]          # (round 6: 8-bit documents at 12 bit too -- write_rgb8_ycbcr16_hot)
     bits = choices[int(rng.integers(0, len(choices)))]
@@ -46,7 +46,7 @@ def _case(i):
     w -= w % int(rng.choice([1, 4, 8, 16]))
     w = max(w, 8)
     h = int(rng.integers(1, 10))
-    alpha = pkg.ALPHA_NONE if planes == 3 else int(rng.choice([pkg.ALPHA_STRAIGHT, pkg.ALPHA_PREMULTIPLIED]))
+    alpha = pkg.ALPHA_NONE if planes in (1, 3) else int(rng.choice([pkg.ALPHA_STRAIGHT, pkg.ALPHA_PREMULTIPLIED]))
     kw = dict(width=w, height=h, depth=depth, planes=planes, bit_depth=bits, alpha_state=alpha, output=pkg.OUT_YCBCR, chroma=chroma,
               matrix_coefficients=int(rng.choice([pkg.MATRIX_BT601, pkg.MATRIX_BT709, pkg.MATRIX_BT2020_NCL])),
               color_primaries=pkg.PRIMARIES_BT709)
@@ -58,6 +58,10 @@ def _case(i):
         if alpha == pkg.ALPHA_PREMULTIPLIED and kw["transfer"] != pkg.TRANSFER_CLIP:
             kw["alpha_state"] = pkg.ALPHA_STRAIGHT               # premultiply is disabled for HDR saves (Write.cpp:251-257)
     cut = 2 * int(rng.integers(0, h // 2 + 1))
+    if planes < 3:                                               # gray: Y (+ alpha) planes, the reference's own hand-off (WriteHeifImage.cpp:169-631)
+        kw["output"] = pkg.OUT_REFERENCE
+        if depth == 32 and kw["transfer"] == pkg.TRANSFER_SMPTE428:
+            kw["transfer"] = pkg.TRANSFER_PQ                     # gray documents: PQ or Clip only (:581-582)
     if rng.random() < 0.2:                                       # round 6: the reference's own interleaved hand-off as well (the 8-bit identity case is a copy kernel)
         kw["output"] = pkg.OUT_REFERENCE
     return kw, cut
