@@ -502,7 +502,12 @@ int32_t avifgpu_icc_clut16_from_transforms(avifgpu_transform_f32_fn float_fn, av
                                            avifgpu_icc_clut16* out);
 
 /* avifgpu_write_rows for 16-bit RGB(A) documents with that transform applied first; alpha takes the reference's
- * [0,32768] -> [0,65535] -> [0,32768] round trip (cmsFLAGS_COPY_ALPHA in between). */
+ * [0,32768] -> [0,65535] -> [0,32768] round trip (cmsFLAGS_COPY_ALPHA in between).
+ * Lifetime of a prepared table (this one, avifgpu_icc_sampled32, the 8-bit table form): the library keeps a copy per device.  Within one
+ * save -- calls that continue one another row for row on one thread: row0 of a call = the row after the previous call's last -- the table
+ * must not change (a strided fingerprint is all that is compared).  Between saves it may be rewritten, freed or reallocated at the same
+ * address: every call that does not continue the previous one (row 0, a gap, another order, another thread) re-verifies each device's
+ * copy byte for byte before it is used. */
 int32_t avifgpu_write_rows_icc16(const avifgpu_write_desc* desc, const avifgpu_icc_clut16* icc,
                                  int32_t row0, int32_t nrows,
                                  const void* src, int64_t src_row_bytes,
